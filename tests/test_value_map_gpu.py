@@ -1,0 +1,167 @@
+"""-m gpu: HIP ValueMap vs the oracle (oracle/ref_value_map.py) on identical seeded inputs, through the C ABI.
+
+Tolerance: 1e-4 absolute on confidence and value maps (BASELINE.json north_star); measured error is ~1e-7
+(f32 storage of the value map vs the reference's f64 drift)."""
+import numpy as np
+import pytest
+
+from vlfm_amd.synthetic import MAX_DEPTH, MIN_DEPTH, SyntheticEnv, camera_intrinsics, pose_to_tf
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _fov(width=640):
+    return camera_intrinsics(width)[2]
+
+
+def _compare(ours, ref, tol=TOL):
+    c, v = ours._map, ours._value_map
+    assert c.shape == ref._map.shape and v.shape == ref._value_map.shape
+    ec = np.abs(c - ref._map).max()
+    ev = np.abs(v - ref._value_map).max()
+    assert ec <= tol and ev <= tol, (ec, ev)
+    # support must be identical: a cell is observed in one iff in the other
+    assert np.array_equal(c > 0, ref._map > 0)
+    return ec, ev
+
+
+@pytest.mark.parametrize("use_max_conf", [False, True])
+def test_trajectory_parity(gpu_device, use_max_conf):
+    from oracle.ref_value_map import RefValueMap
+    from vlfm_amd.mapping import ValueMap
+
+    env = SyntheticEnv(3)
+    ours = ValueMap(1, use_max_confidence=use_max_conf, device=gpu_device)
+    ref = RefValueMap(1, use_max_confidence=use_max_conf)
+    for step in range(40):
+        depth, tf, values = env.observe()
+        ours.update_map(values, depth, tf, MIN_DEPTH, MAX_DEPTH, _fov())
+        ref.update_map(values, depth.copy(), tf, MIN_DEPTH, MAX_DEPTH, _fov())
+        if step % 13 == 0:
+            _compare(ours, ref)
+    ec, ev = _compare(ours, ref)
+    print("max err conf/value", ec, ev)
+
+
+@pytest.mark.parametrize("fusion", ["replace", "equal_weighting"])
+def test_fusion_ablations(gpu_device, fusion):
+    from oracle.ref_value_map import RefValueMap
+    from vlfm_amd.mapping import ValueMap
+
+    env = SyntheticEnv(5)
+    ours = ValueMap(1, use_max_confidence=False, fusion_type=fusion, device=gpu_device)
+    ref = RefValueMap(1, use_max_confidence=False, fusion_type=fusion)
+    for _ in range(15):
+        depth, tf, values = env.observe()
+        ours.update_map(values, depth, tf, MIN_DEPTH, MAX_DEPTH, _fov())
+        ref.update_map(values, depth.copy(), tf, MIN_DEPTH, MAX_DEPTH, _fov())
+    _compare(ours, ref)
+
+
+def test_multichannel_and_arbitrary_yaw(gpu_device):
+    from oracle.ref_value_map import RefValueMap
+    from vlfm_amd.mapping import ValueMap
+
+    rng = np.random.default_rng(7)
+    env = SyntheticEnv(11, channels=2)
+    ours = ValueMap(2, use_max_confidence=False, device=gpu_device)
+    ref = RefValueMap(2, use_max_confidence=False)
+    for k in range(25):
+        depth, _, values = env.observe()
+        tf = pose_to_tf(rng.uniform(-3, 3), rng.uniform(-3, 3), rng.uniform(-np.pi, np.pi))
+        ours.update_map(values, depth, tf, MIN_DEPTH, MAX_DEPTH, _fov())
+        ref.update_map(values, depth.copy(), tf, MIN_DEPTH, MAX_DEPTH, _fov())
+    _compare(ours, ref)
+
+
+def test_depth_extremes_and_channel_dim(gpu_device):
+    """depth == 1 everywhere -> whole cone visible; depth == 0 -> profile at min_depth (SURVEY 8c pin 3);
+    (H,W,1) depth is squeezed (value_map.py:231-232)."""
+    from oracle.ref_value_map import RefValueMap
+    from vlfm_amd.mapping import ValueMap
+
+    for fill in (1.0, 0.0, 0.37):
+        ours = ValueMap(1, use_max_confidence=False, device=gpu_device)
+        ref = RefValueMap(1, use_max_confidence=False)
+        depth = np.full((480, 640, 1), fill, np.float32)
+        tf = pose_to_tf(1.03, -2.2, 0.7)
+        ours.update_map(np.array([0.4]), depth, tf, MIN_DEPTH, MAX_DEPTH, _fov())
+        ref.update_map(np.array([0.4]), depth.copy(), tf, MIN_DEPTH, MAX_DEPTH, _fov())
+        _compare(ours, ref)
+
+
+def test_window_clipped_at_map_edge_and_outside_assert(gpu_device):
+    from oracle.ref_value_map import RefValueMap
+    from vlfm_amd.mapping import ValueMap
+
+    ours = ValueMap(1, use_max_confidence=False, device=gpu_device)
+    ref = RefValueMap(1, use_max_confidence=False)
+    depth = SyntheticEnv(2).observe()[0]
+    for (x, y, yaw) in [(24.9, 24.9, 0.3), (-24.9, 24.0, 2.0), (24.0, -24.95, -1.0), (-24.95, -24.95, 3.0)]:
+        tf = pose_to_tf(x, y, yaw)
+        ours.update_map(np.array([0.3]), depth, tf, MIN_DEPTH, MAX_DEPTH, _fov())
+        ref.update_map(np.array([0.3]), depth.copy(), tf, MIN_DEPTH, MAX_DEPTH, _fov())
+    _compare(ours, ref)
+    with pytest.raises(AssertionError, match="outside the image"):
+        ours.update_map(np.array([0.3]), depth, pose_to_tf(25.2, 0, 0), MIN_DEPTH, MAX_DEPTH, _fov())
+    with pytest.raises(AssertionError, match="Incorrect number of values"):
+        ours.update_map(np.array([0.3, 0.1]), depth, pose_to_tf(0, 0, 0), MIN_DEPTH, MAX_DEPTH, _fov())
+
+
+def test_sort_waypoints_parity(gpu_device):
+    from oracle.ref_value_map import RefValueMap
+    from vlfm_amd.mapping import ValueMap
+
+    env = SyntheticEnv(9)
+    ours = ValueMap(1, use_max_confidence=False, device=gpu_device)
+    ref = RefValueMap(1, use_max_confidence=False)
+    for _ in range(20):
+        depth, tf, values = env.observe()
+        ours.update_map(values, depth, tf, MIN_DEPTH, MAX_DEPTH, _fov())
+        ref.update_map(values, depth.copy(), tf, MIN_DEPTH, MAX_DEPTH, _fov())
+    rng = np.random.default_rng(3)
+    wps = np.concatenate([rng.uniform(-4, 4, size=(12, 2)), np.array([[20.0, 20.0], [-24.99, 24.99], [0.0, 0.0]])])
+    s_o, v_o = ours.sort_waypoints(wps, 0.5)
+    s_r, v_r = ref.sort_waypoints(wps, 0.5)
+    assert np.array_equal(s_o, s_r)  # bit-exact frontier order
+    assert np.allclose(np.array(v_o, float), np.array(v_r, float), atol=TOL, rtol=0)
+    assert v_o[-1] == -1  # never-seen waypoint (img_utils.py:257-258)
+
+
+def test_batched_envs_match_single(gpu_device):
+    """One launch for 6 envs == 6 independent oracles (no cross-env leakage)."""
+    from oracle.ref_value_map import RefValueMap
+    from vlfm_amd.mapping import ValueMapBatch
+
+    E = 6
+    envs = [SyntheticEnv(20 + e) for e in range(E)]
+    batch = ValueMapBatch(E, 1, use_max_confidence=False, device=gpu_device)
+    refs = [RefValueMap(1, use_max_confidence=False) for _ in range(E)]
+    for _ in range(10):
+        obs = [e.observe() for e in envs]
+        depth = np.stack([o[0] for o in obs])
+        tf = np.stack([o[1] for o in obs])
+        vals = np.stack([o[2] for o in obs])
+        batch.update(vals, depth, tf, MIN_DEPTH, MAX_DEPTH, _fov())
+        for r, o in zip(refs, obs):
+            r.update_map(o[2], o[0].copy(), o[1], MIN_DEPTH, MAX_DEPTH, _fov())
+    conf = batch.conf.cpu().numpy()
+    val = batch.value.cpu().numpy()
+    for e in range(E):
+        assert np.abs(conf[e] - refs[e]._map).max() <= TOL
+        assert np.abs(val[e] - refs[e]._value_map).max() <= TOL
+
+
+def test_hd_depth_1280x720(gpu_device):
+    from oracle.ref_value_map import RefValueMap
+    from vlfm_amd.mapping import ValueMap
+
+    env = SyntheticEnv(4, height=720, width=1280)
+    ours = ValueMap(1, use_max_confidence=False, device=gpu_device)
+    ref = RefValueMap(1, use_max_confidence=False)
+    for _ in range(6):
+        depth, tf, values = env.observe()
+        ours.update_map(values, depth, tf, MIN_DEPTH, MAX_DEPTH, _fov(1280))
+        ref.update_map(values, depth.copy(), tf, MIN_DEPTH, MAX_DEPTH, _fov(1280))
+    _compare(ours, ref)

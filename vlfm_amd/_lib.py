@@ -1,0 +1,102 @@
+"""ctypes binding of libvlfm_amd.so (the C ABI declared in include/vlfm_amd.h).
+
+There is deliberately NO fallback: if the shared library is missing the import of any map class fails
+loudly, and if no HIP device is present the device entry points are never reached because the map
+classes refuse to construct.  The oracle under oracle/ is test infrastructure and is never imported here.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvlfm_amd.so")
+SOURCES = ["value_map.hip", "depth_ingest.hip", "obstacle_map.hip", "vlm_ops.hip", "host.cpp"]
+
+VLFM_OK = 0
+VLFM_ERR_INVALID = -1
+VLFM_ERR_OUTSIDE_MAP = -2
+VLFM_ERR_INDEX = -3
+VLFM_ERR_HIP = -4
+VLFM_ERR_CAPACITY = -5
+
+FUSION_TYPES = {"default": 0, "replace": 1, "equal_weighting": 2}
+
+
+class VmPose(ctypes.Structure):
+    _fields_ = [("inv_affine", ctypes.c_double * 6), ("row0", ctypes.c_int32), ("col0", ctypes.c_int32),
+                ("env", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class IngestParams(ctypes.Structure):
+    _fields_ = [("tf", ctypes.c_double * 12), ("depth_scale", ctypes.c_float), ("depth_offset", ctypes.c_float),
+                ("depth_max", ctypes.c_float), ("reserved0", ctypes.c_float), ("fx", ctypes.c_double),
+                ("fy", ctypes.c_double), ("min_height", ctypes.c_double), ("max_height", ctypes.c_double),
+                ("env", ctypes.c_int32), ("scatter", ctypes.c_int32)]
+
+
+assert ctypes.sizeof(VmPose) == 64 and ctypes.sizeof(IngestParams) == 152
+
+
+def build(verbose: bool = False) -> str:
+    """Compile every HIP/C++ source under vlfm_amd/csrc for gfx950 into vlfm_amd/libvlfm_amd.so (in-tree)."""
+    csrc = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(csrc, s) for s in SOURCES if os.path.exists(os.path.join(csrc, s))]
+    deps = srcs + [os.path.join(csrc, h) for h in os.listdir(csrc) if h.endswith(".h")] + [
+        os.path.join(_HERE, "..", "include", "vlfm_amd.h")]
+    if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+           "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  vlfm_amd has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+        L.vlfm_last_error.restype = ctypes.c_char_p
+        L.vlfm_abi_version.restype = ci
+        L.vlfm_value_map_pose_params.argtypes = [vp, vp, ci, ci, ci, ci, vp, ctypes.POINTER(ci)]
+        L.vlfm_cone_template_host.argtypes = [cd, cd, ci, cd, vp, ci, vp, ci, ctypes.POINTER(ci)]
+        L.vlfm_tan_table_host.argtypes = [cd, ci, vp]
+        L.vlfm_disc_rows_host.argtypes = [ci, vp]
+        L.vlfm_cone_template_build.argtypes = [vp, vp, ci, ci, vp, vp]
+        L.vlfm_depth_ingest_batched.argtypes = [vp, ci, ci, ci, vp, vp, vp, ci, ci, vp, vp]
+        L.vlfm_value_map_update_batched.argtypes = [vp, ci, vp, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci, cd, cd, ci,
+                                                    ci, vp, vp]
+        L.vlfm_value_map_mask_unexplored_batched.argtypes = [vp, ci, vp, vp, vp, ci, ci, vp]
+        L.vlfm_value_map_sort_waypoints_batched.argtypes = [vp, ci, ci, vp, ci, ci, vp, vp, vp]
+        for name in dir(L):
+            pass
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    return lib().vlfm_last_error().decode()
+
+
+def check(rc: int, what: str = "") -> int:
+    """Map a vlfm_status to the reference's Python exception conventions."""
+    if rc >= 0:
+        return rc
+    msg = last_error()
+    if rc == VLFM_ERR_OUTSIDE_MAP:
+        raise AssertionError(msg or "Pixel location is outside the image.")
+    if rc == VLFM_ERR_INDEX:
+        raise IndexError(msg or "index out of bounds for obstacle map")
+    raise RuntimeError(f"libvlfm_amd {what} failed ({rc}): {msg}")

@@ -1,0 +1,2 @@
+from .base_map import BaseMap  # noqa: F401
+from .value_map import ValueMap, ValueMapBatch  # noqa: F401

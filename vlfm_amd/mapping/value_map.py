@@ -1,0 +1,321 @@
+"""vlfm.mapping.value_map.ValueMap, MI355X-native (reference: /root/reference/vlfm/mapping/value_map.py).
+
+Two layers:
+
+* :class:`ValueMapBatch` -- ``n_envs`` value maps resident in HBM on one GPU, updated by ONE kernel launch per step
+  for all environments (depth ingest -> profile polygon -> LDS coverage -> rotate/place/fuse).  This is what the
+  batched-episode harness drives.
+* :class:`ValueMap` -- the reference's class signature (value_map.py:44-51, :100-108, :146-148) as a drop-in for
+  ``BaseITMPolicy`` (itm_policy.py:48-54, :191-211, :263-267); a thin single-slot view of a ValueMapBatch.
+
+PyTorch is used for device memory and streams only; every per-pixel operation is a hand-written gfx950 kernel in
+``vlfm_amd/csrc`` reached through the C ABI of ``include/vlfm_amd.h``.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from .. import _lib
+from .base_map import BaseMap, require_gpu
+
+
+def _stream_ptr() -> int:
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _bytes_to_device(buf, device):
+    """Upload a ctypes array / bytes object as a uint8 tensor (8-byte aligned by the caching allocator)."""
+    import torch
+
+    host = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8)
+    return host.to(device, non_blocking=False)
+
+
+class _ConeTemplates:
+    """Per-device cache of masked confidence templates, keyed like ValueMap._confidence_masks (value_map.py:37)."""
+
+    def __init__(self) -> None:
+        self._tmpl: Dict[Tuple[Any, ...], Any] = {}
+        self._tan: Dict[Tuple[Any, ...], Any] = {}
+        self._disc: Dict[Tuple[Any, ...], Any] = {}
+
+    def template(self, device, fov: float, max_depth: float, ppm: int, min_conf: float):
+        import torch
+
+        key = (str(device), float(fov), float(max_depth), int(ppm), float(min_conf))
+        if key not in self._tmpl:
+            L = _lib.lib()
+            size = int(max_depth * ppm)
+            T = 2 * size + 1
+            conf = np.zeros(T * T, np.float32)
+            poly = np.zeros(2 * 512, np.int64)
+            n_poly = ctypes.c_int(0)
+            rc = L.vlfm_cone_template_host(float(fov), float(max_depth), int(ppm), float(min_conf),
+                                           conf.ctypes.data, conf.size, poly.ctypes.data, 512, ctypes.byref(n_poly))
+            _lib.check(rc, "cone_template_host")
+            assert rc == T
+            d_conf = torch.from_numpy(conf).to(device)
+            d_poly = torch.from_numpy(poly).to(device)
+            d_tmpl = torch.empty(T * T, dtype=torch.float32, device=device)
+            with torch.cuda.device(device):
+                _lib.check(L.vlfm_cone_template_build(d_conf.data_ptr(), d_poly.data_ptr(), n_poly.value, T,
+                                                      d_tmpl.data_ptr(), _stream_ptr()), "cone_template_build")
+                torch.cuda.current_stream().synchronize()
+            self._tmpl[key] = (d_tmpl, T)
+        return self._tmpl[key]
+
+    def tan_table(self, device, fov: float, width: int):
+        import torch
+
+        key = (str(device), float(fov), int(width))
+        if key not in self._tan:
+            tab = np.zeros(width, np.float64)
+            _lib.check(_lib.lib().vlfm_tan_table_host(float(fov), int(width), tab.ctypes.data), "tan_table_host")
+            self._tan[key] = torch.from_numpy(tab).to(device)
+        return self._tan[key]
+
+    def disc(self, device, radius: int):
+        import torch
+
+        key = (str(device), int(radius))
+        if key not in self._disc:
+            hw = np.zeros(2 * radius + 1, np.int32)
+            _lib.check(_lib.lib().vlfm_disc_rows_host(int(radius), hw.ctypes.data), "disc_rows_host")
+            self._disc[key] = torch.from_numpy(hw).to(device)
+        return self._disc[key]
+
+
+_TEMPLATES = _ConeTemplates()
+
+
+def pose_params(tf: np.ndarray, env_ids: Optional[Sequence[int]], size: int, ppm: int, T: int):
+    """Host prologue of ValueMap._localize_new_data for n observations -> ctypes array of VmPose."""
+    tf = np.ascontiguousarray(np.asarray(tf, np.float64).reshape(-1, 16))
+    n = tf.shape[0]
+    out = (_lib.VmPose * n)()
+    env = None
+    if env_ids is not None:
+        env = np.ascontiguousarray(np.asarray(env_ids, np.int32))
+        assert env.shape == (n,)
+    bad = ctypes.c_int(-1)
+    rc = _lib.lib().vlfm_value_map_pose_params(tf.ctypes.data, env.ctypes.data if env is not None else None, n, size,
+                                               ppm, T, ctypes.addressof(out), ctypes.byref(bad))
+    _lib.check(rc, "value_map_pose_params")
+    return out
+
+
+class ValueMapBatch:
+    """``n_envs`` value maps (+ confidence maps) resident in HBM, updated together."""
+
+    _min_confidence: float = 0.25  # value_map.py:40
+
+    def __init__(self, n_envs: int, value_channels: int, size: int = 1000, use_max_confidence: bool = True,
+                 fusion_type: str = "default", pixels_per_meter: int = 20, device=None,
+                 explored: Optional[Any] = None) -> None:
+        import torch
+
+        self.device = require_gpu(device)
+        _lib.lib()
+        self.n_envs, self.channels, self.size, self.pixels_per_meter = n_envs, value_channels, size, pixels_per_meter
+        self.use_max_confidence = bool(use_max_confidence)
+        self.fusion_type = fusion_type
+        if os.environ.get("MAP_FUSION_TYPE", "") != "":  # value_map.py:74-75
+            self.fusion_type = os.environ["MAP_FUSION_TYPE"]
+        assert self.fusion_type in _lib.FUSION_TYPES, f"Unknown fusion type {self.fusion_type}"
+        self.conf = torch.zeros((n_envs, size, size), dtype=torch.float32, device=self.device)
+        self.value = torch.zeros((n_envs, size, size, value_channels), dtype=torch.float32, device=self.device)
+        # ObstacleMap.explored_area of the same slots ([n_envs,S,S] uint8/bool tensor) when sync_explored_areas
+        self.explored = explored
+        self._colmax = None
+        self._status = None
+
+    # ------------------------------------------------------------------------------------------ helpers
+    def reset(self, env_ids: Optional[Sequence[int]] = None) -> None:
+        if env_ids is None:
+            self.conf.zero_()
+            self.value.zero_()
+        else:
+            idx = list(env_ids)
+            self.conf[idx] = 0
+            self.value[idx] = 0
+
+    def _scratch(self, n: int, width: int):
+        import torch
+
+        if self._colmax is None or self._colmax.shape[0] < n or self._colmax.shape[1] != width:
+            self._colmax = torch.empty((max(n, self.n_envs), width), dtype=torch.float32, device=self.device)
+            self._status = torch.zeros(max(n, self.n_envs), dtype=torch.int32, device=self.device)
+        return self._colmax, self._status
+
+    def column_max(self, depth) -> Any:
+        """np.max(depth, axis=0) for a [n,H,W] device tensor via the depth-ingest kernel (no obstacle scatter)."""
+        import torch
+
+        n, H, W = depth.shape
+        colmax, status = self._scratch(n, W)
+        prm = (_lib.IngestParams * n)()
+        d_prm = _bytes_to_device(prm, self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().vlfm_depth_ingest_batched(depth.data_ptr(), n, H, W, d_prm.data_ptr(),
+                                                           colmax.data_ptr(), None, self.size, self.pixels_per_meter,
+                                                           status.data_ptr(), _stream_ptr()), "depth_ingest")
+        return colmax[:n]
+
+    # ------------------------------------------------------------------------------------------ update
+    def update(self, values, depth, tf_camera_to_episodic, min_depth: float, max_depth: float, fov: float,
+               env_ids: Optional[Sequence[int]] = None, colmax=None) -> None:
+        """ValueMap.update_map for n observations at once (value_map.py:100-128).
+
+        values [n,C] f64 host array; depth [n,H,W] f32 (device tensor, or host array that is uploaded);
+        tf [n,4,4] f64 host; ``colmax`` = precomputed column maxima [n,W] on device (from a shared depth ingest).
+        """
+        import torch
+
+        values = np.ascontiguousarray(np.asarray(values, np.float64).reshape(-1, self.channels))
+        n = values.shape[0]
+        if colmax is None:
+            if not torch.is_tensor(depth):
+                depth = torch.from_numpy(np.ascontiguousarray(depth, np.float32)).to(self.device)
+            depth = depth.reshape(n, depth.shape[-2], depth.shape[-1]).contiguous()
+            assert depth.dtype == torch.float32
+            colmax = self.column_max(depth)
+        W = colmax.shape[-1]
+        d_tmpl, T = _TEMPLATES.template(self.device, fov, max_depth, self.pixels_per_meter, self._min_confidence)
+        d_tan = _TEMPLATES.tan_table(self.device, fov, W)
+        pose = pose_params(tf_camera_to_episodic, env_ids, self.size, self.pixels_per_meter, T)
+        d_pose = _bytes_to_device(pose, self.device)
+        d_vals = torch.from_numpy(values).to(self.device)
+        explored_ptr = None
+        with torch.cuda.device(self.device):
+            L = _lib.lib()
+            if self.explored is not None:
+                ex = self.explored
+                assert ex.dtype in (torch.uint8, torch.bool) and ex.is_contiguous()
+                explored_ptr = ex.data_ptr()
+                slots = list(env_ids) if env_ids is not None else list(range(n))
+                d_env = torch.tensor(sorted(set(slots)), dtype=torch.int32, device=self.device)
+                _lib.check(L.vlfm_value_map_mask_unexplored_batched(d_env.data_ptr(), d_env.numel(), explored_ptr,
+                                                                    self.conf.data_ptr(), self.value.data_ptr(),
+                                                                    self.size, self.channels, _stream_ptr()),
+                           "mask_unexplored")
+            _lib.check(L.vlfm_value_map_update_batched(colmax.data_ptr(), W, d_tan.data_ptr(), d_tmpl.data_ptr(), T,
+                                                       d_pose.data_ptr(), d_vals.data_ptr(), n,
+                                                       self.conf.data_ptr(), self.value.data_ptr(), self.size,
+                                                       self.channels, self.pixels_per_meter, float(min_depth),
+                                                       float(max_depth), int(self.use_max_confidence),
+                                                       _lib.FUSION_TYPES[self.fusion_type], explored_ptr,
+                                                       _stream_ptr()), "value_map_update")
+
+    # ------------------------------------------------------------------------------------------ frontier scoring
+    def waypoint_values(self, waypoints_xy: np.ndarray, env_of_waypoint: Sequence[int], radius: float) -> np.ndarray:
+        """Disc medians for m waypoints -> [m, C] f32 (value_map.py:161-176, img_utils.py:213-266)."""
+        import torch
+
+        wp = np.asarray(waypoints_xy, np.float64).reshape(-1, 2)
+        m = wp.shape[0]
+        if m == 0:
+            return np.zeros((0, self.channels), np.float32)
+        radius_px = int(radius * self.pixels_per_meter)
+        cells = np.zeros((m, 3), np.int32)
+        for i, ((x, y), e) in enumerate(zip(wp, env_of_waypoint)):
+            px = int(-x * self.pixels_per_meter) + self.size // 2  # truncation (value_map.py:165-166)
+            py = int(-y * self.pixels_per_meter) + self.size // 2
+            row, col = self.size - px, py
+            assert 0 <= row < self.size and 0 <= col < self.size, "Pixel location is outside the image."
+            cells[i] = (e, row, col)
+        d_cells = torch.from_numpy(cells).to(self.device)
+        d_disc = _TEMPLATES.disc(self.device, radius_px)
+        out = torch.empty((m, self.channels), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().vlfm_value_map_sort_waypoints_batched(self.value.data_ptr(), self.size,
+                                                                       self.channels, d_cells.data_ptr(), m,
+                                                                       radius_px, d_disc.data_ptr(), out.data_ptr(),
+                                                                       _stream_ptr()), "sort_waypoints")
+        return out.cpu().numpy()
+
+
+class ValueMap(BaseMap):
+    """Drop-in for vlfm.mapping.value_map.ValueMap (same constructor and method signatures)."""
+
+    _confidence_masks: Dict[Tuple[float, float], np.ndarray] = {}
+    _min_confidence: float = 0.25
+    _decision_threshold: float = 0.35
+
+    def __init__(self, value_channels: int, size: int = 1000, use_max_confidence: bool = True,
+                 fusion_type: str = "default", obstacle_map: Optional["ObstacleMap"] = None,  # noqa: F821
+                 device=None, _batch: Optional[ValueMapBatch] = None, _slot: int = 0) -> None:
+        super().__init__(size)
+        self._value_channels = value_channels
+        self._use_max_confidence = use_max_confidence
+        self._obstacle_map = obstacle_map
+        if obstacle_map is not None:
+            assert obstacle_map.pixels_per_meter == self.pixels_per_meter  # value_map.py:71-73
+            assert obstacle_map.size == self.size
+        if _batch is None:
+            _batch = ValueMapBatch(1, value_channels, size, use_max_confidence, fusion_type, self.pixels_per_meter,
+                                   device)
+            _slot = 0
+        self._batch, self._slot = _batch, _slot
+        self._fusion_type = _batch.fusion_type
+
+    # maps are HBM-resident; these attributes are host snapshots for the callers that read them (visualisation)
+    @property
+    def _map(self) -> np.ndarray:
+        return self._batch.conf[self._slot].cpu().numpy()
+
+    @property
+    def _value_map(self) -> np.ndarray:
+        return self._batch.value[self._slot].cpu().numpy()
+
+    def reset(self) -> None:
+        super().reset()
+        self._batch.reset([self._slot])
+
+    def update_map(self, values: np.ndarray, depth: np.ndarray, tf_camera_to_episodic: np.ndarray,
+                   min_depth: float, max_depth: float, fov: float) -> None:
+        assert len(values) == self._value_channels, \
+            f"Incorrect number of values given ({len(values)}). Expected {self._value_channels}."
+        import torch
+
+        if not torch.is_tensor(depth):
+            depth = np.asarray(depth, np.float32)
+            if depth.ndim == 3:
+                depth = depth.squeeze(2)  # value_map.py:231-232
+            depth = depth[None]
+        else:
+            depth = depth.reshape(1, depth.shape[0], depth.shape[1])
+        if self._obstacle_map is not None:
+            self._batch.explored = self._obstacle_map.explored_area_device()
+        self._batch.update(np.asarray(values, np.float64)[None], depth, np.asarray(tf_camera_to_episodic)[None],
+                           min_depth, max_depth, fov, env_ids=[self._slot])
+
+    def sort_waypoints(self, waypoints: np.ndarray, radius: float,
+                       reduce_fn: Optional[Callable] = None) -> Tuple[np.ndarray, List[float]]:
+        vals = self._batch.waypoint_values(waypoints, [self._slot] * len(waypoints), radius)
+        if self._value_channels == 1:
+            values: List[Any] = [float(v) if v != -1 else -1 for v in vals[:, 0]]
+        else:
+            values = [tuple(float(c) for c in v) for v in vals]
+            assert reduce_fn is not None, "Must provide a reduction function when using multiple value channels."
+            values = reduce_fn(values)
+        order = np.argsort([-v for v in values])  # the reference's own ordering call (value_map.py:183)
+        return np.array([waypoints[i] for i in order]), [values[i] for i in order]
+
+    def visualize(self, markers=None, reduce_fn: Callable = lambda i: np.max(i, axis=-1), obstacle_map=None):
+        """Plain grey-scale rendering (the reference's OpenCV inferno/trajectory drawing is out of scope)."""
+        reduced = reduce_fn(self._value_map).copy()
+        if obstacle_map is not None:
+            reduced[obstacle_map.explored_area == 0] = 0
+        img = np.flipud(reduced)
+        zero = img == 0
+        top = float(img.max()) if img.size else 0.0
+        scaled = np.zeros(img.shape, np.uint8) if top <= 0 else (img / top * 255).astype(np.uint8)
+        rgb = np.stack([scaled] * 3, axis=-1)
+        rgb[zero] = (255, 255, 255)
+        return rgb
