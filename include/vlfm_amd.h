@@ -53,9 +53,11 @@ typedef struct {
 
 /* Host: restates ValueMap._localize_new_data's scalar prologue (value_map.py:297-313) + rotate_image's matrix
  * (img_utils.py:23-25) for n observations.  h_tf: [n][16] row-major camera->episodic transforms (f64).
+ * h_yaw: [n] yaw angles if the caller already evaluated extract_yaw (geometry_utils.py:145-159) -- a Python host
+ * passes numpy.arctan2's result so that the angle is the reference's to the last bit -- or NULL (libm atan2).
  * h_env: [n] env slot per observation (NULL = 0..n-1).  Returns VLFM_ERR_OUTSIDE_MAP if a camera cell falls
  * outside [0,S) (place_img_in_img's assertion, img_utils.py:43); *bad_index then holds the observation. */
-int vlfm_value_map_pose_params(const double* h_tf, const int32_t* h_env, int n, int map_size,
+int vlfm_value_map_pose_params(const double* h_tf, const double* h_yaw, const int32_t* h_env, int n, int map_size,
                                int pixels_per_meter, int template_size, vlfm_vm_pose* h_out, int* bad_index);
 
 /* Host: the unmasked confidence table of ValueMap._get_confidence_mask (value_map.py:337-351) for a T x T

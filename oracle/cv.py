@@ -145,9 +145,12 @@ def polylines(img, pts, isClosed, color, thickness=1):
 
 
 def getRotationMatrix2D(center, angle, scale):
-    angle = angle * (np.pi / 180)  # cv: angle *= CV_PI/180 (constant folded first)
-    alpha = np.cos(angle) * scale
-    beta = np.sin(angle) * scale
+    import math
+
+    angle = float(angle) * (np.pi / 180)  # cv: angle *= CV_PI/180 (constant folded first)
+    # cv::getRotationMatrix2D is C++: std::cos/std::sin = libm (NumPy's SIMD cos/sin differ from libm by a few ulp)
+    alpha = math.cos(angle) * scale
+    beta = math.sin(angle) * scale
     cx, cy = float(np.float32(center[0])), float(np.float32(center[1]))  # Point2f
     return np.array([[alpha, beta, (1 - alpha) * cx - beta * cy], [-beta, alpha, beta * cx + (1 - alpha) * cy]])
 

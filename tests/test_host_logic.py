@@ -1,0 +1,78 @@
+"""Host half of the C ABI (scalar f64 prologues, CPU-callable) against the oracle's restatement."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import cv
+from oracle.ref_geometry import pose_to_tf, yaw_of
+from oracle.ref_value_map import RefValueMap
+from vlfm_amd import _lib
+from vlfm_amd.mapping.value_map import pose_params
+
+FOV = np.deg2rad(79)
+
+
+def test_pose_params_match_oracle_rotation_and_cell():
+    rng = np.random.default_rng(0)
+    tfs = np.stack([pose_to_tf((rng.uniform(-20, 20), rng.uniform(-20, 20), 0.88), rng.uniform(-np.pi, np.pi))
+                    for _ in range(64)] + [pose_to_tf((0.049, -0.049, 0.88), np.pi / 6 * k) for k in range(12)])
+    out = pose_params(tfs, None, 1000, 20, 201)
+    for k, tf in enumerate(tfs):
+        M = cv.getRotationMatrix2D((100, 100), np.degrees(-yaw_of(tf)), 1.0).reshape(-1).copy()
+        D = M[0] * M[4] - M[1] * M[3]
+        D = 1.0 / D if D != 0 else 0
+        A11, A22 = M[4] * D, M[0] * D
+        M[0] = A11; M[1] *= -D; M[3] *= -D; M[4] = A22
+        b1 = -M[0] * M[2] - M[1] * M[5]; b2 = -M[3] * M[2] - M[4] * M[5]
+        M[2] = b1; M[5] = b2
+        assert list(out[k].inv_affine) == M.tolist()      # bit-exact f64
+        px = int(tf[0, 3] * 20) + 500
+        py = int(-tf[1, 3] * 20) + 500
+        assert (out[k].row0, out[k].col0, out[k].env) == (px - 100, py - 100, k)
+
+
+def test_pose_params_outside_map_is_the_reference_assertion():
+    with pytest.raises(AssertionError, match="Pixel location is outside the image."):
+        pose_params(pose_to_tf((25.05, 0, 0.88), 0.0)[None], None, 1000, 20, 201)
+    with pytest.raises(AssertionError):
+        pose_params(pose_to_tf((0, 25.05, 0.88), 0.0)[None], None, 1000, 20, 201)
+    pose_params(pose_to_tf((24.99, -24.99, 0.88), 0.0)[None], None, 1000, 20, 201)
+
+
+@pytest.mark.parametrize("fov_deg,max_depth", [(79.0, 5.0), (60.0, 3.5), (90.0, 10.0)])
+def test_cone_template_host_matches_oracle(fov_deg, max_depth):
+    fov = np.deg2rad(fov_deg)
+    T = 2 * int(max_depth * 20) + 1
+    conf = np.zeros(T * T, np.float32)
+    poly = np.zeros(1024, np.int64)
+    n = ctypes.c_int(0)
+    rc = _lib.lib().vlfm_cone_template_host(fov, max_depth, 20, 0.25, conf.ctypes.data, conf.size, poly.ctypes.data,
+                                            512, ctypes.byref(n))
+    assert rc == T
+    want_poly = cv.ellipse_polygon((T // 2, T // 2), (T // 2, T // 2), 0, -np.rad2deg(fov) / 2 + 90,
+                                   np.rad2deg(fov) / 2 + 90)
+    assert np.array_equal(poly[: 2 * n.value].reshape(-1, 2), want_poly)
+    RefValueMap._confidence_masks.pop((fov, max_depth), None)
+    ref = RefValueMap(1)._get_confidence_mask(fov, max_depth)
+    inside = ref > 0
+    got = conf.reshape(T, T)
+    # NumPy's scalar trig may differ from libm by an ulp of f64 before the f32 store: allow one f32 ulp
+    assert np.abs(got[inside] - ref[inside]).max() <= 2 ** -23
+    assert (got[inside] == ref[inside].astype(np.float32)).mean() > 0.999
+
+
+def test_tan_table_and_disc_rows():
+    tab = np.zeros(640)
+    _lib.lib().vlfm_tan_table_host(FOV, 640, tab.ctypes.data)
+    want = np.tan(np.linspace(-FOV / 2, FOV / 2, 640))
+    assert np.abs(tab - want).max() <= 4 * np.finfo(np.float64).eps
+    assert tab[-1] == np.tan(FOV / 2) or abs(tab[-1] - np.tan(FOV / 2)) < 1e-15
+    for r in (1, 2, 5, 10, 17):
+        hw = np.zeros(2 * r + 1, np.int32)
+        _lib.lib().vlfm_disc_rows_host(r, hw.ctypes.data)
+        disc = np.zeros((2 * r + 1, 2 * r + 1), np.uint8)
+        cv.circle(disc, (r, r), r, 255, -1)
+        for i in range(2 * r + 1):
+            xs = np.where(disc[i])[0]
+            assert xs[0] == r - hw[i] and xs[-1] == r + hw[i] and len(xs) == 2 * hw[i] + 1

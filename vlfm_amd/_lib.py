@@ -70,7 +70,7 @@ def lib() -> ctypes.CDLL:
         vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
         L.vlfm_last_error.restype = ctypes.c_char_p
         L.vlfm_abi_version.restype = ci
-        L.vlfm_value_map_pose_params.argtypes = [vp, vp, ci, ci, ci, ci, vp, ctypes.POINTER(ci)]
+        L.vlfm_value_map_pose_params.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp, ctypes.POINTER(ci)]
         L.vlfm_cone_template_host.argtypes = [cd, cd, ci, cd, vp, ci, vp, ci, ctypes.POINTER(ci)]
         L.vlfm_tan_table_host.argtypes = [cd, ci, vp]
         L.vlfm_disc_rows_host.argtypes = [ci, vp]
@@ -80,8 +80,6 @@ def lib() -> ctypes.CDLL:
                                                     ci, vp, vp]
         L.vlfm_value_map_mask_unexplored_batched.argtypes = [vp, ci, vp, vp, vp, ci, ci, vp]
         L.vlfm_value_map_sort_waypoints_batched.argtypes = [vp, ci, ci, vp, ci, ci, vp, vp, vp]
-        for name in dir(L):
-            pass
         _lib = L
     return _lib
 

@@ -38,17 +38,18 @@ float sin_deg_table(int deg) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ pose prologue
-extern "C" int vlfm_value_map_pose_params(const double* h_tf, const int32_t* h_env, int n, int map_size,
-                                          int pixels_per_meter, int template_size, vlfm_vm_pose* h_out,
-                                          int* bad_index) {
+extern "C" int vlfm_value_map_pose_params(const double* h_tf, const double* h_yaw, const int32_t* h_env, int n,
+                                          int map_size, int pixels_per_meter, int template_size,
+                                          vlfm_vm_pose* h_out, int* bad_index) {
     if (!h_tf || !h_out || n < 0 || map_size <= 0 || template_size <= 0)
         return vlfm::fail(VLFM_ERR_INVALID, "value_map_pose_params: bad argument");
     const double ppm = (double)pixels_per_meter;
     const int half = template_size / 2;
     for (int k = 0; k < n; k++) {
         const double* tf = h_tf + 16 * k;
-        // extract_yaw (geometry_utils.py:145-159)
-        const double yaw = std::atan2(tf[4], tf[0]);
+        // extract_yaw (geometry_utils.py:145-159).  A Python host passes numpy.arctan2's own result (h_yaw): NumPy's
+        // SIMD arctan2 and libm's atan2 can differ by one ulp, and the reference calls NumPy here.
+        const double yaw = h_yaw ? h_yaw[k] : std::atan2(tf[4], tf[0]);
         // rotate_image(curr_data, -yaw) (value_map.py:304, img_utils.py:23-25): centre (T//2, T//2) as Point2f,
         // np.degrees, then cv::getRotationMatrix2D's "angle *= CV_PI/180"
         const double degrees = (-yaw) * (180.0 / kPi);

@@ -60,6 +60,7 @@ class _ConeTemplates:
                                            conf.ctypes.data, conf.size, poly.ctypes.data, 512, ctypes.byref(n_poly))
             _lib.check(rc, "cone_template_host")
             assert rc == T
+            conf = _confidence_table_numpy(T, fov, min_conf)
             d_conf = torch.from_numpy(conf).to(device)
             d_poly = torch.from_numpy(poly).to(device)
             d_tmpl = torch.empty(T * T, dtype=torch.float32, device=device)
@@ -94,6 +95,21 @@ class _ConeTemplates:
 _TEMPLATES = _ConeTemplates()
 
 
+def _confidence_table_numpy(T: int, fov: float, min_conf: float) -> np.ndarray:
+    """Unmasked confidence of value_map.py:343-351 evaluated with the reference's own math library (NumPy ufuncs for
+    arctan2/cos, libm pow for the scalar ``** 2``), vectorised over the template; replaces the libm-only table of
+    vlfm_cone_template_host when the host is Python so that the f64 intermediates are NumPy's to the last bit."""
+    import math
+
+    off = np.abs(np.arange(T) - T // 2)
+    theta = np.arctan2(off[None, :].repeat(T, 0), off[:, None].repeat(T, 1))
+    theta = (theta - 0) * (np.pi / 2 - 0) / (fov / 2 - 0) + 0
+    cos = np.cos(theta)
+    sq = np.array([math.pow(c, 2.0) for c in cos.reshape(-1)])
+    conf = (sq - 0) * (1 - min_conf) / (1 - 0) + min_conf
+    return np.ascontiguousarray(conf.astype(np.float32))
+
+
 def pose_params(tf: np.ndarray, env_ids: Optional[Sequence[int]], size: int, ppm: int, T: int):
     """Host prologue of ValueMap._localize_new_data for n observations -> ctypes array of VmPose."""
     tf = np.ascontiguousarray(np.asarray(tf, np.float64).reshape(-1, 16))
@@ -104,7 +120,10 @@ def pose_params(tf: np.ndarray, env_ids: Optional[Sequence[int]], size: int, ppm
         env = np.ascontiguousarray(np.asarray(env_ids, np.int32))
         assert env.shape == (n,)
     bad = ctypes.c_int(-1)
-    rc = _lib.lib().vlfm_value_map_pose_params(tf.ctypes.data, env.ctypes.data if env is not None else None, n, size,
+    # extract_yaw with the reference's own function: numpy.arctan2 (geometry_utils.py:157)
+    yaw = np.ascontiguousarray(np.arctan2(tf[:, 4], tf[:, 0]))
+    rc = _lib.lib().vlfm_value_map_pose_params(tf.ctypes.data, yaw.ctypes.data,
+                                               env.ctypes.data if env is not None else None, n, size,
                                                ppm, T, ctypes.addressof(out), ctypes.byref(bad))
     _lib.check(rc, "value_map_pose_params")
     return out
