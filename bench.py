@@ -1,0 +1,233 @@
+#!/usr/bin/env python
+"""bench.py -- env-steps/s of the VLFM perception + value-map hot path on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one ITMPolicyV2 perception+mapping step for every resident environment (BASELINE.json metric
+"env-steps/s (VLM+value-map update), 640x480 RGB-D"): batched in-process BLIP-2 ITC cosine at the full ViT-g/14
+geometry (random-init weights: no checkpoints offline), one depth-ingest pass, ObstacleMap update (when built),
+ValueMap.update_map and frontier scoring (sort_waypoints) -- see vlfm_amd/harness.py.  Observations are synthetic and
+already resident in HBM when the timed region starts.  Episodes are independent: env e lives on rank e mod N
+(weak scaling, --envs per GPU fixed), the only collective is the final metric all-reduce.
+
+Prints ONE JSON line (rank 0) with the driver's keys plus:
+  roofline      dominant HIP map kernel: algorithmic bytes per launch / mean launch time (HIP events on the launch
+                stream, inside the timed region) vs the 8 TB/s HBM peak
+  cpu_baseline  the reference-faithful CPU path (oracle/ NumPy+C restatement of the maps + the same ITC graph in fp32
+                on the host cores), timed on rank 0 at N=1 on a bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--envs", type=int, default=8, help="environments resident per GPU (configs[3]: 8/GPU)")
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--no-blip2", action="store_true", help="map kernels only (NOT the headline metric)")
+    ap.add_argument("--no-obstacle", action="store_true")
+    ap.add_argument("--sync-explored", action="store_true", help="config 5: value map synchronised with explored area")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, with_blip2: bool):
+    """Reference-faithful CPU path on the host cores: oracle maps (NumPy + oracle/libcvport.so) and the same BLIP-2
+    ITC graph in fp32 through PyTorch-CPU (the reference's own fallback device, vlfm/vlm/blip2itm.py:26-27)."""
+    import numpy as np
+    import torch
+
+    from oracle.ref_value_map import RefValueMap
+    from vlfm_amd.synthetic import MAX_DEPTH, MIN_DEPTH, SyntheticEnv, camera_intrinsics, rgb_frame
+
+    cores = min(os.cpu_count() or 1, 16)  # more intra-op threads than this only oversubscribes the fp32 GEMMs
+    torch.set_num_threads(cores)
+    fov = camera_intrinsics(args.width)[2]
+    env = SyntheticEnv(0, args.height, args.width)
+    vm = RefValueMap(1, use_max_confidence=False)
+    om = None
+    try:
+        from oracle.ref_obstacle_map import RefObstacleMap
+
+        if not args.no_obstacle:
+            om = RefObstacleMap(min_height=0.61, max_height=0.88, agent_radius=0.18, area_thresh=1.5)
+    except ImportError:
+        om = None
+    fx, fy, _ = camera_intrinsics(args.width)
+    # maps: warm-up populates the confidence-mask cache, then a bounded timed sample
+    n_map = 60
+    obs = [env.observe() for _ in range(n_map + 5)]
+    t_map = 0.0
+    for i, (depth, tf, values) in enumerate(obs):
+        t0 = time.perf_counter()
+        if om is not None:
+            om.update_map(depth, tf, MIN_DEPTH, MAX_DEPTH, fx, fy, fov)
+        vm.update_map(values, depth.copy(), tf, MIN_DEPTH, MAX_DEPTH, fov)
+        if om is not None and len(om.frontiers):
+            vm.sort_waypoints(om.frontiers, 0.5)
+        dt = time.perf_counter() - t0
+        if i >= 5:
+            t_map += dt
+    map_s = t_map / n_map
+    blip_s = 0.0
+    if with_blip2:
+        from vlfm_amd.vlm.blip2itm import Blip2ITCConfig, Blip2ITCModel
+        from vlfm_amd.vlm.ops import CLIP_MEAN, CLIP_STD
+        from PIL import Image
+
+        model = Blip2ITCModel(Blip2ITCConfig()).eval()
+        with torch.no_grad():  # throughput does not depend on the weight values: cheap deterministic fill, no RNG
+            for p in model.parameters():
+                if p.dim() > 1:
+                    p.copy_(((torch.arange(p.numel()) % 23).float() * 0.002 - 0.022).view(p.shape))
+                else:
+                    p.fill_(0.0)
+            for m_ in model.modules():
+                if isinstance(m_, torch.nn.LayerNorm):
+                    m_.weight.fill_(1.0)
+        rng = np.random.default_rng(0)
+        ids = torch.randint(0, 30000, (1, 9))
+        mean = torch.tensor(CLIP_MEAN).view(3, 1, 1)
+        std = torch.tensor(CLIP_STD).view(3, 1, 1)
+        times = []
+        with torch.inference_mode():
+            text = model.text_feature(ids)
+            for i in range(args.cpu_steps + 1):
+                rgb = rgb_frame(rng, args.height, args.width)
+                t0 = time.perf_counter()
+                pil = np.asarray(Image.fromarray(rgb).resize((224, 224), Image.BICUBIC))
+                pix = ((torch.from_numpy(pil.copy()).permute(2, 0, 1).float().div(255) - mean) / std)[None]
+                float(model.itc_reference_head(model.query_features(model.vision_tokens(pix)), text)[0])
+                if i > 0:
+                    times.append(time.perf_counter() - t0)
+        blip_s = float(np.mean(times))
+    total = map_s + blip_s
+    return {
+        "value": round(1.0 / total, 3), "unit": "env-steps/s", "cores": cores, "kind": "port",
+        "sample": (f"1 env, {n_map} timed map steps (oracle ValueMap{'+ObstacleMap' if om is not None else ''}, "
+                   f"{map_s * 1e3:.1f} ms/step on 1 core)"
+                   + (f" + {args.cpu_steps} BLIP-2 ITC fp32 forwards on {cores} torch threads ({blip_s * 1e3:.0f} ms/frame)"
+                      if with_blip2 else " (BLIP-2 leg skipped)")),
+        "maps_only_env_steps_per_s": round(1.0 / map_s, 2),
+    }
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    device = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+
+    from vlfm_amd.harness import BatchedEpisodes
+
+    have_obstacle = os.path.exists(os.path.join(ROOT, "vlfm_amd", "mapping", "obstacle_map.py")) and not args.no_obstacle
+    sim = BatchedEpisodes(args.envs, device=device, height=args.height, width=args.width, env_offset=rank * args.envs,
+                          use_blip2=not args.no_blip2, obstacle=have_obstacle, sync_explored=args.sync_explored)
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        sim.step()
+    sim.timers.clear()
+    from vlfm_amd import _lib
+
+    _lib.lib().vlfm_profile_enable(1)  # HIP events around every kernel launch of libvlfm_amd, on its launch stream
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sim.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    totals = torch.tensor([float(args.envs * args.steps), 0.0], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)        # slowest rank defines the job time
+        dist.all_reduce(totals, op=dist.ReduceOp.SUM)   # the metric all-reduce over RCCL/xGMI
+    elapsed_max = float(t.item())
+    env_steps = float(totals[0].item())
+
+    torch.cuda.synchronize(device)
+    kms = {}
+    for kname in ("depth_ingest_kernel", "depth_profile_kernel", "value_map_update_kernel", "sort_waypoints_kernel",
+                  "mask_unexplored_kernel",
+                  "resample_h_kernel", "resample_v_norm_kernel", "itc_head_kernel", "obstacle_dilate_kernel",
+                  "fog_of_war_kernel", "frontier_kernel"):
+        ms, n = _lib.profile_read(kname)
+        if n:
+            kms[kname] = ms
+    _lib.lib().vlfm_profile_enable(0)
+    if rank == 0:
+        H, W, E = args.height, args.width, args.envs
+        T = 2 * int(5.0 * 20) + 1
+        # algorithmic bytes per launch: depth ingest reads 4HW per env (+ <=HW scatter byte stores with
+        # the obstacle map); value-map update reads the template (4T^2) and RMWs conf (8T^2) + value (8T^2, C=1)
+        ingest_bytes = E * (4 * H * W + (H * W if have_obstacle else 0))
+        update_bytes = E * (4 * T * T + 8 * T * T + 8 * T * T)
+        cands = []
+        if "depth_ingest_kernel" in kms:
+            cands.append(("depth_ingest_kernel", ingest_bytes, kms["depth_ingest_kernel"]))
+        if "value_map_update_kernel" in kms:
+            cands.append(("value_map_update_kernel", update_bytes, kms["value_map_update_kernel"]))
+        name, nbytes, ms = max(cands, key=lambda c: c[1])
+        achieved = nbytes / (ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(achieved / 8000.0, 4), "traffic": None,
+                    "algorithmic_bytes_per_launch": nbytes, "launch_ms": round(ms, 5),
+                    "all_kernels_ms": {k: round(v, 5) for k, v in kms.items()}}
+        out = {
+            "metric": "env-steps/s (VLM+value-map update), 640x480 RGB-D",
+            "value": round(env_steps / elapsed_max, 2), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 maps / f16 ViT-g + f32 Q-Former", "data": "synthetic",
+            "config": {"workload": ("configs[1] step (BLIP-2 ITC cosine + ValueMap fusion"
+                                    + (" + ObstacleMap update" if have_obstacle else "")
+                                    + " + sort_waypoints), batched over the resident envs as in configs[3]"
+                                    if not args.no_blip2 else "MAP KERNELS ONLY (no VLM) -- not the headline metric"),
+                       "envs_per_gpu": E, "global_envs": E * world, "rgbd": f"{W}x{H}", "map": "1000x1000 @ 20 px/m",
+                       "blip2": "ViT-g/14 39 blocks + Q-Former 12 layers, random-init" if not args.no_blip2 else None,
+                       "parallelism": f"env-sharded x{world}, metric all-reduce only"},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, with_blip2=not args.no_blip2)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -38,6 +38,11 @@ enum { VLFM_FUSE_DEFAULT = 0, VLFM_FUSE_REPLACE = 1, VLFM_FUSE_EQUAL_WEIGHTING =
 const char* vlfm_last_error(void);
 int vlfm_abi_version(void);
 
+/* Optional per-kernel timing: when enabled every kernel launch of this library is bracketed by hipEvents on its
+ * launch stream.  kernel_name is the device function's name (e.g. "depth_ingest_kernel"). */
+int vlfm_profile_enable(int on);
+int vlfm_profile_read(const char* kernel_name, double* mean_ms, int* launches);
+
 /* ---------------------------------------------------------------------------------------------
  * Per-observation pose parameters of one value-map update (64 bytes, uploaded to HBM by the caller).
  * Filled on the host by vlfm_value_map_pose_params(); consumed by vlfm_value_map_update_batched().
@@ -80,8 +85,11 @@ int vlfm_cone_template_build(const float* d_conf, const int64_t* d_poly_xy, int 
  *   (a) column max  -> d_colmax[n][W]      (np.max(depth, axis=0), value_map.py:234)
  *   (b) obstacle scatter -> d_obstacle[env][S][S] u8 (unproject, transform, height band, rint cell, store 1;
  *       obstacle_map.py:92-101 + geometry_utils.py:205-236 + base_map.py:44-46)          [optional]
- * d_depth: [n][H][W] f32 in [0,1].  d_colmax must be zero-filled by the caller before the call when it is used
- * (vlfm_depth_ingest_batched does it itself with a memset node on `stream`).
+ * d_depth: [n][H][W] f32 in [0,1].
+ * d_colmax_keys [n][W] u32: column maxima as order-preserving keys (0 = -inf).  The buffer must be zero when the call
+ * is made: allocate it zeroed once; vlfm_value_map_update_batched consumes the keys and writes the zeros back, so a
+ * steady ingest -> update cadence needs no memset.  d_status [n] is sticky: the kernel only ever writes
+ * VLFM_ERR_INDEX into it; the caller zeroes it after reading.
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
     double tf[12];        /* first three rows of the camera->episodic 4x4 (row-major) */
@@ -97,14 +105,14 @@ typedef struct {
 
 int vlfm_depth_ingest_batched(const float* d_depth, int n, int height, int width,
                               const vlfm_ingest_params* d_params,
-                              float* d_colmax /* [n][W] or NULL */,
+                              uint32_t* d_colmax_keys /* [n][W] or NULL */,
                               uint8_t* d_obstacle /* [n_envs][S][S] or NULL */, int map_size, int pixels_per_meter,
                               int32_t* d_status /* [n] out: 0 ok, VLFM_ERR_INDEX if a point fell off the map */,
                               void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * ValueMap.update_map for n observations (value_map.py:100-128 = :221-260 + :288-319 + :357-429).
- *   d_colmax   [n][W]        raw column maxima from depth ingest
+ *   d_colmax_keys [n][W]     column-max keys from depth ingest (consumed: reset to 0 by this call)
  *   d_tan      [W]           f64 tan table (vlfm_tan_table_host)
  *   d_template [T*T]         f32 masked confidence template
  *   d_pose     [n]           vlfm_vm_pose
@@ -115,13 +123,14 @@ int vlfm_depth_ingest_batched(const float* d_depth, int n, int height, int width
  *              obstacle_map=... (value_map.py:369-375); NULL = Habitat default (windowed update, exact).
  * With d_explored the full-map zeroing is done by vlfm_value_map_mask_unexplored_batched (call it first).
  * ------------------------------------------------------------------------------------------- */
-int vlfm_value_map_update_batched(const float* d_colmax, int width, const double* d_tan,
+int vlfm_value_map_update_batched(uint32_t* d_colmax_keys, int width, const double* d_tan,
                                   const float* d_template, int template_size,
                                   const vlfm_vm_pose* d_pose, const double* d_values, int n,
                                   float* d_conf, float* d_value, int map_size, int channels, int pixels_per_meter,
                                   double min_depth, double max_depth,
                                   int use_max_confidence, int fusion_type,
-                                  const uint8_t* d_explored, void* stream);
+                                  const uint8_t* d_explored,
+                                  int32_t* d_vertices /* scratch [n][width+2][2] int32 */, void* stream);
 
 /* Full-map half of _fuse_new_data when an obstacle map is attached (value_map.py:369-375):
  * conf = value = 0 wherever explored == 0, for the n listed env slots.  Streaming, HBM-bound. */
@@ -139,6 +148,31 @@ int vlfm_disc_rows_host(int radius, int32_t* h_halfwidth /* [2r+1] */);
 int vlfm_value_map_sort_waypoints_batched(const float* d_value, int map_size, int channels,
                                           const int32_t* d_cells, int m, int radius, const int32_t* d_disc,
                                           float* d_out, void* stream);
+
+
+/* ---------------------------------------------------------------------------------------------
+ * VLM-side kernels (vlfm/vlm/blip2itm.py:37-54; LAVIS eval transform + ITC head [ext])
+ * ------------------------------------------------------------------------------------------- */
+
+/* Host: Pillow's precompute_coeffs + normalize_coeffs_8bpc (bicubic, a=-0.5, antialiased) for one axis.
+ * h_bounds [out_size][2] = (first tap, tap count); h_kk [out_size][ksize] 22-bit fixed-point taps. */
+int vlfm_resample_coeffs_host(int in_size, int out_size, int32_t* h_bounds, int32_t* h_kk, int kk_capacity,
+                              int* ksize_out);
+
+/* Device: d_rgb [n][H][W][3] u8 -> d_out [n][3][out][out] (out_dtype 0=f32, 1=f16, 2=bf16):
+ * PIL.Image.resize((out,out), BICUBIC) (two 8-bit passes, d_tmp [n][H][out][3] u8 scratch) -> /255 -> (x-mean)/std. */
+int vlfm_preprocess_rgb_batched(const uint8_t* d_rgb, int n, int height, int width, int out_size,
+                                const int32_t* d_hbounds, const int32_t* d_hk, int hksize,
+                                const int32_t* d_vbounds, const int32_t* d_vk, int vksize,
+                                const float* h_mean3, const float* h_std3, uint8_t* d_tmp, void* d_out,
+                                int out_dtype, void* stream);
+
+/* Device: ITC head epilogue.  d_proj [B][NQ][P] f32 = vision_proj(Q-Former query outputs) (the 768->256 GEMM itself is
+ * a plain library GEMM), d_text [B][P] L2-normalised text features -> d_out [B] = max_q <normalize(proj_q), text>.
+ * One wavefront per (image, query): L2 norm + dot by lane-strided loads and a 64-lane shuffle reduction, then the
+ * max over queries.  NQ <= 64. */
+int vlfm_itc_head_batched(const float* d_proj, int batch, int n_query, int proj_dim,
+                          const float* d_text, float* d_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,83 @@
+"""-m gpu: VLM-side HIP kernels against the real PIL / plain PyTorch fp32, and the in-process BLIP-2 ITC path."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (720, 1280), (100, 150)])
+def test_preprocess_matches_pil_bit_exact(gpu_device, shape):
+    from PIL import Image
+
+    from vlfm_amd.vlm import ops
+
+    rng = np.random.default_rng(1)
+    H, W = shape
+    imgs = rng.integers(0, 256, size=(3, H, W, 3), dtype=np.uint8)
+    out = ops.preprocess_rgb(torch.from_numpy(imgs).to(gpu_device), 224, torch.float32).cpu()
+    mean = torch.tensor(ops.CLIP_MEAN).view(3, 1, 1)
+    std = torch.tensor(ops.CLIP_STD).view(3, 1, 1)
+    for i in range(3):
+        pil = np.asarray(Image.fromarray(imgs[i]).resize((224, 224), Image.BICUBIC))
+        want = (torch.from_numpy(pil.copy()).permute(2, 0, 1).float().div(255) - mean) / std  # ToTensor + Normalize
+        assert torch.equal(out[i], want)  # bit-exact f32
+    half = ops.preprocess_rgb(torch.from_numpy(imgs).to(gpu_device), 224, torch.float16).cpu()
+    assert torch.equal(half, out.half())
+
+
+def test_itc_head_vs_fp32_reference(gpu_device):
+    from vlfm_amd.vlm import ops
+
+    g = torch.Generator().manual_seed(0)
+    for (B, NQ, H, P) in [(5, 32, 768, 256), (2, 5, 24, 8), (1, 32, 768, 256)]:
+        q = torch.randn(B, NQ, H, generator=g)
+        w = torch.randn(P, H, generator=g) * 0.05
+        b = torch.randn(P, generator=g) * 0.1
+        t = torch.nn.functional.normalize(torch.randn(B, P, generator=g), dim=-1)
+        want = torch.einsum("bqp,bp->bq", torch.nn.functional.normalize(q @ w.t() + b, dim=-1), t).max(1).values
+        got = ops.itc_head(q.to(gpu_device), w.t().contiguous().to(gpu_device), b.to(gpu_device),
+                           t.to(gpu_device)).cpu()
+        assert torch.allclose(got, want, atol=2e-5, rtol=0), (got, want)
+
+
+def test_blip2_cosine_fp16_gpu_vs_fp32_cpu(gpu_device):
+    """Self-parity of the whole ITC path: fp16 ViT on the GPU vs the same random weights in
+    fp32 on the CPU, small geometry.  Tolerance 2e-2 on a cosine (fp16 ViT activations)."""
+    from vlfm_amd.vlm.blip2itm import BLIP2ITM, Blip2ITCConfig, Blip2ITCModel, blip_caption
+    from vlfm_amd.vlm import ops
+
+    cfg = Blip2ITCConfig(image_size=56, patch_size=14, v_hidden=128, v_layers=3, v_heads=4, v_mlp=256, q_hidden=64,
+                         q_layers=4, q_heads=4, q_mlp=128, vocab_size=2000, max_position_embeddings=40,
+                         num_query_tokens=8, proj_dim=32)
+    gpu = BLIP2ITM(device=gpu_device, config=cfg, seed=5)
+    cpu = Blip2ITCModel(cfg).init_random(5).eval()
+    # random-init at 0.02 gives near-degenerate cosines; scale the weights up identically on both sides
+    with torch.no_grad():
+        for (n1, p1), (n2, p2) in zip(gpu.model.named_parameters(), cpu.named_parameters()):
+            if p2.dim() > 1:
+                p2.mul_(6.0)
+                p1.copy_(p2.to(p1.dtype))
+    rng = np.random.default_rng(0)
+    imgs = rng.integers(0, 256, size=(4, 120, 160, 3), dtype=np.uint8)
+    txt = "Seems like there is a chair ahead."
+    got = gpu.cosine_batch(torch.from_numpy(imgs).to(gpu_device), [txt]).cpu()
+    pix = ops.preprocess_rgb(torch.from_numpy(imgs).to(gpu_device), 56, torch.float32).cpu()
+    ids = torch.tensor([gpu.tokenizer(blip_caption(txt))])
+    with torch.inference_mode():
+        want = cpu.itc_reference_head(cpu.query_features(cpu.vision_tokens(pix)), cpu.text_feature(ids))
+    assert torch.allclose(got, want, atol=2e-2, rtol=0), (got, want)
+    one = gpu.cosine(imgs[2], txt)
+    assert isinstance(one, float) and abs(one - float(got[2])) < 1e-3
+
+
+def test_blip2_client_signature_and_full_geometry(gpu_device):
+    """BLIP2ITMClient(port).cosine(image, txt) -> float at the real ViT-g/14 geometry (random weights)."""
+    from vlfm_amd.vlm.blip2itm import BLIP2ITMClient
+
+    client = BLIP2ITMClient(port=12182, device=gpu_device)
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, size=(480, 640, 3), dtype=np.uint8)
+    c = client.cosine(img, "Seems like there is a target_object ahead.".replace("target_object", "bed"))
+    assert isinstance(c, float) and -1.0 <= c <= 1.0
+    assert client._model.cfg.v_layers == 39 and client._model.weights == "random-init"

@@ -70,6 +70,8 @@ def lib() -> ctypes.CDLL:
         vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
         L.vlfm_last_error.restype = ctypes.c_char_p
         L.vlfm_abi_version.restype = ci
+        L.vlfm_profile_enable.argtypes = [ci]
+        L.vlfm_profile_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(cd), ctypes.POINTER(ci)]
         L.vlfm_value_map_pose_params.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp, ctypes.POINTER(ci)]
         L.vlfm_cone_template_host.argtypes = [cd, cd, ci, cd, vp, ci, vp, ci, ctypes.POINTER(ci)]
         L.vlfm_tan_table_host.argtypes = [cd, ci, vp]
@@ -77,11 +79,21 @@ def lib() -> ctypes.CDLL:
         L.vlfm_cone_template_build.argtypes = [vp, vp, ci, ci, vp, vp]
         L.vlfm_depth_ingest_batched.argtypes = [vp, ci, ci, ci, vp, vp, vp, ci, ci, vp, vp]
         L.vlfm_value_map_update_batched.argtypes = [vp, ci, vp, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci, cd, cd, ci,
-                                                    ci, vp, vp]
+                                                    ci, vp, vp, vp]
         L.vlfm_value_map_mask_unexplored_batched.argtypes = [vp, ci, vp, vp, vp, ci, ci, vp]
         L.vlfm_value_map_sort_waypoints_batched.argtypes = [vp, ci, ci, vp, ci, ci, vp, vp, vp]
+        L.vlfm_resample_coeffs_host.argtypes = [ci, ci, vp, vp, ci, ctypes.POINTER(ci)]
+        L.vlfm_preprocess_rgb_batched.argtypes = [vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, ci, vp]
+        L.vlfm_itc_head_batched.argtypes = [vp, ci, ci, ci, vp, vp, vp]
         _lib = L
     return _lib
+
+
+def profile_read(kernel: str):
+    """(mean_ms, launches) of a kernel since vlfm_profile_enable(1)."""
+    ms, n = ctypes.c_double(0.0), ctypes.c_int(0)
+    lib().vlfm_profile_read(kernel.encode(), ctypes.byref(ms), ctypes.byref(n))
+    return ms.value, n.value
 
 
 def last_error() -> str:

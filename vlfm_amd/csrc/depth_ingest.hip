@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include "../../include/vlfm_amd.h"
+#include "profile.h"
 #include "status.h"
 
 namespace vlfm {
@@ -90,15 +91,27 @@ __global__ __launch_bounds__(1024) void depth_ingest_kernel(IngestArgs a) {
     const float ninf = -__builtin_huge_valf();
     float4 m = make_float4(ninf, ninf, ninf, ninf);
     if (live) {
-        for (int r = r_begin + ry; r < r_end; r += a.ry) {
-            const float4 d = reinterpret_cast<const float4*>(img + (size_t)r * a.W)[col4];
-            m.x = fmaxf(m.x, d.x); m.y = fmaxf(m.y, d.y); m.z = fmaxf(m.z, d.z); m.w = fmaxf(m.w, d.w);
-            if (SCATTER && p.scatter) {
-                const int u = col4 * 4;
-                scatter_point(a, p, grid, obs, u + 0, r, d.x);
-                scatter_point(a, p, grid, obs, u + 1, r, d.y);
-                scatter_point(a, p, grid, obs, u + 2, r, d.z);
-                scatter_point(a, p, grid, obs, u + 3, r, d.w);
+        // four independent 16-byte loads in flight per lane before any use (latency hiding with few waves per CU)
+        constexpr int UNROLL = 4;
+        for (int r0 = r_begin + ry; r0 < r_end; r0 += UNROLL * a.ry) {
+            float4 d[UNROLL];
+#pragma unroll
+            for (int k = 0; k < UNROLL; k++) {
+                const int r = r0 + k * a.ry;
+                d[k] = r < r_end ? reinterpret_cast<const float4*>(img + (size_t)r * a.W)[col4]
+                                 : make_float4(ninf, ninf, ninf, ninf);
+            }
+#pragma unroll
+            for (int k = 0; k < UNROLL; k++) {
+                const int r = r0 + k * a.ry;
+                m.x = fmaxf(m.x, d[k].x); m.y = fmaxf(m.y, d[k].y); m.z = fmaxf(m.z, d[k].z); m.w = fmaxf(m.w, d[k].w);
+                if (SCATTER && p.scatter && r < r_end) {
+                    const int u = col4 * 4;
+                    scatter_point(a, p, grid, obs, u + 0, r, d[k].x);
+                    scatter_point(a, p, grid, obs, u + 1, r, d[k].y);
+                    scatter_point(a, p, grid, obs, u + 2, r, d[k].z);
+                    scatter_point(a, p, grid, obs, u + 3, r, d[k].w);
+                }
             }
         }
     }
@@ -118,30 +131,22 @@ __global__ __launch_bounds__(1024) void depth_ingest_kernel(IngestArgs a) {
     }
 }
 
-// keys -> floats, in place
-__global__ void colmax_decode_kernel(unsigned* keys, int count) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) {
-        const unsigned k = keys[i];
-        reinterpret_cast<float*>(keys)[i] = key_f32(k);
-    }
-}
 
 }  // namespace vlfm
 
 using namespace vlfm;
 
 extern "C" int vlfm_depth_ingest_batched(const float* d_depth, int n, int height, int width,
-                                         const vlfm_ingest_params* d_params, float* d_colmax, uint8_t* d_obstacle,
+                                         const vlfm_ingest_params* d_params, uint32_t* d_colmax_keys, uint8_t* d_obstacle,
                                          int map_size, int pixels_per_meter, int32_t* d_status, void* stream) {
     if (n == 0) return VLFM_OK;
     if (!d_depth || !d_params || !d_status || n < 0 || height <= 0 || width <= 0)
         return fail(VLFM_ERR_INVALID, "depth_ingest_batched: bad argument");
     if (width % 4 != 0) return fail(VLFM_ERR_INVALID, "depth_ingest_batched: width must be a multiple of 4");
-    if (!d_colmax && !d_obstacle) return VLFM_OK;
+    if (!d_colmax_keys && !d_obstacle) return VLFM_OK;
     hipStream_t s = (hipStream_t)stream;
     IngestArgs a;
-    a.depth = d_depth; a.prm = d_params; a.colmax_keys = reinterpret_cast<unsigned*>(d_colmax);
+    a.depth = d_depth; a.prm = d_params; a.colmax_keys = reinterpret_cast<unsigned*>(d_colmax_keys);
     a.obstacle = d_obstacle; a.status = d_status;
     a.H = height; a.W = width; a.W4 = width / 4; a.S = map_size; a.ppm = (double)pixels_per_meter;
     a.cols_per_block = a.W4 < 256 ? a.W4 : 256;
@@ -150,25 +155,18 @@ extern "C" int vlfm_depth_ingest_batched(const float* d_depth, int n, int height
     if (a.ry > 8) a.ry = 8;
     const int threads = a.cols_per_block * a.ry;
     // enough workgroups to cover 256 CUs several times over, but at least 2 loads per thread
-    int rows_per_block = 2 * a.ry;
+    int rows_per_block = 4 * a.ry;
     const int gx = (a.W4 + a.cols_per_block - 1) / a.cols_per_block;
     while ((long)n * gx * ((height + rows_per_block - 1) / rows_per_block) > 4096 && rows_per_block < height) rows_per_block *= 2;
     a.rows_per_block = rows_per_block;
     const int gy = (height + rows_per_block - 1) / rows_per_block;
-    if (hipMemsetAsync(d_status, 0, sizeof(int32_t) * (size_t)n, s) != hipSuccess) return check_launch("memset status");
-    if (d_colmax && hipMemsetAsync(d_colmax, 0, sizeof(float) * (size_t)n * width, s) != hipSuccess)
-        return check_launch("memset colmax");
     const size_t lds = (size_t)threads * sizeof(float4);
-    if (d_obstacle)
-        hipLaunchKernelGGL(depth_ingest_kernel<true>, dim3(gx, gy, n), dim3(threads), lds, s, a);
-    else
-        hipLaunchKernelGGL(depth_ingest_kernel<false>, dim3(gx, gy, n), dim3(threads), lds, s, a);
-    int rc = check_launch("depth_ingest_kernel");
-    if (rc != VLFM_OK) return rc;
-    if (d_colmax) {
-        const int count = n * width;
-        hipLaunchKernelGGL(colmax_decode_kernel, dim3((count + 255) / 256), dim3(256), 0, s, a.colmax_keys, count);
-        rc = check_launch("colmax_decode_kernel");
+    {
+        VLFM_TIMED("depth_ingest_kernel", s);
+        if (d_obstacle)
+            hipLaunchKernelGGL(depth_ingest_kernel<true>, dim3(gx, gy, n), dim3(threads), lds, s, a);
+        else
+            hipLaunchKernelGGL(depth_ingest_kernel<false>, dim3(gx, gy, n), dim3(threads), lds, s, a);
     }
-    return rc;
+    return check_launch("depth_ingest_kernel");
 }

@@ -180,3 +180,62 @@ extern "C" int vlfm_disc_rows_host(int radius, int32_t* h_halfwidth) {
     }
     return VLFM_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ kernel timing
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <vector>
+
+#include "profile.h"
+
+namespace vlfm {
+namespace {
+struct KernelLog { std::vector<std::pair<hipEvent_t, hipEvent_t>> spans; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::map<std::string, KernelLog> g_prof;
+const size_t kMaxSpans = 8192;
+}  // namespace
+
+ProfileScope::ProfileScope(const char* name, hipStream_t stream) : name_(name), stream_(stream) {
+    if (!g_prof_on) return;
+    if (hipEventCreate(&start_) != hipSuccess || hipEventCreate(&stop_) != hipSuccess) return;
+    active_ = true;
+    hipEventRecord(start_, stream_);
+}
+ProfileScope::~ProfileScope() {
+    if (!active_) return;
+    hipEventRecord(stop_, stream_);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    KernelLog& log = g_prof[name_];
+    if (log.spans.size() < kMaxSpans) log.spans.emplace_back(start_, stop_);
+    else { hipEventDestroy(start_); hipEventDestroy(stop_); }
+}
+}  // namespace vlfm
+
+extern "C" int vlfm_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(vlfm::g_prof_mu);
+    for (auto& kv : vlfm::g_prof)
+        for (auto& sp : kv.second.spans) { hipEventDestroy(sp.first); hipEventDestroy(sp.second); }
+    vlfm::g_prof.clear();
+    vlfm::g_prof_on = on != 0;
+    return VLFM_OK;
+}
+
+extern "C" int vlfm_profile_read(const char* kernel_name, double* mean_ms, int* launches) {
+    if (!kernel_name || !mean_ms || !launches) return vlfm::fail(VLFM_ERR_INVALID, "profile_read: bad argument");
+    std::lock_guard<std::mutex> lk(vlfm::g_prof_mu);
+    auto it = vlfm::g_prof.find(kernel_name);
+    *mean_ms = 0.0; *launches = 0;
+    if (it == vlfm::g_prof.end()) return VLFM_OK;
+    double total = 0.0; int n = 0;
+    for (auto& sp : it->second.spans) {
+        if (hipEventSynchronize(sp.second) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, sp.first, sp.second) == hipSuccess) { total += ms; n++; }
+    }
+    *launches = n;
+    *mean_ms = n ? total / n : 0.0;
+    return VLFM_OK;
+}

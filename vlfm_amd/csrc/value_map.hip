@@ -23,6 +23,7 @@
 #include <stdint.h>
 
 #include "../../include/vlfm_amd.h"
+#include "profile.h"
 #include "raster.h"
 #include "status.h"
 
@@ -58,10 +59,11 @@ __global__ __launch_bounds__(1024) void cone_template_kernel(const float* __rest
 
 // ------------------------------------------------------------------------------------------------ update
 struct UpdateArgs {
-    const float* colmax;      // [n][W]
+    unsigned* colmax;         // [n][W] order-preserving keys from depth ingest (consumed and reset to 0 here)
     const double* tan_tab;    // [W]
     const float* tmpl;        // [T][T]
     const vlfm_vm_pose* pose; // [n]
+    int2* vertices;           // [n][W+2] scratch: profile polygon (x=col, y=row)
     const double* values;     // [n][C]
     float* conf;              // [n_envs][S][S]
     float* value;             // [n_envs][S][S][C]
@@ -79,41 +81,54 @@ __device__ inline float tap(const float* __restrict__ tmpl, const unsigned* cut,
     return tmpl[y * T + x];
 }
 
+// keys -> profile polygon (global scratch), and hand the key buffer back zeroed for the next ingest
+__global__ __launch_bounds__(256) void depth_profile_kernel(UpdateArgs a) {
+    const int obs = blockIdx.x, T = a.T, W = a.W;
+    unsigned* cm = a.colmax + (size_t)obs * W;
+    int2* vert = a.vertices + (size_t)obs * (W + 2);
+    for (int i = threadIdx.x; i < W; i += blockDim.x) {
+        const unsigned key = cm[i];
+        cm[i] = 0u;
+        const float raw = __uint_as_float((key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key);
+        const float d = __fadd_rn(__fmul_rn(raw, a.depth_scale), a.depth_offset);        // f32 (value_map.py:234)
+        const float xr = __fadd_rn(__fmul_rn(d, a.ppm_f), a.half_t_f);                   // f32 (:248)
+        const double yl = __dadd_rn(__dmul_rn(__dmul_rn((double)d, a.tan_tab[i]), a.ppm_d), a.half_t_d);  // f64 (:242,249)
+        vert[i + 1] = make_int2((int)(long long)yl, (int)(long long)xr);                 // astype(int): truncation
+    }
+    if (threadIdx.x == 0) {
+        vert[0] = make_int2(0, T - 1);              // [0, last_col]         (:253)
+        vert[W + 1] = make_int2(T - 1, T - 1);      // [last_row, last_col]  (:254)
+    }
+}
+
+// grid = (row tiles, observations).  Every workgroup rasterises the (cheap) coverage bitmap of its observation into
+// its own LDS and then fuses ROWS_PER_TILE template rows: ~13x more workgroups in flight than one-per-observation,
+// which is what hides the L2/HBM latency of the tap + read-modify-write chain.
+constexpr int ROWS_PER_TILE = 8;
+
 template <int C_STATIC>
-__global__ __launch_bounds__(1024) void value_map_update_kernel(UpdateArgs a) {
+__global__ __launch_bounds__(512) void value_map_update_kernel(UpdateArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int T = a.T, W = a.W;
     const int words = (T + 31) >> 5;
     const int n_vert = W + 2;
-    // LDS carve (all 16-byte aligned): bitmaps | vertices | affine tables
+    // LDS carve (all 16-byte aligned): bitmaps | affine tables
     unsigned* solid = reinterpret_cast<unsigned*>(smem);
     unsigned* parity = solid + T * words;
-    int2* vert = reinterpret_cast<int2*>(parity + T * words + ((4 - ((2 * T * words) & 3)) & 3));
-    int* adelta = reinterpret_cast<int*>(vert + n_vert);
+    int* adelta = reinterpret_cast<int*>(parity + T * words + ((4 - ((2 * T * words) & 3)) & 3));
     int* bdelta = adelta + T;
     int* X0 = bdelta + T;
     int* Y0 = X0 + T;
 
-    const int obs = blockIdx.x;
+    const int obs = blockIdx.y;
+    const int row_begin = blockIdx.x * ROWS_PER_TILE;
+    const int row_end = min(row_begin + ROWS_PER_TILE, T);
     const vlfm_vm_pose pose = a.pose[obs];
     const int tid = threadIdx.x, nth = blockDim.x;
 
     LdsBitmap bm;
     bm.solid = solid; bm.parity = parity; bm.rows = T; bm.cols = T; bm.words = words;
     for (int i = tid; i < 2 * T * words; i += nth) solid[i] = 0u;
-
-    // ---- phase 0: depth profile polygon (value_map.py:234-257), contour points are (x=col, y=row)
-    const float* cm = a.colmax + (size_t)obs * W;
-    for (int i = tid; i < W; i += nth) {
-        const float d = __fadd_rn(__fmul_rn(cm[i], a.depth_scale), a.depth_offset);      // f32 (:234)
-        const float xr = __fadd_rn(__fmul_rn(d, a.ppm_f), a.half_t_f);                   // f32 (:248)
-        const double yl = __dadd_rn(__dmul_rn(__dmul_rn((double)d, a.tan_tab[i]), a.ppm_d), a.half_t_d);  // f64 (:242,249)
-        vert[i + 1] = make_int2((int)(long long)yl, (int)(long long)xr);                 // astype(int): truncation
-    }
-    if (tid == 0) {
-        vert[0] = make_int2(0, T - 1);          // [0, last_col]            (:253)
-        vert[n_vert - 1] = make_int2(T - 1, T - 1);  // [last_row, last_col] (:254)
-    }
     // affine tables of cv::warpAffine (AB_BITS = 10, INTER_BITS = 5, round_delta = 16)
     for (int i = tid; i < T; i += nth) {
         adelta[i] = __double2int_rn(__dmul_rn(__dmul_rn(pose.inv_affine[0], (double)i), 1024.0));
@@ -123,7 +138,8 @@ __global__ __launch_bounds__(1024) void value_map_update_kernel(UpdateArgs a) {
     }
     __syncthreads();
 
-    // ---- phase 1: coverage of the "beyond the depth profile" polygon
+    // ---- phase 1: coverage of the "beyond the depth profile" polygon (value_map.py:253-260)
+    const int2* vert = a.vertices + (size_t)obs * n_vert;
     for (int i = tid; i < n_vert; i += nth) {
         const int2 p0 = vert[i == 0 ? n_vert - 1 : i - 1], p1 = vert[i];
         raster_edge(bm, (long long)p0.x << XY_SHIFT, p0.y, (long long)p1.x << XY_SHIFT, p1.y);
@@ -143,7 +159,7 @@ __global__ __launch_bounds__(1024) void value_map_update_kernel(UpdateArgs a) {
 
     // one wavefront per template row, lanes along x: coalesced map accesses, no integer division
     const int lane = tid & 63, wave = tid >> 6, n_waves = nth >> 6;
-    for (int y = wave; y < T; y += n_waves)
+    for (int y = row_begin + wave; y < row_end; y += n_waves)
     for (int x = lane; x < T; x += 64) {
         const int mr = pose.row0 + y, mc = pose.col0 + x;
         if ((unsigned)mr >= (unsigned)S || (unsigned)mc >= (unsigned)S) continue;  // place_img_in_img clipping
@@ -320,25 +336,25 @@ extern "C" int vlfm_cone_template_build(const float* d_conf, const int64_t* d_po
     return check_launch("cone_template_kernel");
 }
 
-static size_t update_lds_bytes(int T, int W) {
+static size_t update_lds_bytes(int T) {
     const int words = (T + 31) >> 5;
     size_t bm_words = (size_t)2 * T * words;
     bm_words += (4 - (bm_words & 3)) & 3;
-    return bm_words * 4 + (size_t)(W + 2) * sizeof(int2) + (size_t)4 * T * sizeof(int);
+    return bm_words * 4 + (size_t)4 * T * sizeof(int);
 }
 
-extern "C" int vlfm_value_map_update_batched(const float* d_colmax, int width, const double* d_tan,
+extern "C" int vlfm_value_map_update_batched(uint32_t* d_colmax_keys, int width, const double* d_tan,
                                              const float* d_template, int template_size, const vlfm_vm_pose* d_pose,
                                              const double* d_values, int n, float* d_conf, float* d_value,
                                              int map_size, int channels, int pixels_per_meter, double min_depth,
                                              double max_depth, int use_max_confidence, int fusion_type,
-                                             const uint8_t* d_explored, void* stream) {
+                                             const uint8_t* d_explored, int32_t* d_vertices, void* stream) {
     if (n == 0) return VLFM_OK;
-    if (!d_colmax || !d_tan || !d_template || !d_pose || !d_values || !d_conf || !d_value || n < 0 || width <= 0 ||
+    if (!d_colmax_keys || !d_tan || !d_template || !d_pose || !d_values || !d_conf || !d_value || n < 0 || width <= 0 ||
         template_size <= 0 || map_size <= 0 || channels <= 0 || fusion_type < 0 || fusion_type > 2)
         return fail(VLFM_ERR_INVALID, "value_map_update_batched: bad argument");
     UpdateArgs a;
-    a.colmax = d_colmax; a.tan_tab = d_tan; a.tmpl = d_template; a.pose = d_pose; a.values = d_values;
+    a.colmax = reinterpret_cast<unsigned*>(d_colmax_keys); a.tan_tab = d_tan; a.tmpl = d_template; a.pose = d_pose; a.values = d_values;
     a.conf = d_conf; a.value = d_value; a.explored = d_explored;
     a.W = width; a.T = template_size; a.S = map_size; a.C = channels;
     // NumPy: f32 array (op) Python float -> the scalar is rounded to f32 first (value_map.py:234,248)
@@ -349,12 +365,20 @@ extern "C" int vlfm_value_map_update_batched(const float* d_colmax, int width, c
     a.ppm_d = (double)pixels_per_meter;
     a.half_t_d = template_size / 2.0;
     a.use_max_conf = use_max_confidence; a.fusion = fusion_type;
-    const size_t lds = update_lds_bytes(template_size, width);
-    if (lds > 160 * 1024) return fail(VLFM_ERR_CAPACITY, "value_map_update_batched: template/width too large for LDS");
+    if (!d_vertices) return fail(VLFM_ERR_INVALID, "value_map_update_batched: d_vertices scratch is null");
+    a.vertices = reinterpret_cast<int2*>(d_vertices);
+    const size_t lds = update_lds_bytes(template_size);
+    if (lds > 160 * 1024) return fail(VLFM_ERR_CAPACITY, "value_map_update_batched: template too large for LDS");
+    {
+        VLFM_TIMED("depth_profile_kernel", stream);
+        hipLaunchKernelGGL(depth_profile_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, a);
+    }
+    const int tiles = (template_size + ROWS_PER_TILE - 1) / ROWS_PER_TILE;
+    VLFM_TIMED("value_map_update_kernel", stream);
     if (channels == 1)
-        hipLaunchKernelGGL(value_map_update_kernel<1>, dim3(n), dim3(1024), lds, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(value_map_update_kernel<1>, dim3(tiles, n), dim3(512), lds, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(value_map_update_kernel<0>, dim3(n), dim3(1024), lds, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(value_map_update_kernel<0>, dim3(tiles, n), dim3(512), lds, (hipStream_t)stream, a);
     return check_launch("value_map_update_kernel");
 }
 
@@ -369,6 +393,7 @@ extern "C" int vlfm_value_map_mask_unexplored_batched(const int32_t* d_env, int 
     int bx = (int)((n16 + 255) / 256);
     if (bx > 512) bx = 512;
     if (bx < 1) bx = 1;
+    VLFM_TIMED("mask_unexplored_kernel", stream);
     hipLaunchKernelGGL(mask_unexplored_kernel, dim3(bx, n), dim3(256), 0, (hipStream_t)stream, d_env, map_size,
                        channels, d_explored, d_conf, d_value);
     return check_launch("mask_unexplored_kernel");
@@ -383,6 +408,7 @@ extern "C" int vlfm_value_map_sort_waypoints_batched(const float* d_value, int m
     const int side = 2 * radius + 1;
     const size_t lds = ((size_t)side * side + 4) * sizeof(float);
     if (lds > 150 * 1024) return fail(VLFM_ERR_CAPACITY, "sort_waypoints_batched: radius too large");
+    VLFM_TIMED("sort_waypoints_kernel", stream);
     hipLaunchKernelGGL(sort_waypoints_kernel, dim3(m, channels), dim3(256), lds, (hipStream_t)stream, d_value,
                        map_size, channels, d_cells, radius, d_disc, d_out);
     return check_launch("sort_waypoints_kernel");

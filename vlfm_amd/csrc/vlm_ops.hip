@@ -1,0 +1,213 @@
+// vlm_ops.hip -- the small HIP kernels either side of the BLIP-2 forward pass (gfx950).
+//
+//   preprocess_rgb   u8 HWC camera frame -> normalised CHW network input.  Restates the LAVIS eval transform the
+//                    reference applies per frame on the CPU (vlfm/vlm/blip2itm.py:48-49 -> PIL Resize(224, BICUBIC)
+//                    -> ToTensor -> Normalize(CLIP mean/std)) with Pillow's exact 8-bit resampler: separable
+//                    antialiased bicubic (a = -0.5), 22-bit fixed-point coefficients, horizontal pass then vertical
+//                    pass with a u8 round trip in between (Pillow src/libImaging/Resample.c).  Bit-exact vs Pillow
+//                    on the u8 intermediate; checked against the real PIL in tests/.
+//   itc_head         the ITC head: vision_proj (768->256) of the 32 Q-Former queries, L2 normalise, dot with the
+//                    cached normalised text feature, max over queries (LAVIS Blip2ITM.forward(match_head="itc") [ext],
+//                    SURVEY.md 3.4) -- one workgroup per image, no host sync.
+#include <hip/hip_fp16.h>
+#include <hip/hip_bf16.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cmath>
+#include <vector>
+
+#include "../../include/vlfm_amd.h"
+#include "profile.h"
+#include "status.h"
+
+namespace vlfm {
+
+constexpr int PRECISION_BITS = 32 - 8 - 2;  // Pillow: 8-bit pixels, 22 fractional bits
+
+__device__ inline unsigned char clip8(int v) {
+    v >>= PRECISION_BITS;
+    return (unsigned char)(v < 0 ? 0 : v > 255 ? 255 : v);
+}
+
+// horizontal pass: [n][H][W][3] u8 -> [n][H][O][3] u8.  One workgroup per (row, image); the source row is staged in LDS.
+__global__ __launch_bounds__(256) void resample_h_kernel(const unsigned char* __restrict__ src, int H, int W, int O,
+                                                         const int* __restrict__ bounds, const int* __restrict__ kk,
+                                                         int ksize, unsigned char* __restrict__ dst) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int y = blockIdx.x, n = blockIdx.y;
+    const unsigned char* row = src + ((size_t)n * H + y) * W * 3;
+    const int row_bytes = W * 3;
+    // 16-byte staging when the row start is aligned (W*3 multiple of 16 for 640 and 1280), scalar otherwise
+    if ((row_bytes & 15) == 0 && ((size_t)row & 15) == 0) {
+        for (int i = threadIdx.x; i < row_bytes / 16; i += blockDim.x)
+            reinterpret_cast<uint4*>(smem)[i] = reinterpret_cast<const uint4*>(row)[i];
+    } else {
+        for (int i = threadIdx.x; i < row_bytes; i += blockDim.x) smem[i] = row[i];
+    }
+    __syncthreads();
+    unsigned char* out = dst + ((size_t)n * H + y) * O * 3;
+    for (int o = threadIdx.x; o < O * 3; o += blockDim.x) {
+        const int xx = o / 3, c = o - xx * 3;
+        const int xmin = bounds[2 * xx], cnt = bounds[2 * xx + 1];
+        const int* k = kk + xx * ksize;
+        int ss = 1 << (PRECISION_BITS - 1);
+        for (int x = 0; x < cnt; x++) ss += (int)smem[(xmin + x) * 3 + c] * k[x];
+        out[o] = clip8(ss);
+    }
+}
+
+template <typename OutT>
+__device__ inline OutT cast_out(float v);
+template <> __device__ inline float cast_out<float>(float v) { return v; }
+template <> __device__ inline __half cast_out<__half>(float v) { return __float2half_rn(v); }
+template <> __device__ inline __hip_bfloat16 cast_out<__hip_bfloat16>(float v) { return __float2bfloat16(v); }
+
+struct Norm3 { float mean[3]; float std[3]; };
+
+// vertical pass + ToTensor + Normalize: [n][H][O][3] u8 -> [n][3][O][O] OutT
+template <typename OutT>
+__global__ __launch_bounds__(256) void resample_v_norm_kernel(const unsigned char* __restrict__ src, int H, int O,
+                                                              const int* __restrict__ bounds,
+                                                              const int* __restrict__ kk, int ksize, Norm3 nrm,
+                                                              OutT* __restrict__ dst) {
+    const int yy = blockIdx.x, n = blockIdx.y;
+    const int ymin = bounds[2 * yy], cnt = bounds[2 * yy + 1];
+    const int* k = kk + yy * ksize;
+    const unsigned char* img = src + (size_t)n * H * O * 3;
+    for (int o = threadIdx.x; o < 3 * O; o += blockDim.x) {
+        const int c = o / O, xx = o - c * O;  // channel-major so that the CHW stores are coalesced
+        int ss = 1 << (PRECISION_BITS - 1);
+        for (int y = 0; y < cnt; y++) ss += (int)img[((size_t)(ymin + y) * O + xx) * 3 + c] * k[y];
+        const float px = (float)clip8(ss);
+        // ToTensor: u8 -> f32 / 255 ; Normalize: (x - mean) / std, all in f32
+        const float v = __fdiv_rn(__fsub_rn(__fdiv_rn(px, 255.0f), nrm.mean[c]), nrm.std[c]);
+        dst[(((size_t)n * 3 + c) * O + yy) * O + xx] = cast_out<OutT>(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ ITC head
+// One workgroup per image, one wavefront per query (round-robin): cos_q = <p_q, t> / max(|p_q|, 1e-12); out = max_q.
+__global__ __launch_bounds__(512) void itc_head_kernel(const float* __restrict__ proj, int NQ, int P,
+                                                       const float* __restrict__ text, float* __restrict__ out) {
+    __shared__ float cos_q[64];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const float* t = text + (size_t)b * P;
+    for (int q = wave; q < NQ; q += n_waves) {
+        const float* p = proj + ((size_t)b * NQ + q) * P;
+        float n2 = 0.0f, dt = 0.0f;
+        for (int j = lane; j < P; j += 64) {
+            const float v = p[j];
+            n2 = fmaf(v, v, n2);
+            dt = fmaf(v, t[j], dt);
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            n2 += __shfl_down(n2, off, 64);
+            dt += __shfl_down(dt, off, 64);
+        }
+        if (lane == 0) cos_q[q] = dt / fmaxf(sqrtf(n2), 1e-12f);  // F.normalize eps
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float c = lane < NQ ? cos_q[lane] : -__builtin_huge_valf();
+        for (int off = 32; off > 0; off >>= 1) c = fmaxf(c, __shfl_down(c, off, 64));
+        if (lane == 0) out[b] = c;
+    }
+}
+
+}  // namespace vlfm
+
+using namespace vlfm;
+
+// Pillow's precompute_coeffs + normalize_coeffs_8bpc for the bicubic filter (support 2, a = -0.5), box = whole axis.
+extern "C" int vlfm_resample_coeffs_host(int in_size, int out_size, int32_t* h_bounds, int32_t* h_kk, int kk_capacity,
+                                         int* ksize_out) {
+    if (in_size <= 0 || out_size <= 0 || !h_bounds || !h_kk || !ksize_out)
+        return fail(VLFM_ERR_INVALID, "resample_coeffs_host: bad argument");
+    auto bicubic = [](double x) {
+        const double a = -0.5;
+        if (x < 0.0) x = -x;
+        if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+        if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+        return 0.0;
+    };
+    const float in0 = 0.0f, in1 = (float)in_size;
+    double scale = (double)(in1 - in0) / out_size, filterscale = scale;
+    if (filterscale < 1.0) filterscale = 1.0;
+    const double support = 2.0 * filterscale;
+    const int ksize = (int)std::ceil(support) * 2 + 1;
+    *ksize_out = ksize;
+    if ((long)out_size * ksize > kk_capacity) return fail(VLFM_ERR_CAPACITY, "resample_coeffs_host: kk capacity");
+    std::vector<double> k(ksize);
+    for (int xx = 0; xx < out_size; xx++) {
+        const double center = in0 + (xx + 0.5) * scale;
+        double ww = 0.0;
+        const double ss = 1.0 / filterscale;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        for (int x = 0; x < xmax; x++) {
+            const double w = bicubic((x + xmin - center + 0.5) * ss);
+            k[x] = w;
+            ww += w;
+        }
+        for (int x = 0; x < xmax; x++)
+            if (ww != 0.0) k[x] /= ww;
+        for (int x = xmax; x < ksize; x++) k[x] = 0;
+        h_bounds[2 * xx] = xmin;
+        h_bounds[2 * xx + 1] = xmax;
+        for (int x = 0; x < ksize; x++) {
+            const double v = k[x];
+            h_kk[(size_t)xx * ksize + x] = v < 0 ? (int)(-0.5 + v * (1 << PRECISION_BITS)) : (int)(0.5 + v * (1 << PRECISION_BITS));
+        }
+    }
+    return VLFM_OK;
+}
+
+extern "C" int vlfm_preprocess_rgb_batched(const uint8_t* d_rgb, int n, int height, int width, int out_size,
+                                           const int32_t* d_hbounds, const int32_t* d_hk, int hksize,
+                                           const int32_t* d_vbounds, const int32_t* d_vk, int vksize,
+                                           const float* h_mean3, const float* h_std3, uint8_t* d_tmp, void* d_out,
+                                           int out_dtype, void* stream) {
+    if (n == 0) return VLFM_OK;
+    if (!d_rgb || !d_hbounds || !d_hk || !d_vbounds || !d_vk || !h_mean3 || !h_std3 || !d_tmp || !d_out || n < 0 ||
+        height <= 0 || width <= 0 || out_size <= 0)
+        return fail(VLFM_ERR_INVALID, "preprocess_rgb_batched: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = ((size_t)width * 3 + 15) / 16 * 16;
+    {
+        VLFM_TIMED("resample_h_kernel", s);
+    hipLaunchKernelGGL(resample_h_kernel, dim3(height, n), dim3(256), lds, s, d_rgb, height, width, out_size,
+                       d_hbounds, d_hk, hksize, d_tmp);
+    }
+    int rc = check_launch("resample_h_kernel");
+    if (rc != VLFM_OK) return rc;
+    Norm3 nrm;
+    for (int c = 0; c < 3; c++) { nrm.mean[c] = h_mean3[c]; nrm.std[c] = h_std3[c]; }
+    VLFM_TIMED("resample_v_norm_kernel", s);
+    if (out_dtype == 0)
+        hipLaunchKernelGGL(resample_v_norm_kernel<float>, dim3(out_size, n), dim3(256), 0, s, d_tmp, height, out_size,
+                           d_vbounds, d_vk, vksize, nrm, (float*)d_out);
+    else if (out_dtype == 1)
+        hipLaunchKernelGGL(resample_v_norm_kernel<__half>, dim3(out_size, n), dim3(256), 0, s, d_tmp, height,
+                           out_size, d_vbounds, d_vk, vksize, nrm, (__half*)d_out);
+    else if (out_dtype == 2)
+        hipLaunchKernelGGL(resample_v_norm_kernel<__hip_bfloat16>, dim3(out_size, n), dim3(256), 0, s, d_tmp, height,
+                           out_size, d_vbounds, d_vk, vksize, nrm, (__hip_bfloat16*)d_out);
+    else
+        return fail(VLFM_ERR_INVALID, "preprocess_rgb_batched: out_dtype must be 0 (f32), 1 (f16) or 2 (bf16)");
+    return check_launch("resample_v_norm_kernel");
+}
+
+extern "C" int vlfm_itc_head_batched(const float* d_proj, int batch, int n_query, int proj_dim, const float* d_text,
+                                     float* d_out, void* stream) {
+    if (batch == 0) return VLFM_OK;
+    if (!d_proj || !d_text || !d_out || batch < 0 || n_query <= 0 || n_query > 64 || proj_dim <= 0)
+        return fail(VLFM_ERR_INVALID, "itc_head_batched: bad argument (n_query <= 64)");
+    VLFM_TIMED("itc_head_kernel", stream);
+    hipLaunchKernelGGL(itc_head_kernel, dim3(batch), dim3(512), 0, (hipStream_t)stream, d_proj, n_query, proj_dim,
+                       d_text, d_out);
+    return check_launch("itc_head_kernel");
+}

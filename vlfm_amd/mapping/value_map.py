@@ -37,6 +37,37 @@ def _bytes_to_device(buf, device):
     return host.to(device, non_blocking=False)
 
 
+class UploadRing:
+    """Small per-step parameter blocks (poses, ingest parameters) go to HBM through a ring of pinned host buffers with
+    asynchronous copies on the compute stream, so a step never blocks on a pageable H2D copy.  A slot is reused only
+    after the copy that last read it has completed (event check)."""
+
+    def __init__(self, device, nbytes: int, slots: int = 4) -> None:
+        import torch
+
+        self.device, self.nbytes = device, nbytes
+        self.host = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(slots)]
+        self.dev = [torch.empty(nbytes, dtype=torch.uint8, device=device) for _ in range(slots)]
+        self.done = [None] * slots
+        self.k = 0
+
+    def upload(self, buf):
+        import torch
+
+        raw = bytes(buf)
+        assert len(raw) <= self.nbytes
+        i = self.k
+        self.k = (self.k + 1) % len(self.host)
+        if self.done[i] is not None:
+            self.done[i].synchronize()
+        self.host[i][: len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+        self.dev[i][: len(raw)].copy_(self.host[i][: len(raw)], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.done[i] = ev
+        return self.dev[i]
+
+
 class _ConeTemplates:
     """Per-device cache of masked confidence templates, keyed like ValueMap._confidence_masks (value_map.py:37)."""
 
@@ -153,6 +184,7 @@ class ValueMapBatch:
         self.explored = explored
         self._colmax = None
         self._status = None
+        self._ring = None
 
     # ------------------------------------------------------------------------------------------ helpers
     def reset(self, env_ids: Optional[Sequence[int]] = None) -> None:
@@ -168,19 +200,31 @@ class ValueMapBatch:
         import torch
 
         if self._colmax is None or self._colmax.shape[0] < n or self._colmax.shape[1] != width:
-            self._colmax = torch.empty((max(n, self.n_envs), width), dtype=torch.float32, device=self.device)
+            # order-preserving u32 keys, zero = "-inf"; produced by depth ingest, consumed + re-zeroed by the update
+            self._colmax = torch.zeros((max(n, self.n_envs), width), dtype=torch.int32, device=self.device)
             self._status = torch.zeros(max(n, self.n_envs), dtype=torch.int32, device=self.device)
+            self._ring = UploadRing(self.device, max(n, self.n_envs) * 256)
+            self._vertices = torch.empty((max(n, self.n_envs), width + 2, 2), dtype=torch.int32, device=self.device)
         return self._colmax, self._status
 
+    def _vertex_scratch(self, n: int, width: int):
+        import torch
+
+        v = getattr(self, "_vertices", None)
+        if v is None or v.shape[0] < n or v.shape[1] != width + 2:
+            self._vertices = torch.empty((max(n, self.n_envs), width + 2, 2), dtype=torch.int32, device=self.device)
+        return self._vertices
+
     def column_max(self, depth) -> Any:
-        """np.max(depth, axis=0) for a [n,H,W] device tensor via the depth-ingest kernel (no obstacle scatter)."""
+        """np.max(depth, axis=0) for a [n,H,W] device tensor via the depth-ingest kernel (no obstacle scatter).
+        Returns the column-max KEY buffer that update() consumes."""
         import torch
 
         n, H, W = depth.shape
         colmax, status = self._scratch(n, W)
         prm = (_lib.IngestParams * n)()
-        d_prm = _bytes_to_device(prm, self.device)
         with torch.cuda.device(self.device):
+            d_prm = self._ring.upload(prm)
             _lib.check(_lib.lib().vlfm_depth_ingest_batched(depth.data_ptr(), n, H, W, d_prm.data_ptr(),
                                                            colmax.data_ptr(), None, self.size, self.pixels_per_meter,
                                                            status.data_ptr(), _stream_ptr()), "depth_ingest")
@@ -196,8 +240,12 @@ class ValueMapBatch:
         """
         import torch
 
-        values = np.ascontiguousarray(np.asarray(values, np.float64).reshape(-1, self.channels))
-        n = values.shape[0]
+        if torch.is_tensor(values):  # device-resident scores straight from the ITC head: no host round trip
+            d_vals = values.to(device=self.device, dtype=torch.float64).reshape(-1, self.channels).contiguous()
+        else:
+            d_vals = torch.from_numpy(
+                np.ascontiguousarray(np.asarray(values, np.float64).reshape(-1, self.channels))).to(self.device)
+        n = d_vals.shape[0]
         if colmax is None:
             if not torch.is_tensor(depth):
                 depth = torch.from_numpy(np.ascontiguousarray(depth, np.float32)).to(self.device)
@@ -208,8 +256,10 @@ class ValueMapBatch:
         d_tmpl, T = _TEMPLATES.template(self.device, fov, max_depth, self.pixels_per_meter, self._min_confidence)
         d_tan = _TEMPLATES.tan_table(self.device, fov, W)
         pose = pose_params(tf_camera_to_episodic, env_ids, self.size, self.pixels_per_meter, T)
-        d_pose = _bytes_to_device(pose, self.device)
-        d_vals = torch.from_numpy(values).to(self.device)
+        if getattr(self, "_ring", None) is None:
+            self._ring = UploadRing(self.device, max(n, self.n_envs) * 256)
+        with torch.cuda.device(self.device):
+            d_pose = self._ring.upload(pose)
         explored_ptr = None
         with torch.cuda.device(self.device):
             L = _lib.lib()
@@ -229,7 +279,8 @@ class ValueMapBatch:
                                                        self.channels, self.pixels_per_meter, float(min_depth),
                                                        float(max_depth), int(self.use_max_confidence),
                                                        _lib.FUSION_TYPES[self.fusion_type], explored_ptr,
-                                                       _stream_ptr()), "value_map_update")
+                                                       self._vertex_scratch(n, W).data_ptr(), _stream_ptr()),
+                       "value_map_update")
 
     # ------------------------------------------------------------------------------------------ frontier scoring
     def waypoint_values(self, waypoints_xy: np.ndarray, env_of_waypoint: Sequence[int], radius: float) -> np.ndarray:

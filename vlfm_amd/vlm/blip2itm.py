@@ -1,0 +1,386 @@
+"""vlfm.vlm.blip2itm, in-process and batched (reference: /root/reference/vlfm/vlm/blip2itm.py).
+
+The reference runs LAVIS ``blip2_image_text_matching``/``pretrain`` behind a Flask server and calls
+``model({"image","text_input"}, match_head="itc")`` one frame at a time (blip2itm.py:37-54); the client ships a
+JPEG over HTTP (blip2itm.py:57-64, server_wrapper.py:71-164).  Here the same ITC graph lives in the
+policy process and is batched across environments:
+
+    u8 HWC frames --[HIP: PIL-exact bicubic 224x224 + CLIP normalise]--> f16 CHW
+      --> EVA ViT-g/14 (39 blocks, PyTorch-ROCm GEMMs + SDPA, fp16) --> LayerNorm
+      --> Q-Former query branch (12 BERT layers, 32 queries, cross-attention every 2nd layer, fp32)
+      --[HIP: vision_proj 768->256, L2 normalise, dot with the cached text feature, max over 32 queries]--> cosine
+
+The text branch runs once per distinct prompt and is cached (the prompt only changes with the target object,
+itm_policy.py:197).  Parameter names follow Hugging Face ``Blip2ForImageTextRetrieval`` so a
+``Salesforce/blip2-itm-vit-g`` state dict loads directly; offline (no weights, no tokenizer vocabulary) the model is
+randomly initialised and prompts are hashed into token ids -- throughput-faithful, not semantically meaningful.
+"""
+from __future__ import annotations
+
+import hashlib
+import math
+import os
+import re
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+@dataclass
+class Blip2ITCConfig:
+    # vision tower (EVA-CLIP ViT-g/14 as shipped with BLIP-2: 39 of 40 blocks)
+    image_size: int = 224
+    patch_size: int = 14
+    v_hidden: int = 1408
+    v_layers: int = 39
+    v_heads: int = 16
+    v_mlp: int = 6144
+    v_ln_eps: float = 1e-6
+    # Q-Former (BERT-base geometry)
+    q_hidden: int = 768
+    q_layers: int = 12
+    q_heads: int = 12
+    q_mlp: int = 3072
+    q_ln_eps: float = 1e-12
+    cross_attention_frequency: int = 2
+    vocab_size: int = 30523
+    max_position_embeddings: int = 512
+    num_query_tokens: int = 32
+    proj_dim: int = 256
+    max_txt_len: int = 32
+
+    @staticmethod
+    def tiny() -> "Blip2ITCConfig":
+        """Small geometry for CPU parity tests."""
+        return Blip2ITCConfig(image_size=28, patch_size=14, v_hidden=32, v_layers=2, v_heads=4, v_mlp=64,
+                              q_hidden=24, q_layers=4, q_heads=4, q_mlp=48, vocab_size=97,
+                              max_position_embeddings=40, num_query_tokens=5, proj_dim=8)
+
+
+class _VitBlock(nn.Module):
+    def __init__(self, c: Blip2ITCConfig):
+        super().__init__()
+        self.heads = c.v_heads
+        self.layer_norm1 = nn.LayerNorm(c.v_hidden, eps=c.v_ln_eps)
+        self.qkv = nn.Linear(c.v_hidden, 3 * c.v_hidden, bias=True)  # bias = [q_bias, 0, v_bias]
+        self.projection = nn.Linear(c.v_hidden, c.v_hidden)
+        self.layer_norm2 = nn.LayerNorm(c.v_hidden, eps=c.v_ln_eps)
+        self.fc1 = nn.Linear(c.v_hidden, c.v_mlp)
+        self.fc2 = nn.Linear(c.v_mlp, c.v_hidden)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        b, n, d = x.shape
+        qkv = self.qkv(self.layer_norm1(x)).view(b, n, 3, self.heads, d // self.heads).permute(2, 0, 3, 1, 4)
+        a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])
+        x = x + self.projection(a.transpose(1, 2).reshape(b, n, d))
+        return x + self.fc2(F.gelu(self.fc1(self.layer_norm2(x))))
+
+
+class _BertAttention(nn.Module):
+    def __init__(self, hidden: int, kv_hidden: int, heads: int, eps: float):
+        super().__init__()
+        self.heads = heads
+        self.query = nn.Linear(hidden, hidden)
+        self.key = nn.Linear(kv_hidden, hidden)
+        self.value = nn.Linear(kv_hidden, hidden)
+        self.dense = nn.Linear(hidden, hidden)
+        self.LayerNorm = nn.LayerNorm(hidden, eps=eps)
+
+    def forward(self, x: torch.Tensor, kv: Optional[torch.Tensor] = None,
+                mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        src = x if kv is None else kv
+        b, n, d = x.shape
+        h = self.heads
+        q = self.query(x).view(b, n, h, d // h).transpose(1, 2)
+        k = self.key(src).view(b, src.shape[1], h, d // h).transpose(1, 2)
+        v = self.value(src).view(b, src.shape[1], h, d // h).transpose(1, 2)
+        a = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
+        return self.LayerNorm(self.dense(a.transpose(1, 2).reshape(b, n, d)) + x)  # post-LN residual (BERT)
+
+
+class _BertFFN(nn.Module):
+    def __init__(self, hidden: int, inter: int, eps: float):
+        super().__init__()
+        self.up = nn.Linear(hidden, inter)
+        self.down = nn.Linear(inter, hidden)
+        self.LayerNorm = nn.LayerNorm(hidden, eps=eps)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.LayerNorm(self.down(F.gelu(self.up(x))) + x)
+
+
+class _QFormerLayer(nn.Module):
+    def __init__(self, c: Blip2ITCConfig, idx: int):
+        super().__init__()
+        self.attention = _BertAttention(c.q_hidden, c.q_hidden, c.q_heads, c.q_ln_eps)
+        self.crossattention = (_BertAttention(c.q_hidden, c.v_hidden, c.q_heads, c.q_ln_eps)
+                               if idx % c.cross_attention_frequency == 0 else None)
+        self.ffn_text = _BertFFN(c.q_hidden, c.q_mlp, c.q_ln_eps)   # HF: intermediate / output
+        self.ffn_query = _BertFFN(c.q_hidden, c.q_mlp, c.q_ln_eps)  # HF: intermediate_query / output_query
+
+
+class Blip2ITCModel(nn.Module):
+    """The ITC graph of BLIP-2 (image branch + text branch); weights interchangeable with HF's port."""
+
+    def __init__(self, cfg: Blip2ITCConfig):
+        super().__init__()
+        c = self.cfg = cfg
+        n_patches = (c.image_size // c.patch_size) ** 2
+        self.class_embedding = nn.Parameter(torch.zeros(1, 1, c.v_hidden))
+        self.position_embedding = nn.Parameter(torch.zeros(1, n_patches + 1, c.v_hidden))
+        self.patch_embedding = nn.Conv2d(3, c.v_hidden, c.patch_size, c.patch_size)
+        self.blocks = nn.ModuleList([_VitBlock(c) for _ in range(c.v_layers)])
+        self.post_layernorm = nn.LayerNorm(c.v_hidden, eps=c.v_ln_eps)
+        self.query_tokens = nn.Parameter(torch.zeros(1, c.num_query_tokens, c.q_hidden))
+        self.word_embeddings = nn.Embedding(c.vocab_size, c.q_hidden)
+        self.position_embeddings = nn.Embedding(c.max_position_embeddings, c.q_hidden)
+        self.q_layernorm = nn.LayerNorm(c.q_hidden, eps=c.q_ln_eps)
+        self.q_layers = nn.ModuleList([_QFormerLayer(c, i) for i in range(c.q_layers)])
+        self.vision_projection = nn.Linear(c.q_hidden, c.proj_dim)
+        self.text_projection = nn.Linear(c.q_hidden, c.proj_dim)
+
+    # ---- weights ---------------------------------------------------------------------------------------------
+    def init_random(self, seed: int = 0) -> "Blip2ITCModel":
+        dev = self.query_tokens.device
+        g = torch.Generator(device=dev).manual_seed(seed)
+        with torch.no_grad():
+            for p in self.parameters():
+                if p.dim() > 1:
+                    p.copy_(torch.randn(p.shape, generator=g, device=dev) * 0.02)
+                else:
+                    p.zero_()
+            for m in self.modules():
+                if isinstance(m, nn.LayerNorm):
+                    m.weight.fill_(1.0)
+        return self
+
+    def vision_dtype(self) -> torch.dtype:
+        return self.patch_embedding.weight.dtype
+
+    def set_precision(self, vision_dtype: torch.dtype = torch.float16) -> "Blip2ITCModel":
+        """LAVIS keeps the ViT in fp16 and the Q-Former in fp32."""
+        for m in (self.patch_embedding, self.blocks, self.post_layernorm):
+            m.to(vision_dtype)
+        self.class_embedding.data = self.class_embedding.data.to(vision_dtype)
+        self.position_embedding.data = self.position_embedding.data.to(vision_dtype)
+        return self
+
+    def load_hf_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        """Load a ``Blip2ForImageTextRetrieval`` state dict (e.g. Salesforce/blip2-itm-vit-g)."""
+        own = dict(self.named_parameters())
+
+        def put(name: str, src: str) -> None:
+            with torch.no_grad():
+                own[name].copy_(sd[src].to(own[name].dtype).reshape(own[name].shape))
+
+        put("class_embedding", "vision_model.embeddings.class_embedding")
+        put("position_embedding", "vision_model.embeddings.position_embedding")
+        put("patch_embedding.weight", "vision_model.embeddings.patch_embedding.weight")
+        put("patch_embedding.bias", "vision_model.embeddings.patch_embedding.bias")
+        for i in range(self.cfg.v_layers):
+            s, d = f"vision_model.encoder.layers.{i}.", f"blocks.{i}."
+            for a, b in [("layer_norm1", "layer_norm1"), ("layer_norm2", "layer_norm2"),
+                         ("self_attn.qkv", "qkv"), ("self_attn.projection", "projection"),
+                         ("mlp.fc1", "fc1"), ("mlp.fc2", "fc2")]:
+                put(d + b + ".weight", s + a + ".weight")
+                put(d + b + ".bias", s + a + ".bias")
+        put("post_layernorm.weight", "vision_model.post_layernorm.weight")
+        put("post_layernorm.bias", "vision_model.post_layernorm.bias")
+        put("query_tokens", "query_tokens")
+        put("word_embeddings.weight", "embeddings.word_embeddings.weight")
+        put("position_embeddings.weight", "embeddings.position_embeddings.weight")
+        put("q_layernorm.weight", "qformer.layernorm.weight")
+        put("q_layernorm.bias", "qformer.layernorm.bias")
+        for i, layer in enumerate(self.q_layers):
+            s, d = f"qformer.encoder.layer.{i}.", f"q_layers.{i}."
+            atts = [("attention", "attention")] + ([("crossattention", "crossattention")]
+                                                   if layer.crossattention is not None else [])
+            for a, b in atts:
+                for hf, mine in [("attention.query", "query"), ("attention.key", "key"), ("attention.value", "value"),
+                                 ("output.dense", "dense"), ("output.LayerNorm", "LayerNorm")]:
+                    put(f"{d}{b}.{mine}.weight", f"{s}{a}.{hf}.weight")
+                    put(f"{d}{b}.{mine}.bias", f"{s}{a}.{hf}.bias")
+            for hf_i, hf_o, mine in [("intermediate", "output", "ffn_text"),
+                                     ("intermediate_query", "output_query", "ffn_query")]:
+                put(f"{d}{mine}.up.weight", f"{s}{hf_i}.dense.weight")
+                put(f"{d}{mine}.up.bias", f"{s}{hf_i}.dense.bias")
+                put(f"{d}{mine}.down.weight", f"{s}{hf_o}.dense.weight")
+                put(f"{d}{mine}.down.bias", f"{s}{hf_o}.dense.bias")
+                put(f"{d}{mine}.LayerNorm.weight", f"{s}{hf_o}.LayerNorm.weight")
+                put(f"{d}{mine}.LayerNorm.bias", f"{s}{hf_o}.LayerNorm.bias")
+        for n in ("vision_projection", "text_projection"):
+            put(n + ".weight", n + ".weight")
+            put(n + ".bias", n + ".bias")
+
+    # ---- branches --------------------------------------------------------------------------------------------
+    def vision_tokens(self, pixel_values: torch.Tensor) -> torch.Tensor:
+        """[B,3,224,224] -> LayerNorm'd ViT tokens [B,257,1408]."""
+        x = self.patch_embedding(pixel_values.to(self.vision_dtype())).flatten(2).transpose(1, 2)
+        x = torch.cat([self.class_embedding.expand(x.shape[0], -1, -1), x], dim=1) + self.position_embedding
+        for blk in self.blocks:
+            x = blk(x)
+        return self.post_layernorm(x)
+
+    def query_features(self, image_tokens: torch.Tensor) -> torch.Tensor:
+        """Q-Former query branch: [B,257,1408] -> [B,32,768] (fp32)."""
+        enc = image_tokens.to(self.q_layernorm.weight.dtype)
+        h = self.q_layernorm(self.query_tokens).expand(enc.shape[0], -1, -1)
+        for layer in self.q_layers:
+            h = layer.attention(h)
+            if layer.crossattention is not None:
+                h = layer.crossattention(h, kv=enc)
+            h = layer.ffn_query(h)
+        return h
+
+    def text_feature(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Q-Former text branch: ids [B,L] -> L2-normalised text_proj(CLS) [B,256]."""
+        pos = torch.arange(input_ids.shape[1], device=input_ids.device)[None]
+        h = self.q_layernorm(self.word_embeddings(input_ids) + self.position_embeddings(pos))
+        mask = None
+        if attention_mask is not None:
+            mask = (attention_mask[:, None, None, :] > 0)
+        for layer in self.q_layers:
+            h = layer.ffn_text(layer.attention(h, mask=mask))
+        return F.normalize(self.text_projection(h[:, 0, :]), dim=-1)
+
+    def itc_reference_head(self, query_feats: torch.Tensor, text_feat: torch.Tensor) -> torch.Tensor:
+        """Plain-PyTorch fp32 reference of the ITC head (the HIP kernel in csrc/vlm_ops.hip is checked against it):
+        max over queries of <normalise(vision_proj(q)), text>."""
+        img = F.normalize(self.vision_projection(query_feats.float()), dim=-1)
+        return torch.einsum("bqd,bd->bq", img, text_feat.float().expand(img.shape[0], -1)).max(dim=1).values
+
+
+# ------------------------------------------------------------------------------------------------------ text side
+_CAPTION_STRIP = re.compile(r"([.!\"()*#:;~])")
+
+
+def blip_caption(text: str, max_words: int = 50) -> str:
+    """LAVIS ``blip_caption`` text processor [ext]: lower-case, strip punctuation, collapse spaces, <= 50 words."""
+    t = _CAPTION_STRIP.sub(" ", text.lower())
+    t = re.sub(r"\s{2,}", " ", t).rstrip("\n").strip(" ")
+    words = t.split(" ")
+    return " ".join(words[:max_words]) if len(words) > max_words else t
+
+
+class HashTokenizer:
+    """Offline stand-in for the BERT WordPiece tokenizer (no vocabulary file in this environment): [CLS] + one
+    deterministic id per word + [SEP].  Only used with randomly initialised weights."""
+
+    def __init__(self, vocab_size: int, max_len: int):
+        self.vocab_size, self.max_len = vocab_size, max_len
+
+    def __call__(self, text: str) -> List[int]:
+        ids = [101 % self.vocab_size]
+        for w in text.split():
+            hv = int.from_bytes(hashlib.sha1(w.encode()).digest()[:4], "little")
+            ids.append(1000 % self.vocab_size + hv % max(1, self.vocab_size - 1000))
+        ids = ids[: self.max_len - 1] + [102 % self.vocab_size]
+        return ids
+
+
+# ------------------------------------------------------------------------------------------------------ wrappers
+class BLIP2ITM:
+    """Same surface as the reference's ``BLIP2ITM`` (blip2itm.py:17-54) plus a batched entry point."""
+
+    def __init__(self, name: str = "blip2_image_text_matching", model_type: str = "pretrain", device=None,
+                 model_dir: Optional[str] = None, config: Optional[Blip2ITCConfig] = None,
+                 vision_dtype: torch.dtype = torch.float16, seed: int = 0) -> None:
+        from ..mapping.base_map import require_gpu
+        from .. import _lib
+
+        self.device = require_gpu(device)
+        _lib.lib()
+        self.cfg = config or Blip2ITCConfig()
+        self.tokenizer = None
+        model_dir = model_dir or os.environ.get("BLIP2ITM_MODEL_DIR")
+        if model_dir:
+            self.model = Blip2ITCModel(self.cfg)
+            self._load_pretrained(model_dir)
+            self.weights = f"pretrained:{model_dir}"
+        else:
+            with torch.device(self.device):  # allocate and initialise the 1.2 B parameters directly in HBM
+                self.model = Blip2ITCModel(self.cfg)
+            self.model.init_random(seed)
+            self.weights = "random-init"
+        if self.tokenizer is None:
+            self.tokenizer = HashTokenizer(self.cfg.vocab_size, self.cfg.max_txt_len)
+        self.model.eval().to(self.device).set_precision(vision_dtype)
+        self._text_cache: Dict[str, torch.Tensor] = {}
+        self._proj_t = None
+
+    def _load_pretrained(self, model_dir: str) -> None:
+        from safetensors.torch import load_file
+
+        sd: Dict[str, torch.Tensor] = {}
+        for f in sorted(os.listdir(model_dir)):
+            if f.endswith(".safetensors"):
+                sd.update(load_file(os.path.join(model_dir, f)))
+        self.model.load_hf_state_dict(sd)
+        from transformers import BertTokenizer
+
+        tok = BertTokenizer.from_pretrained(model_dir)
+        self.tokenizer = lambda t: tok(t, truncation=True, max_length=self.cfg.max_txt_len)["input_ids"]
+
+    # -- text (cached) ----------------------------------------------------------------------------------------
+    @torch.inference_mode()
+    def text_feature(self, txt: str) -> torch.Tensor:
+        if txt not in self._text_cache:
+            ids = torch.tensor([self.tokenizer(blip_caption(txt))], device=self.device)
+            self._text_cache[txt] = self.model.text_feature(ids)[0].float().contiguous()
+        return self._text_cache[txt]
+
+    # -- images -----------------------------------------------------------------------------------------------
+    @torch.inference_mode()
+    def cosine_batch(self, images_u8: torch.Tensor, txts: Sequence[str]) -> torch.Tensor:
+        """images_u8: [B,H,W,3] uint8 RGB on device; txts: one prompt per image (or a single shared prompt).
+        Returns [B] fp32 cosines on device (no host sync)."""
+        from . import ops
+
+        B = images_u8.shape[0]
+        pix = ops.preprocess_rgb(images_u8, self.cfg.image_size, self.model.vision_dtype())
+        q = self.model.query_features(self.model.vision_tokens(pix)).float().contiguous()
+        if len(txts) == 1:
+            text = self.text_feature(txts[0])[None].expand(B, -1).contiguous()
+        else:
+            assert len(txts) == B
+            text = torch.stack([self.text_feature(t) for t in txts]).contiguous()
+        if self._proj_t is None:
+            self._proj_t = (self.model.vision_projection.weight.float().t().contiguous(),
+                            self.model.vision_projection.bias.float().contiguous())
+        return ops.itc_head(q, self._proj_t[0], self._proj_t[1], text)
+
+    def cosine(self, image: np.ndarray, txt: str) -> float:
+        """blip2itm.py:37-54: one RGB frame (H,W,3) u8 + prompt -> Python float."""
+        img = torch.from_numpy(np.ascontiguousarray(image)).to(self.device)[None]
+        return float(self.cosine_batch(img, [txt])[0].item())
+
+
+class BLIP2ITMClient:
+    """Drop-in for the reference client (blip2itm.py:57-64): same constructor and ``cosine`` signature, but the
+    model lives in this process (the ``port`` argument is accepted and ignored; there is no HTTP hop, no JPEG
+    round trip -- pass ``emulate_jpeg=True`` to reproduce the reference's q90 transport for A/B fidelity checks)."""
+
+    _shared: Dict[str, BLIP2ITM] = {}
+
+    def __init__(self, port: int = 12182, device=None, emulate_jpeg: bool = False, **model_kwargs) -> None:
+        key = str(device)
+        if key not in BLIP2ITMClient._shared:
+            BLIP2ITMClient._shared[key] = BLIP2ITM(device=device, **model_kwargs)
+        self._model = BLIP2ITMClient._shared[key]
+        self._emulate_jpeg = emulate_jpeg
+        self.url = f"inprocess://blip2itm (port {port} ignored)"
+
+    def cosine(self, image: np.ndarray, txt: str) -> float:
+        if self._emulate_jpeg:
+            import io
+
+            from PIL import Image
+
+            buf = io.BytesIO()
+            Image.fromarray(image).save(buf, format="JPEG", quality=90)  # server_wrapper.py:57-61
+            image = np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGB"))
+        return self._model.cosine(image, txt)

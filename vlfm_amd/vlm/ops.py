@@ -1,0 +1,78 @@
+"""Python wrappers of the VLM-side HIP kernels (csrc/vlm_ops.hip)."""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+# LAVIS blip2 eval image processor = CLIP statistics
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+_DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+_coeff_cache: Dict[Tuple[str, int, int], Tuple[torch.Tensor, torch.Tensor, int]] = {}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def resample_coeffs(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarray, int]:
+    """Pillow bicubic taps for one axis (host): bounds [out,2] int32, kk [out,ksize] int32, ksize."""
+    bounds = np.zeros((out_size, 2), np.int32)
+    cap = out_size * (2 * int(np.ceil(2.0 * max(1.0, in_size / out_size))) + 1)
+    kk = np.zeros(cap, np.int32)
+    ks = ctypes.c_int(0)
+    _lib.check(_lib.lib().vlfm_resample_coeffs_host(in_size, out_size, bounds.ctypes.data, kk.ctypes.data, cap,
+                                                    ctypes.byref(ks)), "resample_coeffs_host")
+    return bounds, kk[: out_size * ks.value].reshape(out_size, ks.value), ks.value
+
+
+def _device_coeffs(device, in_size: int, out_size: int):
+    key = (str(device), in_size, out_size)
+    if key not in _coeff_cache:
+        b, k, ks = resample_coeffs(in_size, out_size)
+        _coeff_cache[key] = (torch.from_numpy(b).to(device), torch.from_numpy(np.ascontiguousarray(k)).to(device), ks)
+    return _coeff_cache[key]
+
+
+def preprocess_rgb(images_u8: torch.Tensor, out_size: int = 224, dtype: torch.dtype = torch.float16,
+                   mean=CLIP_MEAN, std=CLIP_STD) -> torch.Tensor:
+    """[n,H,W,3] uint8 (device) -> [n,3,out,out] normalised, via the PIL-exact bicubic kernels."""
+    assert images_u8.is_cuda and images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.shape[-1] == 3
+    images_u8 = images_u8.contiguous()
+    n, H, W, _ = images_u8.shape
+    dev = images_u8.device
+    hb, hk, hks = _device_coeffs(dev, W, out_size)
+    vb, vk, vks = _device_coeffs(dev, H, out_size)
+    tmp = torch.empty((n, H, out_size, 3), dtype=torch.uint8, device=dev)
+    out = torch.empty((n, 3, out_size, out_size), dtype=dtype, device=dev)
+    m = (ctypes.c_float * 3)(*mean)
+    s = (ctypes.c_float * 3)(*std)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().vlfm_preprocess_rgb_batched(images_u8.data_ptr(), n, H, W, out_size, hb.data_ptr(),
+                                                         hk.data_ptr(), hks, vb.data_ptr(), vk.data_ptr(), vks,
+                                                         ctypes.addressof(m), ctypes.addressof(s), tmp.data_ptr(),
+                                                         out.data_ptr(), _DTYPE_CODE[dtype], _stream()),
+                   "preprocess_rgb")
+    return out
+
+
+def itc_head(query_feats: torch.Tensor, proj_t: torch.Tensor, proj_bias: torch.Tensor,
+             text_feats: torch.Tensor) -> torch.Tensor:
+    """query_feats [B,NQ,H] f32, proj_t [H,P] f32, proj_bias [P], text_feats [B,P] -> [B] cosines.
+    The 768->256 projection is one hipBLASLt GEMM over all B*NQ rows; normalise + dot + max is the HIP epilogue."""
+    B, NQ, Hd = query_feats.shape
+    P = proj_t.shape[1]
+    for t in (query_feats, proj_t, proj_bias, text_feats):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+    assert proj_t.shape[0] == Hd and text_feats.shape == (B, P)
+    proj = torch.addmm(proj_bias, query_feats.view(B * NQ, Hd), proj_t)
+    out = torch.empty(B, dtype=torch.float32, device=query_feats.device)
+    with torch.cuda.device(query_feats.device):
+        _lib.check(_lib.lib().vlfm_itc_head_batched(proj.data_ptr(), B, NQ, P, text_feats.data_ptr(), out.data_ptr(),
+                                                   _stream()), "itc_head")
+    return out
