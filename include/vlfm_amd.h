@@ -83,13 +83,13 @@ int vlfm_cone_template_build(const float* d_conf, const int64_t* d_poly_xy, int 
 /* ---------------------------------------------------------------------------------------------
  * Depth ingest: ONE pass over each depth image feeding both maps.
  *   (a) column max  -> d_colmax[n][W]      (np.max(depth, axis=0), value_map.py:234)
- *   (b) obstacle scatter -> d_obstacle[env][S][S] u8 (unproject, transform, height band, rint cell, store 1;
+ *   (b) obstacle scatter -> d_obstacle[env][S][stride] bit-packed (unproject, transform, height band, rint cell, set bit;
  *       obstacle_map.py:92-101 + geometry_utils.py:205-236 + base_map.py:44-46)          [optional]
  * d_depth: [n][H][W] f32 in [0,1].
  * d_colmax_keys [n][W] u32: column maxima as order-preserving keys (0 = -inf).  The buffer must be zero when the call
  * is made: allocate it zeroed once; vlfm_value_map_update_batched consumes the keys and writes the zeros back, so a
- * steady ingest -> update cadence needs no memset.  d_status [n] is sticky: the kernel only ever writes
- * VLFM_ERR_INDEX into it; the caller zeroes it after reading.
+ * steady ingest -> update cadence needs no memset.  d_status [n][2] is sticky: the kernel only ever sets flags in it;
+ * the caller zeroes it after reading.
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
     double tf[12];        /* first three rows of the camera->episodic 4x4 (row-major) */
@@ -100,14 +100,16 @@ typedef struct {
     double fx, fy;
     double min_height, max_height;
     int32_t env;          /* obstacle-map slot */
-    int32_t scatter;      /* 0: column max only (update_obstacles=False) */
+    int32_t scatter;      /* bit 0: scatter obstacles (0 = column max only, update_obstacles=False);
+                             bit 1: every zero depth texel is a filled hole (hole_area_thresh == -1, obstacle_map.py:87-89) */
 } vlfm_ingest_params;     /* 152 bytes */
 
 int vlfm_depth_ingest_batched(const float* d_depth, int n, int height, int width,
                               const vlfm_ingest_params* d_params,
                               uint32_t* d_colmax_keys /* [n][W] or NULL */,
-                              uint8_t* d_obstacle /* [n_envs][S][S] or NULL */, int map_size, int pixels_per_meter,
-                              int32_t* d_status /* [n] out: 0 ok, VLFM_ERR_INDEX if a point fell off the map */,
+                              uint32_t* d_obstacle /* [n_envs][S][ceil(S/32)] bit-packed or NULL */, int map_size, int pixels_per_meter,
+                              int32_t* d_status /* [n][2] sticky: [0] VLFM_ERR_INDEX if a point fell off the map,
+                                                   [1] 1 if a zero depth texel was scattered un-filled */,
                               void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -173,6 +175,65 @@ int vlfm_preprocess_rgb_batched(const uint8_t* d_rgb, int n, int height, int wid
  * max over queries.  NQ <= 64. */
 int vlfm_itc_head_batched(const float* d_proj, int batch, int n_query, int proj_dim,
                           const float* d_text, float* d_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * ObstacleMap planes are bit-packed: 1 bit per cell, row stride ceil(cols/32) u32 words, bit x&31 of word x>>5.
+ * ------------------------------------------------------------------------------------------- */
+int vlfm_bits_pack(const uint8_t* d_src, uint32_t* d_dst, int planes, int rows, int cols, void* stream);
+int vlfm_bits_unpack(const uint32_t* d_src, uint8_t* d_dst, int planes, int rows, int cols, void* stream);
+
+/* cv2.dilate(img, ones((kernel_h, kernel_w))) on packed planes (odd sizes, anchor centre, border ignored)
+ * (obstacle_map.py:105-109,125,159-163). */
+int vlfm_bits_dilate(const uint32_t* d_src, uint32_t* d_dst, int planes, int rows, int cols, int kernel_w,
+                     int kernel_h, void* stream);
+
+/* cv2.findContours(img, RETR_EXTERNAL, method) (obstacle_map.py:128-132) on packed planes, one wavefront per plane.
+ * method 1 = CHAIN_APPROX_NONE, 2 = CHAIN_APPROX_SIMPLE.  Outputs per plane: d_pts [cap_pts][2] (x,y) in DISCOVERY
+ * order (OpenCV returns the reverse), d_starts/d_lens [cap_contours], d_counts [3] = (contours, points, overflow). */
+int vlfm_find_contours_external(const uint32_t* d_img, int planes, int rows, int cols, int method,
+                                uint32_t* d_scratch /* [2][planes][rows][stride] */, int32_t* d_pts, int cap_pts,
+                                int32_t* d_starts, int32_t* d_lens, int cap_contours, int32_t* d_counts, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * ObstacleMap.update_map, explore half (obstacle_map.py:105-169) for n environments.
+ * ------------------------------------------------------------------------------------------- */
+#define VLFM_FOG_MAX_POLY 80
+typedef struct {
+    int32_t env;            /* plane slot */
+    int32_t ax, ay;         /* agent cell (x = col, y = row) = BaseMap._xy_to_px(tf[:2,3]) (obstacle_map.py:115-116) */
+    int32_t radius;         /* int(max_line_len) = int(max_depth * ppm) */
+    int32_t n_poly;         /* vertices in poly; 0 = this environment is skipped */
+    int32_t reserved;
+    double rot_c, rot_s;    /* cos/sin(-angle_cv2) as reveal_fog_of_war's get_two_farthest_points evaluates them [ext] */
+    double line_len;        /* max_line_len * 1.05 */
+    long long poly[2 * VLFM_FOG_MAX_POLY]; /* 16.16 fixed-point FOV sector polygon (cv2.ellipse), image coordinates */
+} vlfm_fog_params;
+
+/* Host: fills vlfm_fog_params for n environments.  h_agent_px [n][2] (x,y) cells; h_angle_cv2_deg [n] =
+ * rad2deg(wrap_heading(yaw + pi/2)); h_rot_cs [n][2]; sector = cv2.ellipse(centre, (R,R), 0, a - fov/2, a + fov/2). */
+int vlfm_fog_params_host(const int32_t* h_agent_px, const double* h_angle_cv2_deg, const double* h_rot_cs,
+                         double fov_deg, double max_line_len, const int32_t* h_env, const int32_t* h_explore, int n,
+                         vlfm_fog_params* h_out);
+
+size_t vlfm_obstacle_scratch_bytes(int n_envs, int map_size, int cap_pts, int cap_contours);
+
+/* Device pipeline: [navigable = ~dilate(obstacle, k x k); explored &= navigable] -> fog of war reveal -> explored
+ * component selection -> frontier midpoints.
+ *   d_obstacle/d_navigable/d_explored  [n_envs][S][stride] bit-packed planes
+ *   d_bbox      [n_envs][4] int32 persistent (ymin, ymax, xmin, xmax) of everything ever revealed; reset value
+ *               (S, -1, S, -1)
+ *   d_frontiers [n_envs][cap_frontiers][2] f64 pixel coordinates (x, y) == ObstacleMap._frontiers_px
+ *   d_counts    [n_envs][4] int32: (n frontiers, overflow flag, n contours, n chain points) */
+int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, int n, const uint32_t* d_obstacle,
+                                     uint32_t* d_navigable, uint32_t* d_explored, int32_t* d_bbox, int n_envs,
+                                     int map_size, int kernel_size, int fog_radius, double area_thresh_px,
+                                     void* d_scratch, size_t scratch_bytes, int cap_pts, int cap_contours,
+                                     double* d_frontiers, int cap_frontiers, int32_t* d_counts, int update_obstacles,
+                                     int explore, void* stream);
+
+/* Debug/diagnostic: copies the per-environment status words of the last pipeline run to the host. */
+int vlfm_obstacle_status(const void* d_scratch, int n_envs, int map_size, int cap_pts, int cap_contours,
+                         int32_t* h_out);
 
 #ifdef __cplusplus
 }

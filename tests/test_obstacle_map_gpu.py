@@ -1,0 +1,117 @@
+"""-m gpu: HIP ObstacleMap vs the oracle (oracle/ref_obstacle_map.py) on identical inputs, through the C ABI.
+Bar: bit-exact obstacle / navigable / explored planes and bit-exact frontier pixel coordinates (f64)."""
+import numpy as np
+import pytest
+
+from vlfm_amd.synthetic import MAX_DEPTH, MIN_DEPTH, SyntheticEnv, camera_intrinsics, depth_frame, pose_to_tf
+
+pytestmark = pytest.mark.gpu
+FX, FY, FOV = camera_intrinsics(640)
+
+
+def _pair(gpu_device, **kw):
+    from oracle.ref_obstacle_map import RefObstacleMap
+    from vlfm_amd.mapping import ObstacleMap
+
+    args = dict(min_height=0.61, max_height=0.88, agent_radius=0.18, area_thresh=1.5)
+    args.update(kw)
+    return ObstacleMap(device=gpu_device, **args), RefObstacleMap(**args)
+
+
+def _same(ours, ref, step=None):
+    assert np.array_equal(ours._map, ref._map), f"obstacle plane differs at step {step}"
+    assert np.array_equal(ours._navigable_map != 0, np.asarray(ref._navigable_map) != 0), f"navigable differs at {step}"
+    a, b = ours.explored_area, ref.explored_area
+    assert np.array_equal(a, b), f"explored differs at step {step}: {np.argwhere(a != b)[:5]}, {(a != b).sum()} cells"
+    fo, fr = np.asarray(ours._frontiers_px), np.asarray(ref._frontiers_px)
+    assert fo.shape == fr.shape, f"frontier count differs at step {step}: {fo} vs {fr}"
+    assert np.array_equal(fo, fr), f"frontier pixels differ at step {step}: {fo} vs {fr}"
+    assert np.array_equal(np.asarray(ours.frontiers), np.asarray(ref.frontiers))
+
+
+@pytest.mark.parametrize("env_id", [3, 8])
+def test_trajectory_parity(gpu_device, env_id):
+    ours, ref = _pair(gpu_device)
+    env = SyntheticEnv(env_id)
+    for step in range(30):
+        depth, tf, _ = env.observe()
+        ours.update_map(depth, tf, MIN_DEPTH, MAX_DEPTH, FX, FY, FOV)
+        ref.update_map(depth, tf, MIN_DEPTH, MAX_DEPTH, FX, FY, FOV)
+        _same(ours, ref, step)
+    assert ref.explored_area.sum() > 1000 and ref._map.sum() > 100
+
+
+def _room_depth(rng, near=2.0, far=4.8):
+    """A frame whose wall is near on one side and beyond max range on the other: leaves open frontiers."""
+    d = depth_frame(rng)
+    d[:, :320] = np.minimum(d[:, :320], np.float32((near - MIN_DEPTH) / (MAX_DEPTH - MIN_DEPTH)))
+    d[:, 320:] = 1.0
+    return d
+
+
+def test_open_space_frontiers_and_arbitrary_poses(gpu_device):
+    ours, ref = _pair(gpu_device)
+    rng = np.random.default_rng(0)
+    pose_rng = np.random.default_rng(1)
+    x = y = 0.0
+    n_with_frontiers = 0
+    for step in range(25):
+        yaw = pose_rng.uniform(-np.pi, np.pi)
+        x += pose_rng.uniform(-0.3, 0.3)
+        y += pose_rng.uniform(-0.3, 0.3)
+        tf = pose_to_tf(x, y, yaw)
+        depth = _room_depth(rng)
+        ours.update_map(depth, tf, MIN_DEPTH, MAX_DEPTH, FX, FY, FOV)
+        ref.update_map(depth, tf, MIN_DEPTH, MAX_DEPTH, FX, FY, FOV)
+        _same(ours, ref, step)
+        n_with_frontiers += len(ref.frontiers) > 0
+    assert n_with_frontiers >= 5
+
+
+def test_no_obstacle_in_cone_reveals_nothing(gpu_device):
+    """reveal_fog_of_war returns the fog unchanged when the cone holds no obstacle."""
+    ours, ref = _pair(gpu_device)
+    depth = np.ones((480, 640), np.float32)
+    tf = pose_to_tf(0.0, 0.0, 0.3)
+    ours.update_map(depth, tf, MIN_DEPTH, MAX_DEPTH, FX, FY, FOV)
+    ref.update_map(depth, tf, MIN_DEPTH, MAX_DEPTH, FX, FY, FOV)
+    _same(ours, ref)
+    assert ref.explored_area.sum() == 0 and len(ref.frontiers) == 0
+
+
+def test_update_flags_and_reset(gpu_device):
+    ours, ref = _pair(gpu_device)
+    env = SyntheticEnv(5)
+    for step in range(6):
+        depth, tf, _ = env.observe()
+        kw = dict(explore=step % 2 == 0, update_obstacles=step % 3 != 0)
+        ours.update_map(depth if kw["update_obstacles"] else None, tf, MIN_DEPTH, MAX_DEPTH, FX, FY, FOV, **kw)
+        ref.update_map(depth, tf, MIN_DEPTH, MAX_DEPTH, FX, FY, FOV, **kw)
+        assert np.array_equal(ours._map, ref._map) and np.array_equal(ours.explored_area, ref.explored_area)
+    ours.reset()
+    ref.reset()
+    depth, tf, _ = env.observe()
+    ours.update_map(depth, tf, MIN_DEPTH, MAX_DEPTH, FX, FY, FOV)
+    ref.update_map(depth, tf, MIN_DEPTH, MAX_DEPTH, FX, FY, FOV)
+    _same(ours, ref)
+
+
+def test_map_edge_index_error_and_hole_flag(gpu_device):
+    ours, ref = _pair(gpu_device)
+    depth = SyntheticEnv(1).observe()[0]
+    tf = pose_to_tf(24.0, 0.0, 0.0)  # looking at the +x edge from 1 m away: points fall beyond row 999
+    with pytest.raises(IndexError):
+        ref.update_map(depth, tf, MIN_DEPTH, MAX_DEPTH, FX, FY, FOV)
+    with pytest.raises(IndexError):
+        ours.update_map(depth, tf, MIN_DEPTH, MAX_DEPTH, FX, FY, FOV)
+    # hole_area_thresh == -1: zeros are filled with 1.0 and vanish beyond max_depth (obstacle_map.py:87-89)
+    o2, r2 = _pair(gpu_device, hole_area_thresh=-1)
+    d2 = SyntheticEnv(2, holes=True).observe()[0]
+    assert (d2 == 0).any()
+    tf2 = pose_to_tf(0.0, 0.0, 0.0)
+    o2.update_map(d2, tf2, MIN_DEPTH, MAX_DEPTH, FX, FY, FOV)
+    r2.update_map(d2, tf2, MIN_DEPTH, MAX_DEPTH, FX, FY, FOV)
+    _same(o2, r2)
+    o3, _ = _pair(gpu_device)
+    with pytest.raises(NotImplementedError):
+        o3.update_map(d2, tf2, MIN_DEPTH, MAX_DEPTH, FX, FY, FOV)

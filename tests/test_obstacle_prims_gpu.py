@@ -1,0 +1,103 @@
+"""-m gpu: bit-packed primitives of the obstacle-map kernels against the oracle's OpenCV restatement."""
+import numpy as np
+import pytest
+import torch
+
+from vlfm_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _pack(img_u8: torch.Tensor) -> torch.Tensor:
+    planes, rows, cols = img_u8.shape
+    out = torch.zeros((planes, rows, (cols + 31) // 32), dtype=torch.int32, device=img_u8.device)
+    _lib.check(_lib.lib().vlfm_bits_pack(img_u8.data_ptr(), out.data_ptr(), planes, rows, cols, _stream()))
+    return out
+
+
+def _unpack(bits: torch.Tensor, cols: int) -> torch.Tensor:
+    planes, rows, _ = bits.shape
+    out = torch.empty((planes, rows, cols), dtype=torch.uint8, device=bits.device)
+    _lib.check(_lib.lib().vlfm_bits_unpack(bits.data_ptr(), out.data_ptr(), planes, rows, cols, _stream()))
+    return out
+
+
+@pytest.mark.parametrize("shape", [(50, 70), (64, 64), (100, 1000), (33, 31)])
+def test_pack_unpack_and_dilate(gpu_device, shape):
+    from oracle import cv
+
+    rng = np.random.default_rng(0)
+    img = (rng.uniform(size=(3,) + shape) < 0.03).astype(np.uint8)
+    d = torch.from_numpy(img).to(gpu_device)
+    bits = _pack(d)
+    assert torch.equal(_unpack(bits, shape[1]), d)
+    for (kw, kh) in [(3, 3), (5, 5), (7, 7), (1, 3), (9, 1)]:
+        out = torch.zeros_like(bits)
+        _lib.check(_lib.lib().vlfm_bits_dilate(bits.data_ptr(), out.data_ptr(), 3, shape[0], shape[1], kw, kh, _stream()))
+        got = _unpack(out, shape[1]).cpu().numpy()
+        for p in range(3):
+            assert np.array_equal(got[p], cv.dilate(img[p], np.ones((kh, kw), np.uint8)))
+
+
+def _gpu_contours(img: np.ndarray, method: int, device):
+    from oracle import cv  # noqa: F401
+
+    planes, rows, cols = img.shape
+    bits = _pack(torch.from_numpy(img).to(device))
+    stride = (cols + 31) // 32
+    scratch = torch.zeros((2, planes, rows, stride), dtype=torch.int32, device=device)
+    cap_p, cap_c = 1 << 16, 4096
+    pts = torch.zeros((planes, cap_p, 2), dtype=torch.int32, device=device)
+    starts = torch.zeros((planes, cap_c), dtype=torch.int32, device=device)
+    lens = torch.zeros((planes, cap_c), dtype=torch.int32, device=device)
+    counts = torch.zeros((planes, 3), dtype=torch.int32, device=device)
+    _lib.check(_lib.lib().vlfm_find_contours_external(bits.data_ptr(), planes, rows, cols, method, scratch.data_ptr(),
+                                                     pts.data_ptr(), cap_p, starts.data_ptr(), lens.data_ptr(), cap_c,
+                                                     counts.data_ptr(), _stream()))
+    pts, starts, lens, counts = pts.cpu().numpy(), starts.cpu().numpy(), lens.cpu().numpy(), counts.cpu().numpy()
+    out = []
+    for p in range(planes):
+        assert counts[p, 2] == 0
+        cs = [pts[p, starts[p, k]:starts[p, k] + lens[p, k]] for k in range(counts[p, 0])]
+        out.append(cs[::-1])  # OpenCV order = reverse discovery order
+    return out
+
+
+@pytest.mark.parametrize("density", [0.02, 0.3, 0.55, 0.8])
+@pytest.mark.parametrize("method", [1, 2])
+def test_find_contours_external_bit_exact(gpu_device, density, method):
+    from oracle import cv
+
+    rng = np.random.default_rng(int(density * 100) + method)
+    img = (rng.uniform(size=(4, 60, 90)) < density).astype(np.uint8)
+    img[1] = 0
+    img[1, 10:40, 20:70] = 1
+    img[1, 15:30, 30:50] = 0
+    img[1, 20:25, 35:45] = 1          # component nested in a hole: not external
+    img[2, 0, :] = 1                  # touches every image border
+    img[2, :, 0] = 1
+    img[2, -1, :] = 1
+    img[2, :, -1] = 1
+    got = _gpu_contours(img, method, gpu_device)
+    for p in range(4):
+        want, _ = cv.findContours(img[p], cv.RETR_EXTERNAL, method)
+        assert len(got[p]) == len(want), (p, len(got[p]), len(want))
+        for g, w in zip(got[p], want):
+            assert np.array_equal(g, w.reshape(-1, 2))
+
+
+def test_find_contours_map_sized(gpu_device):
+    from oracle import cv
+    from scipy import ndimage
+
+    rng = np.random.default_rng(5)
+    blobs = ndimage.binary_dilation(rng.uniform(size=(1000, 1000)) < 0.0005, iterations=9).astype(np.uint8)
+    got = _gpu_contours(blobs[None], 2, gpu_device)[0]
+    want, _ = cv.findContours(blobs, cv.RETR_EXTERNAL, cv.CHAIN_APPROX_SIMPLE)
+    assert len(got) == len(want) and len(want) > 20
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w.reshape(-1, 2))

@@ -37,7 +37,16 @@ class IngestParams(ctypes.Structure):
                 ("env", ctypes.c_int32), ("scatter", ctypes.c_int32)]
 
 
-assert ctypes.sizeof(VmPose) == 64 and ctypes.sizeof(IngestParams) == 152
+FOG_MAX_POLY = 80
+
+
+class FogParams(ctypes.Structure):
+    _fields_ = [("env", ctypes.c_int32), ("ax", ctypes.c_int32), ("ay", ctypes.c_int32), ("radius", ctypes.c_int32),
+                ("n_poly", ctypes.c_int32), ("reserved", ctypes.c_int32), ("rot_c", ctypes.c_double),
+                ("rot_s", ctypes.c_double), ("line_len", ctypes.c_double), ("poly", ctypes.c_longlong * (2 * FOG_MAX_POLY))]
+
+
+assert ctypes.sizeof(VmPose) == 64 and ctypes.sizeof(IngestParams) == 152 and ctypes.sizeof(FogParams) == 48 + 16 * FOG_MAX_POLY
 
 
 def build(verbose: bool = False) -> str:
@@ -85,6 +94,16 @@ def lib() -> ctypes.CDLL:
         L.vlfm_resample_coeffs_host.argtypes = [ci, ci, vp, vp, ci, ctypes.POINTER(ci)]
         L.vlfm_preprocess_rgb_batched.argtypes = [vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, ci, vp]
         L.vlfm_itc_head_batched.argtypes = [vp, ci, ci, ci, vp, vp, vp]
+        L.vlfm_bits_pack.argtypes = [vp, vp, ci, ci, ci, vp]
+        L.vlfm_bits_unpack.argtypes = [vp, vp, ci, ci, ci, vp]
+        L.vlfm_bits_dilate.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
+        L.vlfm_find_contours_external.argtypes = [vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, vp, vp]
+        L.vlfm_fog_params_host.argtypes = [vp, vp, vp, cd, cd, vp, vp, ci, vp]
+        L.vlfm_obstacle_scratch_bytes.argtypes = [ci, ci, ci, ci]
+        L.vlfm_obstacle_scratch_bytes.restype = ctypes.c_size_t
+        L.vlfm_obstacle_map_update_batched.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, cd, vp, ctypes.c_size_t,
+                                                       ci, ci, vp, ci, vp, ci, ci, vp]
+        L.vlfm_obstacle_status.argtypes = [vp, ci, ci, ci, ci, vp]
         _lib = L
     return _lib
 

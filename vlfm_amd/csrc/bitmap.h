@@ -1,0 +1,191 @@
+// bitmap.h -- bit-packed binary maps (1 bit per cell, row = `stride` 32-bit words, bit x of a row lives in word x>>5 at
+// position x&31) and the wave-cooperative border follower used by the obstacle-map kernels (gfx950).
+//
+// Why bit-packed: ObstacleMap's planes (obstacles, navigable, explored) are boolean 1000x1000 grids.  Packed they are
+// 125 KB each (L2/MALL-resident for dozens of environments), a k x k dilation is k word-shifts + ORs, and a 205x205
+// fog-of-war window is 5.7 KB of LDS.
+//
+// Border following restates the Suzuki-Abe scan of OpenCV's legacy findContours (RETR_EXTERNAL; CHAIN_APPROX_NONE /
+// _SIMPLE) for a 64-wide wavefront: the raster scan for border starts is done 64 words at a time with ballot/ctz, the
+// "last labelled pixel to the left" test (lnbd) is a masked clz over the row's label words, and only the inherently
+// sequential chain walk is executed by a single lane.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vlfm {
+
+struct Bits {            // read view
+    const unsigned* w;
+    int stride;          // words per row
+    int rows, cols;
+};
+
+__device__ inline unsigned bit_get(const unsigned* w, int stride, int rows, int cols, int x, int y) {
+    if ((unsigned)x >= (unsigned)cols || (unsigned)y >= (unsigned)rows) return 0u;
+    return (w[(size_t)y * stride + (x >> 5)] >> (x & 31)) & 1u;
+}
+__device__ inline unsigned bit_get(const Bits& b, int x, int y) { return bit_get(b.w, b.stride, b.rows, b.cols, x, y); }
+
+// three consecutive bits x-1, x, x+1 of row y (zero outside) -> bits 0..2
+__device__ inline unsigned bits3(const Bits& b, int x, int y) {
+    if ((unsigned)y >= (unsigned)b.rows) return 0u;
+    const unsigned* row = b.w + (size_t)y * b.stride;
+    const int xm = x - 1;
+    // 64-bit window starting at word of xm (handles xm == -1)
+    unsigned long long win;
+    if (xm < 0) {
+        win = ((unsigned long long)row[0]) << 1;  // bit 0 = x=-1 (zero), bit1 = x=0 ...
+        unsigned r = (unsigned)(win & 7u);
+        if (b.cols < 2) r &= 3u;
+        return r;
+    }
+    const int wi = xm >> 5, sh = xm & 31;
+    win = row[wi];
+    if (wi + 1 < b.stride) win |= ((unsigned long long)row[wi + 1]) << 32;
+    unsigned r = (unsigned)((win >> sh) & 7u);
+    // mask columns beyond cols
+    if (x + 1 >= b.cols) r &= (x >= b.cols) ? 1u : 3u;
+    return r;
+}
+
+// 8-neighbourhood of (x,y) as a mask indexed by chain code: 0=E 1=NE 2=N 3=NW 4=W 5=SW 6=S 7=SE (y grows downwards)
+__device__ inline unsigned nbr8(const Bits& b, int x, int y) {
+    const unsigned up = bits3(b, x, y - 1), mid = bits3(b, x, y), dn = bits3(b, x, y + 1);
+    return ((mid >> 2) & 1u)            /* E  */
+         | (((up >> 2) & 1u) << 1)      /* NE */
+         | (((up >> 1) & 1u) << 2)      /* N  */
+         | ((up & 1u) << 3)             /* NW */
+         | ((mid & 1u) << 4)            /* W  */
+         | ((dn & 1u) << 5)             /* SW */
+         | (((dn >> 1) & 1u) << 6)      /* S  */
+         | (((dn >> 2) & 1u) << 7);     /* SE */
+}
+
+__device__ __constant__ const int kCodeDx[8] = {1, 1, 0, -1, -1, -1, 0, 1};
+__device__ __constant__ const int kCodeDy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+
+struct ContourSink {         // per-environment output of a scan
+    int2* pts;               // [cap_pts]
+    int* start;              // [cap_contours]
+    int* len;                // [cap_contours]
+    int cap_pts, cap_contours;
+    int n_pts, n_contours;   // running counts (uniform across the wave)
+    int overflow;
+};
+
+// Follow one outer border starting at (x0,y0) (the scan guarantees: pixel set, left neighbour clear, not yet traced).
+// Executed by ONE lane.  Labels: `traced` = pixel carries a border label, `neg` = the label is the negative one
+// (the pixel's east neighbour was examined and found empty).  method: 1 = every chain point, 2 = direction changes only.
+__device__ inline int follow_border(const Bits& img, unsigned* traced, unsigned* neg, int x0, int y0, int method,
+                                    int2* out, int cap) {
+    int n = 0;
+    auto mark = [&](int x, int y, bool negative) {
+        const size_t wi = (size_t)y * img.stride + (x >> 5);
+        const unsigned m = 1u << (x & 31);
+        traced[wi] |= m;
+        if (negative) neg[wi] |= m;
+    };
+    auto emit = [&](int x, int y) {
+        if (n < cap) out[n] = make_int2(x, y);
+        n++;
+    };
+    unsigned nb = nbr8(img, x0, y0);
+    int s_end = 4, s = 4;
+    do {
+        s = (s - 1) & 7;
+    } while (!((nb >> s) & 1u) && s != s_end);
+    if (s == s_end) {  // isolated pixel
+        mark(x0, y0, true);
+        emit(x0, y0);
+        return n;
+    }
+    const int x1 = x0 + kCodeDx[s], y1 = y0 + kCodeDy[s];
+    int x3 = x0, y3 = y0;
+    int prev_s = s ^ 4;
+    for (;;) {
+        s_end = s;
+        nb = nbr8(img, x3, y3);
+        for (;;) {  // counter-clockwise search for the next border pixel (always terminates: we came from one)
+            ++s;
+            if ((nb >> (s & 7)) & 1u) break;
+        }
+        s &= 7;
+        if ((unsigned)(s - 1) < (unsigned)s_end) {
+            mark(x3, y3, true);
+        } else {
+            const size_t wi = (size_t)y3 * img.stride + (x3 >> 5);
+            if (!((traced[wi] >> (x3 & 31)) & 1u)) mark(x3, y3, false);
+        }
+        if (s != prev_s || method == 1) {
+            emit(x3, y3);
+            prev_s = s;
+        }
+        const int x4 = x3 + kCodeDx[s], y4 = y3 + kCodeDy[s];
+        if (x4 == x0 && y4 == y0 && x3 == x1 && y3 == y1) break;
+        x3 = x4; y3 = y4;
+        s = (s + 4) & 7;
+    }
+    return n;
+}
+
+// RETR_EXTERNAL scan of rows [y_lo, y_hi] by one wavefront (all 64 lanes must call).  `traced`/`neg` must be zero in
+// that row range on entry.  stride <= 64 words (maps up to 2048 columns).
+__device__ inline void scan_external(const Bits& img, unsigned* traced, unsigned* neg, int y_lo, int y_hi, int method,
+                                     ContourSink& sink) {
+    const int lane = threadIdx.x & 63;
+    if (y_lo < 0) y_lo = 0;
+    if (y_hi > img.rows - 1) y_hi = img.rows - 1;
+    for (int y = y_lo; y <= y_hi; y++) {
+        const unsigned* row = img.w + (size_t)y * img.stride;
+        unsigned w = lane < img.stride ? row[lane] : 0u;
+        const unsigned left = __shfl_up(w, 1, 64);
+        const unsigned carry = lane > 0 ? (left >> 31) : 0u;
+        unsigned starts = w & ~((w << 1) | carry);
+        unsigned long long any = __ballot(starts != 0u);
+        while (any) {
+            const int L = __builtin_ctzll(any);
+            const unsigned sL = __shfl(starts, L, 64);
+            const int bit = __builtin_ctz(sL);
+            const int x = L * 32 + bit;
+            if (lane == L) starts &= starts - 1;  // consume the candidate
+            // already on a traced border?
+            const size_t roww = (size_t)y * img.stride;
+            const unsigned tw_here = traced[roww + (x >> 5)];
+            if (!((tw_here >> (x & 31)) & 1u)) {
+                // lnbd: nearest labelled pixel to the left in this row; positive label => we are inside a component
+                unsigned tw = lane < img.stride ? traced[roww + lane] : 0u;
+                if (lane > (x >> 5)) tw = 0u;
+                else if (lane == (x >> 5)) tw &= (1u << (x & 31)) - 1u;
+                const unsigned long long have = __ballot(tw != 0u);
+                bool inside = false;
+                if (have) {
+                    const int Lh = 63 - __builtin_clzll(have);
+                    const unsigned twh = __shfl(tw, Lh, 64);
+                    const int xb = Lh * 32 + (31 - __builtin_clz(twh));
+                    inside = !((neg[roww + (xb >> 5)] >> (xb & 31)) & 1u);
+                }
+                if (!inside) {
+                    int n = 0;
+                    if (lane == 0) {
+                        const int room = sink.cap_pts - sink.n_pts;
+                        n = follow_border(img, traced, neg, x, y, method, sink.pts + sink.n_pts, room > 0 ? room : 0);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    n = __shfl(n, 0, 64);
+                    if (sink.n_contours < sink.cap_contours && sink.n_pts + n <= sink.cap_pts) {
+                        if (lane == 0) { sink.start[sink.n_contours] = sink.n_pts; sink.len[sink.n_contours] = n; }
+                    } else {
+                        sink.overflow = 1;
+                    }
+                    sink.n_contours++;
+                    sink.n_pts += n;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                }
+            }
+            any = __ballot(starts != 0u);
+        }
+    }
+}
+
+}  // namespace vlfm

@@ -7,7 +7,7 @@
 //                                  vlfm/mapping/base_map.py:44-46
 // Here each depth texel is loaded from HBM exactly once (16 B per lane, coalesced), reduced into a per-column
 // running maximum held in registers, and -- when obstacle scatter is requested -- unprojected in f64 and stored as a
-// single byte into the environment's obstacle grid.  HBM-bound: 4*H*W bytes read + <= H*W byte stores per
+// single bit (atomicOr) into the environment's bit-packed obstacle plane.  HBM-bound: 4*H*W bytes read per
 // observation.  No MFMA: this is a reduction + scatter.
 //
 // Work decomposition: a workgroup owns ROWS_PER_BLOCK image rows; thread (cx, ry) owns one float4 column group and
@@ -34,17 +34,24 @@ struct IngestArgs {
     const float* depth;             // [n][H][W]
     const vlfm_ingest_params* prm;  // [n]
     unsigned* colmax_keys;          // [n][W] (zero-initialised keys) or null
-    unsigned char* obstacle;        // [n_envs][S][S] or null
-    int* status;                    // [n]
-    int H, W, W4, S;
+    unsigned* obstacle;             // [n_envs][S][stride] bit-packed, or null
+    int* status;                    // [n][2]: (index error, saw zero depth)
+    int H, W, W4, S, stride;
     int cols_per_block;             // float4 column groups handled by one workgroup in x
     int ry;                         // rows advanced per iteration (= blockDim.x / cols_per_block)
     int rows_per_block;
     double ppm;
 };
 
-__device__ inline void scatter_point(const IngestArgs& a, const vlfm_ingest_params& p, unsigned char* grid, int obs,
+__device__ inline void scatter_point(const IngestArgs& a, const vlfm_ingest_params& p, unsigned* grid, int obs,
                                      int u, int v, float d) {
+    if (d == 0.0f) {
+        // a hole in the depth image.  scatter bit 1 set: hole_area_thresh == -1 semantics (obstacle_map.py:87-89), every
+        // zero becomes 1.0 and therefore falls outside max_depth.  Otherwise the caller must have filled small holes
+        // already; we only report that zeros were present (status word 1) and use the texel as it is.
+        if (p.scatter & 2) return;
+        a.status[2 * obs + 1] = 1;
+    }
     const float z = __fadd_rn(__fmul_rn(d, p.depth_scale), p.depth_offset);  // obstacle_map.py:92 (f32)
     if (!(z < p.depth_max)) return;                                          // :93
     // get_point_cloud (geometry_utils.py:230-234): int64 * f32 -> f64, then / fx
@@ -66,12 +73,12 @@ __device__ inline void scatter_point(const IngestArgs& a, const vlfm_ingest_para
     long long row = (long long)rowf, col = (long long)colf;
     // NumPy fancy-index semantics (obstacle_map.py:101): [-S, -1] wraps, anything else outside raises IndexError
     if (row >= a.S || row < -a.S || col >= a.S || col < -a.S) {
-        a.status[obs] = VLFM_ERR_INDEX;
+        a.status[2 * obs] = VLFM_ERR_INDEX;
         return;
     }
     if (row < 0) row += a.S;
     if (col < 0) col += a.S;
-    grid[(size_t)row * a.S + col] = 1;  // idempotent byte store: race-free without atomics
+    atomicOr(&grid[(size_t)row * a.stride + (col >> 5)], 1u << (col & 31));  // few in-band points: contention-free in practice
 }
 
 template <bool SCATTER>
@@ -86,8 +93,8 @@ __global__ __launch_bounds__(1024) void depth_ingest_kernel(IngestArgs a) {
     const bool live = col4 < a.W4 && ry < a.ry;
     const vlfm_ingest_params p = a.prm[obs];
     const float* img = a.depth + (size_t)obs * a.H * a.W;
-    unsigned char* grid = nullptr;
-    if (SCATTER) grid = a.obstacle + (size_t)p.env * a.S * a.S;
+    unsigned* grid = nullptr;
+    if (SCATTER) grid = a.obstacle + (size_t)p.env * a.S * a.stride;
     const float ninf = -__builtin_huge_valf();
     float4 m = make_float4(ninf, ninf, ninf, ninf);
     if (live) {
@@ -105,7 +112,7 @@ __global__ __launch_bounds__(1024) void depth_ingest_kernel(IngestArgs a) {
             for (int k = 0; k < UNROLL; k++) {
                 const int r = r0 + k * a.ry;
                 m.x = fmaxf(m.x, d[k].x); m.y = fmaxf(m.y, d[k].y); m.z = fmaxf(m.z, d[k].z); m.w = fmaxf(m.w, d[k].w);
-                if (SCATTER && p.scatter && r < r_end) {
+                if (SCATTER && (p.scatter & 1) && r < r_end) {
                     const int u = col4 * 4;
                     scatter_point(a, p, grid, obs, u + 0, r, d[k].x);
                     scatter_point(a, p, grid, obs, u + 1, r, d[k].y);
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(1024) void depth_ingest_kernel(IngestArgs a) {
 using namespace vlfm;
 
 extern "C" int vlfm_depth_ingest_batched(const float* d_depth, int n, int height, int width,
-                                         const vlfm_ingest_params* d_params, uint32_t* d_colmax_keys, uint8_t* d_obstacle,
+                                         const vlfm_ingest_params* d_params, uint32_t* d_colmax_keys, uint32_t* d_obstacle,
                                          int map_size, int pixels_per_meter, int32_t* d_status, void* stream) {
     if (n == 0) return VLFM_OK;
     if (!d_depth || !d_params || !d_status || n < 0 || height <= 0 || width <= 0)
@@ -148,7 +155,8 @@ extern "C" int vlfm_depth_ingest_batched(const float* d_depth, int n, int height
     IngestArgs a;
     a.depth = d_depth; a.prm = d_params; a.colmax_keys = reinterpret_cast<unsigned*>(d_colmax_keys);
     a.obstacle = d_obstacle; a.status = d_status;
-    a.H = height; a.W = width; a.W4 = width / 4; a.S = map_size; a.ppm = (double)pixels_per_meter;
+    a.H = height; a.W = width; a.W4 = width / 4; a.S = map_size; a.stride = (map_size + 31) / 32;
+    a.ppm = (double)pixels_per_meter;
     a.cols_per_block = a.W4 < 256 ? a.W4 : 256;
     a.ry = 640 / a.cols_per_block;
     if (a.ry < 1) a.ry = 1;

@@ -84,6 +84,66 @@ extern "C" int vlfm_value_map_pose_params(const double* h_tf, const double* h_ya
     return VLFM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ cv2.ellipse sector
+// Vertices (16.16 fixed point) of the polygon cv2.ellipse(img, (cx,cy), (r,r), 0, start, end, color, -1) fills:
+// integer-rounded angles, ellipse2Poly arc in double from the float sine table, snapped to 16.16, duplicates dropped,
+// centre appended for sectors.  Returns the vertex count or a negative status.
+static int ellipse_sector_polygon(int cx, int cy, int radius, double start_angle, double end_angle, int64_t* out_xy,
+                                  int capacity) {
+    int a0 = (int)round_half_even(start_angle), a1 = (int)round_half_even(end_angle);
+    const bool full = (a1 - a0) >= 360;
+    if (a0 > a1) { int t = a0; a0 = a1; a1 = t; }
+    while (a0 < 0) { a0 += 360; a1 += 360; }
+    while (a1 > 360) { a1 -= 360; a0 -= 360; }
+    if (a1 - a0 > 360) { a0 = 0; a1 = 360; }
+    const int step = radius < 3 ? 90 : radius < 10 ? 30 : radius < 15 ? 18 : 5;
+    const double ccx = (double)((int64_t)cx << 16), ccy = (double)((int64_t)cy << 16);
+    const double axis = (double)((int64_t)radius << 16);
+    int m = 0;
+    int64_t last_x = -1, last_y = -1;
+    for (int a = a0; a < a1 + step; a += step) {
+        int t = a > a1 ? a1 : a;
+        if (t < 0) t += 360;
+        const double ex = axis * sin_deg_table(450 - t), ey = axis * sin_deg_table(t);
+        const double vx = ccx + ex * sin_deg_table(90) - ey * sin_deg_table(0);   // rotation angle 0: alpha = 1, beta = 0
+        const double vy = ccy + ex * sin_deg_table(0) + ey * sin_deg_table(90);
+        int64_t qx = (int64_t)round_half_even(vx / 65536.0) << 16, qy = (int64_t)round_half_even(vy / 65536.0) << 16;
+        qx += round_half_even(vx - (double)qx);
+        qy += round_half_even(vy - (double)qy);
+        if (qx == last_x && qy == last_y) continue;
+        if (m >= capacity) return VLFM_ERR_CAPACITY;
+        out_xy[2 * m] = qx; out_xy[2 * m + 1] = qy; m++;
+        last_x = qx; last_y = qy;
+    }
+    if (!full) {
+        if (m >= capacity) return VLFM_ERR_CAPACITY;
+        out_xy[2 * m] = (int64_t)cx << 16; out_xy[2 * m + 1] = (int64_t)cy << 16; m++;
+    }
+    return m;
+}
+
+extern "C" int vlfm_fog_params_host(const int32_t* h_agent_px, const double* h_angle_cv2_deg, const double* h_rot_cs,
+                                    double fov_deg, double max_line_len, const int32_t* h_env,
+                                    const int32_t* h_explore, int n, vlfm_fog_params* h_out) {
+    if (!h_agent_px || !h_angle_cv2_deg || !h_rot_cs || !h_out || n < 0)
+        return vlfm::fail(VLFM_ERR_INVALID, "fog_params_host: bad argument");
+    for (int k = 0; k < n; k++) {
+        vlfm_fog_params& p = h_out[k];
+        std::memset(&p, 0, sizeof(p));
+        p.env = h_env ? h_env[k] : k;
+        p.ax = h_agent_px[2 * k]; p.ay = h_agent_px[2 * k + 1];
+        p.radius = (int)max_line_len;
+        p.rot_c = h_rot_cs[2 * k]; p.rot_s = h_rot_cs[2 * k + 1];
+        p.line_len = max_line_len * 1.05;
+        if (h_explore && !h_explore[k]) { p.n_poly = 0; continue; }
+        const int m = ellipse_sector_polygon(p.ax, p.ay, p.radius, h_angle_cv2_deg[k] - fov_deg / 2,
+                                             h_angle_cv2_deg[k] + fov_deg / 2, (int64_t*)p.poly, VLFM_FOG_MAX_POLY);
+        if (m < 0) return vlfm::fail(m, "fog_params_host: sector polygon does not fit VLFM_FOG_MAX_POLY");
+        p.n_poly = m;
+    }
+    return VLFM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ confidence template
 extern "C" int vlfm_cone_template_host(double fov, double max_depth, int pixels_per_meter, double min_confidence,
                                        float* h_conf, int conf_capacity, int64_t* h_poly_xy, int poly_capacity,
@@ -107,38 +167,10 @@ extern "C" int vlfm_cone_template_host(double fov, double max_depth, int pixels_
             h_conf[(size_t)r * T + c] = (float)cf;
         }
     }
-    // cv2.ellipse(mask, (size,size), (size,size), 0, -deg/2+90, deg/2+90, 1, -1)  (value_map.py:325-334):
-    // integer-rounded angles, ellipse2Poly arc in double from the float sine table, vertices snapped to 16.16.
+    // cv2.ellipse(mask, (size,size), (size,size), 0, -deg/2+90, deg/2+90, 1, -1)  (value_map.py:325-334)
     const double deg = fov * (180.0 / kPi);
-    int a0 = (int)round_half_even(-deg / 2 + 90), a1 = (int)round_half_even(deg / 2 + 90);
-    const bool full = (a1 - a0) >= 360;
-    if (a0 > a1) { int t = a0; a0 = a1; a1 = t; }
-    while (a0 < 0) { a0 += 360; a1 += 360; }
-    while (a1 > 360) { a1 -= 360; a0 -= 360; }
-    if (a1 - a0 > 360) { a0 = 0; a1 = 360; }
-    const int step = size < 3 ? 90 : size < 10 ? 30 : size < 15 ? 18 : 5;
-    const double centre = (double)((int64_t)size << 16), axis = (double)((int64_t)size << 16);
-    int m = 0;
-    int64_t last_x = -1, last_y = -1;
-    for (int a = a0; a < a1 + step; a += step) {
-        int t = a > a1 ? a1 : a;
-        if (t < 0) t += 360;
-        // rotation angle 0: alpha = cos 0 = 1, beta = sin 0 = 0 (table values), kept to mirror the f32*f64 products
-        const double ex = axis * sin_deg_table(450 - t), ey = axis * sin_deg_table(t);
-        const double vx = centre + ex * sin_deg_table(90) - ey * sin_deg_table(0);
-        const double vy = centre + ex * sin_deg_table(0) + ey * sin_deg_table(90);
-        int64_t qx = (int64_t)round_half_even(vx / 65536.0) << 16, qy = (int64_t)round_half_even(vy / 65536.0) << 16;
-        qx += round_half_even(vx - (double)qx);
-        qy += round_half_even(vy - (double)qy);
-        if (qx == last_x && qy == last_y) continue;
-        if (m >= poly_capacity) return vlfm::fail(VLFM_ERR_CAPACITY, "cone_template_host: polygon capacity");
-        h_poly_xy[2 * m] = qx; h_poly_xy[2 * m + 1] = qy; m++;
-        last_x = qx; last_y = qy;
-    }
-    if (!full) {  // a sector gets the centre appended before filling
-        if (m >= poly_capacity) return vlfm::fail(VLFM_ERR_CAPACITY, "cone_template_host: polygon capacity");
-        h_poly_xy[2 * m] = (int64_t)size << 16; h_poly_xy[2 * m + 1] = (int64_t)size << 16; m++;
-    }
+    const int m = ellipse_sector_polygon(size, size, size, -deg / 2 + 90, deg / 2 + 90, h_poly_xy, poly_capacity);
+    if (m < 0) return vlfm::fail(m, "cone_template_host: polygon capacity");
     *n_poly = m;
     return T;
 }
@@ -202,22 +234,22 @@ ProfileScope::ProfileScope(const char* name, hipStream_t stream) : name_(name), 
     if (!g_prof_on) return;
     if (hipEventCreate(&start_) != hipSuccess || hipEventCreate(&stop_) != hipSuccess) return;
     active_ = true;
-    hipEventRecord(start_, stream_);
+    (void)hipEventRecord(start_, stream_);
 }
 ProfileScope::~ProfileScope() {
     if (!active_) return;
-    hipEventRecord(stop_, stream_);
+    (void)hipEventRecord(stop_, stream_);
     std::lock_guard<std::mutex> lk(g_prof_mu);
     KernelLog& log = g_prof[name_];
     if (log.spans.size() < kMaxSpans) log.spans.emplace_back(start_, stop_);
-    else { hipEventDestroy(start_); hipEventDestroy(stop_); }
+    else { (void)hipEventDestroy(start_); (void)hipEventDestroy(stop_); }
 }
 }  // namespace vlfm
 
 extern "C" int vlfm_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(vlfm::g_prof_mu);
     for (auto& kv : vlfm::g_prof)
-        for (auto& sp : kv.second.spans) { hipEventDestroy(sp.first); hipEventDestroy(sp.second); }
+        for (auto& sp : kv.second.spans) { (void)hipEventDestroy(sp.first); (void)hipEventDestroy(sp.second); }
     vlfm::g_prof.clear();
     vlfm::g_prof_on = on != 0;
     return VLFM_OK;

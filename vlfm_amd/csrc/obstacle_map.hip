@@ -1,0 +1,1079 @@
+// obstacle_map.hip -- gfx950 kernels for vlfm.mapping.ObstacleMap
+// (reference: /root/reference/vlfm/mapping/obstacle_map.py; third-party steps restated per SURVEY.md App. B2/B3).
+//
+// All planes are bit-packed (bitmap.h): obstacles (written by depth_ingest's scatter), navigable, explored, plus
+// scratch planes.  Per step and environment:
+//
+//   navigable_kernel     navigable = ~dilate(obstacles, k x k) ; explored &= navigable         obstacle_map.py:105-109,127
+//   fog_of_war_kernel    one workgroup per env, everything in LDS on a window around the agent: cone sector raster,
+//                        obstacle blobs in the cone -> shadow-casting thick lines, visible component nearest the agent,
+//                        filled, dilated 3x3, OR-ed into explored                               obstacle_map.py:115-126 + B2
+//   explored_select      external components of explored; if more than one keep (and fill) the agent's
+//                                                                                               obstacle_map.py:128-146
+//   frontier_kernel      dilate explored 5x5, small-pocket filter, border chain of the explored region, frontier runs
+//                        and their arc-length midpoints                                         obstacle_map.py:155-169 + B3
+//
+// Dense work (dilations, masks, rasterisation, packing) is data-parallel over words/pixels; the order-dependent part
+// (border chains) is a single-lane walk driven by a wave-parallel scan (bitmap.h).  No MFMA; bit and integer work.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vlfm_amd.h"
+#include "bitmap.h"
+#include "profile.h"
+#include "raster.h"
+#include "status.h"
+
+namespace vlfm {
+
+// ------------------------------------------------------------------------------------------------ pack / unpack
+__global__ void pack_u8_kernel(const unsigned char* __restrict__ src, unsigned* __restrict__ dst, int rows, int cols,
+                               int stride) {
+    const int y = blockIdx.y, wi = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t plane = blockIdx.z;
+    if (wi >= stride) return;
+    const unsigned char* row = src + (plane * rows + y) * (size_t)cols;
+    unsigned w = 0;
+    for (int b = 0; b < 32; b++) {
+        const int x = wi * 32 + b;
+        if (x < cols && row[x]) w |= 1u << b;
+    }
+    dst[(plane * rows + y) * (size_t)stride + wi] = w;
+}
+
+__global__ void unpack_u8_kernel(const unsigned* __restrict__ src, unsigned char* __restrict__ dst, int rows, int cols,
+                                 int stride) {
+    const int y = blockIdx.y, x = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t plane = blockIdx.z;
+    if (x >= cols) return;
+    dst[(plane * rows + y) * (size_t)cols + x] = (src[(plane * rows + y) * (size_t)stride + (x >> 5)] >> (x & 31)) & 1u;
+}
+
+// ------------------------------------------------------------------------------------------------ dilation on words
+// horizontal dilation of one row word by radius r (r <= 31) given its neighbours
+__device__ inline unsigned hdilate(unsigned prev, unsigned cur, unsigned next, int r) {
+    unsigned out = cur;
+    for (int d = 1; d <= r; d++) out |= (cur << d) | (prev >> (32 - d)) | (cur >> d) | (next << (32 - d));
+    return out;
+}
+
+__device__ inline unsigned row_word(const unsigned* plane, int stride, int rows, int y, int wi) {
+    if ((unsigned)y >= (unsigned)rows || (unsigned)wi >= (unsigned)stride) return 0u;
+    return plane[(size_t)y * stride + wi];
+}
+
+__device__ inline unsigned tail_mask(int cols, int wi) {
+    const int rem = cols - wi * 32;
+    return rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << rem) - 1u));
+}
+
+// dst = dilate(src, (2rx+1) x (2ry+1)) over the rows [y_lo, y_hi] of each listed plane.
+// mode 0: plain;  mode 1: dst = ~dilated (navigable) and and_plane &= dst (explored &= navigable)
+__global__ __launch_bounds__(256) void dilate_bits_kernel(const unsigned* __restrict__ src, unsigned* __restrict__ dst,
+                                                          unsigned* __restrict__ and_plane, const int* __restrict__ env,
+                                                          int rows, int cols, int stride, int rx, int ry, int mode) {
+    const int e = env ? env[blockIdx.z] : (int)blockIdx.z;
+    const size_t off = (size_t)e * rows * stride;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * stride) return;
+    const int y = idx / stride, wi = idx - y * stride;
+    const unsigned* s = src + off;
+    unsigned acc = 0;
+    for (int dy = -ry; dy <= ry; dy++) {
+        const unsigned c = row_word(s, stride, rows, y + dy, wi);
+        const unsigned p = row_word(s, stride, rows, y + dy, wi - 1), n = row_word(s, stride, rows, y + dy, wi + 1);
+        acc |= hdilate(p, c, n, rx);
+    }
+    const unsigned m = tail_mask(cols, wi);
+    if (mode == 0) {
+        dst[off + idx] = acc & m;
+    } else {
+        const unsigned nav = ~acc & m;
+        dst[off + idx] = nav;
+        if (and_plane) and_plane[off + idx] &= nav;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ contour test entry
+// One wavefront per plane: RETR_EXTERNAL contours of a bit-packed image (used by the parity tests and by hosts that
+// want raw contours).
+__global__ __launch_bounds__(64) void find_contours_kernel(const unsigned* __restrict__ img, unsigned* __restrict__ traced,
+                                                           unsigned* __restrict__ neg, int rows, int cols, int stride,
+                                                           int method, int2* __restrict__ pts, int cap_pts,
+                                                           int* __restrict__ starts, int* __restrict__ lens,
+                                                           int cap_contours, int* __restrict__ counts /* [planes][3] */) {
+    const size_t plane = blockIdx.x;
+    Bits b{img + plane * rows * stride, stride, rows, cols};
+    unsigned* t = traced + plane * rows * stride;
+    unsigned* ng = neg + plane * rows * stride;
+    for (int i = threadIdx.x; i < rows * stride; i += 64) { t[i] = 0u; ng[i] = 0u; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    ContourSink sink;
+    sink.pts = pts + plane * cap_pts; sink.start = starts + plane * cap_contours; sink.len = lens + plane * cap_contours;
+    sink.cap_pts = cap_pts; sink.cap_contours = cap_contours; sink.n_pts = 0; sink.n_contours = 0; sink.overflow = 0;
+    scan_external(b, t, ng, 0, rows - 1, method, sink);
+    if (threadIdx.x == 0) {
+        counts[plane * 3 + 0] = sink.n_contours;
+        counts[plane * 3 + 1] = sink.n_pts;
+        counts[plane * 3 + 2] = sink.overflow;
+    }
+}
+
+
+// ================================================================================================ drawing helpers
+// Window view of a bit plane living in LDS: wn x wn cells, top-left = image cell (ox, oy); image is S x S.
+struct Win {
+    int ox, oy, wn, words, S;
+};
+
+__device__ inline void win_clear_span(unsigned* plane, const Win& w, int y, int x1, int x2) {  // image coords, inclusive
+    const int ly = y - w.oy;
+    if ((unsigned)ly >= (unsigned)w.wn) return;
+    int a = x1 - w.ox, b = x2 - w.ox;
+    if (a < 0) a = 0;
+    if (b > w.wn - 1) b = w.wn - 1;
+    if (a > b) return;
+    for (int wi = a >> 5; wi <= (b >> 5); wi++) {
+        const int lo = wi == (a >> 5) ? (a & 31) : 0, hi = wi == (b >> 5) ? (b & 31) : 31;
+        const unsigned m = (hi == 31 ? 0xFFFFFFFFu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+        atomicAnd(&plane[ly * w.words + wi], ~m);
+    }
+}
+__device__ inline void win_clear_px(unsigned* plane, const Win& w, long long x, long long y) {
+    if (x < 0 || y < 0 || x >= w.S || y >= w.S) return;
+    win_clear_span(plane, w, (int)y, (int)x, (int)x);
+}
+
+// cv Line2: DDA between 16.16 endpoints, clipped to the image
+__device__ inline void line2_clear(unsigned* plane, const Win& w, long long x1, long long y1, long long x2, long long y2) {
+    if (!clip_line((long long)w.S << XY_SHIFT, (long long)w.S << XY_SHIFT, x1, y1, x2, y2)) return;
+    long long dx = x2 - x1, dy = y2 - y1;
+    const long long j = dx < 0 ? -1 : 0, i = dy < 0 ? -1 : 0;
+    const long long ax = (dx ^ j) - j, ay = (dy ^ i) - i;
+    long long x_step, y_step;
+    int ecount;
+    if (ax > ay) {
+        dy = (dy ^ j) - j;
+        if (j) { long long t = x1; x1 = x2; x2 = t; t = y1; y1 = y2; y2 = t; }
+        x_step = XY_ONE;
+        y_step = (dy << XY_SHIFT) / (ax | 1);
+        ecount = (int)((x2 - x1) >> XY_SHIFT);
+    } else {
+        dx = (dx ^ i) - i;
+        if (i) { long long t = x1; x1 = x2; x2 = t; t = y1; y1 = y2; y2 = t; }
+        x_step = (dx << XY_SHIFT) / (ay | 1);
+        y_step = XY_ONE;
+        ecount = (int)((y2 - y1) >> XY_SHIFT);
+    }
+    x1 += XY_ONE >> 1;
+    y1 += XY_ONE >> 1;
+    win_clear_px(plane, w, (x2 + (XY_ONE >> 1)) >> XY_SHIFT, (y2 + (XY_ONE >> 1)) >> XY_SHIFT);
+    if (ax > ay) {
+        x1 >>= XY_SHIFT;
+        while (ecount >= 0) { win_clear_px(plane, w, x1, y1 >> XY_SHIFT); x1++; y1 += y_step; ecount--; }
+    } else {
+        y1 >>= XY_SHIFT;
+        while (ecount >= 0) { win_clear_px(plane, w, x1 >> XY_SHIFT, y1); x1 += x_step; y1++; ecount--; }
+    }
+}
+
+// cv FillConvexPoly for a 16.16 quadrilateral (LINE_8), painting zeros
+__device__ inline void fill_convex_quad_clear(unsigned* plane, const Win& w, const long long* vx, const long long* vy) {
+    const int npts = 4, shift = XY_SHIFT;
+    const int delta = 1 << shift >> 1;
+    struct { int idx, di; long long x, dx; int ye; } edge[2];
+    int imin = 0, edges = npts;
+    long long xmin = vx[0], xmax = vx[0], ymin = vy[0], ymax = vy[0];
+    long long p0x = vx[npts - 1], p0y = vy[npts - 1];
+    for (int i = 0; i < npts; i++) {
+        if (vy[i] < ymin) { ymin = vy[i]; imin = i; }
+        if (vy[i] > ymax) ymax = vy[i];
+        if (vx[i] > xmax) xmax = vx[i];
+        if (vx[i] < xmin) xmin = vx[i];
+        line2_clear(plane, w, p0x, p0y, vx[i], vy[i]);
+        p0x = vx[i]; p0y = vy[i];
+    }
+    xmin = (xmin + delta) >> shift; xmax = (xmax + delta) >> shift;
+    ymin = (ymin + delta) >> shift; ymax = (ymax + delta) >> shift;
+    if ((int)xmax < 0 || (int)ymax < 0 || (int)xmin >= w.S || (int)ymin >= w.S) return;
+    if (ymax > w.S - 1) ymax = w.S - 1;
+    edge[0].idx = edge[1].idx = imin;
+    int y = (int)ymin;
+    edge[0].ye = edge[1].ye = y;
+    edge[0].di = 1; edge[1].di = npts - 1;
+    edge[0].x = edge[1].x = -XY_ONE;
+    edge[0].dx = edge[1].dx = 0;
+    do {
+        for (int i = 0; i < 2; i++) {
+            if (y >= edge[i].ye) {
+                int idx0 = edge[i].idx, di = edge[i].di;
+                int idx = idx0 + di;
+                if (idx >= npts) idx -= npts;
+                int ty = 0;
+                for (; edges-- > 0;) {
+                    ty = (int)((vy[idx] + delta) >> shift);
+                    if (ty > y) {
+                        const long long xs = vx[idx0], xe = vx[idx];
+                        edge[i].ye = ty;
+                        edge[i].dx = ((xe - xs) * 2 + (ty - y)) / (2 * (ty - y));
+                        edge[i].x = xs;
+                        edge[i].idx = idx;
+                        break;
+                    }
+                    idx0 = idx;
+                    idx += di;
+                    if (idx >= npts) idx -= npts;
+                }
+            }
+        }
+        if (edges < 0) break;
+        if (y >= 0) {
+            int left = 0, right = 1;
+            if (edge[0].x > edge[1].x) { left = 1; right = 0; }
+            int xx1 = (int)((edge[left].x + (XY_ONE >> 1)) >> XY_SHIFT);
+            int xx2 = (int)((edge[right].x + (XY_ONE >> 1)) >> XY_SHIFT);
+            if (xx2 >= 0 && xx1 < w.S) {
+                if (xx1 < 0) xx1 = 0;
+                if (xx2 >= w.S) xx2 = w.S - 1;
+                win_clear_span(plane, w, y, xx1, xx2);
+            }
+        }
+        edge[0].x += edge[0].dx;
+        edge[1].x += edge[1].dx;
+    } while (++y <= (int)ymax);
+}
+
+// cv Circle(center, radius, fill) painting zeros
+__device__ inline void circle_clear(unsigned* plane, const Win& w, int cx, int cy, int radius) {
+    int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+    auto span = [&](int y, int x1, int x2) {
+        if ((unsigned)y >= (unsigned)w.S) return;
+        if (x1 < 0) x1 = 0;
+        if (x2 > w.S - 1) x2 = w.S - 1;
+        if (x1 <= x2) win_clear_span(plane, w, y, x1, x2);
+    };
+    while (dx >= dy) {
+        span(cy - dy, cx - dx, cx + dx); span(cy + dy, cx - dx, cx + dx);
+        span(cy - dx, cx - dy, cx + dy); span(cy + dx, cx - dy, cx + dy);
+        dy++;
+        err += plus;
+        plus += 2;
+        const int mask = (err <= 0) - 1;
+        err -= minus & mask;
+        dx += mask;
+        minus -= 2 & mask;
+    }
+}
+
+// cv ThickLine(thickness = 2) from integer p0 to p1, painting zeros (frontier_exploration's shadow cuts)
+__device__ inline void thick_line2_clear(unsigned* plane, const Win& w, int p0x, int p0y, int p1x, int p1y) {
+    const long long a0x = (long long)p0x << XY_SHIFT, a0y = (long long)p0y << XY_SHIFT;
+    const long long a1x = (long long)p1x << XY_SHIFT, a1y = (long long)p1y << XY_SHIFT;
+    const double INV = 1. / XY_ONE;
+    const double dx = (double)(a0x - a1x) * INV, dy = (double)(a1y - a0y) * INV;
+    double r = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
+    const long long thickness = 2LL << (XY_SHIFT - 1);
+    if (fabs(r) > 2.220446049250313e-16) {
+        r = __ddiv_rn((double)thickness, sqrt(r));
+        const long long dpx = __double2ll_rn(__dmul_rn(dy, r)), dpy = __double2ll_rn(__dmul_rn(dx, r));
+        const long long vx[4] = {a0x + dpx, a0x - dpx, a1x - dpx, a1x + dpx};
+        const long long vy[4] = {a0y + dpy, a0y - dpy, a1y - dpy, a1y + dpy};
+        fill_convex_quad_clear(plane, w, vx, vy);
+    }
+    const int rad = (int)((thickness + (XY_ONE >> 1)) >> XY_SHIFT);
+    circle_clear(plane, w, p0x, p0y, rad);
+    circle_clear(plane, w, p1x, p1y, rad);
+}
+
+// |cv::pointPolygonTest(contour, pt, true)| and the inside flag for an integer contour; evaluated by one wavefront.
+// Returns squared-distance quotient (num/denom as a double) in *d2 and the crossing parity in *inside.
+__device__ inline void wave_point_polygon(const int2* c, int n, int ptx, int pty, double* d2_out, int* inside_out) {
+    const int lane = threadIdx.x & 63;
+    double best = 3.4028234663852886e38;  // FLT_MAX / 1
+    int counter = 0;
+    const float fx = (float)ptx, fy = (float)pty;
+    for (int i = lane; i < n; i += 64) {
+        const int2 a = c[i == 0 ? n - 1 : i - 1], b = c[i];
+        const float v0x = (float)a.x, v0y = (float)a.y, vx = (float)b.x, vy = (float)b.y;
+        const double dx = vx - v0x, dy = vy - v0y, dx1 = fx - v0x, dy1 = fy - v0y, dx2 = fx - vx, dy2 = fy - vy;
+        double num, den = 1;
+        if (dx1 * dx + dy1 * dy <= 0) num = dx1 * dx1 + dy1 * dy1;
+        else if (dx2 * dx + dy2 * dy >= 0) num = dx2 * dx2 + dy2 * dy2;
+        else { num = dy1 * dx - dx1 * dy; num *= num; den = dx * dx + dy * dy; }
+        const double q = num / den;
+        if (q < best) best = q;
+        if (!((v0y <= fy && vy <= fy) || (v0y > fy && vy > fy) || (v0x < fx && vx < fx))) {
+            double t = dy1 * dx - dx1 * dy;
+            if (dy < 0) t = -t;
+            counter += t > 0;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_down(best, off, 64);
+        if (o < best) best = o;
+        counter += __shfl_down(counter, off, 64);
+    }
+    *d2_out = __shfl(best, 0, 64);
+    *inside_out = __shfl(counter, 0, 64) & 1;
+}
+
+// ================================================================================================ navigable
+// navigable = ~dilate(obstacles, k x k) (obstacle_map.py:105-109); explored &= navigable (obstacle_map.py:127, applied
+// before this step's reveal, which only ever adds navigable cells)
+// -> dilate_bits_kernel mode 1.
+
+// ================================================================================================ fog of war
+constexpr int FOG_MAX_POLY = VLFM_FOG_MAX_POLY;
+using FogParams = vlfm_fog_params;  // one per environment and step, host-computed (vlfm_fog_params_host)
+
+struct MapPlanes {
+    const unsigned* obstacle;  // [n_envs][S][stride]
+    unsigned* navigable;    // [n_envs][S][stride]
+    unsigned* explored;     // [n_envs][S][stride]
+    int S, stride;
+};
+
+struct FogScratch {         // per environment slices of global scratch
+    int2* pts;              // [n_envs][cap_pts]
+    int* starts; int* lens; // [n_envs][cap_contours]
+    int4* lines;            // [n_envs][cap_pts]
+    int* status;            // [n_envs][4]: overflow flag, n obstacle contours, n lines, selected dist*1000
+    int* bbox;              // [n_envs][4]: explored rows/cols touched so far (ymin, ymax, xmin, xmax)
+    int cap_pts, cap_contours;
+};
+
+// navigable = ~dilate(obstacles, k x k) (obstacle_map.py:105-109); explored &= navigable (obstacle_map.py:127 -- applied
+// ahead of this step's reveal, which only ever adds navigable cells, so the order is immaterial)
+__global__ __launch_bounds__(256) void navigable_kernel(const FogParams* __restrict__ prm, MapPlanes mp, int radius,
+                                                        int update_obstacles, int explore) {
+    const int e = prm[blockIdx.z].env;
+    const int S = mp.S, stride = mp.stride;
+    const size_t off = (size_t)e * S * stride;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= S * stride) return;
+    const int y = idx / stride, wi = idx - y * stride;
+    unsigned nav;
+    if (update_obstacles) {
+        const unsigned* src = mp.obstacle + off;
+        unsigned acc = 0;
+        for (int dy = -radius; dy <= radius; dy++)
+            acc |= hdilate(row_word(src, stride, S, y + dy, wi - 1), row_word(src, stride, S, y + dy, wi),
+                           row_word(src, stride, S, y + dy, wi + 1), radius);
+        nav = ~acc & tail_mask(S, wi);
+        mp.navigable[off + idx] = nav;
+    } else {
+        nav = mp.navigable[off + idx];
+    }
+    if (explore && prm[blockIdx.z].n_poly > 0) mp.explored[off + idx] &= nav;  // only the explore branch masks (:127)
+}
+
+__device__ inline unsigned load_window_word(const unsigned* plane, int S, int stride, int ox, int oy, int ly, int lw) {
+    const int y = oy + ly;
+    if ((unsigned)y >= (unsigned)S) return 0u;
+    const int x0 = ox + lw * 32;  // image x of bit 0 of this window word (may be negative)
+    unsigned out = 0;
+    const unsigned* row = plane + (size_t)y * stride;
+    // assemble from up to two image words
+    const int wi = x0 >= 0 ? (x0 >> 5) : -((-x0 + 31) >> 5);
+    const int sh = x0 - wi * 32;  // 0..31
+    const unsigned lo = (wi >= 0 && wi < stride) ? row[wi] : 0u;
+    const unsigned hi = (wi + 1 >= 0 && wi + 1 < stride) ? row[wi + 1] : 0u;
+    out = sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;
+    return out;
+}
+
+__global__ __launch_bounds__(256) void fog_of_war_kernel(const FogParams* __restrict__ prm, MapPlanes mp, FogScratch sc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const FogParams& P = prm[blockIdx.x];
+    if (P.n_poly <= 0) return;
+    const int S = mp.S;
+    const int R = P.radius;
+    const int wn = 2 * R + 5, words = (wn + 31) >> 5, plane_words = wn * words;
+    const int ox = P.ax - R - 2, oy = P.ay - R - 2;
+    unsigned* cone = reinterpret_cast<unsigned*>(smem);
+    unsigned* par = cone + plane_words;     // parity scratch (cone), later fill parity
+    unsigned* nav = par + plane_words;
+    unsigned* obst = nav + plane_words;
+    unsigned* vis = obst + plane_words;
+    unsigned* traced = vis + plane_words;
+    unsigned* neg = traced + plane_words;
+    unsigned* fill = neg + plane_words;
+    int* sh_i = reinterpret_cast<int*>(fill + plane_words);  // small shared ints
+    const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const size_t eoff = (size_t)P.env * S * mp.stride;
+    const unsigned last_mask = (wn & 31) ? ((1u << (wn & 31)) - 1u) : 0xFFFFFFFFu;
+    Win W{ox, oy, wn, words, S};
+    int2* pts = sc.pts + (size_t)P.env * sc.cap_pts;
+    int* cstart = sc.starts + (size_t)P.env * sc.cap_contours;
+    int* clen = sc.lens + (size_t)P.env * sc.cap_contours;
+    int4* lines = sc.lines + (size_t)P.env * sc.cap_pts;
+    int* status = sc.status + (size_t)P.env * 4;
+
+    for (int i = tid; i < 8 * plane_words; i += nth) cone[i] = 0u;
+    if (tid < 16) sh_i[tid] = 0;
+    __syncthreads();
+
+    // ---- 1. cone sector (cv2.ellipse filled) into cone/par
+    LdsBitmap bm;
+    bm.solid = cone; bm.parity = par; bm.rows = S; bm.cols = S; bm.words = words;
+    bm.ox = ox; bm.oy = oy; bm.wrows = wn; bm.wcols = wn;
+    for (int i = tid; i < P.n_poly; i += nth) {
+        const int j = i == 0 ? P.n_poly - 1 : i - 1;
+        const long long ax = P.poly[2 * j], ay = (P.poly[2 * j + 1] + (XY_ONE >> 1)) >> XY_SHIFT;
+        const long long bx = P.poly[2 * i], by = (P.poly[2 * i + 1] + (XY_ONE >> 1)) >> XY_SHIFT;
+        raster_edge(bm, ax, (int)ay, bx, (int)by);
+    }
+    __syncthreads();
+    resolve_rows(bm, tid, nth);
+    __syncthreads();
+    // ---- 2. navigable window; obstacles_in_cone = cone & ~nav; visible = cone & nav
+    for (int i = tid; i < plane_words; i += nth) {
+        const int ly = i / words, lw = i - ly * words;
+        unsigned c = cone[i];
+        if (lw == words - 1) c &= last_mask;
+        cone[i] = c;
+        const unsigned n = load_window_word(mp.navigable + eoff, S, mp.stride, ox, oy, ly, lw);
+        nav[i] = n;
+        obst[i] = c & ~n;
+        vis[i] = c & n;
+        par[i] = 0u;
+    }
+    __syncthreads();
+    // ---- 3. external contours (SIMPLE) of the obstacle blobs: wave 0
+    if (wave == 0) {
+        ContourSink sink;
+        sink.pts = pts; sink.start = cstart; sink.len = clen; sink.cap_pts = sc.cap_pts; sink.cap_contours = sc.cap_contours;
+        sink.n_pts = 0; sink.n_contours = 0; sink.overflow = 0;
+        Bits b{obst, words, wn, wn};
+        scan_external(b, traced, neg, 0, wn - 1, 2, sink);
+        if (lane == 0) { sh_i[0] = sink.n_contours; sh_i[1] = sink.n_pts; sh_i[2] = sink.overflow; }
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int n_obst = sh_i[0];
+    if (sh_i[2]) { if (tid == 0) status[0] = 1; return; }
+    if (tid == 0) { status[1] = n_obst; }
+    if (n_obst == 0) return;  // "no obstacles in the cone": fog returned unchanged -> nothing revealed this step
+    // ---- 4. shadow-casting points: convex blobs contribute their two angular extremes, the others every vertex
+    const int acx = P.ax - ox, acy = P.ay - oy;  // agent in window coordinates (contour points are window-local)
+    for (int c = 0; c < n_obst; c++) {
+        const int n = clen[c];
+        const int2* cp = pts + cstart[c];
+        if (tid == 0) sh_i[4] = 0;
+        __syncthreads();
+        // cv::isContourConvex on the SIMPLE vertices
+        for (int i = tid; i < n; i += nth) {
+            const int2 p2 = cp[(i - 2 + 2 * n) % n], p1 = cp[(i - 1 + n) % n], p = cp[i];
+            const int dx0 = p1.x - p2.x, dy0 = p1.y - p2.y, dx = p.x - p1.x, dy = p.y - p1.y;
+            const int dxdy0 = dx * dy0, dydx0 = dy * dx0;
+            atomicOr(&sh_i[4], dydx0 > dxdy0 ? 1 : (dydx0 < dxdy0 ? 2 : 3));
+        }
+        __syncthreads();
+        const bool convex = n > 0 && sh_i[4] != 3;
+        const int base = sh_i[3];
+        if (convex) {
+            if (tid == 0) {
+                // get_two_farthest_points: rotate (pt - source) by the upstream matrix, atan2, first argmin / argmax
+                int imin = 0, imax = 0;
+                double amin = 0, amax = 0;
+                for (int i = 0; i < n; i++) {
+                    const double px = (double)(cp[i].x - acx), py = (double)(cp[i].y - acy);
+                    const double rx = __dadd_rn(__dmul_rn(px, P.rot_c), __dmul_rn(py, P.rot_s));
+                    const double ry = __dadd_rn(__dmul_rn(px, -P.rot_s), __dmul_rn(py, P.rot_c));
+                    const double a = atan2(ry, rx);
+                    if (i == 0 || a < amin) { if (i == 0 || a < amin) { amin = a; imin = i; } }
+                    if (i == 0 || a > amax) { amax = a; imax = i; }
+                }
+                lines[base] = make_int4(cp[imin].x, cp[imin].y, 0, 0);
+                lines[base + 1] = make_int4(cp[imax].x, cp[imax].y, 0, 0);
+                sh_i[3] = base + 2;
+            }
+        } else {
+            for (int i = tid; i < n; i += nth) lines[base + i] = make_int4(cp[i].x, cp[i].y, 0, 0);
+            if (tid == 0) sh_i[3] = base + n;
+        }
+        __syncthreads();
+    }
+    const int n_lines = sh_i[3];
+    if (tid == 0) status[2] = n_lines;
+    // ---- 5. cut the visible mask with 2-px lines from every point away from the agent (cv2.polylines, color 0)
+    for (int i = tid; i < n_lines; i += nth) {
+        const int px = lines[i].x + ox, py = lines[i].y + oy;  // image coordinates
+        const double ang = atan2((double)(py - P.ay), (double)(px - P.ax));
+        const double ex = __dadd_rn((double)px, __dmul_rn(P.line_len, cos(ang)));
+        const double ey = __dadd_rn((double)py, __dmul_rn(P.line_len, sin(ang)));
+        thick_line2_clear(vis, W, px, py, (int)ex, (int)ey);  // .astype(np.int32): truncation
+    }
+    __syncthreads();
+    // ---- 6. external contours of what is left; keep the one nearest the agent (|pointPolygonTest|, <= 3 px)
+    for (int i = tid; i < 2 * plane_words; i += nth) traced[i] = 0u;  // traced + neg are adjacent
+    __syncthreads();
+    if (wave == 0) {
+        ContourSink sink;
+        sink.pts = pts; sink.start = cstart; sink.len = clen; sink.cap_pts = sc.cap_pts; sink.cap_contours = sc.cap_contours;
+        sink.n_pts = 0; sink.n_contours = 0; sink.overflow = 0;
+        Bits b{vis, words, wn, wn};
+        scan_external(b, traced, neg, 0, wn - 1, 2, sink);
+        int best = -1;
+        double best_d2 = 0;
+        if (!sink.overflow) {
+            // OpenCV lists contours in reverse discovery order and the loop keeps the FIRST strict minimum:
+            // walking discovery order with <= selects the same contour
+            for (int c = 0; c < sink.n_contours; c++) {
+                double d2; int inside;
+                wave_point_polygon(pts + cstart[c], clen[c], acx, acy, &d2, &inside);
+                if (best < 0 || d2 <= best_d2) { best = c; best_d2 = d2; }
+            }
+        }
+        if (lane == 0) { sh_i[5] = best; sh_i[6] = sink.overflow; sh_i[7] = (best >= 0 && sqrt(best_d2) > 3.0) ? 1 : 0; }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (sh_i[6]) { if (tid == 0) status[0] = 1; return; }
+    const int best = sh_i[5];
+    if (best < 0 || sh_i[7]) return;  // nothing visible / closest contour too far away
+    // ---- 7. drawContours(fog, [visible_area], 0, 1, -1): fill the chosen outline (component + enclosed holes)
+    {
+        LdsBitmap fb;
+        fb.solid = fill; fb.parity = par; fb.rows = wn; fb.cols = wn; fb.words = words;  // window-local polygon
+        const int n = clen[best];
+        const int2* cp = pts + cstart[best];
+        for (int i = tid; i < n; i += nth) {
+            const int2 a = cp[i == 0 ? n - 1 : i - 1], b = cp[i];
+            raster_edge(fb, (long long)a.x << XY_SHIFT, a.y, (long long)b.x << XY_SHIFT, b.y);
+        }
+        __syncthreads();
+        resolve_rows(fb, tid, nth);
+        __syncthreads();
+    }
+    // ---- 8. dilate 3x3 (obstacle_map.py:125), keep navigable cells (:127), OR into the explored plane (:126)
+    unsigned* expl = mp.explored + eoff;
+    for (int i = tid; i < plane_words; i += nth) {
+        const int ly = i / words, lw = i - ly * words;
+        unsigned acc = 0;
+        for (int dy = -1; dy <= 1; dy++) {
+            const int yy = ly + dy;
+            if ((unsigned)yy >= (unsigned)wn) continue;
+            unsigned c = fill[yy * words + lw], p = lw > 0 ? fill[yy * words + lw - 1] : 0u,
+                     n = lw + 1 < words ? fill[yy * words + lw + 1] : 0u;
+            if (lw == words - 1) c &= last_mask;
+            if (lw + 1 == words - 1) n &= last_mask;
+            acc |= hdilate(p, c, n, 1);
+        }
+        if (lw == words - 1) acc &= last_mask;
+        acc &= nav[i];
+        if (!acc) continue;
+        // scatter the window word into (up to) two image words
+        const int y = oy + ly;
+        if ((unsigned)y >= (unsigned)S) continue;
+        const int x0 = ox + lw * 32;
+        const int wi = x0 >= 0 ? (x0 >> 5) : -((-x0 + 31) >> 5);
+        const int sh = x0 - wi * 32;
+        const unsigned lo = acc << sh, hi = sh ? (acc >> (32 - sh)) : 0u;
+        if (lo && wi >= 0 && wi < mp.stride) atomicOr(&expl[(size_t)y * mp.stride + wi], lo & tail_mask(S, wi));
+        if (hi && wi + 1 >= 0 && wi + 1 < mp.stride) atomicOr(&expl[(size_t)y * mp.stride + wi + 1], hi & tail_mask(S, wi + 1));
+    }
+    if (tid == 0) {
+        int* bb = sc.bbox + (size_t)P.env * 4;
+        atomicMin(&bb[0], max(oy, 0)); atomicMax(&bb[1], min(oy + wn - 1, S - 1));
+        atomicMin(&bb[2], max(ox, 0)); atomicMax(&bb[3], min(ox + wn - 1, S - 1));
+    }
+}
+
+// ================================================================================================ explored selection
+// obstacle_map.py:128-146: if the explored area has split into several external components keep the one that contains
+// the agent (else the nearest), redrawn filled.  One workgroup per environment; wave 0 scans.
+struct SelectScratch {
+    unsigned* traced; unsigned* neg;       // [n_envs][S][stride] each
+    unsigned* fill_solid; unsigned* fill_par;
+    int2* pts; int* starts; int* lens; int* status;  // status [n_envs][4]: overflow, n contours, chosen, refilled
+    int cap_pts, cap_contours;
+};
+
+__global__ __launch_bounds__(256) void explored_select_kernel(const FogParams* __restrict__ prm, MapPlanes mp,
+                                                              SelectScratch sc, const int* __restrict__ bbox) {
+    const FogParams& P = prm[blockIdx.x];
+    if (P.n_poly <= 0) return;
+    __shared__ int sh_i[8];
+    const int S = mp.S, stride = mp.stride;
+    const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const size_t eoff = (size_t)P.env * S * stride;
+    unsigned* expl = mp.explored + eoff;
+    unsigned* traced = sc.traced + eoff;
+    unsigned* neg = sc.neg + eoff;
+    const int* bb = bbox + (size_t)P.env * 4;
+    const int y_lo = max(bb[0] - 1, 0), y_hi = min(bb[1] + 1, S - 1);
+    if (y_lo > y_hi) return;  // nothing explored yet
+    for (int i = tid + y_lo * stride; i < (y_hi + 1) * stride; i += nth) { traced[i] = 0u; neg[i] = 0u; }
+    __threadfence();
+    __syncthreads();
+    int2* pts = sc.pts + (size_t)P.env * sc.cap_pts;
+    int* cstart = sc.starts + (size_t)P.env * sc.cap_contours;
+    int* clen = sc.lens + (size_t)P.env * sc.cap_contours;
+    int* status = sc.status + (size_t)P.env * 4;
+    if (wave == 0) {
+        ContourSink sink;
+        sink.pts = pts; sink.start = cstart; sink.len = clen; sink.cap_pts = sc.cap_pts; sink.cap_contours = sc.cap_contours;
+        sink.n_pts = 0; sink.n_contours = 0; sink.overflow = 0;
+        Bits b{expl, stride, S, S};
+        scan_external(b, traced, neg, y_lo, y_hi, 2, sink);
+        int chosen = -1;
+        if (!sink.overflow && sink.n_contours > 1) {
+            // OpenCV order = reverse discovery.  First contour with dist >= 0 wins outright; otherwise the first strict
+            // minimum of |dist| (best_idx starts at 0 = the last discovered contour).
+            double min_d2 = 1e300;
+            chosen = sink.n_contours - 1;
+            for (int c = sink.n_contours - 1; c >= 0; c--) {
+                double d2; int inside;
+                wave_point_polygon(pts + cstart[c], clen[c], P.ax, P.ay, &d2, &inside);
+                if (inside || d2 == 0.0) { chosen = c; break; }   // dist >= 0: inside or on the outline
+                if (d2 < min_d2) { min_d2 = d2; chosen = c; }
+            }
+        }
+        if (lane == 0) { sh_i[0] = sink.n_contours; sh_i[1] = sink.overflow; sh_i[2] = chosen; }
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) { status[0] = sh_i[1]; status[1] = sh_i[0]; status[2] = sh_i[2]; status[3] = 0; }
+    if (sh_i[1] || sh_i[0] <= 1) return;
+    // redraw the chosen outline filled on an empty plane (global-memory bitmaps; rare path)
+    const int chosen = sh_i[2];
+    unsigned* fs = sc.fill_solid + eoff;
+    unsigned* fp = sc.fill_par + eoff;
+    for (int i = tid; i < S * stride; i += nth) { fs[i] = 0u; fp[i] = 0u; }
+    __threadfence();
+    __syncthreads();
+    LdsBitmap fb;
+    fb.solid = fs; fb.parity = fp; fb.rows = S; fb.cols = S; fb.words = stride;
+    const int n = clen[chosen];
+    const int2* cp = pts + cstart[chosen];
+    for (int i = tid; i < n; i += nth) {
+        const int2 a = cp[i == 0 ? n - 1 : i - 1], b = cp[i];
+        raster_edge(fb, (long long)a.x << XY_SHIFT, a.y, (long long)b.x << XY_SHIFT, b.y);
+    }
+    __threadfence();
+    __syncthreads();
+    resolve_rows(fb, tid, nth);
+    __threadfence();
+    __syncthreads();
+    for (int i = tid; i < S * stride; i += nth) expl[i] = fs[i] & tail_mask(S, i % stride);
+    if (tid == 0) status[3] = 1;
+}
+
+// ================================================================================================ frontiers
+// obstacle_map.py:155-169 + frontier_exploration.detect_frontier_waypoints.
+struct FrontierScratch {
+    unsigned* explored_d;                  // [n_envs][S][stride]  dilate5(explored) & navigable, then "filtered"
+    unsigned* unexplored;                  // [n_envs][S][stride]
+    unsigned* traced; unsigned* neg;       // [n_envs][S][stride]
+    unsigned* fill_solid; unsigned* fill_par;
+    int2* pts; int* starts; int* lens;     // chain points
+    unsigned char* bad;                    // [n_envs][cap_pts]
+    int* pieces;                           // [n_envs][cap_contours * 6]: (chain base, chain n, s1, l1, s2, l2)
+    double* out_xy;                        // [n_envs][cap_frontiers][2]
+    int* out_n;                            // [n_envs][4]: n frontiers, overflow, n contours, n chain points
+    int cap_pts, cap_contours, cap_frontiers;
+    double area_thresh;
+};
+
+__device__ inline unsigned ring_all_set(const unsigned* plane, int S, int stride, int tid, int nth) {
+    // every pixel of the image border ring set?  returns 0/1 partial (thread-local AND)
+    unsigned ok = 1;
+    for (int i = tid; i < S; i += nth) {
+        ok &= bit_get(plane, stride, S, S, i, 0) & bit_get(plane, stride, S, S, i, S - 1) &
+              bit_get(plane, stride, S, S, 0, i) & bit_get(plane, stride, S, S, S - 1, i);
+    }
+    return ok;
+}
+
+__device__ inline int reflect101(int i, int n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * n - 2 - i;
+    return i < 0 ? 0 : i;
+}
+
+__global__ __launch_bounds__(256) void frontier_kernel(const FogParams* __restrict__ prm, MapPlanes mp, FrontierScratch sc,
+                                                       const int* __restrict__ bbox) {
+    const FogParams& P = prm[blockIdx.x];
+    if (P.n_poly <= 0) return;
+    __shared__ int sh_i[16];
+    const int S = mp.S, stride = mp.stride;
+    const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const size_t eoff = (size_t)P.env * S * stride;
+    const unsigned* expl = mp.explored + eoff;
+    const unsigned* navp = mp.navigable + eoff;
+    unsigned* ed = sc.explored_d + eoff;
+    unsigned* un = sc.unexplored + eoff;
+    unsigned* traced = sc.traced + eoff;
+    unsigned* neg = sc.neg + eoff;
+    int2* pts = sc.pts + (size_t)P.env * sc.cap_pts;
+    int* cstart = sc.starts + (size_t)P.env * sc.cap_contours;
+    int* clen = sc.lens + (size_t)P.env * sc.cap_contours;
+    unsigned char* bad = sc.bad + (size_t)P.env * sc.cap_pts;
+    int* pieces = sc.pieces + (size_t)P.env * sc.cap_contours * 6;
+    double* out_xy = sc.out_xy + (size_t)P.env * sc.cap_frontiers * 2;
+    int* out_n = sc.out_n + (size_t)P.env * 4;
+    if (tid < 16) sh_i[tid] = 0;
+    if (tid == 0) sh_i[0] = 1;
+    __syncthreads();
+    // ---- a. explored_d = dilate(explored, 5x5) & navigable ; unexplored = navigable & ~explored_d   (full planes)
+    unsigned ring_ok = 1;
+    for (int idx = tid; idx < S * stride; idx += nth) {
+        const int y = idx / stride, wi = idx - y * stride;
+        unsigned acc = 0;
+        for (int dy = -2; dy <= 2; dy++)
+            acc |= hdilate(row_word(expl, stride, S, y + dy, wi - 1), row_word(expl, stride, S, y + dy, wi),
+                           row_word(expl, stride, S, y + dy, wi + 1), 2);
+        const unsigned nv = navp[idx];
+        acc &= nv & tail_mask(S, wi);
+        ed[idx] = acc;
+        un[idx] = nv & ~acc;
+        traced[idx] = 0u;
+        neg[idx] = 0u;
+    }
+    __threadfence();
+    __syncthreads();
+    // ---- b. filter_out_small_unexplored.  Exact shortcut: when the border ring of `unexplored` is fully set, that one
+    // component encloses every other one, RETR_EXTERNAL returns it alone and its contour area is (S-1)^2.
+    ring_ok = ring_all_set(un, S, stride, tid, nth);
+    if (!ring_ok) atomicAnd(&sh_i[0], 0);
+    __syncthreads();
+    const bool shortcut = sh_i[0] && ((double)(S - 1) * (double)(S - 1) >= sc.area_thresh);
+    if (!shortcut) {
+        if (wave == 0) {
+            ContourSink sink;
+            sink.pts = pts; sink.start = cstart; sink.len = clen; sink.cap_pts = sc.cap_pts; sink.cap_contours = sc.cap_contours;
+            sink.n_pts = 0; sink.n_contours = 0; sink.overflow = 0;
+            Bits b{un, stride, S, S};
+            scan_external(b, traced, neg, 0, S - 1, 2, sink);
+            if (lane == 0) { sh_i[1] = sink.n_contours; sh_i[2] = sink.overflow; }
+        }
+        __threadfence();
+        __syncthreads();
+        if (sh_i[2]) { if (tid == 0) { out_n[0] = 0; out_n[1] = 1; } return; }
+        const int nc = sh_i[1];
+        unsigned* fs = sc.fill_solid + eoff;
+        unsigned* fp = sc.fill_par + eoff;
+        for (int c = 0; c < nc; c++) {
+            const int n = clen[c];
+            const int2* cp = pts + cstart[c];
+            // cv::contourArea (exact: integer cross products accumulate without rounding in a double)
+            if (tid == 0) { sh_i[3] = 0; sh_i[4] = 0; }
+            __syncthreads();
+            long long part = 0;
+            for (int i = tid; i < n; i += nth) {
+                const int2 a = cp[i == 0 ? n - 1 : i - 1], b = cp[i];
+                part += (long long)a.x * b.y - (long long)a.y * b.x;
+            }
+            // 64-bit sum through two 32-bit shared atomics is awkward; use a global-memory-free tree: wave shuffle + LDS
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+            __shared__ long long wsum[4];
+            if (lane == 0) wsum[wave] = part;
+            __syncthreads();
+            const long long twice = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            const double area = fabs((double)twice * 0.5);
+            if (!(area < sc.area_thresh)) { __syncthreads(); continue; }
+            // mask = filled outline; keep it only if every covered cell is unexplored-navigable
+            for (int i = tid; i < S * stride; i += nth) { fs[i] = 0u; fp[i] = 0u; }
+            __threadfence();
+            __syncthreads();
+            LdsBitmap fb;
+            fb.solid = fs; fb.parity = fp; fb.rows = S; fb.cols = S; fb.words = stride;
+            for (int i = tid; i < n; i += nth) {
+                const int2 a = cp[i == 0 ? n - 1 : i - 1], b = cp[i];
+                raster_edge(fb, (long long)a.x << XY_SHIFT, a.y, (long long)b.x << XY_SHIFT, b.y);
+            }
+            __threadfence();
+            __syncthreads();
+            resolve_rows(fb, tid, nth);
+            __threadfence();
+            __syncthreads();
+            for (int i = tid; i < S * stride; i += nth) {
+                const unsigned m = fs[i] & tail_mask(S, i % stride);
+                if (m & ~un[i]) atomicOr(&sh_i[3], 1);  // covers something that is not unexplored
+                if (m) atomicOr(&sh_i[4], 1);
+            }
+            __syncthreads();
+            if (sh_i[4] && !sh_i[3])
+                for (int i = tid; i < S * stride; i += nth) ed[i] |= fs[i] & tail_mask(S, i % stride);
+            __threadfence();
+            __syncthreads();
+        }
+        for (int i = tid; i < S * stride; i += nth) { traced[i] = 0u; neg[i] = 0u; }
+        __threadfence();
+        __syncthreads();
+    }
+    // ---- c. border chain (CHAIN_APPROX_NONE) of the filtered explored mask
+    const int* bb = bbox + (size_t)P.env * 4;
+    if (wave == 0) {
+        ContourSink sink;
+        sink.pts = pts; sink.start = cstart; sink.len = clen; sink.cap_pts = sc.cap_pts; sink.cap_contours = sc.cap_contours;
+        sink.n_pts = 0; sink.n_contours = 0; sink.overflow = 0;
+        Bits b{ed, stride, S, S};
+        const int y_lo = shortcut ? max(bb[0] - 3, 0) : 0, y_hi = shortcut ? min(bb[1] + 3, S - 1) : S - 1;
+        scan_external(b, traced, neg, y_lo, y_hi, 1, sink);
+        if (lane == 0) { sh_i[5] = sink.n_contours; sh_i[6] = sink.n_pts; sh_i[7] = sink.overflow; }
+    }
+    __threadfence();
+    __syncthreads();
+    const int nc = sh_i[5], npts_all = sh_i[6];
+    if (sh_i[7]) { if (tid == 0) { out_n[0] = 0; out_n[1] = 1; } return; }
+    // ---- d. a chain point is "bad" when no unexplored-navigable cell lies in its 3x3 neighbourhood
+    //         (cv2.blur 3x3, BORDER_REFLECT_101, of 255*(navigable & ~filtered) is zero there)
+    for (int i = tid; i < npts_all; i += nth) {
+        const int2 p = pts[i];
+        unsigned any = 0;
+        for (int dy = -1; dy <= 1; dy++) {
+            const int yy = reflect101(p.y + dy, S);
+            for (int dx = -1; dx <= 1; dx++) {
+                const int xx = reflect101(p.x + dx, S);
+                any |= bit_get(navp, stride, S, S, xx, yy) & (1u ^ bit_get(ed, stride, S, S, xx, yy));
+            }
+        }
+        bad[i] = any ? 0 : 1;
+    }
+    __threadfence();
+    __syncthreads();
+    // ---- e. frontier runs + arc-length midpoints.  Contours in OpenCV order (reverse discovery); the chain handed to
+    // contour_to_frontiers is the contour rotated by one (interpolate_contour emits end points only).
+    // Thread 0 lists the kept pieces; then one thread per piece computes its midpoint.
+    if (tid == 0) {
+        // np.split(chain, bad) -> pieces [0,b0) [b0,b1) ... [b_last,n); a piece is kept when it has more than two
+        // points (its leading bad point is then dropped) -- or is the head piece of a chain whose ends both lie on a
+        // frontier (front_last_split), in which case the LAST kept piece is finally glued in front of it.
+        int np = 0, overflow = 0;
+        for (int c = nc - 1; c >= 0; c--) {
+            const int n = clen[c], base = cstart[c];
+            if (n < 2) continue;  // a single-pixel contour interpolates to nothing
+            auto is_bad = [&](int j) { return bad[base + (j + 1) % n] != 0; };  // chain rotated by one
+            int nbad = 0, first_bad = -1, last_bad = -1;
+            for (int j = 0; j < n; j++)
+                if (is_bad(j)) { if (first_bad < 0) first_bad = j; last_bad = j; nbad++; }
+            const bool fls = nbad > 0 && first_bad != 0 && last_bad < n - 2;
+            int piece_s = 0, idx = 0, first_slot = -1, kept = 0;
+            for (int j = 0; j <= n; j++) {
+                if (j == n || is_bad(j)) {
+                    const int len = j - piece_s;
+                    if (len > 2 || (idx == 0 && fls)) {
+                        if (np < sc.cap_contours) {
+                            int* pc = pieces + 6 * np;
+                            pc[0] = base; pc[1] = n;
+                            pc[2] = idx == 0 ? piece_s : piece_s + 1; pc[3] = idx == 0 ? len : len - 1;
+                            pc[4] = 0; pc[5] = 0;
+                            if (kept == 0) first_slot = np;
+                            np++; kept++;
+                        } else overflow = 1;
+                    }
+                    piece_s = j;
+                    idx++;
+                }
+            }
+            if (kept > 1 && fls) {  // kept[0] = concat(kept.pop(), kept[0])
+                int* head = pieces + 6 * first_slot;
+                int* tail = pieces + 6 * (np - 1);
+                const int hs = head[2], hl = head[3];
+                head[2] = tail[2]; head[3] = tail[3]; head[4] = hs; head[5] = hl;
+                np--;
+            }
+        }
+        sh_i[8] = np; sh_i[9] = overflow;
+    }
+    __threadfence();
+    __syncthreads();
+    const int np = sh_i[8];
+    for (int f = tid; f < np; f += nth) {
+        const int* pc = pieces + 6 * f;
+        const int base = pc[0], n = pc[1], s1 = pc[2], l1 = pc[3], s2 = pc[4], l2 = pc[5];
+        const int m = l1 + l2;
+        auto q = [&](int j) { const int k = j < l1 ? s1 + j : s2 + (j - l1); return pts[base + (k + 1) % n]; };
+        double ox_ = 0, oy_ = 0;
+        if (m < 2) {
+            if (m == 1) { const int2 p = q(0); ox_ = p.x; oy_ = p.y; }
+        } else {
+            // get_frontier_midpoint: np.cumsum of segment lengths (sequential f64), first index with cum > total/2
+            double total = 0;
+            for (int k = 0; k + 1 < m; k++) {
+                const int2 a = q(k), b = q(k + 1);
+                const double ddx = (double)(a.x - b.x), ddy = (double)(a.y - b.y);
+                total = __dadd_rn(total, sqrt(__dadd_rn(__dmul_rn(ddx, ddx), __dmul_rn(ddy, ddy))));
+            }
+            const double half = total / 2;
+            double cum = 0, upto = 0, seglen = 0;
+            int idx = 0;
+            bool found = false;
+            for (int k = 0; k + 1 < m; k++) {
+                const int2 a = q(k), b = q(k + 1);
+                const double ddx = (double)(a.x - b.x), ddy = (double)(a.y - b.y);
+                const double l = sqrt(__dadd_rn(__dmul_rn(ddx, ddx), __dmul_rn(ddy, ddy)));
+                const double c2 = __dadd_rn(cum, l);
+                if (c2 > half) { idx = k; upto = k > 0 ? cum : 0; seglen = l; found = true; break; }
+                cum = c2;
+            }
+            if (!found) {
+                const int2 a = q(0), b = q(1);
+                const double ddx = (double)(a.x - b.x), ddy = (double)(a.y - b.y);
+                idx = 0; upto = 0; seglen = sqrt(__dadd_rn(__dmul_rn(ddx, ddx), __dmul_rn(ddy, ddy)));
+            }
+            const double prop = __ddiv_rn(__dsub_rn(half, upto), seglen);
+            const int2 a = q(idx), b = q(idx + 1);
+            ox_ = __dadd_rn((double)a.x, __dmul_rn(prop, (double)(b.x - a.x)));
+            oy_ = __dadd_rn((double)a.y, __dmul_rn(prop, (double)(b.y - a.y)));
+        }
+        if (f < sc.cap_frontiers) { out_xy[2 * f] = ox_; out_xy[2 * f + 1] = oy_; }
+    }
+    if (tid == 0) {
+        out_n[0] = np < sc.cap_frontiers ? np : sc.cap_frontiers;
+        out_n[1] = sh_i[9] || np > sc.cap_frontiers;
+        out_n[2] = nc; out_n[3] = npts_all;
+    }
+}
+
+}  // namespace vlfm
+
+using namespace vlfm;
+
+extern "C" int vlfm_bits_pack(const uint8_t* d_src, uint32_t* d_dst, int planes, int rows, int cols, void* stream) {
+    if (!d_src || !d_dst || planes <= 0 || rows <= 0 || cols <= 0) return fail(VLFM_ERR_INVALID, "bits_pack: bad argument");
+    const int stride = (cols + 31) / 32;
+    hipLaunchKernelGGL(pack_u8_kernel, dim3((stride + 63) / 64, rows, planes), dim3(64), 0, (hipStream_t)stream, d_src,
+                       d_dst, rows, cols, stride);
+    return check_launch("pack_u8_kernel");
+}
+
+extern "C" int vlfm_bits_unpack(const uint32_t* d_src, uint8_t* d_dst, int planes, int rows, int cols, void* stream) {
+    if (!d_src || !d_dst || planes <= 0 || rows <= 0 || cols <= 0) return fail(VLFM_ERR_INVALID, "bits_unpack: bad argument");
+    const int stride = (cols + 31) / 32;
+    hipLaunchKernelGGL(unpack_u8_kernel, dim3((cols + 255) / 256, rows, planes), dim3(256), 0, (hipStream_t)stream,
+                       d_src, d_dst, rows, cols, stride);
+    return check_launch("unpack_u8_kernel");
+}
+
+extern "C" int vlfm_bits_dilate(const uint32_t* d_src, uint32_t* d_dst, int planes, int rows, int cols, int kernel_w,
+                                int kernel_h, void* stream) {
+    if (!d_src || !d_dst || planes <= 0 || rows <= 0 || cols <= 0 || kernel_w < 1 || kernel_h < 1 || !(kernel_w & 1) ||
+        !(kernel_h & 1) || kernel_w > 63)
+        return fail(VLFM_ERR_INVALID, "bits_dilate: bad argument (odd kernel sizes, width <= 63)");
+    const int stride = (cols + 31) / 32;
+    VLFM_TIMED("dilate_bits_kernel", stream);
+    hipLaunchKernelGGL(dilate_bits_kernel, dim3((rows * stride + 255) / 256, 1, planes), dim3(256), 0,
+                       (hipStream_t)stream, d_src, d_dst, (unsigned*)nullptr, (const int*)nullptr, rows, cols, stride,
+                       kernel_w / 2, kernel_h / 2, 0);
+    return check_launch("dilate_bits_kernel");
+}
+
+extern "C" int vlfm_find_contours_external(const uint32_t* d_img, int planes, int rows, int cols, int method,
+                                           uint32_t* d_scratch /* [planes][2][rows][stride] */, int32_t* d_pts,
+                                           int cap_pts, int32_t* d_starts, int32_t* d_lens, int cap_contours,
+                                           int32_t* d_counts, void* stream) {
+    if (!d_img || !d_scratch || !d_pts || !d_starts || !d_lens || !d_counts || planes <= 0 || rows <= 0 || cols <= 0 ||
+        (method != 1 && method != 2) || cols > 2048)
+        return fail(VLFM_ERR_INVALID, "find_contours_external: bad argument (method 1|2, cols <= 2048)");
+    const int stride = (cols + 31) / 32;
+    unsigned* traced = d_scratch;
+    unsigned* neg = d_scratch + (size_t)planes * rows * stride;
+    VLFM_TIMED("find_contours_kernel", stream);
+    hipLaunchKernelGGL(find_contours_kernel, dim3(planes), dim3(64), 0, (hipStream_t)stream, d_img, traced, neg, rows,
+                       cols, stride, method, reinterpret_cast<int2*>(d_pts), cap_pts, d_starts, d_lens, cap_contours,
+                       d_counts);
+    return check_launch("find_contours_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+struct ScratchLayout {
+    size_t plane_words, total;
+    size_t off_planes[6], off_pts, off_lines, off_starts, off_lens, off_bad, off_pieces, off_status;
+};
+ScratchLayout layout(int n_envs, int S, int cap_pts, int cap_contours) {
+    ScratchLayout L;
+    const size_t stride = (S + 31) / 32;
+    L.plane_words = (size_t)n_envs * S * stride;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) / 256 * 256; return r; };
+    for (int k = 0; k < 6; k++) L.off_planes[k] = take(L.plane_words * 4);
+    L.off_pts = take((size_t)n_envs * cap_pts * sizeof(int2));
+    L.off_lines = take((size_t)n_envs * cap_pts * sizeof(int4));
+    L.off_starts = take((size_t)n_envs * cap_contours * 4);
+    L.off_lens = take((size_t)n_envs * cap_contours * 4);
+    L.off_bad = take((size_t)n_envs * cap_pts);
+    L.off_pieces = take((size_t)n_envs * cap_contours * 6 * 4);
+    L.off_status = take((size_t)n_envs * 16 * 4);
+    L.total = o;
+    return L;
+}
+}  // namespace
+
+extern "C" size_t vlfm_obstacle_scratch_bytes(int n_envs, int map_size, int cap_pts, int cap_contours) {
+    if (n_envs <= 0 || map_size <= 0 || cap_pts <= 0 || cap_contours <= 0) return 0;
+    return layout(n_envs, map_size, cap_pts, cap_contours).total;
+}
+
+extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, int n, const uint32_t* d_obstacle,
+                                                uint32_t* d_navigable, uint32_t* d_explored, int32_t* d_bbox,
+                                                int n_envs, int map_size, int kernel_size, int fog_radius,
+                                                double area_thresh_px, void* d_scratch, size_t scratch_bytes,
+                                                int cap_pts, int cap_contours, double* d_frontiers, int cap_frontiers,
+                                                int32_t* d_counts, int update_obstacles, int explore, void* stream) {
+    if (n == 0) return VLFM_OK;
+    if (!d_prm || !d_obstacle || !d_navigable || !d_explored || !d_bbox || !d_scratch || !d_frontiers || !d_counts ||
+        n < 0 || map_size <= 0 || map_size > 2048 || kernel_size < 1 || !(kernel_size & 1) || kernel_size > 63 ||
+        fog_radius <= 0)
+        return fail(VLFM_ERR_INVALID, "obstacle_map_update_batched: bad argument");
+    const ScratchLayout L = layout(n_envs, map_size, cap_pts, cap_contours);
+    if (scratch_bytes < L.total) return fail(VLFM_ERR_CAPACITY, "obstacle_map_update_batched: scratch too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int stride = (map_size + 31) / 32;
+    unsigned char* base = (unsigned char*)d_scratch;
+    MapPlanes mp{d_obstacle, d_navigable, d_explored, map_size, stride};
+    unsigned* planes[6];
+    for (int k = 0; k < 6; k++) planes[k] = (unsigned*)(base + L.off_planes[k]);
+    int2* pts = (int2*)(base + L.off_pts);
+    int4* lines = (int4*)(base + L.off_lines);
+    int* starts = (int*)(base + L.off_starts);
+    int* lens = (int*)(base + L.off_lens);
+    int* status = (int*)(base + L.off_status);
+    if (update_obstacles || explore) {
+        VLFM_TIMED("navigable_kernel", s);
+        hipLaunchKernelGGL(navigable_kernel, dim3((map_size * stride + 255) / 256, 1, n), dim3(256), 0, s, d_prm, mp,
+                           kernel_size / 2, update_obstacles, explore);
+    }
+    int rc = check_launch("navigable_kernel");
+    if (rc != VLFM_OK || !explore) return rc;
+    {
+        FogScratch fs{pts, starts, lens, lines, status, d_bbox, cap_pts, cap_contours};
+        const int wn = 2 * fog_radius + 5, words = (wn + 31) / 32;
+        const size_t lds = (size_t)8 * wn * words * 4 + 64;
+        if (lds > 160 * 1024) return fail(VLFM_ERR_CAPACITY, "obstacle_map_update_batched: fog window too large for LDS");
+        VLFM_TIMED("fog_of_war_kernel", s);
+        hipLaunchKernelGGL(fog_of_war_kernel, dim3(n), dim3(256), lds, s, d_prm, mp, fs);
+    }
+    rc = check_launch("fog_of_war_kernel");
+    if (rc != VLFM_OK) return rc;
+    {
+        SelectScratch ss{planes[0], planes[1], planes[2], planes[3], pts, starts, lens, status + (size_t)n_envs * 4,
+                         cap_pts, cap_contours};
+        VLFM_TIMED("explored_select_kernel", s);
+        hipLaunchKernelGGL(explored_select_kernel, dim3(n), dim3(256), 0, s, d_prm, mp, ss, (const int*)d_bbox);
+    }
+    rc = check_launch("explored_select_kernel");
+    if (rc != VLFM_OK) return rc;
+    {
+        FrontierScratch fr{planes[4], planes[5], planes[0], planes[1], planes[2], planes[3], pts, starts, lens,
+                           (unsigned char*)(base + L.off_bad), (int*)(base + L.off_pieces), d_frontiers, d_counts,
+                           cap_pts, cap_contours, cap_frontiers, area_thresh_px};
+        VLFM_TIMED("frontier_kernel", s);
+        hipLaunchKernelGGL(frontier_kernel, dim3(n), dim3(256), 0, s, d_prm, mp, fr, (const int*)d_bbox);
+    }
+    return check_launch("frontier_kernel");
+}
+
+extern "C" int vlfm_obstacle_status(const void* d_scratch, int n_envs, int map_size, int cap_pts, int cap_contours,
+                                    int32_t* h_out /* [n_envs][8] */) {
+    if (!d_scratch || !h_out) return fail(VLFM_ERR_INVALID, "obstacle_status: bad argument");
+    const ScratchLayout L = layout(n_envs, map_size, cap_pts, cap_contours);
+    if (hipMemcpy(h_out, (const unsigned char*)d_scratch + L.off_status, (size_t)n_envs * 8 * 4, hipMemcpyDeviceToHost) !=
+        hipSuccess)
+        return check_launch("obstacle_status");
+    return VLFM_OK;
+}

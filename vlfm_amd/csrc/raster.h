@@ -24,17 +24,25 @@ namespace vlfm {
 constexpr int XY_SHIFT = 16;
 constexpr long long XY_ONE = 1LL << XY_SHIFT;
 
+// rows/cols are the extents of the IMAGE the polygon is drawn on (all clipping follows them); the bitmaps may cover
+// only a window of it: wrows x wcols cells whose top-left cell is image cell (ox, oy).  ox = oy = 0 and
+// wrows/wcols = rows/cols is the plain whole-image case.
 struct LdsBitmap {
-    unsigned* solid;   // [rows][words]  OR-accumulated
-    unsigned* parity;  // [rows][words]  XOR-accumulated toggles
+    unsigned* solid;   // [wrows][words]  OR-accumulated
+    unsigned* parity;  // [wrows][words]  XOR-accumulated toggles
     int rows, cols, words;
+    int ox = 0, oy = 0, wrows = -1, wcols = -1;
+    __device__ int win_rows() const { return wrows < 0 ? rows : wrows; }
+    __device__ int win_cols() const { return wcols < 0 ? cols : wcols; }
 };
 
-__device__ inline void bm_or(const LdsBitmap& bm, int y, int x) {
-    atomicOr(&bm.solid[y * bm.words + (x >> 5)], 1u << (x & 31));
+__device__ inline void bm_or(const LdsBitmap& bm, int y, int x) {  // image coordinates
+    const int lx = x - bm.ox, ly = y - bm.oy;
+    if ((unsigned)lx >= (unsigned)bm.win_cols() || (unsigned)ly >= (unsigned)bm.win_rows()) return;
+    atomicOr(&bm.solid[ly * bm.words + (lx >> 5)], 1u << (lx & 31));
 }
-__device__ inline void bm_toggle(const LdsBitmap& bm, int y, int x) {
-    atomicXor(&bm.parity[y * bm.words + (x >> 5)], 1u << (x & 31));
+__device__ inline void bm_toggle_local(const LdsBitmap& bm, int ly, int lx) {
+    atomicXor(&bm.parity[ly * bm.words + (lx >> 5)], 1u << (lx & 31));
 }
 
 // cv::clipLine on 64-bit points against [0,width) x [0,height)
@@ -112,21 +120,27 @@ __device__ inline void raster_edge(const LdsBitmap& bm, long long ax, int ay, lo
     int y0, y1;
     long long xs;
     if (ay < by) { y0 = ay; y1 = by; xs = ax; } else { y0 = by; y1 = ay; xs = bx; }
-    const int ys = y0 < 0 ? 0 : y0;
-    const int ye = y1 > bm.rows ? bm.rows : y1;  // half-open [y0, y1)
+    int ys = y0 < 0 ? 0 : y0;
+    int ye = y1 > bm.rows ? bm.rows : y1;  // half-open [y0, y1), clipped to the image
+    if (ys < bm.oy) ys = bm.oy;            // ... and to the window rows
+    if (ye > bm.oy + bm.win_rows()) ye = bm.oy + bm.win_rows();
     for (int y = ys; y < ye; y++) {
         const long long c = xs + (long long)(y - y0) * dxdy;
         const long long px = c >> XY_SHIFT;  // floor
         if ((c & (XY_ONE - 1)) == 0 && px >= 0 && px < bm.cols) bm_or(bm, y, (int)px);
         long long first = px + 1;  // first pixel strictly right of the crossing
         if (first < 0) first = 0;
-        if (first < bm.cols) bm_toggle(bm, y, (int)first);
+        if (first < bm.cols) {
+            long long lf = first - bm.ox;  // a toggle left of the window flips the whole window row
+            if (lf < 0) lf = 0;
+            if (lf < bm.win_cols()) bm_toggle_local(bm, y - bm.oy, (int)lf);
+        }
     }
 }
 
 // After all edges: coverage[row] = prefix_xor(parity[row]) | solid[row], written back into `solid`.
 __device__ inline void resolve_rows(const LdsBitmap& bm, int tid, int nthreads) {
-    for (int y = tid; y < bm.rows; y += nthreads) {
+    for (int y = tid; y < bm.win_rows(); y += nthreads) {
         unsigned carry = 0;
         for (int w = 0; w < bm.words; w++) {
             unsigned p = bm.parity[y * bm.words + w];

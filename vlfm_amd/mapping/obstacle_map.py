@@ -1,0 +1,265 @@
+"""vlfm.mapping.obstacle_map.ObstacleMap, MI355X-native (reference: /root/reference/vlfm/mapping/obstacle_map.py).
+
+* :class:`ObstacleMapBatch` -- ``n_envs`` obstacle / navigable / explored planes resident in HBM, bit-packed, updated by
+  one kernel pipeline per step for all environments (csrc/depth_ingest.hip + csrc/obstacle_map.hip).
+* :class:`ObstacleMap` -- the reference's class signature (obstacle_map.py:25-34, :55-66) as a drop-in for
+  ``BaseObjectNavPolicy`` (base_objectnav_policy.py:86-92) and ``HabitatMixin._cache_observations``
+  (habitat_policies.py:193-203).
+
+Scalar prologues (agent cell, cone angles) are evaluated in NumPy exactly as the reference does; every per-pixel step is
+a HIP kernel.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Any, List, Optional, Sequence, Union
+
+import numpy as np
+
+from .. import _lib
+from .base_map import BaseMap, require_gpu
+from .value_map import UploadRing, _stream_ptr
+
+
+def _wrap_heading(theta):
+    return (theta + np.pi) % (2 * np.pi) - np.pi
+
+
+class ObstacleMapBatch:
+    CAP_PTS = 16384       # border points per environment and scan
+    CAP_CONTOURS = 2048
+    CAP_FRONTIERS = 256
+
+    def __init__(self, n_envs: int, min_height: float, max_height: float, agent_radius: float, area_thresh: float = 3.0,
+                 hole_area_thresh: int = 100000, size: int = 1000, pixels_per_meter: int = 20, device=None) -> None:
+        import torch
+
+        self.device = require_gpu(device)
+        L = _lib.lib()
+        self.n_envs, self.size, self.pixels_per_meter = n_envs, size, pixels_per_meter
+        self.stride = (size + 31) // 32
+        self._min_height, self._max_height = min_height, max_height
+        self._area_thresh_in_pixels = area_thresh * (pixels_per_meter ** 2)
+        self._hole_area_thresh = hole_area_thresh
+        k = pixels_per_meter * agent_radius * 2
+        self.kernel_size = int(k) + (int(k) % 2 == 0)  # obstacle_map.py:43-45
+        z = lambda: torch.zeros((n_envs, size, self.stride), dtype=torch.int32, device=self.device)  # noqa: E731
+        self.obstacle_bits, self.navigable_bits, self.explored_bits = z(), z(), z()
+        self.bbox = torch.tensor([[size, -1, size, -1]] * n_envs, dtype=torch.int32, device=self.device)
+        nbytes = L.vlfm_obstacle_scratch_bytes(n_envs, size, self.CAP_PTS, self.CAP_CONTOURS)
+        self.scratch = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        self.frontiers_px_dev = torch.zeros((n_envs, self.CAP_FRONTIERS, 2), dtype=torch.float64, device=self.device)
+        self.counts = torch.zeros((n_envs, 4), dtype=torch.int32, device=self.device)
+        self.colmax_keys = None
+        self.status = torch.zeros((n_envs, 2), dtype=torch.int32, device=self.device)
+        self._ring_ingest = UploadRing(self.device, n_envs * ctypes.sizeof(_lib.IngestParams))
+        self._ring_fog = UploadRing(self.device, n_envs * ctypes.sizeof(_lib.FogParams))
+        self.frontiers_ready = False
+        self._explored_u8 = None
+
+    # ------------------------------------------------------------------------------------------ state
+    def reset(self, env_ids: Optional[Sequence[int]] = None) -> None:
+        import torch
+
+        idx = list(range(self.n_envs)) if env_ids is None else list(env_ids)
+        for t in (self.obstacle_bits, self.navigable_bits, self.explored_bits):
+            t[idx] = 0
+        self.bbox[idx] = torch.tensor([self.size, -1, self.size, -1], dtype=torch.int32, device=self.device)
+        self.counts[idx] = 0
+        self.frontiers_ready = False
+        self._explored_u8 = None
+
+    def _unpack(self, bits):
+        import torch
+
+        out = torch.empty((self.n_envs, self.size, self.size), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().vlfm_bits_unpack(bits.data_ptr(), out.data_ptr(), self.n_envs, self.size, self.size,
+                                                  _stream_ptr()), "bits_unpack")
+        return out
+
+    @property
+    def explored(self):
+        """[n_envs,S,S] uint8 view of ObstacleMap.explored_area (unpacked on demand, cached per step)."""
+        if self._explored_u8 is None:
+            self._explored_u8 = self._unpack(self.explored_bits)
+        return self._explored_u8
+
+    # ------------------------------------------------------------------------------------------ step, part 1
+    def ingest(self, depth, tf, min_depth: float, max_depth: float, fx: float, fy: float, want_colmax: bool = False,
+               env_ids: Optional[Sequence[int]] = None, update_obstacles: bool = True):
+        """obstacle_map.py:86-101 for n observations: one pass over the depth images (shared with the value map's
+        column maximum when ``want_colmax``).  Returns the column-max key buffer (or None)."""
+        import torch
+
+        n, H, W = depth.shape
+        tf = np.asarray(tf, np.float64).reshape(n, 4, 4)
+        assert np.array_equal(tf[:, 3, :], np.tile([0.0, 0, 0, 1], (n, 1))), "camera transforms must be affine"
+        prm = (_lib.IngestParams * n)()
+        for k in range(n):
+            p = prm[k]
+            p.tf[:] = tf[k, :3, :].reshape(-1).tolist()
+            p.depth_scale, p.depth_offset, p.depth_max = max_depth - min_depth, min_depth, max_depth
+            p.fx, p.fy = fx, fy
+            p.min_height, p.max_height = self._min_height, self._max_height
+            p.env = k if env_ids is None else env_ids[k]
+            p.scatter = (1 if update_obstacles else 0) | (2 if self._hole_area_thresh == -1 else 0)
+        keys = None
+        if want_colmax:
+            if self.colmax_keys is None or self.colmax_keys.shape != (max(n, self.n_envs), W):
+                self.colmax_keys = torch.zeros((max(n, self.n_envs), W), dtype=torch.int32, device=self.device)
+            keys = self.colmax_keys
+        with torch.cuda.device(self.device):
+            d_prm = self._ring_ingest.upload(prm)
+            _lib.check(_lib.lib().vlfm_depth_ingest_batched(depth.data_ptr(), n, H, W, d_prm.data_ptr(),
+                                                           keys.data_ptr() if keys is not None else None,
+                                                           self.obstacle_bits.data_ptr() if update_obstacles else None,
+                                                           self.size, self.pixels_per_meter, self.status.data_ptr(),
+                                                           _stream_ptr()), "depth_ingest")
+        return keys
+
+    # ------------------------------------------------------------------------------------------ step, part 2
+    def fog_params(self, tf, max_depth: float, topdown_fov: float, env_ids=None, explore=None):
+        """Scalar prologue of obstacle_map.py:115-124 + reveal_fog_of_war's first lines, in NumPy like the reference."""
+        tf = np.asarray(tf, np.float64).reshape(-1, 4, 4)
+        n = tf.shape[0]
+        # BaseMap._xy_to_px (rint) of the camera position -> (col, row)
+        px = np.rint(tf[:, :2, 3][:, ::-1] * self.pixels_per_meter) + self.size // 2
+        px[:, 0] = self.size - px[:, 0]
+        agent = np.ascontiguousarray(px.astype(np.int32))
+        yaw = np.arctan2(tf[:, 1, 0], tf[:, 0, 0])
+        current_angle = -yaw
+        angle_cv2 = np.rad2deg(_wrap_heading(-current_angle + np.pi / 2))
+        rot = np.ascontiguousarray(np.stack([np.cos(-angle_cv2), np.sin(-angle_cv2)], axis=1))  # degrees-as-radians [ext]
+        out = (_lib.FogParams * n)()
+        env = None if env_ids is None else np.ascontiguousarray(np.asarray(env_ids, np.int32))
+        ex = None if explore is None else np.ascontiguousarray(np.asarray(explore, np.int32))
+        angle_cv2 = np.ascontiguousarray(angle_cv2)
+        _lib.check(_lib.lib().vlfm_fog_params_host(agent.ctypes.data, angle_cv2.ctypes.data, rot.ctypes.data,
+                                                  float(np.rad2deg(topdown_fov)),
+                                                  float(max_depth * self.pixels_per_meter),
+                                                  env.ctypes.data if env is not None else None,
+                                                  ex.ctypes.data if ex is not None else None, n,
+                                                  ctypes.addressof(out)), "fog_params_host")
+        return out
+
+    def update_after_ingest(self, tf, max_depth: float, topdown_fov: float, env_ids=None, explore: bool = True,
+                            update_obstacles: bool = True) -> None:
+        import torch
+
+        prm = self.fog_params(tf, max_depth, topdown_fov, env_ids)
+        n = len(prm)
+        with torch.cuda.device(self.device):
+            d_prm = self._ring_fog.upload(prm)
+            _lib.check(_lib.lib().vlfm_obstacle_map_update_batched(
+                d_prm.data_ptr(), n, self.obstacle_bits.data_ptr(), self.navigable_bits.data_ptr(),
+                self.explored_bits.data_ptr(), self.bbox.data_ptr(), self.n_envs, self.size, self.kernel_size,
+                int(max_depth * self.pixels_per_meter), float(self._area_thresh_in_pixels), self.scratch.data_ptr(),
+                self.scratch.numel(), self.CAP_PTS, self.CAP_CONTOURS, self.frontiers_px_dev.data_ptr(),
+                self.CAP_FRONTIERS, self.counts.data_ptr(), int(update_obstacles), int(explore), _stream_ptr()),
+                "obstacle_map_update")
+        self.frontiers_ready = bool(explore)
+        self._explored_u8 = None
+
+    # ------------------------------------------------------------------------------------------ read-back
+    def frontiers_px(self) -> List[np.ndarray]:
+        """Per environment: (F,2) f64 pixel coordinates (x,y) == ObstacleMap._frontiers_px.  One D2H copy."""
+        counts = self.counts.cpu().numpy()
+        if (counts[:, 1] != 0).any():
+            raise RuntimeError("obstacle-map scratch capacity exceeded (CAP_PTS/CAP_CONTOURS/CAP_FRONTIERS)")
+        fr = self.frontiers_px_dev.cpu().numpy()
+        return [fr[e, :counts[e, 0]].copy() for e in range(self.n_envs)]
+
+    def px_to_xy(self, px: np.ndarray) -> np.ndarray:
+        q = px.copy()
+        q[:, 0] = self.size - q[:, 0]
+        pts = (q - self.size // 2) / self.pixels_per_meter
+        return pts[:, ::-1]
+
+    def frontier_list(self):
+        """All frontiers of all environments as (xy [M,2], env index [M]) for ValueMapBatch.waypoint_values."""
+        per_env = self.frontiers_px()
+        xy = [self.px_to_xy(p) if len(p) else np.zeros((0, 2)) for p in per_env]
+        env_of = np.concatenate([np.full(len(p), e, np.int64) for e, p in enumerate(per_env)]) if per_env else np.zeros(0)
+        return (np.concatenate(xy) if len(xy) else np.zeros((0, 2))), env_of
+
+    def check_status(self) -> None:
+        st = self.status.cpu().numpy()
+        self.status.zero_()
+        if (st[:, 0] != 0).any():
+            raise IndexError("index out of bounds: obstacle point fell off the map (obstacle_map.py:101)")
+        if (st[:, 1] != 0).any() and self._hole_area_thresh != -1:
+            raise NotImplementedError(
+                "depth image contains zero (invalid) texels: fill_small_holes (img_utils.py:361-390) is not implemented "
+                "on the device yet; pass hole_area_thresh=-1 or feed filter_depth-ed (hole-free) depth")
+
+
+class ObstacleMap(BaseMap):
+    """Drop-in for vlfm.mapping.obstacle_map.ObstacleMap."""
+
+    radius_padding_color: tuple = (100, 100, 100)
+
+    def __init__(self, min_height: float, max_height: float, agent_radius: float, area_thresh: float = 3.0,
+                 hole_area_thresh: int = 100000, size: int = 1000, pixels_per_meter: int = 20, device=None):
+        super().__init__(size, pixels_per_meter)
+        self._batch = ObstacleMapBatch(1, min_height, max_height, agent_radius, area_thresh, hole_area_thresh, size,
+                                       pixels_per_meter, device)
+        self._min_height, self._max_height = min_height, max_height
+        self._area_thresh_in_pixels = self._batch._area_thresh_in_pixels
+        self._hole_area_thresh = hole_area_thresh
+        self._navigable_kernel = np.ones((self._batch.kernel_size, self._batch.kernel_size), np.uint8)
+        self._frontiers_px: np.ndarray = np.array([])
+        self.frontiers: np.ndarray = np.array([])
+
+    # host snapshots of the HBM planes for callers that read them
+    @property
+    def _map(self) -> np.ndarray:
+        return self._batch._unpack(self._batch.obstacle_bits)[0].cpu().numpy().astype(bool)
+
+    @property
+    def _navigable_map(self) -> np.ndarray:
+        return self._batch._unpack(self._batch.navigable_bits)[0].cpu().numpy().astype(np.int64)
+
+    @property
+    def explored_area(self) -> np.ndarray:
+        return self._batch.explored[0].cpu().numpy().astype(bool)
+
+    def explored_area_device(self):
+        """[1,S,S] uint8 device tensor for ValueMap's explored-area synchronisation (value_map.py:369-375)."""
+        return self._batch.explored
+
+    def reset(self) -> None:
+        super().reset()
+        self._batch.reset()
+        self._frontiers_px = np.array([])
+        self.frontiers = np.array([])
+
+    def update_map(self, depth: Union[np.ndarray, Any], tf_camera_to_episodic: np.ndarray, min_depth: float,
+                   max_depth: float, fx: float, fy: float, topdown_fov: float, explore: bool = True,
+                   update_obstacles: bool = True) -> None:
+        import torch
+
+        tf = np.asarray(tf_camera_to_episodic, np.float64)
+        if update_obstacles:
+            if not torch.is_tensor(depth):
+                depth = torch.from_numpy(np.ascontiguousarray(depth, np.float32)).to(self._batch.device)
+            depth = depth.reshape(1, depth.shape[-2], depth.shape[-1]).contiguous()
+            self._batch.ingest(depth, tf[None], min_depth, max_depth, fx, fy)
+            self._batch.check_status()
+        self._batch.update_after_ingest(tf[None], max_depth, topdown_fov, explore=explore,
+                                        update_obstacles=update_obstacles)
+        if not explore:
+            return
+        self._frontiers_px = self._batch.frontiers_px()[0]
+        if len(self._frontiers_px) == 0:
+            self._frontiers_px = np.array([])
+            self.frontiers = np.array([])
+        else:
+            self.frontiers = self._px_to_xy(self._frontiers_px)
+
+    def visualize(self) -> np.ndarray:
+        vis = np.ones((self.size, self.size, 3), dtype=np.uint8) * 255
+        vis[self.explored_area == 1] = (200, 255, 200)
+        vis[self._navigable_map == 0] = self.radius_padding_color
+        vis[self._map == 1] = (0, 0, 0)
+        return vis[::-1].copy()

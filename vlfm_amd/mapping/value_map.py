@@ -202,7 +202,7 @@ class ValueMapBatch:
         if self._colmax is None or self._colmax.shape[0] < n or self._colmax.shape[1] != width:
             # order-preserving u32 keys, zero = "-inf"; produced by depth ingest, consumed + re-zeroed by the update
             self._colmax = torch.zeros((max(n, self.n_envs), width), dtype=torch.int32, device=self.device)
-            self._status = torch.zeros(max(n, self.n_envs), dtype=torch.int32, device=self.device)
+            self._status = torch.zeros((max(n, self.n_envs), 2), dtype=torch.int32, device=self.device)
             self._ring = UploadRing(self.device, max(n, self.n_envs) * 256)
             self._vertices = torch.empty((max(n, self.n_envs), width + 2, 2), dtype=torch.int32, device=self.device)
         return self._colmax, self._status
