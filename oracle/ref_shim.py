@@ -1,0 +1,81 @@
+"""oracle/ref_shim.py -- TEST INFRASTRUCTURE ONLY.
+
+Makes the REFERENCE'S OWN Python sources importable in this container, so that the reference itself (not a
+restatement) generates the golden vectors under tests/golden/ and cross-checks the oracle:
+
+    /root/reference/vlfm/mapping/{base_map,value_map,obstacle_map}.py
+    /root/reference/vlfm/utils/{geometry_utils,img_utils}.py
+
+Those modules import three packages that are absent here and not installable (no network):
+``cv2`` (opencv-python==4.5.5.64), ``frontier_exploration`` (un-pinned git HEAD) and -- only for visualisation -- a few
+more cv2 entry points.  install() registers stand-in modules for exactly those names:
+
+    cv2                                   -> oracle/cv.py  (facade over oracle/cvport.c, OpenCV 4.5.5 restated)
+    frontier_exploration.frontier_detection.detect_frontier_waypoints
+    frontier_exploration.utils.fog_of_war.reveal_fog_of_war
+                                          -> oracle/ref_frontier_exploration.py (restated by contract)
+
+What this pins: every line of arithmetic that lives IN the reference tree (dtype promotions, truncation vs rint, the
+fusion algebra, the depth-profile polygon, index conventions, control flow, error behaviour) is executed from the
+reference's own source.  What it does NOT pin: the behaviour of the stand-ins themselves (OpenCV rasterisation rules,
+frontier_exploration) -- those remain restatements checked only by the hand-derived known answers in
+tests/test_oracle_cv.py.  /root/reference does not exist on the GPU box: only the generator script
+(tests/golden/make_golden.py) and the live cross-check in tests/test_golden_reference.py (skipped when the reference
+is absent) call install().
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+REFERENCE_ROOT = "/root/reference"
+
+
+def available() -> bool:
+    return os.path.isfile(os.path.join(REFERENCE_ROOT, "vlfm", "mapping", "value_map.py"))
+
+
+def install() -> None:
+    """Idempotent.  Call in a dedicated process: it plants fake top-level modules in sys.modules."""
+    if "vlfm.mapping.value_map" in sys.modules:
+        return
+    if not available():
+        raise ImportError(f"{REFERENCE_ROOT} is not present (GPU box?) -- golden fixtures are the pin there")
+    from . import cv as facade
+    from . import ref_frontier_exploration as fe
+
+    cv2 = types.ModuleType("cv2")
+    cv2.__doc__ = "stand-in for opencv-python==4.5.5.64 backed by oracle/cvport.c (see oracle/ref_shim.py)"
+    for name in ("ellipse", "drawContours", "circle", "polylines", "getRotationMatrix2D", "warpAffine", "dilate",
+                 "blur", "findContours", "contourArea", "pointPolygonTest", "isContourConvex", "bitwise_and",
+                 "RETR_EXTERNAL", "RETR_LIST", "RETR_CCOMP", "RETR_TREE", "CHAIN_APPROX_NONE", "CHAIN_APPROX_SIMPLE"):
+        setattr(cv2, name, getattr(facade, name))
+    # constants that visualisation-only code paths name (never evaluated by the golden generator)
+    for k, name in enumerate(("COLORMAP_INFERNO", "COLOR_BGR2RGB", "COLOR_GRAY2RGB", "COLOR_GRAY2BGR", "INTER_AREA",
+                              "BORDER_CONSTANT", "IMREAD_GRAYSCALE", "FONT_HERSHEY_SIMPLEX")):
+        setattr(cv2, name, k)
+    sys.modules["cv2"] = cv2
+
+    pkg = types.ModuleType("frontier_exploration")
+    pkg.__path__ = []  # mark as package
+    det = types.ModuleType("frontier_exploration.frontier_detection")
+    det.detect_frontier_waypoints = fe.detect_frontier_waypoints
+    utils = types.ModuleType("frontier_exploration.utils")
+    utils.__path__ = []
+    fow = types.ModuleType("frontier_exploration.utils.fog_of_war")
+    fow.reveal_fog_of_war = fe.reveal_fog_of_war
+    pkg.frontier_detection, pkg.utils, utils.fog_of_war = det, utils, fow
+    sys.modules.update({"frontier_exploration": pkg, "frontier_exploration.frontier_detection": det,
+                        "frontier_exploration.utils": utils, "frontier_exploration.utils.fog_of_war": fow})
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+
+
+def reference_modules():
+    """(value_map, obstacle_map, geometry_utils, img_utils) modules of the real reference."""
+    install()
+    import importlib
+
+    return tuple(importlib.import_module(m) for m in (
+        "vlfm.mapping.value_map", "vlfm.mapping.obstacle_map", "vlfm.utils.geometry_utils", "vlfm.utils.img_utils"))

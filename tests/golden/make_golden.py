@@ -1,0 +1,225 @@
+#!/usr/bin/env python
+"""tests/golden/make_golden.py -- generate (or --check) the golden fixtures from THE REFERENCE'S OWN SOURCE.
+
+Runs /root/reference/vlfm/mapping/{value_map,obstacle_map}.py and vlfm/utils/{geometry_utils,img_utils}.py -- the real
+files, imported through oracle/ref_shim.py, which stands in for the three absent third-party packages (cv2 ->
+oracle/cvport.c restatement; frontier_exploration -> oracle/ref_frontier_exploration.py).  So the fixtures pin the
+in-tree arithmetic of the reference (dtype promotions, truncations, fusion algebra, index conventions, control flow);
+the OpenCV / frontier_exploration rules stay restatements (PARITY UNPINNED for those, see oracle/ref_shim.py).
+
+    python tests/golden/make_golden.py            # (re)write tests/golden/*.npz   (needs /root/reference)
+    python tests/golden/make_golden.py --check    # regenerate in memory and compare with the committed files
+
+Inputs are the deterministic synthetic episodes of vlfm_amd/synthetic.py; each fixture stores the poses
+and values explicitly and a SHA-256 of every depth frame, so a consumer that regenerates the depth from the seed can
+prove it fed identical bytes.  Maps are stored sparsely (flat index + value of the non-zero cells) to keep the
+fixtures small.
+"""
+from __future__ import annotations
+
+import argparse
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from vlfm_amd.synthetic import MAX_DEPTH, MIN_DEPTH, SyntheticEnv, camera_intrinsics  # noqa: E402
+
+# ------------------------------------------------------------------------------------------------ case table
+VM_CASES = {
+    # name: (env seed, steps, channels, use_max_confidence, fusion_type, height, width)
+    "vm_default_c1": (3, 30, 1, False, "default", 480, 640),
+    "vm_maxconf_c1": (4, 16, 1, True, "default", 480, 640),
+    "vm_default_c2": (6, 14, 2, False, "default", 480, 640),
+    "vm_replace_c1": (5, 8, 1, False, "replace", 480, 640),
+    "vm_equal_c1": (5, 8, 1, False, "equal_weighting", 480, 640),
+    "vm_default_hd": (8, 6, 1, False, "default", 720, 1280),
+}
+OM_CASES = {
+    # name: (env seed, steps, holes, hole_area_thresh)
+    "om_traj": (1, 26, False, 100000),
+    "om_holes_fill": (2, 6, True, 100000),
+    "om_holes_all": (2, 6, True, -1),
+}
+SYNC_CASE = ("vm_sync_explored", 7, 14)  # ValueMap(obstacle_map=...) full-map mode: (name, seed, steps)
+OBSTACLE_KW = dict(min_height=0.61, max_height=0.88, agent_radius=0.18, area_thresh=1.5)
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def sparse(a: np.ndarray):
+    flat = np.ascontiguousarray(a).reshape(-1)
+    idx = np.flatnonzero(flat).astype(np.int32)
+    return idx, flat[idx]
+
+
+def packbits(a: np.ndarray) -> np.ndarray:
+    return np.packbits(np.asarray(a).astype(bool), axis=None)
+
+
+def frontier_blob(per_step):
+    """list of (F,2) arrays -> (counts, concatenated) so that empty steps survive the round trip."""
+    counts = np.array([len(f) for f in per_step], np.int32)
+    cat = np.concatenate([np.asarray(f, np.float64).reshape(-1, 2) for f in per_step]) if counts.sum() else \
+        np.zeros((0, 2))
+    return counts, cat
+
+
+# ------------------------------------------------------------------------------------------------ generators
+def gen_value_map(ref_vm, seed, steps, channels, use_max, fusion, H, W):
+    fov = camera_intrinsics(W)[2]
+    env = SyntheticEnv(seed, H, W, channels=channels)
+    vm = ref_vm.ValueMap(channels, use_max_confidence=use_max, fusion_type=fusion)
+    tfs, vals, hashes = [], [], []
+    for _ in range(steps):
+        depth, tf, values = env.observe()
+        hashes.append(sha(depth))
+        tfs.append(tf)
+        vals.append(values)
+        vm.update_map(values, depth.copy(), tf, MIN_DEPTH, MAX_DEPTH, fov)
+    ci, cv = sparse(vm._map)
+    vi, vv = sparse(vm._value_map)
+    # frontier scoring on the final map: a ring of waypoints around the last pose + two never-seen ones
+    x, y = tfs[-1][0, 3], tfs[-1][1, 3]
+    ang = np.linspace(0, 2 * np.pi, 9, endpoint=False)
+    wps = np.concatenate([np.stack([x + 1.2 * np.cos(ang), y + 1.2 * np.sin(ang)], 1), [[20.0, 20.0], [-18.5, 3.25]]])
+    out = dict(seed=seed, steps=steps, channels=channels, use_max_confidence=use_max, fusion_type=fusion, height=H,
+               width=W, min_depth=MIN_DEPTH, max_depth=MAX_DEPTH, fov=fov, tf=np.stack(tfs), values=np.stack(vals),
+               depth_sha256=np.array(hashes), conf_idx=ci, conf_val=cv.astype(np.float32), value_idx=vi,
+               value_val=np.asarray(vv, np.float64), value_dtype=str(vm._value_map.dtype), waypoints=wps)
+    if channels == 1:
+        s_wp, s_val = vm.sort_waypoints(wps, 0.5)
+        out.update(sorted_waypoints=np.asarray(s_wp), sorted_values=np.asarray(s_val, np.float64))
+    else:
+        s_wp, s_val = vm.sort_waypoints(wps, 0.5, reduce_fn=lambda vs: [max(v) for v in vs])
+        out.update(sorted_waypoints=np.asarray(s_wp), sorted_values=np.asarray(s_val, np.float64))
+    return out
+
+
+def gen_obstacle_map(ref_om, seed, steps, holes, hole_thresh):
+    fx, fy, fov = camera_intrinsics(640)
+    env = SyntheticEnv(seed, holes=holes)
+    om = ref_om.ObstacleMap(hole_area_thresh=hole_thresh, **OBSTACLE_KW)
+    tfs, hashes, fr_px, fr_xy = [], [], [], []
+    for _ in range(steps):
+        depth, tf, _ = env.observe()
+        hashes.append(sha(depth))
+        tfs.append(tf)
+        om.update_map(depth.copy(), tf, MIN_DEPTH, MAX_DEPTH, fx, fy, fov)
+        fr_px.append(np.asarray(om._frontiers_px, np.float64).reshape(-1, 2))
+        fr_xy.append(np.asarray(om.frontiers, np.float64).reshape(-1, 2))
+    cpx, fpx = frontier_blob(fr_px)
+    _, fxy = frontier_blob(fr_xy)
+    return dict(seed=seed, steps=steps, holes=holes, hole_area_thresh=hole_thresh, fx=fx, fy=fy, fov=fov,
+                min_depth=MIN_DEPTH, max_depth=MAX_DEPTH, tf=np.stack(tfs), depth_sha256=np.array(hashes),
+                obstacle_bits=packbits(om._map), navigable_bits=packbits(om._navigable_map),
+                explored_bits=packbits(om.explored_area), frontier_counts=cpx, frontiers_px=fpx, frontiers_xy=fxy,
+                **{k: v for k, v in OBSTACLE_KW.items()})
+
+
+def gen_sync(ref_vm, ref_om, seed, steps):
+    """reality-style ValueMap(obstacle_map=...) (value_map.py:369-375): full-map zeroing by the explored area."""
+    fx, fy, fov = camera_intrinsics(640)
+    env = SyntheticEnv(seed)
+    om = ref_om.ObstacleMap(**OBSTACLE_KW)
+    vm = ref_vm.ValueMap(1, use_max_confidence=False, obstacle_map=om)
+    tfs, vals, hashes = [], [], []
+    for _ in range(steps):
+        depth, tf, values = env.observe()
+        hashes.append(sha(depth))
+        tfs.append(tf)
+        vals.append(values)
+        om.update_map(depth.copy(), tf, MIN_DEPTH, MAX_DEPTH, fx, fy, fov)
+        vm.update_map(values, depth.copy(), tf, MIN_DEPTH, MAX_DEPTH, fov)
+    ci, cv = sparse(vm._map)
+    vi, vv = sparse(vm._value_map)
+    return dict(seed=seed, steps=steps, fx=fx, fy=fy, fov=fov, min_depth=MIN_DEPTH, max_depth=MAX_DEPTH,
+                tf=np.stack(tfs), values=np.stack(vals), depth_sha256=np.array(hashes), conf_idx=ci,
+                conf_val=cv.astype(np.float32), value_idx=vi, value_val=np.asarray(vv, np.float64),
+                explored_bits=packbits(om.explored_area), **{k: v for k, v in OBSTACLE_KW.items()})
+
+
+def gen_helpers(geo, img, ref_vm):
+    """Small known-answer tables of the in-tree helpers (geometry_utils / img_utils / BaseMap)."""
+    rng = np.random.Generator(np.random.PCG64(2024))
+    yaws = rng.uniform(-np.pi, np.pi, 8)
+    xyz = rng.uniform(-10, 10, (8, 3))
+    tfs = np.stack([geo.xyz_yaw_to_tf_matrix(p, y) for p, y in zip(xyz, yaws)])
+    ex_yaw = np.array([geo.extract_yaw(t) for t in tfs])
+    fovs = np.array([geo.get_fov(388.19, 640), geo.get_fov(500.0, 1280)])
+    depth = rng.uniform(0.5, 5.0, (6, 8)).astype(np.float32)
+    mask = depth < 4.0
+    cloud = geo.get_point_cloud(depth, mask, 7.5, 7.25)
+    moved = geo.transform_points(tfs[0], cloud)
+    bm = ref_vm.ValueMap(1, size=200)
+    pts = rng.uniform(-4.9, 4.9, (16, 2))
+    pts[:4] = [[0.025, -0.025], [0.075, 0.125], [-0.025, 0.025], [1.225, -2.375]]  # rint half-way cases
+    px = bm._xy_to_px(pts)
+    back = bm._px_to_xy(px)
+    # pixel_value_within_radius incl. the clipped-crop quirk (img_utils.py:243-253) and the empty (-1) case
+    field = np.zeros((60, 60), np.float32)
+    field[5:40, 3:33] = rng.uniform(0.1, 1.0, (35, 30)).astype(np.float32)
+    cells = np.array([[20, 20], [3, 4], [58, 58], [0, 30], [30, 0], [39, 32]])
+    med = np.array([img.pixel_value_within_radius(field, tuple(c), 10) for c in cells], np.float64)
+    # rotate_image / place_img_in_img
+    tile = np.zeros((21, 21))
+    tile[3:15, 8:14] = rng.uniform(0.2, 1.0, (12, 6))
+    rot = np.stack([img.rotate_image(tile, a) for a in (0.0, 0.3, -1.1, np.pi / 2)])
+    canvas = img.place_img_in_img(np.zeros((30, 30), np.float32), tile, 4, 27)
+    return dict(yaws=yaws, xyz=xyz, tfs=tfs, extract_yaw=ex_yaw, fovs=fovs, depth=depth, mask=mask, cloud=cloud,
+                moved=moved, pts=pts, px=px, back=back, field=field, cells=cells, medians=med, tile=tile, rotated=rot,
+                placed=canvas)
+
+
+def generate():
+    from oracle import ref_shim
+
+    ref_vm, ref_om, geo, img = ref_shim.reference_modules()
+    out = {}
+    for name, args in VM_CASES.items():
+        out[name] = gen_value_map(ref_vm, *args)
+    for name, args in OM_CASES.items():
+        out[name] = gen_obstacle_map(ref_om, *args)
+    out[SYNC_CASE[0]] = gen_sync(ref_vm, ref_om, SYNC_CASE[1], SYNC_CASE[2])
+    out["helpers"] = gen_helpers(geo, img, ref_vm)
+    return out
+
+
+def same(a, b) -> bool:
+    a, b = np.asarray(a), np.asarray(b)
+    if a.dtype.kind in "US" or b.dtype.kind in "US":
+        return a.shape == b.shape and bool(np.all(a.astype(str) == b.astype(str)))
+    return a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check", action="store_true")
+    args = ap.parse_args()
+    cases = generate()
+    bad = 0
+    for name, blob in cases.items():
+        path = os.path.join(HERE, name + ".npz")
+        if args.check:
+            with np.load(path, allow_pickle=False) as have:
+                for k, v in blob.items():
+                    if k not in have.files or not same(have[k], v):
+                        print(f"MISMATCH {name}.{k}")
+                        bad += 1
+            print(f"checked {name}: {'ok' if not bad else 'DIFFERS'}")
+        else:
+            np.savez_compressed(path, **blob)
+            print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,69 @@
+"""-m gpu: the HIP path (through the C ABI) against the golden fixtures that the REFERENCE'S OWN SOURCE produced
+(tests/golden/make_golden.py).  Float maps within 1e-4 with identical support (BASELINE.json north_star); obstacle /
+navigable / explored planes, frontier pixels, frontier world coordinates and the sort_waypoints permutation bit-exact.
+Nothing here reads /root/reference: the fixtures travel with the repo."""
+import numpy as np
+import pytest
+
+from golden_util import OM_CASES, VM_CASES, dense, frames, load, split_frontiers, unpack_plane
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.mark.parametrize("name", VM_CASES)
+def test_value_map_matches_reference_fixture(gpu_device, name):
+    from vlfm_amd.mapping import ValueMap
+
+    g = load(name)
+    C, H, W = int(g["channels"]), int(g["height"]), int(g["width"])
+    vm = ValueMap(C, use_max_confidence=bool(g["use_max_confidence"]), fusion_type=str(g["fusion_type"]),
+                  device=gpu_device)
+    for depth, tf, values in frames(g, C, height=H, width=W):
+        vm.update_map(values, depth, tf, float(g["min_depth"]), float(g["max_depth"]), float(g["fov"]))
+    conf = dense(g["conf_idx"], g["conf_val"], (1000, 1000), np.float32)
+    value = dense(g["value_idx"], g["value_val"], (1000, 1000, C), np.float64)
+    got_c, got_v = vm._map, vm._value_map
+    assert np.array_equal(got_c > 0, conf > 0)
+    assert np.abs(got_c - conf).max() <= TOL and np.abs(got_v - value).max() <= TOL
+    red = None if C == 1 else (lambda vs: [max(v) for v in vs])
+    s_wp, s_val = vm.sort_waypoints(g["waypoints"], 0.5, reduce_fn=red)
+    assert np.array_equal(np.asarray(s_wp), g["sorted_waypoints"])  # bit-exact frontier order
+    assert np.abs(np.asarray(s_val, np.float64) - g["sorted_values"]).max() <= TOL
+
+
+@pytest.mark.parametrize("name", OM_CASES)
+def test_obstacle_map_matches_reference_fixture(gpu_device, name):
+    from vlfm_amd.mapping import ObstacleMap
+
+    g = load(name)
+    om = ObstacleMap(min_height=float(g["min_height"]), max_height=float(g["max_height"]),
+                     agent_radius=float(g["agent_radius"]), area_thresh=float(g["area_thresh"]),
+                     hole_area_thresh=int(g["hole_area_thresh"]), device=gpu_device)
+    want_px, want_xy = split_frontiers(g)
+    for k, (depth, tf, _) in enumerate(frames(g, holes=bool(g["holes"]))):
+        om.update_map(depth, tf, float(g["min_depth"]), float(g["max_depth"]), float(g["fx"]), float(g["fy"]),
+                      float(g["fov"]))
+        assert np.array_equal(np.asarray(om._frontiers_px, np.float64).reshape(-1, 2), want_px[k]), f"step {k}"
+        assert np.array_equal(np.asarray(om.frontiers, np.float64).reshape(-1, 2), want_xy[k]), f"step {k}"
+    assert np.array_equal(om._map.astype(bool), unpack_plane(g["obstacle_bits"]))
+    assert np.array_equal(om._navigable_map.astype(bool), unpack_plane(g["navigable_bits"]))
+    assert np.array_equal(om.explored_area.astype(bool), unpack_plane(g["explored_bits"]))
+
+
+def test_sync_explored_matches_reference_fixture(gpu_device):
+    from vlfm_amd.mapping import ObstacleMap, ValueMap
+
+    g = load("vm_sync_explored")
+    om = ObstacleMap(min_height=float(g["min_height"]), max_height=float(g["max_height"]),
+                     agent_radius=float(g["agent_radius"]), area_thresh=float(g["area_thresh"]), device=gpu_device)
+    vm = ValueMap(1, use_max_confidence=False, obstacle_map=om, device=gpu_device)
+    for depth, tf, values in frames(g):
+        om.update_map(depth, tf, float(g["min_depth"]), float(g["max_depth"]), float(g["fx"]), float(g["fy"]),
+                      float(g["fov"]))
+        vm.update_map(values, depth, tf, float(g["min_depth"]), float(g["max_depth"]), float(g["fov"]))
+    conf = dense(g["conf_idx"], g["conf_val"], (1000, 1000), np.float32)
+    value = dense(g["value_idx"], g["value_val"], (1000, 1000, 1), np.float64)
+    assert np.array_equal(om.explored_area.astype(bool), unpack_plane(g["explored_bits"]))
+    assert np.array_equal(vm._map > 0, conf > 0)
+    assert np.abs(vm._map - conf).max() <= TOL and np.abs(vm._value_map - value).max() <= TOL
