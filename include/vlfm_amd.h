@@ -15,6 +15,7 @@
 #ifndef VLFM_AMD_H
 #define VLFM_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -76,9 +77,10 @@ int vlfm_cone_template_host(double fov, double max_depth, int pixels_per_meter, 
 /* Host: tan(linspace(-fov/2, fov/2, W)) in f64 (value_map.py:237,242). */
 int vlfm_tan_table_host(double fov, int width, double* h_out);
 
-/* Device: d_template[T*T] = inside(sector polygon) ? d_conf[T*T] : 0.  One workgroup. */
+/* Device: d_template[T*T] = inside(sector polygon) ? d_conf[T*T] : 0, and d_template_bits [T][ceil(T/32)] = the bit
+ * plane (d_template > 0).  One workgroup; once per (fov, max_depth), like the reference's cache (value_map.py:37). */
 int vlfm_cone_template_build(const float* d_conf, const int64_t* d_poly_xy, int n_poly, int template_size,
-                             float* d_template, void* stream);
+                             float* d_template, uint32_t* d_template_bits, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Depth ingest: ONE pass over each depth image feeding both maps.
@@ -116,28 +118,34 @@ int vlfm_depth_ingest_batched(const float* d_depth, int n, int height, int width
  * ValueMap.update_map for n observations (value_map.py:100-128 = :221-260 + :288-319 + :357-429).
  *   d_colmax_keys [n][W]     column-max keys from depth ingest (consumed: reset to 0 by this call)
  *   d_tan      [W]           f64 tan table (vlfm_tan_table_host)
- *   d_template [T*T]         f32 masked confidence template
+ *   d_template [T*T]         f32 masked confidence template;  d_template_bits [T][ceil(T/32)] its (> 0) bit plane
  *   d_pose     [n]           vlfm_vm_pose
  *   d_values   [n][C]        f64 values (BLIP-2 cosines)
  *   d_conf     [n_envs][S][S]      f32 confidence maps   (BaseMap._map)
  *   d_value    [n_envs][S][S][C]   f32 value maps        (ValueMap._value_map)
- *   d_explored [n_envs][S][S] u8 or NULL: ObstacleMap.explored_area when the value map was built with
- *              obstacle_map=... (value_map.py:369-375); NULL = Habitat default (windowed update, exact).
- * With d_explored the full-map zeroing is done by vlfm_value_map_mask_unexplored_batched (call it first).
+ *   d_explored_bits [n_envs][S][ceil(S/32)] bit-packed ObstacleMap.explored_area when the value map was built with
+ *              obstacle_map=... (value_map.py:369-375), or NULL = Habitat default (windowed update, exact).
+ *              With it, the full-map zeroing is done by vlfm_value_map_mask_unexplored_batched (call it first).
+ *   d_scratch  vlfm_value_map_scratch_bytes(n, T) bytes: per-observation visibility bit planes
+ * Two launches: visible_mask_kernel (one workgroup per observation) and value_map_fuse_kernel (row tiles x n).
  * ------------------------------------------------------------------------------------------- */
+size_t vlfm_value_map_scratch_bytes(int n, int template_size);
 int vlfm_value_map_update_batched(uint32_t* d_colmax_keys, int width, const double* d_tan,
-                                  const float* d_template, int template_size,
+                                  const float* d_template, const uint32_t* d_template_bits, int template_size,
                                   const vlfm_vm_pose* d_pose, const double* d_values, int n,
                                   float* d_conf, float* d_value, int map_size, int channels, int pixels_per_meter,
                                   double min_depth, double max_depth,
                                   int use_max_confidence, int fusion_type,
-                                  const uint8_t* d_explored,
-                                  int32_t* d_vertices /* scratch [n][width+2][2] int32 */, void* stream);
+                                  const uint32_t* d_explored_bits, void* d_scratch, void* stream);
 
-/* Full-map half of _fuse_new_data when an obstacle map is attached (value_map.py:369-375):
- * conf = value = 0 wherever explored == 0, for the n listed env slots.  Streaming, HBM-bound. */
-int vlfm_value_map_mask_unexplored_batched(const int32_t* d_env /* [n] or NULL = 0..n-1 */, int n,
-                                           const uint8_t* d_explored, float* d_conf, float* d_value,
+/* Full-map half of _fuse_new_data when an obstacle map is attached (value_map.py:369-375): conf = value = 0 wherever
+ * explored == 0, over rows [row_lo, row_hi) of the listed environment slots.  The reference sweeps the whole map; rows
+ * that no update window has ever touched are zero already, so a host that tracks the union of its update windows may
+ * pass that row range (identical result); row_lo = 0, row_hi = S is always valid.  max_rows = max(row_hi - row_lo)
+ * sizes the launch.  Streaming, HBM-bound. */
+typedef struct { int32_t env, row_lo, row_hi, reserved; } vlfm_mask_job;
+int vlfm_value_map_mask_unexplored_batched(const vlfm_mask_job* d_jobs, int n, int max_rows,
+                                           const uint32_t* d_explored_bits, float* d_conf, float* d_value,
                                            int map_size, int channels, void* stream);
 
 /* ValueMap.sort_waypoints scoring (value_map.py:146-187 + img_utils.py:213-266): per waypoint and channel the

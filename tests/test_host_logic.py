@@ -26,10 +26,10 @@ def test_pose_params_match_oracle_rotation_and_cell():
         M[0] = A11; M[1] *= -D; M[3] *= -D; M[4] = A22
         b1 = -M[0] * M[2] - M[1] * M[5]; b2 = -M[3] * M[2] - M[4] * M[5]
         M[2] = b1; M[5] = b2
-        assert list(out[k].inv_affine) == M.tolist()      # bit-exact f64
+        assert out[k]['inv_affine'].tolist() == M.tolist()      # bit-exact f64
         px = int(tf[0, 3] * 20) + 500
         py = int(-tf[1, 3] * 20) + 500
-        assert (out[k].row0, out[k].col0, out[k].env) == (px - 100, py - 100, k)
+        assert (out[k]['row0'], out[k]['col0'], out[k]['env']) == (px - 100, py - 100, k)
 
 
 def test_pose_params_outside_map_is_the_reference_assertion():

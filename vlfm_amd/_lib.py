@@ -85,11 +85,13 @@ def lib() -> ctypes.CDLL:
         L.vlfm_cone_template_host.argtypes = [cd, cd, ci, cd, vp, ci, vp, ci, ctypes.POINTER(ci)]
         L.vlfm_tan_table_host.argtypes = [cd, ci, vp]
         L.vlfm_disc_rows_host.argtypes = [ci, vp]
-        L.vlfm_cone_template_build.argtypes = [vp, vp, ci, ci, vp, vp]
+        L.vlfm_cone_template_build.argtypes = [vp, vp, ci, ci, vp, vp, vp]
         L.vlfm_depth_ingest_batched.argtypes = [vp, ci, ci, ci, vp, vp, vp, ci, ci, vp, vp]
-        L.vlfm_value_map_update_batched.argtypes = [vp, ci, vp, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci, cd, cd, ci,
+        L.vlfm_value_map_scratch_bytes.argtypes = [ci, ci]
+        L.vlfm_value_map_scratch_bytes.restype = ctypes.c_size_t
+        L.vlfm_value_map_update_batched.argtypes = [vp, ci, vp, vp, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci, cd, cd, ci,
                                                     ci, vp, vp, vp]
-        L.vlfm_value_map_mask_unexplored_batched.argtypes = [vp, ci, vp, vp, vp, ci, ci, vp]
+        L.vlfm_value_map_mask_unexplored_batched.argtypes = [vp, ci, ci, vp, vp, vp, ci, ci, vp]
         L.vlfm_value_map_sort_waypoints_batched.argtypes = [vp, ci, ci, vp, ci, ci, vp, vp, vp]
         L.vlfm_resample_coeffs_host.argtypes = [ci, ci, vp, vp, ci, ctypes.POINTER(ci)]
         L.vlfm_preprocess_rgb_batched.argtypes = [vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, ci, vp]

@@ -10,9 +10,8 @@
 // single bit (atomicOr) into the environment's bit-packed obstacle plane.  HBM-bound: 4*H*W bytes read per
 // observation.  No MFMA: this is a reduction + scatter.
 //
-// Work decomposition: a workgroup owns ROWS_PER_BLOCK image rows; thread (cx, ry) owns one float4 column group and
-// walks rows ry, ry+RY, ...; partial maxima are combined through LDS, then one atomicMax per column and workgroup
-// (column maxima are stored as order-preserving unsigned keys so that atomicMax works for any sign).
+// Column maxima are stored as order-preserving unsigned keys so that atomicMax works for any sign (work decomposition:
+// see depth_ingest_kernel).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -43,8 +42,25 @@ struct IngestArgs {
     double ppm;
 };
 
-__device__ inline void scatter_point(const IngestArgs& a, const vlfm_ingest_params& p, unsigned* grid, int obs,
-                                     int u, int v, float d) {
+struct HeightBand {  // f32 shadow of the height test, widened by a safety margin
+    float t8, t9, t10, t11, inv_fx, inv_fy, lo, hi;
+};
+__device__ inline HeightBand make_band(const vlfm_ingest_params& p, int W, int H) {
+    HeightBand b;
+    b.t8 = (float)p.tf[8]; b.t9 = (float)p.tf[9]; b.t10 = (float)p.tf[10]; b.t11 = (float)p.tf[11];
+    b.inv_fx = (float)(1.0 / p.fx); b.inv_fy = (float)(1.0 / p.fy);
+    // |x_cam| <= depth_max * (W/2)/fx, |y_cam| <= depth_max * (H/2)/fy.  A dozen f32 roundings (2^-24 each) on terms of
+    // that magnitude give an absolute error below 1e-6 * mag; the margin is 1e-4 * mag (100x).
+    const float mag = fabsf(b.t8) * p.depth_max + fabsf(b.t9) * p.depth_max * (float)(W / 2 + 1) * fabsf(b.inv_fx) +
+                      fabsf(b.t10) * p.depth_max * (float)(H / 2 + 1) * fabsf(b.inv_fy) + fabsf(b.t11) + 1.0f;
+    const float margin = 1e-4f * mag;
+    b.lo = (float)p.min_height - margin;
+    b.hi = (float)p.max_height + margin;
+    return b;
+}
+
+__device__ inline void scatter_point(const IngestArgs& a, const vlfm_ingest_params& p, const HeightBand& band,
+                                     unsigned* grid, int obs, int u, int v, float d) {
     if (d == 0.0f) {
         // a hole in the depth image.  scatter bit 1 set: hole_area_thresh == -1 semantics (obstacle_map.py:87-89), every
         // zero becomes 1.0 and therefore falls outside max_depth.  Otherwise the caller must have filled small holes
@@ -54,6 +70,16 @@ __device__ inline void scatter_point(const IngestArgs& a, const vlfm_ingest_para
     }
     const float z = __fadd_rn(__fmul_rn(d, p.depth_scale), p.depth_offset);  // obstacle_map.py:92 (f32)
     if (!(z < p.depth_max)) return;                                          // :93
+    // Conservative f32 pre-test of the height band: the exact f64 evaluation below is what decides, but ~90 % of the
+    // texels (floor, ceiling) are far outside [min_height, max_height] and two f64 divisions + nine f64 products per
+    // texel would make this kernel compute-bound instead of HBM-bound.  The f32 estimate of Z is within
+    // 1e-6 * (|row 3 of tf| . |point|) of the f64 value; the band is widened by 1e-4 of that magnitude, and NaNs fall through
+    // to the exact path.
+    {
+        const float xf = (float)(u - a.W / 2) * z * band.inv_fx, yf = (float)(v - a.H / 2) * z * band.inv_fy;
+        const float zf = band.t8 * z - band.t9 * xf - band.t10 * yf + band.t11;
+        if (zf < band.lo || zf > band.hi) return;
+    }
     // get_point_cloud (geometry_utils.py:230-234): int64 * f32 -> f64, then / fx
     const double zd = (double)z;
     const double xc = __ddiv_rn(__dmul_rn((double)(u - a.W / 2), zd), p.fx);
@@ -78,56 +104,67 @@ __device__ inline void scatter_point(const IngestArgs& a, const vlfm_ingest_para
     }
     if (row < 0) row += a.S;
     if (col < 0) col += a.S;
-    atomicOr(&grid[(size_t)row * a.stride + (col >> 5)], 1u << (col & 31));  // few in-band points: contention-free in practice
+    // Obstacle bits are only ever SET between resets, so a plain (possibly stale) read that already shows the bit lets
+    // us skip the device-scope atomic: in steady state almost every in-band point re-observes a known obstacle cell.
+    unsigned* word = &grid[(size_t)row * a.stride + (col >> 5)];
+    const unsigned bit = 1u << (col & 31);
+    if (!(*word & bit)) atomicOr(word, bit);
 }
 
+// Work decomposition: a workgroup owns CG float4 column groups (CG*4 image columns, CG*16 contiguous bytes per row) and
+// a band of rows; lane (cx, ry) walks rows ry, ry+RL, ... of the band with UNROLL 16-byte loads in flight.  With one
+// band per image (the large-batch case) every column maximum is produced by exactly one workgroup -- no atomic
+// contention; small batches split the rows into bands to fill the chip and merge through atomicMax on the keys.
+constexpr int CG = 32;   // float4 column groups per workgroup
+constexpr int RL = 16;   // row lanes per workgroup  -> 512 threads, a wavefront covers 2 rows x 512 B
+
 template <bool SCATTER>
-__global__ __launch_bounds__(1024) void depth_ingest_kernel(IngestArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float4* part = reinterpret_cast<float4*>(smem);  // [ry][cols_per_block]
+__global__ __launch_bounds__(CG * RL) void depth_ingest_kernel(IngestArgs a) {
+    __shared__ float4 part[RL][CG];
     const int obs = blockIdx.z;
-    const int cx = threadIdx.x % a.cols_per_block, ry = threadIdx.x / a.cols_per_block;
-    const int col4 = blockIdx.x * a.cols_per_block + cx;
+    const int cx = threadIdx.x % CG, ry = threadIdx.x / CG;
+    const int col4 = blockIdx.x * CG + cx;
     const int r_begin = blockIdx.y * a.rows_per_block;
     const int r_end = min(r_begin + a.rows_per_block, a.H);
-    const bool live = col4 < a.W4 && ry < a.ry;
+    const bool live = col4 < a.W4;
     const vlfm_ingest_params p = a.prm[obs];
+    const HeightBand band = make_band(p, a.W, a.H);
     const float* img = a.depth + (size_t)obs * a.H * a.W;
     unsigned* grid = nullptr;
     if (SCATTER) grid = a.obstacle + (size_t)p.env * a.S * a.stride;
     const float ninf = -__builtin_huge_valf();
     float4 m = make_float4(ninf, ninf, ninf, ninf);
     if (live) {
-        // four independent 16-byte loads in flight per lane before any use (latency hiding with few waves per CU)
         constexpr int UNROLL = 4;
-        for (int r0 = r_begin + ry; r0 < r_end; r0 += UNROLL * a.ry) {
+        for (int r0 = r_begin + ry; r0 < r_end; r0 += UNROLL * RL) {
             float4 d[UNROLL];
 #pragma unroll
             for (int k = 0; k < UNROLL; k++) {
-                const int r = r0 + k * a.ry;
+                const int r = r0 + k * RL;
                 d[k] = r < r_end ? reinterpret_cast<const float4*>(img + (size_t)r * a.W)[col4]
                                  : make_float4(ninf, ninf, ninf, ninf);
             }
 #pragma unroll
             for (int k = 0; k < UNROLL; k++) {
-                const int r = r0 + k * a.ry;
+                const int r = r0 + k * RL;
                 m.x = fmaxf(m.x, d[k].x); m.y = fmaxf(m.y, d[k].y); m.z = fmaxf(m.z, d[k].z); m.w = fmaxf(m.w, d[k].w);
                 if (SCATTER && (p.scatter & 1) && r < r_end) {
                     const int u = col4 * 4;
-                    scatter_point(a, p, grid, obs, u + 0, r, d[k].x);
-                    scatter_point(a, p, grid, obs, u + 1, r, d[k].y);
-                    scatter_point(a, p, grid, obs, u + 2, r, d[k].z);
-                    scatter_point(a, p, grid, obs, u + 3, r, d[k].w);
+                    scatter_point(a, p, band, grid, obs, u + 0, r, d[k].x);
+                    scatter_point(a, p, band, grid, obs, u + 1, r, d[k].y);
+                    scatter_point(a, p, band, grid, obs, u + 2, r, d[k].z);
+                    scatter_point(a, p, band, grid, obs, u + 3, r, d[k].w);
                 }
             }
         }
     }
     if (a.colmax_keys == nullptr) return;
-    if (ry < a.ry) part[ry * a.cols_per_block + cx] = m;
+    part[ry][cx] = m;
     __syncthreads();
-    if (ry == 0 && col4 < a.W4) {
-        for (int k = 1; k < a.ry; k++) {
-            const float4 o = part[k * a.cols_per_block + cx];
+    if (ry == 0 && live) {
+#pragma unroll
+        for (int k = 1; k < RL; k++) {
+            const float4 o = part[k][cx];
             m.x = fmaxf(m.x, o.x); m.y = fmaxf(m.y, o.y); m.z = fmaxf(m.z, o.z); m.w = fmaxf(m.w, o.w);
         }
         unsigned* out = a.colmax_keys + (size_t)obs * a.W + col4 * 4;
@@ -137,7 +174,6 @@ __global__ __launch_bounds__(1024) void depth_ingest_kernel(IngestArgs a) {
         atomicMax(out + 3, f32_key(m.w));
     }
 }
-
 
 }  // namespace vlfm
 
@@ -157,24 +193,22 @@ extern "C" int vlfm_depth_ingest_batched(const float* d_depth, int n, int height
     a.obstacle = d_obstacle; a.status = d_status;
     a.H = height; a.W = width; a.W4 = width / 4; a.S = map_size; a.stride = (map_size + 31) / 32;
     a.ppm = (double)pixels_per_meter;
-    a.cols_per_block = a.W4 < 256 ? a.W4 : 256;
-    a.ry = 640 / a.cols_per_block;
-    if (a.ry < 1) a.ry = 1;
-    if (a.ry > 8) a.ry = 8;
-    const int threads = a.cols_per_block * a.ry;
-    // enough workgroups to cover 256 CUs several times over, but at least 2 loads per thread
-    int rows_per_block = 4 * a.ry;
-    const int gx = (a.W4 + a.cols_per_block - 1) / a.cols_per_block;
-    while ((long)n * gx * ((height + rows_per_block - 1) / rows_per_block) > 4096 && rows_per_block < height) rows_per_block *= 2;
-    a.rows_per_block = rows_per_block;
-    const int gy = (height + rows_per_block - 1) / rows_per_block;
-    const size_t lds = (size_t)threads * sizeof(float4);
+    a.cols_per_block = CG; a.ry = RL;
+    const int gx = (a.W4 + CG - 1) / CG;
+    // row bands: aim for ~2048 workgroups (8 per CU) so that enough 16-byte loads are in flight to cover HBM latency,
+    // but never fewer than RL rows per band
+    int bands = (int)((2048 + (long)n * gx - 1) / ((long)n * gx));
+    const int max_bands = (height + RL - 1) / RL;
+    if (bands > max_bands) bands = max_bands;
+    if (bands < 1) bands = 1;
+    a.rows_per_block = (height + bands - 1) / bands;
+    const int gy = (height + a.rows_per_block - 1) / a.rows_per_block;
     {
         VLFM_TIMED("depth_ingest_kernel", s);
         if (d_obstacle)
-            hipLaunchKernelGGL(depth_ingest_kernel<true>, dim3(gx, gy, n), dim3(threads), lds, s, a);
+            hipLaunchKernelGGL(depth_ingest_kernel<true>, dim3(gx, gy, n), dim3(CG * RL), 0, s, a);
         else
-            hipLaunchKernelGGL(depth_ingest_kernel<false>, dim3(gx, gy, n), dim3(threads), lds, s, a);
+            hipLaunchKernelGGL(depth_ingest_kernel<false>, dim3(gx, gy, n), dim3(CG * RL), 0, s, a);
     }
     return check_launch("depth_ingest_kernel");
 }

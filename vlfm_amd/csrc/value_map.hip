@@ -32,7 +32,7 @@ namespace vlfm {
 // ------------------------------------------------------------------------------------------------ template build
 __global__ __launch_bounds__(1024) void cone_template_kernel(const float* __restrict__ conf,
                                                              const long long* __restrict__ poly, int n_poly, int T,
-                                                             float* __restrict__ out) {
+                                                             float* __restrict__ out, unsigned* __restrict__ out_bits) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int words = (T + 31) >> 5;
     LdsBitmap bm;
@@ -55,6 +55,16 @@ __global__ __launch_bounds__(1024) void cone_template_kernel(const float* __rest
         const int y = i / T, x = i - y * T;
         out[i] = bm_test(bm.solid, words, y, x) ? conf[i] : 0.0f;
     }
+    // bit plane of (template > 0): what the per-observation visibility mask starts from
+    for (int i = threadIdx.x; i < T * words; i += blockDim.x) {
+        const int y = i / words, w = i - y * words;
+        unsigned bits = 0u;
+        for (int b = 0; b < 32; b++) {
+            const int x = w * 32 + b;
+            if (x < T && bm_test(bm.solid, words, y, x) && conf[y * T + x] > 0.0f) bits |= 1u << b;
+        }
+        out_bits[i] = bits;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ update
@@ -62,31 +72,40 @@ struct UpdateArgs {
     unsigned* colmax;         // [n][W] order-preserving keys from depth ingest (consumed and reset to 0 here)
     const double* tan_tab;    // [W]
     const float* tmpl;        // [T][T]
+    const unsigned* tmpl_bits;// [T][words]  template > 0
     const vlfm_vm_pose* pose; // [n]
-    int2* vertices;           // [n][W+2] scratch: profile polygon (x=col, y=row)
+    unsigned* visible;        // [n][vis_stride] scratch: per observation (template > 0) & ~(beyond the depth profile)
     const double* values;     // [n][C]
     float* conf;              // [n_envs][S][S]
     float* value;             // [n_envs][S][S][C]
-    const unsigned char* explored;  // [n_envs][S][S] or null
+    const unsigned* explored; // [n_envs][S][ceil(S/32)] bit-packed ObstacleMap.explored_area, or null
     int W, T, S, C;
+    int vis_stride;           // words per observation in `visible` (T * words rounded up to a multiple of 4)
     float depth_scale, depth_offset;  // f32(max-min), f32(min)
     float ppm_f, half_t_f;            // f32(ppm), f32(T/2.0)
     double ppm_d, half_t_d;
     int use_max_conf, fusion;
 };
 
-__device__ inline float tap(const float* __restrict__ tmpl, const unsigned* cut, int words, int T, int y, int x) {
-    if ((unsigned)x >= (unsigned)T || (unsigned)y >= (unsigned)T) return 0.0f;
-    if (bm_test(cut, words, y, x)) return 0.0f;
-    return tmpl[y * T + x];
-}
+// One workgroup per observation: column-max keys -> depth-profile polygon (value_map.py:234-257) -> LDS coverage of the
+// "beyond the profile" region (cv2.drawContours fill, value_map.py:260) -> visible = (template > 0) & ~coverage, 5.6 KB
+// per observation written to HBM scratch.  The key buffer is handed back zeroed for the next depth ingest.
+// Doing this ONCE per observation (instead of once per fuse workgroup) is what keeps the fuse kernel HBM-bound.
+__global__ __launch_bounds__(512) void visible_mask_kernel(UpdateArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int T = a.T, W = a.W;
+    const int words = (T + 31) >> 5;
+    const int n_vert = W + 2;
+    unsigned* solid = reinterpret_cast<unsigned*>(smem);
+    unsigned* parity = solid + T * words;
+    int2* vert = reinterpret_cast<int2*>(parity + T * words + ((2 * T * words) & 1));  // 8-byte aligned
+    const int obs = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
 
-// keys -> profile polygon (global scratch), and hand the key buffer back zeroed for the next ingest
-__global__ __launch_bounds__(256) void depth_profile_kernel(UpdateArgs a) {
-    const int obs = blockIdx.x, T = a.T, W = a.W;
+    LdsBitmap bm;
+    bm.solid = solid; bm.parity = parity; bm.rows = T; bm.cols = T; bm.words = words;
+    for (int i = tid; i < 2 * T * words; i += nth) solid[i] = 0u;
     unsigned* cm = a.colmax + (size_t)obs * W;
-    int2* vert = a.vertices + (size_t)obs * (W + 2);
-    for (int i = threadIdx.x; i < W; i += blockDim.x) {
+    for (int i = tid; i < W; i += nth) {
         const unsigned key = cm[i];
         cm[i] = 0u;
         const float raw = __uint_as_float((key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key);
@@ -95,51 +114,11 @@ __global__ __launch_bounds__(256) void depth_profile_kernel(UpdateArgs a) {
         const double yl = __dadd_rn(__dmul_rn(__dmul_rn((double)d, a.tan_tab[i]), a.ppm_d), a.half_t_d);  // f64 (:242,249)
         vert[i + 1] = make_int2((int)(long long)yl, (int)(long long)xr);                 // astype(int): truncation
     }
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         vert[0] = make_int2(0, T - 1);              // [0, last_col]         (:253)
         vert[W + 1] = make_int2(T - 1, T - 1);      // [last_row, last_col]  (:254)
     }
-}
-
-// grid = (row tiles, observations).  Every workgroup rasterises the (cheap) coverage bitmap of its observation into
-// its own LDS and then fuses ROWS_PER_TILE template rows: ~13x more workgroups in flight than one-per-observation,
-// which is what hides the L2/HBM latency of the tap + read-modify-write chain.
-constexpr int ROWS_PER_TILE = 8;
-
-template <int C_STATIC>
-__global__ __launch_bounds__(512) void value_map_update_kernel(UpdateArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int T = a.T, W = a.W;
-    const int words = (T + 31) >> 5;
-    const int n_vert = W + 2;
-    // LDS carve (all 16-byte aligned): bitmaps | affine tables
-    unsigned* solid = reinterpret_cast<unsigned*>(smem);
-    unsigned* parity = solid + T * words;
-    int* adelta = reinterpret_cast<int*>(parity + T * words + ((4 - ((2 * T * words) & 3)) & 3));
-    int* bdelta = adelta + T;
-    int* X0 = bdelta + T;
-    int* Y0 = X0 + T;
-
-    const int obs = blockIdx.y;
-    const int row_begin = blockIdx.x * ROWS_PER_TILE;
-    const int row_end = min(row_begin + ROWS_PER_TILE, T);
-    const vlfm_vm_pose pose = a.pose[obs];
-    const int tid = threadIdx.x, nth = blockDim.x;
-
-    LdsBitmap bm;
-    bm.solid = solid; bm.parity = parity; bm.rows = T; bm.cols = T; bm.words = words;
-    for (int i = tid; i < 2 * T * words; i += nth) solid[i] = 0u;
-    // affine tables of cv::warpAffine (AB_BITS = 10, INTER_BITS = 5, round_delta = 16)
-    for (int i = tid; i < T; i += nth) {
-        adelta[i] = __double2int_rn(__dmul_rn(__dmul_rn(pose.inv_affine[0], (double)i), 1024.0));
-        bdelta[i] = __double2int_rn(__dmul_rn(__dmul_rn(pose.inv_affine[3], (double)i), 1024.0));
-        X0[i] = __double2int_rn(__dmul_rn(__dadd_rn(__dmul_rn(pose.inv_affine[1], (double)i), pose.inv_affine[2]), 1024.0)) + 16;
-        Y0[i] = __double2int_rn(__dmul_rn(__dadd_rn(__dmul_rn(pose.inv_affine[4], (double)i), pose.inv_affine[5]), 1024.0)) + 16;
-    }
     __syncthreads();
-
-    // ---- phase 1: coverage of the "beyond the depth profile" polygon (value_map.py:253-260)
-    const int2* vert = a.vertices + (size_t)obs * n_vert;
     for (int i = tid; i < n_vert; i += nth) {
         const int2 p0 = vert[i == 0 ? n_vert - 1 : i - 1], p1 = vert[i];
         raster_edge(bm, (long long)p0.x << XY_SHIFT, p0.y, (long long)p1.x << XY_SHIFT, p1.y);
@@ -147,119 +126,205 @@ __global__ __launch_bounds__(512) void value_map_update_kernel(UpdateArgs a) {
     __syncthreads();
     resolve_rows(bm, tid, nth);
     __syncthreads();
+    unsigned* out = a.visible + (size_t)obs * a.vis_stride;
+    for (int i = tid; i < T * words; i += nth) out[i] = a.tmpl_bits[i] & ~solid[i];
+}
 
-    // ---- phase 2: rotate + place + fuse
-    const int S = a.S;
+// grid = (row tiles, observations), 4 wavefronts per workgroup.  The workgroup stages its observation's visible bitmap
+// in LDS (5.6 KB, L2-resident), then each wavefront walks template rows with lanes along x (coalesced 256-B map
+// segments).  Per pixel: inverse-affine 1/32-pixel source coordinate (cv::warpAffine, img_utils.py:9-28), four bit
+// tests in LDS, template taps from L2 only where a bit is set, placement at the camera cell with clipping
+// (place_img_in_img, img_utils.py:31-61) and the fusion read-modify-write (value_map.py:357-429).  Cells whose new
+// confidence is 0 are never touched: the reference's full-map arithmetic leaves them bit-identical (w1 == 1, w2 == 0).
+constexpr int ROWS_PER_TILE = 8;
+
+__device__ inline bool vis_test(const unsigned* vis, int words, int T, int y, int x) {
+    if ((unsigned)x >= (unsigned)T || (unsigned)y >= (unsigned)T) return false;
+    return (vis[y * words + (x >> 5)] >> (x & 31)) & 1u;
+}
+
+// The fusion arithmetic of one cell (value_map.py:377-429).  Returns false when the cell is left untouched.
+template <int C>
+__device__ inline bool fuse_cell(const UpdateArgs& a, float nw, float old, const float* oldv, const double* vals,
+                                 float& conf_out, float* value_out) {
+    if (a.fusion == VLFM_FUSE_REPLACE) {  // (:377-385)
+        conf_out = nw;
+        for (int c = 0; c < C; c++) value_out[c] = (float)vals[c];
+        return true;
+    }
+    if (a.fusion == VLFM_FUSE_EQUAL_WEIGHTING) {  // (:386-391)
+        if (old > 0.0f) old = 1.0f;
+        nw = 1.0f;
+    }
+    if (nw < 0.35f && nw < old) return false;  // decision threshold (:398-399)
+    if (a.use_max_conf) {                       // (:401-408)
+        if (!(nw > old)) return false;
+        conf_out = nw;
+        for (int c = 0; c < C; c++) value_out[c] = (float)vals[c];
+        return true;
+    }
+    // weighted average (:414-424): weights in f32, value blend in f64 (values is an f64 ndarray), conf in f32
+    const float den = __fadd_rn(old, nw);
+    const float w_old = __fdiv_rn(old, den), w_new = __fdiv_rn(nw, den);
+    for (int c = 0; c < C; c++)
+        value_out[c] = (float)__dadd_rn(__dmul_rn((double)oldv[c], (double)w_old), __dmul_rn(vals[c], (double)w_new));
+    conf_out = __fadd_rn(__fmul_rn(old, w_old), __fmul_rn(nw, w_new));
+    return true;
+}
+
+template <int C_STATIC>
+__global__ __launch_bounds__(256) void value_map_fuse_kernel(UpdateArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned* vis = reinterpret_cast<unsigned*>(smem);
+    const int T = a.T, S = a.S;
+    const int words = (T + 31) >> 5;
+    const int obs = blockIdx.y;
+    const int row_begin = blockIdx.x * ROWS_PER_TILE;
+    const vlfm_vm_pose pose = a.pose[obs];
+    // whole tile clipped away by place_img_in_img?
+    if (pose.row0 + min(row_begin + ROWS_PER_TILE, T) <= 0 || pose.row0 + row_begin >= S) return;
+    const int tid = threadIdx.x;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(a.visible + (size_t)obs * a.vis_stride);
+        uint4* dst = reinterpret_cast<uint4*>(vis);
+        for (int i = tid; i < a.vis_stride / 4; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+
     const int C = C_STATIC > 0 ? C_STATIC : a.C;
     float* conf = a.conf + (size_t)pose.env * S * S;
     float* value = a.value + (size_t)pose.env * S * S * C;
-    const unsigned char* explored = a.explored ? a.explored + (size_t)pose.env * S * S : nullptr;
+    const int ex_stride = (S + 31) >> 5;
+    const unsigned* explored = a.explored ? a.explored + (size_t)pose.env * S * ex_stride : nullptr;
     const double* vals = a.values + (size_t)obs * C;
     const float* __restrict__ tmpl = a.tmpl;
+    const int lane = tid & 63, wave = tid >> 6;
 
-    // one wavefront per template row, lanes along x: coalesced map accesses, no integer division
-    const int lane = tid & 63, wave = tid >> 6, n_waves = nth >> 6;
-    for (int y = row_begin + wave; y < row_end; y += n_waves)
-    for (int x = lane; x < T; x += 64) {
-        const int mr = pose.row0 + y, mc = pose.col0 + x;
-        if ((unsigned)mr >= (unsigned)S || (unsigned)mc >= (unsigned)S) continue;  // place_img_in_img clipping
-        const int Xq = (X0[y] + adelta[x]) >> 5, Yq = (Y0[y] + bdelta[x]) >> 5;
-        const int sx = Xq >> 5, sy = Yq >> 5;
-        const int fxi = Xq & 31, fyi = Yq & 31;
-        const float v0 = tap(tmpl, solid, words, T, sy, sx), v1 = tap(tmpl, solid, words, T, sy, sx + 1);
-        const float v2 = tap(tmpl, solid, words, T, sy + 1, sx), v3 = tap(tmpl, solid, words, T, sy + 1, sx + 1);
-        if (v0 == 0.0f && v1 == 0.0f && v2 == 0.0f && v3 == 0.0f) continue;
-        // BilinearTab_f weights are products of k/32 in float (exact); accumulate in double like remapBilinear<double>
-        const float fx = (float)fxi * 0.03125f, fy = (float)fyi * 0.03125f;
-        const float w0 = (1.f - fy) * (1.f - fx), w1 = (1.f - fy) * fx, w2 = fy * (1.f - fx), w3 = fy * fx;
-        const double nd = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn((double)v0, (double)w0), __dmul_rn((double)v1, (double)w1)),
-                                              __dmul_rn((double)v2, (double)w2)), __dmul_rn((double)v3, (double)w3));
-        float nw = (float)nd;  // curr_map is f32 (value_map.py:316-317)
-        if (nw == 0.0f) continue;
-        const size_t cell = (size_t)mr * S + mc;
-        if (explored && explored[cell] == 0) continue;  // new_map[explored == 0] = 0 (:373); old already zeroed
-        float old = conf[cell];
-        if (a.fusion == VLFM_FUSE_REPLACE) {  // (:377-385)
-            conf[cell] = nw;
-            for (int c = 0; c < C; c++) value[cell * C + c] = (float)vals[c];
-            continue;
+    // Each wavefront owns a 64-column x segment of the tile (4 wavefronts cover T <= 256 in one pass) and processes the
+    // tile's rows as ONE batch in three straight-line phases, so that all template taps, then all map reads, are in
+    // flight together: one memory latency per phase instead of one per pixel.  Inactive pixels read a harmless fixed
+    // address and are masked at the end.
+    constexpr int ROWS_PER_WAVE = ROWS_PER_TILE;
+    for (int x = wave * 64 + lane; x < T; x += 256) {
+        const int mc = pose.col0 + x;
+        const bool col_ok = (unsigned)mc < (unsigned)S;
+        // affine tables of cv::warpAffine (AB_BITS = 10, INTER_BITS = 5, round_delta = 16), evaluated per lane
+        const int adelta = __double2int_rn(__dmul_rn(__dmul_rn(pose.inv_affine[0], (double)x), 1024.0));
+        const int bdelta = __double2int_rn(__dmul_rn(__dmul_rn(pose.inv_affine[3], (double)x), 1024.0));
+        float tapv[ROWS_PER_WAVE][4];
+        int fxi[ROWS_PER_WAVE], fyi[ROWS_PER_WAVE];
+        bool any_tap[ROWS_PER_WAVE];
+        // ---- phase A: source coordinates, visibility bits (LDS), template taps (L2)
+#pragma unroll
+        for (int k = 0; k < ROWS_PER_WAVE; k++) {
+            const int y = row_begin + k;
+            const int X0 = __double2int_rn(__dmul_rn(__dadd_rn(__dmul_rn(pose.inv_affine[1], (double)y), pose.inv_affine[2]), 1024.0)) + 16;
+            const int Y0 = __double2int_rn(__dmul_rn(__dadd_rn(__dmul_rn(pose.inv_affine[4], (double)y), pose.inv_affine[5]), 1024.0)) + 16;
+            const int Xq = (X0 + adelta) >> 5, Yq = (Y0 + bdelta) >> 5;
+            const int sx = Xq >> 5, sy = Yq >> 5;
+            fxi[k] = Xq & 31; fyi[k] = Yq & 31;
+            const bool row_ok = y < T && (unsigned)(pose.row0 + y) < (unsigned)S && col_ok;
+            const bool b0 = row_ok && vis_test(vis, words, T, sy, sx), b1 = row_ok && vis_test(vis, words, T, sy, sx + 1);
+            const bool b2 = row_ok && vis_test(vis, words, T, sy + 1, sx), b3 = row_ok && vis_test(vis, words, T, sy + 1, sx + 1);
+            any_tap[k] = b0 | b1 | b2 | b3;
+            const float t0 = tmpl[b0 ? sy * T + sx : 0], t1 = tmpl[b1 ? sy * T + sx + 1 : 0];
+            const float t2 = tmpl[b2 ? (sy + 1) * T + sx : 0], t3 = tmpl[b3 ? (sy + 1) * T + sx + 1 : 0];
+            tapv[k][0] = b0 ? t0 : 0.0f; tapv[k][1] = b1 ? t1 : 0.0f; tapv[k][2] = b2 ? t2 : 0.0f; tapv[k][3] = b3 ? t3 : 0.0f;
         }
-        if (a.fusion == VLFM_FUSE_EQUAL_WEIGHTING) {  // (:386-391)
-            if (old > 0.0f) old = 1.0f;
-            nw = 1.0f;
+        // ---- phase B: bilinear blend -> new confidence; issue the map reads of every active pixel
+        float nw[ROWS_PER_WAVE], old[ROWS_PER_WAVE];
+        size_t cell[ROWS_PER_WAVE];
+        bool act[ROWS_PER_WAVE];
+        float oldv1[ROWS_PER_WAVE];
+#pragma unroll
+        for (int k = 0; k < ROWS_PER_WAVE; k++) {
+            // BilinearTab_f weights are products of k/32 in float (exact); accumulate in double like remapBilinear<double>
+            const float fx = (float)fxi[k] * 0.03125f, fy = (float)fyi[k] * 0.03125f;
+            const float w0 = (1.f - fy) * (1.f - fx), w1 = (1.f - fy) * fx, w2 = fy * (1.f - fx), w3 = fy * fx;
+            const double nd = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn((double)tapv[k][0], (double)w0), __dmul_rn((double)tapv[k][1], (double)w1)),
+                                                  __dmul_rn((double)tapv[k][2], (double)w2)), __dmul_rn((double)tapv[k][3], (double)w3));
+            nw[k] = (float)nd;  // curr_map is f32 (value_map.py:316-317)
+            const int mr = pose.row0 + row_begin + k;
+            act[k] = any_tap[k] && nw[k] != 0.0f;
+            // new_map[explored == 0] = 0 (:373); the old values of such cells were zeroed by mask_unexplored
+            if (explored && act[k]) act[k] = (explored[(size_t)mr * ex_stride + (mc >> 5)] >> (mc & 31)) & 1u;
+            cell[k] = act[k] ? (size_t)mr * S + mc : 0;
+            old[k] = conf[cell[k]];
+            if (C_STATIC == 1) oldv1[k] = value[cell[k]];
         }
-        if (nw < 0.35f && nw < old) continue;  // decision threshold (:398-399)
-        if (a.use_max_conf) {                   // (:401-408)
-            if (nw > old) {
-                conf[cell] = nw;
-                for (int c = 0; c < C; c++) value[cell * C + c] = (float)vals[c];
+        // ---- phase C: fuse and write back
+#pragma unroll
+        for (int k = 0; k < ROWS_PER_WAVE; k++) {
+            if (!act[k]) continue;
+            if (C_STATIC == 1) {
+                float c_out, v_out;
+                if (fuse_cell<1>(a, nw[k], old[k], &oldv1[k], vals, c_out, &v_out)) {
+                    conf[cell[k]] = c_out;
+                    value[cell[k]] = v_out;
+                }
+            } else {
+                // the keep/skip decision and the new confidence do not depend on the channel
+                float c_out = 0.0f;
+                bool wrote = false;
+                for (int c = 0; c < C; c++) {
+                    const float ov = value[cell[k] * C + c];
+                    float nv;
+                    wrote = fuse_cell<1>(a, nw[k], old[k], &ov, vals + c, c_out, &nv);
+                    if (!wrote) break;
+                    value[cell[k] * C + c] = nv;
+                }
+                if (wrote) conf[cell[k]] = c_out;
             }
-            continue;
         }
-        // weighted average (:414-424): weights in f32, value blend in f64 (values is an f64 ndarray), conf in f32
-        const float den = __fadd_rn(old, nw);
-        const float w_old = __fdiv_rn(old, den), w_new = __fdiv_rn(nw, den);
-        for (int c = 0; c < C; c++) {
-            const double v = __dadd_rn(__dmul_rn((double)value[cell * C + c], (double)w_old), __dmul_rn(vals[c], (double)w_new));
-            value[cell * C + c] = (float)v;
-        }
-        conf[cell] = __fadd_rn(__fmul_rn(old, w_old), __fmul_rn(nw, w_new));
     }
 }
 
 // ------------------------------------------------------------------------------------------------ full-map mask
-// conf = value = 0 where explored == 0.  16 cells per thread: one 16-B explored load, 16-B conf/value accesses.
-// A group whose 16 cells are all explored costs 16 bytes; otherwise conf/value are read and only rewritten when a
-// non-zero cell has to be cleared, so an idle (already clean) map costs reads only.
-__device__ inline bool clear_unexplored4(float4& v, unsigned e4) {
+// conf = value = 0 where explored == 0 (value_map.py:369-375), for the rows [row_lo, row_hi) of each listed environment.
+// One thread per group of 4 cells: a 4-bit nibble of the bit-packed explored plane (8 lanes share a word), one 16-B conf
+// access and one 16-B value access (C == 1); a wavefront covers 1 KB of contiguous map.  A group whose cells are all
+// explored costs nothing beyond the bit word; otherwise conf/value are read and rewritten only if a non-zero cell has
+// to be cleared, so a clean map costs reads only.  The row range lets the host skip rows no update window has ever
+// touched (they are zero already): identical result, bytes proportional to the area the episode has covered.
+struct MaskJob { int env, row_lo, row_hi, reserved; };
+
+__device__ inline bool clear_unexplored4(float4& v, unsigned nib) {
     bool dirty = false;
-    if ((e4 & 0x000000FFu) == 0 && v.x != 0.0f) { v.x = 0.0f; dirty = true; }
-    if ((e4 & 0x0000FF00u) == 0 && v.y != 0.0f) { v.y = 0.0f; dirty = true; }
-    if ((e4 & 0x00FF0000u) == 0 && v.z != 0.0f) { v.z = 0.0f; dirty = true; }
-    if ((e4 & 0xFF000000u) == 0 && v.w != 0.0f) { v.w = 0.0f; dirty = true; }
+    if (!(nib & 1u) && v.x != 0.0f) { v.x = 0.0f; dirty = true; }
+    if (!(nib & 2u) && v.y != 0.0f) { v.y = 0.0f; dirty = true; }
+    if (!(nib & 4u) && v.z != 0.0f) { v.z = 0.0f; dirty = true; }
+    if (!(nib & 8u) && v.w != 0.0f) { v.w = 0.0f; dirty = true; }
     return dirty;
 }
-__device__ inline bool all_explored4(unsigned e4) {
-    return (e4 & 0xFFu) && (e4 & 0xFF00u) && (e4 & 0xFF0000u) && (e4 & 0xFF000000u);
-}
 
-__global__ __launch_bounds__(256) void mask_unexplored_kernel(const int* __restrict__ env_ids, int S, int C,
-                                                              const unsigned char* __restrict__ explored,
+__global__ __launch_bounds__(256) void mask_unexplored_kernel(const MaskJob* __restrict__ jobs, int S, int C,
+                                                              const unsigned* __restrict__ explored,
                                                               float* __restrict__ conf, float* __restrict__ value) {
-    const int slot = env_ids ? env_ids[blockIdx.y] : (int)blockIdx.y;
+    const MaskJob job = jobs[blockIdx.y];
+    const int ex_stride = (S + 31) >> 5;
+    const int groups = S >> 2;  // S % 4 == 0 (checked by the host)
     const size_t cells = (size_t)S * S;
-    const unsigned char* ex = explored + (size_t)slot * cells;
-    float* cf = conf + (size_t)slot * cells;
-    float* vl = value + (size_t)slot * cells * C;
-    const size_t n16 = cells / 16;
-    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < n16; g += (size_t)gridDim.x * blockDim.x) {
-        const uint4 e = reinterpret_cast<const uint4*>(ex)[g];
-        const unsigned ew[4] = {e.x, e.y, e.z, e.w};
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            if (all_explored4(ew[q])) continue;
-            const size_t quad = g * 4 + q;  // index of this float4 of cells
-            float4 c4 = reinterpret_cast<float4*>(cf)[quad];
-            if (clear_unexplored4(c4, ew[q])) reinterpret_cast<float4*>(cf)[quad] = c4;
-            if (C == 1) {
-                float4 v4 = reinterpret_cast<float4*>(vl)[quad];
-                if (clear_unexplored4(v4, ew[q])) reinterpret_cast<float4*>(vl)[quad] = v4;
-            } else {
-                for (int k = 0; k < 4; k++) {
-                    if (((ew[q] >> (8 * k)) & 0xFFu) != 0) continue;
-                    for (int c = 0; c < C; c++) {
-                        float* vp = vl + (quad * 4 + k) * C + c;
-                        if (*vp != 0.0f) *vp = 0.0f;
-                    }
+    const unsigned* ex = explored + (size_t)job.env * S * ex_stride;
+    float* cf = conf + (size_t)job.env * cells;
+    float* vl = value + (size_t)job.env * cells * C;
+    const long long total = (long long)(job.row_hi - job.row_lo) * groups;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int row = job.row_lo + (int)(i / groups), g = (int)(i % groups);
+        const unsigned nib = (ex[(size_t)row * ex_stride + (g >> 3)] >> ((g & 7) * 4)) & 0xFu;
+        if (nib == 0xFu) continue;
+        const size_t quad = ((size_t)row * S >> 2) + g;
+        float4 c4 = reinterpret_cast<float4*>(cf)[quad];
+        if (clear_unexplored4(c4, nib)) reinterpret_cast<float4*>(cf)[quad] = c4;
+        if (C == 1) {
+            float4 v4 = reinterpret_cast<float4*>(vl)[quad];
+            if (clear_unexplored4(v4, nib)) reinterpret_cast<float4*>(vl)[quad] = v4;
+        } else {
+            for (int k = 0; k < 4; k++) {
+                if ((nib >> k) & 1u) continue;
+                for (int c = 0; c < C; c++) {
+                    float* vp = vl + (quad * 4 + k) * C + c;
+                    if (*vp != 0.0f) *vp = 0.0f;
                 }
-            }
-        }
-    }
-    if (blockIdx.x == 0) {  // tail when S*S is not a multiple of 16
-        for (size_t i = n16 * 16 + threadIdx.x; i < cells; i += blockDim.x) {
-            if (ex[i] == 0) {
-                cf[i] = 0.0f;
-                for (int c = 0; c < C; c++) vl[i * C + c] = 0.0f;
             }
         }
     }
@@ -326,37 +391,46 @@ __global__ __launch_bounds__(256) void sort_waypoints_kernel(const float* __rest
 using namespace vlfm;
 
 extern "C" int vlfm_cone_template_build(const float* d_conf, const int64_t* d_poly_xy, int n_poly, int template_size,
-                                        float* d_template, void* stream) {
-    if (!d_conf || !d_poly_xy || !d_template || n_poly < 3 || template_size <= 0) return fail(VLFM_ERR_INVALID, "cone_template_build: bad argument");
+                                        float* d_template, uint32_t* d_template_bits, void* stream) {
+    if (!d_conf || !d_poly_xy || !d_template || !d_template_bits || n_poly < 3 || template_size <= 0)
+        return fail(VLFM_ERR_INVALID, "cone_template_build: bad argument");
     const int T = template_size, words = (T + 31) >> 5;
     const size_t lds = (size_t)2 * T * words * sizeof(unsigned);
     if (lds > 160 * 1024) return fail(VLFM_ERR_CAPACITY, "cone_template_build: template too large for LDS");
     hipLaunchKernelGGL(cone_template_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, d_conf,
-                       reinterpret_cast<const long long*>(d_poly_xy), n_poly, T, d_template);
+                       reinterpret_cast<const long long*>(d_poly_xy), n_poly, T, d_template, d_template_bits);
     return check_launch("cone_template_kernel");
 }
 
-static size_t update_lds_bytes(int T) {
+static int vis_stride_words(int T) {
     const int words = (T + 31) >> 5;
-    size_t bm_words = (size_t)2 * T * words;
-    bm_words += (4 - (bm_words & 3)) & 3;
-    return bm_words * 4 + (size_t)4 * T * sizeof(int);
+    return (T * words + 3) & ~3;
+}
+
+extern "C" size_t vlfm_value_map_scratch_bytes(int n, int template_size) {
+    if (n <= 0 || template_size <= 0) return 0;
+    return (size_t)n * vis_stride_words(template_size) * sizeof(uint32_t);
 }
 
 extern "C" int vlfm_value_map_update_batched(uint32_t* d_colmax_keys, int width, const double* d_tan,
-                                             const float* d_template, int template_size, const vlfm_vm_pose* d_pose,
+                                             const float* d_template, const uint32_t* d_template_bits,
+                                             int template_size, const vlfm_vm_pose* d_pose,
                                              const double* d_values, int n, float* d_conf, float* d_value,
                                              int map_size, int channels, int pixels_per_meter, double min_depth,
                                              double max_depth, int use_max_confidence, int fusion_type,
-                                             const uint8_t* d_explored, int32_t* d_vertices, void* stream) {
+                                             const uint32_t* d_explored_bits, void* d_scratch, void* stream) {
     if (n == 0) return VLFM_OK;
-    if (!d_colmax_keys || !d_tan || !d_template || !d_pose || !d_values || !d_conf || !d_value || n < 0 || width <= 0 ||
-        template_size <= 0 || map_size <= 0 || channels <= 0 || fusion_type < 0 || fusion_type > 2)
+    if (!d_colmax_keys || !d_tan || !d_template || !d_template_bits || !d_pose || !d_values || !d_conf || !d_value ||
+        n < 0 || width <= 0 || template_size <= 0 || map_size <= 0 || channels <= 0 || fusion_type < 0 || fusion_type > 2)
         return fail(VLFM_ERR_INVALID, "value_map_update_batched: bad argument");
+    if (!d_scratch) return fail(VLFM_ERR_INVALID, "value_map_update_batched: d_scratch is null");
     UpdateArgs a;
-    a.colmax = reinterpret_cast<unsigned*>(d_colmax_keys); a.tan_tab = d_tan; a.tmpl = d_template; a.pose = d_pose; a.values = d_values;
-    a.conf = d_conf; a.value = d_value; a.explored = d_explored;
+    a.colmax = reinterpret_cast<unsigned*>(d_colmax_keys); a.tan_tab = d_tan; a.tmpl = d_template;
+    a.tmpl_bits = d_template_bits; a.pose = d_pose; a.values = d_values;
+    a.conf = d_conf; a.value = d_value; a.explored = d_explored_bits;
     a.W = width; a.T = template_size; a.S = map_size; a.C = channels;
+    a.vis_stride = vis_stride_words(template_size);
+    a.visible = reinterpret_cast<unsigned*>(d_scratch);
     // NumPy: f32 array (op) Python float -> the scalar is rounded to f32 first (value_map.py:234,248)
     a.depth_scale = (float)(max_depth - min_depth);
     a.depth_offset = (float)min_depth;
@@ -365,37 +439,39 @@ extern "C" int vlfm_value_map_update_batched(uint32_t* d_colmax_keys, int width,
     a.ppm_d = (double)pixels_per_meter;
     a.half_t_d = template_size / 2.0;
     a.use_max_conf = use_max_confidence; a.fusion = fusion_type;
-    if (!d_vertices) return fail(VLFM_ERR_INVALID, "value_map_update_batched: d_vertices scratch is null");
-    a.vertices = reinterpret_cast<int2*>(d_vertices);
-    const size_t lds = update_lds_bytes(template_size);
-    if (lds > 160 * 1024) return fail(VLFM_ERR_CAPACITY, "value_map_update_batched: template too large for LDS");
+    const int T = template_size, words = (T + 31) >> 5;
+    const size_t lds_mask = (size_t)(2 * T * words + ((2 * T * words) & 1)) * 4 + (size_t)(width + 2) * sizeof(int2);
+    const size_t lds_fuse = (size_t)a.vis_stride * 4;
+    if (lds_mask > 160 * 1024) return fail(VLFM_ERR_CAPACITY, "value_map_update_batched: template/width too large for LDS");
     {
-        VLFM_TIMED("depth_profile_kernel", stream);
-        hipLaunchKernelGGL(depth_profile_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, a);
+        VLFM_TIMED("visible_mask_kernel", stream);
+        hipLaunchKernelGGL(visible_mask_kernel, dim3(n), dim3(512), lds_mask, (hipStream_t)stream, a);
     }
     const int tiles = (template_size + ROWS_PER_TILE - 1) / ROWS_PER_TILE;
-    VLFM_TIMED("value_map_update_kernel", stream);
+    VLFM_TIMED("value_map_fuse_kernel", stream);
     if (channels == 1)
-        hipLaunchKernelGGL(value_map_update_kernel<1>, dim3(tiles, n), dim3(512), lds, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(value_map_fuse_kernel<1>, dim3(tiles, n), dim3(256), lds_fuse, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(value_map_update_kernel<0>, dim3(tiles, n), dim3(512), lds, (hipStream_t)stream, a);
-    return check_launch("value_map_update_kernel");
+        hipLaunchKernelGGL(value_map_fuse_kernel<0>, dim3(tiles, n), dim3(256), lds_fuse, (hipStream_t)stream, a);
+    return check_launch("value_map_fuse_kernel");
 }
 
-extern "C" int vlfm_value_map_mask_unexplored_batched(const int32_t* d_env, int n, const uint8_t* d_explored,
-                                                      float* d_conf, float* d_value, int map_size, int channels,
-                                                      void* stream) {
-    if (n == 0) return VLFM_OK;
-    if (!d_explored || !d_conf || !d_value || n < 0 || map_size <= 0 || channels <= 0)
+extern "C" int vlfm_value_map_mask_unexplored_batched(const vlfm_mask_job* d_jobs, int n, int max_rows,
+                                                      const uint32_t* d_explored_bits, float* d_conf, float* d_value,
+                                                      int map_size, int channels, void* stream) {
+    if (n == 0 || max_rows == 0) return VLFM_OK;
+    if (!d_jobs || !d_explored_bits || !d_conf || !d_value || n < 0 || max_rows < 0 || map_size <= 0 || channels <= 0)
         return fail(VLFM_ERR_INVALID, "mask_unexplored_batched: bad argument");
-    if (((size_t)map_size * map_size) % 4 != 0) return fail(VLFM_ERR_INVALID, "mask_unexplored_batched: S*S must be a multiple of 4");
-    const size_t n16 = (size_t)map_size * map_size / 16;
-    int bx = (int)((n16 + 255) / 256);
-    if (bx > 512) bx = 512;
+    if (map_size % 4 != 0) return fail(VLFM_ERR_INVALID, "mask_unexplored_batched: map size must be a multiple of 4");
+    static_assert(sizeof(MaskJob) == sizeof(vlfm_mask_job), "mask job layout");
+    const long long groups = (long long)max_rows * (map_size / 4);
+    long long bx = (groups + 255) / 256;
+    const long long cap = n >= 8 ? 256 : 2048 / (n > 0 ? n : 1);  // ~2048 workgroups in flight over all environments
+    if (bx > cap) bx = cap;
     if (bx < 1) bx = 1;
     VLFM_TIMED("mask_unexplored_kernel", stream);
-    hipLaunchKernelGGL(mask_unexplored_kernel, dim3(bx, n), dim3(256), 0, (hipStream_t)stream, d_env, map_size,
-                       channels, d_explored, d_conf, d_value);
+    hipLaunchKernelGGL(mask_unexplored_kernel, dim3((unsigned)bx, n), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const MaskJob*>(d_jobs), map_size, channels, d_explored_bits, d_conf, d_value);
     return check_launch("mask_unexplored_kernel");
 }
 

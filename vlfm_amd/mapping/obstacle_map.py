@@ -18,7 +18,7 @@ import numpy as np
 
 from .. import _lib
 from .base_map import BaseMap, require_gpu
-from .value_map import UploadRing, _stream_ptr
+from .value_map import INGEST_DTYPE, UploadRing, _stream_ptr
 
 
 def _wrap_heading(theta):
@@ -29,6 +29,7 @@ class ObstacleMapBatch:
     CAP_PTS = 16384       # border points per environment and scan
     CAP_CONTOURS = 2048
     CAP_FRONTIERS = 256
+    READ_FRONTIERS = 32   # frontiers per environment fetched by the fast read-back path (more -> one full copy)
 
     def __init__(self, n_envs: int, min_height: float, max_height: float, agent_radius: float, area_thresh: float = 3.0,
                  hole_area_thresh: int = 100000, size: int = 1000, pixels_per_meter: int = 20, device=None) -> None:
@@ -52,10 +53,16 @@ class ObstacleMapBatch:
         self.counts = torch.zeros((n_envs, 4), dtype=torch.int32, device=self.device)
         self.colmax_keys = None
         self.status = torch.zeros((n_envs, 2), dtype=torch.int32, device=self.device)
-        self._ring_ingest = UploadRing(self.device, n_envs * ctypes.sizeof(_lib.IngestParams))
-        self._ring_fog = UploadRing(self.device, n_envs * ctypes.sizeof(_lib.FogParams))
+        self._ring_ingest = UploadRing(self.device, n_envs * INGEST_DTYPE.itemsize, slots=8)
+        self._ring_fog = UploadRing(self.device, n_envs * ctypes.sizeof(_lib.FogParams), slots=8)
         self.frontiers_ready = False
         self._explored_u8 = None
+        # read-back path of the step: fixed-size staging + pinned host buffers, so a step never allocates and never
+        # hands the runtime a pageable destination (which it would have to pin on the fly)
+        self._d_fr_stage = torch.zeros((n_envs, self.READ_FRONTIERS, 2), dtype=torch.float64, device=self.device)
+        self._h_fr = torch.zeros((n_envs, self.READ_FRONTIERS, 2), dtype=torch.float64).pin_memory()
+        self._h_counts = torch.zeros((n_envs, 4), dtype=torch.int32).pin_memory()
+        self._h_status = torch.zeros((n_envs, 2), dtype=torch.int32).pin_memory()
 
     # ------------------------------------------------------------------------------------------ state
     def reset(self, env_ids: Optional[Sequence[int]] = None) -> None:
@@ -95,15 +102,13 @@ class ObstacleMapBatch:
         n, H, W = depth.shape
         tf = np.asarray(tf, np.float64).reshape(n, 4, 4)
         assert np.array_equal(tf[:, 3, :], np.tile([0.0, 0, 0, 1], (n, 1))), "camera transforms must be affine"
-        prm = (_lib.IngestParams * n)()
-        for k in range(n):
-            p = prm[k]
-            p.tf[:] = tf[k, :3, :].reshape(-1).tolist()
-            p.depth_scale, p.depth_offset, p.depth_max = max_depth - min_depth, min_depth, max_depth
-            p.fx, p.fy = fx, fy
-            p.min_height, p.max_height = self._min_height, self._max_height
-            p.env = k if env_ids is None else env_ids[k]
-            p.scatter = (1 if update_obstacles else 0) | (2 if self._hole_area_thresh == -1 else 0)
+        prm = np.zeros(n, INGEST_DTYPE)
+        prm["tf"] = tf[:, :3, :].reshape(n, 12)
+        prm["depth_scale"], prm["depth_offset"], prm["depth_max"] = max_depth - min_depth, min_depth, max_depth
+        prm["fx"], prm["fy"] = fx, fy
+        prm["min_height"], prm["max_height"] = self._min_height, self._max_height
+        prm["env"] = np.arange(n) if env_ids is None else np.asarray(env_ids)
+        prm["scatter"] = (1 if update_obstacles else 0) | (2 if self._hole_area_thresh == -1 else 0)
         keys = None
         if want_colmax:
             if self.colmax_keys is None or self.colmax_keys.shape != (max(n, self.n_envs), W):
@@ -164,11 +169,23 @@ class ObstacleMapBatch:
     # ------------------------------------------------------------------------------------------ read-back
     def frontiers_px(self) -> List[np.ndarray]:
         """Per environment: (F,2) f64 pixel coordinates (x,y) == ObstacleMap._frontiers_px.  One D2H copy."""
-        counts = self.counts.cpu().numpy()
+        counts, fr = self._read_frontiers()
+        return [fr[e, :counts[e, 0]].copy() for e in range(self.n_envs)]
+
+    def _read_frontiers(self):
+        import torch
+
+        with torch.cuda.device(self.device):
+            self._d_fr_stage.copy_(self.frontiers_px_dev[:, :self.READ_FRONTIERS])
+            self._h_counts.copy_(self.counts, non_blocking=True)
+            self._h_fr.copy_(self._d_fr_stage, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        counts = self._h_counts.numpy()
         if (counts[:, 1] != 0).any():
             raise RuntimeError("obstacle-map scratch capacity exceeded (CAP_PTS/CAP_CONTOURS/CAP_FRONTIERS)")
-        fr = self.frontiers_px_dev.cpu().numpy()
-        return [fr[e, :counts[e, 0]].copy() for e in range(self.n_envs)]
+        if len(counts) and int(counts[:, 0].max()) > self.READ_FRONTIERS:
+            return counts, self.frontiers_px_dev.cpu().numpy()
+        return counts, self._h_fr.numpy()
 
     def px_to_xy(self, px: np.ndarray) -> np.ndarray:
         q = px.copy()
@@ -178,13 +195,19 @@ class ObstacleMapBatch:
 
     def frontier_list(self):
         """All frontiers of all environments as (xy [M,2], env index [M]) for ValueMapBatch.waypoint_values."""
-        per_env = self.frontiers_px()
-        xy = [self.px_to_xy(p) if len(p) else np.zeros((0, 2)) for p in per_env]
-        env_of = np.concatenate([np.full(len(p), e, np.int64) for e, p in enumerate(per_env)]) if per_env else np.zeros(0)
-        return (np.concatenate(xy) if len(xy) else np.zeros((0, 2))), env_of
+        counts, fr = self._read_frontiers()
+        keep = np.arange(fr.shape[1])[None, :] < counts[:, :1]          # [n_envs, top]
+        env_of = np.nonzero(keep)[0]
+        px = fr[keep]                                                    # env-major, frontier order preserved
+        return (self.px_to_xy(px) if len(px) else np.zeros((0, 2))), env_of
 
     def check_status(self) -> None:
-        st = self.status.cpu().numpy()
+        import torch
+
+        with torch.cuda.device(self.device):
+            self._h_status.copy_(self.status, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        st = self._h_status.numpy().copy()
         self.status.zero_()
         if (st[:, 0] != 0).any():
             raise IndexError("index out of bounds: obstacle point fell off the map (obstacle_map.py:101)")
@@ -224,9 +247,10 @@ class ObstacleMap(BaseMap):
     def explored_area(self) -> np.ndarray:
         return self._batch.explored[0].cpu().numpy().astype(bool)
 
-    def explored_area_device(self):
-        """[1,S,S] uint8 device tensor for ValueMap's explored-area synchronisation (value_map.py:369-375)."""
-        return self._batch.explored
+    def explored_bits_device(self):
+        """[1,S,ceil(S/32)] bit-packed explored area in HBM for ValueMap's explored-area synchronisation
+        (value_map.py:369-375)."""
+        return self._batch.explored_bits
 
     def reset(self) -> None:
         super().reset()

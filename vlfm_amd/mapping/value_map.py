@@ -40,13 +40,16 @@ def _bytes_to_device(buf, device):
 class UploadRing:
     """Small per-step parameter blocks (poses, ingest parameters) go to HBM through a ring of pinned host buffers with
     asynchronous copies on the compute stream, so a step never blocks on a pageable H2D copy.  A slot is reused only
-    after the copy that last read it has completed (event check)."""
+    after the copy that last read it has completed (event check).  The host-side fill is a plain single-threaded
+    NumPy memcpy into the pinned buffer: a torch CPU copy of >= 32 K elements would fan out over the OpenMP pool, whose
+    spinning workers can exhaust a container's CPU quota and stall the whole process until the next scheduler period."""
 
     def __init__(self, device, nbytes: int, slots: int = 4) -> None:
         import torch
 
         self.device, self.nbytes = device, nbytes
         self.host = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(slots)]
+        self.host_np = [h.numpy() for h in self.host]
         self.dev = [torch.empty(nbytes, dtype=torch.uint8, device=device) for _ in range(slots)]
         self.done = [None] * slots
         self.k = 0
@@ -54,18 +57,32 @@ class UploadRing:
     def upload(self, buf):
         import torch
 
-        raw = bytes(buf)
-        assert len(raw) <= self.nbytes
+        if isinstance(buf, np.ndarray):
+            src = np.ascontiguousarray(buf).view(np.uint8).reshape(-1)
+        else:
+            src = np.frombuffer(buf, dtype=np.uint8)  # ctypes arrays / bytes expose the buffer protocol
+        n = src.size
+        assert n <= self.nbytes
         i = self.k
         self.k = (self.k + 1) % len(self.host)
         if self.done[i] is not None:
             self.done[i].synchronize()
-        self.host[i][: len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
-        self.dev[i][: len(raw)].copy_(self.host[i][: len(raw)], non_blocking=True)
+        self.host_np[i][:n] = src
+        self.dev[i][:n].copy_(self.host[i][:n], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self.done[i] = ev
         return self.dev[i]
+
+
+# NumPy views of the C structs of include/vlfm_amd.h (filled by the library's host functions or by array ops)
+VM_POSE_DTYPE = np.dtype([("inv_affine", "<f8", (6,)), ("row0", "<i4"), ("col0", "<i4"), ("env", "<i4"),
+                          ("reserved", "<i4")])
+INGEST_DTYPE = np.dtype([("tf", "<f8", (12,)), ("depth_scale", "<f4"), ("depth_offset", "<f4"), ("depth_max", "<f4"),
+                         ("reserved0", "<f4"), ("fx", "<f8"), ("fy", "<f8"), ("min_height", "<f8"),
+                         ("max_height", "<f8"), ("env", "<i4"), ("scatter", "<i4")])
+MASK_JOB_DTYPE = np.dtype([("env", "<i4"), ("row_lo", "<i4"), ("row_hi", "<i4"), ("reserved", "<i4")])
+assert VM_POSE_DTYPE.itemsize == 64 and INGEST_DTYPE.itemsize == 152 and MASK_JOB_DTYPE.itemsize == 16
 
 
 class _ConeTemplates:
@@ -95,11 +112,13 @@ class _ConeTemplates:
             d_conf = torch.from_numpy(conf).to(device)
             d_poly = torch.from_numpy(poly).to(device)
             d_tmpl = torch.empty(T * T, dtype=torch.float32, device=device)
+            d_bits = torch.empty(T * ((T + 31) // 32), dtype=torch.int32, device=device)
             with torch.cuda.device(device):
                 _lib.check(L.vlfm_cone_template_build(d_conf.data_ptr(), d_poly.data_ptr(), n_poly.value, T,
-                                                      d_tmpl.data_ptr(), _stream_ptr()), "cone_template_build")
+                                                      d_tmpl.data_ptr(), d_bits.data_ptr(), _stream_ptr()),
+                           "cone_template_build")
                 torch.cuda.current_stream().synchronize()
-            self._tmpl[key] = (d_tmpl, T)
+            self._tmpl[key] = (d_tmpl, d_bits, T)
         return self._tmpl[key]
 
     def tan_table(self, device, fov: float, width: int):
@@ -141,11 +160,11 @@ def _confidence_table_numpy(T: int, fov: float, min_conf: float) -> np.ndarray:
     return np.ascontiguousarray(conf.astype(np.float32))
 
 
-def pose_params(tf: np.ndarray, env_ids: Optional[Sequence[int]], size: int, ppm: int, T: int):
-    """Host prologue of ValueMap._localize_new_data for n observations -> ctypes array of VmPose."""
+def pose_params(tf: np.ndarray, env_ids: Optional[Sequence[int]], size: int, ppm: int, T: int) -> np.ndarray:
+    """Host prologue of ValueMap._localize_new_data for n observations -> structured array of vlfm_vm_pose."""
     tf = np.ascontiguousarray(np.asarray(tf, np.float64).reshape(-1, 16))
     n = tf.shape[0]
-    out = (_lib.VmPose * n)()
+    out = np.zeros(n, VM_POSE_DTYPE)
     env = None
     if env_ids is not None:
         env = np.ascontiguousarray(np.asarray(env_ids, np.int32))
@@ -155,7 +174,7 @@ def pose_params(tf: np.ndarray, env_ids: Optional[Sequence[int]], size: int, ppm
     yaw = np.ascontiguousarray(np.arctan2(tf[:, 4], tf[:, 0]))
     rc = _lib.lib().vlfm_value_map_pose_params(tf.ctypes.data, yaw.ctypes.data,
                                                env.ctypes.data if env is not None else None, n, size,
-                                               ppm, T, ctypes.addressof(out), ctypes.byref(bad))
+                                               ppm, T, out.ctypes.data, ctypes.byref(bad))
     _lib.check(rc, "value_map_pose_params")
     return out
 
@@ -167,7 +186,7 @@ class ValueMapBatch:
 
     def __init__(self, n_envs: int, value_channels: int, size: int = 1000, use_max_confidence: bool = True,
                  fusion_type: str = "default", pixels_per_meter: int = 20, device=None,
-                 explored: Optional[Any] = None) -> None:
+                 explored_bits: Optional[Any] = None) -> None:
         import torch
 
         self.device = require_gpu(device)
@@ -180,21 +199,37 @@ class ValueMapBatch:
         assert self.fusion_type in _lib.FUSION_TYPES, f"Unknown fusion type {self.fusion_type}"
         self.conf = torch.zeros((n_envs, size, size), dtype=torch.float32, device=self.device)
         self.value = torch.zeros((n_envs, size, size, value_channels), dtype=torch.float32, device=self.device)
-        # ObstacleMap.explored_area of the same slots ([n_envs,S,S] uint8/bool tensor) when sync_explored_areas
-        self.explored = explored
+        # bit-packed ObstacleMap.explored_area of the same slots ([n_envs,S,ceil(S/32)] int32) when the value map is
+        # synchronised with an obstacle map (value_map.py:369-375); None = Habitat default
+        self.explored_bits = explored_bits
+        # rows any update window has ever touched, per slot: everything outside is still zero, so the full-map
+        # "zero where unexplored" sweep only has to visit these rows
+        self._row_lo = np.full(n_envs, size, np.int64)
+        self._row_hi = np.zeros(n_envs, np.int64)
         self._colmax = None
         self._status = None
         self._ring = None
+        self._vis = None
+        self._wp_out = self._wp_host = self._wp_cells = None
 
     # ------------------------------------------------------------------------------------------ helpers
     def reset(self, env_ids: Optional[Sequence[int]] = None) -> None:
         if env_ids is None:
             self.conf.zero_()
             self.value.zero_()
+            self._row_lo[:] = self.size
+            self._row_hi[:] = 0
         else:
             idx = list(env_ids)
             self.conf[idx] = 0
             self.value[idx] = 0
+            self._row_lo[idx] = self.size
+            self._row_hi[idx] = 0
+
+    def _rings(self, n: int):
+        if self._ring is None or self._ring.nbytes < max(n, self.n_envs) * 256:
+            self._ring = UploadRing(self.device, max(n, self.n_envs) * 256, slots=8)
+        return self._ring
 
     def _scratch(self, n: int, width: int):
         import torch
@@ -203,17 +238,15 @@ class ValueMapBatch:
             # order-preserving u32 keys, zero = "-inf"; produced by depth ingest, consumed + re-zeroed by the update
             self._colmax = torch.zeros((max(n, self.n_envs), width), dtype=torch.int32, device=self.device)
             self._status = torch.zeros((max(n, self.n_envs), 2), dtype=torch.int32, device=self.device)
-            self._ring = UploadRing(self.device, max(n, self.n_envs) * 256)
-            self._vertices = torch.empty((max(n, self.n_envs), width + 2, 2), dtype=torch.int32, device=self.device)
         return self._colmax, self._status
 
-    def _vertex_scratch(self, n: int, width: int):
+    def _vis_scratch(self, n: int, T: int):
         import torch
 
-        v = getattr(self, "_vertices", None)
-        if v is None or v.shape[0] < n or v.shape[1] != width + 2:
-            self._vertices = torch.empty((max(n, self.n_envs), width + 2, 2), dtype=torch.int32, device=self.device)
-        return self._vertices
+        need = _lib.lib().vlfm_value_map_scratch_bytes(max(n, self.n_envs), T)
+        if self._vis is None or self._vis.numel() < need:
+            self._vis = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._vis
 
     def column_max(self, depth) -> Any:
         """np.max(depth, axis=0) for a [n,H,W] device tensor via the depth-ingest kernel (no obstacle scatter).
@@ -222,9 +255,9 @@ class ValueMapBatch:
 
         n, H, W = depth.shape
         colmax, status = self._scratch(n, W)
-        prm = (_lib.IngestParams * n)()
+        prm = np.zeros(n, INGEST_DTYPE)
         with torch.cuda.device(self.device):
-            d_prm = self._ring.upload(prm)
+            d_prm = self._rings(n).upload(prm)
             _lib.check(_lib.lib().vlfm_depth_ingest_batched(depth.data_ptr(), n, H, W, d_prm.data_ptr(),
                                                            colmax.data_ptr(), None, self.size, self.pixels_per_meter,
                                                            status.data_ptr(), _stream_ptr()), "depth_ingest")
@@ -235,8 +268,8 @@ class ValueMapBatch:
                env_ids: Optional[Sequence[int]] = None, colmax=None) -> None:
         """ValueMap.update_map for n observations at once (value_map.py:100-128).
 
-        values [n,C] f64 host array; depth [n,H,W] f32 (device tensor, or host array that is uploaded);
-        tf [n,4,4] f64 host; ``colmax`` = precomputed column maxima [n,W] on device (from a shared depth ingest).
+        values [n,C] f64 host array or device tensor; depth [n,H,W] f32 (device tensor, or host array that is
+        uploaded); tf [n,4,4] f64 host; ``colmax`` = column-max keys [n,W] on device (from a shared depth ingest).
         """
         import torch
 
@@ -253,34 +286,44 @@ class ValueMapBatch:
             assert depth.dtype == torch.float32
             colmax = self.column_max(depth)
         W = colmax.shape[-1]
-        d_tmpl, T = _TEMPLATES.template(self.device, fov, max_depth, self.pixels_per_meter, self._min_confidence)
+        d_tmpl, d_bits, T = _TEMPLATES.template(self.device, fov, max_depth, self.pixels_per_meter,
+                                                self._min_confidence)
         d_tan = _TEMPLATES.tan_table(self.device, fov, W)
         pose = pose_params(tf_camera_to_episodic, env_ids, self.size, self.pixels_per_meter, T)
-        if getattr(self, "_ring", None) is None:
-            self._ring = UploadRing(self.device, max(n, self.n_envs) * 256)
+        L = _lib.lib()
         with torch.cuda.device(self.device):
-            d_pose = self._ring.upload(pose)
-        explored_ptr = None
-        with torch.cuda.device(self.device):
-            L = _lib.lib()
-            if self.explored is not None:
-                ex = self.explored
-                assert ex.dtype in (torch.uint8, torch.bool) and ex.is_contiguous()
+            ring = self._rings(n)
+            d_pose = ring.upload(pose)
+            explored_ptr = None
+            if self.explored_bits is not None:
+                ex = self.explored_bits
+                assert ex.dtype == torch.int32 and ex.is_contiguous() and ex.shape[-2] == self.size
                 explored_ptr = ex.data_ptr()
-                slots = list(env_ids) if env_ids is not None else list(range(n))
-                d_env = torch.tensor(sorted(set(slots)), dtype=torch.int32, device=self.device)
-                _lib.check(L.vlfm_value_map_mask_unexplored_batched(d_env.data_ptr(), d_env.numel(), explored_ptr,
-                                                                    self.conf.data_ptr(), self.value.data_ptr(),
-                                                                    self.size, self.channels, _stream_ptr()),
-                           "mask_unexplored")
-            _lib.check(L.vlfm_value_map_update_batched(colmax.data_ptr(), W, d_tan.data_ptr(), d_tmpl.data_ptr(), T,
-                                                       d_pose.data_ptr(), d_vals.data_ptr(), n,
+                slots = np.unique(pose["env"])
+                jobs = np.zeros(len(slots), MASK_JOB_DTYPE)
+                jobs["env"] = slots
+                jobs["row_lo"] = np.minimum(self._row_lo[slots], self.size)
+                jobs["row_hi"] = self._row_hi[slots]
+                jobs = jobs[jobs["row_hi"] > jobs["row_lo"]]
+                if len(jobs):
+                    d_jobs = ring.upload(jobs)
+                    _lib.check(L.vlfm_value_map_mask_unexplored_batched(
+                        d_jobs.data_ptr(), len(jobs), int((jobs["row_hi"] - jobs["row_lo"]).max()), explored_ptr,
+                        self.conf.data_ptr(), self.value.data_ptr(), self.size, self.channels, _stream_ptr()),
+                        "mask_unexplored")
+            _lib.check(L.vlfm_value_map_update_batched(colmax.data_ptr(), W, d_tan.data_ptr(), d_tmpl.data_ptr(),
+                                                       d_bits.data_ptr(), T, d_pose.data_ptr(), d_vals.data_ptr(), n,
                                                        self.conf.data_ptr(), self.value.data_ptr(), self.size,
                                                        self.channels, self.pixels_per_meter, float(min_depth),
                                                        float(max_depth), int(self.use_max_confidence),
                                                        _lib.FUSION_TYPES[self.fusion_type], explored_ptr,
-                                                       self._vertex_scratch(n, W).data_ptr(), _stream_ptr()),
+                                                       self._vis_scratch(n, T).data_ptr(), _stream_ptr()),
                        "value_map_update")
+        # rows this step's windows may have written
+        lo = np.clip(pose["row0"], 0, self.size)
+        hi = np.clip(pose["row0"] + T, 0, self.size)
+        np.minimum.at(self._row_lo, pose["env"], lo)
+        np.maximum.at(self._row_hi, pose["env"], hi)
 
     # ------------------------------------------------------------------------------------------ frontier scoring
     def waypoint_values(self, waypoints_xy: np.ndarray, env_of_waypoint: Sequence[int], radius: float) -> np.ndarray:
@@ -292,22 +335,45 @@ class ValueMapBatch:
         if m == 0:
             return np.zeros((0, self.channels), np.float32)
         radius_px = int(radius * self.pixels_per_meter)
-        cells = np.zeros((m, 3), np.int32)
-        for i, ((x, y), e) in enumerate(zip(wp, env_of_waypoint)):
-            px = int(-x * self.pixels_per_meter) + self.size // 2  # truncation (value_map.py:165-166)
-            py = int(-y * self.pixels_per_meter) + self.size // 2
-            row, col = self.size - px, py
-            assert 0 <= row < self.size and 0 <= col < self.size, "Pixel location is outside the image."
-            cells[i] = (e, row, col)
-        d_cells = torch.from_numpy(cells).to(self.device)
+        # int() truncates toward zero (value_map.py:165-166) == ndarray.astype(int64) for finite values
+        px = (-wp[:, 0] * self.pixels_per_meter).astype(np.int64) + self.size // 2
+        py = (-wp[:, 1] * self.pixels_per_meter).astype(np.int64) + self.size // 2
+        row, col = self.size - px, py
+        assert ((row >= 0) & (row < self.size) & (col >= 0) & (col < self.size)).all(), \
+            "Pixel location is outside the image."
+        cells = np.stack([np.asarray(env_of_waypoint, np.int64), row, col], axis=1).astype(np.int32)
         d_disc = _TEMPLATES.disc(self.device, radius_px)
-        out = torch.empty((m, self.channels), dtype=torch.float32, device=self.device)
+        if self._wp_out is None or self._wp_out.shape[0] < m:
+            cap = max(64, 1 << (m - 1).bit_length())
+            self._wp_out = torch.empty((cap, self.channels), dtype=torch.float32, device=self.device)
+            self._wp_host = torch.empty((cap, self.channels), dtype=torch.float32).pin_memory()
+            self._wp_cells = UploadRing(self.device, cap * 12, slots=4)
         with torch.cuda.device(self.device):
+            d_cells = self._wp_cells.upload(cells)
             _lib.check(_lib.lib().vlfm_value_map_sort_waypoints_batched(self.value.data_ptr(), self.size,
                                                                        self.channels, d_cells.data_ptr(), m,
-                                                                       radius_px, d_disc.data_ptr(), out.data_ptr(),
-                                                                       _stream_ptr()), "sort_waypoints")
-        return out.cpu().numpy()
+                                                                       radius_px, d_disc.data_ptr(),
+                                                                       self._wp_out.data_ptr(), _stream_ptr()),
+                       "sort_waypoints")
+            self._wp_host[:m].copy_(self._wp_out[:m], non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        return self._wp_host[:m].numpy().copy()
+
+
+def _explored_bits_of(obstacle_map, device):
+    """Bit-packed explored area [1,S,ceil(S/32)] of an attached obstacle map: ours hands over its HBM plane; any other
+    object exposing the reference attribute ``explored_area`` (S,S bool) is uploaded and packed on the device."""
+    import torch
+
+    if hasattr(obstacle_map, "explored_bits_device"):
+        return obstacle_map.explored_bits_device()
+    area = np.ascontiguousarray(np.asarray(obstacle_map.explored_area).astype(np.uint8))
+    S = area.shape[0]
+    src = torch.from_numpy(area).to(device)
+    dst = torch.empty((1, S, (S + 31) // 32), dtype=torch.int32, device=device)
+    with torch.cuda.device(device):
+        _lib.check(_lib.lib().vlfm_bits_pack(src.data_ptr(), dst.data_ptr(), 1, S, S, _stream_ptr()), "bits_pack")
+    return dst
 
 
 class ValueMap(BaseMap):
@@ -361,7 +427,7 @@ class ValueMap(BaseMap):
         else:
             depth = depth.reshape(1, depth.shape[0], depth.shape[1])
         if self._obstacle_map is not None:
-            self._batch.explored = self._obstacle_map.explored_area_device()
+            self._batch.explored_bits = _explored_bits_of(self._obstacle_map, self._batch.device)
         self._batch.update(np.asarray(values, np.float64)[None], depth, np.asarray(tf_camera_to_episodic)[None],
                            min_depth, max_depth, fov, env_ids=[self._slot])
 
