@@ -169,13 +169,15 @@ int vlfm_value_map_sort_waypoints_batched(const float* d_value, int map_size, in
 int vlfm_resample_coeffs_host(int in_size, int out_size, int32_t* h_bounds, int32_t* h_kk, int kk_capacity,
                               int* ksize_out);
 
-/* Device: d_rgb [n][H][W][3] u8 -> d_out [n][3][out][out] (out_dtype 0=f32, 1=f16, 2=bf16):
- * PIL.Image.resize((out,out), BICUBIC) (two 8-bit passes, d_tmp [n][H][out][3] u8 scratch) -> /255 -> (x-mean)/std. */
+/* Device: d_rgb [n][H][W][3] u8 -> d_out (out_dtype 0=f32, 1=f16, 2=bf16):
+ * PIL.Image.resize((out,out), BICUBIC) (two 8-bit passes, d_tmp [n][H][out][3] u8 scratch) -> /255 -> (x-mean)/std.
+ * patch_size == 0: d_out is [n][3][out][out] (ToTensor layout).  patch_size == P > 0 (P divides out): d_out is
+ * [n][(out/P)^2][3*P*P], the im2col rows of a stride-P patch-embedding convolution (same values, GEMM-ready). */
 int vlfm_preprocess_rgb_batched(const uint8_t* d_rgb, int n, int height, int width, int out_size,
                                 const int32_t* d_hbounds, const int32_t* d_hk, int hksize,
                                 const int32_t* d_vbounds, const int32_t* d_vk, int vksize,
                                 const float* h_mean3, const float* h_std3, uint8_t* d_tmp, void* d_out,
-                                int out_dtype, void* stream);
+                                int out_dtype, int patch_size, void* stream);
 
 /* Device: ITC head epilogue.  d_proj [B][NQ][P] f32 = vision_proj(Q-Former query outputs) (the 768->256 GEMM itself is
  * a plain library GEMM), d_text [B][P] L2-normalised text features -> d_out [B] = max_q <normalize(proj_q), text>.

@@ -105,3 +105,25 @@ def test_resample_taps_reproduce_real_pil(shape):
         acc = (tmp[y0:y0 + cnt].astype(np.int64) * vk[yy, :cnt, None, None]).sum(axis=0) + (1 << 21)
         out[yy] = np.clip(acc >> 22, 0, 255)
     assert np.array_equal(out, want)
+
+
+def test_head_padding_is_exact():
+    """_VitBlock.pack_heads zero-pads the 88-wide heads to 96 inside the weights: outputs must not change."""
+    cfg = Blip2ITCConfig(image_size=28, patch_size=14, v_hidden=88 * 2, v_layers=2, v_heads=2, v_mlp=64, q_hidden=24,
+                         q_layers=2, q_heads=4, q_mlp=48, vocab_size=97, max_position_embeddings=40,
+                         num_query_tokens=5, proj_dim=8)
+    m = Blip2ITCModel(cfg).init_random(1).eval()
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() > 1:
+                p.mul_(8)
+            else:
+                p.add_(torch.randn_like(p) * 0.1)
+    x = torch.randn(2, 3, 28, 28)
+    with torch.inference_mode():
+        want = m.vision_tokens(x)
+        for blk in m.blocks:
+            blk.pack_heads()
+        assert m.blocks[0]._packed is not None and m.blocks[0]._packed[3] == 96
+        got = m.vision_tokens(x)
+    assert torch.allclose(got, want, atol=1e-6, rtol=0)

@@ -24,6 +24,10 @@ def test_preprocess_matches_pil_bit_exact(gpu_device, shape):
         assert torch.equal(out[i], want)  # bit-exact f32
     half = ops.preprocess_rgb(torch.from_numpy(imgs).to(gpu_device), 224, torch.float16).cpu()
     assert torch.equal(half, out.half())
+    # im2col layout for the GEMM patch embedding: same values, [n, 256, 588] in conv-weight order (c, ky, kx)
+    pat = ops.preprocess_rgb(torch.from_numpy(imgs).to(gpu_device), 224, torch.float32, patch_size=14).cpu()
+    want_pat = out.reshape(3, 3, 16, 14, 16, 14).permute(0, 2, 4, 1, 3, 5).reshape(3, 256, 588)
+    assert torch.equal(pat, want_pat)
 
 
 def test_itc_head_vs_fp32_reference(gpu_device):

@@ -94,7 +94,7 @@ def lib() -> ctypes.CDLL:
         L.vlfm_value_map_mask_unexplored_batched.argtypes = [vp, ci, ci, vp, vp, vp, ci, ci, vp]
         L.vlfm_value_map_sort_waypoints_batched.argtypes = [vp, ci, ci, vp, ci, ci, vp, vp, vp]
         L.vlfm_resample_coeffs_host.argtypes = [ci, ci, vp, vp, ci, ctypes.POINTER(ci)]
-        L.vlfm_preprocess_rgb_batched.argtypes = [vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, ci, vp]
+        L.vlfm_preprocess_rgb_batched.argtypes = [vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, ci, ci, vp]
         L.vlfm_itc_head_batched.argtypes = [vp, ci, ci, ci, vp, vp, vp]
         L.vlfm_bits_pack.argtypes = [vp, vp, ci, ci, ci, vp]
         L.vlfm_bits_unpack.argtypes = [vp, vp, ci, ci, ci, vp]

@@ -65,12 +65,14 @@ template <> __device__ inline __hip_bfloat16 cast_out<__hip_bfloat16>(float v) {
 
 struct Norm3 { float mean[3]; float std[3]; };
 
-// vertical pass + ToTensor + Normalize: [n][H][O][3] u8 -> [n][3][O][O] OutT
+// vertical pass + ToTensor + Normalize: [n][H][O][3] u8 -> OutT, either [n][3][O][O] (patch == 0) or, for a ViT whose
+// patch embedding is a stride-P convolution, directly in im2col order [n][(O/P)^2][3*P*P] (patch == P): the embedding
+// then is one plain GEMM with the conv weight viewed as [out][3*P*P], with no unfold pass over the image.
 template <typename OutT>
 __global__ __launch_bounds__(256) void resample_v_norm_kernel(const unsigned char* __restrict__ src, int H, int O,
                                                               const int* __restrict__ bounds,
                                                               const int* __restrict__ kk, int ksize, Norm3 nrm,
-                                                              OutT* __restrict__ dst) {
+                                                              OutT* __restrict__ dst, int patch) {
     const int yy = blockIdx.x, n = blockIdx.y;
     const int ymin = bounds[2 * yy], cnt = bounds[2 * yy + 1];
     const int* k = kk + yy * ksize;
@@ -82,7 +84,13 @@ __global__ __launch_bounds__(256) void resample_v_norm_kernel(const unsigned cha
         const float px = (float)clip8(ss);
         // ToTensor: u8 -> f32 / 255 ; Normalize: (x - mean) / std, all in f32
         const float v = __fdiv_rn(__fsub_rn(__fdiv_rn(px, 255.0f), nrm.mean[c]), nrm.std[c]);
-        dst[(((size_t)n * 3 + c) * O + yy) * O + xx] = cast_out<OutT>(v);
+        if (patch == 0) {
+            dst[(((size_t)n * 3 + c) * O + yy) * O + xx] = cast_out<OutT>(v);
+        } else {
+            const int g = O / patch, py = yy / patch, px_ = xx / patch;
+            const size_t cell = ((size_t)n * g * g + (size_t)py * g + px_) * (3 * patch * patch);
+            dst[cell + (size_t)c * patch * patch + (yy - py * patch) * patch + (xx - px_ * patch)] = cast_out<OutT>(v);
+        }
     }
 }
 
@@ -170,10 +178,10 @@ extern "C" int vlfm_preprocess_rgb_batched(const uint8_t* d_rgb, int n, int heig
                                            const int32_t* d_hbounds, const int32_t* d_hk, int hksize,
                                            const int32_t* d_vbounds, const int32_t* d_vk, int vksize,
                                            const float* h_mean3, const float* h_std3, uint8_t* d_tmp, void* d_out,
-                                           int out_dtype, void* stream) {
+                                           int out_dtype, int patch_size, void* stream) {
     if (n == 0) return VLFM_OK;
     if (!d_rgb || !d_hbounds || !d_hk || !d_vbounds || !d_vk || !h_mean3 || !h_std3 || !d_tmp || !d_out || n < 0 ||
-        height <= 0 || width <= 0 || out_size <= 0)
+        height <= 0 || width <= 0 || out_size <= 0 || patch_size < 0 || (patch_size > 0 && out_size % patch_size != 0))
         return fail(VLFM_ERR_INVALID, "preprocess_rgb_batched: bad argument");
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = ((size_t)width * 3 + 15) / 16 * 16;
@@ -189,13 +197,13 @@ extern "C" int vlfm_preprocess_rgb_batched(const uint8_t* d_rgb, int n, int heig
     VLFM_TIMED("resample_v_norm_kernel", s);
     if (out_dtype == 0)
         hipLaunchKernelGGL(resample_v_norm_kernel<float>, dim3(out_size, n), dim3(256), 0, s, d_tmp, height, out_size,
-                           d_vbounds, d_vk, vksize, nrm, (float*)d_out);
+                           d_vbounds, d_vk, vksize, nrm, (float*)d_out, patch_size);
     else if (out_dtype == 1)
         hipLaunchKernelGGL(resample_v_norm_kernel<__half>, dim3(out_size, n), dim3(256), 0, s, d_tmp, height,
-                           out_size, d_vbounds, d_vk, vksize, nrm, (__half*)d_out);
+                           out_size, d_vbounds, d_vk, vksize, nrm, (__half*)d_out, patch_size);
     else if (out_dtype == 2)
         hipLaunchKernelGGL(resample_v_norm_kernel<__hip_bfloat16>, dim3(out_size, n), dim3(256), 0, s, d_tmp, height,
-                           out_size, d_vbounds, d_vk, vksize, nrm, (__hip_bfloat16*)d_out);
+                           out_size, d_vbounds, d_vk, vksize, nrm, (__hip_bfloat16*)d_out, patch_size);
     else
         return fail(VLFM_ERR_INVALID, "preprocess_rgb_batched: out_dtype must be 0 (f32), 1 (f16) or 2 (bf16)");
     return check_launch("resample_v_norm_kernel");

@@ -40,8 +40,9 @@ def _device_coeffs(device, in_size: int, out_size: int):
 
 
 def preprocess_rgb(images_u8: torch.Tensor, out_size: int = 224, dtype: torch.dtype = torch.float16,
-                   mean=CLIP_MEAN, std=CLIP_STD) -> torch.Tensor:
-    """[n,H,W,3] uint8 (device) -> [n,3,out,out] normalised, via the PIL-exact bicubic kernels."""
+                   mean=CLIP_MEAN, std=CLIP_STD, patch_size: int = 0) -> torch.Tensor:
+    """[n,H,W,3] uint8 (device) -> [n,3,out,out] normalised, via the PIL-exact bicubic kernels.  With ``patch_size`` P
+    the same values come out as [n,(out/P)^2,3*P*P]: the im2col rows of the ViT's stride-P patch-embedding conv."""
     assert images_u8.is_cuda and images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.shape[-1] == 3
     images_u8 = images_u8.contiguous()
     n, H, W, _ = images_u8.shape
@@ -49,14 +50,18 @@ def preprocess_rgb(images_u8: torch.Tensor, out_size: int = 224, dtype: torch.dt
     hb, hk, hks = _device_coeffs(dev, W, out_size)
     vb, vk, vks = _device_coeffs(dev, H, out_size)
     tmp = torch.empty((n, H, out_size, 3), dtype=torch.uint8, device=dev)
-    out = torch.empty((n, 3, out_size, out_size), dtype=dtype, device=dev)
+    if patch_size:
+        g = out_size // patch_size
+        out = torch.empty((n, g * g, 3 * patch_size * patch_size), dtype=dtype, device=dev)
+    else:
+        out = torch.empty((n, 3, out_size, out_size), dtype=dtype, device=dev)
     m = (ctypes.c_float * 3)(*mean)
     s = (ctypes.c_float * 3)(*std)
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().vlfm_preprocess_rgb_batched(images_u8.data_ptr(), n, H, W, out_size, hb.data_ptr(),
                                                          hk.data_ptr(), hks, vb.data_ptr(), vk.data_ptr(), vks,
                                                          ctypes.addressof(m), ctypes.addressof(s), tmp.data_ptr(),
-                                                         out.data_ptr(), _DTYPE_CODE[dtype], _stream()),
+                                                         out.data_ptr(), _DTYPE_CODE[dtype], int(patch_size), _stream()),
                    "preprocess_rgb")
     return out
 
