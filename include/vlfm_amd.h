@@ -111,8 +111,27 @@ int vlfm_depth_ingest_batched(const float* d_depth, int n, int height, int width
                               uint32_t* d_colmax_keys /* [n][W] or NULL */,
                               uint32_t* d_obstacle /* [n_envs][S][ceil(S/32)] bit-packed or NULL */, int map_size, int pixels_per_meter,
                               int32_t* d_status /* [n][2] sticky: [0] VLFM_ERR_INDEX if a point fell off the map,
-                                                   [1] 1 if a zero depth texel was scattered un-filled */,
+                                                   [1] 1 if the image holds a zero (invalid) depth texel */,
+                              uint32_t* d_hole_bits /* OUT [n][H][ceil(W/32)] bit plane of (depth == 0), or NULL */,
+                              const uint32_t* d_filled_bits /* IN  [n][H][ceil(W/32)] texels fill_small_holes set to
+                                                               1.0 (vlfm_fill_small_holes_batched), or NULL */,
                               void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * fill_small_holes (vlfm/utils/img_utils.py:361-390) for n depth images, on the bit plane (depth == 0) produced by
+ * vlfm_depth_ingest_batched: cv2.findContours(RETR_TREE, CHAIN_APPROX_SIMPLE) = every outer AND hole border, in OpenCV's
+ * order; each border whose cv2.contourArea is < area_thresh is drawn filled (cv2.drawContours(.., 1, -1)) into
+ * d_filled_bits.  One workgroup per image; images whose status word [1] is 0 (no zero texel) cost one early exit and
+ * get an all-zero d_filled_bits only if they had holes before (see d_dirty).
+ *   d_status   [n][2] the ingest status (word 1 = image has zeros)
+ *   d_scratch  vlfm_hole_scratch_bytes(n, H, W, cap_pts, cap_contours) bytes
+ *   d_counts   [n][4] int32: (contours traced, contours filled, overflow flag, reserved)
+ * The obstacle scatter then runs as a second vlfm_depth_ingest_batched call with d_filled_bits (d_colmax_keys = NULL).
+ * ------------------------------------------------------------------------------------------- */
+size_t vlfm_hole_scratch_bytes(int n, int height, int width, int cap_pts, int cap_contours);
+int vlfm_fill_small_holes_batched(const uint32_t* d_hole_bits, const int32_t* d_status, int n, int height, int width,
+                                  double area_thresh, void* d_scratch, size_t scratch_bytes, int cap_pts,
+                                  int cap_contours, uint32_t* d_filled_bits, int32_t* d_counts, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * ValueMap.update_map for n observations (value_map.py:100-128 = :221-260 + :288-319 + :357-429).

@@ -112,6 +112,74 @@ def test_map_edge_index_error_and_hole_flag(gpu_device):
     o2.update_map(d2, tf2, MIN_DEPTH, MAX_DEPTH, FX, FY, FOV)
     r2.update_map(d2, tf2, MIN_DEPTH, MAX_DEPTH, FX, FY, FOV)
     _same(o2, r2)
-    o3, _ = _pair(gpu_device)
-    with pytest.raises(NotImplementedError):
-        o3.update_map(d2, tf2, MIN_DEPTH, MAX_DEPTH, FX, FY, FOV)
+
+
+def _hole_cases():
+    """Depth images with invalid (zero) texels: rectangles, speckle, a ring enclosing a valid island, a hole larger than
+    the area threshold, holes touching the image border, single pixels and diagonal (8-connected) chains."""
+    rng = np.random.default_rng(77)
+    base = SyntheticEnv(9).observe()[0]
+    cases = {}
+    d = base.copy(); d[100:140, 200:260] = 0; d[300:310, 50:55] = 0
+    cases["rects"] = d
+    d = base.copy(); d[rng.random(d.shape) < 0.02] = 0
+    cases["speckle"] = d
+    d = base.copy(); d[150:260, 250:400] = 0; d[180:230, 290:360] = base[180:230, 290:360]; d[200:210, 310:330] = 0
+    cases["ring_island_nested"] = d
+    d = base.copy(); d[40:400, 100:500] = 0  # 360 x 400 = 144000 px > 100000: stays a hole (z = min_depth points)
+    cases["big"] = d
+    d = base.copy(); d[0:30, 0:40] = 0; d[470:480, 600:640] = 0; d[0:5, 300:340] = 0; d[200:260, 636:640] = 0
+    cases["borders"] = d
+    d = base.copy()
+    for k in range(40):
+        d[250 + k, 100 + k] = 0           # diagonal chain: one 8-connected component
+    d[50, 50] = 0; d[52, 52] = 0; d[300, 639] = 0; d[479, 0] = 0
+    cases["diag_single"] = d
+    d = base.copy(); d[:] = 0
+    cases["all_zero"] = d
+    return cases
+
+
+@pytest.mark.parametrize("thresh", [100000, 600, 40])
+def test_fill_small_holes_parity(gpu_device, thresh):
+    """img_utils.py:361-390 on the device (depth_holes.hip): the filled-texel plane and the resulting obstacle map against
+    the oracle, for every case and an area threshold that fills all / some / almost no contours."""
+    from oracle.ref_geometry import fill_small_holes
+
+    tf = pose_to_tf(0.3, -0.2, 0.4)
+    for name, depth in _hole_cases().items():
+        ours, ref = _pair(gpu_device, hole_area_thresh=thresh)
+        ours.update_map(depth, tf, MIN_DEPTH, MAX_DEPTH, FX, FY, FOV)
+        ref.update_map(depth.copy(), tf, MIN_DEPTH, MAX_DEPTH, FX, FY, FOV)
+        # texels the reference rewrites to 1.0 (probe image: 0 in the holes, 0.5 elsewhere)
+        want = fill_small_holes(np.where(depth == 0, 0, 0.5).astype(np.float32), thresh) == 1
+        got_bits = ours._batch._filled_bits[0].cpu().numpy().view(np.uint32)
+        got = ((got_bits[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(depth.shape[0], -1)[:, :depth.shape[1]]
+        assert np.array_equal(got.astype(bool), want), f"{name}: filled plane differs in {(got.astype(bool) != want).sum()} texels"
+        _same(ours, ref)
+
+
+def test_fill_small_holes_batched_and_clean_frames(gpu_device):
+    """A frame without zeros after a frame with zeros must not inherit the old fill; batch slots are independent."""
+    from oracle.ref_obstacle_map import RefObstacleMap
+    from vlfm_amd.mapping import ObstacleMapBatch
+    import torch
+
+    cases = _hole_cases()
+    clean = SyntheticEnv(9).observe()[0]
+    frames = [np.stack([cases["rects"], clean, cases["ring_island_nested"]]),
+              np.stack([clean, cases["speckle"], clean])]
+    kw = dict(min_height=0.61, max_height=0.88, agent_radius=0.18, area_thresh=1.5)
+    batch = ObstacleMapBatch(3, device=gpu_device, **kw)
+    refs = [RefObstacleMap(**kw) for _ in range(3)]
+    tfs = np.stack([pose_to_tf(0.1 * e, 0.0, 0.2 * e) for e in range(3)])
+    for f in frames:
+        batch.ingest(torch.from_numpy(f).to(gpu_device), tfs, MIN_DEPTH, MAX_DEPTH, FX, FY)
+        batch.check_status()
+        batch.update_after_ingest(tfs, MAX_DEPTH, FOV)
+        for e in range(3):
+            refs[e].update_map(f[e].copy(), tfs[e], MIN_DEPTH, MAX_DEPTH, FX, FY, FOV)
+    obst = batch._unpack(batch.obstacle_bits).cpu().numpy().astype(bool)
+    for e in range(3):
+        assert np.array_equal(obst[e], refs[e]._map.astype(bool)), f"slot {e}"
+        assert np.array_equal(batch.explored[e].cpu().numpy().astype(bool), refs[e].explored_area.astype(bool))

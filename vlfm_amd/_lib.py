@@ -13,7 +13,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvlfm_amd.so")
-SOURCES = ["value_map.hip", "depth_ingest.hip", "obstacle_map.hip", "vlm_ops.hip", "host.cpp"]
+SOURCES = ["value_map.hip", "depth_ingest.hip", "depth_holes.hip", "obstacle_map.hip", "vlm_ops.hip", "host.cpp"]
 
 VLFM_OK = 0
 VLFM_ERR_INVALID = -1
@@ -86,7 +86,10 @@ def lib() -> ctypes.CDLL:
         L.vlfm_tan_table_host.argtypes = [cd, ci, vp]
         L.vlfm_disc_rows_host.argtypes = [ci, vp]
         L.vlfm_cone_template_build.argtypes = [vp, vp, ci, ci, vp, vp, vp]
-        L.vlfm_depth_ingest_batched.argtypes = [vp, ci, ci, ci, vp, vp, vp, ci, ci, vp, vp]
+        L.vlfm_depth_ingest_batched.argtypes = [vp, ci, ci, ci, vp, vp, vp, ci, ci, vp, vp, vp, vp]
+        L.vlfm_hole_scratch_bytes.argtypes = [ci, ci, ci, ci, ci]
+        L.vlfm_hole_scratch_bytes.restype = ctypes.c_size_t
+        L.vlfm_fill_small_holes_batched.argtypes = [vp, vp, ci, ci, ci, cd, vp, ctypes.c_size_t, ci, ci, vp, vp, vp]
         L.vlfm_value_map_scratch_bytes.argtypes = [ci, ci]
         L.vlfm_value_map_scratch_bytes.restype = ctypes.c_size_t
         L.vlfm_value_map_update_batched.argtypes = [vp, ci, vp, vp, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci, cd, cd, ci,

@@ -72,13 +72,16 @@ struct ContourSink {         // per-environment output of a scan
     int cap_pts, cap_contours;
     int n_pts, n_contours;   // running counts (uniform across the wave)
     int overflow;
+    unsigned char* hole = nullptr;  // [cap_contours] 1 = hole border (RETR_LIST scans only), optional
 };
 
 // Follow one outer border starting at (x0,y0) (the scan guarantees: pixel set, left neighbour clear, not yet traced).
 // Executed by ONE lane.  Labels: `traced` = pixel carries a border label, `neg` = the label is the negative one
 // (the pixel's east neighbour was examined and found empty).  method: 1 = every chain point, 2 = direction changes only.
+// is_hole: the border is a hole border (starts at the pixel WEST of the first hole pixel; the initial search direction
+// is east instead of west -- cvFindNextContour / icvFetchContour).
 __device__ inline int follow_border(const Bits& img, unsigned* traced, unsigned* neg, int x0, int y0, int method,
-                                    int2* out, int cap) {
+                                    int2* out, int cap, int is_hole = 0) {
     int n = 0;
     auto mark = [&](int x, int y, bool negative) {
         const size_t wi = (size_t)y * img.stride + (x >> 5);
@@ -91,7 +94,7 @@ __device__ inline int follow_border(const Bits& img, unsigned* traced, unsigned*
         n++;
     };
     unsigned nb = nbr8(img, x0, y0);
-    int s_end = 4, s = 4;
+    int s_end = is_hole ? 0 : 4, s = s_end;
     do {
         s = (s - 1) & 7;
     } while (!((nb >> s) & 1u) && s != s_end);
@@ -184,6 +187,61 @@ __device__ inline void scan_external(const Bits& img, unsigned* traced, unsigned
                 }
             }
             any = __ballot(starts != 0u);
+        }
+    }
+}
+
+// RETR_LIST / RETR_TREE scan (every outer AND hole border, discovery order) of a whole image by one wavefront; the
+// hierarchy is not produced (no caller on the path reads it: img_utils.py:377 discards it).  Border starts, per row and in
+// x order (cvFindNextContour): an unlabelled set pixel whose west neighbour is clear starts an OUTER border; a clear
+// pixel whose west neighbour is set and does not carry a negative label starts a HOLE border at that west neighbour.
+// `traced`/`neg` must be zero on entry.  stride <= 64 words.
+__device__ inline void scan_list(const Bits& img, unsigned* traced, unsigned* neg, int method, ContourSink& sink) {
+    const int lane = threadIdx.x & 63;
+    for (int y = 0; y < img.rows; y++) {
+        const unsigned* row = img.w + (size_t)y * img.stride;
+        const unsigned w = lane < img.stride ? row[lane] : 0u;
+        const unsigned left = __shfl_up(w, 1, 64);
+        const unsigned carry = lane > 0 ? (left >> 31) : 0u;
+        const unsigned west = (w << 1) | carry;       // bit x = pixel x-1
+        unsigned valid = 0u;                          // columns < cols in this word
+        if (lane * 32 < img.cols) valid = (img.cols - lane * 32 >= 32) ? 0xFFFFFFFFu : ((1u << (img.cols - lane * 32)) - 1u);
+        unsigned cand = ((w & ~west) | (~w & west)) & valid;
+        unsigned long long any = __ballot(cand != 0u);
+        while (any) {
+            const int L = __builtin_ctzll(any);
+            const unsigned cL = __shfl(cand, L, 64);
+            const unsigned wL = __shfl(w, L, 64);
+            const int bit = __builtin_ctz(cL);
+            const int x = L * 32 + bit;
+            if (lane == L) cand &= cand - 1;          // consume the candidate
+            const int is_hole = !((wL >> bit) & 1u);
+            const int xo = x - is_hole;               // origin pixel of the border
+            const size_t wi = (size_t)y * img.stride + (xo >> 5);
+            const unsigned tb = (traced[wi] >> (xo & 31)) & 1u, nb = (neg[wi] >> (xo & 31)) & 1u;
+            const bool start = is_hole ? !(tb && nb) : !tb;
+            if (start) {
+                int n = 0;
+                if (lane == 0) {
+                    const int room = sink.cap_pts - sink.n_pts;
+                    n = follow_border(img, traced, neg, xo, y, method, sink.pts + sink.n_pts, room > 0 ? room : 0, is_hole);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                n = __shfl(n, 0, 64);
+                if (sink.n_contours < sink.cap_contours && sink.n_pts + n <= sink.cap_pts) {
+                    if (lane == 0) {
+                        sink.start[sink.n_contours] = sink.n_pts;
+                        sink.len[sink.n_contours] = n;
+                        if (sink.hole) sink.hole[sink.n_contours] = (unsigned char)is_hole;
+                    }
+                } else {
+                    sink.overflow = 1;
+                }
+                sink.n_contours++;
+                sink.n_pts += n;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+            any = __ballot(cand != 0u);
         }
     }
 }

@@ -35,6 +35,9 @@ struct IngestArgs {
     unsigned* colmax_keys;          // [n][W] (zero-initialised keys) or null
     unsigned* obstacle;             // [n_envs][S][stride] bit-packed, or null
     int* status;                    // [n][2]: (index error, saw zero depth)
+    unsigned* hole_bits;            // [n][H][hw] OUT: bit plane of (depth == 0), or null
+    const unsigned* filled_bits;    // [n][H][hw] IN: fill_small_holes' result (texel -> 1.0), or null
+    int hw;                         // words per image row in hole/filled planes = ceil(W/32)
     int H, W, W4, S, stride;
     int cols_per_block;             // float4 column groups handled by one workgroup in x
     int ry;                         // rows advanced per iteration (= blockDim.x / cols_per_block)
@@ -60,13 +63,14 @@ __device__ inline HeightBand make_band(const vlfm_ingest_params& p, int W, int H
 }
 
 __device__ inline void scatter_point(const IngestArgs& a, const vlfm_ingest_params& p, const HeightBand& band,
-                                     unsigned* grid, int obs, int u, int v, float d) {
+                                     unsigned* grid, int obs, int u, int v, float d, bool filled) {
+    // fill_small_holes (img_utils.py:361-390) turned this texel into 1.0 -> z == max_depth -> masked out (:93)
+    if (filled) return;
     if (d == 0.0f) {
         // a hole in the depth image.  scatter bit 1 set: hole_area_thresh == -1 semantics (obstacle_map.py:87-89), every
-        // zero becomes 1.0 and therefore falls outside max_depth.  Otherwise the caller must have filled small holes
-        // already; we only report that zeros were present (status word 1) and use the texel as it is.
+        // zero becomes 1.0 and therefore falls outside max_depth.  Otherwise an unfilled (large) hole is used as it is:
+        // depth 0 -> z = min_depth, exactly like the reference.
         if (p.scatter & 2) return;
-        a.status[2 * obs + 1] = 1;
     }
     const float z = __fadd_rn(__fmul_rn(d, p.depth_scale), p.depth_offset);  // obstacle_map.py:92 (f32)
     if (!(z < p.depth_max)) return;                                          // :93
@@ -132,32 +136,50 @@ __global__ __launch_bounds__(CG * RL) void depth_ingest_kernel(IngestArgs a) {
     const float* img = a.depth + (size_t)obs * a.H * a.W;
     unsigned* grid = nullptr;
     if (SCATTER) grid = a.obstacle + (size_t)p.env * a.S * a.stride;
+    unsigned* holes = a.hole_bits ? a.hole_bits + (size_t)obs * a.H * a.hw : nullptr;
+    const unsigned* filled = a.filled_bits ? a.filled_bits + (size_t)obs * a.H * a.hw : nullptr;
     const float ninf = -__builtin_huge_valf();
     float4 m = make_float4(ninf, ninf, ninf, ninf);
-    if (live) {
-        constexpr int UNROLL = 4;
-        for (int r0 = r_begin + ry; r0 < r_end; r0 += UNROLL * RL) {
-            float4 d[UNROLL];
+    bool saw_zero = false;
+    constexpr int UNROLL = 4;
+    // every lane of the workgroup runs the same trip count (predicated), so the cross-lane packing of hole bits below is
+    // always executed convergently
+    for (int base = r_begin; base < r_end; base += UNROLL * RL) {
+        float4 d[UNROLL];
 #pragma unroll
-            for (int k = 0; k < UNROLL; k++) {
-                const int r = r0 + k * RL;
-                d[k] = r < r_end ? reinterpret_cast<const float4*>(img + (size_t)r * a.W)[col4]
-                                 : make_float4(ninf, ninf, ninf, ninf);
+        for (int k = 0; k < UNROLL; k++) {
+            const int r = base + ry + k * RL;
+            d[k] = (live && r < r_end) ? reinterpret_cast<const float4*>(img + (size_t)r * a.W)[col4]
+                                       : make_float4(ninf, ninf, ninf, ninf);
+        }
+#pragma unroll
+        for (int k = 0; k < UNROLL; k++) {
+            const int r = base + ry + k * RL;
+            const bool ok = live && r < r_end;
+            m.x = fmaxf(m.x, d[k].x); m.y = fmaxf(m.y, d[k].y); m.z = fmaxf(m.z, d[k].z); m.w = fmaxf(m.w, d[k].w);
+            if (holes) {
+                // 4 texels -> a nibble; 8 neighbouring lanes (same row) -> one 32-bit word of the (depth == 0) plane
+                unsigned nib = 0u;
+                if (ok) nib = (d[k].x == 0.0f) | ((d[k].y == 0.0f) << 1) | ((d[k].z == 0.0f) << 2) | ((d[k].w == 0.0f) << 3);
+                saw_zero |= nib != 0u;
+                unsigned word = nib << ((cx & 7) * 4);
+                word |= __shfl_xor(word, 1, 64);
+                word |= __shfl_xor(word, 2, 64);
+                word |= __shfl_xor(word, 4, 64);
+                if (ok && (cx & 7) == 0) holes[(size_t)r * a.hw + (col4 >> 3)] = word;
             }
-#pragma unroll
-            for (int k = 0; k < UNROLL; k++) {
-                const int r = r0 + k * RL;
-                m.x = fmaxf(m.x, d[k].x); m.y = fmaxf(m.y, d[k].y); m.z = fmaxf(m.z, d[k].z); m.w = fmaxf(m.w, d[k].w);
-                if (SCATTER && (p.scatter & 1) && r < r_end) {
-                    const int u = col4 * 4;
-                    scatter_point(a, p, band, grid, obs, u + 0, r, d[k].x);
-                    scatter_point(a, p, band, grid, obs, u + 1, r, d[k].y);
-                    scatter_point(a, p, band, grid, obs, u + 2, r, d[k].z);
-                    scatter_point(a, p, band, grid, obs, u + 3, r, d[k].w);
-                }
+            if (SCATTER && (p.scatter & 1) && ok) {
+                unsigned fnib = 0u;
+                if (filled) fnib = (filled[(size_t)r * a.hw + (col4 >> 3)] >> ((col4 & 7) * 4)) & 0xFu;
+                const int u = col4 * 4;
+                scatter_point(a, p, band, grid, obs, u + 0, r, d[k].x, fnib & 1u);
+                scatter_point(a, p, band, grid, obs, u + 1, r, d[k].y, fnib & 2u);
+                scatter_point(a, p, band, grid, obs, u + 2, r, d[k].z, fnib & 4u);
+                scatter_point(a, p, band, grid, obs, u + 3, r, d[k].w, fnib & 8u);
             }
         }
     }
+    if (saw_zero) a.status[2 * obs + 1] = 1;
     if (a.colmax_keys == nullptr) return;
     part[ry][cx] = m;
     __syncthreads();
@@ -181,16 +203,18 @@ using namespace vlfm;
 
 extern "C" int vlfm_depth_ingest_batched(const float* d_depth, int n, int height, int width,
                                          const vlfm_ingest_params* d_params, uint32_t* d_colmax_keys, uint32_t* d_obstacle,
-                                         int map_size, int pixels_per_meter, int32_t* d_status, void* stream) {
+                                         int map_size, int pixels_per_meter, int32_t* d_status, uint32_t* d_hole_bits,
+                                         const uint32_t* d_filled_bits, void* stream) {
     if (n == 0) return VLFM_OK;
     if (!d_depth || !d_params || !d_status || n < 0 || height <= 0 || width <= 0)
         return fail(VLFM_ERR_INVALID, "depth_ingest_batched: bad argument");
     if (width % 4 != 0) return fail(VLFM_ERR_INVALID, "depth_ingest_batched: width must be a multiple of 4");
-    if (!d_colmax_keys && !d_obstacle) return VLFM_OK;
+    if (!d_colmax_keys && !d_obstacle && !d_hole_bits) return VLFM_OK;
     hipStream_t s = (hipStream_t)stream;
     IngestArgs a;
     a.depth = d_depth; a.prm = d_params; a.colmax_keys = reinterpret_cast<unsigned*>(d_colmax_keys);
     a.obstacle = d_obstacle; a.status = d_status;
+    a.hole_bits = d_hole_bits; a.filled_bits = d_filled_bits; a.hw = (width + 31) / 32;
     a.H = height; a.W = width; a.W4 = width / 4; a.S = map_size; a.stride = (map_size + 31) / 32;
     a.ppm = (double)pixels_per_meter;
     a.cols_per_block = CG; a.ry = RL;

@@ -30,6 +30,8 @@ class ObstacleMapBatch:
     CAP_CONTOURS = 2048
     CAP_FRONTIERS = 256
     READ_FRONTIERS = 32   # frontiers per environment fetched by the fast read-back path (more -> one full copy)
+    HOLE_CAP_PTS = 1 << 17      # border points per depth image in fill_small_holes
+    HOLE_CAP_CONTOURS = 1 << 15
 
     def __init__(self, n_envs: int, min_height: float, max_height: float, agent_radius: float, area_thresh: float = 3.0,
                  hole_area_thresh: int = 100000, size: int = 1000, pixels_per_meter: int = 20, device=None) -> None:
@@ -114,14 +116,52 @@ class ObstacleMapBatch:
             if self.colmax_keys is None or self.colmax_keys.shape != (max(n, self.n_envs), W):
                 self.colmax_keys = torch.zeros((max(n, self.n_envs), W), dtype=torch.int32, device=self.device)
             keys = self.colmax_keys
+        L = _lib.lib()
+        fill = update_obstacles and self._hole_area_thresh != -1
         with torch.cuda.device(self.device):
             d_prm = self._ring_ingest.upload(prm)
-            _lib.check(_lib.lib().vlfm_depth_ingest_batched(depth.data_ptr(), n, H, W, d_prm.data_ptr(),
-                                                           keys.data_ptr() if keys is not None else None,
-                                                           self.obstacle_bits.data_ptr() if update_obstacles else None,
-                                                           self.size, self.pixels_per_meter, self.status.data_ptr(),
-                                                           _stream_ptr()), "depth_ingest")
+            if not fill:
+                # hole_area_thresh == -1 (every zero texel -> 1.0, obstacle_map.py:87-89) or no obstacle update:
+                # one pass over the depth images
+                _lib.check(L.vlfm_depth_ingest_batched(depth.data_ptr(), n, H, W, d_prm.data_ptr(),
+                                                       keys.data_ptr() if keys is not None else None,
+                                                       self.obstacle_bits.data_ptr() if update_obstacles else None,
+                                                       self.size, self.pixels_per_meter, self.status.data_ptr(),
+                                                       None, None, _stream_ptr()), "depth_ingest")
+            else:
+                # fill_small_holes (img_utils.py:361-390) sits between reading the depth and scattering it: pass 1
+                # streams the images once (column maxima + the (depth == 0) bit plane + "has zeros" flag), the hole
+                # kernel exits immediately for images without zeros, pass 2 scatters with the filled texels masked
+                # (the images are still in the 256 MB Infinity Cache)
+                holes, filled, scratch, counts = self._hole_buffers(n, H, W)
+                _lib.check(L.vlfm_depth_ingest_batched(depth.data_ptr(), n, H, W, d_prm.data_ptr(),
+                                                       keys.data_ptr() if keys is not None else None, None,
+                                                       self.size, self.pixels_per_meter, self.status.data_ptr(),
+                                                       holes.data_ptr(), None, _stream_ptr()), "depth_ingest(1)")
+                _lib.check(L.vlfm_fill_small_holes_batched(holes.data_ptr(), self.status.data_ptr(), n, H, W,
+                                                           float(self._hole_area_thresh), scratch.data_ptr(),
+                                                           scratch.numel(), self.HOLE_CAP_PTS, self.HOLE_CAP_CONTOURS,
+                                                           filled.data_ptr(), counts.data_ptr(), _stream_ptr()),
+                           "fill_small_holes")
+                _lib.check(L.vlfm_depth_ingest_batched(depth.data_ptr(), n, H, W, d_prm.data_ptr(), None,
+                                                       self.obstacle_bits.data_ptr(), self.size,
+                                                       self.pixels_per_meter, self.status.data_ptr(), None,
+                                                       filled.data_ptr(), _stream_ptr()), "depth_ingest(2)")
         return keys
+
+    def _hole_buffers(self, n: int, H: int, W: int):
+        import torch
+
+        key = (max(n, self.n_envs), H, W)
+        if getattr(self, "_hole_key", None) != key:
+            m, hw = key[0], (W + 31) // 32
+            self._hole_bits = torch.zeros((m, H, hw), dtype=torch.int32, device=self.device)
+            self._filled_bits = torch.zeros((m, H, hw), dtype=torch.int32, device=self.device)
+            nbytes = _lib.lib().vlfm_hole_scratch_bytes(m, H, W, self.HOLE_CAP_PTS, self.HOLE_CAP_CONTOURS)
+            self._hole_scratch = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+            self._hole_counts = torch.zeros((m, 4), dtype=torch.int32, device=self.device)
+            self._hole_key = key
+        return self._hole_bits, self._filled_bits, self._hole_scratch, self._hole_counts
 
     # ------------------------------------------------------------------------------------------ step, part 2
     def fog_params(self, tf, max_depth: float, topdown_fov: float, env_ids=None, explore=None):
@@ -211,10 +251,10 @@ class ObstacleMapBatch:
         self.status.zero_()
         if (st[:, 0] != 0).any():
             raise IndexError("index out of bounds: obstacle point fell off the map (obstacle_map.py:101)")
-        if (st[:, 1] != 0).any() and self._hole_area_thresh != -1:
-            raise NotImplementedError(
-                "depth image contains zero (invalid) texels: fill_small_holes (img_utils.py:361-390) is not implemented "
-                "on the device yet; pass hole_area_thresh=-1 or feed filter_depth-ed (hole-free) depth")
+        if getattr(self, "_hole_key", None) is not None:
+            hc = self._hole_counts.cpu().numpy()
+            if (hc[:, 2] != 0).any():
+                raise RuntimeError("fill_small_holes scratch capacity exceeded (HOLE_CAP_PTS/HOLE_CAP_CONTOURS)")
 
 
 class ObstacleMap(BaseMap):
