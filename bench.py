@@ -217,7 +217,8 @@ def main():
 
     torch.cuda.synchronize(device)
     kms = {}
-    for kname in ("depth_ingest_kernel", "visible_mask_kernel", "value_map_fuse_kernel", "sort_waypoints_kernel",
+    for kname in ("depth_ingest_kernel", "depth_scatter_kernel", "depth_ingest_scatter_kernel", "fill_small_holes_kernel",
+                  "visible_mask_kernel", "value_map_fuse_kernel", "sort_waypoints_kernel",
                   "mask_unexplored_kernel", "resample_h_kernel", "resample_v_norm_kernel", "itc_head_kernel",
                   "navigable_kernel", "fog_of_war_kernel", "explored_select_kernel", "frontier_kernel"):
         ms, n = _lib.profile_read(kname)
@@ -241,6 +242,8 @@ def main():
                                     "achieved": round(gbs, 1), "frac": round(gbs / 8000.0, 4)}
 
         entry("depth_ingest_kernel", E * 4 * H * W)
+        entry("depth_scatter_kernel", E * 4 * H * W)
+        entry("depth_ingest_scatter_kernel", E * 4 * H * W)
         entry("value_map_fuse_kernel", E * (4 * T * T + 8 * T * T + 8 * T * T))
         entry("mask_unexplored_kernel", E * (S * S + 8 * S * S + 8 * S * S))
         # the kernel BASELINE.json's north_star names for the roofline target is the map-fusion kernel

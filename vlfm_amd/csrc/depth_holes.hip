@@ -186,6 +186,6 @@ extern "C" int vlfm_fill_small_holes_batched(const uint32_t* d_hole_bits, const 
     a.H = height; a.W = width; a.hw = (width + 31) / 32; a.cap_pts = cap_pts; a.cap_contours = cap_contours;
     a.area_thresh = area_thresh;
     VLFM_TIMED("fill_small_holes_kernel", stream);
-    hipLaunchKernelGGL(fill_small_holes_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, a);
+    VLFM_KLAUNCH(fill_small_holes_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("fill_small_holes_kernel");
 }

@@ -29,6 +29,14 @@ __device__ inline float key_f32(unsigned k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
 
+// bit j of an 8-bit value -> bit 4j of the result
+__device__ inline unsigned spread8(unsigned x) {
+    x = (x | (x << 12)) & 0x000F000Fu;
+    x = (x | (x << 6)) & 0x03030303u;
+    x = (x | (x << 3)) & 0x11111111u;
+    return x;
+}
+
 struct IngestArgs {
     const float* depth;             // [n][H][W]
     const vlfm_ingest_params* prm;  // [n]
@@ -158,15 +166,20 @@ __global__ __launch_bounds__(CG * RL) void depth_ingest_kernel(IngestArgs a) {
             const bool ok = live && r < r_end;
             m.x = fmaxf(m.x, d[k].x); m.y = fmaxf(m.y, d[k].y); m.z = fmaxf(m.z, d[k].z); m.w = fmaxf(m.w, d[k].w);
             if (holes) {
-                // 4 texels -> a nibble; 8 neighbouring lanes (same row) -> one 32-bit word of the (depth == 0) plane
-                unsigned nib = 0u;
-                if (ok) nib = (d[k].x == 0.0f) | ((d[k].y == 0.0f) << 1) | ((d[k].z == 0.0f) << 2) | ((d[k].w == 0.0f) << 3);
-                saw_zero |= nib != 0u;
-                unsigned word = nib << ((cx & 7) * 4);
-                word |= __shfl_xor(word, 1, 64);
-                word |= __shfl_xor(word, 2, 64);
-                word |= __shfl_xor(word, 4, 64);
-                if (ok && (cx & 7) == 0) holes[(size_t)r * a.hw + (col4 >> 3)] = word;
+                // (depth == 0) bit plane: 4 texels per lane, 8 neighbouring lanes (same row) per 32-bit word.  Four
+                // wave ballots (scalar unit) + a bit spread in the group's leader lane; no cross-lane data movement.
+                const unsigned long long b0 = __ballot(ok && d[k].x == 0.0f), b1 = __ballot(ok && d[k].y == 0.0f);
+                const unsigned long long b2 = __ballot(ok && d[k].z == 0.0f), b3 = __ballot(ok && d[k].w == 0.0f);
+                saw_zero |= (b0 | b1 | b2 | b3) != 0ull;
+                if (ok && (cx & 7) == 0) {
+                    unsigned word = 0u;
+                    if (b0 | b1 | b2 | b3) {
+                        const int sh = (threadIdx.x & 63) & ~7;
+                        word = spread8((unsigned)(b0 >> sh) & 0xFFu) | (spread8((unsigned)(b1 >> sh) & 0xFFu) << 1) |
+                               (spread8((unsigned)(b2 >> sh) & 0xFFu) << 2) | (spread8((unsigned)(b3 >> sh) & 0xFFu) << 3);
+                    }
+                    holes[(size_t)r * a.hw + (col4 >> 3)] = word;
+                }
             }
             if (SCATTER && (p.scatter & 1) && ok) {
                 unsigned fnib = 0u;
@@ -227,12 +240,14 @@ extern "C" int vlfm_depth_ingest_batched(const float* d_depth, int n, int height
     if (bands < 1) bands = 1;
     a.rows_per_block = (height + bands - 1) / bands;
     const int gy = (height + a.rows_per_block - 1) / a.rows_per_block;
-    {
+    if (d_obstacle) {
+        // profile name: the streaming pass (column maxima [+ hole bits]) is "depth_ingest_kernel"; a pass that ALSO or
+        // ONLY scatters obstacle points is reported separately
+        VLFM_TIMED(d_colmax_keys ? "depth_ingest_scatter_kernel" : "depth_scatter_kernel", s);
+        VLFM_KLAUNCH(depth_ingest_kernel<true>, dim3(gx, gy, n), dim3(CG * RL), 0, s, a);
+    } else {
         VLFM_TIMED("depth_ingest_kernel", s);
-        if (d_obstacle)
-            hipLaunchKernelGGL(depth_ingest_kernel<true>, dim3(gx, gy, n), dim3(CG * RL), 0, s, a);
-        else
-            hipLaunchKernelGGL(depth_ingest_kernel<false>, dim3(gx, gy, n), dim3(CG * RL), 0, s, a);
+        VLFM_KLAUNCH(depth_ingest_kernel<false>, dim3(gx, gy, n), dim3(CG * RL), 0, s, a);
     }
     return check_launch("depth_ingest_kernel");
 }

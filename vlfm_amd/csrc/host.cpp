@@ -230,15 +230,20 @@ std::map<std::string, KernelLog> g_prof;
 const size_t kMaxSpans = 8192;
 }  // namespace
 
+static thread_local ProfileScope* g_scope = nullptr;
+ProfileScope* current_profile_scope() { return g_scope; }
+
 ProfileScope::ProfileScope(const char* name, hipStream_t stream) : name_(name), stream_(stream) {
+    prev_ = g_scope;
+    g_scope = this;
     if (!g_prof_on) return;
     if (hipEventCreate(&start_) != hipSuccess || hipEventCreate(&stop_) != hipSuccess) return;
     active_ = true;
-    (void)hipEventRecord(start_, stream_);
 }
 ProfileScope::~ProfileScope() {
+    g_scope = prev_;
     if (!active_) return;
-    (void)hipEventRecord(stop_, stream_);
+    if (!used_) { (void)hipEventDestroy(start_); (void)hipEventDestroy(stop_); return; }
     std::lock_guard<std::mutex> lk(g_prof_mu);
     KernelLog& log = g_prof[name_];
     if (log.spans.size() < kMaxSpans) log.spans.emplace_back(start_, stop_);

@@ -936,7 +936,7 @@ using namespace vlfm;
 extern "C" int vlfm_bits_pack(const uint8_t* d_src, uint32_t* d_dst, int planes, int rows, int cols, void* stream) {
     if (!d_src || !d_dst || planes <= 0 || rows <= 0 || cols <= 0) return fail(VLFM_ERR_INVALID, "bits_pack: bad argument");
     const int stride = (cols + 31) / 32;
-    hipLaunchKernelGGL(pack_u8_kernel, dim3((stride + 63) / 64, rows, planes), dim3(64), 0, (hipStream_t)stream, d_src,
+    VLFM_KLAUNCH(pack_u8_kernel, dim3((stride + 63) / 64, rows, planes), dim3(64), 0, (hipStream_t)stream, d_src,
                        d_dst, rows, cols, stride);
     return check_launch("pack_u8_kernel");
 }
@@ -944,7 +944,7 @@ extern "C" int vlfm_bits_pack(const uint8_t* d_src, uint32_t* d_dst, int planes,
 extern "C" int vlfm_bits_unpack(const uint32_t* d_src, uint8_t* d_dst, int planes, int rows, int cols, void* stream) {
     if (!d_src || !d_dst || planes <= 0 || rows <= 0 || cols <= 0) return fail(VLFM_ERR_INVALID, "bits_unpack: bad argument");
     const int stride = (cols + 31) / 32;
-    hipLaunchKernelGGL(unpack_u8_kernel, dim3((cols + 255) / 256, rows, planes), dim3(256), 0, (hipStream_t)stream,
+    VLFM_KLAUNCH(unpack_u8_kernel, dim3((cols + 255) / 256, rows, planes), dim3(256), 0, (hipStream_t)stream,
                        d_src, d_dst, rows, cols, stride);
     return check_launch("unpack_u8_kernel");
 }
@@ -956,7 +956,7 @@ extern "C" int vlfm_bits_dilate(const uint32_t* d_src, uint32_t* d_dst, int plan
         return fail(VLFM_ERR_INVALID, "bits_dilate: bad argument (odd kernel sizes, width <= 63)");
     const int stride = (cols + 31) / 32;
     VLFM_TIMED("dilate_bits_kernel", stream);
-    hipLaunchKernelGGL(dilate_bits_kernel, dim3((rows * stride + 255) / 256, 1, planes), dim3(256), 0,
+    VLFM_KLAUNCH(dilate_bits_kernel, dim3((rows * stride + 255) / 256, 1, planes), dim3(256), 0,
                        (hipStream_t)stream, d_src, d_dst, (unsigned*)nullptr, (const int*)nullptr, rows, cols, stride,
                        kernel_w / 2, kernel_h / 2, 0);
     return check_launch("dilate_bits_kernel");
@@ -973,7 +973,7 @@ extern "C" int vlfm_find_contours_external(const uint32_t* d_img, int planes, in
     unsigned* traced = d_scratch;
     unsigned* neg = d_scratch + (size_t)planes * rows * stride;
     VLFM_TIMED("find_contours_kernel", stream);
-    hipLaunchKernelGGL(find_contours_kernel, dim3(planes), dim3(64), 0, (hipStream_t)stream, d_img, traced, neg, rows,
+    VLFM_KLAUNCH(find_contours_kernel, dim3(planes), dim3(64), 0, (hipStream_t)stream, d_img, traced, neg, rows,
                        cols, stride, method, reinterpret_cast<int2*>(d_pts), cap_pts, d_starts, d_lens, cap_contours,
                        d_counts);
     return check_launch("find_contours_kernel");
@@ -1035,7 +1035,7 @@ extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, in
     int* status = (int*)(base + L.off_status);
     if (update_obstacles || explore) {
         VLFM_TIMED("navigable_kernel", s);
-        hipLaunchKernelGGL(navigable_kernel, dim3((map_size * stride + 255) / 256, 1, n), dim3(256), 0, s, d_prm, mp,
+        VLFM_KLAUNCH(navigable_kernel, dim3((map_size * stride + 255) / 256, 1, n), dim3(256), 0, s, d_prm, mp,
                            kernel_size / 2, update_obstacles, explore);
     }
     int rc = check_launch("navigable_kernel");
@@ -1046,7 +1046,7 @@ extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, in
         const size_t lds = (size_t)8 * wn * words * 4 + 64;
         if (lds > 160 * 1024) return fail(VLFM_ERR_CAPACITY, "obstacle_map_update_batched: fog window too large for LDS");
         VLFM_TIMED("fog_of_war_kernel", s);
-        hipLaunchKernelGGL(fog_of_war_kernel, dim3(n), dim3(256), lds, s, d_prm, mp, fs);
+        VLFM_KLAUNCH(fog_of_war_kernel, dim3(n), dim3(256), lds, s, d_prm, mp, fs);
     }
     rc = check_launch("fog_of_war_kernel");
     if (rc != VLFM_OK) return rc;
@@ -1054,7 +1054,7 @@ extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, in
         SelectScratch ss{planes[0], planes[1], planes[2], planes[3], pts, starts, lens, status + (size_t)n_envs * 4,
                          cap_pts, cap_contours};
         VLFM_TIMED("explored_select_kernel", s);
-        hipLaunchKernelGGL(explored_select_kernel, dim3(n), dim3(256), 0, s, d_prm, mp, ss, (const int*)d_bbox);
+        VLFM_KLAUNCH(explored_select_kernel, dim3(n), dim3(256), 0, s, d_prm, mp, ss, (const int*)d_bbox);
     }
     rc = check_launch("explored_select_kernel");
     if (rc != VLFM_OK) return rc;
@@ -1063,7 +1063,7 @@ extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, in
                            (unsigned char*)(base + L.off_bad), (int*)(base + L.off_pieces), d_frontiers, d_counts,
                            cap_pts, cap_contours, cap_frontiers, area_thresh_px};
         VLFM_TIMED("frontier_kernel", s);
-        hipLaunchKernelGGL(frontier_kernel, dim3(n), dim3(256), 0, s, d_prm, mp, fr, (const int*)d_bbox);
+        VLFM_KLAUNCH(frontier_kernel, dim3(n), dim3(256), 0, s, d_prm, mp, fr, (const int*)d_bbox);
     }
     return check_launch("frontier_kernel");
 }

@@ -74,7 +74,8 @@ struct UpdateArgs {
     const float* tmpl;        // [T][T]
     const unsigned* tmpl_bits;// [T][words]  template > 0
     const vlfm_vm_pose* pose; // [n]
-    unsigned* visible;        // [n][vis_stride] scratch: per observation (template > 0) & ~(beyond the depth profile)
+    unsigned* visible;        // [n][vis_stride] scratch per observation: 4-word header (dst bounding box) + the bit plane
+                              // (template > 0) & ~(beyond the depth profile)
     const double* values;     // [n][C]
     float* conf;              // [n_envs][S][S]
     float* value;             // [n_envs][S][S][C]
@@ -86,6 +87,9 @@ struct UpdateArgs {
     double ppm_d, half_t_d;
     int use_max_conf, fusion;
 };
+
+constexpr int ROWS_PER_TILE = 8;
+constexpr int VIS_META_WORDS = 4;  // per-observation header in the visibility scratch: dst row_lo,row_hi,col_lo,col_hi
 
 // One workgroup per observation: column-max keys -> depth-profile polygon (value_map.py:234-257) -> LDS coverage of the
 // "beyond the profile" region (cv2.drawContours fill, value_map.py:260) -> visible = (template > 0) & ~coverage, 5.6 KB
@@ -126,8 +130,47 @@ __global__ __launch_bounds__(512) void visible_mask_kernel(UpdateArgs a) {
     __syncthreads();
     resolve_rows(bm, tid, nth);
     __syncthreads();
-    unsigned* out = a.visible + (size_t)obs * a.vis_stride;
-    for (int i = tid; i < T * words; i += nth) out[i] = a.tmpl_bits[i] & ~solid[i];
+    // visible plane + its bounding box in SOURCE (template) coordinates
+    __shared__ int box[4];  // row_lo, row_hi, col_lo, col_hi
+    if (tid == 0) { box[0] = T; box[1] = -1; box[2] = T; box[3] = -1; }
+    __syncthreads();
+    unsigned* blk = a.visible + (size_t)obs * a.vis_stride;
+    unsigned* out = blk + VIS_META_WORDS;
+    int r_lo = T, r_hi = -1, c_lo = T, c_hi = -1;
+    for (int i = tid; i < T * words; i += nth) {
+        const unsigned v = a.tmpl_bits[i] & ~solid[i];
+        out[i] = v;
+        if (v) {
+            const int y = i / words, w = i - y * words;
+            r_lo = min(r_lo, y); r_hi = max(r_hi, y);
+            c_lo = min(c_lo, w * 32 + __builtin_ctz(v)); c_hi = max(c_hi, w * 32 + 31 - __builtin_clz(v));
+        }
+    }
+    if (r_hi >= 0) { atomicMin(&box[0], r_lo); atomicMax(&box[1], r_hi); atomicMin(&box[2], c_lo); atomicMax(&box[3], c_hi); }
+    __syncthreads();
+    if (tid == 0) {
+        // Destination (rotated) bounding box of everything that can receive a non-zero tap: forward-map the corners of
+        // the source box grown by one pixel (bilinear footprint), then grow by two more for the 1/32-pixel rounding of
+        // the source coordinates.  The fuse kernel only uses it to skip work whose taps are all zero.
+        int* meta = reinterpret_cast<int*>(blk);
+        if (box[1] < 0) {
+            meta[0] = 1; meta[1] = 0; meta[2] = 1; meta[3] = 0;  // empty
+        } else {
+            const vlfm_vm_pose pose = a.pose[obs];
+            const double a0 = pose.inv_affine[0], a1 = pose.inv_affine[1], a2 = pose.inv_affine[2];
+            const double a3 = pose.inv_affine[3], a4 = pose.inv_affine[4], a5 = pose.inv_affine[5];
+            const double det = a0 * a4 - a1 * a3;
+            double xlo = 1e30, xhi = -1e30, ylo = 1e30, yhi = -1e30;
+            for (int k = 0; k < 4; k++) {
+                const double sx = (k & 1) ? box[3] + 1.0 : box[2] - 1.0, sy = (k & 2) ? box[1] + 1.0 : box[0] - 1.0;
+                const double dx = (a4 * (sx - a2) - a1 * (sy - a5)) / det, dy = (-a3 * (sx - a2) + a0 * (sy - a5)) / det;
+                xlo = fmin(xlo, dx); xhi = fmax(xhi, dx); ylo = fmin(ylo, dy); yhi = fmax(yhi, dy);
+            }
+            if (!(fabs(det) > 1e-9) || !(xlo == xlo) || !(ylo == ylo)) { xlo = ylo = 0; xhi = yhi = T; }  // degenerate: no skipping
+            meta[0] = max(0, (int)floor(ylo) - 2); meta[1] = min(T - 1, (int)ceil(yhi) + 2);
+            meta[2] = max(0, (int)floor(xlo) - 2); meta[3] = min(T - 1, (int)ceil(xhi) + 2);
+        }
+    }
 }
 
 // grid = (row tiles, observations), 4 wavefronts per workgroup.  The workgroup stages its observation's visible bitmap
@@ -136,7 +179,6 @@ __global__ __launch_bounds__(512) void visible_mask_kernel(UpdateArgs a) {
 // tests in LDS, template taps from L2 only where a bit is set, placement at the camera cell with clipping
 // (place_img_in_img, img_utils.py:31-61) and the fusion read-modify-write (value_map.py:357-429).  Cells whose new
 // confidence is 0 are never touched: the reference's full-map arithmetic leaves them bit-identical (w1 == 1, w2 == 0).
-constexpr int ROWS_PER_TILE = 8;
 
 __device__ inline bool vis_test(const unsigned* vis, int words, int T, int y, int x) {
     if ((unsigned)x >= (unsigned)T || (unsigned)y >= (unsigned)T) return false;
@@ -180,14 +222,32 @@ __global__ __launch_bounds__(256) void value_map_fuse_kernel(UpdateArgs a) {
     const int words = (T + 31) >> 5;
     const int obs = blockIdx.y;
     const int row_begin = blockIdx.x * ROWS_PER_TILE;
-    const vlfm_vm_pose pose = a.pose[obs];
-    // whole tile clipped away by place_img_in_img?
-    if (pose.row0 + min(row_begin + ROWS_PER_TILE, T) <= 0 || pose.row0 + row_begin >= S) return;
     const int tid = threadIdx.x;
+    // Independent loads first, branches afterwards: pose, the cone's dst bounding box and this thread's share of the
+    // visibility plane are all in flight together (one memory round trip instead of three).
+    const unsigned* blk = a.visible + (size_t)obs * a.vis_stride;
+    const uint4* vsrc = reinterpret_cast<const uint4*>(blk + VIS_META_WORDS);
+    const int n_vec = (a.vis_stride - VIS_META_WORDS) / 4;
+    constexpr int VEC_PER_THREAD = 2;  // 2 x 256 x 16 B = 8 KB >= 5.6 KB (T = 201); larger templates loop below
+    uint4 vreg[VEC_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < VEC_PER_THREAD; k++) {
+        const int i = tid + k * 256;
+        vreg[k] = vsrc[i < n_vec ? i : 0];
+    }
+    const vlfm_vm_pose pose = a.pose[obs];
+    const int4 box = *reinterpret_cast<const int4*>(blk);  // dst bounding box of the visible cone (visible_mask_kernel)
+    // whole tile clipped away by place_img_in_img, or outside the cone: no non-zero tap
+    if (pose.row0 + min(row_begin + ROWS_PER_TILE, T) <= 0 || pose.row0 + row_begin >= S) return;
+    if (row_begin > box.y || row_begin + ROWS_PER_TILE <= box.x || box.z > box.w) return;
     {
-        const uint4* src = reinterpret_cast<const uint4*>(a.visible + (size_t)obs * a.vis_stride);
         uint4* dst = reinterpret_cast<uint4*>(vis);
-        for (int i = tid; i < a.vis_stride / 4; i += blockDim.x) dst[i] = src[i];
+#pragma unroll
+        for (int k = 0; k < VEC_PER_THREAD; k++) {
+            const int i = tid + k * 256;
+            if (i < n_vec) dst[i] = vreg[k];
+        }
+        for (int i = tid + VEC_PER_THREAD * 256; i < n_vec; i += 256) dst[i] = vsrc[i];
     }
     __syncthreads();
 
@@ -206,6 +266,7 @@ __global__ __launch_bounds__(256) void value_map_fuse_kernel(UpdateArgs a) {
     // address and are masked at the end.
     constexpr int ROWS_PER_WAVE = ROWS_PER_TILE;
     for (int x = wave * 64 + lane; x < T; x += 256) {
+        if (x - lane > box.w || x - lane + 63 < box.z) continue;  // wave-uniform: segment outside the cone's columns
         const int mc = pose.col0 + x;
         const bool col_ok = (unsigned)mc < (unsigned)S;
         // affine tables of cv::warpAffine (AB_BITS = 10, INTER_BITS = 5, round_delta = 16), evaluated per lane
@@ -397,14 +458,14 @@ extern "C" int vlfm_cone_template_build(const float* d_conf, const int64_t* d_po
     const int T = template_size, words = (T + 31) >> 5;
     const size_t lds = (size_t)2 * T * words * sizeof(unsigned);
     if (lds > 160 * 1024) return fail(VLFM_ERR_CAPACITY, "cone_template_build: template too large for LDS");
-    hipLaunchKernelGGL(cone_template_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, d_conf,
+    VLFM_KLAUNCH(cone_template_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, d_conf,
                        reinterpret_cast<const long long*>(d_poly_xy), n_poly, T, d_template, d_template_bits);
     return check_launch("cone_template_kernel");
 }
 
 static int vis_stride_words(int T) {
     const int words = (T + 31) >> 5;
-    return (T * words + 3) & ~3;
+    return VIS_META_WORDS + ((T * words + 3) & ~3);
 }
 
 extern "C" size_t vlfm_value_map_scratch_bytes(int n, int template_size) {
@@ -441,18 +502,18 @@ extern "C" int vlfm_value_map_update_batched(uint32_t* d_colmax_keys, int width,
     a.use_max_conf = use_max_confidence; a.fusion = fusion_type;
     const int T = template_size, words = (T + 31) >> 5;
     const size_t lds_mask = (size_t)(2 * T * words + ((2 * T * words) & 1)) * 4 + (size_t)(width + 2) * sizeof(int2);
-    const size_t lds_fuse = (size_t)a.vis_stride * 4;
+    const size_t lds_fuse = (size_t)(a.vis_stride - VIS_META_WORDS) * 4;
     if (lds_mask > 160 * 1024) return fail(VLFM_ERR_CAPACITY, "value_map_update_batched: template/width too large for LDS");
     {
         VLFM_TIMED("visible_mask_kernel", stream);
-        hipLaunchKernelGGL(visible_mask_kernel, dim3(n), dim3(512), lds_mask, (hipStream_t)stream, a);
+        VLFM_KLAUNCH(visible_mask_kernel, dim3(n), dim3(512), lds_mask, (hipStream_t)stream, a);
     }
     const int tiles = (template_size + ROWS_PER_TILE - 1) / ROWS_PER_TILE;
     VLFM_TIMED("value_map_fuse_kernel", stream);
     if (channels == 1)
-        hipLaunchKernelGGL(value_map_fuse_kernel<1>, dim3(tiles, n), dim3(256), lds_fuse, (hipStream_t)stream, a);
+        VLFM_KLAUNCH(value_map_fuse_kernel<1>, dim3(tiles, n), dim3(256), lds_fuse, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(value_map_fuse_kernel<0>, dim3(tiles, n), dim3(256), lds_fuse, (hipStream_t)stream, a);
+        VLFM_KLAUNCH(value_map_fuse_kernel<0>, dim3(tiles, n), dim3(256), lds_fuse, (hipStream_t)stream, a);
     return check_launch("value_map_fuse_kernel");
 }
 
@@ -470,7 +531,7 @@ extern "C" int vlfm_value_map_mask_unexplored_batched(const vlfm_mask_job* d_job
     if (bx > cap) bx = cap;
     if (bx < 1) bx = 1;
     VLFM_TIMED("mask_unexplored_kernel", stream);
-    hipLaunchKernelGGL(mask_unexplored_kernel, dim3((unsigned)bx, n), dim3(256), 0, (hipStream_t)stream,
+    VLFM_KLAUNCH(mask_unexplored_kernel, dim3((unsigned)bx, n), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const MaskJob*>(d_jobs), map_size, channels, d_explored_bits, d_conf, d_value);
     return check_launch("mask_unexplored_kernel");
 }
@@ -485,7 +546,7 @@ extern "C" int vlfm_value_map_sort_waypoints_batched(const float* d_value, int m
     const size_t lds = ((size_t)side * side + 4) * sizeof(float);
     if (lds > 150 * 1024) return fail(VLFM_ERR_CAPACITY, "sort_waypoints_batched: radius too large");
     VLFM_TIMED("sort_waypoints_kernel", stream);
-    hipLaunchKernelGGL(sort_waypoints_kernel, dim3(m, channels), dim3(256), lds, (hipStream_t)stream, d_value,
+    VLFM_KLAUNCH(sort_waypoints_kernel, dim3(m, channels), dim3(256), lds, (hipStream_t)stream, d_value,
                        map_size, channels, d_cells, radius, d_disc, d_out);
     return check_launch("sort_waypoints_kernel");
 }

@@ -187,7 +187,7 @@ extern "C" int vlfm_preprocess_rgb_batched(const uint8_t* d_rgb, int n, int heig
     const size_t lds = ((size_t)width * 3 + 15) / 16 * 16;
     {
         VLFM_TIMED("resample_h_kernel", s);
-    hipLaunchKernelGGL(resample_h_kernel, dim3(height, n), dim3(256), lds, s, d_rgb, height, width, out_size,
+    VLFM_KLAUNCH(resample_h_kernel, dim3(height, n), dim3(256), lds, s, d_rgb, height, width, out_size,
                        d_hbounds, d_hk, hksize, d_tmp);
     }
     int rc = check_launch("resample_h_kernel");
@@ -196,13 +196,13 @@ extern "C" int vlfm_preprocess_rgb_batched(const uint8_t* d_rgb, int n, int heig
     for (int c = 0; c < 3; c++) { nrm.mean[c] = h_mean3[c]; nrm.std[c] = h_std3[c]; }
     VLFM_TIMED("resample_v_norm_kernel", s);
     if (out_dtype == 0)
-        hipLaunchKernelGGL(resample_v_norm_kernel<float>, dim3(out_size, n), dim3(256), 0, s, d_tmp, height, out_size,
+        VLFM_KLAUNCH(resample_v_norm_kernel<float>, dim3(out_size, n), dim3(256), 0, s, d_tmp, height, out_size,
                            d_vbounds, d_vk, vksize, nrm, (float*)d_out, patch_size);
     else if (out_dtype == 1)
-        hipLaunchKernelGGL(resample_v_norm_kernel<__half>, dim3(out_size, n), dim3(256), 0, s, d_tmp, height,
+        VLFM_KLAUNCH(resample_v_norm_kernel<__half>, dim3(out_size, n), dim3(256), 0, s, d_tmp, height,
                            out_size, d_vbounds, d_vk, vksize, nrm, (__half*)d_out, patch_size);
     else if (out_dtype == 2)
-        hipLaunchKernelGGL(resample_v_norm_kernel<__hip_bfloat16>, dim3(out_size, n), dim3(256), 0, s, d_tmp, height,
+        VLFM_KLAUNCH(resample_v_norm_kernel<__hip_bfloat16>, dim3(out_size, n), dim3(256), 0, s, d_tmp, height,
                            out_size, d_vbounds, d_vk, vksize, nrm, (__hip_bfloat16*)d_out, patch_size);
     else
         return fail(VLFM_ERR_INVALID, "preprocess_rgb_batched: out_dtype must be 0 (f32), 1 (f16) or 2 (bf16)");
@@ -215,7 +215,7 @@ extern "C" int vlfm_itc_head_batched(const float* d_proj, int batch, int n_query
     if (!d_proj || !d_text || !d_out || batch < 0 || n_query <= 0 || n_query > 64 || proj_dim <= 0)
         return fail(VLFM_ERR_INVALID, "itc_head_batched: bad argument (n_query <= 64)");
     VLFM_TIMED("itc_head_kernel", stream);
-    hipLaunchKernelGGL(itc_head_kernel, dim3(batch), dim3(512), 0, (hipStream_t)stream, d_proj, n_query, proj_dim,
+    VLFM_KLAUNCH(itc_head_kernel, dim3(batch), dim3(512), 0, (hipStream_t)stream, d_proj, n_query, proj_dim,
                        d_text, d_out);
     return check_launch("itc_head_kernel");
 }
