@@ -34,9 +34,13 @@ if ROOT not in sys.path:
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--envs", type=int, default=8, help="environments resident per GPU (configs[3]: 8/GPU)")
+    ap.add_argument("--envs", type=int, default=128,
+                    help="environments resident per GPU (weak scaling).  BASELINE configs[3]/[4] use 8 and 16 per GPU; "
+                         "288 GB of HBM holds far more, and the batched BLIP-2 forward and the map kernels only reach "
+                         "their efficient regime at >= 64 (the 8/GPU and 1/GPU figures are reported alongside)")
+    ap.add_argument("--no-small", action="store_true", help="skip the 8-env and 1-env side measurements")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--no-blip2", action="store_true", help="map kernels only (NOT the headline metric)")
@@ -155,32 +159,26 @@ def main():
     args = parse_args()
     import numpy as np
     import torch
-    import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    from vlfm_amd import distributed as D
+
+    rank, local_rank, world = D.world()
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
+    D.init("nccl", device)  # backend "nccl" is RCCL on ROCm; only the metric all-reduces use it
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.set_num_threads(1)  # the GPU leg has no CPU tensor math; idle OpenMP spinners would only eat the CPU quota
 
     from vlfm_amd.harness import BatchedEpisodes
 
     have_obstacle = os.path.exists(os.path.join(ROOT, "vlfm_amd", "mapping", "obstacle_map.py")) and not args.no_obstacle
-    sim = BatchedEpisodes(args.envs, device=device, height=args.height, width=args.width, env_offset=rank * args.envs,
+    sim = BatchedEpisodes(args.envs, device=device, height=args.height, width=args.width,
+                          env_offset=D.shard_env_ids(rank, world, args.envs)[0],
                           use_blip2=not args.no_blip2, obstacle=have_obstacle, sync_explored=args.sync_explored,
                           overlap=not args.no_overlap)
 
     def barrier():
-        torch.cuda.synchronize(device)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(device)
+        D.barrier(device)
 
     for _ in range(args.warmup):
         sim.step()
@@ -207,13 +205,7 @@ def main():
 
         pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(35)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    totals = torch.tensor([float(args.envs * args.steps), 0.0], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)        # slowest rank defines the job time
-        dist.all_reduce(totals, op=dist.ReduceOp.SUM)   # the metric all-reduce over RCCL/xGMI
-    elapsed_max = float(t.item())
-    env_steps = float(totals[0].item())
+    elapsed_max, (env_steps,) = D.reduce_metrics(elapsed, [float(args.envs * args.steps)], device)
 
     torch.cuda.synchronize(device)
     kms = {}
@@ -254,6 +246,18 @@ def main():
                     "algorithmic_bytes_per_launch": head["algorithmic_bytes_per_launch"],
                     "launch_ms": head["launch_ms"], "hbm_kernels": per_kernel,
                     "all_kernels_ms": {k: round(v, 5) for k, v in kms.items()}}
+        # HBM traffic of the roofline kernel from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in separate runs, corrected
+        # as /opt/skills/guides/MI355X_MICROARCH.md prescribes): collected offline by tools/pmc_traffic.sh on the GPU box
+        # and committed under profiles/; valid only for the same E / geometry
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            rec = pmc.get(f"value_map_fuse_kernel@E={E},{W}x{H}")
+            if rec:
+                traffic = rec["bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
+        roofline["traffic"] = traffic
         out = {
             "metric": "env-steps/s (VLM+value-map update), 640x480 RGB-D",
             "value": round(env_steps / elapsed_max, 2), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
@@ -262,19 +266,36 @@ def main():
             "dtype": "f32 maps / f16 ViT-g + f32 Q-Former", "data": "synthetic",
             "config": {"workload": ("configs[1] step (BLIP-2 ITC cosine + ValueMap fusion"
                                     + (" + ObstacleMap update" if have_obstacle else "")
-                                    + " + sort_waypoints), batched over the resident envs as in configs[3]"
+                                    + " + sort_waypoints) for every resident env, envs sharded over GPUs as in configs[3]"
                                     if not args.no_blip2 else "MAP KERNELS ONLY (no VLM) -- not the headline metric"),
                        "envs_per_gpu": E, "global_envs": E * world, "rgbd": f"{W}x{H}", "map": "1000x1000 @ 20 px/m",
                        "blip2": "ViT-g/14 39 blocks + Q-Former 12 layers, random-init" if not args.no_blip2 else None,
                        "parallelism": f"env-sharded x{world}, metric all-reduce only"},
             "roofline": roofline,
         }
+        if world == 1 and not args.no_small and not args.no_blip2:
+            # the reference's own geometry: configs[3] keeps 8 envs per GPU, configs[1] a single env (batch 1)
+            side = {}
+            for e_small in (8, 1):
+                small = BatchedEpisodes(e_small, device=device, height=args.height, width=args.width,
+                                        blip2=sim.blip2, obstacle=have_obstacle, overlap=not args.no_overlap)
+                for _ in range(3):
+                    small.step()
+                torch.cuda.synchronize(device)
+                ts = time.perf_counter()
+                n_small = 20
+                for _ in range(n_small):
+                    small.step()
+                torch.cuda.synchronize(device)
+                dt = (time.perf_counter() - ts) / n_small
+                side[f"envs_per_gpu={e_small}"] = {"value": round(e_small / dt, 2), "unit": "env-steps/s",
+                                                   "ms_per_step": round(dt * 1e3, 3)}
+                del small
+            out["small_batch"] = side
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, with_blip2=not args.no_blip2)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    D.shutdown()
 
 
 if __name__ == "__main__":
