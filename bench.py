@@ -41,6 +41,9 @@ def parse_args():
                          "288 GB of HBM holds far more, and the batched BLIP-2 forward and the map kernels only reach "
                          "their efficient regime at >= 64 (the 8/GPU and 1/GPU figures are reported alongside)")
     ap.add_argument("--no-small", action="store_true", help="skip the 8-env and 1-env side measurements")
+    ap.add_argument("--with-full", action="store_true",
+                    help="also time configs[2] (8 envs: BLIP-2 + detector + MobileSAM + maps); the detector/segmenter are "
+                         "random-init stand-ins of the YOLOv7-E6E / MobileSAM class, so this is a side figure")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--no-blip2", action="store_true", help="map kernels only (NOT the headline metric)")
@@ -291,6 +294,26 @@ def main():
                 side[f"envs_per_gpu={e_small}"] = {"value": round(e_small / dt, 2), "unit": "env-steps/s",
                                                    "ms_per_step": round(dt * 1e3, 3)}
                 del small
+            if args.with_full:
+                from vlfm_amd.vlm.sam import MobileSAM
+                from vlfm_amd.vlm.yolov7 import YOLOv7
+
+                full = BatchedEpisodes(8, device=device, height=args.height, width=args.width, blip2=sim.blip2,
+                                       obstacle=have_obstacle, overlap=not args.no_overlap,
+                                       detector=YOLOv7(device=device), sam=MobileSAM(device=device))
+                for _ in range(3):
+                    full.step()
+                torch.cuda.synchronize(device)
+                ts = time.perf_counter()
+                for _ in range(20):
+                    full.step()
+                torch.cuda.synchronize(device)
+                dt = (time.perf_counter() - ts) / 20
+                side["configs[2] full step, envs_per_gpu=8"] = {
+                    "value": round(8 / dt, 2), "unit": "env-steps/s", "ms_per_step": round(dt * 1e3, 3),
+                    "detector": full.detector.weights, "segmenter": "MobileSAM (TinyViT-5M) random-init, 1 box for every "
+                                                                    "4th env-step"}
+                del full
             out["small_batch"] = side
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, with_blip2=not args.no_blip2)

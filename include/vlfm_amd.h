@@ -188,6 +188,19 @@ int vlfm_value_map_sort_waypoints_batched(const float* d_value, int map_size, in
 int vlfm_resample_coeffs_host(int in_size, int out_size, int32_t* h_bounds, int32_t* h_kk, int kk_capacity,
                               int* ksize_out);
 
+/* Same for Pillow's BICUBIC (filter 0) or BILINEAR (filter 1) kernels. */
+int vlfm_resample_coeffs_filter_host(int in_size, int out_size, int filter, int32_t* h_bounds, int32_t* h_kk,
+                                     int kk_capacity, int* ksize_out);
+
+/* Device: MobileSAM.segment_bbox preprocessing (vlfm/vlm/sam.py:54 -> SamPredictor.set_image [ext]): PIL BILINEAR resize
+ * to (out_h, out_w) (longest side 1024), (x - mean) / std on the 0..255 scale, zero padding to pad x pad:
+ * d_rgb [n][H][W][3] u8 -> d_out [n][3][pad][pad] f32.  d_tmp: [n][H][out_w][3] u8 scratch. */
+int vlfm_preprocess_sam_batched(const uint8_t* d_rgb, int n, int height, int width, int out_h, int out_w,
+                                const int32_t* d_hbounds, const int32_t* d_hk, int hksize,
+                                const int32_t* d_vbounds, const int32_t* d_vk, int vksize,
+                                const float* h_mean3, const float* h_std3, int pad_size, uint8_t* d_tmp, float* d_out,
+                                void* stream);
+
 /* Device: d_rgb [n][H][W][3] u8 -> d_out (out_dtype 0=f32, 1=f16, 2=bf16):
  * PIL.Image.resize((out,out), BICUBIC) (two 8-bit passes, d_tmp [n][H][out][3] u8 scratch) -> /255 -> (x-mean)/std.
  * patch_size == 0: d_out is [n][3][out][out] (ToTensor layout).  patch_size == P > 0 (P divides out): d_out is
@@ -204,6 +217,32 @@ int vlfm_preprocess_rgb_batched(const uint8_t* d_rgb, int n, int height, int wid
  * max over queries.  NQ <= 64. */
 int vlfm_itc_head_batched(const float* d_proj, int batch, int n_query, int proj_dim,
                           const float* d_text, float* d_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Detector-side kernels (vlfm/vlm/yolov7.py:50-110, vlfm/vlm/grounding_dino.py:38-74)
+ * ------------------------------------------------------------------------------------------- */
+
+/* Host: cv::computeResizeAreaTab for one axis (cv2.resize INTER_AREA, shrinking or identity).  Returns the tap count
+ * used (<= ktaps_capacity) or a negative status.  h_first/h_count [dsize], h_w [dsize][ktaps_capacity]. */
+int vlfm_resize_area_tab_host(int ssize, int dsize, int32_t* h_first, int32_t* h_count, float* h_w, int ktaps_capacity);
+
+/* Device: YOLOv7.predict preprocessing (yolov7.py:70-83): d_rgb [n][H][W][3] u8 -> cv2.resize(.., (out_w, out_h),
+ * INTER_AREA) -> CHW -> /255 in out_dtype (0 = f32, 1 = f16): d_out [n][3][out_h][out_w]. */
+int vlfm_resize_area_batched(const uint8_t* d_rgb, int n, int height, int width, int out_h, int out_w,
+                             const int32_t* d_xfirst, const int32_t* d_xcount, const float* d_xw, int xktaps,
+                             const int32_t* d_yfirst, const int32_t* d_ycount, const float* d_yw, int yktaps,
+                             void* d_out, int out_dtype, void* stream);
+
+/* Device: torchvision to_tensor + normalize (grounding_dino.py:52-54): d_rgb [n][H][W][3] u8 -> d_out [n][3][H][W] f32. */
+int vlfm_to_tensor_normalize_batched(const uint8_t* d_rgb, int n, int height, int width, const float* h_mean3,
+                                     const float* h_std3, float* d_out, void* stream);
+
+/* Device: torchvision.ops.nms (yolov7 non_max_suppression, yolov7.py:91-99).  d_boxes_xyxy [N][4] f32, d_order [n] int32 =
+ * candidate indices sorted by descending score; d_keep [max_keep] receives the kept indices in that order, d_num_keep
+ * their count.  d_scratch: vlfm_nms_scratch_bytes(n).  The whole reduction runs on the device (no host sync). */
+size_t vlfm_nms_scratch_bytes(int n);
+int vlfm_nms(const float* d_boxes_xyxy, const int32_t* d_order, int n, float iou_threshold, void* d_scratch,
+             size_t scratch_bytes, int32_t* d_keep, int32_t* d_num_keep, int max_keep, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * ObstacleMap planes are bit-packed: 1 bit per cell, row stride ceil(cols/32) u32 words, bit x&31 of word x>>5.

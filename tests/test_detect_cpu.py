@@ -1,0 +1,84 @@
+"""CPU: host logic of the detector wrappers -- ObjectDetections (drop-in container), yolov7 post-processing with a plain
+NMS plugged in, caption handling -- and the stand-in networks' output contracts at tiny sizes."""
+import numpy as np
+import torch
+
+from vlfm_amd.vlm import det_ops
+from vlfm_amd.vlm.detections import ObjectDetections, box_convert
+
+
+def test_object_detections_container():
+    boxes = torch.tensor([[0.5, 0.5, 0.2, 0.4], [0.25, 0.3, 0.1, 0.1], [0.8, 0.7, 0.3, 0.2]])
+    d = ObjectDetections(boxes, torch.tensor([0.9, 0.4, 0.8]), ["chair", "bed", "chair"], image_source=None)
+    assert torch.allclose(d.boxes[0], torch.tensor([0.4, 0.3, 0.6, 0.7]))            # cxcywh -> xyxy (detections.py:30-33)
+    assert d.num_detections == 3
+    d.filter_by_class(["chair", "tv"])
+    assert d.phrases == ["chair", "chair"] and d.boxes.shape == (2, 4)
+    d.filter_by_conf(0.8)                                                               # >= (detections.py:70)
+    assert d.num_detections == 2
+    d.filter_by_conf(0.85)
+    assert d.phrases == ["chair"] and torch.allclose(d.logits, torch.tensor([0.9]))
+    j = d.to_json()
+    r = ObjectDetections.from_json(j)
+    assert r.phrases == d.phrases and torch.allclose(r.boxes, d.boxes) and "chair (0.90)" in repr(r)
+    d.filter_by_class([])
+    assert d.num_detections == 0 and repr(d) == "No detections"
+    assert torch.equal(box_convert(boxes, "cxcywh", "cxcywh"), boxes)
+
+
+def _torch_nms(b, s, thr, max_keep=None):
+    from oracle.ref_detect import nms
+
+    k = torch.from_numpy(nms(b.numpy(), s.numpy(), thr))
+    return k if max_keep is None else k[:max_keep]
+
+
+def test_yolo_postprocessing_host_logic():
+    g = torch.Generator().manual_seed(0)
+    pred = torch.zeros(2, 50, 85)
+    pred[..., :2] = torch.rand(2, 50, 2, generator=g) * torch.tensor([640.0, 448.0])
+    pred[..., 2:4] = torch.rand(2, 50, 2, generator=g) * 150 + 10
+    pred[..., 4] = torch.rand(2, 50, generator=g)
+    pred[..., 5:] = torch.rand(2, 50, 80, generator=g)
+    out = det_ops.non_max_suppression(pred, 0.25, 0.45, nms_fn=_torch_nms)
+    assert len(out) == 2
+    for o in out:
+        assert o.shape[1] == 6 and (o[:, 4] > 0.25).all() and o.shape[0] <= 300
+        assert (o[:, 5] == o[:, 5].round()).all() and (o[:-1, 4] >= o[1:, 4]).all()   # kept in score order
+    only = det_ops.non_max_suppression(pred, 0.25, 0.45, classes=[3, 7], nms_fn=_torch_nms)
+    assert all(set(o[:, 5].tolist()) <= {3.0, 7.0} for o in only)
+    # scale_coords reproduces the reference's quirk: the image was resized NON-uniformly (480 -> 448) but boxes are mapped
+    # back with the letterbox formula (gain = min, pad on x)
+    c = det_ops.scale_coords((448, 640), torch.tensor([[100.0, 100.0, 300.0, 400.0]]), (480, 640, 3))
+    gain = 448 / 480
+    pad = (640 - 640 * gain) / 2
+    assert torch.allclose(c, torch.tensor([[(100 - pad) / gain, 100 / gain, (300 - pad) / gain, 400 / gain]]))
+
+
+def test_resize_area_oracle_known_answers():
+    from oracle.ref_detect import resize_area_u8
+
+    img = np.arange(4 * 6 * 3, dtype=np.uint8).reshape(4, 6, 3)
+    assert np.array_equal(resize_area_u8(img, 6, 4), img)                              # identity
+    half = resize_area_u8(img, 3, 2)                                                   # integer factor = box mean
+    want = img.reshape(2, 2, 3, 2, 3).astype(np.float32).mean(axis=(1, 3))
+    assert np.array_equal(half, np.rint(want).astype(np.uint8))
+    const = np.full((480, 640, 3), 77, np.uint8)
+    assert (resize_area_u8(const, 640, 448) == 77).all()                               # weights sum to 1
+
+
+def test_stand_in_networks_contracts():
+    from vlfm_amd.vlm.sam import TinyViT
+    from vlfm_amd.vlm.yolov7 import YoloV7E6EClassNet
+
+    with torch.inference_mode():
+        y = YoloV7E6EClassNet(width=8).eval()(torch.rand(1, 3, 128, 192))
+        assert y.shape == (1, (16 * 24 + 8 * 12 + 4 * 6 + 2 * 3) * 3, 85)
+        e = TinyViT().eval()(torch.rand(1, 3, 128, 128))[0]
+        assert e.shape == (1, 256, 8, 8)
+    from vlfm_amd.vlm.grounding_dino import WordTokenizer, preprocess_caption
+
+    tok = WordTokenizer()
+    ids = tok(preprocess_caption("Chair . potted plant"))
+    assert ids[0] == 101 and ids[-1] == 102 and ids.count(1012) == 2
+    assert tok.decode(ids[1:2]) == "chair" and tok.decode(ids[3:5]) == "potted plant"

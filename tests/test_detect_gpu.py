@@ -1,0 +1,161 @@
+"""-m gpu: detector-side HIP kernels against their CPU restatements (oracle/ref_detect.py), the real Pillow, plain PyTorch,
+and the in-process YOLOv7 / GroundingDINO / MobileSAM wrappers (random-init weights: contracts + GPU-vs-CPU self-parity)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (720, 1280), (448, 640)])
+def test_resize_area_matches_oracle_bit_exact(gpu_device, shape):
+    from oracle.ref_detect import resize_area_u8
+    from vlfm_amd.vlm import det_ops
+
+    rng = np.random.default_rng(3)
+    imgs = rng.integers(0, 256, size=(2, shape[0], shape[1], 3), dtype=np.uint8)
+    got = det_ops.resize_area(torch.from_numpy(imgs).to(gpu_device), 448, 640, torch.float32).cpu()
+    for i in range(2):
+        want = torch.from_numpy(resize_area_u8(imgs[i], 640, 448)).permute(2, 0, 1).float() / 255.0
+        assert torch.equal(got[i], want)
+    half = det_ops.resize_area(torch.from_numpy(imgs).to(gpu_device), 448, 640, torch.float16).cpu()
+    u8 = torch.from_numpy(np.stack([resize_area_u8(im, 640, 448) for im in imgs])).permute(0, 3, 1, 2)
+    assert torch.equal(half, u8.half() / 255.0)                     # yolov7.py:81-82: img.half(); img /= 255.0
+
+
+def test_to_tensor_normalize_bit_exact(gpu_device):
+    from vlfm_amd.vlm import det_ops
+
+    rng = np.random.default_rng(4)
+    imgs = rng.integers(0, 256, size=(2, 120, 160, 3), dtype=np.uint8)
+    got = det_ops.to_tensor_normalize(torch.from_numpy(imgs).to(gpu_device)).cpu()
+    t = torch.from_numpy(imgs).permute(0, 3, 1, 2).float().div(255)                    # to_tensor
+    mean = torch.tensor(det_ops.IMAGENET_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(det_ops.IMAGENET_STD).view(1, 3, 1, 1)
+    assert torch.equal(got, (t - mean) / std)                                          # sub_(mean).div_(std)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 700, 3000])
+def test_nms_matches_oracle(gpu_device, n):
+    from oracle.ref_detect import nms as ref_nms
+    from vlfm_amd.vlm import det_ops
+
+    rng = np.random.default_rng(n)
+    xy = rng.uniform(0, 600, (n, 2)).astype(np.float32)
+    wh = rng.uniform(5, 200, (n, 2)).astype(np.float32)
+    boxes = np.concatenate([xy, xy + wh], 1)
+    boxes[n // 2] = boxes[0]                                        # exact duplicates and ties in score
+    scores = rng.permutation(n).astype(np.float32) / n              # distinct scores: the order is unambiguous
+    for thr in (0.45, 0.1, 0.9):
+        got = det_ops.nms(torch.from_numpy(boxes).to(gpu_device), torch.from_numpy(scores).to(gpu_device), thr).cpu().numpy()
+        want = ref_nms(boxes, scores, thr)
+        assert np.array_equal(got, want), (n, thr, len(got), len(want))
+    capped = det_ops.nms(torch.from_numpy(boxes).to(gpu_device), torch.from_numpy(scores).to(gpu_device), 0.45, 5).cpu().numpy()
+    assert np.array_equal(capped, ref_nms(boxes, scores, 0.45)[:5])
+    assert det_ops.nms(torch.zeros((0, 4), device=gpu_device), torch.zeros(0, device=gpu_device), 0.5).numel() == 0
+
+
+def test_preprocess_sam_matches_pil(gpu_device):
+    from PIL import Image
+
+    from vlfm_amd.vlm import ops
+
+    rng = np.random.default_rng(5)
+    imgs = rng.integers(0, 256, size=(2, 480, 640, 3), dtype=np.uint8)
+    got, (oh, ow) = ops.preprocess_sam(torch.from_numpy(imgs).to(gpu_device))
+    assert (oh, ow) == (768, 1024) and got.shape == (2, 3, 1024, 1024)
+    mean = torch.tensor(ops.SAM_MEAN).view(3, 1, 1)
+    std = torch.tensor(ops.SAM_STD).view(3, 1, 1)
+    for i in range(2):
+        pil = np.asarray(Image.fromarray(imgs[i]).resize((ow, oh), Image.BILINEAR))   # ResizeLongestSide.apply_image
+        want = (torch.from_numpy(pil.copy()).permute(2, 0, 1).float() - mean) / std     # Sam.preprocess
+        assert torch.equal(got[i, :, :oh, :ow].cpu(), want)
+        assert (got[i, :, oh:, :] == 0).all()                                           # zero padding after normalisation
+
+
+def test_yolov7_pipeline(gpu_device):
+    from vlfm_amd.vlm import det_ops
+    from vlfm_amd.vlm.coco_classes import COCO_CLASSES
+    from vlfm_amd.vlm.yolov7 import YOLOv7, YOLOv7Client
+
+    model = YOLOv7(device=gpu_device, width=16)
+    with torch.no_grad():   # make the random net emit confident boxes
+        for d in model.model.detect:
+            d.bias.fill_(0.0)
+            d.bias.view(3, 85)[:, 4] = 1.5
+    rng = np.random.default_rng(6)
+    imgs = rng.integers(0, 256, size=(2, 480, 640, 3), dtype=np.uint8)
+    dets = model.predict_batch(torch.from_numpy(imgs).to(gpu_device))
+    assert len(dets) == 2
+    for d in dets:
+        assert d.boxes.shape[1] == 4 and d.num_detections == len(d.logits) <= 300
+        assert (d.logits > 0.25).all() and all(p in COCO_CLASSES for p in d.phrases)
+        assert (d.boxes >= 0).all() and (d.boxes[:, [0, 2]] <= 1.0 + 1e-6).all()
+    # the single-image entry point is the batched one at B = 1
+    one = model.predict(imgs[1])
+    assert one.phrases == dets[1].phrases and torch.allclose(one.boxes, dets[1].boxes)
+    # post-processing parity: same raw predictions -> HIP NMS == reference NMS
+    from oracle.ref_detect import nms as ref_nms
+
+    img = det_ops.resize_area(torch.from_numpy(imgs).to(gpu_device), 448, 640, torch.float16)
+    with torch.inference_mode():
+        pred = model.model(img).float()
+    a = det_ops.non_max_suppression(pred, 0.25, 0.45)
+    b = det_ops.non_max_suppression(pred.cpu(), 0.25, 0.45,
+                                    nms_fn=lambda bx, s, t, m: torch.from_numpy(ref_nms(bx.numpy(), s.numpy(), t))[:m])
+    for x, y in zip(a, b):
+        assert torch.equal(x.cpu(), y)
+    c = YOLOv7Client(port=12184, device=gpu_device, width=16)
+    assert isinstance(c.predict(imgs[0]).to_json()["phrases"], list)
+
+
+def test_grounding_dino_wrapper(gpu_device):
+    from transformers import GroundingDinoConfig
+
+    from vlfm_amd.vlm.grounding_dino import GroundingDINO
+
+    tiny = GroundingDinoConfig(num_queries=30, d_model=32, encoder_layers=2, decoder_layers=2, encoder_ffn_dim=64,
+                               decoder_ffn_dim=64, encoder_attention_heads=2, decoder_attention_heads=2,
+                               backbone_config={"model_type": "swin", "embed_dim": 16, "depths": [1, 1, 1, 1],
+                                                "num_heads": [1, 2, 2, 2], "window_size": 4,
+                                                "out_features": ["stage2", "stage3", "stage4"]},
+                               text_config={"model_type": "bert", "hidden_size": 32, "num_hidden_layers": 1,
+                                            "num_attention_heads": 2, "intermediate_size": 64, "vocab_size": 30522,
+                                            "max_position_embeddings": 64})
+    gd = GroundingDINO(device=gpu_device, hf_config=tiny, box_threshold=0.0, text_threshold=0.0)
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, size=(96, 128, 3), dtype=np.uint8)
+    det = gd.predict(img, caption="chair . potted plant .")
+    # thresholds 0 -> every query survives with the phrase "chair potted plant", which is not an exact class -> filtered
+    assert det.num_detections == 0
+    gd.text_threshold = 2.0   # no token passes -> empty phrases -> filtered as well
+    assert gd.predict(img, caption="chair .").num_detections == 0
+    # raw model outputs: GPU == CPU fp32 of the same weights (the deformable attention runs in plain PyTorch on both)
+    from vlfm_amd.vlm import det_ops
+
+    pix = det_ops.to_tensor_normalize(torch.from_numpy(img).to(gpu_device)[None])
+    ids = torch.tensor([gd.tokenizer("chair .")])
+    kw = dict(input_ids=ids, attention_mask=torch.ones_like(ids), token_type_ids=torch.zeros_like(ids))
+    with torch.inference_mode():
+        g = gd.model(pixel_values=pix, **{k: v.to(gpu_device) for k, v in kw.items()})
+        cpu_model = gd.model.to("cpu")
+        c = cpu_model(pixel_values=pix.cpu(), **kw)
+    assert torch.allclose(g.pred_boxes.cpu(), c.pred_boxes, atol=2e-3)
+    assert torch.allclose(g.logits.cpu().sigmoid(), c.logits.sigmoid(), atol=2e-3)
+
+
+def test_mobile_sam_wrapper(gpu_device):
+    from vlfm_amd.vlm.sam import MobileSAM, MobileSAMClient
+
+    sam = MobileSAM(device=gpu_device)
+    rng = np.random.default_rng(8)
+    img = rng.integers(0, 256, size=(480, 640, 3), dtype=np.uint8)
+    mask = sam.segment_bbox(img, [100, 120, 400, 380])
+    assert mask.shape == (480, 640) and mask.dtype == np.bool_          # full-frame mask (sam.py:49-57 quirk)
+    imgs = torch.from_numpy(np.stack([img, img[::-1].copy()])).to(gpu_device)
+    boxes = torch.tensor([[[100, 120, 400, 380], [10, 10, 200, 200]], [[300, 50, 630, 470], [0, 0, 639, 479]]], dtype=torch.float32)
+    masks = sam.segment_bboxes(imgs, boxes)
+    assert masks.shape == (2, 2, 480, 640) and masks.dtype == torch.bool
+    assert np.array_equal(masks[0, 0].cpu().numpy(), mask)              # batched == single
+    c = MobileSAMClient(port=12183, device=gpu_device)
+    assert c.segment_bbox(img, [100, 120, 400, 380]).shape == (480, 640)

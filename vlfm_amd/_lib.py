@@ -13,7 +13,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvlfm_amd.so")
-SOURCES = ["value_map.hip", "depth_ingest.hip", "depth_holes.hip", "obstacle_map.hip", "vlm_ops.hip", "host.cpp"]
+SOURCES = ["value_map.hip", "depth_ingest.hip", "depth_holes.hip", "obstacle_map.hip", "vlm_ops.hip", "detect_ops.hip", "host.cpp"]
 
 VLFM_OK = 0
 VLFM_ERR_INVALID = -1
@@ -97,8 +97,17 @@ def lib() -> ctypes.CDLL:
         L.vlfm_value_map_mask_unexplored_batched.argtypes = [vp, ci, ci, vp, vp, vp, ci, ci, vp]
         L.vlfm_value_map_sort_waypoints_batched.argtypes = [vp, ci, ci, vp, ci, ci, vp, vp, vp]
         L.vlfm_resample_coeffs_host.argtypes = [ci, ci, vp, vp, ci, ctypes.POINTER(ci)]
+        L.vlfm_resample_coeffs_filter_host.argtypes = [ci, ci, ci, vp, vp, ci, ctypes.POINTER(ci)]
+        L.vlfm_preprocess_sam_batched.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, vp, vp, ci, vp, vp, vp]
         L.vlfm_preprocess_rgb_batched.argtypes = [vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, ci, ci, vp]
         L.vlfm_itc_head_batched.argtypes = [vp, ci, ci, ci, vp, vp, vp]
+        cf = ctypes.c_float
+        L.vlfm_resize_area_tab_host.argtypes = [ci, ci, vp, vp, vp, ci]
+        L.vlfm_resize_area_batched.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, ci, vp]
+        L.vlfm_to_tensor_normalize_batched.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp]
+        L.vlfm_nms_scratch_bytes.argtypes = [ci]
+        L.vlfm_nms_scratch_bytes.restype = ctypes.c_size_t
+        L.vlfm_nms.argtypes = [vp, vp, ci, cf, vp, ctypes.c_size_t, vp, vp, ci, vp]
         L.vlfm_bits_pack.argtypes = [vp, vp, ci, ci, ci, vp]
         L.vlfm_bits_unpack.argtypes = [vp, vp, ci, ci, ci, vp]
         L.vlfm_bits_dilate.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]

@@ -1,0 +1,238 @@
+// detect_ops.hip -- HIP kernels either side of the detector forward passes (gfx950).
+//
+//   resize_area      YOLOv7.predict's preprocessing (vlfm/vlm/yolov7.py:70-83): cv2.resize(image, (640, 448), INTER_AREA)
+//                    -> letterbox (a no-op at that size) -> HWC->CHW -> half()/float() -> /255, one kernel, u8 in, network
+//                    tensor out.  Restates cv::resize's general area path (computeResizeAreaTab + ResizeArea_<uchar,float>:
+//                    float accumulation row by row, cvRound saturate) [ext OpenCV 4.5.5].
+//   to_tensor_norm   GroundingDINO.predict's preprocessing (vlfm/vlm/grounding_dino.py:52-54): to_tensor + normalize at
+//                    native resolution, u8 HWC -> f32 CHW.
+//   nms              torchvision.ops.nms [ext] as used by yolov7's non_max_suppression (yolov7.py:91-99): 64x64 IoU
+//                    bit-mask tiles (one 64-bit word per row box and column block -- a wavefront-native layout), then an
+//                    in-order reduction by a single wavefront ON THE DEVICE (torchvision copies the mask to the host).
+// Memory-bound / latency-bound integer+float work; no MFMA.
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vlfm_amd.h"
+#include "profile.h"
+#include "status.h"
+
+namespace vlfm {
+
+// ------------------------------------------------------------------------------------------------ INTER_AREA resize
+struct AreaTab {       // per destination index: first source index, tap count, taps (alpha)
+    const int* first;  // [dsize]
+    const int* count;  // [dsize]
+    const float* w;    // [dsize][ktaps]
+    int ktaps;
+};
+
+template <typename OutT> __device__ inline OutT to_out(float v);
+template <> __device__ inline float to_out<float>(float v) { return v; }
+template <> __device__ inline __half to_out<__half>(float v) { return __float2half_rn(v); }
+
+// one workgroup per (dst row, image); threads over dst x * channel.  Accumulation order follows ResizeArea_: for every
+// contributing source row (top to bottom) the horizontal weighted sum is formed first (left to right), then scaled by the
+// row weight and added.
+template <typename OutT>
+__global__ __launch_bounds__(256) void resize_area_kernel(const unsigned char* __restrict__ src, int H, int W, int OH,
+                                                          int OW, AreaTab xt, AreaTab yt, OutT* __restrict__ dst) {
+    const int dy = blockIdx.x, n = blockIdx.y;
+    const unsigned char* img = src + (size_t)n * H * W * 3;
+    const int y0 = yt.first[dy], yc = yt.count[dy];
+    const float* yw = yt.w + (size_t)dy * yt.ktaps;
+    for (int o = threadIdx.x; o < OW * 3; o += blockDim.x) {
+        const int c = o / OW, dx = o - c * OW;  // channel-major: CHW stores are coalesced
+        const int x0 = xt.first[dx], xc = xt.count[dx];
+        const float* xw = xt.w + (size_t)dx * xt.ktaps;
+        float sum = 0.0f;
+        for (int j = 0; j < yc; j++) {
+            const unsigned char* row = img + ((size_t)(y0 + j) * W) * 3 + c;
+            float buf = 0.0f;
+            for (int i = 0; i < xc; i++) buf = __fadd_rn(buf, __fmul_rn((float)row[(size_t)(x0 + i) * 3], xw[i]));
+            sum = j == 0 ? __fmul_rn(yw[0], buf) : __fadd_rn(sum, __fmul_rn(yw[j], buf));
+        }
+        // saturate_cast<uchar>(float) = cvRound (half-even) + clamp; then uint8 -> half/float, /= 255 (yolov7.py:81-82)
+        int q = __float2int_rn(sum);
+        q = q < 0 ? 0 : q > 255 ? 255 : q;
+        dst[(((size_t)n * 3 + c) * OH + dy) * OW + dx] = to_out<OutT>(__fdiv_rn((float)q, 255.0f));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ to_tensor + normalize
+struct Norm3f { float mean[3]; float std[3]; };
+__global__ __launch_bounds__(256) void to_tensor_norm_kernel(const unsigned char* __restrict__ src, int HW, Norm3f nrm,
+                                                             float* __restrict__ dst) {
+    const int n = blockIdx.y;
+    const unsigned char* img = src + (size_t)n * HW * 3;
+    float* out = dst + (size_t)n * HW * 3;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float v = __fdiv_rn((float)img[(size_t)i * 3 + c], 255.0f);                       // to_tensor
+            out[(size_t)c * HW + i] = __fdiv_rn(__fsub_rn(v, nrm.mean[c]), nrm.std[c]);            // sub_(mean).div_(std)
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ NMS
+__device__ inline bool iou_over(const float4 a, const float4 b, float thr) {
+    const float left = fmaxf(a.x, b.x), right = fminf(a.z, b.z), top = fmaxf(a.y, b.y), bottom = fminf(a.w, b.w);
+    const float width = fmaxf(__fsub_rn(right, left), 0.f), height = fmaxf(__fsub_rn(bottom, top), 0.f);
+    const float inter = __fmul_rn(width, height);
+    const float sa = __fmul_rn(__fsub_rn(a.z, a.x), __fsub_rn(a.w, a.y)), sb = __fmul_rn(__fsub_rn(b.z, b.x), __fsub_rn(b.w, b.y));
+    return __fdiv_rn(inter, __fsub_rn(__fadd_rn(sa, sb), inter)) > thr;
+}
+
+// grid (col_blocks, row_blocks), 64 threads: thread t of block (cb, rb) owns sorted box rb*64+t and tests it against the
+// 64 boxes of column block cb (staged in LDS); only cb >= rb matters (a box can only suppress lower-ranked ones).
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__ boxes, const int* __restrict__ order,
+                                                      int n, float thr, unsigned long long* __restrict__ mask,
+                                                      int col_blocks) {
+    const int cb = blockIdx.x, rb = blockIdx.y, t = threadIdx.x;
+    if (cb < rb) return;
+    __shared__ float4 cbox[64];
+    const int cj = cb * 64 + t;
+    if (cj < n) cbox[t] = boxes[order[cj]];
+    __syncthreads();
+    const int ri = rb * 64 + t;
+    if (ri >= n) return;
+    const float4 me = boxes[order[ri]];
+    const int ncol = min(64, n - cb * 64);
+    unsigned long long bits = 0ull;
+    for (int j = (cb == rb ? t + 1 : 0); j < ncol; j++)
+        if (iou_over(me, cbox[j], thr)) bits |= 1ull << j;
+    mask[(size_t)ri * col_blocks + cb] = bits;
+}
+
+// one wavefront: walk the sorted boxes in order; lane l holds the "removed" words l, l+64, ...
+__global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* __restrict__ mask,
+                                                      const int* __restrict__ order, int n, int col_blocks,
+                                                      int* __restrict__ keep, int* __restrict__ num_keep, int max_keep) {
+    constexpr int MAXW = 8;  // 64 lanes x 8 words x 64 bits = 32768 boxes
+    unsigned long long remv[MAXW];
+#pragma unroll
+    for (int k = 0; k < MAXW; k++) remv[k] = 0ull;
+    const int lane = threadIdx.x;
+    int kept = 0;
+    for (int i = 0; i < n; i++) {
+        const int w = i >> 6, owner = w & 63, slot = w >> 6;
+        unsigned long long word = 0ull;
+#pragma unroll
+        for (int k = 0; k < MAXW; k++) if (k == slot) word = remv[k];
+        const unsigned lo = __shfl((unsigned)word, owner, 64), hi = __shfl((unsigned)(word >> 32), owner, 64);
+        const unsigned long long rw = ((unsigned long long)hi << 32) | lo;
+        if (!((rw >> (i & 63)) & 1ull)) {
+            if (lane == 0 && kept < max_keep) keep[kept] = order[i];
+            kept++;
+            if (kept >= max_keep) break;  // yolov7: i = i[:max_det]
+            const unsigned long long* row = mask + (size_t)i * col_blocks;
+#pragma unroll
+            for (int k = 0; k < MAXW; k++) {
+                const int cw = lane + 64 * k;
+                if (cw < col_blocks && cw >= w) remv[k] |= row[cw];
+            }
+        }
+    }
+    if (lane == 0) *num_keep = kept < max_keep ? kept : max_keep;
+}
+
+}  // namespace vlfm
+
+using namespace vlfm;
+
+// cv::computeResizeAreaTab for one axis.  h_first/h_count [dsize], h_w [dsize][ktaps].  Returns ktaps needed (>0) or <0.
+extern "C" int vlfm_resize_area_tab_host(int ssize, int dsize, int32_t* h_first, int32_t* h_count, float* h_w,
+                                         int ktaps_capacity) {
+    if (ssize <= 0 || dsize <= 0 || dsize > ssize || !h_first || !h_count || !h_w)
+        return fail(VLFM_ERR_INVALID, "resize_area_tab_host: bad argument (only shrinking or identity)");
+    const double scale = (double)ssize / dsize;
+    int need = 0;
+    for (int dx = 0; dx < dsize; dx++) {
+        const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+        const double cell = scale < ssize - fsx1 ? scale : ssize - fsx1;
+        int sx1 = (int)__builtin_ceil(fsx1), sx2 = (int)__builtin_floor(fsx2);
+        if (sx2 > ssize - 1) sx2 = ssize - 1;
+        if (sx1 > sx2) sx1 = sx2;
+        int k = 0, first = -1;
+        float* w = h_w + (size_t)dx * ktaps_capacity;
+        auto put = [&](int si, float a) {
+            if (first < 0) first = si;
+            if (k < ktaps_capacity) w[k] = a;
+            k++;
+        };
+        if (sx1 - fsx1 > 1e-3) put(sx1 - 1, (float)((sx1 - fsx1) / cell));
+        for (int sx = sx1; sx < sx2; sx++) put(sx, (float)(1.0 / cell));
+        if (fsx2 - sx2 > 1e-3) {
+            double a = fsx2 - sx2;
+            if (a > 1.0) a = 1.0;
+            if (a > cell) a = cell;
+            put(sx2, (float)(a / cell));
+        }
+        h_first[dx] = first < 0 ? 0 : first;
+        h_count[dx] = k;
+        if (k > need) need = k;
+    }
+    if (need > ktaps_capacity) return fail(VLFM_ERR_CAPACITY, "resize_area_tab_host: ktaps capacity");
+    return need;
+}
+
+extern "C" int vlfm_resize_area_batched(const uint8_t* d_rgb, int n, int height, int width, int out_h, int out_w,
+                                        const int32_t* d_xfirst, const int32_t* d_xcount, const float* d_xw, int xktaps,
+                                        const int32_t* d_yfirst, const int32_t* d_ycount, const float* d_yw, int yktaps,
+                                        void* d_out, int out_dtype, void* stream) {
+    if (n == 0) return VLFM_OK;
+    if (!d_rgb || !d_xfirst || !d_xcount || !d_xw || !d_yfirst || !d_ycount || !d_yw || !d_out || n < 0 || height <= 0 ||
+        width <= 0 || out_h <= 0 || out_w <= 0 || (out_dtype != 0 && out_dtype != 1))
+        return fail(VLFM_ERR_INVALID, "resize_area_batched: bad argument (out_dtype 0 = f32, 1 = f16)");
+    AreaTab xt{d_xfirst, d_xcount, d_xw, xktaps}, yt{d_yfirst, d_ycount, d_yw, yktaps};
+    VLFM_TIMED("resize_area_kernel", stream);
+    if (out_dtype == 0)
+        VLFM_KLAUNCH(resize_area_kernel<float>, dim3(out_h, n), dim3(256), 0, stream, d_rgb, height, width, out_h, out_w,
+                     xt, yt, (float*)d_out);
+    else
+        VLFM_KLAUNCH(resize_area_kernel<__half>, dim3(out_h, n), dim3(256), 0, stream, d_rgb, height, width, out_h, out_w,
+                     xt, yt, (__half*)d_out);
+    return check_launch("resize_area_kernel");
+}
+
+extern "C" int vlfm_to_tensor_normalize_batched(const uint8_t* d_rgb, int n, int height, int width, const float* h_mean3,
+                                                const float* h_std3, float* d_out, void* stream) {
+    if (n == 0) return VLFM_OK;
+    if (!d_rgb || !h_mean3 || !h_std3 || !d_out || n < 0 || height <= 0 || width <= 0)
+        return fail(VLFM_ERR_INVALID, "to_tensor_normalize_batched: bad argument");
+    Norm3f nrm;
+    for (int c = 0; c < 3; c++) { nrm.mean[c] = h_mean3[c]; nrm.std[c] = h_std3[c]; }
+    const int HW = height * width;
+    int bx = (HW + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    VLFM_TIMED("to_tensor_norm_kernel", stream);
+    VLFM_KLAUNCH(to_tensor_norm_kernel, dim3(bx, n), dim3(256), 0, stream, d_rgb, HW, nrm, d_out);
+    return check_launch("to_tensor_norm_kernel");
+}
+
+extern "C" size_t vlfm_nms_scratch_bytes(int n) {
+    if (n <= 0) return 0;
+    const size_t cb = ((size_t)n + 63) / 64;
+    return (size_t)n * cb * sizeof(unsigned long long);
+}
+
+extern "C" int vlfm_nms(const float* d_boxes_xyxy, const int32_t* d_order, int n, float iou_threshold, void* d_scratch,
+                        size_t scratch_bytes, int32_t* d_keep, int32_t* d_num_keep, int max_keep, void* stream) {
+    if (!d_num_keep) return fail(VLFM_ERR_INVALID, "nms: d_num_keep is null");
+    if (n == 0) return hipMemsetAsync(d_num_keep, 0, sizeof(int32_t), (hipStream_t)stream) == hipSuccess ? VLFM_OK : VLFM_ERR_HIP;
+    if (!d_boxes_xyxy || !d_order || !d_scratch || !d_keep || n < 0 || n > 32768 || max_keep <= 0)
+        return fail(VLFM_ERR_INVALID, "nms: bad argument (n <= 32768)");
+    if (scratch_bytes < vlfm_nms_scratch_bytes(n)) return fail(VLFM_ERR_CAPACITY, "nms: scratch too small");
+    const int cb = (n + 63) / 64;
+    {
+        VLFM_TIMED("nms_mask_kernel", stream);
+        VLFM_KLAUNCH(nms_mask_kernel, dim3(cb, cb), dim3(64), 0, stream, reinterpret_cast<const float4*>(d_boxes_xyxy),
+                     d_order, n, iou_threshold, reinterpret_cast<unsigned long long*>(d_scratch), cb);
+    }
+    VLFM_TIMED("nms_scan_kernel", stream);
+    VLFM_KLAUNCH(nms_scan_kernel, dim3(1), dim3(64), 0, stream, reinterpret_cast<const unsigned long long*>(d_scratch),
+                 d_order, n, cb, d_keep, d_num_keep, max_keep);
+    return check_launch("nms_scan_kernel");
+}

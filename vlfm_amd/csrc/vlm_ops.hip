@@ -94,6 +94,29 @@ __global__ __launch_bounds__(256) void resample_v_norm_kernel(const unsigned cha
     }
 }
 
+// SamPredictor.set_image [ext mobile_sam]: vertical pass of the PIL BILINEAR resize to (OH, OW) (longest side 1024), then
+// Sam.preprocess: (x - pixel_mean) / pixel_std on the 0..255 scale and zero padding to P x P.  [n][H][OW][3] u8 -> [n][3][P][P]
+__global__ __launch_bounds__(256) void resample_v_sam_kernel(const unsigned char* __restrict__ src, int H, int OH, int OW,
+                                                             int P, const int* __restrict__ bounds,
+                                                             const int* __restrict__ kk, int ksize, Norm3 nrm,
+                                                             float* __restrict__ dst) {
+    const int yy = blockIdx.x, n = blockIdx.y;
+    const unsigned char* img = src + (size_t)n * H * OW * 3;
+    const bool row_in = yy < OH;
+    const int ymin = row_in ? bounds[2 * yy] : 0, cnt = row_in ? bounds[2 * yy + 1] : 0;
+    const int* k = kk + (size_t)(row_in ? yy : 0) * ksize;
+    for (int o = threadIdx.x; o < 3 * P; o += blockDim.x) {
+        const int c = o / P, xx = o - c * P;
+        float v = 0.0f;  // padding is applied AFTER normalisation: zeros
+        if (row_in && xx < OW) {
+            int ss = 1 << (PRECISION_BITS - 1);
+            for (int y = 0; y < cnt; y++) ss += (int)img[((size_t)(ymin + y) * OW + xx) * 3 + c] * k[y];
+            v = __fdiv_rn(__fsub_rn((float)clip8(ss), nrm.mean[c]), nrm.std[c]);
+        }
+        dst[(((size_t)n * 3 + c) * P + yy) * P + xx] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ ITC head
 // One workgroup per image, one wavefront per query (round-robin): cos_q = <p_q, t> / max(|p_q|, 1e-12); out = max_q.
 __global__ __launch_bounds__(512) void itc_head_kernel(const float* __restrict__ proj, int NQ, int P,
@@ -128,13 +151,14 @@ __global__ __launch_bounds__(512) void itc_head_kernel(const float* __restrict__
 using namespace vlfm;
 
 // Pillow's precompute_coeffs + normalize_coeffs_8bpc for the bicubic filter (support 2, a = -0.5), box = whole axis.
-extern "C" int vlfm_resample_coeffs_host(int in_size, int out_size, int32_t* h_bounds, int32_t* h_kk, int kk_capacity,
-                                         int* ksize_out) {
-    if (in_size <= 0 || out_size <= 0 || !h_bounds || !h_kk || !ksize_out)
-        return fail(VLFM_ERR_INVALID, "resample_coeffs_host: bad argument");
-    auto bicubic = [](double x) {
-        const double a = -0.5;
+extern "C" int vlfm_resample_coeffs_filter_host(int in_size, int out_size, int filter, int32_t* h_bounds, int32_t* h_kk,
+                                                int kk_capacity, int* ksize_out) {
+    if (in_size <= 0 || out_size <= 0 || !h_bounds || !h_kk || !ksize_out || (filter != 0 && filter != 1))
+        return fail(VLFM_ERR_INVALID, "resample_coeffs_host: bad argument (filter 0 = bicubic, 1 = bilinear)");
+    auto bicubic = [filter](double x) {
         if (x < 0.0) x = -x;
+        if (filter == 1) return x < 1.0 ? 1.0 - x : 0.0;  // Pillow bilinear_filter (support 1)
+        const double a = -0.5;
         if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
         if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
         return 0.0;
@@ -142,7 +166,7 @@ extern "C" int vlfm_resample_coeffs_host(int in_size, int out_size, int32_t* h_b
     const float in0 = 0.0f, in1 = (float)in_size;
     double scale = (double)(in1 - in0) / out_size, filterscale = scale;
     if (filterscale < 1.0) filterscale = 1.0;
-    const double support = 2.0 * filterscale;
+    const double support = (filter == 1 ? 1.0 : 2.0) * filterscale;
     const int ksize = (int)std::ceil(support) * 2 + 1;
     *ksize_out = ksize;
     if ((long)out_size * ksize > kk_capacity) return fail(VLFM_ERR_CAPACITY, "resample_coeffs_host: kk capacity");
@@ -172,6 +196,37 @@ extern "C" int vlfm_resample_coeffs_host(int in_size, int out_size, int32_t* h_b
         }
     }
     return VLFM_OK;
+}
+
+extern "C" int vlfm_resample_coeffs_host(int in_size, int out_size, int32_t* h_bounds, int32_t* h_kk, int kk_capacity,
+                                         int* ksize_out) {
+    return vlfm_resample_coeffs_filter_host(in_size, out_size, 0, h_bounds, h_kk, kk_capacity, ksize_out);
+}
+
+extern "C" int vlfm_preprocess_sam_batched(const uint8_t* d_rgb, int n, int height, int width, int out_h, int out_w,
+                                           const int32_t* d_hbounds, const int32_t* d_hk, int hksize,
+                                           const int32_t* d_vbounds, const int32_t* d_vk, int vksize,
+                                           const float* h_mean3, const float* h_std3, int pad_size, uint8_t* d_tmp,
+                                           float* d_out, void* stream) {
+    if (n == 0) return VLFM_OK;
+    if (!d_rgb || !d_hbounds || !d_hk || !d_vbounds || !d_vk || !h_mean3 || !h_std3 || !d_tmp || !d_out || n < 0 ||
+        height <= 0 || width <= 0 || out_h <= 0 || out_w <= 0 || pad_size < out_h || pad_size < out_w)
+        return fail(VLFM_ERR_INVALID, "preprocess_sam_batched: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = ((size_t)width * 3 + 15) / 16 * 16;
+    {
+        VLFM_TIMED("resample_h_kernel", s);
+        VLFM_KLAUNCH(resample_h_kernel, dim3(height, n), dim3(256), lds, s, d_rgb, height, width, out_w, d_hbounds, d_hk,
+                     hksize, d_tmp);
+    }
+    int rc = check_launch("resample_h_kernel");
+    if (rc != VLFM_OK) return rc;
+    Norm3 nrm;
+    for (int c = 0; c < 3; c++) { nrm.mean[c] = h_mean3[c]; nrm.std[c] = h_std3[c]; }
+    VLFM_TIMED("resample_v_sam_kernel", s);
+    VLFM_KLAUNCH(resample_v_sam_kernel, dim3(pad_size, n), dim3(256), 0, s, d_tmp, height, out_h, out_w, pad_size,
+                 d_vbounds, d_vk, vksize, nrm, d_out);
+    return check_launch("resample_v_sam_kernel");
 }
 
 extern "C" int vlfm_preprocess_rgb_batched(const uint8_t* d_rgb, int n, int height, int width, int out_size,

@@ -33,7 +33,7 @@ class BatchedEpisodes:
     def __init__(self, n_envs: int, device=None, height: int = 480, width: int = 640, env_offset: int = 0,
                  blip2=None, use_blip2: bool = True, frame_pool: int = 4, map_size: int = 1000,
                  n_frontiers: int = 8, sync_explored: bool = False, obstacle: bool = True,
-                 episode_len: int = 500, overlap: bool = True) -> None:
+                 episode_len: int = 500, overlap: bool = True, detector=None, sam=None, sam_every: int = 4) -> None:
         self.device = require_gpu(device)
         self.E, self.H, self.W, self.S = n_envs, height, width, map_size
         self.fx, self.fy, self.fov = camera_intrinsics(width)
@@ -70,6 +70,12 @@ class BatchedEpisodes:
                 self.values.explored_bits = self.obstacles.explored_bits
         # The obstacle pipeline is a handful of latency-bound workgroups per environment: it runs on its own HIP
         # stream beside the BLIP-2 GEMMs (which fill the chip) instead of in front of them.
+        # "full" ITMPolicyV2 step (configs[2]): object detector on every frame (YOLOv7 for the COCO targets of HM3D,
+        # base_objectnav_policy.py:221-233) and MobileSAM on the boxes that survive (:311-321).  With random-init networks
+        # detections carry no meaning, so SAM is exercised on one synthetic box for every ``sam_every``-th environment-step.
+        self.detector, self.sam, self.sam_every = detector, sam, sam_every
+        self.last_detections = None
+        self.last_masks = None
         self.map_stream = torch.cuda.Stream(self.device) if overlap else None
         self.last_cosines: Optional[torch.Tensor] = None
         self.last_frontier_values: Optional[np.ndarray] = None
@@ -103,6 +109,13 @@ class BatchedEpisodes:
         else:
             cos = torch.from_numpy(self.stub_rng.uniform(0.15, 0.45, size=self.E)).to(self.device)
         self.last_cosines = cos
+        if self.detector is not None:
+            self.last_detections = self.detector.predict_batch(rgb)
+        if self.sam is not None:
+            sel = [e for e in range(self.E) if (self.t + e) % self.sam_every == 0]
+            if sel:
+                box = torch.tensor([[[0.3 * self.W, 0.3 * self.H, 0.7 * self.W, 0.8 * self.H]]] * len(sel))
+                self.last_masks = self.sam.segment_bboxes(rgb[sel], box)
         # ---- frontiers back to the host (the policy needs them); waits for the side stream only, so the host-side
         # prologue of the value update overlaps the GPU's BLIP-2 work
         if self.obstacles is not None and self.obstacles.frontiers_ready:

@@ -1,0 +1,143 @@
+"""Python faces of the detector-side HIP kernels (csrc/detect_ops.hip) + the yolov7 post-processing built on them."""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)  # grounding_dino.py:54
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+_AREA_TABS: Dict[Tuple[str, int, int], Tuple[torch.Tensor, torch.Tensor, torch.Tensor, int]] = {}
+
+
+def _area_tab(device, ssize: int, dsize: int):
+    key = (str(device), ssize, dsize)
+    if key not in _AREA_TABS:
+        cap = int(np.ceil(ssize / dsize)) + 2
+        first, count = np.zeros(dsize, np.int32), np.zeros(dsize, np.int32)
+        w = np.zeros((dsize, cap), np.float32)
+        k = _lib.check(_lib.lib().vlfm_resize_area_tab_host(ssize, dsize, first.ctypes.data, count.ctypes.data,
+                                                            w.ctypes.data, cap), "resize_area_tab_host")
+        _AREA_TABS[key] = (torch.from_numpy(first).to(device), torch.from_numpy(count).to(device),
+                           torch.from_numpy(w).to(device), cap)
+        assert k <= cap
+    return _AREA_TABS[key]
+
+
+def resize_area(images_u8: torch.Tensor, out_h: int, out_w: int, dtype: torch.dtype = torch.float16) -> torch.Tensor:
+    """[n,H,W,3] u8 (device) -> cv2.resize(.., (out_w,out_h), INTER_AREA) -> CHW -> /255: [n,3,out_h,out_w]."""
+    assert images_u8.is_cuda and images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.shape[-1] == 3
+    images_u8 = images_u8.contiguous()
+    n, H, W, _ = images_u8.shape
+    dev = images_u8.device
+    xf, xc, xw, xk = _area_tab(dev, W, out_w)
+    yf, yc, yw, yk = _area_tab(dev, H, out_h)
+    out = torch.empty((n, 3, out_h, out_w), dtype=dtype, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().vlfm_resize_area_batched(images_u8.data_ptr(), n, H, W, out_h, out_w, xf.data_ptr(),
+                                                      xc.data_ptr(), xw.data_ptr(), xk, yf.data_ptr(), yc.data_ptr(),
+                                                      yw.data_ptr(), yk, out.data_ptr(),
+                                                      {torch.float32: 0, torch.float16: 1}[dtype], _stream()),
+                   "resize_area")
+    return out
+
+
+def to_tensor_normalize(images_u8: torch.Tensor, mean=IMAGENET_MEAN, std=IMAGENET_STD) -> torch.Tensor:
+    """[n,H,W,3] u8 (device) -> torchvision to_tensor + normalize -> [n,3,H,W] f32."""
+    assert images_u8.is_cuda and images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.shape[-1] == 3
+    images_u8 = images_u8.contiguous()
+    n, H, W, _ = images_u8.shape
+    out = torch.empty((n, 3, H, W), dtype=torch.float32, device=images_u8.device)
+    m, s = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+    with torch.cuda.device(images_u8.device):
+        _lib.check(_lib.lib().vlfm_to_tensor_normalize_batched(images_u8.data_ptr(), n, H, W, ctypes.addressof(m),
+                                                              ctypes.addressof(s), out.data_ptr(), _stream()),
+                   "to_tensor_normalize")
+    return out
+
+
+def nms(boxes_xyxy: torch.Tensor, scores: torch.Tensor, iou_threshold: float, max_keep: Optional[int] = None) -> torch.Tensor:
+    """torchvision.ops.nms: indices of the kept boxes, by descending score.  Device-resident result (int64)."""
+    assert boxes_xyxy.is_cuda and boxes_xyxy.dtype == torch.float32 and boxes_xyxy.shape[-1] == 4
+    n = boxes_xyxy.shape[0]
+    dev = boxes_xyxy.device
+    if n == 0:
+        return torch.zeros(0, dtype=torch.int64, device=dev)
+    boxes_xyxy = boxes_xyxy.contiguous()
+    order = torch.sort(scores, descending=True).indices.to(torch.int32).contiguous()
+    max_keep = n if max_keep is None else min(max_keep, n)
+    scratch = torch.empty(_lib.lib().vlfm_nms_scratch_bytes(n), dtype=torch.uint8, device=dev)
+    keep = torch.empty(max_keep, dtype=torch.int32, device=dev)
+    num = torch.zeros(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().vlfm_nms(boxes_xyxy.data_ptr(), order.data_ptr(), n, float(iou_threshold),
+                                      scratch.data_ptr(), scratch.numel(), keep.data_ptr(), num.data_ptr(), max_keep,
+                                      _stream()), "nms")
+    return keep[: int(num.item())].to(torch.int64)
+
+
+def xywh2xyxy(x: torch.Tensor) -> torch.Tensor:
+    y = x.clone()
+    y[..., 0] = x[..., 0] - x[..., 2] / 2
+    y[..., 1] = x[..., 1] - x[..., 3] / 2
+    y[..., 2] = x[..., 0] + x[..., 2] / 2
+    y[..., 3] = x[..., 1] + x[..., 3] / 2
+    return y
+
+
+def non_max_suppression(prediction: torch.Tensor, conf_thres: float = 0.25, iou_thres: float = 0.45,
+                        classes: Optional[Sequence[int]] = None, agnostic: bool = False,
+                        nms_fn=nms) -> List[torch.Tensor]:
+    """yolov7 utils.general.non_max_suppression [ext] as the reference calls it (yolov7.py:91-97: multi_label off,
+    no labels): per image an (k,6) tensor (x1, y1, x2, y2, conf, cls).  ``nms_fn`` is the HIP NMS on the GPU."""
+    nc = prediction.shape[2] - 5
+    xc = prediction[..., 4] > conf_thres
+    max_wh, max_det, max_nms = 4096, 300, 30000
+    out = [torch.zeros((0, 6), device=prediction.device)] * prediction.shape[0]
+    for xi, x in enumerate(prediction):
+        x = x[xc[xi]]
+        if not x.shape[0]:
+            continue
+        x = x.clone()
+        if nc == 1:
+            x[:, 5:] = x[:, 4:5]
+        else:
+            x[:, 5:] *= x[:, 4:5]  # conf = obj_conf * cls_conf
+        box = xywh2xyxy(x[:, :4])
+        conf, j = x[:, 5:].max(1, keepdim=True)
+        x = torch.cat((box, conf, j.float()), 1)[conf.view(-1) > conf_thres]
+        if classes is not None:
+            x = x[(x[:, 5:6] == torch.tensor(classes, device=x.device)).any(1)]
+        n = x.shape[0]
+        if not n:
+            continue
+        if n > max_nms:
+            x = x[x[:, 4].argsort(descending=True)[:max_nms]]
+        c = x[:, 5:6] * (0 if agnostic else max_wh)  # class offset trick
+        i = nms_fn((x[:, :4] + c).float(), x[:, 4].float(), iou_thres, max_det)
+        out[xi] = x[i]
+    return out
+
+
+def scale_coords(img1_shape, coords: torch.Tensor, img0_shape) -> torch.Tensor:
+    """yolov7 utils.general.scale_coords [ext] + clip_coords."""
+    gain = min(img1_shape[0] / img0_shape[0], img1_shape[1] / img0_shape[1])
+    pad = (img1_shape[1] - img0_shape[1] * gain) / 2, (img1_shape[0] - img0_shape[0] * gain) / 2
+    coords[:, [0, 2]] -= pad[0]
+    coords[:, [1, 3]] -= pad[1]
+    coords[:, :4] /= gain
+    coords[:, 0].clamp_(0, img0_shape[1])
+    coords[:, 1].clamp_(0, img0_shape[0])
+    coords[:, 2].clamp_(0, img0_shape[1])
+    coords[:, 3].clamp_(0, img0_shape[0])
+    return coords

@@ -1,0 +1,146 @@
+"""vlfm.vlm.grounding_dino, MI355X in-process (reference: /root/reference/vlfm/vlm/grounding_dino.py:22-85).
+
+``GroundingDINO.predict(image, caption)`` keeps the reference's pipeline: to_tensor + ImageNet normalise at NATIVE resolution
+(no resize, :52-54) -> model -> ``predict()`` post-processing of the un-vendored groundingdino package [ext] (caption
+lower-cased and forced to end with "."; per query the sigmoid maximum over text tokens must exceed ``box_threshold``;
+phrase = the tokens whose probability exceeds ``text_threshold``) -> ``ObjectDetections`` (cxcywh -> xyxy) -> keep only
+phrases that exactly match a class of the caption (:70-72).
+
+Network: HF ``GroundingDinoForObjectDetection`` at the Swin-T / BERT-base geometry of ``groundingdino_swint_ogc`` (172 M
+parameters) on PyTorch-ROCm; its deformable attention runs through the pure-PyTorch sampling path (the reference's CUDA
+extension has no ROCm build).  Pretrained weights are not available offline: ``model_dir`` (or
+``GROUNDING_DINO_MODEL_DIR``) loads an HF checkpoint + tokenizer, otherwise weights are random-init and a deterministic
+word-level tokenizer stands in (special ids 101/102/1012 kept so that the model's phrase-block attention masks form)."""
+from __future__ import annotations
+
+import os
+import re
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import det_ops
+from .detections import ObjectDetections
+
+CLASSES = "chair . person . dog ."  # grounding_dino.py:19
+
+
+class WordTokenizer:
+    """Stand-in for BertTokenizer when no vocabulary is on disk: words hash into the vocabulary, "." -> 1012,
+    [CLS]/[SEP] = 101/102; ``decode`` maps ids back to the words seen so far."""
+
+    def __init__(self, vocab_size: int = 30522, max_len: int = 256) -> None:
+        self.vocab_size, self.max_len = vocab_size, max_len
+        self._words: Dict[int, str] = {101: "[CLS]", 102: "[SEP]", 1012: "."}
+
+    def _id(self, w: str) -> int:
+        if w == ".":
+            return 1012
+        h = 2166136261
+        for ch in w.encode():
+            h = ((h ^ ch) * 16777619) & 0xFFFFFFFF
+        i = 2000 + h % (self.vocab_size - 2000)
+        self._words[i] = w
+        return i
+
+    def __call__(self, text: str) -> List[int]:
+        toks = re.findall(r"[a-z0-9]+|[^\sa-z0-9]", text.lower())
+        return ([101] + [self._id(t) for t in toks][: self.max_len - 2] + [102])
+
+    def decode(self, ids: Sequence[int]) -> str:
+        return " ".join(self._words.get(int(i), "[UNK]") for i in ids)
+
+
+def preprocess_caption(caption: str) -> str:
+    """groundingdino.util.inference.preprocess_caption [ext]."""
+    result = caption.lower().strip()
+    return result if result.endswith(".") else result + "."
+
+
+class GroundingDINO:
+    def __init__(self, config_path: Optional[str] = None, weights_path: Optional[str] = None, caption: str = CLASSES,
+                 box_threshold: float = 0.35, text_threshold: float = 0.25, device=None, model_dir: Optional[str] = None,
+                 hf_config=None, seed: int = 0) -> None:
+        from transformers import GroundingDinoConfig, GroundingDinoForObjectDetection
+
+        from ..mapping.base_map import require_gpu
+
+        self.device = require_gpu(device)
+        self.caption, self.box_threshold, self.text_threshold = caption, box_threshold, text_threshold
+        model_dir = model_dir or os.environ.get("GROUNDING_DINO_MODEL_DIR")
+        if model_dir:
+            from transformers import AutoTokenizer
+
+            self.model = GroundingDinoForObjectDetection.from_pretrained(model_dir)
+            tok = AutoTokenizer.from_pretrained(model_dir)
+            self.tokenizer = lambda t: tok(t)["input_ids"]
+            self.decode = tok.decode
+            self.weights = f"pretrained:{model_dir}"
+        else:
+            torch.manual_seed(seed)
+            cfg = hf_config or GroundingDinoConfig()
+            self.model = GroundingDinoForObjectDetection(cfg)
+            wt = WordTokenizer(cfg.text_config.vocab_size, cfg.max_text_len)
+            self.tokenizer, self.decode = wt, wt.decode
+            self.weights = "random-init"
+        self.model.eval().to(self.device)
+
+    @torch.inference_mode()
+    def predict_batch(self, images_u8: torch.Tensor, captions: Sequence[str]) -> List[ObjectDetections]:
+        """images_u8 [B,H,W,3] u8 RGB on device; one caption per image (or a single shared caption)."""
+        B = images_u8.shape[0]
+        raw = list(captions) if len(captions) == B else list(captions) * B
+        caps = [preprocess_caption(c) for c in raw]
+        ids = [self.tokenizer(c) for c in caps]
+        L = max(len(i) for i in ids)
+        input_ids = torch.zeros((B, L), dtype=torch.long)
+        mask = torch.zeros((B, L), dtype=torch.long)
+        for b, i in enumerate(ids):
+            input_ids[b, : len(i)] = torch.tensor(i)
+            mask[b, : len(i)] = 1
+        pix = det_ops.to_tensor_normalize(images_u8)
+        out = self.model(pixel_values=pix, input_ids=input_ids.to(self.device), attention_mask=mask.to(self.device),
+                         token_type_ids=torch.zeros_like(input_ids).to(self.device))
+        probs = out.logits.sigmoid().float().cpu()     # [B, nq, max_text_len]
+        boxes = out.pred_boxes.float().cpu()            # [B, nq, 4] normalised cxcywh
+        dets = []
+        for b in range(B):
+            keep = probs[b].max(dim=1)[0] > self.box_threshold
+            logit, box = probs[b][keep], boxes[b][keep]
+            phrases = []
+            for row in logit:
+                pos = row[: len(ids[b])] > self.text_threshold
+                pos[0] = False          # [CLS]
+                pos[len(ids[b]) - 1:] = False  # [SEP] and beyond (get_phrases_from_posmap [ext])
+                toks = [ids[b][k] for k in torch.nonzero(pos).flatten().tolist()]
+                phrases.append(self.decode(toks).replace(".", "").strip())
+            det = ObjectDetections(box, logit.max(dim=1)[0] if len(logit) else torch.zeros(0), phrases, image_source=None)
+            # grounding_dino.py:70-72, literally (assumes the caller's caption ends with " ." -- SURVEY.md App. C9)
+            det.filter_by_class(raw[b][: -len(" .")].split(" . "))
+            dets.append(det)
+        return dets
+
+    def predict(self, image: np.ndarray, caption: Optional[str] = None) -> ObjectDetections:
+        caption_to_use = self.caption if caption is None else caption
+        img = torch.from_numpy(np.ascontiguousarray(image)).to(self.device)[None]
+        det = self.predict_batch(img, [caption_to_use])[0]
+        det.image_source = image
+        return det
+
+
+class GroundingDINOClient:
+    """grounding_dino.py:77-85; ``port`` accepted and ignored (the model lives in this process)."""
+
+    _shared: Dict[str, GroundingDINO] = {}
+
+    def __init__(self, port: int = 12181, device=None, **model_kwargs) -> None:
+        key = str(device)
+        if key not in GroundingDINOClient._shared:
+            GroundingDINOClient._shared[key] = GroundingDINO(device=device, **model_kwargs)
+        self._model = GroundingDINOClient._shared[key]
+        self.url = f"inprocess://gdino (port {port} ignored)"
+
+    def predict(self, image_numpy: np.ndarray, caption: Optional[str] = "") -> ObjectDetections:
+        det = self._model.predict(image_numpy, caption=caption)
+        return ObjectDetections.from_json(det.to_json(), image_source=image_numpy)

@@ -20,21 +20,22 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-def resample_coeffs(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarray, int]:
-    """Pillow bicubic taps for one axis (host): bounds [out,2] int32, kk [out,ksize] int32, ksize."""
+def resample_coeffs(in_size: int, out_size: int, bilinear: bool = False) -> Tuple[np.ndarray, np.ndarray, int]:
+    """Pillow bicubic (or bilinear) taps for one axis (host): bounds [out,2] int32, kk [out,ksize] int32, ksize."""
     bounds = np.zeros((out_size, 2), np.int32)
     cap = out_size * (2 * int(np.ceil(2.0 * max(1.0, in_size / out_size))) + 1)
     kk = np.zeros(cap, np.int32)
     ks = ctypes.c_int(0)
-    _lib.check(_lib.lib().vlfm_resample_coeffs_host(in_size, out_size, bounds.ctypes.data, kk.ctypes.data, cap,
-                                                    ctypes.byref(ks)), "resample_coeffs_host")
+    _lib.check(_lib.lib().vlfm_resample_coeffs_filter_host(in_size, out_size, int(bilinear), bounds.ctypes.data,
+                                                           kk.ctypes.data, cap, ctypes.byref(ks)),
+               "resample_coeffs_host")
     return bounds, kk[: out_size * ks.value].reshape(out_size, ks.value), ks.value
 
 
-def _device_coeffs(device, in_size: int, out_size: int):
-    key = (str(device), in_size, out_size)
+def _device_coeffs(device, in_size: int, out_size: int, bilinear: bool = False):
+    key = (str(device), in_size, out_size, bilinear)
     if key not in _coeff_cache:
-        b, k, ks = resample_coeffs(in_size, out_size)
+        b, k, ks = resample_coeffs(in_size, out_size, bilinear)
         _coeff_cache[key] = (torch.from_numpy(b).to(device), torch.from_numpy(np.ascontiguousarray(k)).to(device), ks)
     return _coeff_cache[key]
 
@@ -81,3 +82,34 @@ def itc_head(query_feats: torch.Tensor, proj_t: torch.Tensor, proj_bias: torch.T
         _lib.check(_lib.lib().vlfm_itc_head_batched(proj.data_ptr(), B, NQ, P, text_feats.data_ptr(), out.data_ptr(),
                                                    _stream()), "itc_head")
     return out
+
+
+SAM_MEAN = (123.675, 116.28, 103.53)   # Sam.pixel_mean / pixel_std [ext segment_anything / mobile_sam build_sam]
+SAM_STD = (58.395, 57.12, 57.375)
+
+
+def sam_target_size(h: int, w: int, long_side: int = 1024) -> Tuple[int, int]:
+    """ResizeLongestSide.get_preprocess_shape [ext]."""
+    scale = long_side * 1.0 / max(h, w)
+    return int(h * scale + 0.5), int(w * scale + 0.5)
+
+
+def preprocess_sam(images_u8: torch.Tensor, long_side: int = 1024) -> Tuple[torch.Tensor, Tuple[int, int]]:
+    """[n,H,W,3] u8 (device) -> SamPredictor.set_image's network input [n,3,1024,1024] f32 (PIL BILINEAR resize of the
+    longest side to 1024, (x-mean)/std, zero pad) and the resized (h, w)."""
+    assert images_u8.is_cuda and images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.shape[-1] == 3
+    images_u8 = images_u8.contiguous()
+    n, H, W, _ = images_u8.shape
+    oh, ow = sam_target_size(H, W, long_side)
+    dev = images_u8.device
+    hb, hk, hks = _device_coeffs(dev, W, ow, True)
+    vb, vk, vks = _device_coeffs(dev, H, oh, True)
+    tmp = torch.empty((n, H, ow, 3), dtype=torch.uint8, device=dev)
+    out = torch.empty((n, 3, long_side, long_side), dtype=torch.float32, device=dev)
+    m, s = (ctypes.c_float * 3)(*SAM_MEAN), (ctypes.c_float * 3)(*SAM_STD)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().vlfm_preprocess_sam_batched(images_u8.data_ptr(), n, H, W, oh, ow, hb.data_ptr(),
+                                                         hk.data_ptr(), hks, vb.data_ptr(), vk.data_ptr(), vks,
+                                                         ctypes.addressof(m), ctypes.addressof(s), long_side,
+                                                         tmp.data_ptr(), out.data_ptr(), _stream()), "preprocess_sam")
+    return out, (oh, ow)

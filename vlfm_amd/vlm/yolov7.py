@@ -1,0 +1,184 @@
+"""vlfm.vlm.yolov7, MI355X in-process (reference: /root/reference/vlfm/vlm/yolov7.py:28-121).
+
+``YOLOv7.predict(image)`` keeps the reference's pipeline -- cv2.resize to (640, 448) INTER_AREA, letterbox (a no-op at that
+size), CHW, fp16, /255, model, non_max_suppression(0.25, 0.45), scale_coords + round, normalise by the ORIGINAL width and
+height -- with the preprocessing and the NMS as HIP kernels (csrc/detect_ops.hip) and everything batched over the resident
+environments (``predict_batch``).  ``YOLOv7Client`` keeps the client signature; the model lives in this process.
+
+Network: the reference loads the pretrained ``yolov7-e6e.pt`` through the un-vendored yolov7 repository [ext]; neither
+exists offline.  ``weights`` may name a TorchScript export of that model (what the reference's TracedModel produces); without
+it a random-init detector of the same I/O contract and the same head geometry (strides 8/16/32/64, 3 anchors each, 85
+channels -> 17 850 candidates at 448x640) stands in, so that throughput is measured on an E6E-class convolutional load."""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import det_ops
+from .coco_classes import COCO_CLASSES
+from .detections import ObjectDetections
+
+
+def _conv(c1: int, c2: int, k: int = 1, s: int = 1) -> nn.Sequential:
+    return nn.Sequential(nn.Conv2d(c1, c2, k, s, k // 2, bias=False), nn.BatchNorm2d(c2), nn.SiLU(inplace=True))
+
+
+class _Elan(nn.Module):
+    """ELAN-style aggregation block (two 1x1 branches, a chain of 3x3 convs, concat, 1x1 fuse)."""
+
+    def __init__(self, c1: int, c2: int, depth: int = 6):
+        super().__init__()
+        h = c2 // 4
+        self.a, self.b = _conv(c1, h), _conv(c1, h)
+        self.chain = nn.ModuleList([_conv(h, h, 3) for _ in range(depth)])
+        self.fuse = _conv(h * (2 + depth // 2), c2)
+
+    def forward(self, x):
+        outs = [self.a(x), self.b(x)]
+        y = outs[-1]
+        for i, m in enumerate(self.chain):
+            y = m(y)
+            if i % 2 == 1:
+                outs.append(y)
+        return self.fuse(torch.cat(outs, 1))
+
+
+class _Down(nn.Module):
+    """DownC: max-pool + 1x1 branch beside a strided 3x3 branch."""
+
+    def __init__(self, c1: int, c2: int):
+        super().__init__()
+        self.p = nn.Sequential(nn.MaxPool2d(2, 2), _conv(c1, c2 // 2))
+        self.c = nn.Sequential(_conv(c1, c1), _conv(c1, c2 // 2, 3, 2))
+
+    def forward(self, x):
+        return torch.cat((self.c(x), self.p(x)), 1)
+
+
+class YoloV7E6EClassNet(nn.Module):
+    """E6E-class detector: ReOrg stem, five Down+ELAN stages (80..1280 channels), SPP neck, top-down/bottom-up fusion and an
+    anchor head on four levels (strides 8, 16, 32, 64).  Output [B, sum(3*h*w), 5 + nc] in input pixels, like the inference
+    output of yolov7's IDetect."""
+
+    ANCHORS = [[19, 27, 44, 40, 38, 94], [96, 68, 86, 152, 180, 137], [140, 301, 303, 264, 238, 542],
+               [436, 615, 739, 380, 925, 792]]
+    STRIDES = [8, 16, 32, 64]
+
+    def __init__(self, nc: int = 80, width: int = 80):
+        super().__init__()
+        w = width
+        self.nc = nc
+        self.stem = _conv(12, w, 3)
+        chans = [w * 2, w * 4, w * 8, w * 12, w * 16]
+        self.down = nn.ModuleList([_Down(c1, c2) for c1, c2 in zip([w] + chans[:-1], chans)])
+        self.elan = nn.ModuleList([_Elan(c, c) for c in chans])
+        self.spp = nn.Sequential(_conv(chans[4], chans[4] // 2), nn.MaxPool2d(5, 1, 2), _conv(chans[4] // 2, chans[4] // 2))
+        head_c = [chans[1] // 2, chans[2] // 2, chans[3] // 2, chans[4] // 2]  # P3..P6
+        self.lat = nn.ModuleList([_conv(chans[i + 1], head_c[i]) for i in range(3)])
+        self.td = nn.ModuleList([_Elan(head_c[i] + head_c[i + 1], head_c[i], 4) for i in range(3)])
+        self.bu_down = nn.ModuleList([_conv(head_c[i], head_c[i + 1], 3, 2) for i in range(3)])
+        self.bu = nn.ModuleList([_Elan(2 * head_c[i + 1], head_c[i + 1], 4) for i in range(3)])
+        self.detect = nn.ModuleList([nn.Conv2d(c, 3 * (5 + nc), 1) for c in head_c])
+        self.register_buffer("anchors", torch.tensor(self.ANCHORS, dtype=torch.float32).view(4, 3, 2))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        b = x.shape[0]
+        x = torch.cat([x[..., ::2, ::2], x[..., 1::2, ::2], x[..., ::2, 1::2], x[..., 1::2, 1::2]], 1)  # ReOrg
+        x = self.stem(x)
+        feats = []
+        for d, e in zip(self.down, self.elan):
+            x = e(d(x))
+            feats.append(x)
+        p = [None, None, None, self.spp(feats[4])]
+        for i in (2, 1, 0):  # top-down
+            up = nn.functional.interpolate(p[i + 1], size=feats[i + 1].shape[-2:], mode="nearest")
+            p[i] = self.td[i](torch.cat((self.lat[i](feats[i + 1]), up), 1))
+        for i in range(3):   # bottom-up
+            p[i + 1] = self.bu[i](torch.cat((self.bu_down[i](p[i]), p[i + 1]), 1))
+        z = []
+        for i, f in enumerate(p):
+            y = self.detect[i](f)
+            _, _, ny, nx = y.shape
+            y = y.view(b, 3, 5 + self.nc, ny, nx).permute(0, 1, 3, 4, 2).sigmoid()
+            gy, gx = torch.meshgrid(torch.arange(ny, device=y.device), torch.arange(nx, device=y.device), indexing="ij")
+            grid = torch.stack((gx, gy), -1).view(1, 1, ny, nx, 2).to(y.dtype)
+            xy = (y[..., 0:2] * 2.0 - 0.5 + grid) * self.STRIDES[i]
+            wh = (y[..., 2:4] * 2) ** 2 * self.anchors[i].view(1, 3, 1, 1, 2).to(y.dtype)
+            z.append(torch.cat((xy, wh, y[..., 4:]), -1).view(b, -1, 5 + self.nc))
+        return torch.cat(z, 1)
+
+
+class YOLOv7:
+    """yolov7.py:28-110 (+ ``predict_batch`` for the batched harness)."""
+
+    def __init__(self, weights: Optional[str] = None, image_size: int = 640, half_precision: bool = True, device=None,
+                 width: int = 80) -> None:
+        from ..mapping.base_map import require_gpu
+
+        self.device = require_gpu(device)
+        self.half_precision = half_precision
+        self.image_size = image_size
+        weights = weights or os.environ.get("YOLOV7_TORCHSCRIPT")
+        if weights and os.path.exists(weights):
+            self.model = torch.jit.load(weights, map_location=self.device).eval()
+            self.weights = f"torchscript:{weights}"
+        else:
+            with torch.device(self.device):
+                self.model = YoloV7E6EClassNet(width=width)
+            self.model.eval()
+            self.weights = "random-init (E6E-class stand-in)"
+        if self.half_precision:
+            self.model.half()
+        self.in_hw = (int(self.image_size * 0.7), self.image_size)  # (448, 640) (yolov7.py:73)
+
+    @torch.inference_mode()
+    def predict_batch(self, images_u8: torch.Tensor, conf_thres: float = 0.25, iou_thres: float = 0.45,
+                      classes: Optional[Sequence[int]] = None, agnostic_nms: bool = False) -> List[ObjectDetections]:
+        """images_u8 [B,H,W,3] u8 RGB on device -> one ObjectDetections per image (boxes normalised xyxy)."""
+        B, H, W, _ = images_u8.shape
+        img = det_ops.resize_area(images_u8, self.in_hw[0], self.in_hw[1],
+                                  torch.float16 if self.half_precision else torch.float32)
+        pred = self.model(img)
+        pred = pred[0] if isinstance(pred, (tuple, list)) else pred
+        dets = det_ops.non_max_suppression(pred.float(), conf_thres, iou_thres, classes=classes, agnostic=agnostic_nms)
+        out = []
+        for b, p in enumerate(dets):
+            p = p.clone()
+            if p.shape[0]:
+                p[:, :4] = det_ops.scale_coords(self.in_hw, p[:, :4], (H, W, 3)).round()
+                p[:, 0] /= W
+                p[:, 1] /= H
+                p[:, 2] /= W
+                p[:, 3] /= H
+            p = p.cpu()
+            phrases = [COCO_CLASSES[int(i)] for i in p[:, 5]]
+            out.append(ObjectDetections(p[:, :4], p[:, 4], phrases, image_source=None, fmt="xyxy"))
+        return out
+
+    def predict(self, image: np.ndarray, conf_thres: float = 0.25, iou_thres: float = 0.45,
+                classes: Optional[List[str]] = None, agnostic_nms: bool = False) -> ObjectDetections:
+        img = torch.from_numpy(np.ascontiguousarray(image)).to(self.device)[None]
+        det = self.predict_batch(img, conf_thres, iou_thres, classes, agnostic_nms)[0]
+        det.image_source = image
+        return det
+
+
+class YOLOv7Client:
+    """yolov7.py:113-121: ``predict(image_numpy) -> ObjectDetections``; ``port`` is accepted and ignored (in-process)."""
+
+    _shared: Dict[str, YOLOv7] = {}
+
+    def __init__(self, port: int = 12184, device=None, **model_kwargs) -> None:
+        key = str(device)
+        if key not in YOLOv7Client._shared:
+            YOLOv7Client._shared[key] = YOLOv7(device=device, **model_kwargs)
+        self._model = YOLOv7Client._shared[key]
+        self.url = f"inprocess://yolov7 (port {port} ignored)"
+
+    def predict(self, image_numpy: np.ndarray) -> ObjectDetections:
+        # the reference round-trips through JSON (yolov7.py:117-119): float32 tensors rebuilt from Python lists
+        return ObjectDetections.from_json(self._model.predict(image_numpy).to_json(), image_source=image_numpy)
