@@ -68,8 +68,32 @@ def install() -> None:
     pkg.frontier_detection, pkg.utils, utils.fog_of_war = det, utils, fow
     sys.modules.update({"frontier_exploration": pkg, "frontier_exploration.frontier_detection": det,
                         "frontier_exploration.utils": utils, "frontier_exploration.utils.fog_of_war": fow})
+    # torchvision (==0.13.1 in the reference) is absent: only ops.box_convert is touched at import/use time by
+    # vlfm/vlm/detections.py:10,31.  Stand-in = torchvision's published formula, written independently of the product's.
+    import torch
+
+    def _box_convert(boxes, in_fmt, out_fmt):
+        assert in_fmt == "cxcywh" and out_fmt == "xyxy"
+        cx, cy, w, h = boxes.unbind(-1)
+        return torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], dim=-1)
+
+    tv = types.ModuleType("torchvision")
+    tv.__path__ = []
+    tv_ops = types.ModuleType("torchvision.ops")
+    tv_ops.box_convert = _box_convert
+    tv.ops = tv_ops
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.ops", tv_ops)
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
+
+
+def reference_detections():
+    """vlfm.vlm.detections of the real reference (needs cv2 + torchvision.ops stand-ins only)."""
+    install()
+    import importlib
+
+    return importlib.import_module("vlfm.vlm.detections")
 
 
 def reference_modules():

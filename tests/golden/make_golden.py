@@ -179,6 +179,30 @@ def gen_helpers(geo, img, ref_vm):
                 placed=canvas)
 
 
+def gen_detections(det_mod):
+    """ObjectDetections of the reference (vlfm/vlm/detections.py:15-126): construction, both filters, JSON round trip."""
+    import torch
+
+    rng = np.random.Generator(np.random.PCG64(11))
+    boxes = torch.from_numpy(rng.uniform(0.05, 0.6, (12, 4)).astype(np.float32))
+    logits = torch.from_numpy(rng.uniform(0.1, 0.95, 12).astype(np.float32))
+    logits[3] = 0.8  # exactly on the threshold: kept by >=
+    names = ["chair", "bed", "potted plant", "tv"]
+    phrases = [names[i % 4] for i in range(12)]
+    d = det_mod.ObjectDetections(boxes, logits, list(phrases), image_source=None)
+    out = dict(in_boxes=boxes.numpy(), in_logits=logits.numpy(), in_phrase_idx=np.arange(12) % 4,
+               boxes_xyxy=d.boxes.numpy().copy())
+    d.filter_by_class(["chair", "tv", "sofa"])
+    out.update(after_class_boxes=d.boxes.numpy().copy(), after_class_phrases=np.array(d.phrases))
+    d.filter_by_conf(0.8)
+    j = d.to_json()
+    out.update(after_conf_boxes=np.array(j["boxes"], np.float64).reshape(-1, 4), after_conf_logits=np.array(j["logits"]),
+               after_conf_phrases=np.array(j["phrases"]), num=d.num_detections)
+    r = det_mod.ObjectDetections.from_json(j)
+    out.update(roundtrip_boxes=r.boxes.numpy().copy())
+    return out
+
+
 def generate():
     from oracle import ref_shim
 
@@ -190,6 +214,7 @@ def generate():
         out[name] = gen_obstacle_map(ref_om, *args)
     out[SYNC_CASE[0]] = gen_sync(ref_vm, ref_om, SYNC_CASE[1], SYNC_CASE[2])
     out["helpers"] = gen_helpers(geo, img, ref_vm)
+    out["detections"] = gen_detections(ref_shim.reference_detections())
     return out
 
 

@@ -82,3 +82,22 @@ def test_stand_in_networks_contracts():
     ids = tok(preprocess_caption("Chair . potted plant"))
     assert ids[0] == 101 and ids[-1] == 102 and ids.count(1012) == 2
     assert tok.decode(ids[1:2]) == "chair" and tok.decode(ids[3:5]) == "potted plant"
+
+
+def test_object_detections_match_reference_fixture():
+    """tests/golden/detections.npz was produced by the reference's own vlfm/vlm/detections.py."""
+    from golden_util import load
+
+    g = load("detections")
+    names = ["chair", "bed", "potted plant", "tv"]
+    d = ObjectDetections(torch.from_numpy(g["in_boxes"]), torch.from_numpy(g["in_logits"]),
+                         [names[i] for i in g["in_phrase_idx"]], image_source=None)
+    assert np.array_equal(d.boxes.numpy(), g["boxes_xyxy"])
+    d.filter_by_class(["chair", "tv", "sofa"])
+    assert np.array_equal(d.boxes.numpy(), g["after_class_boxes"]) and d.phrases == list(g["after_class_phrases"])
+    d.filter_by_conf(0.8)
+    j = d.to_json()
+    assert np.array_equal(np.array(j["boxes"], np.float64).reshape(-1, 4), g["after_conf_boxes"])
+    assert np.array_equal(np.array(j["logits"]), g["after_conf_logits"]) and j["phrases"] == list(g["after_conf_phrases"])
+    assert d.num_detections == int(g["num"])
+    assert np.array_equal(ObjectDetections.from_json(j).boxes.numpy(), g["roundtrip_boxes"])
