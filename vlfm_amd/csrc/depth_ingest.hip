@@ -55,6 +55,8 @@ struct IngestArgs {
 
 struct HeightBand {  // f32 shadow of the height test, widened by a safety margin
     float t8, t9, t10, t11, inv_fx, inv_fy, lo, hi;
+    float zmin, zmax;    // range of scaled depth: d in [0, 1] -> z in [offset, scale + offset]
+    float gx_lo, gx_hi;  // range over the image columns of  -t9 * (u - W/2) / fx
 };
 __device__ inline HeightBand make_band(const vlfm_ingest_params& p, int W, int H) {
     HeightBand b;
@@ -67,7 +69,25 @@ __device__ inline HeightBand make_band(const vlfm_ingest_params& p, int W, int H
     const float margin = 1e-4f * mag;
     b.lo = (float)p.min_height - margin;
     b.hi = (float)p.max_height + margin;
+    b.zmin = fminf(p.depth_offset, p.depth_offset + p.depth_scale);
+    b.zmax = fmaxf(p.depth_offset, p.depth_offset + p.depth_scale);
+    const float g0 = -b.t9 * (float)(0 - W / 2) * b.inv_fx, g1 = -b.t9 * (float)(W - 1 - W / 2) * b.inv_fx;
+    b.gx_lo = fminf(g0, g1); b.gx_hi = fmaxf(g0, g1);
     return b;
+}
+
+// Can ANY texel of image row v land in the (widened) height band?  Z = z * g(u, v) + t11 with
+// g = t8 - t9 (u - W/2)/fx - t10 (v - H/2)/fy; over the row g spans [g_lo, g_hi] and z spans [zmin, zmax] (depth is
+// normalised to [0, 1] by contract), so Z spans the hull of the four corner products.  Rows that cannot hit the band (sky,
+// ceiling: about half of a level camera's image) are never loaded by the scatter-only pass.  Conservative: an extra
+// 1e-3 * |terms| slack on top of the band's own margin.
+__device__ inline bool row_may_hit(const HeightBand& b, int v, int H) {
+    const float gv = b.t8 - b.t10 * (float)(v - H / 2) * b.inv_fy;
+    const float g_lo = gv + b.gx_lo, g_hi = gv + b.gx_hi;
+    const float c0 = b.zmin * g_lo, c1 = b.zmin * g_hi, c2 = b.zmax * g_lo, c3 = b.zmax * g_hi;
+    const float z_lo = fminf(fminf(c0, c1), fminf(c2, c3)) + b.t11, z_hi = fmaxf(fmaxf(c0, c1), fmaxf(c2, c3)) + b.t11;
+    const float slack = 1e-3f * (fabsf(z_lo) + fabsf(z_hi) + fabsf(b.t11) + 1.0f);
+    return !(z_hi + slack < b.lo || z_lo - slack > b.hi);  // NaN -> true
 }
 
 __device__ inline void scatter_point(const IngestArgs& a, const vlfm_ingest_params& p, const HeightBand& band,
@@ -136,8 +156,12 @@ __global__ __launch_bounds__(CG * RL) void depth_ingest_kernel(IngestArgs a) {
     const int obs = blockIdx.z;
     const int cx = threadIdx.x % CG, ry = threadIdx.x / CG;
     const int col4 = blockIdx.x * CG + cx;
-    const int r_begin = blockIdx.y * a.rows_per_block;
-    const int r_end = min(r_begin + a.rows_per_block, a.H);
+    // Row bands are INTERLEAVED: band b owns the 16-row groups b, b + bands, b + 2 bands, ...  The texels that reach the
+    // expensive f64 placement sit in a few adjacent image rows; contiguous bands would hand all of them to a fraction of
+    // the workgroups (wave divergence makes that path the critical one: a wavefront pays for it if any lane needs it).
+    const int bands = gridDim.y, band_id = blockIdx.y;
+    const int n_groups = (a.H + RL - 1) / RL;
+    const int r_end = a.H;
     const bool live = col4 < a.W4;
     const vlfm_ingest_params p = a.prm[obs];
     const HeightBand band = make_band(p, a.W, a.H);
@@ -149,21 +173,25 @@ __global__ __launch_bounds__(CG * RL) void depth_ingest_kernel(IngestArgs a) {
     const float ninf = -__builtin_huge_valf();
     float4 m = make_float4(ninf, ninf, ninf, ninf);
     bool saw_zero = false;
+    const bool scatter_only = a.colmax_keys == nullptr && holes == nullptr;  // the pass after fill_small_holes
     constexpr int UNROLL = 4;
     // every lane of the workgroup runs the same trip count (predicated), so the cross-lane packing of hole bits below is
     // always executed convergently
-    for (int base = r_begin; base < r_end; base += UNROLL * RL) {
+    for (int g0 = band_id; g0 < n_groups; g0 += UNROLL * bands) {
         float4 d[UNROLL];
+        bool rowok[UNROLL];
 #pragma unroll
         for (int k = 0; k < UNROLL; k++) {
-            const int r = base + ry + k * RL;
-            d[k] = (live && r < r_end) ? reinterpret_cast<const float4*>(img + (size_t)r * a.W)[col4]
-                                       : make_float4(ninf, ninf, ninf, ninf);
+            const int r = (g0 + k * bands) * RL + ry;
+            bool want = live && r < r_end;
+            if (SCATTER && scatter_only) want = want && row_may_hit(band, r, a.H);
+            rowok[k] = want;
+            d[k] = want ? reinterpret_cast<const float4*>(img + (size_t)r * a.W)[col4] : make_float4(ninf, ninf, ninf, ninf);
         }
 #pragma unroll
         for (int k = 0; k < UNROLL; k++) {
-            const int r = base + ry + k * RL;
-            const bool ok = live && r < r_end;
+            const int r = (g0 + k * bands) * RL + ry;
+            const bool ok = rowok[k];
             m.x = fmaxf(m.x, d[k].x); m.y = fmaxf(m.y, d[k].y); m.z = fmaxf(m.z, d[k].z); m.w = fmaxf(m.w, d[k].w);
             if (holes) {
                 // (depth == 0) bit plane: 4 texels per lane, 8 neighbouring lanes (same row) per 32-bit word.  Four
@@ -238,8 +266,8 @@ extern "C" int vlfm_depth_ingest_batched(const float* d_depth, int n, int height
     const int max_bands = (height + RL - 1) / RL;
     if (bands > max_bands) bands = max_bands;
     if (bands < 1) bands = 1;
-    a.rows_per_block = (height + bands - 1) / bands;
-    const int gy = (height + a.rows_per_block - 1) / a.rows_per_block;
+    a.rows_per_block = (height + bands - 1) / bands;  // informational: rows per workgroup (interleaved in 16-row groups)
+    const int gy = bands;
     if (d_obstacle) {
         // profile name: the streaming pass (column maxima [+ hole bits]) is "depth_ingest_kernel"; a pass that ALSO or
         // ONLY scatters obstacle points is reported separately
