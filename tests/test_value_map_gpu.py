@@ -165,3 +165,32 @@ def test_hd_depth_1280x720(gpu_device):
         ours.update_map(values, depth, tf, MIN_DEPTH, MAX_DEPTH, _fov(1280))
         ref.update_map(values, depth.copy(), tf, MIN_DEPTH, MAX_DEPTH, _fov(1280))
     _compare(ours, ref)
+
+
+def test_record_and_replay_in_the_reference_format(gpu_device, tmp_path, monkeypatch):
+    """RECORD_VALUE_MAP / replay (value_map.py:26-30,77-94,130-144,448-475): 8-bit depth PNGs + data.json + kwargs.json.
+    A replay must rebuild the map the recording run would have built from the SAME quantised depth."""
+    import json
+
+    from oracle.ref_value_map import RefValueMap
+    from PIL import Image
+    from vlfm_amd.mapping import value_map as vm_mod
+
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(vm_mod, "RECORDING", True)
+    env = SyntheticEnv(11)
+    rec = vm_mod.ValueMap(1, use_max_confidence=False, device=gpu_device)
+    frames = [env.observe() for _ in range(5)]
+    for depth, tf, values in frames:
+        rec.update_map(values, depth, tf, MIN_DEPTH, MAX_DEPTH, _fov())
+    monkeypatch.setattr(vm_mod, "RECORDING", False)
+    data = json.load(open(tmp_path / "value_map_recordings" / "data.json"))
+    assert len(data) == 5 and json.load(open(tmp_path / "value_map_recordings" / "kwargs.json")) == {
+        "value_channels": 1, "size": 1000, "use_max_confidence": False}
+    replayed = vm_mod.replay_from_dir(device=gpu_device)
+    ref = RefValueMap(1, use_max_confidence=False)
+    for k, (depth, tf, values) in enumerate(frames):
+        png = np.asarray(Image.open(tmp_path / "value_map_recordings" / f"{k:04d}.png")).astype(np.float32) / 255.0
+        assert np.array_equal(png, (depth * 255).astype(np.uint8).astype(np.float32) / 255.0)
+        ref.update_map(values, png, tf, MIN_DEPTH, MAX_DEPTH, _fov())
+    _compare(replayed, ref)

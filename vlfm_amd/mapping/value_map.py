@@ -377,6 +377,14 @@ def _explored_bits_of(obstacle_map, device):
     return dst
 
 
+# value_map.py:26-30 -- the reference's record/replay switches and on-disk format (8-bit depth PNGs + data.json + kwargs.json)
+RECORDING = os.environ.get("RECORD_VALUE_MAP", "0") == "1"
+PLAYING = os.environ.get("PLAY_VALUE_MAP", "0") == "1"
+RECORDING_DIR = "value_map_recordings"
+JSON_PATH = os.path.join(RECORDING_DIR, "data.json")
+KWARGS_JSON = os.path.join(RECORDING_DIR, "kwargs.json")
+
+
 class ValueMap(BaseMap):
     """Drop-in for vlfm.mapping.value_map.ValueMap (same constructor and method signatures)."""
 
@@ -400,6 +408,19 @@ class ValueMap(BaseMap):
             _slot = 0
         self._batch, self._slot = _batch, _slot
         self._fusion_type = _batch.fusion_type
+        if RECORDING:  # value_map.py:77-94
+            import json
+            import shutil
+            import warnings
+
+            if os.path.isdir(RECORDING_DIR):
+                warnings.warn(f"Recording directory {RECORDING_DIR} already exists. Deleting it.")
+                shutil.rmtree(RECORDING_DIR)
+            os.mkdir(RECORDING_DIR)
+            with open(KWARGS_JSON, "w") as f:
+                json.dump({"value_channels": value_channels, "size": size, "use_max_confidence": use_max_confidence}, f)
+            with open(JSON_PATH, "w") as f:
+                f.write("{}")
 
     # maps are HBM-resident; these attributes are host snapshots for the callers that read them (visualisation)
     @property
@@ -431,6 +452,23 @@ class ValueMap(BaseMap):
             self._batch.explored_bits = _explored_bits_of(self._obstacle_map, self._batch.device)
         self._batch.update(np.asarray(values, np.float64)[None], depth, np.asarray(tf_camera_to_episodic)[None],
                            min_depth, max_depth, fov, env_ids=[self._slot])
+        if RECORDING:  # value_map.py:130-144 (cv2.imwrite of a single-channel u8 image == an 8-bit greyscale PNG)
+            import glob
+            import json
+
+            from PIL import Image
+
+            d = depth.cpu().numpy() if torch.is_tensor(depth) else np.asarray(depth)
+            idx = len(glob.glob(os.path.join(RECORDING_DIR, "*.png")))
+            img_path = os.path.join(RECORDING_DIR, f"{idx:04d}.png")
+            Image.fromarray((d.reshape(d.shape[-2], d.shape[-1]) * 255).astype(np.uint8)).save(img_path)
+            with open(JSON_PATH, "r") as f:
+                data = json.load(f)
+            data[img_path] = {"values": np.asarray(values).tolist(),
+                              "tf_camera_to_episodic": np.asarray(tf_camera_to_episodic).tolist(),
+                              "min_depth": min_depth, "max_depth": max_depth, "fov": fov}
+            with open(JSON_PATH, "w") as f:
+                json.dump(data, f)
 
     def sort_waypoints(self, waypoints: np.ndarray, radius: float,
                        reduce_fn: Optional[Callable] = None) -> Tuple[np.ndarray, List[float]]:
@@ -456,3 +494,33 @@ class ValueMap(BaseMap):
         rgb = np.stack([scaled] * 3, axis=-1)
         rgb[zero] = (255, 255, 255)
         return rgb
+
+
+def replay_from_dir(recording_dir: str = RECORDING_DIR, device=None) -> ValueMap:
+    """value_map.py:448-475 without the interactive window: rebuilds a ValueMap from a recording made by the reference
+    (or by this class) and returns it.  ``PLAY_VALUE_MAP=1 python -m vlfm_amd.mapping.value_map`` mirrors the reference's
+    entry point and writes ``value_map_replay.png``."""
+    import json
+
+    from PIL import Image
+
+    with open(os.path.join(recording_dir, "kwargs.json"), "r") as f:
+        kwargs = json.load(f)
+    with open(os.path.join(recording_dir, "data.json"), "r") as f:
+        data = json.load(f)
+    v = ValueMap(device=device, **kwargs)
+    for img_path in sorted(data.keys()):
+        rec = data[img_path]
+        path = img_path if os.path.exists(img_path) else os.path.join(recording_dir, os.path.basename(img_path))
+        depth = np.asarray(Image.open(path).convert("L")).astype(np.float32) / 255.0
+        v.update_map(np.array(rec["values"]), depth, np.array(rec["tf_camera_to_episodic"]), float(rec["min_depth"]),
+                     float(rec["max_depth"]), float(rec["fov"]))
+    return v
+
+
+if __name__ == "__main__":
+    if PLAYING:
+        from PIL import Image
+
+        Image.fromarray(replay_from_dir().visualize()).save("value_map_replay.png")
+        print("wrote value_map_replay.png")
