@@ -18,7 +18,9 @@ def world() -> Tuple[int, int, int]:
 
 
 def init(backend: str, device: torch.device | None = None) -> None:
-    if world()[2] > 1 and not dist.is_initialized():
+    # VLFM_FORCE_DIST=1 initialises the process group even for a single rank (smoke test of the RCCL path on a 1-GPU box)
+    force = os.environ.get("VLFM_FORCE_DIST") == "1" and "MASTER_PORT" in os.environ
+    if (world()[2] > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kw = {}
         if backend == "nccl" and device is not None:
@@ -42,7 +44,7 @@ def reduce_metrics(elapsed_s: float, sums: Sequence[float], device) -> Tuple[flo
     over ranks.  Two all-reduces of <= 64 bytes each: latency-bound, algorithm choice immaterial."""
     t = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
     v = torch.tensor(list(sums), dtype=torch.float64, device=device)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(v, op=dist.ReduceOp.SUM)
     return float(t.item()), [float(x) for x in v.tolist()]
@@ -51,7 +53,7 @@ def reduce_metrics(elapsed_s: float, sums: Sequence[float], device) -> Tuple[flo
 def barrier(device=None) -> None:
     if device is not None and torch.device(device).type == "cuda":
         torch.cuda.synchronize(device)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.barrier()
     if device is not None and torch.device(device).type == "cuda":
         torch.cuda.synchronize(device)
