@@ -245,6 +245,26 @@ int vlfm_nms(const float* d_boxes_xyxy, const int32_t* d_order, int n, float iou
              size_t scratch_bytes, int32_t* d_keep, int32_t* d_num_keep, int max_keep, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * ObjectPointCloudMap._extract_object_cloud (vlfm/mapping/object_point_cloud_map.py:150-170,186-212)
+ * ------------------------------------------------------------------------------------------- */
+
+/* cv2.erode(mask, None, iterations) -> valid_depth -> get_point_cloud over the eroded mask, in np.where order.
+ * d_depth [H][W] f32, d_mask [H][W] u8 (non-zero = object).  d_cloud [capacity][3] f64 (z, -x, -y); *d_count = number of
+ * masked pixels (may exceed capacity: only the first `capacity` are written).  d_scratch:
+ * vlfm_object_cloud_scratch_bytes(H, W). */
+size_t vlfm_object_cloud_scratch_bytes(int height, int width);
+int vlfm_object_cloud_extract(const float* d_depth, const uint8_t* d_mask, int height, int width, int erosion_iterations,
+                              double min_depth, double max_depth, double fx, double fy, void* d_scratch, double* d_cloud,
+                              int capacity, int32_t* d_count, void* stream);
+
+/* open3d cluster_dbscan(eps, min_points) + "largest non-noise cluster" (object_point_cloud_map.py:186-212) for n <= 8192
+ * f64 points.  d_labels [n] receives the cluster root index of every point (INT32_MAX = noise), d_keep the indices of the
+ * largest cluster in ascending order, d_num_keep their count (0 = only noise). */
+size_t vlfm_dbscan_scratch_bytes(int n);
+int vlfm_dbscan_largest_cluster(const double* d_points, int n, double eps, int min_points, void* d_scratch,
+                                size_t scratch_bytes, int32_t* d_labels, int32_t* d_keep, int32_t* d_num_keep, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * ObstacleMap planes are bit-packed: 1 bit per cell, row stride ceil(cols/32) u32 words, bit x&31 of word x>>5.
  * ------------------------------------------------------------------------------------------- */
 int vlfm_bits_pack(const uint8_t* d_src, uint32_t* d_dst, int planes, int rows, int cols, void* stream);

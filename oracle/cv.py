@@ -220,3 +220,21 @@ def isContourConvex(cnt) -> bool:
 
 def bitwise_and(a, b):
     return np.bitwise_and(a, b)
+
+
+def erode(src, kernel=None, iterations=1):
+    """cv2.erode with the default 3x3 rectangular element (kernel=None), border = morphologyDefaultBorderValue."""
+    assert kernel is None
+    from .ref_object_map import erode3x3
+
+    out = erode3x3(src, iterations)
+    return np.where(out > 0, np.asarray(src).max() if np.asarray(src).size else 0, 0).astype(np.asarray(src).dtype)
+
+
+def boundingRect(array):
+    """cv2.boundingRect of a mask image: bounding box of the non-zero pixels (x, y, w, h); all zeros -> (0, 0, 0, 0)."""
+    a = np.asarray(array)
+    ys, xs = np.nonzero(a)
+    if len(xs) == 0:
+        return (0, 0, 0, 0)
+    return (int(xs.min()), int(ys.min()), int(xs.max() - xs.min() + 1), int(ys.max() - ys.min() + 1))

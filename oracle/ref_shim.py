@@ -29,6 +29,8 @@ import os
 import sys
 import types
 
+import numpy as np
+
 REFERENCE_ROOT = "/root/reference"
 
 
@@ -48,7 +50,8 @@ def install() -> None:
     cv2 = types.ModuleType("cv2")
     cv2.__doc__ = "stand-in for opencv-python==4.5.5.64 backed by oracle/cvport.c (see oracle/ref_shim.py)"
     for name in ("ellipse", "drawContours", "circle", "polylines", "getRotationMatrix2D", "warpAffine", "dilate",
-                 "blur", "findContours", "contourArea", "pointPolygonTest", "isContourConvex", "bitwise_and",
+                 "blur", "findContours", "contourArea", "pointPolygonTest", "isContourConvex", "bitwise_and", "erode",
+                 "boundingRect",
                  "RETR_EXTERNAL", "RETR_LIST", "RETR_CCOMP", "RETR_TREE", "CHAIN_APPROX_NONE", "CHAIN_APPROX_SIMPLE"):
         setattr(cv2, name, getattr(facade, name))
     # constants that visualisation-only code paths name (never evaluated by the golden generator)
@@ -84,8 +87,29 @@ def install() -> None:
     tv.ops = tv_ops
     sys.modules.setdefault("torchvision", tv)
     sys.modules.setdefault("torchvision.ops", tv_ops)
+    # open3d (object_point_cloud_map.py:7,186-192): PointCloud.points / Vector3dVector / cluster_dbscan only
+    from . import ref_object_map as rom
+
+    class _PointCloud:
+        points = None
+
+        def cluster_dbscan(self, eps, min_points):
+            return rom.cluster_dbscan(np.asarray(self.points), eps, min_points).tolist()
+
+    o3d = types.ModuleType("open3d")
+    o3d.geometry = types.SimpleNamespace(PointCloud=_PointCloud)
+    o3d.utility = types.SimpleNamespace(Vector3dVector=lambda a: np.asarray(a))
+    sys.modules.setdefault("open3d", o3d)
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
+
+
+def reference_object_map():
+    """vlfm.mapping.object_point_cloud_map of the real reference (cv2.erode/boundingRect + open3d DBSCAN stand-ins)."""
+    install()
+    import importlib
+
+    return importlib.import_module("vlfm.mapping.object_point_cloud_map")
 
 
 def reference_detections():

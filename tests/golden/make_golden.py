@@ -203,6 +203,54 @@ def gen_detections(det_mod):
     return out
 
 
+def object_map_script():
+    """Seeded sequence of ObjectPointCloudMap calls shared by the generator and the replaying tests: (op, args) tuples."""
+    rng = np.random.Generator(np.random.PCG64(21))
+    from vlfm_amd.synthetic import depth_frame, pose_to_tf
+
+    H, W = 480, 640
+    yy, xx = np.mgrid[0:H, 0:W]
+    ops = []
+    blobs = [(320, 250, 60, 45, 0.0), (150, 300, 50, 70, 0.3), (30, 240, 25, 60, 0.6), (600, 260, 30, 50, 0.9),
+             (330, 260, 120, 90, 1.2), (320, 250, 8, 8, 1.5)]
+    for k, (cx, cy, ax, ay, yaw) in enumerate(blobs):
+        depth = depth_frame(rng, H, W)
+        depth[(xx - cx) ** 2 / (1.3 * ax) ** 2 + (yy - cy) ** 2 / (1.3 * ay) ** 2 <= 1] = 0.35 + 0.08 * k  # an object in front of the wall
+        if k == 1:
+            depth[cy - 5:cy + 5, cx - 5:cx + 5] = 0.0  # holes inside the mask -> "far"
+        mask = ((xx - cx) ** 2 / ax ** 2 + (yy - cy) ** 2 / ay ** 2 <= 1).astype(np.uint8)
+        tf = pose_to_tf(0.2 * k, -0.1 * k, yaw)
+        ops.append(("update", "chair" if k % 2 == 0 else "bed", depth, mask, tf))
+        ops.append(("best", "chair", np.array([0.2 * k, -0.1 * k])))
+        if k == 3:
+            ops.append(("explored", pose_to_tf(1.0, 0.5, 0.4)))
+    return ops
+
+
+def gen_object_map(om_mod):
+    """ObjectPointCloudMap of the reference (object_point_cloud_map.py) driven by object_map_script() with NumPy's global
+    RNG seeded: cloud per class after every operation, get_best_object results."""
+    fx, fy, fov = camera_intrinsics(640)
+    np.random.seed(1234)
+    m = om_mod.ObjectPointCloudMap(erosion_size=5)
+    out = {}
+    for i, op in enumerate(object_map_script()):
+        if op[0] == "update":
+            m.update_map(op[1], op[2], op[3], op[4], MIN_DEPTH, MAX_DEPTH, fx, fy)
+        elif op[0] == "best":
+            if m.has_object(op[1]):
+                out[f"best_{i}"] = np.asarray(m.get_best_object(op[1], op[2]), np.float64)
+        else:
+            m.update_explored(op[1], MAX_DEPTH, fov)
+        for name in ("chair", "bed"):   # per operation: a digest; the full clouds only once, at the end
+            if name in m.clouds:
+                c = np.asarray(m.clouds[name], np.float64)
+                out[f"sig_{i}_{name}"] = np.array([str(c.shape[0]), sha(c)])
+    for name in ("chair", "bed"):
+        out[f"final_{name}"] = np.asarray(m.clouds[name], np.float64)
+    return out
+
+
 def generate():
     from oracle import ref_shim
 
@@ -215,6 +263,7 @@ def generate():
     out[SYNC_CASE[0]] = gen_sync(ref_vm, ref_om, SYNC_CASE[1], SYNC_CASE[2])
     out["helpers"] = gen_helpers(geo, img, ref_vm)
     out["detections"] = gen_detections(ref_shim.reference_detections())
+    out["object_map"] = gen_object_map(ref_shim.reference_object_map())
     return out
 
 

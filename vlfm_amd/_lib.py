@@ -13,7 +13,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvlfm_amd.so")
-SOURCES = ["value_map.hip", "depth_ingest.hip", "depth_holes.hip", "obstacle_map.hip", "vlm_ops.hip", "detect_ops.hip", "host.cpp"]
+SOURCES = ["value_map.hip", "depth_ingest.hip", "depth_holes.hip", "obstacle_map.hip", "vlm_ops.hip", "detect_ops.hip", "object_cloud.hip", "host.cpp"]
 
 VLFM_OK = 0
 VLFM_ERR_INVALID = -1
@@ -108,6 +108,12 @@ def lib() -> ctypes.CDLL:
         L.vlfm_nms_scratch_bytes.argtypes = [ci]
         L.vlfm_nms_scratch_bytes.restype = ctypes.c_size_t
         L.vlfm_nms.argtypes = [vp, vp, ci, cf, vp, ctypes.c_size_t, vp, vp, ci, vp]
+        L.vlfm_object_cloud_scratch_bytes.argtypes = [ci, ci]
+        L.vlfm_object_cloud_scratch_bytes.restype = ctypes.c_size_t
+        L.vlfm_object_cloud_extract.argtypes = [vp, vp, ci, ci, ci, cd, cd, cd, cd, vp, vp, ci, vp, vp]
+        L.vlfm_dbscan_scratch_bytes.argtypes = [ci]
+        L.vlfm_dbscan_scratch_bytes.restype = ctypes.c_size_t
+        L.vlfm_dbscan_largest_cluster.argtypes = [vp, ci, cd, ci, vp, ctypes.c_size_t, vp, vp, vp, vp]
         L.vlfm_bits_pack.argtypes = [vp, vp, ci, ci, ci, vp]
         L.vlfm_bits_unpack.argtypes = [vp, vp, ci, ci, ci, vp]
         L.vlfm_bits_dilate.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
