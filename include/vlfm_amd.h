@@ -244,6 +244,14 @@ size_t vlfm_nms_scratch_bytes(int n);
 int vlfm_nms(const float* d_boxes_xyxy, const int32_t* d_order, int n, float iou_threshold, void* d_scratch,
              size_t scratch_bytes, int32_t* d_keep, int32_t* d_num_keep, int max_keep, void* stream);
 
+/* Device: multi-scale deformable attention sampling of GroundingDINO (replaces the CUDA extension of the reference's
+ * groundingdino package / its grid_sample fallback, vlfm/vlm/grounding_dino.py:14,61).  d_value [B][total][heads][D] f32,
+ * d_spatial_shapes [L][2] (H,W) int32, d_level_start [L] int32, d_sampling_loc [B][Q][heads][L][P][2] in [0,1],
+ * d_attn_weight [B][Q][heads][L][P] -> d_out [B][Q][heads*D].  Bilinear, zero padding, align_corners = False. */
+int vlfm_ms_deform_attn(const float* d_value, const int32_t* d_spatial_shapes, const int32_t* d_level_start,
+                        const float* d_sampling_loc, const float* d_attn_weight, int batch, int n_query, int n_heads,
+                        int head_dim, int n_levels, int n_points, int total_len, float* d_out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * ObjectPointCloudMap._extract_object_cloud (vlfm/mapping/object_point_cloud_map.py:150-170,186-212)
  * ------------------------------------------------------------------------------------------- */

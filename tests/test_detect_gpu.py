@@ -159,3 +159,23 @@ def test_mobile_sam_wrapper(gpu_device):
     assert np.array_equal(masks[0, 0].cpu().numpy(), mask)              # batched == single
     c = MobileSAMClient(port=12183, device=gpu_device)
     assert c.segment_bbox(img, [100, 120, 400, 380]).shape == (480, 640)
+
+
+def test_ms_deform_attn_matches_hf_pytorch_path(gpu_device):
+    """HIP multi-scale deformable attention vs the HF module's own grid_sample formulation (fp32, 1e-5)."""
+    from transformers.models.grounding_dino.modeling_grounding_dino import MultiScaleDeformableAttention
+
+    from vlfm_amd.vlm import det_ops
+
+    g = torch.Generator().manual_seed(0)
+    shapes = [(60, 80), (30, 40), (15, 20), (8, 10)]
+    B, Q, heads, D, L, P = 2, 50, 8, 32, 4, 4
+    S = sum(h * w for h, w in shapes)
+    value = torch.randn(B, S, heads, D, generator=g)
+    loc = torch.rand(B, Q, heads, L, P, 2, generator=g) * 1.3 - 0.15       # some samples fall outside: zero padding
+    w = torch.softmax(torch.randn(B, Q, heads, L * P, generator=g), -1).view(B, Q, heads, L, P)
+    start = torch.tensor([0] + list(np.cumsum([h * w_ for h, w_ in shapes])[:-1]))
+    want = MultiScaleDeformableAttention()(value, torch.tensor(shapes), shapes, start, loc, w, 64)
+    got = det_ops.ms_deform_attn(value.to(gpu_device), shapes, start.to(gpu_device), loc.to(gpu_device), w.to(gpu_device)).cpu()
+    assert got.shape == want.shape == (B, Q, heads * D)
+    assert torch.allclose(got, want, atol=1e-5, rtol=1e-5), float((got - want).abs().max())

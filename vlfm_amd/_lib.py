@@ -108,6 +108,7 @@ def lib() -> ctypes.CDLL:
         L.vlfm_nms_scratch_bytes.argtypes = [ci]
         L.vlfm_nms_scratch_bytes.restype = ctypes.c_size_t
         L.vlfm_nms.argtypes = [vp, vp, ci, cf, vp, ctypes.c_size_t, vp, vp, ci, vp]
+        L.vlfm_ms_deform_attn.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]
         L.vlfm_object_cloud_scratch_bytes.argtypes = [ci, ci]
         L.vlfm_object_cloud_scratch_bytes.restype = ctypes.c_size_t
         L.vlfm_object_cloud_extract.argtypes = [vp, vp, ci, ci, ci, cd, cd, cd, cd, vp, vp, ci, vp, vp]

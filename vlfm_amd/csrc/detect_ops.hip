@@ -236,3 +236,64 @@ extern "C" int vlfm_nms(const float* d_boxes_xyxy, const int32_t* d_order, int n
                  d_order, n, cb, d_keep, d_num_keep, max_keep);
     return check_launch("nms_scan_kernel");
 }
+
+// ------------------------------------------------------------------------------------------------ MsDeformAttn
+// Multi-scale deformable attention sampling (GroundingDINO encoder/decoder; the reference's package ships a CUDA extension
+// for it -- groundingdino/models/GroundingDINO/csrc/MsDeformAttn [ext] -- with a grid_sample fallback).
+//   value   [B][sum(H_l W_l)][heads][D] f32        loc [B][Q][heads][L][P][2] in [0,1]       w [B][Q][heads][L][P]
+//   out     [B][Q][heads * D]:  sum_{l,p} w * bilinear(value_l, loc)   (grid_sample: align_corners = False, zero padding)
+// One lane per output channel: the D channels of a (location, head) are contiguous, so every tap is one coalesced
+// D*4-byte read; locations and weights are wave-broadcast loads.  Gather-bound; no MFMA.
+namespace vlfm {
+__global__ __launch_bounds__(256) void ms_deform_attn_kernel(const float* __restrict__ value, const int* __restrict__ shapes,
+                                                             const int* __restrict__ level_start, const float* __restrict__ loc,
+                                                             const float* __restrict__ weight, int B, int Q, int heads, int D,
+                                                             int L, int P, int total, float* __restrict__ out) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n_out = (long long)B * Q * heads * D;
+    if (gid >= n_out) return;
+    const int d = (int)(gid % D);
+    const int h = (int)((gid / D) % heads);
+    const int q = (int)((gid / ((long long)D * heads)) % Q);
+    const int b = (int)(gid / ((long long)D * heads * Q));
+    const float* lq = loc + ((((size_t)b * Q + q) * heads + h) * L) * P * 2;
+    const float* wq = weight + ((((size_t)b * Q + q) * heads + h) * L) * P;
+    const float* vb = value + (size_t)b * total * heads * D + (size_t)h * D + d;
+    float acc = 0.0f;
+    for (int l = 0; l < L; l++) {
+        const int Hl = shapes[2 * l], Wl = shapes[2 * l + 1];
+        const float* vl = vb + (size_t)level_start[l] * heads * D;
+        for (int p = 0; p < P; p++) {
+            const float x = lq[(l * P + p) * 2] * (float)Wl - 0.5f, y = lq[(l * P + p) * 2 + 1] * (float)Hl - 0.5f;
+            const float xf = floorf(x), yf = floorf(y);
+            const int x0 = (int)xf, y0 = (int)yf;
+            const float tx = x - xf, ty = y - yf;
+            float s = 0.0f;
+            const bool xin0 = (unsigned)x0 < (unsigned)Wl, xin1 = (unsigned)(x0 + 1) < (unsigned)Wl;
+            const bool yin0 = (unsigned)y0 < (unsigned)Hl, yin1 = (unsigned)(y0 + 1) < (unsigned)Hl;
+            if (yin0 && xin0) s += vl[((size_t)y0 * Wl + x0) * heads * D] * (1.f - tx) * (1.f - ty);
+            if (yin0 && xin1) s += vl[((size_t)y0 * Wl + x0 + 1) * heads * D] * tx * (1.f - ty);
+            if (yin1 && xin0) s += vl[((size_t)(y0 + 1) * Wl + x0) * heads * D] * (1.f - tx) * ty;
+            if (yin1 && xin1) s += vl[((size_t)(y0 + 1) * Wl + x0 + 1) * heads * D] * tx * ty;
+            acc += s * wq[l * P + p];
+        }
+    }
+    out[gid] = acc;
+}
+}  // namespace vlfm
+
+extern "C" int vlfm_ms_deform_attn(const float* d_value, const int32_t* d_spatial_shapes, const int32_t* d_level_start,
+                                   const float* d_sampling_loc, const float* d_attn_weight, int batch, int n_query,
+                                   int n_heads, int head_dim, int n_levels, int n_points, int total_len, float* d_out,
+                                   void* stream) {
+    if (batch == 0 || n_query == 0) return VLFM_OK;
+    if (!d_value || !d_spatial_shapes || !d_level_start || !d_sampling_loc || !d_attn_weight || !d_out || batch < 0 ||
+        n_query < 0 || n_heads <= 0 || head_dim <= 0 || n_levels <= 0 || n_points <= 0 || total_len <= 0)
+        return fail(VLFM_ERR_INVALID, "ms_deform_attn: bad argument");
+    const long long n_out = (long long)batch * n_query * n_heads * head_dim;
+    VLFM_TIMED("ms_deform_attn_kernel", stream);
+    VLFM_KLAUNCH(vlfm::ms_deform_attn_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, stream, d_value,
+                 d_spatial_shapes, d_level_start, d_sampling_loc, d_attn_weight, batch, n_query, n_heads, head_dim, n_levels,
+                 n_points, total_len, d_out);
+    return check_launch("ms_deform_attn_kernel");
+}

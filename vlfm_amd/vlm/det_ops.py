@@ -141,3 +141,42 @@ def scale_coords(img1_shape, coords: torch.Tensor, img0_shape) -> torch.Tensor:
     coords[:, 2].clamp_(0, img0_shape[1])
     coords[:, 3].clamp_(0, img0_shape[0])
     return coords
+
+
+def ms_deform_attn(value: torch.Tensor, spatial_shapes_list, level_start_index: torch.Tensor,
+                   sampling_locations: torch.Tensor, attention_weights: torch.Tensor) -> torch.Tensor:
+    """HIP multi-scale deformable attention: value [B,S,heads,D], sampling_locations [B,Q,heads,L,P,2],
+    attention_weights [B,Q,heads,L,P] (all f32, device) -> [B,Q,heads*D]."""
+    B, S, heads, D = value.shape
+    _, Q, _, Lv, Pn, _ = sampling_locations.shape
+    dev = value.device
+    shapes = torch.tensor([[int(h), int(w)] for h, w in spatial_shapes_list], dtype=torch.int32, device=dev)
+    out = torch.empty((B, Q, heads * D), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().vlfm_ms_deform_attn(value.contiguous().data_ptr(), shapes.data_ptr(),
+                                                  level_start_index.to(torch.int32).contiguous().data_ptr(),
+                                                  sampling_locations.contiguous().data_ptr(),
+                                                  attention_weights.contiguous().data_ptr(), B, Q, heads, D, Lv, Pn, S,
+                                                  out.data_ptr(), _stream()), "ms_deform_attn")
+    return out
+
+
+def patch_hf_deformable_attention(model) -> int:
+    """Route every HF ``MultiScaleDeformableAttention`` module of ``model`` (GroundingDINO) through the HIP kernel when its
+    inputs are f32 device tensors; anything else keeps the module's own PyTorch path.  Returns the number patched."""
+    n = 0
+    for mod in model.modules():
+        if type(mod).__name__ == "MultiScaleDeformableAttention":
+            torch_forward = mod.forward
+
+            def forward(value, value_spatial_shapes, value_spatial_shapes_list, level_start_index, sampling_locations,
+                        attention_weights, im2col_step, _fallback=torch_forward):
+                if value.is_cuda and value.dtype == torch.float32 and sampling_locations.dtype == torch.float32:
+                    return ms_deform_attn(value, value_spatial_shapes_list, level_start_index, sampling_locations,
+                                          attention_weights.to(torch.float32))
+                return _fallback(value, value_spatial_shapes, value_spatial_shapes_list, level_start_index,
+                                 sampling_locations, attention_weights, im2col_step)
+
+            mod.forward = forward
+            n += 1
+    return n

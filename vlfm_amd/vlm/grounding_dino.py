@@ -85,6 +85,7 @@ class GroundingDINO:
             self.tokenizer, self.decode = wt, wt.decode
             self.weights = "random-init"
         self.model.eval().to(self.device)
+        self.hip_deform_attn = det_ops.patch_hf_deformable_attention(self.model)  # HIP MsDeformAttn
 
     @torch.inference_mode()
     def predict_batch(self, images_u8: torch.Tensor, captions: Sequence[str]) -> List[ObjectDetections]:
