@@ -1,0 +1,25 @@
+"""Where do the obstacle-pipeline kernels spend their time?  Needs the diagnostic build:
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -DVLFM_PHASE_TIMING \
+          -o gpurun_out/libvlfm_amd_phase.so vlfm_amd/csrc/*.hip vlfm_amd/csrc/host.cpp
+    VLFM_LIB_PATH=$PWD/gpurun_out/libvlfm_amd_phase.so python tools/phase_probe.py 8
+Prints per-phase microseconds of workgroup 0 (100 MHz wall clock) averaged over steps."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from vlfm_amd import _lib
+from vlfm_amd.harness import BatchedEpisodes
+E = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+sim = BatchedEpisodes(E, device=torch.device("cuda:0"), use_blip2=False, overlap=False)
+for _ in range(14): sim.step()
+acc = np.zeros((3, 16)); n = 0
+for _ in range(20):
+    sim.step(); torch.cuda.synchronize()
+    buf = np.zeros((3, 16), np.int64)
+    _lib.lib().vlfm_debug_phase_clocks(ctypes.c_void_p(buf.ctypes.data))
+    d = np.diff(buf, axis=1) * 0.01   # 100 MHz ticks -> us
+    d[(d < 0) | (d > 1e5)] = 0
+    acc[:, :15] += d; n += 1
+names = {0: ["cone raster", "window+masks", "obst contours", "shadow pts", "cut lines", "visible contours+pick", "fill", "dilate+OR"],
+         1: ["zero+scan+pick"], 2: ["dilate5 full planes", "small-unexplored filter", "border chain", "bad flags", "pieces+midpoints"]}
+for k, nm in names.items():
+    print(["fog_of_war", "explored_select", "frontier"][k], " ".join(f"{a}={acc[k, i] / n:.0f}us" for i, a in enumerate(nm)))

@@ -12,7 +12,7 @@ import subprocess
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvlfm_amd.so")
+LIB_PATH = os.environ.get("VLFM_LIB_PATH") or os.path.join(_HERE, "libvlfm_amd.so")  # override: diagnostic builds
 SOURCES = ["value_map.hip", "depth_ingest.hip", "depth_holes.hip", "obstacle_map.hip", "vlm_ops.hip", "detect_ops.hip", "object_cloud.hip", "host.cpp"]
 
 VLFM_OK = 0

@@ -31,8 +31,10 @@ __device__ inline unsigned bit_get(const Bits& b, int x, int y) { return bit_get
 __device__ inline unsigned bits3(const Bits& b, int x, int y) {
     if ((unsigned)y >= (unsigned)b.rows) return 0u;
     const unsigned* row = b.w + (size_t)y * b.stride;
+    const int sh = x & 31, wi = x >> 5;
+    // fast path (15/16 of all positions): the three bits live in one word and none is beyond the last column
+    if (sh != 0 && sh != 31 && x > 0 && x + 1 < b.cols) return (row[wi] >> (sh - 1)) & 7u;
     const int xm = x - 1;
-    // 64-bit window starting at word of xm (handles xm == -1)
     unsigned long long win;
     if (xm < 0) {
         win = ((unsigned long long)row[0]) << 1;  // bit 0 = x=-1 (zero), bit1 = x=0 ...
@@ -40,10 +42,10 @@ __device__ inline unsigned bits3(const Bits& b, int x, int y) {
         if (b.cols < 2) r &= 3u;
         return r;
     }
-    const int wi = xm >> 5, sh = xm & 31;
-    win = row[wi];
-    if (wi + 1 < b.stride) win |= ((unsigned long long)row[wi + 1]) << 32;
-    unsigned r = (unsigned)((win >> sh) & 7u);
+    const int wm = xm >> 5, shm = xm & 31;
+    win = row[wm];
+    if (wm + 1 < b.stride) win |= ((unsigned long long)row[wm + 1]) << 32;
+    unsigned r = (unsigned)((win >> shm) & 7u);
     // mask columns beyond cols
     if (x + 1 >= b.cols) r &= (x >= b.cols) ? 1u : 3u;
     return r;
@@ -83,25 +85,38 @@ struct ContourSink {         // per-environment output of a scan
 __device__ inline int follow_border(const Bits& img, unsigned* traced, unsigned* neg, int x0, int y0, int method,
                                     int2* out, int cap, int is_hole = 0) {
     int n = 0;
-    auto mark = [&](int x, int y, bool negative) {
+    // labels are only ever set, by this single lane: plain OR stores (no read-back needed for the negative label)
+    auto mark_neg = [&](int x, int y) {
         const size_t wi = (size_t)y * img.stride + (x >> 5);
         const unsigned m = 1u << (x & 31);
         traced[wi] |= m;
-        if (negative) neg[wi] |= m;
+        neg[wi] |= m;
     };
     auto emit = [&](int x, int y) {
         if (n < cap) out[n] = make_int2(x, y);
         n++;
     };
+    // first set direction at or after `from` (mod 8), searching towards increasing chain codes: rotate + ctz
+    auto next_ccw = [](unsigned nb, int from) {
+        const unsigned rot = ((nb | (nb << 8)) >> (from & 7)) & 0xFFu;
+        return (from & 7) + __builtin_ctz(rot);  // caller guarantees nb != 0
+    };
     unsigned nb = nbr8(img, x0, y0);
     int s_end = is_hole ? 0 : 4, s = s_end;
-    do {
-        s = (s - 1) & 7;
-    } while (!((nb >> s) & 1u) && s != s_end);
-    if (s == s_end) {  // isolated pixel
-        mark(x0, y0, true);
+    // the reference's start loop tries s_end - 1, s_end - 2, ... and gives up when it is back at s_end WITHOUT testing that
+    // direction: mask it out (the scan guarantees it is clear anyway)
+    const unsigned nb0 = nb & ~(1u << s_end);
+    if (nb0 == 0u) {  // isolated pixel
+        mark_neg(x0, y0);
         emit(x0, y0);
         return n;
+    }
+    {   // clockwise search for the first neighbour: s = s_end - 1, s_end - 2, ... (mod 8)
+        const unsigned mir = __brev(nb0) >> 24;                   // bit k of mir = bit (7 - k) of nb0
+        const int from = (8 - s_end) & 7;                         // direction s_end - 1  <->  mirrored index 8 - s_end
+        const unsigned rot = ((mir | (mir << 8)) >> from) & 0xFFu;
+        const int k = __builtin_ctz(rot);
+        s = (s_end - 1 - k) & 7;
     }
     const int x1 = x0 + kCodeDx[s], y1 = y0 + kCodeDy[s];
     int x3 = x0, y3 = y0;
@@ -109,16 +124,13 @@ __device__ inline int follow_border(const Bits& img, unsigned* traced, unsigned*
     for (;;) {
         s_end = s;
         nb = nbr8(img, x3, y3);
-        for (;;) {  // counter-clockwise search for the next border pixel (always terminates: we came from one)
-            ++s;
-            if ((nb >> (s & 7)) & 1u) break;
-        }
-        s &= 7;
+        if (nb == 0u) break;       // cannot happen (we came from a neighbour); guards the ctz below
+        s = next_ccw(nb, s + 1) & 7;   // counter-clockwise search for the next border pixel, then "s &= 7"
         if ((unsigned)(s - 1) < (unsigned)s_end) {
-            mark(x3, y3, true);
+            mark_neg(x3, y3);
         } else {
             const size_t wi = (size_t)y3 * img.stride + (x3 >> 5);
-            if (!((traced[wi] >> (x3 & 31)) & 1u)) mark(x3, y3, false);
+            traced[wi] |= 1u << (x3 & 31);   // positive label unless already labelled: OR-ing `traced` alone is exactly that
         }
         if (s != prev_s || method == 1) {
             emit(x3, y3);

@@ -121,6 +121,19 @@ __global__ __launch_bounds__(64) void find_contours_kernel(const unsigned* __res
 }
 
 
+// Optional phase timing (compile with -DVLFM_PHASE_TIMING; tools/phase_probe.py): workgroup 0's thread 0 stamps the
+// constant-rate 100 MHz counter at phase boundaries.  Zero cost when the macro is not defined.
+#ifdef VLFM_PHASE_TIMING
+__device__ long long g_phase_clock[3][16];
+#define VLFM_PHASE(kernel_id, k)                                                                  \
+    do {                                                                                          \
+        __syncthreads();                                                                          \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_clock[kernel_id][k] = wall_clock64();    \
+    } while (0)
+#else
+#define VLFM_PHASE(kernel_id, k) do {} while (0)
+#endif
+
 // ================================================================================================ drawing helpers
 // Window view of a bit plane living in LDS: wn x wn cells, top-left = image cell (ox, oy); image is S x S.
 struct Win {
@@ -414,6 +427,7 @@ __global__ __launch_bounds__(256) void fog_of_war_kernel(const FogParams* __rest
     if (tid < 16) sh_i[tid] = 0;
     __syncthreads();
 
+    VLFM_PHASE(0, 0);
     // ---- 1. cone sector (cv2.ellipse filled) into cone/par
     LdsBitmap bm;
     bm.solid = cone; bm.parity = par; bm.rows = S; bm.cols = S; bm.words = words;
@@ -427,6 +441,7 @@ __global__ __launch_bounds__(256) void fog_of_war_kernel(const FogParams* __rest
     __syncthreads();
     resolve_rows(bm, tid, nth);
     __syncthreads();
+    VLFM_PHASE(0, 1);
     // ---- 2. navigable window; obstacles_in_cone = cone & ~nav; visible = cone & nav
     for (int i = tid; i < plane_words; i += nth) {
         const int ly = i / words, lw = i - ly * words;
@@ -440,6 +455,7 @@ __global__ __launch_bounds__(256) void fog_of_war_kernel(const FogParams* __rest
         par[i] = 0u;
     }
     __syncthreads();
+    VLFM_PHASE(0, 2);
     // ---- 3. external contours (SIMPLE) of the obstacle blobs: wave 0
     if (wave == 0) {
         ContourSink sink;
@@ -455,6 +471,7 @@ __global__ __launch_bounds__(256) void fog_of_war_kernel(const FogParams* __rest
     if (sh_i[2]) { if (tid == 0) status[0] = 1; return; }
     if (tid == 0) { status[1] = n_obst; }
     if (n_obst == 0) return;  // "no obstacles in the cone": fog returned unchanged -> nothing revealed this step
+    VLFM_PHASE(0, 3);
     // ---- 4. shadow-casting points: convex blobs contribute their two angular extremes, the others every vertex
     const int acx = P.ax - ox, acy = P.ay - oy;  // agent in window coordinates (contour points are window-local)
     for (int c = 0; c < n_obst; c++) {
@@ -497,6 +514,7 @@ __global__ __launch_bounds__(256) void fog_of_war_kernel(const FogParams* __rest
     }
     const int n_lines = sh_i[3];
     if (tid == 0) status[2] = n_lines;
+    VLFM_PHASE(0, 4);
     // ---- 5. cut the visible mask with 2-px lines from every point away from the agent (cv2.polylines, color 0)
     for (int i = tid; i < n_lines; i += nth) {
         const int px = lines[i].x + ox, py = lines[i].y + oy;  // image coordinates
@@ -506,6 +524,7 @@ __global__ __launch_bounds__(256) void fog_of_war_kernel(const FogParams* __rest
         thick_line2_clear(vis, W, px, py, (int)ex, (int)ey);  // .astype(np.int32): truncation
     }
     __syncthreads();
+    VLFM_PHASE(0, 5);
     // ---- 6. external contours of what is left; keep the one nearest the agent (|pointPolygonTest|, <= 3 px)
     for (int i = tid; i < 2 * plane_words; i += nth) traced[i] = 0u;  // traced + neg are adjacent
     __syncthreads();
@@ -533,6 +552,7 @@ __global__ __launch_bounds__(256) void fog_of_war_kernel(const FogParams* __rest
     if (sh_i[6]) { if (tid == 0) status[0] = 1; return; }
     const int best = sh_i[5];
     if (best < 0 || sh_i[7]) return;  // nothing visible / closest contour too far away
+    VLFM_PHASE(0, 6);
     // ---- 7. drawContours(fog, [visible_area], 0, 1, -1): fill the chosen outline (component + enclosed holes)
     {
         LdsBitmap fb;
@@ -547,6 +567,7 @@ __global__ __launch_bounds__(256) void fog_of_war_kernel(const FogParams* __rest
         resolve_rows(fb, tid, nth);
         __syncthreads();
     }
+    VLFM_PHASE(0, 7);
     // ---- 8. dilate 3x3 (obstacle_map.py:125), keep navigable cells (:127), OR into the explored plane (:126)
     unsigned* expl = mp.explored + eoff;
     for (int i = tid; i < plane_words; i += nth) {
@@ -574,6 +595,7 @@ __global__ __launch_bounds__(256) void fog_of_war_kernel(const FogParams* __rest
         if (lo && wi >= 0 && wi < mp.stride) atomicOr(&expl[(size_t)y * mp.stride + wi], lo & tail_mask(S, wi));
         if (hi && wi + 1 >= 0 && wi + 1 < mp.stride) atomicOr(&expl[(size_t)y * mp.stride + wi + 1], hi & tail_mask(S, wi + 1));
     }
+    VLFM_PHASE(0, 8);
     if (tid == 0) {
         int* bb = sc.bbox + (size_t)P.env * 4;
         atomicMin(&bb[0], max(oy, 0)); atomicMax(&bb[1], min(oy + wn - 1, S - 1));
@@ -605,6 +627,7 @@ __global__ __launch_bounds__(256) void explored_select_kernel(const FogParams* _
     const int* bb = bbox + (size_t)P.env * 4;
     const int y_lo = max(bb[0] - 1, 0), y_hi = min(bb[1] + 1, S - 1);
     if (y_lo > y_hi) return;  // nothing explored yet
+    VLFM_PHASE(1, 0);
     for (int i = tid + y_lo * stride; i < (y_hi + 1) * stride; i += nth) { traced[i] = 0u; neg[i] = 0u; }
     __threadfence();
     __syncthreads();
@@ -636,6 +659,7 @@ __global__ __launch_bounds__(256) void explored_select_kernel(const FogParams* _
     __threadfence();
     __syncthreads();
     if (tid == 0) { status[0] = sh_i[1]; status[1] = sh_i[0]; status[2] = sh_i[2]; status[3] = 0; }
+    VLFM_PHASE(1, 1);
     if (sh_i[1] || sh_i[0] <= 1) return;
     // redraw the chosen outline filled on an empty plane (global-memory bitmaps; rare path)
     const int chosen = sh_i[2];
@@ -717,6 +741,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(const FogParams* __restri
     if (tid < 16) sh_i[tid] = 0;
     if (tid == 0) sh_i[0] = 1;
     __syncthreads();
+    VLFM_PHASE(2, 0);
     // ---- a. explored_d = dilate(explored, 5x5) & navigable ; unexplored = navigable & ~explored_d   (full planes)
     unsigned ring_ok = 1;
     for (int idx = tid; idx < S * stride; idx += nth) {
@@ -734,6 +759,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(const FogParams* __restri
     }
     __threadfence();
     __syncthreads();
+    VLFM_PHASE(2, 1);
     // ---- b. filter_out_small_unexplored.  Exact shortcut: when the border ring of `unexplored` is fully set, that one
     // component encloses every other one, RETR_EXTERNAL returns it alone and its contour area is (S-1)^2.
     ring_ok = ring_all_set(un, S, stride, tid, nth);
@@ -804,6 +830,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(const FogParams* __restri
         __threadfence();
         __syncthreads();
     }
+    VLFM_PHASE(2, 2);
     // ---- c. border chain (CHAIN_APPROX_NONE) of the filtered explored mask
     const int* bb = bbox + (size_t)P.env * 4;
     if (wave == 0) {
@@ -819,6 +846,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(const FogParams* __restri
     __syncthreads();
     const int nc = sh_i[5], npts_all = sh_i[6];
     if (sh_i[7]) { if (tid == 0) { out_n[0] = 0; out_n[1] = 1; } return; }
+    VLFM_PHASE(2, 3);
     // ---- d. a chain point is "bad" when no unexplored-navigable cell lies in its 3x3 neighbourhood
     //         (cv2.blur 3x3, BORDER_REFLECT_101, of 255*(navigable & ~filtered) is zero there)
     for (int i = tid; i < npts_all; i += nth) {
@@ -835,6 +863,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(const FogParams* __restri
     }
     __threadfence();
     __syncthreads();
+    VLFM_PHASE(2, 4);
     // ---- e. frontier runs + arc-length midpoints.  Contours in OpenCV order (reverse discovery); the chain handed to
     // contour_to_frontiers is the contour rotated by one (interpolate_contour emits end points only).
     // Thread 0 lists the kept pieces; then one thread per piece computes its midpoint.
@@ -922,6 +951,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(const FogParams* __restri
         }
         if (f < sc.cap_frontiers) { out_xy[2 * f] = ox_; out_xy[2 * f + 1] = oy_; }
     }
+    VLFM_PHASE(2, 5);
     if (tid == 0) {
         out_n[0] = np < sc.cap_frontiers ? np : sc.cap_frontiers;
         out_n[1] = sh_i[9] || np > sc.cap_frontiers;
@@ -1067,6 +1097,12 @@ extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, in
     }
     return check_launch("frontier_kernel");
 }
+
+#ifdef VLFM_PHASE_TIMING
+extern "C" int vlfm_debug_phase_clocks(long long* h_out /* [3][16] */) {
+    return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(vlfm::g_phase_clock), sizeof(long long) * 48) == hipSuccess ? VLFM_OK : VLFM_ERR_HIP;
+}
+#endif
 
 extern "C" int vlfm_obstacle_status(const void* d_scratch, int n_envs, int map_size, int cap_pts, int cap_contours,
                                     int32_t* h_out /* [n_envs][8] */) {
