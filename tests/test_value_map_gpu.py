@@ -194,3 +194,28 @@ def test_record_and_replay_in_the_reference_format(gpu_device, tmp_path, monkeyp
         assert np.array_equal(png, (depth * 255).astype(np.uint8).astype(np.float32) / 255.0)
         ref.update_map(values, png, tf, MIN_DEPTH, MAX_DEPTH, _fov())
     _compare(replayed, ref)
+
+
+def test_multi_camera_same_slot_is_sequential_and_batch_rejects_duplicates(gpu_device):
+    """RealityMixin feeds several cameras into ONE map per step (reality_policies.py:113-141), sequentially.  The drop-in
+    does the same; the batched entry point refuses two observations of one slot in a single launch."""
+    from oracle.ref_value_map import RefValueMap
+    from vlfm_amd.mapping import ValueMap, ValueMapBatch
+
+    env = SyntheticEnv(12)
+    ours = ValueMap(1, use_max_confidence=False, device=gpu_device)
+    ref = RefValueMap(1, use_max_confidence=False)
+    for step in range(4):
+        for cam in range(3):   # three cameras, same position, different headings
+            depth, _, values = env.observe()
+            tf = pose_to_tf(0.3 * step, 0.1 * step, 2.0 * cam + 0.2 * step)
+            ours.update_map(values, depth, tf, MIN_DEPTH, MAX_DEPTH, _fov())
+            ref.update_map(values, depth.copy(), tf, MIN_DEPTH, MAX_DEPTH, _fov())
+    _compare(ours, ref)
+    vb = ValueMapBatch(2, 1, device=gpu_device)
+    d = np.stack([env.observe()[0] for _ in range(2)])
+    tfs = np.stack([pose_to_tf(0, 0, 0), pose_to_tf(0, 0, 1)])
+    with pytest.raises(AssertionError, match="one observation per environment slot"):
+        vb.update(np.array([[0.3], [0.4]]), d, tfs, MIN_DEPTH, MAX_DEPTH, _fov(), env_ids=[1, 1])
+    with pytest.raises(AssertionError, match="out of range"):
+        vb.update(np.array([[0.3]]), d[:1], tfs[:1], MIN_DEPTH, MAX_DEPTH, _fov(), env_ids=[2])

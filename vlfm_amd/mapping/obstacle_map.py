@@ -110,6 +110,7 @@ class ObstacleMapBatch:
         prm["fx"], prm["fy"] = fx, fy
         prm["min_height"], prm["max_height"] = self._min_height, self._max_height
         prm["env"] = np.arange(n) if env_ids is None else np.asarray(env_ids)
+        assert int(prm["env"].max()) < self.n_envs and int(prm["env"].min()) >= 0, "environment slot out of range"
         prm["scatter"] = (1 if update_obstacles else 0) | (2 if self._hole_area_thresh == -1 else 0)
         keys = None
         if want_colmax:

@@ -291,6 +291,10 @@ class ValueMapBatch:
                                                 self._min_confidence)
         d_tan = _TEMPLATES.tan_table(self.device, fov, W)
         pose = pose_params(tf_camera_to_episodic, env_ids, self.size, self.pixels_per_meter, T)
+        # one launch fuses every observation concurrently: two observations of the SAME slot (the reference's multi-camera
+        # loop, reality_policies.py:113-141, is sequential) must go through separate calls
+        assert len(np.unique(pose["env"])) == len(pose), "one observation per environment slot and call"
+        assert int(pose["env"].max()) < self.n_envs and int(pose["env"].min()) >= 0, "environment slot out of range"
         L = _lib.lib()
         with torch.cuda.device(self.device):
             ring = self._rings(n)
