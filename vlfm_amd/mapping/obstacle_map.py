@@ -195,6 +195,8 @@ class ObstacleMapBatch:
 
         prm = self.fog_params(tf, max_depth, topdown_fov, env_ids)
         n = len(prm)
+        if env_ids is not None:  # the explore pipeline owns a slot's planes for the whole launch
+            assert len(set(int(e) for e in env_ids)) == n, "one observation per environment slot and call"
         with torch.cuda.device(self.device):
             d_prm = self._ring_fog.upload(prm)
             _lib.check(_lib.lib().vlfm_obstacle_map_update_batched(
