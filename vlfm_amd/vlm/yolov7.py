@@ -84,6 +84,16 @@ class YoloV7E6EClassNet(nn.Module):
         self.bu = nn.ModuleList([_Elan(2 * head_c[i + 1], head_c[i + 1], 4) for i in range(3)])
         self.detect = nn.ModuleList([nn.Conv2d(c, 3 * (5 + nc), 1) for c in head_c])
         self.register_buffer("anchors", torch.tensor(self.ANCHORS, dtype=torch.float32).view(4, 3, 2))
+        # yolov7's Detect._initialize_biases [ext]: objectness prior of ~8 objects per 640-px image, class prior 0.6/nc --
+        # without it a random-init head passes half of the 17 850 candidates through conf > 0.25, which no trained detector
+        # does and which would turn the NMS into the dominant cost of the "full step" side figure
+        import math
+
+        with torch.no_grad():
+            for m, stride in zip(self.detect, self.STRIDES):
+                b = m.bias.view(3, -1)
+                b[:, 4] = math.log(8 / (640 / stride) ** 2)
+                b[:, 5:] = math.log(0.6 / (nc - 0.99))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         b = x.shape[0]
