@@ -12,6 +12,8 @@ E = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 sim = BatchedEpisodes(E, device=torch.device("cuda:0"), use_blip2=False, overlap=False)
 for _ in range(14): sim.step()
 acc = np.zeros((3, 16)); n = 0
+walk = np.zeros(3)
+w0 = np.zeros(3, np.int64); _lib.lib().vlfm_debug_walk_stats(ctypes.c_void_p(w0.ctypes.data))  # reset
 for _ in range(20):
     sim.step(); torch.cuda.synchronize()
     buf = np.zeros((3, 16), np.int64)
@@ -19,7 +21,11 @@ for _ in range(20):
     d = np.diff(buf, axis=1) * 0.01   # 100 MHz ticks -> us
     d[(d < 0) | (d > 1e5)] = 0
     acc[:, :15] += d; n += 1
+    w = np.zeros(3, np.int64); _lib.lib().vlfm_debug_walk_stats(ctypes.c_void_p(w.ctypes.data)); walk += w
 names = {0: ["cone raster", "window+masks", "obst contours", "shadow pts", "cut lines", "visible contours+pick", "fill", "dilate+OR"],
          1: ["zero+scan+pick"], 2: ["dilate5 full planes", "small-unexplored filter", "border chain", "bad flags", "pieces+midpoints"]}
 for k, nm in names.items():
     print(["fog_of_war", "explored_select", "frontier"][k], " ".join(f"{a}={acc[k, i] / n:.0f}us" for i, a in enumerate(nm)))
+print(f"border walks, all envs and scans: {walk[0] * 0.01 / n / E:.0f} us per env-step inside follow_border, "
+      f"{walk[1] / n / E:.0f} emitted points, {walk[2] / n / E:.1f} contours per env-step")
+print("frontier counts (frontiers, overflow, contours, chain points) env 0:", sim.obstacles.counts[0].tolist())

@@ -412,7 +412,12 @@ __global__ __launch_bounds__(256) void fog_of_war_kernel(const FogParams* __rest
     unsigned* traced = vis + plane_words;
     unsigned* neg = traced + plane_words;
     unsigned* fill = neg + plane_words;
-    int* sh_i = reinterpret_cast<int*>(fill + plane_words);  // small shared ints
+    // padded copies for the two border scans (Bits::padded): image + both label planes, (wn + 2) x (words + 2) words each
+    const int pw = words + 2, pad_words = (wn + 2) * pw;
+    unsigned* p_img = fill + plane_words;
+    unsigned* p_tr = p_img + pad_words;
+    unsigned* p_ng = p_tr + pad_words;
+    int* sh_i = reinterpret_cast<int*>(p_ng + pad_words);  // small shared ints
     const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wave = tid >> 6;
     const size_t eoff = (size_t)P.env * S * mp.stride;
     const unsigned last_mask = (wn & 31) ? ((1u << (wn & 31)) - 1u) : 0xFFFFFFFFu;
@@ -456,13 +461,19 @@ __global__ __launch_bounds__(256) void fog_of_war_kernel(const FogParams* __rest
     }
     __syncthreads();
     VLFM_PHASE(0, 2);
-    // ---- 3. external contours (SIMPLE) of the obstacle blobs: wave 0
+    // ---- 3. external contours (SIMPLE) of the obstacle blobs: wave 0 walks a padded copy
+    for (int i = tid; i < pad_words; i += nth) {
+        const int ly = i / pw - 1, lw = i % pw - 1;
+        p_img[i] = ((unsigned)ly < (unsigned)wn && (unsigned)lw < (unsigned)words) ? obst[ly * words + lw] : 0u;
+        p_tr[i] = 0u; p_ng[i] = 0u;
+    }
+    __syncthreads();
     if (wave == 0) {
         ContourSink sink;
         sink.pts = pts; sink.start = cstart; sink.len = clen; sink.cap_pts = sc.cap_pts; sink.cap_contours = sc.cap_contours;
         sink.n_pts = 0; sink.n_contours = 0; sink.overflow = 0;
-        Bits b{obst, words, wn, wn};
-        scan_external(b, traced, neg, 0, wn - 1, 2, sink);
+        Bits b{p_img + pw + 1, pw, wn, wn, 1};
+        scan_external(b, p_tr + pw + 1, p_ng + pw + 1, 0, wn - 1, 2, sink);
         if (lane == 0) { sh_i[0] = sink.n_contours; sh_i[1] = sink.n_pts; sh_i[2] = sink.overflow; }
     }
     __threadfence_block();
@@ -526,14 +537,18 @@ __global__ __launch_bounds__(256) void fog_of_war_kernel(const FogParams* __rest
     __syncthreads();
     VLFM_PHASE(0, 5);
     // ---- 6. external contours of what is left; keep the one nearest the agent (|pointPolygonTest|, <= 3 px)
-    for (int i = tid; i < 2 * plane_words; i += nth) traced[i] = 0u;  // traced + neg are adjacent
+    for (int i = tid; i < pad_words; i += nth) {
+        const int ly = i / pw - 1, lw = i % pw - 1;
+        p_img[i] = ((unsigned)ly < (unsigned)wn && (unsigned)lw < (unsigned)words) ? vis[ly * words + lw] : 0u;
+        p_tr[i] = 0u; p_ng[i] = 0u;
+    }
     __syncthreads();
     if (wave == 0) {
         ContourSink sink;
         sink.pts = pts; sink.start = cstart; sink.len = clen; sink.cap_pts = sc.cap_pts; sink.cap_contours = sc.cap_contours;
         sink.n_pts = 0; sink.n_contours = 0; sink.overflow = 0;
-        Bits b{vis, words, wn, wn};
-        scan_external(b, traced, neg, 0, wn - 1, 2, sink);
+        Bits b{p_img + pw + 1, pw, wn, wn, 1};
+        scan_external(b, p_tr + pw + 1, p_ng + pw + 1, 0, wn - 1, 2, sink);
         int best = -1;
         double best_d2 = 0;
         if (!sink.overflow) {
@@ -611,6 +626,7 @@ struct SelectScratch {
     unsigned* fill_solid; unsigned* fill_par;
     int2* pts; int* starts; int* lens; int* status;  // status [n_envs][4]: overflow, n contours, chosen, refilled
     int cap_pts, cap_contours;
+    unsigned lds_bytes;                    // dynamic LDS available for the window copy
 };
 
 __global__ __launch_bounds__(256) void explored_select_kernel(const FogParams* __restrict__ prm, MapPlanes mp,
@@ -628,7 +644,26 @@ __global__ __launch_bounds__(256) void explored_select_kernel(const FogParams* _
     const int y_lo = max(bb[0] - 1, 0), y_hi = min(bb[1] + 1, S - 1);
     if (y_lo > y_hi) return;  // nothing explored yet
     VLFM_PHASE(1, 0);
-    for (int i = tid + y_lo * stride; i < (y_hi + 1) * stride; i += nth) { traced[i] = 0u; neg[i] = 0u; }
+    // The border walk is a single-lane pointer chase: run it on an LDS copy of the explored window (everything ever revealed
+    // lies inside the persistent bounding box) whenever image + two label planes fit; the global planes are the fallback.
+    extern __shared__ __attribute__((aligned(16))) unsigned lds_win[];
+    const int w_lo = max(bb[2] - 1, 0) >> 5, w_hi = min(bb[3] + 1, S - 1) >> 5;
+    const int wrows = y_hi - y_lo + 1, wwords = w_hi - w_lo + 1;
+    const int pw = wwords + 2, wn = (wrows + 2) * pw;  // padded: one zero row / word all around (Bits::padded)
+    const bool in_lds = (size_t)3 * wn * sizeof(unsigned) <= sc.lds_bytes;
+    unsigned* L_img = lds_win;
+    unsigned* L_tr = lds_win + wn;
+    unsigned* L_ng = lds_win + 2 * wn;
+    if (in_lds) {
+        for (int i = tid; i < wn; i += nth) {
+            const int ly = i / pw - 1, lw = i % pw - 1;
+            const bool real = (unsigned)ly < (unsigned)wrows && (unsigned)lw < (unsigned)wwords;
+            L_img[i] = real ? expl[(size_t)(y_lo + ly) * stride + w_lo + lw] : 0u;
+            L_tr[i] = 0u; L_ng[i] = 0u;
+        }
+    } else {
+        for (int i = tid + y_lo * stride; i < (y_hi + 1) * stride; i += nth) { traced[i] = 0u; neg[i] = 0u; }
+    }
     __threadfence();
     __syncthreads();
     int2* pts = sc.pts + (size_t)P.env * sc.cap_pts;
@@ -639,8 +674,17 @@ __global__ __launch_bounds__(256) void explored_select_kernel(const FogParams* _
         ContourSink sink;
         sink.pts = pts; sink.start = cstart; sink.len = clen; sink.cap_pts = sc.cap_pts; sink.cap_contours = sc.cap_contours;
         sink.n_pts = 0; sink.n_contours = 0; sink.overflow = 0;
-        Bits b{expl, stride, S, S};
-        scan_external(b, traced, neg, y_lo, y_hi, 2, sink);
+        if (in_lds) {
+            Bits b{L_img + pw + 1, pw, wrows, wwords * 32, 1};
+            scan_external(b, L_tr + pw + 1, L_ng + pw + 1, 0, wrows - 1, 2, sink);
+            const int npt = sink.n_pts < sc.cap_pts ? sink.n_pts : sc.cap_pts;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            for (int i = lane; i < npt; i += 64) { int2 q = pts[i]; q.x += w_lo * 32; q.y += y_lo; pts[i] = q; }  // -> image coords
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        } else {
+            Bits b{expl, stride, S, S};
+            scan_external(b, traced, neg, y_lo, y_hi, 2, sink);
+        }
         int chosen = -1;
         if (!sink.overflow && sink.n_contours > 1) {
             // OpenCV order = reverse discovery.  First contour with dist >= 0 wins outright; otherwise the first strict
@@ -699,6 +743,7 @@ struct FrontierScratch {
     int* out_n;                            // [n_envs][4]: n frontiers, overflow, n contours, n chain points
     int cap_pts, cap_contours, cap_frontiers;
     double area_thresh;
+    unsigned lds_bytes;  // dynamic LDS available for the window copy of the border walk
 };
 
 __device__ inline unsigned ring_all_set(const unsigned* plane, int S, int stride, int tid, int nth) {
@@ -715,6 +760,29 @@ __device__ inline int reflect101(int i, int n) {
     if (i < 0) i = -i;
     if (i >= n) i = 2 * n - 2 - i;
     return i < 0 ? 0 : i;
+}
+
+// obstacle_map.py:159-163 + the first lines of detect_frontier_waypoints: explored_d = dilate(explored, 5x5) & navigable,
+// unexplored = navigable & ~explored_d, for every listed environment, one thread per 32-cell word.
+__global__ __launch_bounds__(256) void frontier_prepare_kernel(const FogParams* __restrict__ prm, MapPlanes mp,
+                                                               unsigned* __restrict__ explored_d,
+                                                               unsigned* __restrict__ unexplored) {
+    const FogParams& P = prm[blockIdx.z];
+    if (P.n_poly <= 0) return;
+    const int S = mp.S, stride = mp.stride;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= S * stride) return;
+    const size_t eoff = (size_t)P.env * S * stride;
+    const unsigned* expl = mp.explored + eoff;
+    const int y = idx / stride, wi = idx - y * stride;
+    unsigned acc = 0;
+    for (int dy = -2; dy <= 2; dy++)
+        acc |= hdilate(row_word(expl, stride, S, y + dy, wi - 1), row_word(expl, stride, S, y + dy, wi),
+                       row_word(expl, stride, S, y + dy, wi + 1), 2);
+    const unsigned nv = mp.navigable[eoff + idx];
+    acc &= nv & tail_mask(S, wi);
+    explored_d[eoff + idx] = acc;
+    unexplored[eoff + idx] = nv & ~acc;
 }
 
 __global__ __launch_bounds__(256) void frontier_kernel(const FogParams* __restrict__ prm, MapPlanes mp, FrontierScratch sc,
@@ -742,23 +810,9 @@ __global__ __launch_bounds__(256) void frontier_kernel(const FogParams* __restri
     if (tid == 0) sh_i[0] = 1;
     __syncthreads();
     VLFM_PHASE(2, 0);
-    // ---- a. explored_d = dilate(explored, 5x5) & navigable ; unexplored = navigable & ~explored_d   (full planes)
+    // ---- a. explored_d = dilate(explored, 5x5) & navigable ; unexplored = navigable & ~explored_d: full-plane, embarrassingly
+    // parallel -> done for all environments at once by frontier_prepare_kernel (a single workgroup took ~125 us for it)
     unsigned ring_ok = 1;
-    for (int idx = tid; idx < S * stride; idx += nth) {
-        const int y = idx / stride, wi = idx - y * stride;
-        unsigned acc = 0;
-        for (int dy = -2; dy <= 2; dy++)
-            acc |= hdilate(row_word(expl, stride, S, y + dy, wi - 1), row_word(expl, stride, S, y + dy, wi),
-                           row_word(expl, stride, S, y + dy, wi + 1), 2);
-        const unsigned nv = navp[idx];
-        acc &= nv & tail_mask(S, wi);
-        ed[idx] = acc;
-        un[idx] = nv & ~acc;
-        traced[idx] = 0u;
-        neg[idx] = 0u;
-    }
-    __threadfence();
-    __syncthreads();
     VLFM_PHASE(2, 1);
     // ---- b. filter_out_small_unexplored.  Exact shortcut: when the border ring of `unexplored` is fully set, that one
     // component encloses every other one, RETR_EXTERNAL returns it alone and its contour area is (S-1)^2.
@@ -767,6 +821,9 @@ __global__ __launch_bounds__(256) void frontier_kernel(const FogParams* __restri
     __syncthreads();
     const bool shortcut = sh_i[0] && ((double)(S - 1) * (double)(S - 1) >= sc.area_thresh);
     if (!shortcut) {
+        for (int i = tid; i < S * stride; i += nth) { traced[i] = 0u; neg[i] = 0u; }
+        __threadfence();
+        __syncthreads();
         if (wave == 0) {
             ContourSink sink;
             sink.pts = pts; sink.start = cstart; sink.len = clen; sink.cap_pts = sc.cap_pts; sink.cap_contours = sc.cap_contours;
@@ -833,14 +890,47 @@ __global__ __launch_bounds__(256) void frontier_kernel(const FogParams* __restri
     VLFM_PHASE(2, 2);
     // ---- c. border chain (CHAIN_APPROX_NONE) of the filtered explored mask
     const int* bb = bbox + (size_t)P.env * 4;
-    if (wave == 0) {
-        ContourSink sink;
-        sink.pts = pts; sink.start = cstart; sink.len = clen; sink.cap_pts = sc.cap_pts; sink.cap_contours = sc.cap_contours;
-        sink.n_pts = 0; sink.n_contours = 0; sink.overflow = 0;
-        Bits b{ed, stride, S, S};
+    {
+        // single-lane pointer chase again: walk an LDS copy of the window when it fits (see explored_select_kernel).  In the
+        // shortcut case the filtered mask is dilate(explored, 5x5) & navigable, i.e. inside the bounding box grown by 2.
+        extern __shared__ __attribute__((aligned(16))) unsigned lds_win[];
         const int y_lo = shortcut ? max(bb[0] - 3, 0) : 0, y_hi = shortcut ? min(bb[1] + 3, S - 1) : S - 1;
-        scan_external(b, traced, neg, y_lo, y_hi, 1, sink);
-        if (lane == 0) { sh_i[5] = sink.n_contours; sh_i[6] = sink.n_pts; sh_i[7] = sink.overflow; }
+        const int w_lo = shortcut ? (max(bb[2] - 3, 0) >> 5) : 0, w_hi = shortcut ? (min(bb[3] + 3, S - 1) >> 5) : stride - 1;
+        const int wrows = y_hi - y_lo + 1, wwords = w_hi - w_lo + 1;
+        const int pw = wwords + 2, wn = (wrows + 2) * pw;  // padded (Bits::padded)
+        const bool in_lds = wrows > 0 && (size_t)3 * wn * sizeof(unsigned) <= sc.lds_bytes;
+        unsigned* L_img = lds_win;
+        unsigned* L_tr = lds_win + wn;
+        unsigned* L_ng = lds_win + 2 * wn;
+        if (in_lds) {
+            for (int i = tid; i < wn; i += nth) {
+                const int ly = i / pw - 1, lw = i % pw - 1;
+                const bool real = (unsigned)ly < (unsigned)wrows && (unsigned)lw < (unsigned)wwords;
+                L_img[i] = real ? ed[(size_t)(y_lo + ly) * stride + w_lo + lw] : 0u;
+                L_tr[i] = 0u; L_ng[i] = 0u;
+            }
+        } else if (shortcut) {  // (the other branch zeroed the whole label planes after its own scan)
+            for (int i = tid + y_lo * stride; i < (y_hi + 1) * stride; i += nth) { traced[i] = 0u; neg[i] = 0u; }
+            __threadfence();
+        }
+        __syncthreads();
+        if (wave == 0) {
+            ContourSink sink;
+            sink.pts = pts; sink.start = cstart; sink.len = clen; sink.cap_pts = sc.cap_pts; sink.cap_contours = sc.cap_contours;
+            sink.n_pts = 0; sink.n_contours = 0; sink.overflow = 0;
+            if (in_lds) {
+                Bits b{L_img + pw + 1, pw, wrows, wwords * 32, 1};
+                scan_external(b, L_tr + pw + 1, L_ng + pw + 1, 0, wrows - 1, 1, sink);
+                const int npt = sink.n_pts < sc.cap_pts ? sink.n_pts : sc.cap_pts;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                for (int i = lane; i < npt; i += 64) { int2 q = pts[i]; q.x += w_lo * 32; q.y += y_lo; pts[i] = q; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            } else {
+                Bits b{ed, stride, S, S};
+                scan_external(b, traced, neg, y_lo, y_hi, 1, sink);
+            }
+            if (lane == 0) { sh_i[5] = sink.n_contours; sh_i[6] = sink.n_pts; sh_i[7] = sink.overflow; }
+        }
     }
     __threadfence();
     __syncthreads();
@@ -1011,6 +1101,10 @@ extern "C" int vlfm_find_contours_external(const uint32_t* d_img, int planes, in
 
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
+// dynamic LDS for the border walks of explored_select / frontier: image + two label planes of a window up to ~640 x 640
+// cells (the chip has 160 KB per CU; these kernels run one narrow workgroup per environment, so occupancy is irrelevant)
+constexpr unsigned kWalkLdsBytes = 144 * 1024;
+
 struct ScratchLayout {
     size_t plane_words, total;
     size_t off_planes[6], off_pts, off_lines, off_starts, off_lens, off_bad, off_pieces, off_status;
@@ -1073,7 +1167,7 @@ extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, in
     {
         FogScratch fs{pts, starts, lens, lines, status, d_bbox, cap_pts, cap_contours};
         const int wn = 2 * fog_radius + 5, words = (wn + 31) / 32;
-        const size_t lds = (size_t)8 * wn * words * 4 + 64;
+        const size_t lds = (size_t)8 * wn * words * 4 + (size_t)3 * (wn + 2) * (words + 2) * 4 + 64;
         if (lds > 160 * 1024) return fail(VLFM_ERR_CAPACITY, "obstacle_map_update_batched: fog window too large for LDS");
         VLFM_TIMED("fog_of_war_kernel", s);
         VLFM_KLAUNCH(fog_of_war_kernel, dim3(n), dim3(256), lds, s, d_prm, mp, fs);
@@ -1081,19 +1175,32 @@ extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, in
     rc = check_launch("fog_of_war_kernel");
     if (rc != VLFM_OK) return rc;
     {
+        static bool lds_opt_in = false;  // > 64 KB of dynamic LDS needs an explicit opt-in per kernel
+        if (!lds_opt_in) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(explored_select_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWalkLdsBytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(frontier_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWalkLdsBytes);
+            lds_opt_in = true;
+        }
         SelectScratch ss{planes[0], planes[1], planes[2], planes[3], pts, starts, lens, status + (size_t)n_envs * 4,
-                         cap_pts, cap_contours};
+                         cap_pts, cap_contours, kWalkLdsBytes};
         VLFM_TIMED("explored_select_kernel", s);
-        VLFM_KLAUNCH(explored_select_kernel, dim3(n), dim3(256), 0, s, d_prm, mp, ss, (const int*)d_bbox);
+        VLFM_KLAUNCH(explored_select_kernel, dim3(n), dim3(256), kWalkLdsBytes, s, d_prm, mp, ss, (const int*)d_bbox);
     }
     rc = check_launch("explored_select_kernel");
     if (rc != VLFM_OK) return rc;
     {
         FrontierScratch fr{planes[4], planes[5], planes[0], planes[1], planes[2], planes[3], pts, starts, lens,
                            (unsigned char*)(base + L.off_bad), (int*)(base + L.off_pieces), d_frontiers, d_counts,
-                           cap_pts, cap_contours, cap_frontiers, area_thresh_px};
+                           cap_pts, cap_contours, cap_frontiers, area_thresh_px, kWalkLdsBytes};
+        {
+            VLFM_TIMED("frontier_prepare_kernel", s);
+            VLFM_KLAUNCH(frontier_prepare_kernel, dim3((map_size * stride + 255) / 256, 1, n), dim3(256), 0, s, d_prm, mp,
+                         planes[4], planes[5]);
+        }
         VLFM_TIMED("frontier_kernel", s);
-        VLFM_KLAUNCH(frontier_kernel, dim3(n), dim3(256), 0, s, d_prm, mp, fr, (const int*)d_bbox);
+        VLFM_KLAUNCH(frontier_kernel, dim3(n), dim3(256), kWalkLdsBytes, s, d_prm, mp, fr, (const int*)d_bbox);
     }
     return check_launch("frontier_kernel");
 }
@@ -1101,6 +1208,16 @@ extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, in
 #ifdef VLFM_PHASE_TIMING
 extern "C" int vlfm_debug_phase_clocks(long long* h_out /* [3][16] */) {
     return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(vlfm::g_phase_clock), sizeof(long long) * 48) == hipSuccess ? VLFM_OK : VLFM_ERR_HIP;
+}
+extern "C" int vlfm_debug_walk_stats(long long* h_out /* ticks, points, calls; reset afterwards */) {
+    long long z = 0;
+    if (hipMemcpyFromSymbol(&h_out[0], HIP_SYMBOL(vlfm::g_walk_ticks), 8) != hipSuccess) return VLFM_ERR_HIP;
+    (void)hipMemcpyFromSymbol(&h_out[1], HIP_SYMBOL(vlfm::g_walk_points), 8);
+    (void)hipMemcpyFromSymbol(&h_out[2], HIP_SYMBOL(vlfm::g_walk_calls), 8);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(vlfm::g_walk_ticks), &z, 8);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(vlfm::g_walk_points), &z, 8);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(vlfm::g_walk_calls), &z, 8);
+    return VLFM_OK;
 }
 #endif
 
