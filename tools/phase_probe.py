@@ -29,3 +29,7 @@ for k, nm in names.items():
 print(f"border walks, all envs and scans: {walk[0] * 0.01 / n / E:.0f} us per env-step inside follow_border, "
       f"{walk[1] / n / E:.0f} emitted points, {walk[2] / n / E:.1f} contours per env-step")
 print("frontier counts (frontiers, overflow, contours, chain points) env 0:", sim.obstacles.counts[0].tolist())
+st = np.zeros((E, 8), np.int32)
+ob = sim.obstacles
+_lib.lib().vlfm_obstacle_status(ctypes.c_void_p(ob.scratch.data_ptr()), ob.n_envs, ob.size, ob.CAP_PTS, ob.CAP_CONTOURS, ctypes.c_void_p(st.ctypes.data))
+print("fog status env 0 (overflow, obstacle contours, shadow lines, -) + select status (overflow, contours, chosen, refilled):", st[0].tolist())

@@ -192,7 +192,10 @@ __device__ inline void line2_clear(unsigned* plane, const Win& w, long long x1, 
 }
 
 // cv FillConvexPoly for a 16.16 quadrilateral (LINE_8), painting zeros
-__device__ inline void fill_convex_quad_clear(unsigned* plane, const Win& w, const long long* vx, const long long* vy) {
+// part < 0: everything; part 0..3: only outline edge `part`; part 4: only the interior scanlines (all parts clear bits, so
+// they may run concurrently on different lanes)
+__device__ inline void fill_convex_quad_clear(unsigned* plane, const Win& w, const long long* vx, const long long* vy,
+                                              int part = -1) {
     const int npts = 4, shift = XY_SHIFT;
     const int delta = 1 << shift >> 1;
     struct { int idx, di; long long x, dx; int ye; } edge[2];
@@ -204,9 +207,10 @@ __device__ inline void fill_convex_quad_clear(unsigned* plane, const Win& w, con
         if (vy[i] > ymax) ymax = vy[i];
         if (vx[i] > xmax) xmax = vx[i];
         if (vx[i] < xmin) xmin = vx[i];
-        line2_clear(plane, w, p0x, p0y, vx[i], vy[i]);
+        if (part < 0 || part == i) line2_clear(plane, w, p0x, p0y, vx[i], vy[i]);
         p0x = vx[i]; p0y = vy[i];
     }
+    if (part >= 0 && part < 4) return;
     xmin = (xmin + delta) >> shift; xmax = (xmax + delta) >> shift;
     ymin = (ymin + delta) >> shift; ymax = (ymax + delta) >> shift;
     if ((int)xmax < 0 || (int)ymax < 0 || (int)xmin >= w.S || (int)ymin >= w.S) return;
@@ -280,7 +284,10 @@ __device__ inline void circle_clear(unsigned* plane, const Win& w, int cx, int c
 }
 
 // cv ThickLine(thickness = 2) from integer p0 to p1, painting zeros (frontier_exploration's shadow cuts)
-__device__ inline void thick_line2_clear(unsigned* plane, const Win& w, int p0x, int p0y, int p1x, int p1y) {
+// part < 0: the whole line; parts 0..6 = the four outline edges, the interior, the two end discs (independent: every part
+// only clears bits), so that one line can be spread over seven lanes
+constexpr int THICK_LINE_PARTS = 7;
+__device__ inline void thick_line2_clear(unsigned* plane, const Win& w, int p0x, int p0y, int p1x, int p1y, int part = -1) {
     const long long a0x = (long long)p0x << XY_SHIFT, a0y = (long long)p0y << XY_SHIFT;
     const long long a1x = (long long)p1x << XY_SHIFT, a1y = (long long)p1y << XY_SHIFT;
     const double INV = 1. / XY_ONE;
@@ -292,11 +299,11 @@ __device__ inline void thick_line2_clear(unsigned* plane, const Win& w, int p0x,
         const long long dpx = __double2ll_rn(__dmul_rn(dy, r)), dpy = __double2ll_rn(__dmul_rn(dx, r));
         const long long vx[4] = {a0x + dpx, a0x - dpx, a1x - dpx, a1x + dpx};
         const long long vy[4] = {a0y + dpy, a0y - dpy, a1y - dpy, a1y + dpy};
-        fill_convex_quad_clear(plane, w, vx, vy);
+        if (part < 5) fill_convex_quad_clear(plane, w, vx, vy, part);
     }
     const int rad = (int)((thickness + (XY_ONE >> 1)) >> XY_SHIFT);
-    circle_clear(plane, w, p0x, p0y, rad);
-    circle_clear(plane, w, p1x, p1y, rad);
+    if (part < 0 || part == 5) circle_clear(plane, w, p0x, p0y, rad);
+    if (part < 0 || part == 6) circle_clear(plane, w, p1x, p1y, rad);
 }
 
 // |cv::pointPolygonTest(contour, pt, true)| and the inside flag for an integer contour; evaluated by one wavefront.
@@ -396,7 +403,7 @@ __device__ inline unsigned load_window_word(const unsigned* plane, int S, int st
     return out;
 }
 
-__global__ __launch_bounds__(256) void fog_of_war_kernel(const FogParams* __restrict__ prm, MapPlanes mp, FogScratch sc) {
+__global__ __launch_bounds__(1024) void fog_of_war_kernel(const FogParams* __restrict__ prm, MapPlanes mp, FogScratch sc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const FogParams& P = prm[blockIdx.x];
     if (P.n_poly <= 0) return;
@@ -527,12 +534,15 @@ __global__ __launch_bounds__(256) void fog_of_war_kernel(const FogParams* __rest
     if (tid == 0) status[2] = n_lines;
     VLFM_PHASE(0, 4);
     // ---- 5. cut the visible mask with 2-px lines from every point away from the agent (cv2.polylines, color 0)
-    for (int i = tid; i < n_lines; i += nth) {
+    // one (part, line) task per lane, PART-MAJOR so that a wavefront runs one code path (edge / interior / end disc): the
+    // critical path becomes one edge + one interior + one disc instead of a whole line
+    for (int t = tid; t < n_lines * THICK_LINE_PARTS; t += nth) {
+        const int part = t / n_lines, i = t - part * n_lines;
         const int px = lines[i].x + ox, py = lines[i].y + oy;  // image coordinates
         const double ang = atan2((double)(py - P.ay), (double)(px - P.ax));
         const double ex = __dadd_rn((double)px, __dmul_rn(P.line_len, cos(ang)));
         const double ey = __dadd_rn((double)py, __dmul_rn(P.line_len, sin(ang)));
-        thick_line2_clear(vis, W, px, py, (int)ex, (int)ey);  // .astype(np.int32): truncation
+        thick_line2_clear(vis, W, px, py, (int)ex, (int)ey, part);  // .astype(np.int32): truncation
     }
     __syncthreads();
     VLFM_PHASE(0, 5);
@@ -939,6 +949,11 @@ __global__ __launch_bounds__(256) void frontier_kernel(const FogParams* __restri
     VLFM_PHASE(2, 3);
     // ---- d. a chain point is "bad" when no unexplored-navigable cell lies in its 3x3 neighbourhood
     //         (cv2.blur 3x3, BORDER_REFLECT_101, of 255*(navigable & ~filtered) is zero there)
+    // the flags are consumed by a single lane below: keep them in LDS (the walk window is free again) when they fit
+    {
+        extern __shared__ __attribute__((aligned(16))) unsigned lds_win[];
+        if ((unsigned)npts_all <= sc.lds_bytes) bad = reinterpret_cast<unsigned char*>(lds_win);
+    }
     for (int i = tid; i < npts_all; i += nth) {
         const int2 p = pts[i];
         unsigned any = 0;
@@ -965,7 +980,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(const FogParams* __restri
         for (int c = nc - 1; c >= 0; c--) {
             const int n = clen[c], base = cstart[c];
             if (n < 2) continue;  // a single-pixel contour interpolates to nothing
-            auto is_bad = [&](int j) { return bad[base + (j + 1) % n] != 0; };  // chain rotated by one
+            auto is_bad = [&](int j) { return bad[base + (j + 1 == n ? 0 : j + 1)] != 0; };  // chain rotated by one
             int nbad = 0, first_bad = -1, last_bad = -1;
             for (int j = 0; j < n; j++)
                 if (is_bad(j)) { if (first_bad < 0) first_bad = j; last_bad = j; nbad++; }
@@ -1001,45 +1016,55 @@ __global__ __launch_bounds__(256) void frontier_kernel(const FogParams* __restri
     __threadfence();
     __syncthreads();
     const int np = sh_i[8];
-    for (int f = tid; f < np; f += nth) {
-        const int* pc = pieces + 6 * f;
-        const int base = pc[0], n = pc[1], s1 = pc[2], l1 = pc[3], s2 = pc[4], l2 = pc[5];
-        const int m = l1 + l2;
-        auto q = [&](int j) { const int k = j < l1 ? s1 + j : s2 + (j - l1); return pts[base + (k + 1) % n]; };
-        double ox_ = 0, oy_ = 0;
-        if (m < 2) {
-            if (m == 1) { const int2 p = q(0); ox_ = p.x; oy_ = p.y; }
-        } else {
-            // get_frontier_midpoint: np.cumsum of segment lengths (sequential f64), first index with cum > total/2
-            double total = 0;
-            for (int k = 0; k + 1 < m; k++) {
+    // get_frontier_midpoint per piece.  The arc-length cumsum is sequential by definition (np.cumsum's rounding order), but
+    // the segment lengths are not: all lanes compute them (f64 sqrt, chain indexing) into LDS, then one lane only adds.
+    {
+        extern __shared__ __attribute__((aligned(16))) unsigned lds_win[];
+        const size_t seg_off = ((size_t)npts_all + 7) & ~(size_t)7;   // after the bad flags (when those live in LDS)
+        const bool bad_in_lds = (unsigned)npts_all <= sc.lds_bytes;
+        double* seg = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(lds_win) + (bad_in_lds ? seg_off : 0));
+        const size_t seg_cap = (sc.lds_bytes - (bad_in_lds ? seg_off : 0)) / sizeof(double);
+        for (int f = 0; f < np; f++) {
+            const int* pc = pieces + 6 * f;
+            const int base = pc[0], n = pc[1], s1 = pc[2], l1 = pc[3], s2 = pc[4], l2 = pc[5];
+            const int m = l1 + l2;
+            auto q = [&](int j) { const int k = j < l1 ? s1 + j : s2 + (j - l1); int idx = k + 1; if (idx >= n) idx -= n; if (idx >= n) idx %= n; return pts[base + idx]; };
+            auto seglen = [&](int k) {
                 const int2 a = q(k), b = q(k + 1);
                 const double ddx = (double)(a.x - b.x), ddy = (double)(a.y - b.y);
-                total = __dadd_rn(total, sqrt(__dadd_rn(__dmul_rn(ddx, ddx), __dmul_rn(ddy, ddy))));
+                return sqrt(__dadd_rn(__dmul_rn(ddx, ddx), __dmul_rn(ddy, ddy)));
+            };
+            const bool staged = m >= 2 && (size_t)(m - 1) <= seg_cap;
+            if (staged)
+                for (int k = tid; k + 1 < m; k += nth) seg[k] = seglen(k);
+            __syncthreads();
+            if (tid == 0) {
+                double ox_ = 0, oy_ = 0;
+                if (m < 2) {
+                    if (m == 1) { const int2 p = q(0); ox_ = p.x; oy_ = p.y; }
+                } else {
+                    double total = 0;
+                    for (int k = 0; k + 1 < m; k++) total = __dadd_rn(total, staged ? seg[k] : seglen(k));
+                    const double half = total / 2;
+                    double cum = 0, upto = 0, sl = 0;
+                    int idx = 0;
+                    bool found = false;
+                    for (int k = 0; k + 1 < m; k++) {
+                        const double l = staged ? seg[k] : seglen(k);
+                        const double c2 = __dadd_rn(cum, l);
+                        if (c2 > half) { idx = k; upto = k > 0 ? cum : 0; sl = l; found = true; break; }
+                        cum = c2;
+                    }
+                    if (!found) { idx = 0; upto = 0; sl = staged ? seg[0] : seglen(0); }
+                    const double prop = __ddiv_rn(__dsub_rn(half, upto), sl);
+                    const int2 a = q(idx), b = q(idx + 1);
+                    ox_ = __dadd_rn((double)a.x, __dmul_rn(prop, (double)(b.x - a.x)));
+                    oy_ = __dadd_rn((double)a.y, __dmul_rn(prop, (double)(b.y - a.y)));
+                }
+                if (f < sc.cap_frontiers) { out_xy[2 * f] = ox_; out_xy[2 * f + 1] = oy_; }
             }
-            const double half = total / 2;
-            double cum = 0, upto = 0, seglen = 0;
-            int idx = 0;
-            bool found = false;
-            for (int k = 0; k + 1 < m; k++) {
-                const int2 a = q(k), b = q(k + 1);
-                const double ddx = (double)(a.x - b.x), ddy = (double)(a.y - b.y);
-                const double l = sqrt(__dadd_rn(__dmul_rn(ddx, ddx), __dmul_rn(ddy, ddy)));
-                const double c2 = __dadd_rn(cum, l);
-                if (c2 > half) { idx = k; upto = k > 0 ? cum : 0; seglen = l; found = true; break; }
-                cum = c2;
-            }
-            if (!found) {
-                const int2 a = q(0), b = q(1);
-                const double ddx = (double)(a.x - b.x), ddy = (double)(a.y - b.y);
-                idx = 0; upto = 0; seglen = sqrt(__dadd_rn(__dmul_rn(ddx, ddx), __dmul_rn(ddy, ddy)));
-            }
-            const double prop = __ddiv_rn(__dsub_rn(half, upto), seglen);
-            const int2 a = q(idx), b = q(idx + 1);
-            ox_ = __dadd_rn((double)a.x, __dmul_rn(prop, (double)(b.x - a.x)));
-            oy_ = __dadd_rn((double)a.y, __dmul_rn(prop, (double)(b.y - a.y)));
+            __syncthreads();
         }
-        if (f < sc.cap_frontiers) { out_xy[2 * f] = ox_; out_xy[2 * f + 1] = oy_; }
     }
     VLFM_PHASE(2, 5);
     if (tid == 0) {
@@ -1170,7 +1195,7 @@ extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, in
         const size_t lds = (size_t)8 * wn * words * 4 + (size_t)3 * (wn + 2) * (words + 2) * 4 + 64;
         if (lds > 160 * 1024) return fail(VLFM_ERR_CAPACITY, "obstacle_map_update_batched: fog window too large for LDS");
         VLFM_TIMED("fog_of_war_kernel", s);
-        VLFM_KLAUNCH(fog_of_war_kernel, dim3(n), dim3(256), lds, s, d_prm, mp, fs);
+        VLFM_KLAUNCH(fog_of_war_kernel, dim3(n), dim3(1024), lds, s, d_prm, mp, fs);
     }
     rc = check_launch("fog_of_war_kernel");
     if (rc != VLFM_OK) return rc;
