@@ -219,3 +219,37 @@ def test_multi_camera_same_slot_is_sequential_and_batch_rejects_duplicates(gpu_d
         vb.update(np.array([[0.3], [0.4]]), d, tfs, MIN_DEPTH, MAX_DEPTH, _fov(), env_ids=[1, 1])
     with pytest.raises(AssertionError, match="out of range"):
         vb.update(np.array([[0.3]]), d[:1], tfs[:1], MIN_DEPTH, MAX_DEPTH, _fov(), env_ids=[2])
+
+
+@pytest.mark.parametrize("size,hfov_deg,max_depth,hw", [(500, 60.0, 3.5, (240, 320)), (700, 90.0, 8.0, (480, 640))])
+def test_other_map_sizes_and_camera_models(gpu_device, size, hfov_deg, max_depth, hw):
+    """Nothing is specialised to S = 1000 / fov = 79 deg / 5 m: other map sizes (tail words of the bit planes), cone template
+    sizes (T = 2 int(max_depth ppm) + 1) and image shapes against the oracle, both maps, with sort_waypoints."""
+    from oracle.ref_obstacle_map import RefObstacleMap
+    from oracle.ref_value_map import RefValueMap
+    from vlfm_amd.mapping import ObstacleMap, ValueMap
+    from vlfm_amd.synthetic import depth_frame
+
+    H, W = hw
+    fx, fy, fov = camera_intrinsics(W, hfov_deg)
+    rng = np.random.default_rng(size)
+    kw = dict(min_height=0.61, max_height=0.88, agent_radius=0.18, area_thresh=1.5, size=size)
+    ours_o, ref_o = ObstacleMap(device=gpu_device, **kw), RefObstacleMap(**kw)
+    ours_v = ValueMap(1, size=size, use_max_confidence=False, device=gpu_device)
+    ref_v = RefValueMap(1, size=size, use_max_confidence=False)
+    for t in range(8):
+        depth = depth_frame(rng, H, W)
+        tf = pose_to_tf(0.3 * t, -0.2 * t, 0.6 * t)
+        vals = rng.uniform(0.15, 0.45, 1)
+        for o in (ours_o, ref_o):
+            o.update_map(depth.copy(), tf, MIN_DEPTH, max_depth, fx, fy, fov)
+        ours_v.update_map(vals, depth, tf, MIN_DEPTH, max_depth, fov)
+        ref_v.update_map(vals, depth.copy(), tf, MIN_DEPTH, max_depth, fov)
+        assert np.array_equal(ours_o._map, ref_o._map) and np.array_equal(ours_o.explored_area, ref_o.explored_area), t
+        assert np.array_equal(np.asarray(ours_o._frontiers_px, np.float64).reshape(-1, 2),
+                              np.asarray(ref_o._frontiers_px, np.float64).reshape(-1, 2)), t
+    _compare(ours_v, ref_v)
+    if len(ref_o.frontiers):
+        a, av = ours_v.sort_waypoints(ref_o.frontiers, 0.5)
+        b, bv = ref_v.sort_waypoints(ref_o.frontiers, 0.5)
+        assert np.array_equal(a, b) and np.allclose(av, bv, atol=TOL)

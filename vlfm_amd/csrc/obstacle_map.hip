@@ -416,9 +416,7 @@ __global__ __launch_bounds__(1024) void fog_of_war_kernel(const FogParams* __res
     unsigned* nav = par + plane_words;
     unsigned* obst = nav + plane_words;
     unsigned* vis = obst + plane_words;
-    unsigned* traced = vis + plane_words;
-    unsigned* neg = traced + plane_words;
-    unsigned* fill = neg + plane_words;
+    unsigned* fill = vis + plane_words;
     // padded copies for the two border scans (Bits::padded): image + both label planes, (wn + 2) x (words + 2) words each
     const int pw = words + 2, pad_words = (wn + 2) * pw;
     unsigned* p_img = fill + plane_words;
@@ -435,7 +433,7 @@ __global__ __launch_bounds__(1024) void fog_of_war_kernel(const FogParams* __res
     int4* lines = sc.lines + (size_t)P.env * sc.cap_pts;
     int* status = sc.status + (size_t)P.env * 4;
 
-    for (int i = tid; i < 8 * plane_words; i += nth) cone[i] = 0u;
+    for (int i = tid; i < 6 * plane_words; i += nth) cone[i] = 0u;
     if (tid < 16) sh_i[tid] = 0;
     __syncthreads();
 
@@ -1192,8 +1190,11 @@ extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, in
     {
         FogScratch fs{pts, starts, lens, lines, status, d_bbox, cap_pts, cap_contours};
         const int wn = 2 * fog_radius + 5, words = (wn + 31) / 32;
-        const size_t lds = (size_t)8 * wn * words * 4 + (size_t)3 * (wn + 2) * (words + 2) * 4 + 64;
+        const size_t lds = (size_t)6 * wn * words * 4 + (size_t)3 * (wn + 2) * (words + 2) * 4 + 64;
         if (lds > 160 * 1024) return fail(VLFM_ERR_CAPACITY, "obstacle_map_update_batched: fog window too large for LDS");
+        if (lds > 64 * 1024)  // beyond the default dynamic-LDS limit (max_depth * pixels_per_meter > ~110 cells)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fog_of_war_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         VLFM_TIMED("fog_of_war_kernel", s);
         VLFM_KLAUNCH(fog_of_war_kernel, dim3(n), dim3(1024), lds, s, d_prm, mp, fs);
     }
