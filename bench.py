@@ -100,6 +100,35 @@ def cpu_baseline(args, with_blip2: bool):
     except ImportError:
         om = None
     fx, fy, _ = camera_intrinsics(args.width)
+    # per-stage CPU times: wrap the oracle's stage functions with wall-clock accumulators
+    stage_s: dict = {}
+
+    def timed(mod, name, label):
+        fn = getattr(mod, name)
+
+        def wrapper(*a, **k):
+            t0 = time.perf_counter()
+            try:
+                return fn(*a, **k)
+            finally:
+                stage_s[label] = stage_s.get(label, 0.0) + time.perf_counter() - t0
+
+        setattr(mod, name, wrapper)
+        return fn
+
+    import oracle.ref_obstacle_map as rom_
+    import oracle.ref_value_map as rvm_
+
+    restore = [(rvm_.RefValueMap, "_process_local_data", timed(rvm_.RefValueMap, "_process_local_data", "depth profile + polygon cut")),
+               (rvm_, "rotate_about_centre", timed(rvm_, "rotate_about_centre", "rotate (warpAffine)")),
+               (rvm_, "paste_centred", timed(rvm_, "paste_centred", "place")),
+               (rvm_.RefValueMap, "_fuse_new_data", timed(rvm_.RefValueMap, "_fuse_new_data", "fuse (full-map NumPy passes)")),
+               (rvm_.RefValueMap, "sort_waypoints", timed(rvm_.RefValueMap, "sort_waypoints", "sort_waypoints")),
+               (rom_, "fill_small_holes", timed(rom_, "fill_small_holes", "fill_small_holes")),
+               (rom_, "unproject", timed(rom_, "unproject", "unproject")),
+               (rom_, "apply_tf", timed(rom_, "apply_tf", "transform_points")),
+               (rom_, "reveal_fog_of_war", timed(rom_, "reveal_fog_of_war", "reveal_fog_of_war")),
+               (rom_, "detect_frontier_waypoints", timed(rom_, "detect_frontier_waypoints", "detect_frontier_waypoints"))]
     # maps: warm-up populates the confidence-mask cache, then a bounded timed sample
     n_map = 60
     obs = [env.observe() for _ in range(n_map + 5)]
@@ -114,6 +143,10 @@ def cpu_baseline(args, with_blip2: bool):
         dt = time.perf_counter() - t0
         if i >= 5:
             t_map += dt
+        else:
+            stage_s.clear()  # warm-up steps do not count
+    for owner, name, fn in restore:
+        setattr(owner, name, fn)
     map_s = t_map / n_map
     blip_s = 0.0
     if with_blip2:
@@ -155,6 +188,7 @@ def cpu_baseline(args, with_blip2: bool):
                    + (f" + {args.cpu_steps} BLIP-2 ITC fp32 forwards on {cores} torch threads ({blip_s * 1e3:.0f} ms/frame)"
                       if with_blip2 else " (BLIP-2 leg skipped)")),
         "maps_only_env_steps_per_s": round(1.0 / map_s, 2),
+        "map_stage_ms_per_step": {k: round(v / n_map * 1e3, 3) for k, v in sorted(stage_s.items(), key=lambda kv: -kv[1])},
     }
 
 
