@@ -85,8 +85,15 @@ def install() -> None:
     tv_ops = types.ModuleType("torchvision.ops")
     tv_ops.box_convert = _box_convert
     tv.ops = tv_ops
+    # grounding_dino.py:7 imports torchvision.transforms.functional at module level (only used inside the model server)
+    tv_tf = types.ModuleType("torchvision.transforms")
+    tv_tf.__path__ = []
+    tv_tf.functional = types.ModuleType("torchvision.transforms.functional")
+    tv.transforms = tv_tf
     sys.modules.setdefault("torchvision", tv)
     sys.modules.setdefault("torchvision.ops", tv_ops)
+    sys.modules.setdefault("torchvision.transforms", tv_tf)
+    sys.modules.setdefault("torchvision.transforms.functional", tv_tf.functional)
     # open3d (object_point_cloud_map.py:7,186-192): PointCloud.points / Vector3dVector / cluster_dbscan only
     from . import ref_object_map as rom
 
@@ -102,6 +109,49 @@ def install() -> None:
     sys.modules.setdefault("open3d", o3d)
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
+
+
+def reference_policy():
+    """(vlfm.policy.itm_policy, vlfm.policy.base_objectnav_policy) of the real reference.
+
+    Needs two more stand-ins, both for things OUTSIDE the hot path (SURVEY.md section 8, row a24 is control flow only):
+    ``hydra.core.config_store.ConfigStore`` (base_objectnav_policy.py:10,387-388 registers a dataclass at import time)
+    and ``vlfm.policy.utils.pointnav_policy.WrappedPointNavResNetPolicy`` (needs gym + weights; the generator overrides
+    ``_pointnav`` anyway).  habitat_policies.py itself is not importable (habitat, omegaconf, depth_camera_filtering):
+    the few lines of HabitatMixin the episode needs are restated in tests/golden/make_golden.py, cited there."""
+    install()
+    import importlib
+
+    if "hydra.core.config_store" not in sys.modules:
+        class ConfigStore:  # noqa: D401 - registration sink
+            _inst = None
+
+            @classmethod
+            def instance(cls):
+                cls._inst = cls._inst or cls()
+                return cls._inst
+
+            def store(self, *a, **k):
+                return None
+
+        hydra, core, store = (types.ModuleType(n) for n in ("hydra", "hydra.core", "hydra.core.config_store"))
+        hydra.__path__, core.__path__ = [], []
+        store.ConfigStore = ConfigStore
+        hydra.core, core.config_store = core, store
+        sys.modules.update({"hydra": hydra, "hydra.core": core, "hydra.core.config_store": store})
+    if "vlfm.policy.utils.pointnav_policy" not in sys.modules:
+        pn = types.ModuleType("vlfm.policy.utils.pointnav_policy")
+
+        class WrappedPointNavResNetPolicy:
+            def __init__(self, *a, **k):
+                self.resets = 0
+
+            def reset(self):
+                self.resets += 1
+
+        pn.WrappedPointNavResNetPolicy = WrappedPointNavResNetPolicy
+        sys.modules["vlfm.policy.utils.pointnav_policy"] = pn
+    return importlib.import_module("vlfm.policy.itm_policy"), importlib.import_module("vlfm.policy.base_objectnav_policy")
 
 
 def reference_object_map():

@@ -26,8 +26,9 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-if ROOT not in sys.path:
-    sys.path.insert(0, ROOT)
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
 
 from vlfm_amd.synthetic import MAX_DEPTH, MIN_DEPTH, SyntheticEnv, camera_intrinsics  # noqa: E402
 
@@ -251,6 +252,190 @@ def gen_object_map(om_mod):
     return out
 
 
+def gen_policy(name):
+    """One scripted episode through THE REFERENCE'S ``ITMPolicyV2`` (vlfm/policy/itm_policy.py:236-267 on top of
+    BaseITMPolicy :26-234 and BaseObjectNavPolicy base_objectnav_policy.py:35-365, real source via
+    ref_shim.reference_policy(), over the reference's real ObstacleMap / ValueMap / ObjectPointCloudMap / ObjectDetections).
+    Only HabitatMixin (habitat_policies.py, needs habitat) is restated, in the subclass below, with line citations; the
+    four model clients are the scripted stand-ins of tests/golden/policy_script.py."""
+    import torch
+
+    from oracle import ref_shim
+
+    import policy_script as ps
+
+    itm_mod, base_mod = ref_shim.reference_policy()
+    det_mod = ref_shim.reference_detections()
+    geo = ref_shim.reference_modules()[2]
+
+    class _CpuTorch:  # BaseObjectNavPolicy._pointnav asks for device="cuda" (base_objectnav_policy.py:254,262): none here
+        def __getattr__(self, n):
+            return getattr(torch, n)
+
+        @staticmethod
+        def tensor(*a, device=None, **k):
+            return torch.tensor(*a, **k)
+
+    base_mod.torch = _CpuTorch()
+    seed, steps, dataset, goal_name, caption = ps.EPISODES[name]
+    vlm = ps.ScriptedVLM(name, det_mod.ObjectDetections)
+    log = dict(mode=[], nav_goal=[], best_value=[], last_frontier=[], stop=[], rho_theta=[], n_det=[], mask_px=[],
+               frontier_counts=[], frontiers=[], goal_xy=[], pointnav_resets=[])
+    TURN_LEFT, STOP = torch.tensor([[2]]), torch.tensor([[0]])  # TorchActionIDs habitat_policies.py:53-57
+
+    class ScriptedHabitatITMPolicyV2(itm_mod.ITMPolicyV2):
+        _stop_action = STOP
+
+        def __init__(self, camera_height, min_depth, max_depth, camera_fov, image_width, **kw):
+            super().__init__(**kw)
+            self._camera_height, self._min_depth, self._max_depth = camera_height, min_depth, max_depth  # :84-91
+            self._camera_fov = np.deg2rad(camera_fov)
+            self._fx = self._fy = image_width / (2 * np.tan(self._camera_fov / 2))
+            self._itm, self._coco_object_detector = vlm.itm, vlm.coco
+            self._object_detector, self._mobile_sam = vlm.gdino, vlm.sam
+
+            class _Act:
+                resets = 0
+
+                def reset(self):
+                    _Act.resets += 1
+
+                def act(self, obs, masks, deterministic=True):
+                    assert obs["depth"].shape[1:3] == (224, 224)
+                    return torch.tensor([[1]])
+
+            self._pointnav_policy = _Act()
+
+        def _initialize(self):  # habitat_policies.py:150-153
+            log["mode"].append("initialize")
+            self._done_initializing = not self._num_steps < 11
+            return TURN_LEFT
+
+        def _explore(self, observations):
+            log["mode"].append("explore")
+            return super()._explore(observations)
+
+        def _pointnav(self, goal, stop=False):
+            if stop:
+                log["mode"].append("navigate")
+            return super()._pointnav(goal, stop=stop)
+
+        def _cache_observations(self, observations):  # habitat_policies.py:173-237 (filter_depth: input is pre-filtered)
+            if len(self._observations_cache) > 0:
+                return
+            rgb, depth = observations["rgb"], observations["depth"]
+            x, y = observations["gps"]
+            camera_yaw = observations["compass"]
+            camera_position = np.array([x, -y, self._camera_height])
+            robot_xy = camera_position[:2]
+            tf = geo.xyz_yaw_to_tf_matrix(camera_position, camera_yaw)
+            self._obstacle_map.update_map(depth, tf, self._min_depth, self._max_depth, self._fx, self._fy, self._camera_fov)
+            frontiers = self._obstacle_map.frontiers
+            self._obstacle_map.update_agent_traj(robot_xy, camera_yaw)
+            self._observations_cache = {
+                "frontier_sensor": frontiers, "nav_depth": torch.from_numpy(depth.reshape(1, *depth.shape, 1)),
+                "robot_xy": robot_xy, "robot_heading": camera_yaw,
+                "object_map_rgbd": [(rgb, depth, tf, self._min_depth, self._max_depth, self._fx, self._fy)],
+                "value_map_rgbd": [(rgb, depth, tf, self._min_depth, self._max_depth, self._camera_fov)],
+                "habitat_start_yaw": camera_yaw,
+            }
+
+    cfg = base_mod.VLFMConfig()
+    kw = {k: getattr(cfg, k) for k in base_mod.VLFMConfig.kwaarg_names}  # the reference's own defaults
+    kw.update(visualize=False)
+    np.random.seed(777)  # ObjectPointCloudMap subsamples / tags with NumPy's global RNG
+    pol = ScriptedHabitatITMPolicyV2(camera_height=0.88, min_depth=MIN_DEPTH, max_depth=MAX_DEPTH, camera_fov=79.0,
+                                     image_width=ps.W, **kw)
+    if dataset == "mp3d":
+        pol._non_coco_caption = caption  # HabitatMixin.act habitat_policies.py:139-141
+    import contextlib
+    import io
+
+    world = ps.ScriptedWorld(name)
+    for _ in range(steps):
+        k, rgb, depth, x, y, yaw = world.observe()
+        obs = {"rgb": rgb, "depth": depth, "gps": (x, -y), "compass": yaw, "objectgoal": goal_name}
+        masks = torch.tensor([[k != 0]])
+        with contextlib.redirect_stdout(io.StringIO()):
+            try:
+                pol.act(obs, None, None, masks)
+            except StopIteration:  # habitat_policies.py:144-145
+                log["mode"].append("edge_of_map")
+        fr = np.asarray(pol._obstacle_map.frontiers, np.float64).reshape(-1, 2)
+        log["frontier_counts"].append(len(fr))
+        log["frontiers"].append(fr)
+        log["nav_goal"].append(np.asarray(pol._last_goal, np.float64))
+        log["best_value"].append(float(pol._last_value))
+        log["last_frontier"].append(np.asarray(pol._last_frontier, np.float64))
+        log["stop"].append(bool(pol._called_stop))
+        log["rho_theta"].append(np.asarray(pol._policy_info.get("rho_theta", [np.nan, np.nan]), np.float64))
+        world.advance(log["mode"][-1], *log["rho_theta"][-1])
+        log["mask_px"].append(int(pol._object_masks.sum()))
+        log["pointnav_resets"].append(int(pol._pointnav_policy.resets))
+        has = pol._object_map.has_object(goal_name)
+        log["goal_xy"].append(np.asarray(pol._object_map.last_target_coord if has and pol._object_map.last_target_coord
+                                         is not None else [np.nan, np.nan], np.float64))
+    conf_idx, conf_val = sparse(pol._value_map._map)
+    vmap = np.asarray(pol._value_map._value_map, np.float64)
+    assert not np.any(vmap.reshape(-1)[np.setdiff1d(np.arange(vmap.size), conf_idx)])  # value support within conf support
+    cloud = pol._object_map.clouds.get(goal_name, np.zeros((0, 4)))
+    return dict(
+        pose=np.array(world.poses, np.float64), wall=np.array(world.walls, np.float32),
+        mode=np.array(log["mode"]), nav_goal=np.array(log["nav_goal"]), best_value=np.array(log["best_value"]),
+        last_frontier=np.array(log["last_frontier"]), stop=np.array(log["stop"]), rho_theta=np.array(log["rho_theta"]),
+        mask_px=np.array(log["mask_px"], np.int64), pointnav_resets=np.array(log["pointnav_resets"], np.int32),
+        frontier_counts=np.array(log["frontier_counts"], np.int32),
+        frontiers=np.concatenate(log["frontiers"]) if sum(log["frontier_counts"]) else np.zeros((0, 2)),
+        goal_xy=np.array(log["goal_xy"]), prompts=np.array(vlm.prompts), captions=np.array(vlm.captions or [""]),
+        calls=np.array([f"{k}:{w}" for k, w in vlm.calls]),
+        conf_idx=conf_idx, conf_val=conf_val, value_val=vmap.reshape(-1)[conf_idx].astype(np.float32),  # f32: 1e-4 bar
+        value_sha=np.array(sha(vmap)),  # ... and the exact f64 map as a digest for the bit-exact CPU comparison
+        cloud_sig=np.array([str(len(cloud)), sha(np.asarray(cloud, np.float64))]),
+        explored=packbits(pol._obstacle_map.explored_area), obstacles=packbits(pol._obstacle_map._map))
+
+
+API = {
+    # reference module -> {class: [methods]} -- the drop-in boundary of SURVEY.md section 8(b)
+    "vlfm.mapping.base_map": {"BaseMap": ["__init__", "reset", "update_agent_traj", "_xy_to_px", "_px_to_xy"]},
+    "vlfm.mapping.value_map": {"ValueMap": ["__init__", "reset", "update_map", "sort_waypoints", "visualize"]},
+    "vlfm.mapping.obstacle_map": {"ObstacleMap": ["__init__", "reset", "update_map", "visualize"]},
+    "vlfm.mapping.object_point_cloud_map": {"ObjectPointCloudMap": [
+        "__init__", "reset", "has_object", "update_map", "get_best_object", "update_explored", "get_target_cloud"]},
+    "vlfm.vlm.blip2itm": {"BLIP2ITM": ["__init__", "cosine"], "BLIP2ITMClient": ["__init__", "cosine"]},
+    "vlfm.vlm.yolov7": {"YOLOv7": ["__init__", "predict"], "YOLOv7Client": ["__init__", "predict"]},
+    "vlfm.vlm.grounding_dino": {"GroundingDINO": ["__init__", "predict"], "GroundingDINOClient": ["__init__", "predict"]},
+    "vlfm.vlm.sam": {"MobileSAM": ["__init__", "segment_bbox"], "MobileSAMClient": ["__init__", "segment_bbox"]},
+    "vlfm.vlm.detections": {"ObjectDetections": ["__init__", "filter_by_conf", "filter_by_class", "to_json", "from_json"]},
+}
+
+
+def signature_table(resolve):
+    """{"module.Class.method": [[name, kind, default-repr or None], ...]} via inspect; ``resolve(module)`` imports it."""
+    import inspect
+
+    table = {}
+    for mod_name, classes in API.items():
+        mod = resolve(mod_name)
+        for cls_name, methods in classes.items():
+            cls = getattr(mod, cls_name)
+            for m in methods:
+                sig = inspect.signature(getattr(cls, m))
+                table[f"{mod_name}.{cls_name}.{m}"] = [
+                    [p.name, p.kind.name, None if p.default is inspect.Parameter.empty else repr(p.default)]
+                    for p in sig.parameters.values()]
+    return table
+
+
+def gen_api():
+    import importlib
+    import json
+
+    from oracle import ref_shim
+
+    ref_shim.reference_policy()  # installs every stand-in the vlm modules need at import time
+    return {"json": np.array(json.dumps(signature_table(importlib.import_module), sort_keys=True))}
+
+
 def generate():
     from oracle import ref_shim
 
@@ -264,6 +449,11 @@ def generate():
     out["helpers"] = gen_helpers(geo, img, ref_vm)
     out["detections"] = gen_detections(ref_shim.reference_detections())
     out["object_map"] = gen_object_map(ref_shim.reference_object_map())
+    import policy_script as ps
+
+    for name in ps.EPISODES:
+        out[name] = gen_policy(name)
+    out["api_signatures"] = gen_api()
     return out
 
 

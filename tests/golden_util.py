@@ -49,3 +49,56 @@ def split_frontiers(g):
 
 def unpack_plane(bits, size=1000):
     return np.unpackbits(bits)[: size * size].reshape(size, size).astype(bool)
+
+
+# ---------------------------------------------------------------------------------------------- policy episodes
+POLICY_CASES = ["policy_hm3d_chair", "policy_mp3d_table", "policy_mp3d_cabinet", "policy_hm3d_explore"]
+
+
+def replay_policy_episode(name, make_step, make_detections, tol=1e-4):
+    """Drive a ``vlfm_amd.policy_step.ITMPolicyV2Step`` (built by ``make_step(vlm, **kwargs)``) through the scripted episode
+    ``name`` and compare every step with what THE REFERENCE'S ``ITMPolicyV2`` did (tests/golden/<name>.npz).  Returns the
+    step object so that the caller can compare final maps."""
+    import sys
+
+    if GOLDEN_DIR not in sys.path:
+        sys.path.insert(0, GOLDEN_DIR)
+    import policy_script as ps
+
+    g = load(name)
+    seed, steps, dataset, goal_name, caption = ps.EPISODES[name]
+    vlm = ps.ScriptedVLM(name, make_detections)
+    world = ps.ScriptedWorld(name, recorded=(g["pose"], g["wall"]))
+    np.random.seed(777)  # ObjectPointCloudMap draws from NumPy's global RNG, as the reference does
+    pol = make_step(vlm, camera_height=0.88, min_depth=0.5, max_depth=5.0, camera_fov=79.0, image_width=ps.W,
+                    dataset_type=dataset, non_coco_caption=caption if dataset == "mp3d" else "")
+    pol.reset(goal_name)
+    offs = np.concatenate([[0], np.cumsum(g["frontier_counts"])])
+    resets = 1  # the reference's counter includes the reset() of the episode start
+    for k in range(steps):
+        _, rgb, depth, x, y, yaw = world.observe()
+        r = pol.step(rgb, depth, x, y, yaw)
+        where = f"{name} step {k}"
+        assert r.mode == str(g["mode"][k]), where
+        assert np.array_equal(r.frontiers, g["frontiers"][offs[k]:offs[k + 1]]), where  # bit-exact frontier list
+        assert np.array_equal(np.asarray(pol.last_goal, np.float64), g["nav_goal"][k]), where
+        want_rt = g["rho_theta"][k]
+        if np.isnan(want_rt[0]):
+            assert np.isnan(r.rho), where
+        else:
+            assert abs(r.rho - want_rt[0]) <= 1e-9 and abs(r.theta - want_rt[1]) <= 1e-9, where
+        assert pol.called_stop == bool(g["stop"][k]), where
+        if np.isfinite(g["best_value"][k]):
+            assert abs(r.best_value - g["best_value"][k]) <= tol, where
+        else:
+            assert r.best_value == g["best_value"][k], where
+        assert int(pol.object_masks.sum()) == int(g["mask_px"][k]), where
+        resets += int(r.pointnav_reset)
+        assert resets == int(g["pointnav_resets"][k]), where
+        world.advance(r.mode, r.rho, r.theta)
+    assert vlm.prompts == [str(p) for p in g["prompts"]]
+    assert [f"{k}:{w}" for k, w in vlm.calls] == [str(c) for c in g["calls"]]  # which model was asked, in which order
+    assert (vlm.captions or [""]) == [str(c) for c in g["captions"]]
+    cloud = pol.maps()[2].clouds.get(goal_name, np.zeros((0, 4)))
+    assert len(cloud) == int(g["cloud_sig"][0])
+    return pol, g

@@ -34,7 +34,7 @@ class BatchedEpisodes:
                  blip2=None, use_blip2: bool = True, frame_pool: int = 4, map_size: int = 1000,
                  n_frontiers: int = 8, sync_explored: bool = False, obstacle: bool = True,
                  episode_len: int = 500, overlap: bool = True, detector=None, sam=None, sam_every: int = 4,
-                 graph_blip2: Optional[bool] = None) -> None:
+                 graph_blip2: Optional[bool] = None, host_inputs: bool = False, select_frontiers: bool = False) -> None:
         self.device = require_gpu(device)
         self.E, self.H, self.W, self.S = n_envs, height, width, map_size
         self.fx, self.fy, self.fov = camera_intrinsics(width)
@@ -48,10 +48,19 @@ class BatchedEpisodes:
         # synthetic observations live in HBM before the timed region starts (bench contract): a small pool of
         # distinct frames per env, cycled; the scripted poses of a whole episode are tabulated up front as well
         rng = np.random.Generator(np.random.PCG64(99991 + env_offset))
-        self.depth_pool = torch.from_numpy(np.stack([
-            np.stack([depth_frame(rng, height, width) for _ in range(n_envs)]) for _ in range(frame_pool)])).to(self.device)
-        self.rgb_pool = torch.from_numpy(np.stack([
-            np.stack([rgb_frame(rng, height, width) for _ in range(n_envs)]) for _ in range(frame_pool)])).to(self.device)
+        depth_pool = torch.from_numpy(np.stack([
+            np.stack([depth_frame(rng, height, width) for _ in range(n_envs)]) for _ in range(frame_pool)]))
+        rgb_pool = torch.from_numpy(np.stack([
+            np.stack([rgb_frame(rng, height, width) for _ in range(n_envs)]) for _ in range(frame_pool)]))
+        # host_inputs: the simulator hands over HOST buffers every step (what the reference's API receives); the frames
+        # then cross PCIe inside the step -- the "PCIe-inclusive" rate of DESIGN.md, never the headline value
+        self.host_inputs = host_inputs
+        if host_inputs:
+            self.depth_pool, self.rgb_pool = depth_pool.pin_memory(), rgb_pool.pin_memory()
+            self.depth_dev = torch.empty(depth_pool.shape[1:], dtype=depth_pool.dtype, device=self.device)
+            self.rgb_dev = torch.empty(rgb_pool.shape[1:], dtype=rgb_pool.dtype, device=self.device)
+        else:
+            self.depth_pool, self.rgb_pool = depth_pool.to(self.device), rgb_pool.to(self.device)
         trajs = [Trajectory(i) for i in self.env_ids]
         self.pose_table = np.array([[tr.step() for tr in trajs] for _ in range(episode_len)])  # [L,E,3]
         self.tf_table = np.stack([np.stack([pose_to_tf(x, y, yaw) for (x, y, yaw) in row]) for row in self.pose_table])
@@ -82,6 +91,13 @@ class BatchedEpisodes:
         self.map_stream = torch.cuda.Stream(self.device) if overlap else None
         self.last_cosines: Optional[torch.Tensor] = None
         self.last_frontier_values: Optional[np.ndarray] = None
+        # frontier selection of ITMPolicyV2 (stick-to-last rule, itm_policy.py:76-152), one selector per environment
+        self.selectors = None
+        if select_frontiers:
+            from .policy_step import FrontierSelector
+
+            self.selectors = [FrontierSelector() for _ in range(n_envs)]
+        self.last_goals: Optional[np.ndarray] = None
         self.timers: Dict[str, List] = {}
 
     def reset(self) -> None:
@@ -89,12 +105,34 @@ class BatchedEpisodes:
         if self.obstacles is not None:
             self.obstacles.reset()
         self.t = 0
+        if self.selectors is not None:
+            from .policy_step import FrontierSelector
+
+            self.selectors = [FrontierSelector() for _ in range(self.E)]
+
+    def _select(self, wps: np.ndarray, env_of: np.ndarray, vals: np.ndarray, poses: np.ndarray) -> np.ndarray:
+        """Per environment: sort_waypoints' descending order (value_map.py:183-186), then the selection rule."""
+        goals = np.full((self.E, 2), np.nan)
+        vals = np.asarray(vals, np.float64).reshape(-1)
+        bounds = np.searchsorted(env_of, np.arange(self.E + 1))
+        for e in range(self.E):
+            lo, hi = bounds[e], bounds[e + 1]
+            if hi > lo:
+                order = np.argsort(-vals[lo:hi])
+                pts = wps[lo:hi]
+                goals[e], _ = self.selectors[e].choose(pts[order], [float(v) for v in vals[lo:hi][order]], pts,
+                                                       poses[e, :2])
+        return goals
 
     def step(self) -> None:
         if self.t and self.t % self.episode_len == 0:
             self.reset()
         k = self.t % self.depth_pool.shape[0]
-        depth, rgb = self.depth_pool[k], self.rgb_pool[k]
+        if self.host_inputs:
+            depth = self.depth_dev.copy_(self.depth_pool[k], non_blocking=True)
+            rgb = self.rgb_dev.copy_(self.rgb_pool[k], non_blocking=True)
+        else:
+            depth, rgb = self.depth_pool[k], self.rgb_pool[k]
         poses, tf = self.pose_table[self.t % self.episode_len], self.tf_table[self.t % self.episode_len]
         main = torch.cuda.current_stream(self.device)
         side = self.map_stream if self.map_stream is not None else main
@@ -136,4 +174,6 @@ class BatchedEpisodes:
         # ---- frontier scoring (ITMPolicyV2._sort_frontiers_by_value, radius 0.5 m)
         if len(wps):
             self.last_frontier_values = self.values.waypoint_values(wps, env_of, 0.5)  # D2H sync: the policy needs it
+            if self.selectors is not None:
+                self.last_goals = self._select(wps, env_of, self.last_frontier_values, poses)
         self.t += 1
