@@ -248,6 +248,7 @@ def main():
     torch.cuda.synchronize(device)
     kms = {}
     for kname in ("depth_ingest_kernel", "depth_scatter_kernel", "depth_ingest_scatter_kernel", "fill_small_holes_kernel",
+                  "hole_scatter_kernel",
                   "visible_mask_kernel", "value_map_fuse_kernel", "sort_waypoints_kernel",
                   "mask_unexplored_kernel", "resample_h_kernel", "resample_v_norm_kernel", "itc_head_kernel",
                   "navigable_kernel", "fog_of_war_kernel", "explored_select_kernel", "frontier_kernel"):

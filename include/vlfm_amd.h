@@ -103,7 +103,9 @@ typedef struct {
     double min_height, max_height;
     int32_t env;          /* obstacle-map slot */
     int32_t scatter;      /* bit 0: scatter obstacles (0 = column max only, update_obstacles=False);
-                             bit 1: every zero depth texel is a filled hole (hole_area_thresh == -1, obstacle_map.py:87-89) */
+                             bit 1: every zero depth texel is a filled hole (hole_area_thresh == -1, obstacle_map.py:87-89);
+                             bit 2: zero texels are left to vlfm_depth_scatter_holes_batched (their fate depends on
+                                    fill_small_holes, which needs the whole image first) */
 } vlfm_ingest_params;     /* 152 bytes */
 
 int vlfm_depth_ingest_batched(const float* d_depth, int n, int height, int width,
@@ -126,12 +128,21 @@ int vlfm_depth_ingest_batched(const float* d_depth, int n, int height, int width
  *   d_status   [n][2] the ingest status (word 1 = image has zeros)
  *   d_scratch  vlfm_hole_scratch_bytes(n, H, W, cap_pts, cap_contours) bytes
  *   d_counts   [n][4] int32: (contours traced, contours filled, overflow flag, reserved)
- * The obstacle scatter then runs as a second vlfm_depth_ingest_batched call with d_filled_bits (d_colmax_keys = NULL).
+ *   d_counts   [n][4] int32: (contours traced, contours filled, overflow flag, image had zero texels)
+ * Single depth pass (what ObstacleMapBatch does): vlfm_depth_ingest_batched with scatter bits 0|2 places every NON-zero
+ * texel and writes d_hole_bits; this call decides which zeros become 1.0; vlfm_depth_scatter_holes_batched then places
+ * the zeros that survived (depth 0 -> z = min_depth) from the two bit planes, without touching the images again.
+ * (Alternative: a second vlfm_depth_ingest_batched call with d_filled_bits and d_colmax_keys = NULL.)
  * ------------------------------------------------------------------------------------------- */
 size_t vlfm_hole_scratch_bytes(int n, int height, int width, int cap_pts, int cap_contours);
 int vlfm_fill_small_holes_batched(const uint32_t* d_hole_bits, const int32_t* d_status, int n, int height, int width,
                                   double area_thresh, void* d_scratch, size_t scratch_bytes, int cap_pts,
                                   int cap_contours, uint32_t* d_filled_bits, int32_t* d_counts, void* stream);
+int vlfm_depth_scatter_holes_batched(const vlfm_ingest_params* d_params, int n, int height, int width,
+                                     const uint32_t* d_hole_bits, const uint32_t* d_filled_bits,
+                                     const int32_t* d_hole_counts /* d_counts of vlfm_fill_small_holes_batched */,
+                                     uint32_t* d_obstacle, int map_size, int pixels_per_meter, int32_t* d_status,
+                                     void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * ValueMap.update_map for n observations (value_map.py:100-128 = :221-260 + :288-319 + :357-429).

@@ -90,6 +90,7 @@ def lib() -> ctypes.CDLL:
         L.vlfm_hole_scratch_bytes.argtypes = [ci, ci, ci, ci, ci]
         L.vlfm_hole_scratch_bytes.restype = ctypes.c_size_t
         L.vlfm_fill_small_holes_batched.argtypes = [vp, vp, ci, ci, ci, cd, vp, ctypes.c_size_t, ci, ci, vp, vp, vp]
+        L.vlfm_depth_scatter_holes_batched.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp, ci, ci, vp, vp]
         L.vlfm_value_map_scratch_bytes.argtypes = [ci, ci]
         L.vlfm_value_map_scratch_bytes.restype = ctypes.c_size_t
         L.vlfm_value_map_update_batched.argtypes = [vp, ci, vp, vp, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci, cd, cd, ci,

@@ -90,15 +90,17 @@ __device__ inline bool row_may_hit(const HeightBand& b, int v, int H) {
     return !(z_hi + slack < b.lo || z_lo - slack > b.hi);  // NaN -> true
 }
 
+template <bool HOLE_PASS = false>
 __device__ inline void scatter_point(const IngestArgs& a, const vlfm_ingest_params& p, const HeightBand& band,
                                      unsigned* grid, int obs, int u, int v, float d, bool filled) {
     // fill_small_holes (img_utils.py:361-390) turned this texel into 1.0 -> z == max_depth -> masked out (:93)
     if (filled) return;
-    if (d == 0.0f) {
-        // a hole in the depth image.  scatter bit 1 set: hole_area_thresh == -1 semantics (obstacle_map.py:87-89), every
-        // zero becomes 1.0 and therefore falls outside max_depth.  Otherwise an unfilled (large) hole is used as it is:
-        // depth 0 -> z = min_depth, exactly like the reference.
-        if (p.scatter & 2) return;
+    if (!HOLE_PASS && d == 0.0f) {
+        // a hole in the depth image.  scatter bit 1: hole_area_thresh == -1 semantics (obstacle_map.py:87-89), every
+        // zero becomes 1.0 and therefore falls outside max_depth.  scatter bit 2: whether this zero survives
+        // fill_small_holes is not known yet -- hole_scatter_kernel places the survivors from the hole bit plane (an
+        // unfilled, large hole is used as it is: depth 0 -> z = min_depth, exactly like the reference).
+        if (p.scatter & 6) return;
     }
     const float z = __fadd_rn(__fmul_rn(d, p.depth_scale), p.depth_offset);  // obstacle_map.py:92 (f32)
     if (!(z < p.depth_max)) return;                                          // :93
@@ -179,12 +181,15 @@ __global__ __launch_bounds__(CG * RL) void depth_ingest_kernel(IngestArgs a) {
     // always executed convergently
     for (int g0 = band_id; g0 < n_groups; g0 += UNROLL * bands) {
         float4 d[UNROLL];
-        bool rowok[UNROLL];
+        bool rowok[UNROLL], rowhit[UNROLL];
 #pragma unroll
         for (int k = 0; k < UNROLL; k++) {
             const int r = (g0 + k * bands) * RL + ry;
             bool want = live && r < r_end;
-            if (SCATTER && scatter_only) want = want && row_may_hit(band, r, a.H);
+            // rows that cannot reach the height band: not even loaded by a scatter-only pass, loaded (column maximum,
+            // hole bits) but not offered to the placement path by a combined pass
+            rowhit[k] = SCATTER && want && row_may_hit(band, r, a.H);
+            if (SCATTER && scatter_only) want = rowhit[k];
             rowok[k] = want;
             d[k] = want ? reinterpret_cast<const float4*>(img + (size_t)r * a.W)[col4] : make_float4(ninf, ninf, ninf, ninf);
         }
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(CG * RL) void depth_ingest_kernel(IngestArgs a) {
                     holes[(size_t)r * a.hw + (col4 >> 3)] = word;
                 }
             }
-            if (SCATTER && (p.scatter & 1) && ok) {
+            if (SCATTER && (p.scatter & 1) && rowhit[k]) {
                 unsigned fnib = 0u;
                 if (filled) fnib = (filled[(size_t)r * a.hw + (col4 >> 3)] >> ((col4 & 7) * 4)) & 0xFu;
                 const int u = col4 * 4;
@@ -238,9 +243,50 @@ __global__ __launch_bounds__(CG * RL) void depth_ingest_kernel(IngestArgs a) {
     }
 }
 
+// The zero texels that fill_small_holes left alone (holes of area >= hole_area_thresh), placed from the bit planes: the
+// depth images are not read again.  One thread per 32-texel word of (hole & ~filled); frames without a zero texel
+// (counts[3] == 0, the common case) cost one early exit per workgroup.
+__global__ __launch_bounds__(256) void hole_scatter_kernel(IngestArgs a, const int* counts) {
+    const int obs = blockIdx.y;
+    if (counts[(size_t)obs * 4 + 3] == 0) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.H * a.hw) return;
+    const vlfm_ingest_params p = a.prm[obs];
+    if (!(p.scatter & 1) || (p.scatter & 2)) return;
+    unsigned w = a.hole_bits[(size_t)obs * a.H * a.hw + i] & ~a.filled_bits[(size_t)obs * a.H * a.hw + i];
+    if (!w) return;
+    const HeightBand band = make_band(p, a.W, a.H);
+    unsigned* grid = a.obstacle + (size_t)p.env * a.S * a.stride;
+    const int v = i / a.hw, u0 = (i % a.hw) * 32;
+    while (w) {
+        const int b = __builtin_ctz(w);
+        w &= w - 1u;
+        if (u0 + b < a.W) scatter_point<true>(a, p, band, grid, obs, u0 + b, v, 0.0f, false);
+    }
+}
+
 }  // namespace vlfm
 
 using namespace vlfm;
+
+extern "C" int vlfm_depth_scatter_holes_batched(const vlfm_ingest_params* d_params, int n, int height, int width,
+                                                const uint32_t* d_hole_bits, const uint32_t* d_filled_bits,
+                                                const int32_t* d_hole_counts, uint32_t* d_obstacle, int map_size,
+                                                int pixels_per_meter, int32_t* d_status, void* stream) {
+    if (n == 0) return VLFM_OK;
+    if (!d_params || !d_hole_bits || !d_filled_bits || !d_hole_counts || !d_obstacle || !d_status || n < 0 ||
+        height <= 0 || width <= 0)
+        return fail(VLFM_ERR_INVALID, "depth_scatter_holes_batched: bad argument");
+    IngestArgs a{};
+    a.prm = d_params; a.obstacle = d_obstacle; a.status = d_status;
+    a.hole_bits = const_cast<uint32_t*>(d_hole_bits); a.filled_bits = d_filled_bits; a.hw = (width + 31) / 32;
+    a.H = height; a.W = width; a.W4 = width / 4; a.S = map_size; a.stride = (map_size + 31) / 32;
+    a.ppm = (double)pixels_per_meter;
+    VLFM_TIMED("hole_scatter_kernel", stream);
+    VLFM_KLAUNCH(hole_scatter_kernel, dim3((a.H * a.hw + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, a,
+                 d_hole_counts);
+    return check_launch("hole_scatter_kernel");
+}
 
 extern "C" int vlfm_depth_ingest_batched(const float* d_depth, int n, int height, int width,
                                          const vlfm_ingest_params* d_params, uint32_t* d_colmax_keys, uint32_t* d_obstacle,

@@ -119,6 +119,8 @@ class ObstacleMapBatch:
             keys = self.colmax_keys
         L = _lib.lib()
         fill = update_obstacles and self._hole_area_thresh != -1
+        if fill:
+            prm["scatter"] |= 4  # zero texels wait for fill_small_holes
         with torch.cuda.device(self.device):
             d_prm = self._ring_ingest.upload(prm)
             if not fill:
@@ -130,24 +132,27 @@ class ObstacleMapBatch:
                                                        self.size, self.pixels_per_meter, self.status.data_ptr(),
                                                        None, None, _stream_ptr()), "depth_ingest")
             else:
-                # fill_small_holes (img_utils.py:361-390) sits between reading the depth and scattering it: pass 1
-                # streams the images once (column maxima + the (depth == 0) bit plane + "has zeros" flag), the hole
-                # kernel exits immediately for images without zeros, pass 2 scatters with the filled texels masked
-                # (the images are still in the 256 MB Infinity Cache)
+                # fill_small_holes (img_utils.py:361-390) sits between reading the depth and scattering it, but it only
+                # decides the fate of ZERO texels: the single streaming pass places every non-zero texel (scatter bit
+                # 2), reduces the column maxima and emits the (depth == 0) bit plane + "has zeros" flag; the hole
+                # kernel exits immediately for images without zeros; the zeros that survive it (large holes keep depth 0
+                # -> z = min_depth) are then placed from the two bit planes.  The images are read exactly once.
                 holes, filled, scratch, counts = self._hole_buffers(n, H, W)
                 _lib.check(L.vlfm_depth_ingest_batched(depth.data_ptr(), n, H, W, d_prm.data_ptr(),
-                                                       keys.data_ptr() if keys is not None else None, None,
-                                                       self.size, self.pixels_per_meter, self.status.data_ptr(),
-                                                       holes.data_ptr(), None, _stream_ptr()), "depth_ingest(1)")
+                                                       keys.data_ptr() if keys is not None else None,
+                                                       self.obstacle_bits.data_ptr(), self.size,
+                                                       self.pixels_per_meter, self.status.data_ptr(),
+                                                       holes.data_ptr(), None, _stream_ptr()), "depth_ingest")
                 _lib.check(L.vlfm_fill_small_holes_batched(holes.data_ptr(), self.status.data_ptr(), n, H, W,
                                                            float(self._hole_area_thresh), scratch.data_ptr(),
                                                            scratch.numel(), self.HOLE_CAP_PTS, self.HOLE_CAP_CONTOURS,
                                                            filled.data_ptr(), counts.data_ptr(), _stream_ptr()),
                            "fill_small_holes")
-                _lib.check(L.vlfm_depth_ingest_batched(depth.data_ptr(), n, H, W, d_prm.data_ptr(), None,
-                                                       self.obstacle_bits.data_ptr(), self.size,
-                                                       self.pixels_per_meter, self.status.data_ptr(), None,
-                                                       filled.data_ptr(), _stream_ptr()), "depth_ingest(2)")
+                _lib.check(L.vlfm_depth_scatter_holes_batched(d_prm.data_ptr(), n, H, W, holes.data_ptr(),
+                                                              filled.data_ptr(), counts.data_ptr(),
+                                                              self.obstacle_bits.data_ptr(), self.size,
+                                                              self.pixels_per_meter, self.status.data_ptr(),
+                                                              _stream_ptr()), "depth_scatter_holes")
         return keys
 
     def _hole_buffers(self, n: int, H: int, W: int):
