@@ -347,13 +347,16 @@ def main():
                 "upload_bytes_per_step": int(args.envs * (4 * args.height * args.width + 3 * args.height * args.width))}
             del host
             if not args.no_full:
+                from vlfm_amd.pointnav import WrappedPointNavResNetPolicy
                 from vlfm_amd.vlm.sam import MobileSAM
                 from vlfm_amd.vlm.yolov7 import YOLOv7
 
                 full = BatchedEpisodes(8, device=device, height=args.height, width=args.width, blip2=sim.blip2,
                                        obstacle=have_obstacle, overlap=not args.no_overlap,
                                        detector=YOLOv7(device=device), sam=MobileSAM(device=device),
-                                       select_frontiers=True)
+                                       select_frontiers=True,
+                                       pointnav=WrappedPointNavResNetPolicy(None, device=device, n_envs=8,
+                                                                            discrete_actions=True))
                 for _ in range(3):
                     full.step()
                 torch.cuda.synchronize(device)
@@ -364,6 +367,7 @@ def main():
                 dt = (time.perf_counter() - ts) / 20
                 side["configs[2] full step, envs_per_gpu=8"] = {
                     "value": round(8 / dt, 2), "unit": "env-steps/s", "ms_per_step": round(dt * 1e3, 3),
+                    "controller": "PointNav ResNet-18-GN + LSTM, random-init, discrete head",
                     "detector": full.detector.weights, "segmenter": "MobileSAM (TinyViT-5M) random-init, 1 box for every "
                                                                     "4th env-step"}
                 del full

@@ -436,6 +436,44 @@ def gen_api():
     return {"json": np.array(json.dumps(signature_table(importlib.import_module), sort_keys=True))}
 
 
+def gen_pointnav():
+    """THE REFERENCE'S PointNav network (vlfm/policy/utils/non_habitat_policy/nh_pointnav_policy.py -- pure PyTorch, runs
+    here unmodified) and its depth transform (vlfm/obs_transformers/utils.py:image_resize), one environment at a time as
+    the reference's wrapper does (pointnav_policy.py:50-128), on the pattern weights / inputs of pointnav_script.py."""
+    import importlib
+
+    import torch
+
+    from oracle import ref_shim
+
+    import pointnav_script as pn
+
+    ref_shim.install()
+    nh = importlib.import_module("vlfm.policy.utils.non_habitat_policy.nh_pointnav_policy")
+    resize = importlib.import_module("vlfm.obs_transformers.utils").image_resize
+    torch.manual_seed(0)
+    policy = nh.PointNavResNetPolicy().eval()
+    with torch.no_grad():
+        pn.pattern_(policy.state_dict())
+        state = [torch.zeros(1, 4, 512) for _ in range(pn.N_ENVS)]
+        prev = [torch.zeros(1, 2) for _ in range(pn.N_ENVS)]
+        actions = []
+        for depth, rt, masks in pn.inputs():
+            row = []
+            for e in range(pn.N_ENVS):
+                obs = {"depth": resize(depth[e:e + 1].unsqueeze(-1), (224, 224), channels_last=True,
+                                       interpolation_mode="area"),
+                       "pointgoal_with_gps_compass": rt[e:e + 1]}
+                a, state[e] = policy.act(obs, state[e], prev[e], masks[e].view(1, 1), deterministic=True)
+                prev[e] = a.clone()
+                row.append(a[0].numpy().copy())
+            actions.append(np.stack(row))
+    keys = sorted(policy.state_dict().keys())
+    return dict(actions=np.stack(actions).astype(np.float32), final_state=torch.cat(state).numpy().astype(np.float32),
+                state_dict_keys=np.array(keys),
+                state_dict_shapes=np.array([str(tuple(policy.state_dict()[k].shape)) for k in keys]))
+
+
 def generate():
     from oracle import ref_shim
 
@@ -454,6 +492,7 @@ def generate():
     for name in ps.EPISODES:
         out[name] = gen_policy(name)
     out["api_signatures"] = gen_api()
+    out["pointnav"] = gen_pointnav()
     return out
 
 

@@ -34,7 +34,8 @@ class BatchedEpisodes:
                  blip2=None, use_blip2: bool = True, frame_pool: int = 4, map_size: int = 1000,
                  n_frontiers: int = 8, sync_explored: bool = False, obstacle: bool = True,
                  episode_len: int = 500, overlap: bool = True, detector=None, sam=None, sam_every: int = 4,
-                 graph_blip2: Optional[bool] = None, host_inputs: bool = False, select_frontiers: bool = False) -> None:
+                 graph_blip2: Optional[bool] = None, host_inputs: bool = False, select_frontiers: bool = False,
+                 pointnav=None) -> None:
         self.device = require_gpu(device)
         self.E, self.H, self.W, self.S = n_envs, height, width, map_size
         self.fx, self.fy, self.fov = camera_intrinsics(width)
@@ -98,6 +99,11 @@ class BatchedEpisodes:
 
             self.selectors = [FrontierSelector() for _ in range(n_envs)]
         self.last_goals: Optional[np.ndarray] = None
+        # PointNav controller (vlfm_amd.pointnav.WrappedPointNavResNetPolicy built for n_envs): the action towards the
+        # selected frontier, one batched forward (base_objectnav_policy.py:243-283)
+        self.pointnav = pointnav
+        self.prev_goals = np.zeros((n_envs, 2))
+        self.last_actions = None
         self.timers: Dict[str, List] = {}
 
     def reset(self) -> None:
@@ -123,6 +129,21 @@ class BatchedEpisodes:
                 goals[e], _ = self.selectors[e].choose(pts[order], [float(v) for v in vals[lo:hi][order]], pts,
                                                        poses[e, :2])
         return goals
+
+    def _navigate(self, depth: torch.Tensor, goals: np.ndarray, poses: np.ndarray) -> torch.Tensor:
+        """(rho, theta) of every environment's goal in its robot frame (geometry_utils.py:9-34), controller state reset
+        where the goal moved by more than 0.1 m (base_objectnav_policy.py:255-259), one batched forward."""
+        goals = np.where(np.isnan(goals), poses[:, :2], goals)
+        moved = np.linalg.norm(goals - self.prev_goals, axis=1) > 0.1
+        self.prev_goals = goals
+        d = goals - poses[:, :2]
+        c, s = np.cos(-poses[:, 2]), np.sin(-poses[:, 2])
+        lx, ly = c * d[:, 0] - s * d[:, 1], s * d[:, 0] + c * d[:, 1]
+        rt = torch.from_numpy(np.stack([np.hypot(lx, ly), np.arctan2(ly, lx)], axis=1).astype(np.float32))
+        fresh = moved | (self.t % self.episode_len == 0)
+        if fresh.any():
+            self.pointnav.reset(np.flatnonzero(fresh))
+        return self.pointnav.act_on_depth(depth, rt, torch.from_numpy(~fresh))
 
     def step(self) -> None:
         if self.t and self.t % self.episode_len == 0:
@@ -176,4 +197,6 @@ class BatchedEpisodes:
             self.last_frontier_values = self.values.waypoint_values(wps, env_of, 0.5)  # D2H sync: the policy needs it
             if self.selectors is not None:
                 self.last_goals = self._select(wps, env_of, self.last_frontier_values, poses)
+                if self.pointnav is not None:
+                    self.last_actions = self._navigate(depth, self.last_goals, poses)
         self.t += 1

@@ -12,8 +12,10 @@ harness, the parity tests -- expressed over the drop-in classes of this package:
                 --> initialise / explore (best frontier) / navigate (object goal)    base_objectnav_policy.py:126-135
                 --> goal bookkeeping + stop rule in front of the PointNav controller  base_objectnav_policy.py:243-283
 
-It ends where the PointNav controller (ResNet-18 + LSTM, weights absent, out of scope) would be asked for an action:
-``StepResult`` carries the goal in metres, (rho, theta) and the reset flag that controller would receive.
+``StepResult`` carries the goal in metres, (rho, theta) and the reset flag the PointNav controller receives; with a
+``pointnav`` controller attached (vlfm_amd.pointnav.WrappedPointNavResNetPolicy) it also carries the
+action (Habitat ids: STOP 0, MOVE_FORWARD 1, TURN_LEFT 2, TURN_RIGHT 3 -- habitat_policies.py:53-57 -- or the
+(linear, angular) pair of a continuous head).
 
 Parity: tests/golden/policy_*.npz are produced by the reference's own ``ITMPolicyV2`` source (through
 oracle/ref_shim.reference_policy()) over scripted observations and scripted model outputs; tests replay them through
@@ -123,6 +125,10 @@ class StepResult:
     best_value: float               # value of the frontier being pursued (-inf before the first choice)
     detections: Any                 # ObjectDetections that survived class / confidence filtering
     frontiers: np.ndarray           # (F,2) frontier list the decision was made on
+    action: Any = None              # with a PointNav controller: action id (discrete head) or (lin, ang) (continuous)
+
+
+ACTION_STOP, ACTION_FORWARD, ACTION_TURN_LEFT, ACTION_TURN_RIGHT = 0, 1, 2, 3  # TorchActionIDs habitat_policies.py:53-57
 
 
 class ITMPolicyV2Step:
@@ -141,7 +147,7 @@ class ITMPolicyV2Step:
                  coco_threshold: float = 0.8, non_coco_threshold: float = 0.4, non_coco_caption: str = "",
                  load_yolo: bool = True, itm: Any = None, coco_detector: Any = None, detector: Any = None,
                  sam: Any = None, obstacle_map: Any = None, value_map: Any = None, object_map: Any = None,
-                 infer_depth: Optional[Callable] = None) -> None:
+                 infer_depth: Optional[Callable] = None, pointnav: Any = None) -> None:
         if use_vqa:
             raise NotImplementedError("BLIP-2 VQA confirmation is disabled in every shipped config and not provided")
         self._camera_height, self._min_depth, self._max_depth = camera_height, min_depth, max_depth
@@ -153,6 +159,7 @@ class ITMPolicyV2Step:
         self._coco_threshold, self._non_coco_threshold = coco_threshold, non_coco_threshold
         self._non_coco_caption, self._load_yolo = non_coco_caption, load_yolo
         self._infer_depth = infer_depth
+        self._pointnav = pointnav
         if obstacle_map is None:
             from .mapping.obstacle_map import ObstacleMap
 
@@ -200,6 +207,8 @@ class ITMPolicyV2Step:
         self._obstacle_map.reset()
         self._value_map.reset()
         self._selector = FrontierSelector()
+        if getattr(self, "_pointnav", None) is not None:
+            self._pointnav.reset()
         self._last_goal = np.zeros(2)
         self._num_steps = 0
         self._done_initializing = False
@@ -314,9 +323,27 @@ class ITMPolicyV2Step:
             mode = "navigate"
             out_goal = goal[:2]
             rho, theta, stop, reset = self._goal_handover(out_goal, True, robot_xy, yaw)
+        action = self._act(mode, depth, rho, theta, stop, reset) if self._pointnav is not None else None
         self._num_steps += 1
         return StepResult(mode, out_goal, rho, theta, stop, reset, self._selector.last_value, det,
-                          np.asarray(frontiers, np.float64).reshape(-1, 2))
+                          np.asarray(frontiers, np.float64).reshape(-1, 2), action)
+
+    def _act(self, mode: str, depth: np.ndarray, rho: float, theta: float, stop: bool, reset: bool):
+        """Initialise = TURN_LEFT, STOP when issued, otherwise the controller on the area-resized depth
+        (habitat_policies.py:150-153, base_objectnav_policy.py:254-283)."""
+        import torch
+
+        discrete = self._pointnav.discrete
+        if mode == "initialize":
+            return ACTION_TURN_LEFT if discrete else np.zeros(2, np.float32)
+        if stop:
+            return ACTION_STOP if discrete else np.zeros(2, np.float32)
+        if reset:
+            self._pointnav.reset()
+        a = self._pointnav.act_on_depth(torch.from_numpy(np.ascontiguousarray(depth, np.float32))[None],
+                                        torch.tensor([[rho, theta]], dtype=torch.float32),
+                                        torch.tensor([not reset]))
+        return int(a[0, 0]) if discrete else a[0].detach().cpu().numpy()
 
     # ------------------------------------------------------------------------------------------------ read-only views
     @property
