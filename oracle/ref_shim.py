@@ -38,10 +38,31 @@ def available() -> bool:
     return os.path.isfile(os.path.join(REFERENCE_ROOT, "vlfm", "mapping", "value_map.py"))
 
 
-def install() -> None:
-    """Idempotent.  Call in a dedicated process: it plants fake top-level modules in sys.modules."""
-    if "vlfm.mapping.value_map" in sys.modules:
+_PLANTED = ("cv2", "frontier_exploration", "torchvision", "open3d", "hydra", "vlfm")
+_before: dict = {}
+
+
+def uninstall() -> None:
+    """Remove every stand-in (and the reference's modules) from sys.modules again and restore what was there before, so
+    that code imported later in the same process (transformers probes for torchvision!) never sees a fake package."""
+    if not _before.get("installed"):
         return
+    for name in [m for m in sys.modules if m.split(".")[0] in _PLANTED]:
+        del sys.modules[name]
+    sys.modules.update(_before.get("modules", {}))
+    if REFERENCE_ROOT in sys.path and not _before.get("path_had_root"):
+        sys.path.remove(REFERENCE_ROOT)
+    _before.clear()
+
+
+def install() -> None:
+    """Idempotent.  Plants fake top-level modules in sys.modules: pair with uninstall() (tests/conftest.py does, after every
+    test) or call in a dedicated process."""
+    if "vlfm.mapping.value_map" in sys.modules and _before.get("installed"):
+        return
+    if not _before.get("installed"):
+        _before.update(installed=True, path_had_root=REFERENCE_ROOT in sys.path,
+                       modules={m: v for m, v in sys.modules.items() if m.split(".")[0] in _PLANTED})
     if not available():
         raise ImportError(f"{REFERENCE_ROOT} is not present (GPU box?) -- golden fixtures are the pin there")
     from . import cv as facade

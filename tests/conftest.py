@@ -19,3 +19,14 @@ def gpu_device():
     if not torch.cuda.is_available():
         pytest.skip("no GPU visible")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _no_reference_standins_leak():
+    """oracle/ref_shim.py plants stand-in packages (cv2, torchvision, ...) in sys.modules to import the reference's own
+    source; take them out again after every test so that nothing imported later (transformers probes for torchvision) can
+    mistake a stand-in for the real package."""
+    yield
+    shim = sys.modules.get("oracle.ref_shim")
+    if shim is not None:
+        shim.uninstall()
