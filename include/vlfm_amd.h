@@ -229,6 +229,21 @@ int vlfm_preprocess_rgb_batched(const uint8_t* d_rgb, int n, int height, int wid
 int vlfm_itc_head_batched(const float* d_proj, int batch, int n_query, int proj_dim,
                           const float* d_text, float* d_out, void* stream);
 
+/* y = LayerNorm(x + c) * gamma + beta over the last dimension of f16 rows [rows][dim] (f32 statistics); c = f32 [dim]
+ * per-channel constant or NULL.  Used by the ViT-g blocks of BLIP-2 (blip2itm.py): the projection / fc2 GEMMs accumulate
+ * straight into the residual stream and their bias vectors, summed per layer on the host once, enter through c -- the
+ * two residual-add kernels per block disappear.  dim % 8 == 0, dim <= 2048; y may alias x. */
+int vlfm_layernorm_bias_f16(const void* d_x, const float* d_channel_bias, const void* d_gamma, const void* d_beta,
+                            void* d_y, int rows, int dim, float eps, void* stream);
+
+/* Self-attention of the ViT-g blocks: d_qkv [batch][tokens][3][heads][head_dim] f16 (the qkv GEMM's output as it is),
+ * d_out [batch][tokens][heads][head_dim] f16 = softmax(q k^T * scale) v per (image, head), ready for the projection
+ * GEMM.  Specialised for tokens == 257 and head_dim == 96 (ViT-g's 88-wide heads zero-padded to 96; scale stays
+ * 1/sqrt(88)); anything else returns VLFM_ERR_INVALID and the caller uses the library attention.  One workgroup per
+ * (image, head) with K and V^T resident in 114 KB of LDS, v_mfma_f32_32x32x16_f16, f32 softmax. */
+int vlfm_vit_attention_f16(const void* d_qkv, void* d_out, int batch, int tokens, int heads, int head_dim, float scale,
+                           void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Detector-side kernels (vlfm/vlm/yolov7.py:50-110, vlfm/vlm/grounding_dino.py:38-74)
  * ------------------------------------------------------------------------------------------- */

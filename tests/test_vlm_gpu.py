@@ -85,3 +85,101 @@ def test_blip2_client_signature_and_full_geometry(gpu_device):
     c = client.cosine(img, "Seems like there is a target_object ahead.".replace("target_object", "bed"))
     assert isinstance(c, float) and -1.0 <= c <= 1.0
     assert client._model.cfg.v_layers == 39 and client._model.weights == "random-init"
+
+
+@pytest.mark.parametrize("rows,dim", [(257 * 3, 1408), (50, 128), (9, 2048), (17, 136)])
+def test_layernorm_bias_kernel_vs_fp32_reference(gpu_device, rows, dim):
+    from vlfm_amd.vlm import ops
+
+    g = torch.Generator().manual_seed(rows + dim)
+    x = (torch.randn(rows, dim, generator=g) * 3).half()
+    c = torch.randn(dim, generator=g)
+    w, b = (1 + 0.2 * torch.randn(dim, generator=g)).half(), (0.3 * torch.randn(dim, generator=g)).half()
+    for cb in (c, None):
+        want = torch.nn.functional.layer_norm(x.float() + (cb if cb is not None else 0), (dim,), w.float(), b.float(), 1e-6)
+        got = ops.layernorm_bias(x.to(gpu_device), cb.to(gpu_device) if cb is not None else None, w.to(gpu_device),
+                                 b.to(gpu_device), 1e-6).cpu()
+        assert got.dtype == torch.float16
+        assert (got.float() - want).abs().max() <= 4e-3  # one f16 ulp at |y| <= 4
+
+
+def test_vit_deferred_bias_path_equals_plain_path(gpu_device):
+    """The ViT fast path (residual adds folded into the GEMMs, biases entering through LayerNorm(x + c)) against the
+    plain block-by-block path on the same f16 weights, and both against fp32 on the CPU.  88-wide heads so that the
+    packed-head path is the one in use, non-zero biases everywhere."""
+    from vlfm_amd.vlm.blip2itm import Blip2ITCConfig, Blip2ITCModel
+
+    cfg = Blip2ITCConfig(image_size=56, patch_size=14, v_hidden=176, v_layers=4, v_heads=2, v_mlp=352, q_hidden=64,
+                         q_layers=2, q_heads=4, q_mlp=128, vocab_size=100, max_position_embeddings=40,
+                         num_query_tokens=4, proj_dim=16)
+    ref = Blip2ITCModel(cfg).init_random(3).eval()
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if p.dim() > 1:
+                p.mul_(4.0)
+            elif "layer_norm" not in n and "LayerNorm" not in n and "layernorm" not in n:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+    gpu = Blip2ITCModel(cfg).eval()
+    gpu.load_state_dict(ref.state_dict())
+    gpu.to(gpu_device).set_precision(torch.float16)
+    for blk in gpu.blocks:
+        blk.pack_heads()
+    assert gpu.blocks[0]._packed is not None
+    pix = torch.randn(5, 3, 56, 56, generator=g)
+    with torch.inference_mode():
+        want = ref.vision_tokens(pix)
+        gpu.deferred_bias = True
+        fast = gpu.vision_tokens(pix.to(gpu_device).half()).float().cpu()
+        gpu.deferred_bias = False
+        plain = gpu.vision_tokens(pix.to(gpu_device).half()).float().cpu()
+    assert (plain - want).abs().max() <= 3e-2 and (fast - want).abs().max() <= 3e-2
+    assert (fast - plain).abs().max() <= 2e-2
+    assert (fast - want).abs().mean() <= 1.2 * (plain - want).abs().mean() + 1e-4  # not less accurate than the plain path
+
+
+def test_vit_attention_kernel_vs_fp32_reference(gpu_device):
+    """vlfm_vit_attention_f16 (257 tokens, 16 heads padded 88 -> 96) against softmax(q k^T / sqrt(88)) v in fp32."""
+    from vlfm_amd.vlm import ops
+
+    g = torch.Generator().manual_seed(7)
+    B, S, H, D = 3, 257, 16, 96
+    qkv = torch.randn(B, S, 3, H, D, generator=g) * 1.5
+    qkv[..., 88:] = 0                                     # what the zero-padded qkv weights produce
+    qkv[0, :, 0, 0, :88] *= 4.0                           # a head with peaked softmax rows
+    half = qkv.half()
+    scale = 88 ** -0.5
+    q, k, v = [half[:, :, i].float().permute(0, 2, 1, 3) for i in range(3)]          # [B,H,S,D]
+    want = torch.softmax(q @ k.transpose(-1, -2) * scale, dim=-1) @ v                 # [B,H,S,D]
+    want = want.permute(0, 2, 1, 3).reshape(B * S, H * D)
+    got = ops.vit_attention(half.to(gpu_device).reshape(B * S, 3 * H * D).contiguous(), B, S, H, D, scale).float().cpu()
+    err = (got - want).abs()
+    assert err.max() <= 6e-3, (float(err.max()), int(err.argmax()))
+    assert float(got[:, 88:96].abs().max()) == 0.0
+
+
+def test_vit_fast_path_full_geometry_vs_plain(gpu_device):
+    """ViT-g/14 at the real geometry (random weights, non-zero biases): attention kernel + deferred-bias path vs the plain
+    PyTorch path on the same f16 weights."""
+    from vlfm_amd.vlm.blip2itm import BLIP2ITM
+
+    m = BLIP2ITM(device=gpu_device).model
+    g = torch.Generator(device=gpu_device).manual_seed(2)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.dim() == 1 and "norm" not in n.lower():
+                p.copy_(torch.randn(p.shape, generator=g, device=gpu_device, dtype=torch.float32).to(p.dtype) * 0.1)
+        for blk in m.blocks:
+            blk.pack_heads()
+    m._deferred_c = None
+    pat = torch.randn(3, 256, 588, generator=g, device=gpu_device, dtype=torch.float32).half()
+    with torch.inference_mode():
+        m.deferred_bias = True
+        fast = m.vision_tokens(pat).float()
+        for blk in m.blocks:
+            blk.hip_attention = False
+        mid = m.vision_tokens(pat).float()
+        m.deferred_bias = False
+        plain = m.vision_tokens(pat).float()
+    assert (mid - plain).abs().max() <= 6e-2 and (fast - plain).abs().max() <= 6e-2   # 39 blocks of f16 rounding noise
+    assert (fast - plain).abs().mean() <= 4e-3 and (fast - mid).abs().mean() <= 4e-3

@@ -1,7 +1,8 @@
 """SDPA variants for the ViT-g attention shape (B=64, H=16, S=257, D=88), fp16."""
 import torch, time, torch.nn.functional as F
 dev = torch.device("cuda:0")
-B, H, S, D = 64, 16, 257, 88
+import sys
+B, H, S, D = (int(sys.argv[1]) if len(sys.argv) > 1 else 64), 16, 257, 88
 def bench(fn, n=20):
     for _ in range(3): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -1,0 +1,243 @@
+// vit_attention.hip -- self-attention of the BLIP-2 ViT-g blocks (S = 257 tokens, 16 heads of 88 -> 96 padded), gfx950.
+//
+// Replaces F.scaled_dot_product_attention in vlfm_amd/vlm/blip2itm.py:_VitBlock (the reference reaches the same maths
+// through LAVIS' eva_vit Attention, vlfm/vlm/blip2itm.py:29-34,52 [ext]).  The library flash kernel spends 290 us per
+// block at 128 images on this shape (257 = 8 x 32 + 1 tokens, head 88); this kernel is specialised for it:
+//
+//   * one workgroup per (image, head), 8 wavefronts; the head's whole K (257 x 96) and V^T (96 x 257) live in LDS
+//     (117 KB of the 160 KB), so nothing is re-read and there is no online-softmax rescaling;
+//   * wavefront w owns the 32 queries of tokens 1+32w .. 32+32w.  It computes S^T = K Q^T with
+//     v_mfma_f32_32x32x16_f16 (A = K rows from LDS, B = Q^T held in registers): in the 32x32 accumulator layout every
+//     lane then holds 16 keys of ONE query column per key tile, so the softmax statistics are lane-local apart from one
+//     exchange with lane^32, and the probabilities are ALREADY in B-operand order for O^T = V^T P^T -- no cross-lane
+//     movement between the two GEMMs (the pairing of accumulator registers with key indices is mirrored in the V^T loads);
+//   * the odd token (the CLS query) is a ninth query tile with one live column: its keys are split over the 8
+//     wavefronts (12 MFMAs each), partial (max, sum, O) are merged through LDS by wavefront 0;
+//   * output goes straight to the [B, S, H, 96] layout the projection GEMM consumes (the library path needs a
+//     transpose copy).
+//
+// MFMA-bound by design: 2 x 4 x 257^2 x 96 flop per (image, head); HBM traffic = qkv read once + output written once.
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vlfm_amd.h"
+#include "profile.h"
+#include "status.h"
+
+namespace vlfm {
+
+using half4_t = __attribute__((ext_vector_type(4))) _Float16;
+using half8_t = __attribute__((ext_vector_type(8))) _Float16;
+using f32x16_t = __attribute__((ext_vector_type(16))) float;
+
+constexpr int AT_D = 96;                  // padded head width (88 real)
+constexpr int AT_NT = 8;                  // full 32-token tiles
+constexpr int AT_S = 32 * AT_NT + 1;      // 257 tokens
+constexpr int AT_KT = AT_NT + 1;          // key tiles incl. the one-token tail
+// LDS row strides (halfs).  Both operands are fetched with ds_read_b128, which the LDS serves in four fixed 16-lane
+// groups; the lanes of a group read 16 different rows at the same column, so a row stride of an ODD number of 16-byte
+// slots (13 and 37) puts them on 16 different slots: conflict-free.
+constexpr int AT_KS = AT_D + 8;           // 208 B = 13 slots
+constexpr int AT_VS = 32 * AT_KT + 8;     // 592 B = 37 slots
+constexpr int AT_KROWS = 32 * AT_KT;      // 288 (rows >= 257 are zero)
+constexpr int AT_WAVES = 8;
+constexpr size_t AT_LDS_K = (size_t)AT_KROWS * AT_KS * 2;        // 59 904 B
+constexpr size_t AT_LDS_V = (size_t)AT_D * AT_VS * 2;            // 56 832 B
+constexpr size_t AT_LDS_PART = (size_t)AT_WAVES * (AT_D + 2) * 4;  // partials of the CLS query
+constexpr size_t AT_LDS_BYTES = AT_LDS_K + AT_LDS_V + AT_LDS_PART;
+
+// Column of token ``key`` in a V^T row.  Accumulator register r of a 32x32 MFMA tile holds row (r & 3) + 8 (r >> 2) +
+// 4 (lane >> 5): the 8 probabilities a lane feeds to one PV MFMA belong to keys {4g..4g+3, 8+4g..8+4g+3} of a 16-key
+// chunk (g = lane >> 5).  V^T is stored with exactly those 8 keys adjacent, so the matching A operand is ONE 16-byte read.
+__device__ inline int vt_col(int key) {
+    const int e = key & 15;
+    return (key & ~15) + 8 * ((e >> 2) & 1) + 4 * (e >> 3) + (e & 3);
+}
+
+// Attention of the 32 query columns in ``qf`` against key tiles kt0 .. kt0+KT-1.  Returns the UNNORMALISED O^T
+// accumulators (3 tiles of 32 head channels), the column maximum of the raw scores and the column sum of
+// exp2((s - max) * c), all per lane for query column lane&31 (combined over both lane halves).
+template <int KT>
+__device__ inline void attend(const _Float16* __restrict__ Kl, const _Float16* __restrict__ Vl, const half8_t (&qf)[AT_D / 16],
+                              int kt0, float c, f32x16_t (&o)[AT_D / 32], float& m_out, float& l_out) {
+    const int lane = threadIdx.x & 63, col = lane & 31, grp = lane >> 5;
+    f32x16_t acc[KT];
+#pragma unroll
+    for (int t = 0; t < KT; t++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
+        const _Float16* krow = Kl + (size_t)(32 * (kt0 + t) + col) * AT_KS + 8 * grp;
+#pragma unroll
+        for (int kk = 0; kk < AT_D / 16; kk++) {
+            const half8_t a = *reinterpret_cast<const half8_t*>(krow + 16 * kk);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[kk], acc[t], 0, 0, 0);
+        }
+    }
+    // accumulator register r of tile t holds key 32 (kt0 + t) + (r & 3) + 8 (r >> 2) + 4 grp of query column ``col``
+    float m = -__builtin_huge_valf();
+#pragma unroll
+    for (int t = 0; t < KT; t++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int key = 32 * (kt0 + t) + (r & 3) + 8 * (r >> 2) + 4 * grp;
+            if (key >= AT_S) acc[t][r] = -__builtin_huge_valf();
+            m = fmaxf(m, acc[t][r]);
+        }
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.0f;
+#pragma unroll
+    for (int t = 0; t < KT; t++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float p = exp2f((acc[t][r] - m) * c);
+            l += p;
+            acc[t][r] = p;
+        }
+    }
+    l += __shfl_xor(l, 32, 64);
+#pragma unroll
+    for (int dt = 0; dt < AT_D / 32; dt++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[dt][r] = 0.0f;
+    }
+#pragma unroll
+    for (int t = 0; t < KT; t++) {
+#pragma unroll
+        for (int c2 = 0; c2 < 2; c2++) {
+            half8_t pb;
+#pragma unroll
+            for (int j = 0; j < 8; j++) pb[j] = (_Float16)acc[t][8 * c2 + j];
+            // keys behind pb[0..3]: 32 t + 16 c2 + 4 grp + (0..3); behind pb[4..7]: the same + 8 -- vt_col() order
+            const int col0 = 32 * (kt0 + t) + 16 * c2 + 8 * grp;
+#pragma unroll
+            for (int dt = 0; dt < AT_D / 32; dt++) {
+                const half8_t va = *reinterpret_cast<const half8_t*>(Vl + (size_t)(32 * dt + col) * AT_VS + col0);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pb, o[dt], 0, 0, 0);
+            }
+        }
+    }
+    m_out = m;
+    l_out = l;
+}
+
+__global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _Float16* __restrict__ qkv,
+                                                                         _Float16* __restrict__ out, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char at_lds[];
+    _Float16* Kl = reinterpret_cast<_Float16*>(at_lds);
+    _Float16* Vl = reinterpret_cast<_Float16*>(at_lds + AT_LDS_K);
+    float* part = reinterpret_cast<float*>(at_lds + AT_LDS_K + AT_LDS_V);
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nth = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, col = lane & 31, grp = lane >> 5;
+    const size_t row_halfs = (size_t)3 * H * AT_D;                       // one token of qkv: [3][H][96]
+    const _Float16* base = qkv + (size_t)b * AT_S * row_halfs + (size_t)h * AT_D;
+    // ---- stage K (row-major) and V^T into LDS; padding rows / columns are zero
+    for (int i = tid; i < (AT_KROWS - AT_S) * AT_KS; i += nth) Kl[(size_t)AT_S * AT_KS + i] = (_Float16)0.0f;
+    for (int i = tid; i < AT_D * (AT_KROWS - AT_S); i += nth) {   // keys 257 .. 287 of every V^T row
+        const int d = i / (AT_KROWS - AT_S), k = AT_S + i % (AT_KROWS - AT_S);
+        Vl[(size_t)d * AT_VS + vt_col(k)] = (_Float16)0.0f;
+    }
+    for (int i = tid; i < AT_S * (AT_D / 8); i += nth) {
+        const int s = i / (AT_D / 8), ch = i % (AT_D / 8);
+        const _Float16* src = base + (size_t)s * row_halfs + (size_t)H * AT_D + 8 * ch;   // K
+        const half8_t kv = *reinterpret_cast<const half8_t*>(src);
+        const half8_t vv = *reinterpret_cast<const half8_t*>(src + (size_t)H * AT_D);     // V
+        _Float16* kd = Kl + (size_t)s * AT_KS + 8 * ch;
+        *reinterpret_cast<half8_t*>(kd) = kv;
+#pragma unroll
+        for (int j = 0; j < 8; j++) Vl[(size_t)(8 * ch + j) * AT_VS + vt_col(s)] = vv[j];
+    }
+    __syncthreads();
+    const float c = scale * 1.4426950408889634f;   // exp(x * scale) = exp2(x * c)
+    // ---- the 32 queries of tokens 1 + 32 wave .. 32 + 32 wave
+    {
+        const int tq = 1 + 32 * wave + col;
+        const _Float16* qptr = base + (size_t)tq * row_halfs + 8 * grp;
+        half8_t qf[AT_D / 16];
+#pragma unroll
+        for (int kk = 0; kk < AT_D / 16; kk++) qf[kk] = *reinterpret_cast<const half8_t*>(qptr + 16 * kk);
+        f32x16_t o[AT_D / 32];
+        float m, l;
+        attend<AT_KT>(Kl, Vl, qf, 0, c, o, m, l);
+        const float inv = 1.0f / l;
+        _Float16* dst = out + ((size_t)(b * AT_S + tq) * H + h) * AT_D + 4 * grp;
+#pragma unroll
+        for (int dt = 0; dt < AT_D / 32; dt++) {
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++) {
+                const half4_t v = half4_t{(_Float16)(o[dt][4 * q4] * inv), (_Float16)(o[dt][4 * q4 + 1] * inv),
+                                          (_Float16)(o[dt][4 * q4 + 2] * inv), (_Float16)(o[dt][4 * q4 + 3] * inv)};
+                *reinterpret_cast<half4_t*>(dst + 32 * dt + 8 * q4) = v;
+            }
+        }
+    }
+    // ---- the CLS query (token 0): column 0 of a ninth query tile; keys split over the wavefronts
+    {
+        half8_t qf[AT_D / 16];
+#pragma unroll
+        for (int kk = 0; kk < AT_D / 16; kk++) {
+            half8_t z;
+#pragma unroll
+            for (int j = 0; j < 8; j++) z[j] = (_Float16)0.0f;
+            qf[kk] = col == 0 ? *reinterpret_cast<const half8_t*>(base + 8 * grp + 16 * kk) : z;
+        }
+        f32x16_t o[AT_D / 32];
+        float m, l;
+        if (wave < AT_WAVES - 1) attend<1>(Kl, Vl, qf, wave, c, o, m, l);
+        else attend<2>(Kl, Vl, qf, AT_WAVES - 1, c, o, m, l);       // key tiles 7 and 8 (the one-token tail)
+        float* mine = part + (size_t)wave * (AT_D + 2);
+        if (col == 0) {
+#pragma unroll
+            for (int dt = 0; dt < AT_D / 32; dt++) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) mine[32 * dt + (r & 3) + 8 * (r >> 2) + 4 * grp] = o[dt][r];
+            }
+            if (grp == 0) { mine[AT_D] = m; mine[AT_D + 1] = l; }
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float mx = -__builtin_huge_valf();
+#pragma unroll
+        for (int w = 0; w < AT_WAVES; w++) mx = fmaxf(mx, part[(size_t)w * (AT_D + 2) + AT_D]);
+        float wgt[AT_WAVES], lsum = 0.0f;
+#pragma unroll
+        for (int w = 0; w < AT_WAVES; w++) {
+            wgt[w] = exp2f((part[(size_t)w * (AT_D + 2) + AT_D] - mx) * c);
+            lsum += wgt[w] * part[(size_t)w * (AT_D + 2) + AT_D + 1];
+        }
+        const float inv = 1.0f / lsum;
+        _Float16* dst = out + ((size_t)(b * AT_S) * H + h) * AT_D;
+        for (int d = lane; d < AT_D; d += 64) {
+            float v = 0.0f;
+#pragma unroll
+            for (int w = 0; w < AT_WAVES; w++) v += wgt[w] * part[(size_t)w * (AT_D + 2) + d];
+            dst[d] = (_Float16)(v * inv);
+        }
+    }
+}
+
+}  // namespace vlfm
+
+using namespace vlfm;
+
+extern "C" int vlfm_vit_attention_f16(const void* d_qkv, void* d_out, int batch, int tokens, int heads, int head_dim,
+                                      float scale, void* stream) {
+    if (batch == 0) return VLFM_OK;
+    if (!d_qkv || !d_out || batch < 0 || heads <= 0)
+        return fail(VLFM_ERR_INVALID, "vit_attention_f16: bad argument");
+    if (tokens != AT_S || head_dim != AT_D)
+        return fail(VLFM_ERR_INVALID, "vit_attention_f16: specialised for 257 tokens and a (padded) head width of 96");
+    static bool opted_in = false;
+    if (!opted_in) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(vit_attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)AT_LDS_BYTES) != hipSuccess)
+            return fail(VLFM_ERR_HIP, "vit_attention_f16: cannot opt in to 114 KB of LDS");
+        opted_in = true;
+    }
+    VLFM_TIMED("vit_attention_kernel", stream);
+    VLFM_KLAUNCH(vit_attention_kernel, dim3(heads, batch), dim3(64 * AT_WAVES), AT_LDS_BYTES, (hipStream_t)stream,
+                 (const _Float16*)d_qkv, (_Float16*)d_out, heads, scale);
+    return check_launch("vit_attention_kernel");
+}

@@ -117,6 +117,104 @@ __global__ __launch_bounds__(256) void resample_v_sam_kernel(const unsigned char
     }
 }
 
+// ------------------------------------------------------------------------------------------------ LayerNorm(x + c)
+// y[r][:] = LayerNorm(x[r][:] + c[:]) * gamma + beta for f16 rows, statistics in f32 (two passes over registers).
+// ``c`` (f32, may be null) is a per-channel constant: the ViT's projection / fc2 biases are not added to the residual
+// stream by separate elementwise kernels -- the GEMMs accumulate into the stream (beta = 1) and the biases, which are
+// constants of the network, are summed once per layer and enter here.  HBM-bound: 2 B in + 2 B out per element.
+// One wavefront per row, LN_ROWS consecutive rows per wavefront so that c / gamma / beta stay in registers; the next
+// row's loads are issued before the current row is reduced.
+constexpr int LN_MAXV = 4;    // 16-byte vectors per lane -> D <= 64 * 8 * 4 = 2048
+constexpr int LN_ROWS = 8;    // upper bound of rows per wavefront (fewer when the batch is small)
+
+struct alignas(16) Half8 { __half2 h[4]; };
+
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bias_f16_kernel(const __half* __restrict__ x, const float* __restrict__ cb,
+                                                                 const __half* __restrict__ gamma,
+                                                                 const __half* __restrict__ beta, __half* __restrict__ y,
+                                                                 int rows, int D, float eps, int rows_per_wave) {
+    const int lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nvec = D >> 3;
+    const int r0 = wave * rows_per_wave;
+    if (r0 >= rows) return;
+    // per-channel constants of this lane's columns: 16-byte loads, kept packed (gamma / beta as half2) in registers
+    Half8 gm[NV], bt[NV];
+    float4 c0[NV], c1[NV];
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const int v = lane + 64 * i;
+        if (v < nvec) {
+            gm[i] = reinterpret_cast<const Half8*>(gamma)[v];
+            bt[i] = reinterpret_cast<const Half8*>(beta)[v];
+            c0[i] = cb ? reinterpret_cast<const float4*>(cb)[2 * v] : make_float4(0.f, 0.f, 0.f, 0.f);
+            c1[i] = cb ? reinterpret_cast<const float4*>(cb)[2 * v + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    Half8 cur[NV], nxt[NV], nx2[NV];
+    auto load_row = [&](int r, Half8* dst) {
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const int v = lane + 64 * i;
+            if (v < nvec) dst[i] = reinterpret_cast<const Half8*>(x + (size_t)r * D)[v];
+        }
+    };
+    // element j (0..7) of vector i as f32, with the channel constant added; 0 for lanes beyond the row
+    auto val = [&](const Half8* row, int i, int j) -> float {
+        const float2 t = __half22float2(row[i].h[j >> 1]);
+        const float cc = j < 4 ? (&c0[i].x)[j] : (&c1[i].x)[j - 4];
+        return ((j & 1) ? t.y : t.x) + cc;
+    };
+    const int r_end = min(rows, r0 + rows_per_wave);
+    load_row(r0, cur);
+    if (r0 + 1 < r_end) load_row(r0 + 1, nxt);
+    const float inv_d = 1.0f / (float)D;
+    for (int r = r0; r < r_end; r++) {
+        if (r + 2 < r_end) load_row(r + 2, nx2);   // two rows in flight behind the one being reduced
+        float sum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            if (lane + 64 * i < nvec) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) sum += val(cur, i, j);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        const float mean = sum * inv_d;
+        float sq = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            if (lane + 64 * i < nvec) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float dlt = val(cur, i, j) - mean;
+                    sq = fmaf(dlt, dlt, sq);
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+        const float rstd = rsqrtf(sq * inv_d + eps);
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const int v = lane + 64 * i;
+            if (v < nvec) {
+                Half8 o;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float2 g2 = __half22float2(gm[i].h[j]), b2 = __half22float2(bt[i].h[j]);
+                    o.h[j] = __floats2half2_rn((val(cur, i, 2 * j) - mean) * rstd * g2.x + b2.x,
+                                               (val(cur, i, 2 * j + 1) - mean) * rstd * g2.y + b2.y);
+                }
+                reinterpret_cast<Half8*>(y + (size_t)r * D)[v] = o;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NV; i++) { cur[i] = nxt[i]; nxt[i] = nx2[i]; }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ ITC head
 // One workgroup per image, one wavefront per query (round-robin): cos_q = <p_q, t> / max(|p_q|, 1e-12); out = max_q.
 __global__ __launch_bounds__(512) void itc_head_kernel(const float* __restrict__ proj, int NQ, int P,
@@ -273,4 +371,27 @@ extern "C" int vlfm_itc_head_batched(const float* d_proj, int batch, int n_query
     VLFM_KLAUNCH(itc_head_kernel, dim3(batch), dim3(512), 0, (hipStream_t)stream, d_proj, n_query, proj_dim,
                        d_text, d_out);
     return check_launch("itc_head_kernel");
+}
+
+extern "C" int vlfm_layernorm_bias_f16(const void* d_x, const float* d_channel_bias, const void* d_gamma, const void* d_beta,
+                                       void* d_y, int rows, int dim, float eps, void* stream) {
+    if (rows == 0) return VLFM_OK;
+    if (!d_x || !d_gamma || !d_beta || !d_y || rows < 0 || dim <= 0 || dim % 8 != 0 || dim > 64 * 8 * LN_MAXV)
+        return fail(VLFM_ERR_INVALID, "layernorm_bias_f16: dim must be a multiple of 8 and <= 2048");
+    const int nvec = dim / 8, nv = (nvec + 63) / 64;
+    // enough wavefronts to fill 256 CUs x 4 SIMDs a few times over before rows are batched per wavefront
+    int rpw = rows / 8192;
+    rpw = rpw < 1 ? 1 : rpw > LN_ROWS ? LN_ROWS : rpw;
+    const int waves = (rows + rpw - 1) / rpw;
+    const dim3 grid((waves + 3) / 4), block(256);
+    const __half* x = (const __half*)d_x; const __half* g = (const __half*)d_gamma; const __half* b = (const __half*)d_beta;
+    __half* y = (__half*)d_y;
+    VLFM_TIMED("layernorm_bias_f16_kernel", stream);
+    switch (nv) {
+        case 1: VLFM_KLAUNCH(layernorm_bias_f16_kernel<1>, grid, block, 0, (hipStream_t)stream, x, d_channel_bias, g, b, y, rows, dim, eps, rpw); break;
+        case 2: VLFM_KLAUNCH(layernorm_bias_f16_kernel<2>, grid, block, 0, (hipStream_t)stream, x, d_channel_bias, g, b, y, rows, dim, eps, rpw); break;
+        case 3: VLFM_KLAUNCH(layernorm_bias_f16_kernel<3>, grid, block, 0, (hipStream_t)stream, x, d_channel_bias, g, b, y, rows, dim, eps, rpw); break;
+        default: VLFM_KLAUNCH(layernorm_bias_f16_kernel<4>, grid, block, 0, (hipStream_t)stream, x, d_channel_bias, g, b, y, rows, dim, eps, rpw); break;
+    }
+    return check_launch("layernorm_bias_f16_kernel");
 }

@@ -73,6 +73,7 @@ class _VitBlock(nn.Module):
         self.fc2 = nn.Linear(c.v_mlp, c.v_hidden)
 
         self._packed = None
+        self.hip_attention = True  # vlfm_vit_attention_f16 at the ViT-g shape (257 tokens, heads padded to 96)
 
     def pack_heads(self, multiple: int = 32) -> None:
         """Inference-time repacking for the attention kernel: the 88-wide heads of ViT-g are zero-padded to the next
@@ -97,6 +98,30 @@ class _VitBlock(nn.Module):
         wp[:, :, :hd] = pw
         self._packed = (wq.view(3 * h * hp, d).contiguous(), bb.view(-1).contiguous(), wp.view(d, h * hp).contiguous(),
                         hp, float(hd) ** -0.5)
+
+    def forward_deferred(self, x: torch.Tensor, c_in: torch.Tensor, c_mid: torch.Tensor) -> torch.Tensor:
+        """Same block, residual adds folded into the GEMMs: ``x`` is the residual stream MINUS the bias vectors of all
+        projection / fc2 layers so far (``c_in`` = their f32 sum, a constant of the network; ``c_mid`` = c_in + this
+        block's projection bias).  LayerNorm(x + c) runs in one HIP kernel, the projection and fc2 GEMMs accumulate into
+        ``x`` in place (beta = 1), so the block has no standalone elementwise add: 2 x (read 2, write 1) passes over the
+        [B,257,1408] stream less per block.  Mathematically identical to forward(); f16 rounding of the stream differs
+        (the biases are added in f32 inside the LayerNorm instead of in f16 on the stream)."""
+        from . import ops
+
+        b, n, d = x.shape
+        wq, bq, wp, hp, scale = self._packed
+        h = ops.layernorm_bias(x, c_in, self.layer_norm1.weight, self.layer_norm1.bias, self.layer_norm1.eps)
+        qkv = F.linear(h.view(b * n, d), wq, bq)
+        if self.hip_attention and n == ops.VIT_ATTENTION_TOKENS and hp == ops.VIT_ATTENTION_HEAD:
+            a = ops.vit_attention(qkv, b, n, self.heads, hp, scale)       # [b*n, heads*hp], no transpose copy
+        else:
+            q = qkv.view(b, n, 3, self.heads, hp).permute(2, 0, 3, 1, 4)
+            a = F.scaled_dot_product_attention(q[0], q[1], q[2], scale=scale).transpose(1, 2).reshape(b * n, self.heads * hp)
+        x2 = x.view(b * n, d)
+        x2.addmm_(a, wp.t())
+        h = ops.layernorm_bias(x, c_mid, self.layer_norm2.weight, self.layer_norm2.bias, self.layer_norm2.eps)
+        x2.addmm_(F.gelu(F.linear(h, self.fc1.weight, self.fc1.bias)).view(b * n, -1), self.fc2.weight.t())
+        return x
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         b, n, d = x.shape
@@ -174,6 +199,10 @@ class Blip2ITCModel(nn.Module):
         self.q_layers = nn.ModuleList([_QFormerLayer(c, i) for i in range(c.q_layers)])
         self.vision_projection = nn.Linear(c.q_hidden, c.proj_dim)
         self.text_projection = nn.Linear(c.q_hidden, c.proj_dim)
+        # inference fast path of the ViT (f16, packed heads, HIP device): residual adds folded into the GEMMs, see
+        # _VitBlock.forward_deferred.  _deferred_c caches the per-layer bias sums; anything that changes weights clears it.
+        self.deferred_bias = True
+        self._deferred_c: Optional[torch.Tensor] = None
 
     # ---- weights ---------------------------------------------------------------------------------------------
     def init_random(self, seed: int = 0) -> "Blip2ITCModel":
@@ -188,6 +217,7 @@ class Blip2ITCModel(nn.Module):
             for m in self.modules():
                 if isinstance(m, nn.LayerNorm):
                     m.weight.fill_(1.0)
+        self._deferred_c = None
         return self
 
     def vision_dtype(self) -> torch.dtype:
@@ -199,6 +229,7 @@ class Blip2ITCModel(nn.Module):
             m.to(vision_dtype)
         self.class_embedding.data = self.class_embedding.data.to(vision_dtype)
         self.position_embedding.data = self.position_embedding.data.to(vision_dtype)
+        self._deferred_c = None
         return self
 
     def load_hf_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
@@ -261,9 +292,32 @@ class Blip2ITCModel(nn.Module):
         w = self.patch_embedding.weight
         x = F.linear(pixel_values.to(w.dtype), w.view(w.shape[0], -1), self.patch_embedding.bias)
         x = torch.cat([self.class_embedding.expand(x.shape[0], -1, -1), x], dim=1) + self.position_embedding
+        if self.deferred_bias and x.is_cuda and x.dtype == torch.float16 and self.blocks[0]._packed is not None \
+                and self.blocks[0]._packed[0].dtype == torch.float16:
+            from . import ops
+
+            c = self._deferred_constants()
+            x = x.contiguous()
+            for i, blk in enumerate(self.blocks):
+                x = blk.forward_deferred(x, c[2 * i], c[2 * i + 1])
+            return ops.layernorm_bias(x, c[2 * len(self.blocks)], self.post_layernorm.weight, self.post_layernorm.bias,
+                                      self.post_layernorm.eps)
         for blk in self.blocks:
             x = blk(x)
         return self.post_layernorm(x)
+
+    def _deferred_constants(self) -> torch.Tensor:
+        """[2 L + 1][hidden] f32: running sum of the projection / fc2 bias vectors in front of every LayerNorm."""
+        if self._deferred_c is None or self._deferred_c.device != self.post_layernorm.weight.device:
+            rows, run = [], torch.zeros(self.cfg.v_hidden, dtype=torch.float32, device=self.post_layernorm.weight.device)
+            for blk in self.blocks:
+                rows.append(run.clone())
+                run = run + blk.projection.bias.detach().float()
+                rows.append(run.clone())
+                run = run + blk.fc2.bias.detach().float()
+            rows.append(run.clone())
+            self._deferred_c = torch.stack(rows).contiguous()
+        return self._deferred_c
 
     def query_features(self, image_tokens: torch.Tensor) -> torch.Tensor:
         """Q-Former query branch: [B,257,1408] -> [B,32,768] (fp32)."""

@@ -113,3 +113,29 @@ def preprocess_sam(images_u8: torch.Tensor, long_side: int = 1024) -> Tuple[torc
                                                          ctypes.addressof(m), ctypes.addressof(s), long_side,
                                                          tmp.data_ptr(), out.data_ptr(), _stream()), "preprocess_sam")
     return out, (oh, ow)
+
+
+def layernorm_bias(x: torch.Tensor, channel_bias, weight: torch.Tensor, bias: torch.Tensor, eps: float) -> torch.Tensor:
+    """LayerNorm(x + channel_bias) over the last dimension of an f16 tensor (HIP kernel, f32 statistics);
+    ``channel_bias`` is an f32 [dim] constant or None."""
+    assert x.is_cuda and x.dtype == torch.float16 and x.is_contiguous() and weight.dtype == torch.float16
+    dim = x.shape[-1]
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().vlfm_layernorm_bias_f16(x.data_ptr(), channel_bias.data_ptr() if channel_bias is not None else None,
+                                                  weight.data_ptr(), bias.data_ptr(), y.data_ptr(), x.numel() // dim, dim,
+                                                  float(eps), _stream()), "layernorm_bias_f16")
+    return y
+
+
+VIT_ATTENTION_TOKENS, VIT_ATTENTION_HEAD = 257, 96
+
+
+def vit_attention(qkv: torch.Tensor, batch: int, tokens: int, heads: int, head_dim: int, scale: float) -> torch.Tensor:
+    """softmax(q k^T * scale) v for the ViT-g shape (257 tokens, heads padded to 96): ``qkv`` is the qkv GEMM's output
+    [batch*tokens, 3*heads*head_dim] f16 as it is; returns [batch*tokens, heads*head_dim] f16 for the projection GEMM."""
+    assert qkv.is_cuda and qkv.dtype == torch.float16 and qkv.is_contiguous()
+    assert qkv.numel() == batch * tokens * 3 * heads * head_dim
+    out = torch.empty((batch * tokens, heads * head_dim), dtype=torch.float16, device=qkv.device)
+    _lib.check(_lib.lib().vlfm_vit_attention_f16(qkv.data_ptr(), out.data_ptr(), batch, tokens, heads, head_dim,
+                                                 float(scale), _stream()), "vit_attention_f16")
+    return out
