@@ -87,11 +87,12 @@ __device__ inline void attend(const _Float16* __restrict__ Kl, const _Float16* _
     }
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     float l = 0.0f;
+    const float mc = -m * c;
 #pragma unroll
     for (int t = 0; t < KT; t++) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const float p = exp2f((acc[t][r] - m) * c);
+            const float p = __builtin_amdgcn_exp2f(fmaf(acc[t][r], c, mc));   // v_exp_f32: argument <= 0, denormals may flush
             l += p;
             acc[t][r] = p;
         }
@@ -123,12 +124,19 @@ __device__ inline void attend(const _Float16* __restrict__ Kl, const _Float16* _
 }
 
 __global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _Float16* __restrict__ qkv,
-                                                                         _Float16* __restrict__ out, int H, float scale) {
+                                                                         _Float16* __restrict__ out, int B, int H,
+                                                                         float scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char at_lds[];
     _Float16* Kl = reinterpret_cast<_Float16*>(at_lds);
     _Float16* Vl = reinterpret_cast<_Float16*>(at_lds + AT_LDS_K);
     float* part = reinterpret_cast<float*>(at_lds + AT_LDS_K + AT_LDS_V);
-    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nth = blockDim.x;
+    // XCD-aware placement: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2).  A head's K / V
+    // rows are 192-byte pieces of 9 KB token rows, so neighbouring heads share cache lines: all 16 heads of an image are
+    // given to ONE XCD, back to back, and each line is fetched from HBM once instead of once per XCD that touches it.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int b = xcd + 8 * (slot / H), h = slot % H;
+    if (b >= B) return;
+    const int tid = threadIdx.x, nth = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, col = lane & 31, grp = lane >> 5;
     const size_t row_halfs = (size_t)3 * H * AT_D;                       // one token of qkv: [3][H][96]
     const _Float16* base = qkv + (size_t)b * AT_S * row_halfs + (size_t)h * AT_D;
@@ -138,28 +146,55 @@ __global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _
         const int d = i / (AT_KROWS - AT_S), k = AT_S + i % (AT_KROWS - AT_S);
         Vl[(size_t)d * AT_VS + vt_col(k)] = (_Float16)0.0f;
     }
-    for (int i = tid; i < AT_S * (AT_D / 8); i += nth) {
-        const int s = i / (AT_D / 8), ch = i % (AT_D / 8);
-        const _Float16* src = base + (size_t)s * row_halfs + (size_t)H * AT_D + 8 * ch;   // K
-        const half8_t kv = *reinterpret_cast<const half8_t*>(src);
-        const half8_t vv = *reinterpret_cast<const half8_t*>(src + (size_t)H * AT_D);     // V
-        _Float16* kd = Kl + (size_t)s * AT_KS + 8 * ch;
-        *reinterpret_cast<half8_t*>(kd) = kv;
+    // All global loads of the staging phase are issued before the first LDS write (one exposure to HBM latency, not
+    // one per iteration); a work item is (token pair, 8-channel chunk) so that V^T is written two tokens (4 bytes) at
+    // a time -- vt_col() keeps an even token and its successor adjacent.
+    constexpr int kPairs = (AT_S + 1) / 2, kItems = kPairs * (AT_D / 8), kIters = (kItems + 64 * AT_WAVES - 1) / (64 * AT_WAVES);
+    half8_t kreg[kIters][2], vreg[kIters][2];
 #pragma unroll
-        for (int j = 0; j < 8; j++) Vl[(size_t)(8 * ch + j) * AT_VS + vt_col(s)] = vv[j];
+    for (int it = 0; it < kIters; it++) {
+        const int i = tid + it * 64 * AT_WAVES;
+        const int s0 = 2 * (i / (AT_D / 8)), ch = i % (AT_D / 8);
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int s = s0 + u;
+            if (i < kItems && s < AT_S) {
+                const _Float16* src = base + (size_t)s * row_halfs + (size_t)H * AT_D + 8 * ch;
+                kreg[it][u] = *reinterpret_cast<const half8_t*>(src);                      // K
+                vreg[it][u] = *reinterpret_cast<const half8_t*>(src + (size_t)H * AT_D);   // V
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) { kreg[it][u][j] = (_Float16)0.0f; vreg[it][u][j] = (_Float16)0.0f; }
+            }
+        }
+    }
+    // the Q fragments of this wavefront's 32 queries travel while K / V are being staged
+    const int tq = 1 + 32 * wave + col;
+    half8_t qmain[AT_D / 16];
+#pragma unroll
+    for (int kk = 0; kk < AT_D / 16; kk++)
+        qmain[kk] = *reinterpret_cast<const half8_t*>(base + (size_t)tq * row_halfs + 8 * grp + 16 * kk);
+#pragma unroll
+    for (int it = 0; it < kIters; it++) {
+        const int i = tid + it * 64 * AT_WAVES;
+        const int s0 = 2 * (i / (AT_D / 8)), ch = i % (AT_D / 8);
+        if (i < kItems) {
+            *reinterpret_cast<half8_t*>(Kl + (size_t)s0 * AT_KS + 8 * ch) = kreg[it][0];
+            if (s0 + 1 < AT_S) *reinterpret_cast<half8_t*>(Kl + (size_t)(s0 + 1) * AT_KS + 8 * ch) = kreg[it][1];
+            const int vc = vt_col(s0);   // s0 is even: vt_col(s0 + 1) == vc + 1 (token 257 does not exist: zero)
+            using half2_t = __attribute__((ext_vector_type(2))) _Float16;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                *reinterpret_cast<half2_t*>(Vl + (size_t)(8 * ch + j) * AT_VS + vc) = half2_t{vreg[it][0][j], vreg[it][1][j]};
+        }
     }
     __syncthreads();
     const float c = scale * 1.4426950408889634f;   // exp(x * scale) = exp2(x * c)
     // ---- the 32 queries of tokens 1 + 32 wave .. 32 + 32 wave
     {
-        const int tq = 1 + 32 * wave + col;
-        const _Float16* qptr = base + (size_t)tq * row_halfs + 8 * grp;
-        half8_t qf[AT_D / 16];
-#pragma unroll
-        for (int kk = 0; kk < AT_D / 16; kk++) qf[kk] = *reinterpret_cast<const half8_t*>(qptr + 16 * kk);
         f32x16_t o[AT_D / 32];
         float m, l;
-        attend<AT_KT>(Kl, Vl, qf, 0, c, o, m, l);
+        attend<AT_KT>(Kl, Vl, qmain, 0, c, o, m, l);
         const float inv = 1.0f / l;
         _Float16* dst = out + ((size_t)(b * AT_S + tq) * H + h) * AT_D + 4 * grp;
 #pragma unroll
@@ -237,7 +272,7 @@ extern "C" int vlfm_vit_attention_f16(const void* d_qkv, void* d_out, int batch,
         opted_in = true;
     }
     VLFM_TIMED("vit_attention_kernel", stream);
-    VLFM_KLAUNCH(vit_attention_kernel, dim3(heads, batch), dim3(64 * AT_WAVES), AT_LDS_BYTES, (hipStream_t)stream,
-                 (const _Float16*)d_qkv, (_Float16*)d_out, heads, scale);
+    VLFM_KLAUNCH(vit_attention_kernel, dim3(8 * ((batch + 7) / 8) * heads), dim3(64 * AT_WAVES), AT_LDS_BYTES,
+                 (hipStream_t)stream, (const _Float16*)d_qkv, (_Float16*)d_out, batch, heads, scale);
     return check_launch("vit_attention_kernel");
 }
