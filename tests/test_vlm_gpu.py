@@ -183,3 +183,37 @@ def test_vit_fast_path_full_geometry_vs_plain(gpu_device):
         plain = m.vision_tokens(pat).float()
     assert (mid - plain).abs().max() <= 6e-2 and (fast - plain).abs().max() <= 6e-2   # 39 blocks of f16 rounding noise
     assert (fast - plain).abs().mean() <= 4e-3 and (fast - mid).abs().mean() <= 4e-3
+
+
+def test_qformer_split_kv_projection_is_f32_grade(gpu_device):
+    """Cross-attention K/V projection of f16 tokens through the exact 3-way weight split (three f16 x f16 -> f32 GEMMs)
+    against the plain f32 GEMM path and against f64: not less accurate than the f32 GEMM."""
+    from vlfm_amd.vlm.blip2itm import Blip2ITCConfig, Blip2ITCModel
+
+    cfg = Blip2ITCConfig(image_size=56, patch_size=14, v_hidden=176, v_layers=1, v_heads=2, v_mlp=352, q_hidden=64,
+                         q_layers=4, q_heads=4, q_mlp=128, vocab_size=100, max_position_embeddings=40,
+                         num_query_tokens=8, proj_dim=16)
+    m = Blip2ITCModel(cfg).init_random(11).eval()
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.3 if p.dim() > 1 else 0.1) + (1.0 if "LayerNorm.weight" in n else 0.0))
+    ref64 = Blip2ITCModel(cfg).eval().double()
+    ref64.load_state_dict({k: v.double() for k, v in m.state_dict().items()})
+    m.to(gpu_device)
+    m.split_kv_min_rows = 0
+    tokens16 = (torch.randn(6, 17, 176, generator=g) * 2).half()
+    with torch.inference_mode():
+        want = ref64.query_features(tokens16.double())
+        m.split_kv = True
+        split = m.query_features(tokens16.to(gpu_device)).double().cpu()
+        m.split_kv = False
+        plain = m.query_features(tokens16.to(gpu_device)).double().cpu()
+    e_split, e_plain = (split - want).abs().max(), (plain - want).abs().max()
+    assert e_split <= 5e-5 and e_plain <= 5e-5, (float(e_split), float(e_plain))
+    assert e_split <= 2.0 * e_plain + 1e-6   # f32-grade
+    layer = next(l for l in m.q_layers if l.crossattention is not None).crossattention
+    w1t, w2t, w3t, _ = layer._kv_split
+    rec = w1t.double() + w2t.double() / 2048 + w3t.double() / 2048 ** 2
+    full = torch.cat([layer.key.weight, layer.value.weight]).detach().double().t()
+    assert float((rec - full).abs().max()) <= 1e-12    # the three f16 pieces carry the f32 weights (2^-33 relative)
