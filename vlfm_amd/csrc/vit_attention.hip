@@ -45,7 +45,20 @@ constexpr int AT_WAVES = 8;
 constexpr size_t AT_LDS_K = (size_t)AT_KROWS * AT_KS * 2;        // 59 904 B
 constexpr size_t AT_LDS_V = (size_t)AT_D * AT_VS * 2;            // 56 832 B
 constexpr size_t AT_LDS_PART = (size_t)AT_WAVES * (AT_D + 2) * 4;  // partials of the CLS query
-constexpr size_t AT_LDS_BYTES = AT_LDS_K + AT_LDS_V + AT_LDS_PART;
+constexpr size_t AT_LDS_QCLS = (size_t)AT_D * 2;                   // the CLS query row
+constexpr size_t AT_LDS_BYTES = AT_LDS_K + AT_LDS_V + AT_LDS_PART + AT_LDS_QCLS;
+
+// Optional phase timing (diagnostic build with -DVLFM_PHASE_TIMING; tools/vit_attn_phase_probe.py): lane 0 of wavefront 0
+// of the LAST workgroup stamps the 100 MHz wall clock at phase boundaries.
+#ifdef VLFM_PHASE_TIMING
+__device__ long long g_att_clk[16];
+#define AT_PHASE(k)                                                                              \
+    do {                                                                                         \
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) g_att_clk[k] = wall_clock64();      \
+    } while (0)
+#else
+#define AT_PHASE(k) do {} while (0)
+#endif
 
 // Column of token ``key`` in a V^T row.  Accumulator register r of a 32x32 MFMA tile holds row (r & 3) + 8 (r >> 2) +
 // 4 (lane >> 5): the 8 probabilities a lane feeds to one PV MFMA belong to keys {4g..4g+3, 8+4g..8+4g+3} of a 16-key
@@ -67,13 +80,33 @@ __device__ inline void attend(const _Float16* __restrict__ Kl, const _Float16* _
     for (int t = 0; t < KT; t++) {
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
-        const _Float16* krow = Kl + (size_t)(32 * (kt0 + t) + col) * AT_KS + 8 * grp;
+    }
+    // S^T = K Q^T.  Key tiles are taken in groups of (up to) 3 with the contraction step as the outer loop: consecutive
+    // MFMAs then write DIFFERENT accumulators (a dependent MFMA is three issue slots away), and the K operands of step
+    // kk + 1 are fetched from LDS while step kk is in the matrix pipe.
+    constexpr int G = KT >= 3 ? 3 : KT;
+    static_assert(KT % G == 0, "key tiles come in whole groups");
+    const _Float16* kbase = Kl + (size_t)(32 * kt0 + col) * AT_KS + 8 * grp;
+#pragma unroll
+    for (int g0 = 0; g0 < KT; g0 += G) {
+        half8_t a_cur[G], a_nxt[G];
+#pragma unroll
+        for (int t = 0; t < G; t++) a_cur[t] = *reinterpret_cast<const half8_t*>(kbase + (size_t)(32 * (g0 + t)) * AT_KS);
 #pragma unroll
         for (int kk = 0; kk < AT_D / 16; kk++) {
-            const half8_t a = *reinterpret_cast<const half8_t*>(krow + 16 * kk);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[kk], acc[t], 0, 0, 0);
+            if (kk + 1 < AT_D / 16) {
+#pragma unroll
+                for (int t = 0; t < G; t++)
+                    a_nxt[t] = *reinterpret_cast<const half8_t*>(kbase + (size_t)(32 * (g0 + t)) * AT_KS + 16 * (kk + 1));
+            }
+#pragma unroll
+            for (int t = 0; t < G; t++)
+                acc[g0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[t], qf[kk], acc[g0 + t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < G; t++) a_cur[t] = a_nxt[t];
         }
     }
+    if (KT == AT_KT) AT_PHASE(4);
     // accumulator register r of tile t holds key 32 (kt0 + t) + (r & 3) + 8 (r >> 2) + 4 grp of query column ``col``
     float m = -__builtin_huge_valf();
 #pragma unroll
@@ -98,26 +131,32 @@ __device__ inline void attend(const _Float16* __restrict__ Kl, const _Float16* _
         }
     }
     l += __shfl_xor(l, 32, 64);
+    if (KT == AT_KT) AT_PHASE(5);
 #pragma unroll
     for (int dt = 0; dt < AT_D / 32; dt++) {
 #pragma unroll
         for (int r = 0; r < 16; r++) o[dt][r] = 0.0f;
     }
+    // O^T = V^T P^T: three channel tiles per 16-key chunk (independent accumulators), the next chunk's V^T operands in flight
+    const _Float16* vbase = Vl + (size_t)col * AT_VS + 32 * kt0 + 8 * grp;
+    half8_t v_cur[AT_D / 32], v_nxt[AT_D / 32];
 #pragma unroll
-    for (int t = 0; t < KT; t++) {
+    for (int dt = 0; dt < AT_D / 32; dt++) v_cur[dt] = *reinterpret_cast<const half8_t*>(vbase + (size_t)(32 * dt) * AT_VS);
 #pragma unroll
-        for (int c2 = 0; c2 < 2; c2++) {
-            half8_t pb;
+    for (int ch = 0; ch < 2 * KT; ch++) {       // chunk ch = 16 keys: tile ch / 2, half ch & 1
+        if (ch + 1 < 2 * KT) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) pb[j] = (_Float16)acc[t][8 * c2 + j];
-            // keys behind pb[0..3]: 32 t + 16 c2 + 4 grp + (0..3); behind pb[4..7]: the same + 8 -- vt_col() order
-            const int col0 = 32 * (kt0 + t) + 16 * c2 + 8 * grp;
-#pragma unroll
-            for (int dt = 0; dt < AT_D / 32; dt++) {
-                const half8_t va = *reinterpret_cast<const half8_t*>(Vl + (size_t)(32 * dt + col) * AT_VS + col0);
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pb, o[dt], 0, 0, 0);
-            }
+            for (int dt = 0; dt < AT_D / 32; dt++)
+                v_nxt[dt] = *reinterpret_cast<const half8_t*>(vbase + (size_t)(32 * dt) * AT_VS + 16 * (ch + 1));
         }
+        half8_t pb;
+        // keys behind pb[0..3]: 16 ch + 4 grp + (0..3); behind pb[4..7]: the same + 8 -- the order vt_col() stores
+#pragma unroll
+        for (int j = 0; j < 8; j++) pb[j] = (_Float16)acc[ch >> 1][8 * (ch & 1) + j];
+#pragma unroll
+        for (int dt = 0; dt < AT_D / 32; dt++) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_cur[dt], pb, o[dt], 0, 0, 0);
+#pragma unroll
+        for (int dt = 0; dt < AT_D / 32; dt++) v_cur[dt] = v_nxt[dt];
     }
     m_out = m;
     l_out = l;
@@ -125,11 +164,12 @@ __device__ inline void attend(const _Float16* __restrict__ Kl, const _Float16* _
 
 __global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _Float16* __restrict__ qkv,
                                                                          _Float16* __restrict__ out, int B, int H,
-                                                                         float scale) {
+                                                                         float scale, int stagger) {
     extern __shared__ __attribute__((aligned(16))) unsigned char at_lds[];
     _Float16* Kl = reinterpret_cast<_Float16*>(at_lds);
     _Float16* Vl = reinterpret_cast<_Float16*>(at_lds + AT_LDS_K);
     float* part = reinterpret_cast<float*>(at_lds + AT_LDS_K + AT_LDS_V);
+    _Float16* qcls = reinterpret_cast<_Float16*>(at_lds + AT_LDS_K + AT_LDS_V + AT_LDS_PART);
     // XCD-aware placement: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2).  A head's K / V
     // rows are 192-byte pieces of 9 KB token rows, so neighbouring heads share cache lines: all 16 heads of an image are
     // given to ONE XCD, back to back, and each line is fetched from HBM once instead of once per XCD that touches it.
@@ -137,6 +177,7 @@ __global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _
     const int b = xcd + 8 * (slot / H), h = slot % H;
     if (b >= B) return;
     const int tid = threadIdx.x, nth = blockDim.x;
+    AT_PHASE(0);
     const int lane = tid & 63, wave = tid >> 6, col = lane & 31, grp = lane >> 5;
     const size_t row_halfs = (size_t)3 * H * AT_D;                       // one token of qkv: [3][H][96]
     const _Float16* base = qkv + (size_t)b * AT_S * row_halfs + (size_t)h * AT_D;
@@ -168,12 +209,14 @@ __global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _
             }
         }
     }
+    AT_PHASE(1);
     // the Q fragments of this wavefront's 32 queries travel while K / V are being staged
     const int tq = 1 + 32 * wave + col;
     half8_t qmain[AT_D / 16];
 #pragma unroll
     for (int kk = 0; kk < AT_D / 16; kk++)
         qmain[kk] = *reinterpret_cast<const half8_t*>(base + (size_t)tq * row_halfs + 8 * grp + 16 * kk);
+    if (tid < AT_D / 8) *reinterpret_cast<half8_t*>(qcls + 8 * tid) = *reinterpret_cast<const half8_t*>(base + 8 * tid);
 #pragma unroll
     for (int it = 0; it < kIters; it++) {
         const int i = tid + it * 64 * AT_WAVES;
@@ -188,13 +231,45 @@ __global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _
                 *reinterpret_cast<half2_t*>(Vl + (size_t)(8 * ch + j) * AT_VS + vc) = half2_t{vreg[it][0][j], vreg[it][1][j]};
         }
     }
+    AT_PHASE(2);
     __syncthreads();
+    AT_PHASE(3);
     const float c = scale * 1.4426950408889634f;   // exp(x * scale) = exp2(x * c)
+    // ---- the CLS query (token 0): column 0 of a ninth query tile; its keys are split over the wavefronts (tile w for
+    // wavefront w, tiles 7 and 8 for the last), partial (max, sum, O) go to LDS and are merged below
+    auto cls_part = [&]() {
+        half8_t qf[AT_D / 16];
+#pragma unroll
+        for (int kk = 0; kk < AT_D / 16; kk++) {
+            half8_t z;
+#pragma unroll
+            for (int j = 0; j < 8; j++) z[j] = (_Float16)0.0f;
+            qf[kk] = col == 0 ? *reinterpret_cast<const half8_t*>(qcls + 8 * grp + 16 * kk) : z;
+        }
+        f32x16_t o[AT_D / 32];
+        float m, l;
+        if (wave < AT_WAVES - 1) attend<1>(Kl, Vl, qf, wave, c, o, m, l);
+        else attend<2>(Kl, Vl, qf, AT_WAVES - 1, c, o, m, l);
+        float* mine = part + (size_t)wave * (AT_D + 2);
+        if (col == 0) {
+#pragma unroll
+            for (int dt = 0; dt < AT_D / 32; dt++) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) mine[32 * dt + (r & 3) + 8 * (r >> 2) + 4 * grp] = o[dt][r];
+            }
+            if (grp == 0) { mine[AT_D] = m; mine[AT_D + 1] = l; }
+        }
+    };
+    // Wavefronts w and w + 4 share a SIMD: the upper four do their (short) CLS share first, so that the pair is out of
+    // phase -- one in the matrix pipe while the other does softmax VALU work.
+    const bool cls_first = stagger && wave >= AT_WAVES / 2;
+    if (cls_first) cls_part();
     // ---- the 32 queries of tokens 1 + 32 wave .. 32 + 32 wave
     {
         f32x16_t o[AT_D / 32];
         float m, l;
         attend<AT_KT>(Kl, Vl, qmain, 0, c, o, m, l);
+        AT_PHASE(7);
         const float inv = 1.0f / l;
         _Float16* dst = out + ((size_t)(b * AT_S + tq) * H + h) * AT_D + 4 * grp;
 #pragma unroll
@@ -207,31 +282,11 @@ __global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _
             }
         }
     }
-    // ---- the CLS query (token 0): column 0 of a ninth query tile; keys split over the wavefronts
-    {
-        half8_t qf[AT_D / 16];
-#pragma unroll
-        for (int kk = 0; kk < AT_D / 16; kk++) {
-            half8_t z;
-#pragma unroll
-            for (int j = 0; j < 8; j++) z[j] = (_Float16)0.0f;
-            qf[kk] = col == 0 ? *reinterpret_cast<const half8_t*>(base + 8 * grp + 16 * kk) : z;
-        }
-        f32x16_t o[AT_D / 32];
-        float m, l;
-        if (wave < AT_WAVES - 1) attend<1>(Kl, Vl, qf, wave, c, o, m, l);
-        else attend<2>(Kl, Vl, qf, AT_WAVES - 1, c, o, m, l);       // key tiles 7 and 8 (the one-token tail)
-        float* mine = part + (size_t)wave * (AT_D + 2);
-        if (col == 0) {
-#pragma unroll
-            for (int dt = 0; dt < AT_D / 32; dt++) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) mine[32 * dt + (r & 3) + 8 * (r >> 2) + 4 * grp] = o[dt][r];
-            }
-            if (grp == 0) { mine[AT_D] = m; mine[AT_D + 1] = l; }
-        }
-    }
+    AT_PHASE(8);
+    if (!cls_first) cls_part();
+    AT_PHASE(9);
     __syncthreads();
+    AT_PHASE(10);
     if (wave == 0) {
         float mx = -__builtin_huge_valf();
 #pragma unroll
@@ -251,6 +306,7 @@ __global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _
             dst[d] = (_Float16)(v * inv);
         }
     }
+    AT_PHASE(11);
 }
 
 }  // namespace vlfm
@@ -271,8 +327,15 @@ extern "C" int vlfm_vit_attention_f16(const void* d_qkv, void* d_out, int batch,
             return fail(VLFM_ERR_HIP, "vit_attention_f16: cannot opt in to 114 KB of LDS");
         opted_in = true;
     }
+    const int stagger = 1;  // measured neutral to +3 %; kept: it costs nothing
     VLFM_TIMED("vit_attention_kernel", stream);
     VLFM_KLAUNCH(vit_attention_kernel, dim3(8 * ((batch + 7) / 8) * heads), dim3(64 * AT_WAVES), AT_LDS_BYTES,
-                 (hipStream_t)stream, (const _Float16*)d_qkv, (_Float16*)d_out, batch, heads, scale);
+                 (hipStream_t)stream, (const _Float16*)d_qkv, (_Float16*)d_out, batch, heads, scale, stagger);
     return check_launch("vit_attention_kernel");
 }
+
+#ifdef VLFM_PHASE_TIMING
+extern "C" int vlfm_debug_attention_clocks(long long* h_out16) {
+    return hipMemcpyFromSymbol(h_out16, HIP_SYMBOL(g_att_clk), sizeof(long long) * 16) == hipSuccess ? VLFM_OK : VLFM_ERR_HIP;
+}
+#endif
