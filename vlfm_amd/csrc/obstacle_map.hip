@@ -1201,14 +1201,10 @@ extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, in
     rc = check_launch("fog_of_war_kernel");
     if (rc != VLFM_OK) return rc;
     {
-        static bool lds_opt_in = false;  // > 64 KB of dynamic LDS needs an explicit opt-in per kernel
-        if (!lds_opt_in) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(explored_select_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWalkLdsBytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(frontier_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWalkLdsBytes);
-            lds_opt_in = true;
-        }
+        static LdsOptIn opt_select, opt_frontier;
+        if (!opt_select.ensure(reinterpret_cast<const void*>(explored_select_kernel), kWalkLdsBytes) ||
+            !opt_frontier.ensure(reinterpret_cast<const void*>(frontier_kernel), kWalkLdsBytes))
+            return fail(VLFM_ERR_HIP, "obstacle_map_update_batched: cannot opt in to 144 KB of LDS");
         SelectScratch ss{planes[0], planes[1], planes[2], planes[3], pts, starts, lens, status + (size_t)n_envs * 4,
                          cap_pts, cap_contours, kWalkLdsBytes};
         VLFM_TIMED("explored_select_kernel", s);

@@ -19,4 +19,17 @@ inline int check_launch(const char* what) {
     }
     return VLFM_OK;
 }
+// More than 64 KB of dynamic LDS needs an explicit opt-in per kernel AND per device.  One instance per call site
+// (function-local static); remembers which devices of this process have been done.
+struct LdsOptIn {
+    unsigned long long done = 0;
+    bool ensure(const void* kernel, size_t bytes) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (dev < 64 && ((done >> dev) & 1ull)) return true;
+        if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+        if (dev < 64) done |= 1ull << dev;
+        return true;
+    }
+};
 }  // namespace vlfm

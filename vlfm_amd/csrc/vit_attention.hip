@@ -320,13 +320,9 @@ extern "C" int vlfm_vit_attention_f16(const void* d_qkv, void* d_out, int batch,
         return fail(VLFM_ERR_INVALID, "vit_attention_f16: bad argument");
     if (tokens != AT_S || head_dim != AT_D)
         return fail(VLFM_ERR_INVALID, "vit_attention_f16: specialised for 257 tokens and a (padded) head width of 96");
-    static bool opted_in = false;
-    if (!opted_in) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(vit_attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)AT_LDS_BYTES) != hipSuccess)
-            return fail(VLFM_ERR_HIP, "vit_attention_f16: cannot opt in to 114 KB of LDS");
-        opted_in = true;
-    }
+    static LdsOptIn opt_in;
+    if (!opt_in.ensure(reinterpret_cast<const void*>(vit_attention_kernel), AT_LDS_BYTES))
+        return fail(VLFM_ERR_HIP, "vit_attention_f16: cannot opt in to 117 KB of LDS");
     const int stagger = 1;  // measured neutral to +3 %; kept: it costs nothing
     VLFM_TIMED("vit_attention_kernel", stream);
     VLFM_KLAUNCH(vit_attention_kernel, dim3(8 * ((batch + 7) / 8) * heads), dim3(64 * AT_WAVES), AT_LDS_BYTES,
