@@ -274,7 +274,9 @@ def main():
 
         entry("depth_ingest_kernel", E * 4 * H * W)
         entry("depth_scatter_kernel", E * 4 * H * W)
-        entry("depth_ingest_scatter_kernel", E * 4 * H * W)
+        # one pass that replaces BOTH of the reference's reads of the depth image (column maximum for the value map,
+        # unprojection for the obstacle map): SURVEY.md 8d prices them at 4*H*W each
+        entry("depth_ingest_scatter_kernel", E * 8 * H * W)
         entry("value_map_fuse_kernel", E * (4 * T * T + 8 * T * T + 8 * T * T))
         entry("mask_unexplored_kernel", E * (S * S + 8 * S * S + 8 * S * S))
         # the kernel BASELINE.json's north_star names for the roofline target is the map-fusion kernel
