@@ -87,6 +87,8 @@ class BatchedEpisodes:
         # base_objectnav_policy.py:221-233) and MobileSAM on the boxes that survive (:311-321).  With random-init networks
         # detections carry no meaning, so SAM is exercised on one synthetic box for every ``sam_every``-th environment-step.
         self.detector, self.sam, self.sam_every = detector, sam, sam_every
+        self.detector_is_prompted = detector is not None and "caption" in getattr(detector, "__dict__", {})
+        self.gdino_caption = " . ".join(TARGETS) + " ."
         self.last_detections = None
         self.last_masks = None
         self.map_stream = torch.cuda.Stream(self.device) if overlap else None
@@ -173,7 +175,9 @@ class BatchedEpisodes:
             cos = torch.from_numpy(self.stub_rng.uniform(0.15, 0.45, size=self.E)).to(self.device)
         self.last_cosines = cos
         if self.detector is not None:
-            self.last_detections = self.detector.predict_batch(rgb)
+            # YOLOv7 takes the frames alone; GroundingDINO is prompted (MP3D-style caption, habitat_policies.py:139-141)
+            self.last_detections = (self.detector.predict_batch(rgb, [self.gdino_caption]) if self.detector_is_prompted
+                                    else self.detector.predict_batch(rgb))
         if self.sam is not None:
             sel = [e for e in range(self.E) if (self.t + e) % self.sam_every == 0]
             if sel:
