@@ -95,3 +95,156 @@ def test_step_logic_over_reference_maps_matches_reference_policy(name):
     target = [k for k in objects.clouds]
     if target:
         assert sha(np.asarray(objects.clouds[target[0]], np.float64)) == str(g["cloud_sig"][1])
+
+
+# ---------------------------------------------------------------------------------------------- branch coverage with stub maps
+class _StubObstacle:
+    def __init__(self, frontiers=None, raise_index=False):
+        self.frontiers = np.zeros((0, 2)) if frontiers is None else frontiers
+        self.raise_index, self.calls = raise_index, 0
+
+    def reset(self):
+        pass
+
+    def update_map(self, *a):
+        self.calls += 1
+        if self.raise_index:
+            raise IndexError("index 1000 is out of bounds for axis 0 with size 1000")  # obstacle_map.py:101
+
+    def update_agent_traj(self, *a):
+        pass
+
+
+class _StubValue:
+    def __init__(self):
+        self.updates = []
+
+    def reset(self):
+        pass
+
+    def update_map(self, values, *a):
+        self.updates.append(np.asarray(values).copy())
+
+    def update_agent_traj(self, *a):
+        pass
+
+    def sort_waypoints(self, wps, radius):
+        vals = [0.1 * (i + 1) for i in range(len(wps))]
+        order = np.argsort([-v for v in vals])
+        return np.array([wps[i] for i in order]), [vals[i] for i in order]
+
+
+class _StubObjects:
+    def __init__(self, goal=None):
+        self.goal, self.updates = goal, 0
+
+    def reset(self):
+        pass
+
+    def has_object(self, name):
+        return self.goal is not None
+
+    def get_best_object(self, name, xy):
+        return self.goal
+
+    def update_map(self, *a):
+        self.updates += 1
+
+    def update_explored(self, *a):
+        pass
+
+
+class _Dets:
+    def __init__(self, n=0):
+        import torch
+
+        self.boxes, self.logits, self.phrases = torch.rand(n, 4), torch.ones(n), ["chair"] * n
+
+    num_detections = property(lambda self: len(self.logits))
+
+    def filter_by_class(self, c):
+        pass
+
+    def filter_by_conf(self, t):
+        pass
+
+
+def _step_obj(obstacle, objects=None, n_det=0, **kw):
+    from vlfm_amd.policy_step import ITMPolicyV2Step
+
+    class Itm:
+        def cosine(self, img, txt):
+            return 0.3
+
+    class Det:
+        def predict(self, img, caption=""):
+            return _Dets(n_det)
+
+    class Sam:
+        def segment_bbox(self, img, box):
+            return np.ones(img.shape[:2], np.uint8)
+
+    pol = ITMPolicyV2Step(camera_height=0.88, min_depth=0.5, max_depth=5.0, camera_fov=79.0, image_width=64, itm=Itm(),
+                          coco_detector=Det(), detector=Det(), sam=Sam(), obstacle_map=obstacle, value_map=_StubValue(),
+                          object_map=objects or _StubObjects(), **kw)
+    pol.reset("chair")
+    return pol
+
+
+def test_step_branches_edge_of_map_no_frontiers_navigate_and_stop():
+    rgb, depth = np.zeros((48, 64, 3), np.uint8), np.full((48, 64), 0.5, np.float32)
+    # IndexError from the obstacle scatter = "Reached edge of map, stopping." (base_objectnav_policy.py:157-162)
+    r = _step_obj(_StubObstacle(raise_index=True)).step(rgb, depth, 0.0, 0.0, 0.0)
+    assert r.mode == "edge_of_map" and r.stop and r.goal is None
+    # initialise for 12 steps, then explore with an empty frontier list -> STOP without called_stop (itm_policy.py:64-67)
+    pol = _step_obj(_StubObstacle())
+    modes = [pol.step(rgb, depth, 0.0, 0.0, 0.0) for _ in range(13)]
+    assert [m.mode for m in modes[:12]] == ["initialize"] * 12 and modes[12].mode == "explore"
+    assert modes[12].stop and not pol.called_stop and modes[12].goal is None
+    # the reference's sentinel "no frontier" value is a single (0, 0) row as well
+    pol = _step_obj(_StubObstacle(frontiers=np.zeros((1, 2))))
+    assert [pol.step(rgb, depth, 0.0, 0.0, 0.0) for _ in range(13)][-1].stop
+    # frontiers -> best value first; goal more than 0.1 m away from the previous one resets the controller
+    fr = np.array([[1.0, 0.0], [0.0, 2.0], [3.0, 3.0]])
+    pol = _step_obj(_StubObstacle(frontiers=fr))
+    r = [pol.step(rgb, depth, 0.0, 0.0, 0.0) for _ in range(13)][-1]
+    assert r.mode == "explore" and np.array_equal(r.goal, fr[2]) and r.pointnav_reset and not r.stop
+    assert abs(r.rho - np.hypot(3, 3)) < 1e-12 and abs(r.theta - np.pi / 4) < 1e-12
+    assert not pol.step(rgb, depth, 0.0, 0.0, 0.0).pointnav_reset                     # same goal again
+    # an object goal: navigate; inside pointnav_stop_radius -> STOP and called_stop
+    pol = _step_obj(_StubObstacle(frontiers=fr), objects=_StubObjects(goal=np.array([0.5, 0.0])), n_det=1)
+    r = [pol.step(rgb, depth, 0.0, 0.0, 0.0) for _ in range(13)][-1]
+    assert r.mode == "navigate" and r.stop and pol.called_stop and pol.maps()[2].updates == 13
+    assert int(pol.object_masks.sum()) == 48 * 64
+
+
+def test_step_all_ones_depth_needs_infer_depth_like_the_reference():
+    rgb, ones = np.zeros((48, 64, 3), np.uint8), np.ones((48, 64), np.float32)
+    with pytest.raises(NotImplementedError):           # BaseObjectNavPolicy._infer_depth base_objectnav_policy.py:358-365
+        _step_obj(_StubObstacle(), n_det=1).step(rgb, ones, 0.0, 0.0, 0.0)
+    pol = _step_obj(_StubObstacle(), n_det=1, infer_depth=lambda rgb, lo, hi: np.full((48, 64), 0.4, np.float32))
+    assert pol.step(rgb, ones, 0.0, 0.0, 0.0).mode == "initialize"
+    with pytest.raises(NotImplementedError):
+        _step_obj(_StubObstacle(), use_vqa=True)
+
+
+def test_multi_prompt_value_channels_and_pipe_substitution():
+    from vlfm_amd.policy_step import ITMPolicyV2Step
+
+    seen = []
+
+    class Itm:
+        def cosine(self, img, txt):
+            seen.append(txt)
+            return 0.1 * len(seen)
+
+    vm = _StubValue()
+    pol = ITMPolicyV2Step(camera_height=0.88, min_depth=0.5, max_depth=5.0, camera_fov=79.0, image_width=64,
+                          text_prompt="Seems like there is a target_object ahead.|There is a lot of area to explore ahead.",
+                          itm=Itm(), coco_detector=None or type("D", (), {"predict": lambda s, i, caption="": _Dets(0)})(),
+                          detector=type("D", (), {"predict": lambda s, i, caption="": _Dets(0)})(),
+                          sam=object(), obstacle_map=_StubObstacle(), value_map=vm, object_map=_StubObjects())
+    pol.reset("table|desk")
+    pol.step(np.zeros((48, 64, 3), np.uint8), np.full((48, 64), 0.5, np.float32), 0.0, 0.0, 0.0)
+    assert seen == ["Seems like there is a table/desk ahead.", "There is a lot of area to explore ahead."]
+    assert vm.updates[0].shape == (2,) and np.allclose(vm.updates[0], [0.1, 0.2])
