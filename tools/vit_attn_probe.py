@@ -4,8 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.nn.functional as F
 from vlfm_amd.vlm import ops
 dev = torch.device("cuda:0")
-for B in (int(a) for a in (sys.argv[1:] or ["128"])):
-    S, H, D = 257, 16, 96
+for B, D in [(int(a), d) for a in (sys.argv[1:] or ["128"]) for d in (96, 88)]:
+    S, H = 257, 16
     qkv = torch.randn(B * S, 3 * H * D, device=dev, dtype=torch.float16)
     def t(fn, n=30):
         for _ in range(5): fn()
@@ -17,4 +17,4 @@ for B in (int(a) for a in (sys.argv[1:] or ["128"])):
         return F.scaled_dot_product_attention(q[0], q[1], q[2], scale=88 ** -0.5).transpose(1, 2).reshape(B * S, H * D)
     a, b = t(lambda: ops.vit_attention(qkv, B, S, H, D, 88 ** -0.5)), t(lib)
     fl = 4 * B * H * S * S * 88
-    print(f"B={B}: hip {a:7.1f} us ({fl/a/1e6:5.0f} TF/s)   library sdpa + transpose {b:7.1f} us   max diff {float((ops.vit_attention(qkv, B, S, H, D, 88 ** -0.5).float() - lib().float()).abs().max()):.4f}")
+    print(f"B={B} D={D}: hip {a:7.1f} us ({fl/a/1e6:5.0f} TF/s)   library sdpa + transpose {b:7.1f} us   max diff {float((ops.vit_attention(qkv, B, S, H, D, 88 ** -0.5).float() - lib().float()).abs().max()):.4f}")

@@ -11,7 +11,9 @@ with torch.no_grad():
     for n, p in m.named_parameters():
         if p.dim() == 1 and "norm" not in n.lower():
             p.copy_(torch.randn_like(p) * 0.1)
-m._deferred_c = None
+for blk in m.blocks:
+    blk.pack_heads()   # the packed copies (library-attention path) follow the edited biases
+m.weights_changed()
 pat = torch.randn(E, 256, 588, device=dev, dtype=torch.float16)
 outs = {}
 for mode in (False, True, False, True):

@@ -162,6 +162,10 @@ __device__ inline void attend(const _Float16* __restrict__ Kl, const _Float16* _
     l_out = l;
 }
 
+// DH = head width as stored in global memory: 96 (heads zero-padded inside the qkv / projection weights) or 88 (ViT-g's
+// native width: the missing 8 channels are zeros that exist only in LDS / registers, so the GEMMs on either side
+// keep their original sizes).
+template <int DH>
 __global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _Float16* __restrict__ qkv,
                                                                          _Float16* __restrict__ out, int B, int H,
                                                                          float scale, int stagger) {
@@ -179,8 +183,9 @@ __global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _
     const int tid = threadIdx.x, nth = blockDim.x;
     AT_PHASE(0);
     const int lane = tid & 63, wave = tid >> 6, col = lane & 31, grp = lane >> 5;
-    const size_t row_halfs = (size_t)3 * H * AT_D;                       // one token of qkv: [3][H][96]
-    const _Float16* base = qkv + (size_t)b * AT_S * row_halfs + (size_t)h * AT_D;
+    static_assert(DH % 8 == 0 && DH <= AT_D, "head width in whole 16-byte chunks");
+    const size_t row_halfs = (size_t)3 * H * DH;                         // one token of qkv: [3][H][DH]
+    const _Float16* base = qkv + (size_t)b * AT_S * row_halfs + (size_t)h * DH;
     // ---- stage K (row-major) and V^T into LDS; padding rows / columns are zero
     for (int i = tid; i < (AT_KROWS - AT_S) * AT_KS; i += nth) Kl[(size_t)AT_S * AT_KS + i] = (_Float16)0.0f;
     for (int i = tid; i < AT_D * (AT_KROWS - AT_S); i += nth) {   // keys 257 .. 287 of every V^T row
@@ -199,11 +204,11 @@ __global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const int s = s0 + u;
-            if (i < kItems && s < AT_S) {
-                const _Float16* src = base + (size_t)s * row_halfs + (size_t)H * AT_D + 8 * ch;
+            if (i < kItems && s < AT_S && ch < DH / 8) {
+                const _Float16* src = base + (size_t)s * row_halfs + (size_t)H * DH + 8 * ch;
                 kreg[it][u] = *reinterpret_cast<const half8_t*>(src);                      // K
-                vreg[it][u] = *reinterpret_cast<const half8_t*>(src + (size_t)H * AT_D);   // V
-            } else {
+                vreg[it][u] = *reinterpret_cast<const half8_t*>(src + (size_t)H * DH);     // V
+            } else {   // token 257 of the last pair, and channels DH .. 95: zeros
 #pragma unroll
                 for (int j = 0; j < 8; j++) { kreg[it][u][j] = (_Float16)0.0f; vreg[it][u][j] = (_Float16)0.0f; }
             }
@@ -214,9 +219,21 @@ __global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _
     const int tq = 1 + 32 * wave + col;
     half8_t qmain[AT_D / 16];
 #pragma unroll
-    for (int kk = 0; kk < AT_D / 16; kk++)
-        qmain[kk] = *reinterpret_cast<const half8_t*>(base + (size_t)tq * row_halfs + 8 * grp + 16 * kk);
-    if (tid < AT_D / 8) *reinterpret_cast<half8_t*>(qcls + 8 * tid) = *reinterpret_cast<const half8_t*>(base + 8 * tid);
+    for (int kk = 0; kk < AT_D / 16; kk++) {
+        if (2 * kk + grp < DH / 8) {
+            qmain[kk] = *reinterpret_cast<const half8_t*>(base + (size_t)tq * row_halfs + 8 * grp + 16 * kk);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) qmain[kk][j] = (_Float16)0.0f;
+        }
+    }
+    if (tid < AT_D / 8) {
+        half8_t qv;
+#pragma unroll
+        for (int j = 0; j < 8; j++) qv[j] = (_Float16)0.0f;
+        if (tid < DH / 8) qv = *reinterpret_cast<const half8_t*>(base + 8 * tid);
+        *reinterpret_cast<half8_t*>(qcls + 8 * tid) = qv;
+    }
 #pragma unroll
     for (int it = 0; it < kIters; it++) {
         const int i = tid + it * 64 * AT_WAVES;
@@ -271,14 +288,14 @@ __global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _
         attend<AT_KT>(Kl, Vl, qmain, 0, c, o, m, l);
         AT_PHASE(7);
         const float inv = 1.0f / l;
-        _Float16* dst = out + ((size_t)(b * AT_S + tq) * H + h) * AT_D + 4 * grp;
+        _Float16* dst = out + ((size_t)(b * AT_S + tq) * H + h) * DH + 4 * grp;
 #pragma unroll
         for (int dt = 0; dt < AT_D / 32; dt++) {
 #pragma unroll
             for (int q4 = 0; q4 < 4; q4++) {
                 const half4_t v = half4_t{(_Float16)(o[dt][4 * q4] * inv), (_Float16)(o[dt][4 * q4 + 1] * inv),
                                           (_Float16)(o[dt][4 * q4 + 2] * inv), (_Float16)(o[dt][4 * q4 + 3] * inv)};
-                *reinterpret_cast<half4_t*>(dst + 32 * dt + 8 * q4) = v;
+                if (32 * dt + 8 * q4 + 4 * grp < DH) *reinterpret_cast<half4_t*>(dst + 32 * dt + 8 * q4) = v;
             }
         }
     }
@@ -298,8 +315,8 @@ __global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _
             lsum += wgt[w] * part[(size_t)w * (AT_D + 2) + AT_D + 1];
         }
         const float inv = 1.0f / lsum;
-        _Float16* dst = out + ((size_t)(b * AT_S) * H + h) * AT_D;
-        for (int d = lane; d < AT_D; d += 64) {
+        _Float16* dst = out + ((size_t)(b * AT_S) * H + h) * DH;
+        for (int d = lane; d < DH; d += 64) {
             float v = 0.0f;
 #pragma unroll
             for (int w = 0; w < AT_WAVES; w++) v += wgt[w] * part[(size_t)w * (AT_D + 2) + d];
@@ -318,15 +335,22 @@ extern "C" int vlfm_vit_attention_f16(const void* d_qkv, void* d_out, int batch,
     if (batch == 0) return VLFM_OK;
     if (!d_qkv || !d_out || batch < 0 || heads <= 0)
         return fail(VLFM_ERR_INVALID, "vit_attention_f16: bad argument");
-    if (tokens != AT_S || head_dim != AT_D)
-        return fail(VLFM_ERR_INVALID, "vit_attention_f16: specialised for 257 tokens and a (padded) head width of 96");
-    static LdsOptIn opt_in;
-    if (!opt_in.ensure(reinterpret_cast<const void*>(vit_attention_kernel), AT_LDS_BYTES))
+    if (tokens != AT_S || (head_dim != AT_D && head_dim != 88))
+        return fail(VLFM_ERR_INVALID, "vit_attention_f16: specialised for 257 tokens and a head width of 88 or 96");
+    static LdsOptIn opt_in96, opt_in88;
+    if (!(head_dim == 88 ? opt_in88.ensure(reinterpret_cast<const void*>(vit_attention_kernel<88>), AT_LDS_BYTES)
+                         : opt_in96.ensure(reinterpret_cast<const void*>(vit_attention_kernel<96>), AT_LDS_BYTES)))
         return fail(VLFM_ERR_HIP, "vit_attention_f16: cannot opt in to 117 KB of LDS");
     const int stagger = 1;  // measured neutral to +3 %; kept: it costs nothing
     VLFM_TIMED("vit_attention_kernel", stream);
-    VLFM_KLAUNCH(vit_attention_kernel, dim3(8 * ((batch + 7) / 8) * heads), dim3(64 * AT_WAVES), AT_LDS_BYTES,
-                 (hipStream_t)stream, (const _Float16*)d_qkv, (_Float16*)d_out, batch, heads, scale, stagger);
+    const dim3 grid(8 * ((batch + 7) / 8) * heads), block(64 * AT_WAVES);
+    if (head_dim == 88) {
+        VLFM_KLAUNCH(vit_attention_kernel<88>, grid, block, AT_LDS_BYTES, (hipStream_t)stream, (const _Float16*)d_qkv,
+                     (_Float16*)d_out, batch, heads, scale, stagger);
+    } else {
+        VLFM_KLAUNCH(vit_attention_kernel<96>, grid, block, AT_LDS_BYTES, (hipStream_t)stream, (const _Float16*)d_qkv,
+                     (_Float16*)d_out, batch, heads, scale, stagger);
+    }
     return check_launch("vit_attention_kernel");
 }
 

@@ -73,7 +73,7 @@ class _VitBlock(nn.Module):
         self.fc2 = nn.Linear(c.v_mlp, c.v_hidden)
 
         self._packed = None
-        self.hip_attention = True  # vlfm_vit_attention_f16 at the ViT-g shape (257 tokens, heads padded to 96)
+        self.hip_attention = True  # vlfm_vit_attention_f16 at the ViT-g shape (257 tokens, 88-wide heads)
 
     def pack_heads(self, multiple: int = 32) -> None:
         """Inference-time repacking for the attention kernel: the 88-wide heads of ViT-g are zero-padded to the next
@@ -109,16 +109,23 @@ class _VitBlock(nn.Module):
         from . import ops
 
         b, n, d = x.shape
-        wq, bq, wp, hp, scale = self._packed
+        hd = d // self.heads
         h = ops.layernorm_bias(x, c_in, self.layer_norm1.weight, self.layer_norm1.bias, self.layer_norm1.eps)
-        qkv = F.linear(h.view(b * n, d), wq, bq)
-        if self.hip_attention and n == ops.VIT_ATTENTION_TOKENS and hp == ops.VIT_ATTENTION_HEAD:
-            a = ops.vit_attention(qkv, b, n, self.heads, hp, scale)       # [b*n, heads*hp], no transpose copy
-        else:
-            q = qkv.view(b, n, 3, self.heads, hp).permute(2, 0, 3, 1, 4)
-            a = F.scaled_dot_product_attention(q[0], q[1], q[2], scale=scale).transpose(1, 2).reshape(b * n, self.heads * hp)
         x2 = x.view(b * n, d)
-        x2.addmm_(a, wp.t())
+        if self.hip_attention and n == ops.VIT_ATTENTION_TOKENS and hd in ops.VIT_ATTENTION_HEADS:
+            # native head width: the HIP kernel pads 88 -> 96 in LDS / registers only, so the qkv and projection GEMMs keep
+            # their original sizes and the attention output needs no transpose copy
+            qkv = F.linear(h.view(b * n, d), self.qkv.weight, self.qkv.bias)
+            x2.addmm_(ops.vit_attention(qkv, b, n, self.heads, hd, float(hd) ** -0.5), self.projection.weight.t())
+        elif self._packed is not None:
+            wq, bq, wp, hp, scale = self._packed
+            q = F.linear(h.view(b * n, d), wq, bq).view(b, n, 3, self.heads, hp).permute(2, 0, 3, 1, 4)
+            a = F.scaled_dot_product_attention(q[0], q[1], q[2], scale=scale).transpose(1, 2).reshape(b * n, self.heads * hp)
+            x2.addmm_(a, wp.t())
+        else:
+            q = self.qkv(h).view(b, n, 3, self.heads, hd).permute(2, 0, 3, 1, 4)
+            a = F.scaled_dot_product_attention(q[0], q[1], q[2]).transpose(1, 2).reshape(b * n, d)
+            x2.addmm_(a, self.projection.weight.t())
         h = ops.layernorm_bias(x, c_mid, self.layer_norm2.weight, self.layer_norm2.bias, self.layer_norm2.eps)
         x2.addmm_(F.gelu(F.linear(h, self.fc1.weight, self.fc1.bias)).view(b * n, -1), self.fc2.weight.t())
         return x
@@ -340,8 +347,7 @@ class Blip2ITCModel(nn.Module):
         w = self.patch_embedding.weight
         x = F.linear(pixel_values.to(w.dtype), w.view(w.shape[0], -1), self.patch_embedding.bias)
         x = torch.cat([self.class_embedding.expand(x.shape[0], -1, -1), x], dim=1) + self.position_embedding
-        if self.deferred_bias and x.is_cuda and x.dtype == torch.float16 and self.blocks[0]._packed is not None \
-                and self.blocks[0]._packed[0].dtype == torch.float16:
+        if self.deferred_bias and x.is_cuda and x.dtype == torch.float16 and c.v_hidden % 8 == 0 and c.v_hidden <= 2048:
             from . import ops
 
             c = self._deferred_constants()
