@@ -154,6 +154,7 @@ class _BertAttention(nn.Module):
         self.dense = nn.Linear(hidden, hidden)
         self.LayerNorm = nn.LayerNorm(hidden, eps=eps)
         self._kv_split = None  # see _project_kv_f16
+        self._qkv_fused = None  # [Wq; Wk; Wv] for self-attention on the device
 
     def _project_kv_f16(self, kv16: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """key(kv) and value(kv) in f32 for an f16 ``kv`` (the ViT's tokens ARE f16 values) without an f32 GEMM: the f32
@@ -180,20 +181,26 @@ class _BertAttention(nn.Module):
 
     def forward(self, x: torch.Tensor, kv: Optional[torch.Tensor] = None,
                 mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-        src = x if kv is None else kv
         b, n, d = x.shape
         h = self.heads
-        q = self.query(x).view(b, n, h, d // h).transpose(1, 2)
-        if kv is not None and kv.dtype == torch.float16 and kv.is_cuda and self.key.weight.dtype == torch.float32:
-            k, v = self._project_kv_f16(kv)
-            k = k.reshape(b, src.shape[1], h, d // h).transpose(1, 2)
-            v = v.reshape(b, src.shape[1], h, d // h).transpose(1, 2)
-            a = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
-            return self.LayerNorm(self.dense(a.transpose(1, 2).reshape(b, n, d)) + x)
-        if kv is not None:
-            src = kv.to(x.dtype)
-        k = self.key(src).view(b, src.shape[1], h, d // h).transpose(1, 2)
-        v = self.value(src).view(b, src.shape[1], h, d // h).transpose(1, 2)
+        if kv is None and x.is_cuda and not self.training:
+            # self-attention: query / key / value share their input -- one GEMM over [Wq; Wk; Wv] instead of three
+            # small ones (every output element is the same dot product; only the launch count changes)
+            if self._qkv_fused is None or self._qkv_fused[0].device != x.device or self._qkv_fused[0].dtype != x.dtype:
+                self._qkv_fused = (torch.cat([self.query.weight, self.key.weight, self.value.weight]).detach(),
+                                   torch.cat([self.query.bias, self.key.bias, self.value.bias]).detach())
+            qkv = F.linear(x, *self._qkv_fused).view(b, n, 3, h, d // h).permute(2, 0, 3, 1, 4)
+            q, k, v = qkv[0], qkv[1], qkv[2]
+        else:
+            q = self.query(x).view(b, n, h, d // h).transpose(1, 2)
+            if kv is not None and kv.dtype == torch.float16 and kv.is_cuda and self.key.weight.dtype == torch.float32:
+                k, v = self._project_kv_f16(kv)
+                src_len = kv.shape[1]
+            else:
+                src = x if kv is None else kv.to(x.dtype)
+                k, v, src_len = self.key(src), self.value(src), src.shape[1]
+            k = k.reshape(b, src_len, h, d // h).transpose(1, 2)
+            v = v.reshape(b, src_len, h, d // h).transpose(1, 2)
         a = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
         return self.LayerNorm(self.dense(a.transpose(1, 2).reshape(b, n, d)) + x)  # post-LN residual (BERT)
 
@@ -258,10 +265,7 @@ class Blip2ITCModel(nn.Module):
             for m in self.modules():
                 if isinstance(m, nn.LayerNorm):
                     m.weight.fill_(1.0)
-        self._deferred_c = None
-        for layer in self.q_layers:
-            if layer.crossattention is not None:
-                layer.crossattention._kv_split = None
+        self.weights_changed()
         return self
 
     def weights_changed(self) -> None:
@@ -269,6 +273,7 @@ class Blip2ITCModel(nn.Module):
         parameters in place."""
         self._deferred_c = None
         for layer in self.q_layers:
+            layer.attention._qkv_fused = None
             if layer.crossattention is not None:
                 layer.crossattention._kv_split = None
 
@@ -281,10 +286,7 @@ class Blip2ITCModel(nn.Module):
             m.to(vision_dtype)
         self.class_embedding.data = self.class_embedding.data.to(vision_dtype)
         self.position_embedding.data = self.position_embedding.data.to(vision_dtype)
-        self._deferred_c = None
-        for layer in self.q_layers:
-            if layer.crossattention is not None:
-                layer.crossattention._kv_split = None
+        self.weights_changed()
         return self
 
     def load_hf_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
