@@ -10,9 +10,9 @@ m = BLIP2ITM(device=dev).model
 pat = torch.randn(E, 256, 588, device=dev, dtype=torch.float16)
 def fwd(x):
     return m.query_features(m.vision_tokens(x))
-def run(K, n=4):
+def run(K, n=4, sizes=None):
     streams = [torch.cuda.Stream(dev) for _ in range(K)]
-    parts = list(pat.chunk(K))
+    parts = list(pat.chunk(K)) if sizes is None else list(pat.split(sizes))
     def once():
         cur = torch.cuda.current_stream(dev)
         outs = []
@@ -37,3 +37,5 @@ with torch.inference_mode():
 print(f"E={E}: one stream {base:.2f} ms")
 for K in (2, 4):
     print(f"E={E}: {K} streams x {E // K} images: {run(K):.2f} ms")
+# NOTE: three concurrent forwards (e.g. sizes [48, 40, 40]) hung this probe on the GPU box (stream-K GEMMs of three
+# streams waiting for workgroups that cannot become resident?) -- do not extend the list below without a short timeout.

@@ -468,7 +468,7 @@ class BLIP2ITM:
             blk.pack_heads()
         self._text_cache: Dict[str, torch.Tensor] = {}
         self._proj_t = None
-        self.two_stream_min = 64      # batches of at least this many images are run as two halves on two streams
+        self.two_stream_min = None    # e.g. 64: run batches of at least that many images as two halves on two streams
         self._side_stream = None
 
     def _load_pretrained(self, model_dir: str) -> None:
@@ -523,9 +523,11 @@ class BLIP2ITM:
         B = images_u8.shape[0]
         pix = ops.preprocess_rgb(images_u8, self.cfg.image_size, self.model.vision_dtype(),
                                  patch_size=self.cfg.patch_size)
-        if B >= self.two_stream_min and not torch.cuda.is_current_stream_capturing():
-            # Two half batches on two HIP streams: the compute-bound GEMMs of one half overlap the memory-bound
-            # LayerNorm / GELU / attention kernels of the other (tools/two_stream_probe.py: -4.5 % at 128 images).
+        if self.two_stream_min is not None and B >= self.two_stream_min and not torch.cuda.is_current_stream_capturing():
+            # OPT-IN.  Two half batches on two HIP streams: the compute-bound GEMMs of one half overlap the memory-bound
+            # LayerNorm / GELU / attention kernels of the other (+2.8 % env-steps/s at 128 images).  Off by default: the
+            # large GEMMs are stream-K kernels whose workgroups wait for each other, and a probe with THREE concurrent
+            # forwards hung (tools/two_stream_probe.py) -- not a risk worth 3 % in an unattended run.
             main = torch.cuda.current_stream(self.device)
             if self._side_stream is None:
                 self._side_stream = torch.cuda.Stream(self.device)
