@@ -174,8 +174,9 @@ class _BertAttention(nn.Module):
         w1t, w2t, w3t, bias = self._kv_split
         x2 = kv16.reshape(-1, kv16.shape[-1])
         o = torch.addmm(bias, x2, w3t, alpha=2.0 ** -22, out_dtype=torch.float32)
-        o = torch.addmm(o, x2, w2t, alpha=2.0 ** -11, out_dtype=torch.float32)
-        o = torch.addmm(o, x2, w1t, out_dtype=torch.float32).view(*kv16.shape[:-1], -1)
+        torch.addmm(o, x2, w2t, alpha=2.0 ** -11, out_dtype=torch.float32, out=o)   # in place: no 200 MB copy of o
+        torch.addmm(o, x2, w1t, out_dtype=torch.float32, out=o)
+        o = o.view(*kv16.shape[:-1], -1)
         hid = self.key.out_features
         return o[..., :hid], o[..., hid:]
 
