@@ -22,33 +22,33 @@ def require_gpu(device=None):
 
 
 class BaseMap:
-    """Same constructor/attributes as the reference BaseMap; `_map` is provided by subclasses from HBM."""
+    """Coordinate conventions and trajectory bookkeeping of the reference's BaseMap (same constructor, same attribute
+    names); the ``_map`` payload is provided by the subclasses from HBM."""
 
     _camera_positions: List[np.ndarray] = []
     _last_camera_yaw: float = 0.0
 
     def __init__(self, size: int = 1000, pixels_per_meter: int = 20, *args: Any, **kwargs: Any):
-        self.pixels_per_meter = pixels_per_meter
-        self.size = size
-        self._episode_pixel_origin = np.array([size // 2, size // 2])
+        self.size, self.pixels_per_meter = size, pixels_per_meter
+        self._episode_pixel_origin = np.array([size // 2, size // 2])   # the episode starts at the map centre
         self._camera_positions = []
 
     def reset(self) -> None:
         self._camera_positions = []
 
     def update_agent_traj(self, robot_xy: np.ndarray, robot_heading: float) -> None:
-        self._camera_positions.append(robot_xy)
         self._last_camera_yaw = robot_heading
+        self._camera_positions.append(robot_xy)
 
     def _xy_to_px(self, points: np.ndarray) -> np.ndarray:
-        """(x, y) metres -> (col, row) cells; rint = round-half-even (base_map.py:44-46)."""
-        px = np.rint(points[:, ::-1] * self.pixels_per_meter) + self._episode_pixel_origin
-        px[:, 0] = self.size - px[:, 0]
-        return px.astype(int)
+        """Metres (x forward, y left) -> integer (col, row) cells: the axes swap, ``rint`` rounds half to even, and the
+        first coordinate is mirrored about the map size (base_map.py:44-46)."""
+        cells = np.rint(points[:, ::-1] * self.pixels_per_meter) + self._episode_pixel_origin
+        cells[:, 0] = self.size - cells[:, 0]
+        return cells.astype(int)
 
     def _px_to_xy(self, px: np.ndarray) -> np.ndarray:
-        """Inverse of _xy_to_px without rounding (base_map.py:57-60)."""
-        q = px.copy()
-        q[:, 0] = self.size - q[:, 0]
-        pts = (q - self._episode_pixel_origin) / self.pixels_per_meter
-        return pts[:, ::-1]
+        """Inverse of ``_xy_to_px`` without the rounding (base_map.py:57-60)."""
+        unmirrored = np.array(px, copy=True)
+        unmirrored[:, 0] = self.size - unmirrored[:, 0]
+        return ((unmirrored - self._episode_pixel_origin) / self.pixels_per_meter)[:, ::-1]

@@ -39,28 +39,32 @@ def within_fov_cone(cone_origin, cone_angle, cone_fov, cone_range, points) -> np
 
 
 def too_offset(mask: np.ndarray) -> bool:
-    """object_point_cloud_map.py:272-297 (cv2.boundingRect of the non-zero pixels = their min/max column)."""
-    cols = np.flatnonzero(np.asarray(mask).any(axis=0))
-    if len(cols) == 0:
-        x, w = 0, 0
-    else:
-        x, w = int(cols[0]), int(cols[-1] - cols[0] + 1)
-    third = mask.shape[1] // 3
-    if x + w <= third:
-        return x <= int(0.05 * mask.shape[1])
-    elif x >= 2 * third:
-        return x + w >= int(0.95 * mask.shape[1])
+    """Does the detection hug the left or right image border (object_point_cloud_map.py:272-297)?  A mask whose column
+    extent lies wholly in the outer third of the image AND reaches within 5 % of that border is "too offset": its
+    points get an out-of-range tag because the object is probably cut off by the image edge."""
+    width = mask.shape[1]
+    occupied = np.flatnonzero(np.asarray(mask).any(axis=0))       # cv2.boundingRect's x-extent
+    left, right = (int(occupied[0]), int(occupied[-1]) + 1) if len(occupied) else (0, 0)
+    band = width // 3
+    if right <= band:
+        return left <= int(0.05 * width)
+    if left >= 2 * band:
+        return right >= int(0.95 * width)
     return False
 
 
 def get_random_subarray(points, size: int):
-    """object_point_cloud_map.py:253-269: the reference's own RNG call decides the indices."""
-    if len(points) <= size:
-        return points
-    return points[np.random.choice(len(points), size, replace=False)]
+    """At most ``size`` rows, chosen by NumPy's GLOBAL generator like the reference (:253-269), so a seeded session
+    reproduces its clouds."""
+    n = len(points)
+    return points if n <= size else points[np.random.choice(n, size, replace=False)]
 
 
 class ObjectPointCloudMap:
+    """Per object class: an (N, 4) cloud of episodic-frame points whose 4th column is a TAG -- 1.0 for points seen within
+    95 % of the depth range, otherwise one random number per observation (so that all far points of an observation can be
+    dropped together once the robot looks there from nearby, ``update_explored``)."""
+
     clouds: Dict[str, np.ndarray] = {}
     use_dbscan: bool = True
 
@@ -73,67 +77,59 @@ class ObjectPointCloudMap:
         self._bufs = None
 
     def reset(self) -> None:
-        self.clouds = {}
-        self.last_target_coord = None
+        self.clouds, self.last_target_coord = {}, None
 
     def has_object(self, target_class: str) -> bool:
-        return target_class in self.clouds and len(self.clouds[target_class]) > 0
+        return len(self.clouds.get(target_class, ())) > 0
 
-    # ------------------------------------------------------------------------------------------ :29-75
     def update_map(self, object_name: str, depth_img: np.ndarray, object_mask: np.ndarray,
                    tf_camera_to_episodic: np.ndarray, min_depth: float, max_depth: float, fx: float, fy: float) -> None:
-        local_cloud = self._extract_object_cloud(depth_img, object_mask, min_depth, max_depth, fx, fy)
-        if len(local_cloud) == 0:
+        """object_point_cloud_map.py:29-75."""
+        camera_frame = self._extract_object_cloud(depth_img, object_mask, min_depth, max_depth, fx, fy)
+        if len(camera_frame) == 0:
             return
+        # exactly ONE draw from the global generator per non-empty observation, whichever branch is taken (the reference
+        # evaluates np.random.rand() on both paths); the "near" path keeps its tags in f32 like the reference's astype
+        tag = np.random.rand()
         if too_offset(object_mask):
-            within_range = np.ones_like(local_cloud[:, 0]) * np.random.rand()
+            tags = np.full(len(camera_frame), tag, dtype=camera_frame.dtype)
         else:
-            within_range = (local_cloud[:, 0] <= max_depth * 0.95) * 1.0  # 5% margin
-            within_range = within_range.astype(np.float32)
-            within_range[within_range == 0] = np.random.rand()
-        global_cloud = transform_points(tf_camera_to_episodic, local_cloud)
-        global_cloud = np.concatenate((global_cloud, within_range[:, None]), axis=1)
-        curr_position = tf_camera_to_episodic[:3, 3]
-        closest_point = self._get_closest_point(global_cloud, curr_position)
-        if np.linalg.norm(closest_point[:3] - curr_position) < 1.0:
-            return  # too close to trust
-        if object_name in self.clouds:
-            self.clouds[object_name] = np.concatenate((self.clouds[object_name], global_cloud), axis=0)
-        else:
-            self.clouds[object_name] = global_cloud
+            near = camera_frame[:, 0] <= max_depth * 0.95
+            tags = np.where(near, np.float32(1.0), np.float32(tag)).astype(np.float32)
+        tagged = np.concatenate((transform_points(tf_camera_to_episodic, camera_frame), tags[:, None]), axis=1)
+        here = tf_camera_to_episodic[:3, 3]
+        if np.linalg.norm(self._get_closest_point(tagged, here)[:3] - here) < 1.0:
+            return  # closer than 1 m: depth this near is not trusted (:63-67)
+        known = self.clouds.get(object_name)
+        self.clouds[object_name] = tagged if known is None else np.concatenate((known, tagged), axis=0)
 
-    # ------------------------------------------------------------------------------------------ :77-101
     def get_best_object(self, target_class: str, curr_position: np.ndarray) -> np.ndarray:
-        target_cloud = self.get_target_cloud(target_class)
-        closest_point_2d = self._get_closest_point(target_cloud, curr_position)[:2]
-        if self.last_target_coord is None:
-            self.last_target_coord = closest_point_2d
-        else:
-            delta_dist = np.linalg.norm(closest_point_2d - self.last_target_coord)
-            if delta_dist < 0.1:
-                return self.last_target_coord
-            elif delta_dist < 0.5 and np.linalg.norm(curr_position - closest_point_2d) > 2.0:
-                return self.last_target_coord
-            else:
-                self.last_target_coord = closest_point_2d
-        return self.last_target_coord
+        """Goal point with hysteresis (:77-101): keep the previous goal when the new closest point moved < 0.1 m, or
+        < 0.5 m while the robot is still more than 2 m away."""
+        candidate = self._get_closest_point(self.get_target_cloud(target_class), curr_position)[:2]
+        previous = self.last_target_coord
+        if previous is not None:
+            moved = np.linalg.norm(candidate - previous)
+            if moved < 0.1 or (moved < 0.5 and np.linalg.norm(curr_position - candidate) > 2.0):
+                return previous
+        self.last_target_coord = candidate
+        return candidate
 
-    # ------------------------------------------------------------------------------------------ :103-135
     def update_explored(self, tf_camera_to_episodic: np.ndarray, max_depth: float, cone_fov: float) -> None:
-        camera_coordinates = tf_camera_to_episodic[:3, 3]
-        camera_yaw = extract_yaw(tf_camera_to_episodic)
-        for obj in self.clouds:
-            within_range = within_fov_cone(camera_coordinates, camera_yaw, cone_fov, max_depth * 0.5, self.clouds[obj])
-            for range_id in set(within_range[..., -1].tolist()):
-                if range_id == 1:
-                    continue
-                self.clouds[obj] = self.clouds[obj][self.clouds[obj][..., -1] != range_id]
+        """Forget far-tagged observations the robot is now looking at from within half the depth range (:103-135): every
+        tag other than 1 that shows up inside the view cone is removed from the cloud as a whole."""
+        origin, heading = tf_camera_to_episodic[:3, 3], extract_yaw(tf_camera_to_episodic)
+        for name, cloud in list(self.clouds.items()):
+            seen_tags = set(within_fov_cone(origin, heading, cone_fov, max_depth * 0.5, cloud)[..., -1].tolist()) - {1}
+            for t in seen_tags:
+                cloud = cloud[cloud[..., -1] != t]
+            self.clouds[name] = cloud
 
     def get_target_cloud(self, target_class: str) -> np.ndarray:
-        target_cloud = self.clouds[target_class].copy()
-        if np.any(target_cloud[:, -1] == 1):
-            target_cloud = target_cloud[target_cloud[:, -1] == 1]
-        return target_cloud
+        """The trusted (tag 1) points when there are any, else everything (:137-144)."""
+        cloud = self.clouds[target_class].copy()
+        trusted = cloud[:, -1] == 1
+        return cloud[trusted] if np.any(trusted) else cloud
 
     # ------------------------------------------------------------------------------------------ :150-170 on the GPU
     def _extract_object_cloud(self, depth: np.ndarray, object_mask: np.ndarray, min_depth: float, max_depth: float,
@@ -178,15 +174,13 @@ class ObjectPointCloudMap:
 
     # ------------------------------------------------------------------------------------------ :172-183
     def _get_closest_point(self, cloud: np.ndarray, curr_position: np.ndarray) -> np.ndarray:
-        ndim = curr_position.shape[0]
+        """With DBSCAN-cleaned clouds: the nearest point.  Without: the median of the nearest quarter, measured from the
+        position lifted to 0.5 m when it is 2-D (outlier-tolerant)."""
+        k = curr_position.shape[0]
         if self.use_dbscan:
-            return cloud[np.argmin(np.linalg.norm(cloud[:, :ndim] - curr_position, axis=1))]
-        ref_point = np.concatenate((curr_position, np.array([0.5]))) if ndim == 2 else curr_position
-        distances = np.linalg.norm(cloud[:, :3] - ref_point, axis=1)
-        sorted_indices = np.argsort(distances)
-        top_percent = sorted_indices[: int(0.25 * len(cloud))]
-        try:
-            median_index = top_percent[int(len(top_percent) / 2)]
-        except IndexError:
-            median_index = 0
-        return cloud[median_index]
+            return cloud[np.argmin(np.linalg.norm(cloud[:, :k] - curr_position, axis=1))]
+        anchor = curr_position if k != 2 else np.concatenate((curr_position, np.array([0.5])))
+        order = np.argsort(np.linalg.norm(cloud[:, :3] - anchor, axis=1))
+        nearest_quarter = order[: int(0.25 * len(cloud))]
+        pick = nearest_quarter[int(len(nearest_quarter) / 2)] if len(nearest_quarter) else 0
+        return cloud[pick]
