@@ -43,60 +43,62 @@ class RefObstacleMap(RefBaseMap):
         self._frontiers_px = np.array([])
         self.frontiers = np.array([])
 
+    # ------------------------------------------------------------------------------------------ obstacle_map.py:86-109
+    def _scatter_obstacles(self, depth, tf, min_depth, max_depth, fx, fy) -> None:
+        """Depth holes -> metres -> camera-frame cloud of everything nearer than max_depth -> episodic frame -> height
+        band -> cells set; the navigable map is the complement of the obstacles grown by the robot's footprint."""
+        if self._hole_area_thresh == -1:
+            patched = np.where(depth == 0, depth.dtype.type(1.0), depth)
+        else:
+            patched = fill_small_holes(depth, self._hole_area_thresh)
+        metres = patched * (max_depth - min_depth) + min_depth
+        world = apply_tf(tf, unproject(metres, metres < max_depth, fx, fy))
+        cells = self._xy_to_px(keep_height_band(world, self._min_height, self._max_height)[:, :2])
+        self._map[cells[:, 1], cells[:, 0]] = 1          # NumPy semantics on purpose: IndexError / negative wrap
+        grown = cv.dilate(self._map.astype(np.uint8), self._navigable_kernel, iterations=1)
+        self._navigable_map = 1 - grown.astype(bool)     # int64 0/1 array, like the reference's
+
+    # ------------------------------------------------------------------------------------------ obstacle_map.py:115-153
+    def _reveal(self, tf, max_depth, topdown_fov, agent_cell) -> None:
+        seen = reveal_fog_of_war(top_down_map=self._navigable_map.astype(np.uint8),
+                                 current_fog_of_war_mask=np.zeros_like(self._map, dtype=np.uint8),
+                                 current_point=agent_cell[::-1], current_angle=-yaw_of(tf),
+                                 fov=np.rad2deg(topdown_fov), max_line_len=max_depth * self.pixels_per_meter)
+        seen = cv.dilate(seen, np.ones((3, 3), np.uint8), iterations=1)
+        self.explored_area[seen > 0] = 1
+        self.explored_area[self._navigable_map == 0] = 0
+
+    def _keep_agent_component(self, agent_cell) -> None:
+        """Several disjoint explored regions: keep the one that contains the agent, else the nearest one (first wins)."""
+        regions, _ = cv.findContours(self.explored_area.astype(np.uint8), cv.RETR_EXTERNAL, cv.CHAIN_APPROX_SIMPLE)
+        if len(regions) <= 1:
+            return
+        here = tuple(int(v) for v in agent_cell)
+        chosen, nearest = 0, np.inf
+        for k, region in enumerate(regions):
+            signed = cv.pointPolygonTest(region, here, True)
+            if signed >= 0:
+                chosen = k
+                break
+            if abs(signed) < nearest:
+                chosen, nearest = k, abs(signed)
+        canvas = np.zeros_like(self.explored_area, dtype=np.uint8)
+        cv.drawContours(canvas, regions, chosen, 1, -1)
+        self.explored_area = canvas.astype(bool)
+
     def update_map(self, depth, tf_camera_to_episodic, min_depth, max_depth, fx, fy, topdown_fov, explore=True,
                    update_obstacles=True) -> None:
-        if update_obstacles:  # obstacle_map.py:86-109
-            if self._hole_area_thresh == -1:
-                filled = depth.copy()
-                filled[depth == 0] = 1.0
-            else:
-                filled = fill_small_holes(depth, self._hole_area_thresh)
-            scaled = filled * (max_depth - min_depth) + min_depth
-            mask = scaled < max_depth
-            cloud_cam = unproject(scaled, mask, fx, fy)
-            cloud_epi = apply_tf(tf_camera_to_episodic, cloud_cam)
-            obstacles = keep_height_band(cloud_epi, self._min_height, self._max_height)
-            px = self._xy_to_px(obstacles[:, :2])
-            self._map[px[:, 1], px[:, 0]] = 1
-            self._navigable_map = 1 - cv.dilate(self._map.astype(np.uint8), self._navigable_kernel,
-                                                iterations=1).astype(bool)
+        if update_obstacles:
+            self._scatter_obstacles(depth, tf_camera_to_episodic, min_depth, max_depth, fx, fy)
         if not explore:
             return
-        # obstacle_map.py:115-153
-        agent_xy = tf_camera_to_episodic[:2, 3]
-        agent_px = self._xy_to_px(agent_xy.reshape(1, 2))[0]
-        new_explored = reveal_fog_of_war(
-            top_down_map=self._navigable_map.astype(np.uint8),
-            current_fog_of_war_mask=np.zeros_like(self._map, dtype=np.uint8),
-            current_point=agent_px[::-1],
-            current_angle=-yaw_of(tf_camera_to_episodic),
-            fov=np.rad2deg(topdown_fov),
-            max_line_len=max_depth * self.pixels_per_meter,
-        )
-        new_explored = cv.dilate(new_explored, np.ones((3, 3), np.uint8), iterations=1)
-        self.explored_area[new_explored > 0] = 1
-        self.explored_area[self._navigable_map == 0] = 0
-        contours, _ = cv.findContours(self.explored_area.astype(np.uint8), cv.RETR_EXTERNAL, cv.CHAIN_APPROX_SIMPLE)
-        if len(contours) > 1:
-            min_dist, best_idx = np.inf, 0
-            for idx, cnt in enumerate(contours):
-                dist = cv.pointPolygonTest(cnt, tuple([int(i) for i in agent_px]), True)
-                if dist >= 0:
-                    best_idx = idx
-                    break
-                elif abs(dist) < min_dist:
-                    min_dist = abs(dist)
-                    best_idx = idx
-            new_area = np.zeros_like(self.explored_area, dtype=np.uint8)
-            cv.drawContours(new_area, contours, best_idx, 1, -1)
-            self.explored_area = new_area.astype(bool)
+        agent_cell = self._xy_to_px(tf_camera_to_episodic[:2, 3].reshape(1, 2))[0]
+        self._reveal(tf_camera_to_episodic, max_depth, topdown_fov, agent_cell)
+        self._keep_agent_component(agent_cell)
         self._frontiers_px = self._get_frontiers()
-        if len(self._frontiers_px) == 0:
-            self.frontiers = np.array([])
-        else:
-            self.frontiers = self._px_to_xy(self._frontiers_px)
+        self.frontiers = self._px_to_xy(self._frontiers_px) if len(self._frontiers_px) else np.array([])
 
     def _get_frontiers(self) -> np.ndarray:
         """obstacle_map.py:155-169."""
-        explored = cv.dilate(self.explored_area.astype(np.uint8), np.ones((5, 5), np.uint8), iterations=1)
-        return detect_frontier_waypoints(self._navigable_map.astype(np.uint8), explored, self._area_thresh_in_pixels)
+        grown = cv.dilate(self.explored_area.astype(np.uint8), np.ones((5, 5), np.uint8), iterations=1)
+        return detect_frontier_waypoints(self._navigable_map.astype(np.uint8), grown, self._area_thresh_in_pixels)
