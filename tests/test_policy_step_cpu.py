@@ -248,3 +248,37 @@ def test_multi_prompt_value_channels_and_pipe_substitution():
     pol.step(np.zeros((48, 64, 3), np.uint8), np.full((48, 64), 0.5, np.float32), 0.0, 0.0, 0.0)
     assert seen == ["Seems like there is a table/desk ahead.", "There is a lot of area to explore ahead."]
     assert vm.updates[0].shape == (2,) and np.allclose(vm.updates[0], [0.1, 0.2])
+
+
+def test_v3_scores_by_exploration_channel_below_the_threshold():
+    """ITMPolicyV3._reduce_values (itm_policy.py:296-318), checked against the reference's own method when available."""
+    from vlfm_amd.policy_step import ITMPolicyV3Step
+
+    class TwoChannel(_StubValue):
+        def sort_waypoints(self, wps, radius, reduce_fn=None):
+            vals = reduce_fn([(0.10, 0.9), (0.30, 0.2), (0.20, 0.5)])
+            order = np.argsort([-v for v in vals])
+            return np.array([wps[i] for i in order]), [vals[i] for i in order]
+
+    fr = np.array([[1.0, 0.0], [0.0, 2.0], [3.0, 3.0]])
+    kw = dict(camera_height=0.88, min_depth=0.5, max_depth=5.0, camera_fov=79.0, image_width=64,
+              text_prompt="a|b", itm=type("I", (), {"cosine": lambda s, i, t: 0.2})(),
+              coco_detector=type("D", (), {"predict": lambda s, i, caption="": _Dets(0)})(),
+              detector=type("D", (), {"predict": lambda s, i, caption="": _Dets(0)})(), sam=object(),
+              obstacle_map=_StubObstacle(frontiers=fr), object_map=_StubObjects())
+    rgb, depth = np.zeros((48, 64, 3), np.uint8), np.full((48, 64), 0.5, np.float32)
+    for thresh, want in ((0.25, fr[1]), (0.35, fr[0])):      # target channel decides / exploration channel decides
+        pol = ITMPolicyV3Step(thresh, value_map=TwoChannel(), **kw)
+        pol.reset("chair")
+        goal = [pol.step(rgb, depth, 0.0, 0.0, 0.0) for _ in range(13)][-1].goal
+        assert np.array_equal(goal, want), (thresh, goal)
+    from oracle import ref_shim
+
+    if ref_shim.available():
+        itm_mod, _ = ref_shim.reference_policy()
+        ref = itm_mod.ITMPolicyV3._reduce_values
+        fake = type("P", (), {"_exploration_thresh": 0.25})()
+        vals = [(0.10, 0.9), (0.30, 0.2), (0.20, 0.5)]
+        assert ref(fake, vals) == ITMPolicyV3Step._reduce_values(fake, vals)
+        fake._exploration_thresh = 0.35
+        assert ref(fake, vals) == ITMPolicyV3Step._reduce_values(fake, vals)

@@ -362,6 +362,23 @@ class ITMPolicyV2Step:
         return self._obstacle_map, self._value_map, self._object_map
 
 
+class ITMPolicyV3Step(ITMPolicyV2Step):
+    """ITMPolicyV3 (itm_policy.py:270-318): two prompts ("target | exploration") -> a two-channel value map; a frontier is
+    scored by its target channel, unless no frontier's target value reaches ``exploration_thresh`` -- then every
+    frontier is scored by its exploration channel."""
+
+    def __init__(self, exploration_thresh: float, *args: Any, **kwargs: Any) -> None:
+        super().__init__(*args, **kwargs)
+        self._exploration_thresh = exploration_thresh
+
+    def _reduce_values(self, values: Sequence[Tuple[float, float]]) -> List[float]:
+        use = 1 if max(v[0] for v in values) < self._exploration_thresh else 0
+        return [v[use] for v in values]
+
+    def _sort_frontiers_by_value(self, frontiers: np.ndarray):
+        return self._value_map.sort_waypoints(frontiers, 0.5, reduce_fn=self._reduce_values)
+
+
 def habitat_objectgoal_name(object_id: int, dataset_type: str = "hm3d") -> str:
     """Category id of Habitat's objectgoal sensor -> the name the detectors / prompt see (habitat_policies.py:28,136-141).
     MP3D's table (with its "|"-joined aliases) is the caller's to provide: only the HM3D list is needed by the harness."""
@@ -370,6 +387,6 @@ def habitat_objectgoal_name(object_id: int, dataset_type: str = "hm3d") -> str:
     return HM3D_ID_TO_NAME[object_id]
 
 
-__all__ = ["ITMPolicyV2Step", "StepResult", "FrontierSelector", "AcyclicEnforcer", "rho_theta", "get_fov",
+__all__ = ["ITMPolicyV2Step", "ITMPolicyV3Step", "StepResult", "FrontierSelector", "AcyclicEnforcer", "rho_theta", "get_fov",
            "xyz_yaw_to_tf_matrix", "closest_point_within_threshold", "habitat_objectgoal_name"]
 _ = List  # typing re-export guard for older linters
