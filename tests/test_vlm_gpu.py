@@ -215,8 +215,13 @@ def test_qformer_split_kv_projection_is_f32_grade(gpu_device):
     e_split, e_plain = (split - want).abs().max(), (plain - want).abs().max()
     assert e_split <= 5e-5 and e_plain <= 5e-5, (float(e_split), float(e_plain))
     assert e_split <= 2.0 * e_plain + 1e-6   # f32-grade
-    layer = next(l for l in m.q_layers if l.crossattention is not None).crossattention
-    w1t, w2t, w3t, _ = layer._kv_split
+    cross = [l.crossattention for l in m.q_layers if l.crossattention is not None]
+    w1t, w2t, w3t, _ = m._kv_all            # all cross-attention layers, [K_0 | V_0 | K_1 | V_1 ...]
     rec = w1t.double() + w2t.double() / 2048 + w3t.double() / 2048 ** 2
-    full = torch.cat([layer.key.weight, layer.value.weight]).detach().double().t()
+    full = torch.cat([torch.cat([c.key.weight, c.value.weight]) for c in cross]).detach().double().t()
     assert float((rec - full).abs().max()) <= 1e-12    # the three f16 pieces carry the f32 weights (2^-33 relative)
+    # the per-layer form of the same projection (used when a caller passes kv= directly)
+    k, v = cross[0]._project_kv_f16(tokens16.to(gpu_device))
+    want_k = torch.nn.functional.linear(tokens16.double(), cross[0].key.weight.detach().double().cpu(),
+                                        cross[0].key.bias.detach().double().cpu())
+    assert (k.double().cpu() - want_k).abs().max() <= 2e-5

@@ -144,6 +144,25 @@ class _VitBlock(nn.Module):
         return x + self.fc2(F.gelu(self.fc1(self.layer_norm2(x))))
 
 
+def _exact_split3(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """f32 weights as three f16 pieces with W = W1 + 2^-11 W2 + 2^-22 W3 (33 mantissa bits cover f32's 24)."""
+    w = w.detach().float()
+    w1 = w.half()
+    r = (w - w1.float()) * 2048.0
+    w2 = r.half()
+    return w1, w2, ((r - w2.float()) * 2048.0).half()
+
+
+def _split_gemm(x16: torch.Tensor, pieces, bias: torch.Tensor) -> torch.Tensor:
+    """x16 [M,K] f16 times the split weights (transposed views [K,N]) + bias -> [M,N] f32: three f16 x f16 -> f32 MFMA
+    GEMMs accumulated in place, smallest term first.  Every product is exact in f32, the accumulation is f32."""
+    w1t, w2t, w3t = pieces
+    o = torch.addmm(bias, x16, w3t, alpha=2.0 ** -22, out_dtype=torch.float32)
+    torch.addmm(o, x16, w2t, alpha=2.0 ** -11, out_dtype=torch.float32, out=o)   # in place: no copy of the f32 output
+    torch.addmm(o, x16, w1t, out_dtype=torch.float32, out=o)
+    return o
+
+
 class _BertAttention(nn.Module):
     def __init__(self, hidden: int, kv_hidden: int, heads: int, eps: float):
         super().__init__()
@@ -164,27 +183,24 @@ class _BertAttention(nn.Module):
         measured against f64 it is 2.5x MORE accurate than the f32 GEMM (fewer roundings) and 1.5x faster
         (tools/split_gemm_probe.py); gfx950 has no TF32-like mode and f32 MFMA runs at 1/16 of the f16 rate."""
         if self._kv_split is None or self._kv_split[0].device != kv16.device:
-            w = torch.cat([self.key.weight, self.value.weight]).detach().float()
-            w1 = w.half()
-            r = (w - w1.float()) * 2048.0
-            w2 = r.half()
-            w3 = ((r - w2.float()) * 2048.0).half()
+            w1, w2, w3 = _exact_split3(torch.cat([self.key.weight, self.value.weight]))
             bias = torch.cat([self.key.bias, self.value.bias]).detach().float()
             self._kv_split = (w1.t(), w2.t(), w3.t(), bias)   # transposed views: [kv_hidden, 2 * hidden]
-        w1t, w2t, w3t, bias = self._kv_split
-        x2 = kv16.reshape(-1, kv16.shape[-1])
-        o = torch.addmm(bias, x2, w3t, alpha=2.0 ** -22, out_dtype=torch.float32)
-        torch.addmm(o, x2, w2t, alpha=2.0 ** -11, out_dtype=torch.float32, out=o)   # in place: no 200 MB copy of o
-        torch.addmm(o, x2, w1t, out_dtype=torch.float32, out=o)
+        o = _split_gemm(kv16.reshape(-1, kv16.shape[-1]), self._kv_split[:3], self._kv_split[3])
         o = o.view(*kv16.shape[:-1], -1)
         hid = self.key.out_features
         return o[..., :hid], o[..., hid:]
 
-    def forward(self, x: torch.Tensor, kv: Optional[torch.Tensor] = None,
-                mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, kv: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
+                kv_proj: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
+        """``kv_proj`` = (key(kv), value(kv)) computed by the caller (all cross-attention layers in one GEMM set)."""
         b, n, d = x.shape
         h = self.heads
-        if kv is None and x.is_cuda and not self.training:
+        if kv_proj is not None:
+            q = self.query(x).view(b, n, h, d // h).transpose(1, 2)
+            k = kv_proj[0].reshape(b, -1, h, d // h).transpose(1, 2)
+            v = kv_proj[1].reshape(b, -1, h, d // h).transpose(1, 2)
+        elif kv is None and x.is_cuda and not self.training:
             # self-attention: query / key / value share their input -- one GEMM over [Wq; Wk; Wv] instead of three
             # small ones (every output element is the same dot product; only the launch count changes)
             if self._qkv_fused is None or self._qkv_fused[0].device != x.device or self._qkv_fused[0].dtype != x.dtype:
@@ -252,6 +268,7 @@ class Blip2ITCModel(nn.Module):
         self._deferred_c: Optional[torch.Tensor] = None
         self.split_kv = True  # Q-Former cross-attention K/V projections of f16 tokens via exact 3-way weight split
         self.split_kv_min_rows = 32 * 257
+        self._kv_all = None
 
     # ---- weights ---------------------------------------------------------------------------------------------
     def init_random(self, seed: int = 0) -> "Blip2ITCModel":
@@ -273,6 +290,7 @@ class Blip2ITCModel(nn.Module):
         """Drop everything derived from the weights (packed heads stay the caller's to redo): call after editing
         parameters in place."""
         self._deferred_c = None
+        self._kv_all = None
         for layer in self.q_layers:
             layer.attention._qkv_fused = None
             if layer.crossattention is not None:
@@ -385,12 +403,32 @@ class Blip2ITCModel(nn.Module):
                     and image_tokens.shape[0] * image_tokens.shape[1] >= self.split_kv_min_rows)
         enc = image_tokens if split_ok else image_tokens.to(self.q_layernorm.weight.dtype)
         h = self.q_layernorm(self.query_tokens).expand(enc.shape[0], -1, -1)
+        proj = self._project_all_kv(enc) if split_ok else None
+        hid, at = self.cfg.q_hidden, 0
         for layer in self.q_layers:
             h = layer.attention(h)
             if layer.crossattention is not None:
-                h = layer.crossattention(h, kv=enc)
+                if proj is not None:
+                    h = layer.crossattention(h, kv_proj=(proj[..., at:at + hid], proj[..., at + hid:at + 2 * hid]))
+                    at += 2 * hid
+                else:
+                    h = layer.crossattention(h, kv=enc)
             h = layer.ffn_query(h)
         return h
+
+    def _project_all_kv(self, tokens16: torch.Tensor) -> torch.Tensor:
+        """key / value projections of EVERY cross-attention layer in one exact-split GEMM set ([B,257,1408] f16 ->
+        [B,257, layers * 2 * hidden] f32, layer-major [K_0 | V_0 | K_1 | V_1 ...]): the image tokens are the same for all
+        layers, and one wide GEMM runs closer to the MFMA peak than six narrow ones (_BertAttention._project_kv_f16 is
+        the per-layer form)."""
+        if self._kv_all is None or self._kv_all[0].device != tokens16.device:
+            cross = [l.crossattention for l in self.q_layers if l.crossattention is not None]
+            w = torch.cat([torch.cat([c.key.weight, c.value.weight]) for c in cross])
+            bias = torch.cat([torch.cat([c.key.bias, c.value.bias]) for c in cross]).detach().float()
+            w1, w2, w3 = _exact_split3(w)
+            self._kv_all = (w1.t(), w2.t(), w3.t(), bias)
+        o = _split_gemm(tokens16.reshape(-1, tokens16.shape[-1]), self._kv_all[:3], self._kv_all[3])
+        return o.view(*tokens16.shape[:-1], -1)
 
     def text_feature(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Q-Former text branch: ids [B,L] -> L2-normalised text_proj(CLS) [B,256]."""
