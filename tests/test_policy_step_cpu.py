@@ -282,3 +282,49 @@ def test_v3_scores_by_exploration_channel_below_the_threshold():
         assert ref(fake, vals) == ITMPolicyV3Step._reduce_values(fake, vals)
         fake._exploration_thresh = 0.35
         assert ref(fake, vals) == ITMPolicyV3Step._reduce_values(fake, vals)
+
+
+def test_step_cameras_follows_the_robot_deployment_call_order():
+    """reality_policies.py:103-141 + itm_policy.py:191-211: obstacle updates (explore=False for all but the last entry, which
+    only reveals), every cosine before the first value-map update, one object-map update per camera."""
+    from vlfm_amd.policy_step import ITMPolicyV2Step
+
+    log = []
+
+    class Obstacle(_StubObstacle):
+        def update_map(self, depth, tf, lo, hi, fx, fy, fov, explore=True, update_obstacles=True):
+            log.append(("obstacle", depth is None, explore, update_obstacles))
+
+    class Value(_StubValue):
+        def update_map(self, values, depth, tf, lo, hi, fov):
+            log.append(("value", float(values[0]), hi))
+
+    class Itm:
+        n = 0
+
+        def cosine(self, img, txt):
+            Itm.n += 1
+            log.append(("cosine", int(img[0, 0, 0])))
+            return 0.1 * Itm.n
+
+    class Objects(_StubObjects):
+        def update_explored(self, tf, max_depth, fov):
+            log.append(("object", max_depth, round(float(fov), 6)))
+
+    det = type("D", (), {"predict": lambda s, i, caption="": _Dets(0)})()
+    pol = ITMPolicyV2Step(camera_height=0.88, min_depth=0.5, max_depth=5.0, camera_fov=79.0, image_width=64, itm=Itm(),
+                          coco_detector=det, detector=det, sam=object(), obstacle_map=Obstacle(), value_map=Value(),
+                          object_map=Objects())
+    pol.reset("chair")
+    tf = np.eye(4)
+    cams = [np.full((4, 6, 3), k, np.uint8) for k in range(2)]
+    d = np.full((4, 6), 0.5, np.float32)
+    r = pol.step_cameras(obstacle_map_depths=[(d, tf, 0.3, 3.0, 5.0, 5.0, 1.0), (d, tf, 0.3, 3.0, 5.0, 5.0, 1.0),
+                                              (None, tf, 0.3, 3.0, 5.0, 5.0, 1.2)],
+                         value_map_rgbd=[(cams[0], d, tf, 0.3, 3.0, 1.0), (cams[1], d, tf, 0.3, 2.5, 1.0)],
+                         object_map_rgbd=[(cams[0], d, tf, 0.3, 3.0, 5.0, 5.0), (cams[1], d, tf, 0.3, 2.5, 4.0, 4.0)],
+                         robot_xy=np.zeros(2), robot_heading=0.0, nav_depth=d)
+    assert r.mode == "initialize"
+    assert log == [("obstacle", False, False, True), ("obstacle", False, False, True), ("obstacle", True, True, False),
+                   ("cosine", 0), ("cosine", 1), ("value", 0.1, 3.0), ("value", 0.2, 2.5),
+                   ("object", 3.0, round(2 * np.arctan(3 / 5.0), 6)), ("object", 2.5, round(2 * np.arctan(3 / 4.0), 6))]

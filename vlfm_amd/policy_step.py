@@ -237,34 +237,38 @@ class ITMPolicyV2Step:
             det.filter_by_conf(self._non_coco_threshold)
         return det
 
-    def _update_object_map(self, rgb: np.ndarray, depth: np.ndarray, tf: np.ndarray):
+    def _update_object_map(self, rgb: np.ndarray, depth: np.ndarray, tf: np.ndarray, min_depth: Optional[float] = None,
+                           max_depth: Optional[float] = None, fx: Optional[float] = None, fy: Optional[float] = None):
         """Detections -> one MobileSAM mask per surviving box -> object point cloud; then prune what the current view
-        proves absent (base_objectnav_policy.py:285-356)."""
+        proves absent (base_objectnav_policy.py:285-356).  Range and intrinsics default to the Habitat camera's."""
+        min_depth = self._min_depth if min_depth is None else min_depth
+        max_depth = self._max_depth if max_depth is None else max_depth
+        fx, fy = (self._fx if fx is None else fx), (self._fy if fy is None else fy)
         det = self._get_object_detections(rgb)
         h, w = rgb.shape[:2]
         self._object_masks = np.zeros((h, w), dtype=np.uint8)
         if np.array_equal(depth, np.ones_like(depth)) and det.num_detections > 0:
             if self._infer_depth is None:
                 raise NotImplementedError("depth image is all ones (no depth sensor) and no infer_depth was given")
-            depth = self._infer_depth(rgb, self._min_depth, self._max_depth)
+            depth = self._infer_depth(rgb, min_depth, max_depth)
         for i in range(len(det.logits)):
             # the reference multiplies the f32 tensor row by an int64 ndarray: NumPy promotes both to f64 first
             box_px = det.boxes[i].detach().cpu().numpy().astype(np.float64) * np.array([w, h, w, h])
             mask = self._mobile_sam.segment_bbox(rgb, box_px.tolist())
             self._object_masks[mask > 0] = 1
-            self._object_map.update_map(self._target_object, depth, mask, tf, self._min_depth, self._max_depth,
-                                        self._fx, self._fy)
-        self._object_map.update_explored(tf, self._max_depth, get_fov(self._fx, depth.shape[1]))
+            self._object_map.update_map(self._target_object, depth, mask, tf, min_depth, max_depth, fx, fy)
+        self._object_map.update_explored(tf, max_depth, get_fov(fx, depth.shape[1]))
         return det
 
-    def _update_value_map(self, rgb: np.ndarray, depth: np.ndarray, tf: np.ndarray, robot_xy: np.ndarray,
-                          heading: float) -> None:
-        """One cosine per prompt ("|"-separated) with target_object substituted, "|" of a multi-name category shown to
-        BLIP-2 as "/" (itm_policy.py:191-211)."""
+    def _update_value_map(self, cameras: Sequence[Tuple], robot_xy: np.ndarray, heading: float) -> None:
+        """``cameras`` = [(rgb, depth, tf, min_depth, max_depth, fov), ...].  One cosine per camera and per prompt
+        ("|"-separated) with target_object substituted, the "|" of a multi-name category shown to BLIP-2 as "/"; ALL
+        cosines are asked for first, then the maps are updated camera by camera (itm_policy.py:191-211)."""
         shown = self._target_object.replace("|", "/")
-        cosines = [self._itm.cosine(rgb, p.replace("target_object", shown))
-                   for p in self._text_prompt.split(PROMPT_SEPARATOR)]
-        self._value_map.update_map(np.array(cosines), depth, tf, self._min_depth, self._max_depth, self._camera_fov)
+        prompts = [p.replace("target_object", shown) for p in self._text_prompt.split(PROMPT_SEPARATOR)]
+        cosines = [[self._itm.cosine(cam[0], p) for p in prompts] for cam in cameras]
+        for cos, (_, depth, tf, min_depth, max_depth, fov) in zip(cosines, cameras):
+            self._value_map.update_map(np.array(cos), depth, tf, min_depth, max_depth, fov)
         self._value_map.update_agent_traj(robot_xy, heading)
 
     # ------------------------------------------------------------------------------------------------ decisions
@@ -286,24 +290,55 @@ class ITMPolicyV2Step:
         return rho, theta, stopped, reset
 
     def step(self, rgb: np.ndarray, depth: np.ndarray, x: float, y: float, yaw: float) -> StepResult:
-        """``x, y`` in the episodic frame (Habitat's GPS y already flipped, habitat_policies.py:186-188), ``depth`` (H,W)
-        in [0,1] already hole-filtered, ``yaw`` = compass."""
+        """Habitat: one forward RGB-D camera.  ``x, y`` in the episodic frame (Habitat's GPS y already flipped,
+        habitat_policies.py:186-188), ``depth`` (H,W) in [0,1] already hole-filtered, ``yaw`` = compass."""
         if depth.ndim == 3:
             depth = depth.reshape(depth.shape[:2])
         camera_position = np.array([x, y, self._camera_height])
         robot_xy = camera_position[:2]
         tf = xyz_yaw_to_tf_matrix(camera_position, yaw)
-        nan = float("nan")
         try:
             self._obstacle_map.update_map(depth, tf, self._min_depth, self._max_depth, self._fx, self._fy,
                                           self._camera_fov)
-        except IndexError:  # "Reached edge of map, stopping." base_objectnav_policy.py:157-162, habitat_policies.py:144-145
-            return StepResult("edge_of_map", None, nan, nan, True, False, self._selector.last_value, None,
-                              np.zeros((0, 2)))
+        except IndexError:
+            return self._edge_of_map()
+        return self._decide(
+            robot_xy, yaw, depth,
+            value_cameras=[(rgb, depth, tf, self._min_depth, self._max_depth, self._camera_fov)],
+            object_cameras=[(rgb, depth, tf, self._min_depth, self._max_depth, self._fx, self._fy)])
+
+    def step_cameras(self, obstacle_map_depths: Sequence[Tuple], value_map_rgbd: Sequence[Tuple],
+                     object_map_rgbd: Sequence[Tuple], robot_xy: np.ndarray, robot_heading: float,
+                     nav_depth: np.ndarray) -> StepResult:
+        """Several cameras per step, the observation layout of the robot deployment (reality_policies.py:103-141):
+        ``obstacle_map_depths`` = [(depth, tf, min_depth, max_depth, fx, fy, topdown_fov), ...] -- every entry but the last
+        only adds obstacles (``explore=False``), the last one (depth ignored) reveals the explored area from the robot's
+        pose; ``value_map_rgbd`` = [(rgb, depth, tf, min_depth, max_depth, fov), ...]; ``object_map_rgbd`` =
+        [(rgb, depth, tf, min_depth, max_depth, fx, fy), ...]; ``nav_depth`` feeds the PointNav controller."""
+        try:
+            for depth, tf, lo, hi, fx, fy, fov in obstacle_map_depths[:-1]:
+                self._obstacle_map.update_map(depth, tf, lo, hi, fx, fy, fov, explore=False)
+            _, tf, lo, hi, fx, fy, fov = obstacle_map_depths[-1]
+            self._obstacle_map.update_map(None, tf, lo, hi, fx, fy, fov, explore=True, update_obstacles=False)
+        except IndexError:
+            return self._edge_of_map()
+        return self._decide(np.asarray(robot_xy), robot_heading, nav_depth, value_map_rgbd, object_map_rgbd)
+
+    def _edge_of_map(self) -> StepResult:
+        """IndexError out of the obstacle scatter = "Reached edge of map, stopping." (base_objectnav_policy.py:157-162,
+        habitat_policies.py:144-145): STOP."""
+        nan = float("nan")
+        return StepResult("edge_of_map", None, nan, nan, True, False, self._selector.last_value, None, np.zeros((0, 2)))
+
+    def _decide(self, robot_xy: np.ndarray, yaw: float, nav_depth: np.ndarray, value_cameras: Sequence[Tuple],
+                object_cameras: Sequence[Tuple]) -> StepResult:
+        """Everything after the obstacle map of ITMPolicyV2.act -> BaseObjectNavPolicy.act (itm_policy.py:251-261,
+        base_objectnav_policy.py:107-150): value map, object map per camera, then initialise / explore / navigate."""
+        nan = float("nan")
         frontiers = self._obstacle_map.frontiers
         self._obstacle_map.update_agent_traj(robot_xy, yaw)
-        self._update_value_map(rgb, depth, tf, robot_xy, yaw)
-        det = self._update_object_map(rgb, depth, tf)
+        self._update_value_map(value_cameras, robot_xy, yaw)
+        dets = [self._update_object_map(*cam) for cam in object_cameras]
         goal = (self._object_map.get_best_object(self._target_object, robot_xy)
                 if self._object_map.has_object(self._target_object) else None)
         rho = theta = nan
@@ -323,9 +358,9 @@ class ITMPolicyV2Step:
             mode = "navigate"
             out_goal = goal[:2]
             rho, theta, stop, reset = self._goal_handover(out_goal, True, robot_xy, yaw)
-        action = self._act(mode, depth, rho, theta, stop, reset) if self._pointnav is not None else None
+        action = self._act(mode, nav_depth, rho, theta, stop, reset) if self._pointnav is not None else None
         self._num_steps += 1
-        return StepResult(mode, out_goal, rho, theta, stop, reset, self._selector.last_value, det,
+        return StepResult(mode, out_goal, rho, theta, stop, reset, self._selector.last_value, dets[0] if dets else None,
                           np.asarray(frontiers, np.float64).reshape(-1, 2), action)
 
     def _act(self, mode: str, depth: np.ndarray, rho: float, theta: float, stop: bool, reset: bool):
