@@ -1,4 +1,4 @@
-// vit_attention.hip -- self-attention of the BLIP-2 ViT-g blocks (S = 257 tokens, 16 heads of 88 -> 96 padded), gfx950.
+// vit_attention.hip -- self-attention of the BLIP-2 ViT-g blocks (S = 257 tokens, 16 heads of 88), gfx950.
 //
 // Replaces F.scaled_dot_product_attention in vlfm_amd/vlm/blip2itm.py:_VitBlock (the reference reaches the same maths
 // through LAVIS' eva_vit Attention, vlfm/vlm/blip2itm.py:29-34,52 [ext]).  The library flash kernel spends 290 us per
@@ -13,10 +13,16 @@
 //     movement between the two GEMMs (the pairing of accumulator registers with key indices is mirrored in the V^T loads);
 //   * the odd token (the CLS query) is a ninth query tile with one live column: its keys are split over the 8
 //     wavefronts (12 MFMAs each), partial (max, sum, O) are merged through LDS by wavefront 0;
-//   * output goes straight to the [B, S, H, 96] layout the projection GEMM consumes (the library path needs a
-//     transpose copy).
+//   * the MFMA-friendly head width 96 exists only in LDS / registers (channels 88..95 are zeros written while staging);
+//     global memory holds the native 88-wide rows, so the qkv and projection GEMMs keep their sizes (DH = 96 serves
+//     weights that were zero-padded instead);
+//   * output goes straight to the [B, S, H, DH] layout the projection GEMM consumes (the library path needs a
+//     transpose copy);
+//   * LDS operand fetches run one contraction step ahead of the MFMAs; key tiles are processed in groups of three so
+//     that consecutive MFMAs write different accumulators.
 //
-// MFMA-bound by design: 2 x 4 x 257^2 x 96 flop per (image, head); HBM traffic = qkv read once + output written once.
+// 4 x 257^2 x 88 flop per (image, head); HBM traffic = qkv read once + output written once (404 MB at 128 images), which
+// is what bounds it: one workgroup per CU (LDS), so staging cannot overlap another workgroup's MFMA phase.
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
