@@ -36,7 +36,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--envs", type=int, default=128,
+    ap.add_argument("--envs", type=int, default=256,
                     help="environments resident per GPU (weak scaling).  BASELINE configs[3]/[4] use 8 and 16 per GPU; "
                          "288 GB of HBM holds far more, and the batched BLIP-2 forward and the map kernels only reach "
                          "their efficient regime at >= 64 (the 8/GPU and 1/GPU figures are reported alongside)")
@@ -327,7 +327,7 @@ def main():
                 torch.cuda.synchronize(device)
 
             def leg_small():
-                for e_small in (8, 1):
+                for e_small in ((128, 8, 1) if args.envs != 128 else (8, 1)):
                     small = BatchedEpisodes(e_small, device=device, height=args.height, width=args.width,
                                             blip2=sim.blip2, obstacle=have_obstacle, overlap=not args.no_overlap)
                     for _ in range(3):
