@@ -47,6 +47,9 @@ OM_CASES = {
     "om_traj": (1, 26, False, 100000),
     "om_holes_fill": (2, 6, True, 100000),
     "om_holes_all": (2, 6, True, -1),
+    # the robot deployment's obstacle band and footprint (config/experiments/reality.yaml:19-21): 0.1-1.5 m puts most
+    # wall texels in the band, agent_radius 0.2 makes the navigable-map dilation 9x9 instead of 7x7
+    "om_reality": (9, 10, True, 100000, dict(min_height=0.1, max_height=1.5, agent_radius=0.2, area_thresh=1.5)),
 }
 SYNC_CASE = ("vm_sync_explored", 7, 14)  # ValueMap(obstacle_map=...) full-map mode: (name, seed, steps)
 OBSTACLE_KW = dict(min_height=0.61, max_height=0.88, agent_radius=0.18, area_thresh=1.5)
@@ -105,10 +108,11 @@ def gen_value_map(ref_vm, seed, steps, channels, use_max, fusion, H, W):
     return out
 
 
-def gen_obstacle_map(ref_om, seed, steps, holes, hole_thresh):
+def gen_obstacle_map(ref_om, seed, steps, holes, hole_thresh, kw=None):
+    kw = dict(OBSTACLE_KW if kw is None else kw)
     fx, fy, fov = camera_intrinsics(640)
     env = SyntheticEnv(seed, holes=holes)
-    om = ref_om.ObstacleMap(hole_area_thresh=hole_thresh, **OBSTACLE_KW)
+    om = ref_om.ObstacleMap(hole_area_thresh=hole_thresh, **kw)
     tfs, hashes, fr_px, fr_xy = [], [], [], []
     for _ in range(steps):
         depth, tf, _ = env.observe()
@@ -122,8 +126,7 @@ def gen_obstacle_map(ref_om, seed, steps, holes, hole_thresh):
     return dict(seed=seed, steps=steps, holes=holes, hole_area_thresh=hole_thresh, fx=fx, fy=fy, fov=fov,
                 min_depth=MIN_DEPTH, max_depth=MAX_DEPTH, tf=np.stack(tfs), depth_sha256=np.array(hashes),
                 obstacle_bits=packbits(om._map), navigable_bits=packbits(om._navigable_map),
-                explored_bits=packbits(om.explored_area), frontier_counts=cpx, frontiers_px=fpx, frontiers_xy=fxy,
-                **{k: v for k, v in OBSTACLE_KW.items()})
+                explored_bits=packbits(om.explored_area), frontier_counts=cpx, frontiers_px=fpx, frontiers_xy=fxy, **kw)
 
 
 def gen_sync(ref_vm, ref_om, seed, steps):

@@ -10,7 +10,7 @@ from vlfm_amd.synthetic import SyntheticEnv
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 VM_CASES = ["vm_default_c1", "vm_maxconf_c1", "vm_default_c2", "vm_replace_c1", "vm_equal_c1", "vm_default_hd"]
-OM_CASES = ["om_traj", "om_holes_fill", "om_holes_all"]
+OM_CASES = ["om_traj", "om_holes_fill", "om_holes_all", "om_reality"]
 
 
 def load(name):
