@@ -129,6 +129,35 @@ def gen_obstacle_map(ref_om, seed, steps, holes, hole_thresh, kw=None):
                 explored_bits=packbits(om.explored_area), frontier_counts=cpx, frontiers_px=fpx, frontiers_xy=fxy, **kw)
 
 
+def multicam_script(seed: int, steps: int):
+    """Per step: two body cameras (yaw offsets -35 / +35 degrees, max depth 2.5 m like the robot's, reality.yaml:24) that
+    only add obstacles, then one reveal from the robot pose without a depth image -- the call pattern of
+    RealityMixin._cache_observations (reality_policies.py:113-138).  Shared by the generator and the replaying tests."""
+    from vlfm_amd.synthetic import depth_frame, pose_to_tf
+
+    env = SyntheticEnv(seed)
+    fx, fy, fov = camera_intrinsics(640)
+    for _ in range(steps):
+        x, y, yaw = env.traj.step()
+        cams = [(depth_frame(env.rng, 480, 640, holes=True), pose_to_tf(x, y, yaw + off)) for off in (-0.61, 0.61)]
+        yield cams, pose_to_tf(x, y, yaw), fx, fy, fov
+
+
+def gen_multicam(ref_om, seed=15, steps=8):
+    om = ref_om.ObstacleMap(hole_area_thresh=100000, min_height=0.1, max_height=1.5, agent_radius=0.2, area_thresh=1.5)
+    fr_xy, hashes = [], []
+    for cams, tf_robot, fx, fy, fov in multicam_script(seed, steps):
+        for depth, tf in cams:
+            hashes.append(sha(depth))
+            om.update_map(depth.copy(), tf, MIN_DEPTH, 2.5, fx, fy, fov, explore=False)
+        om.update_map(None, tf_robot, MIN_DEPTH, 2.5, fx, fy, 2 * fov, explore=True, update_obstacles=False)
+        fr_xy.append(np.asarray(om.frontiers, np.float64).reshape(-1, 2))
+    counts, cat = frontier_blob(fr_xy)
+    return dict(seed=seed, steps=steps, depth_sha256=np.array(hashes), frontier_counts=counts, frontiers_xy=cat,
+                obstacle_bits=packbits(om._map), navigable_bits=packbits(om._navigable_map),
+                explored_bits=packbits(om.explored_area))
+
+
 def gen_sync(ref_vm, ref_om, seed, steps):
     """reality-style ValueMap(obstacle_map=...) (value_map.py:369-375): full-map zeroing by the explored area."""
     fx, fy, fov = camera_intrinsics(640)
@@ -488,6 +517,7 @@ def generate():
     for name, args in OM_CASES.items():
         out[name] = gen_obstacle_map(ref_om, *args)
     out[SYNC_CASE[0]] = gen_sync(ref_vm, ref_om, SYNC_CASE[1], SYNC_CASE[2])
+    out["om_multicam"] = gen_multicam(ref_om)
     out["helpers"] = gen_helpers(geo, img, ref_vm)
     out["detections"] = gen_detections(ref_shim.reference_detections())
     out["object_map"] = gen_object_map(ref_shim.reference_object_map())

@@ -102,3 +102,29 @@ def replay_policy_episode(name, make_step, make_detections, tol=1e-4):
     cloud = pol.maps()[2].clouds.get(goal_name, np.zeros((0, 4)))
     assert len(cloud) == int(g["cloud_sig"][0])
     return pol, g
+
+
+def replay_multicam(make_map):
+    """Drive an ObstacleMap through the multi-camera script of make_golden.py (explore=False per body camera, then a reveal
+    without depth) and compare with the fixture the reference produced.  Returns nothing; asserts."""
+    import sys
+
+    if GOLDEN_DIR not in sys.path:
+        sys.path.insert(0, GOLDEN_DIR)
+    import make_golden as mg
+
+    g = load("om_multicam")
+    om = make_map(hole_area_thresh=100000, min_height=0.1, max_height=1.5, agent_radius=0.2, area_thresh=1.5)
+    offs = np.concatenate([[0], np.cumsum(g["frontier_counts"])])
+    k = 0
+    for step, (cams, tf_robot, fx, fy, fov) in enumerate(mg.multicam_script(int(g["seed"]), int(g["steps"]))):
+        for depth, tf in cams:
+            assert sha(depth) == str(g["depth_sha256"][k]), "synthetic depth differs from the fixture's input"
+            k += 1
+            om.update_map(depth, tf, 0.5, 2.5, fx, fy, fov, explore=False)
+        om.update_map(None, tf_robot, 0.5, 2.5, fx, fy, 2 * fov, explore=True, update_obstacles=False)
+        got = np.asarray(om.frontiers, np.float64).reshape(-1, 2)
+        assert np.array_equal(got, g["frontiers_xy"][offs[step]:offs[step + 1]]), f"step {step}"
+    assert np.array_equal(np.asarray(om._map).astype(bool), unpack_plane(g["obstacle_bits"]))
+    assert np.array_equal(np.asarray(om._navigable_map).astype(bool), unpack_plane(g["navigable_bits"]))
+    assert np.array_equal(np.asarray(om.explored_area).astype(bool), unpack_plane(g["explored_bits"]))

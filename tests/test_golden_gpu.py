@@ -67,3 +67,12 @@ def test_sync_explored_matches_reference_fixture(gpu_device):
     assert np.array_equal(om.explored_area.astype(bool), unpack_plane(g["explored_bits"]))
     assert np.array_equal(vm._map > 0, conf > 0)
     assert np.abs(vm._map - conf).max() <= TOL and np.abs(vm._value_map - value).max() <= TOL
+
+
+def test_multicamera_obstacle_map_matches_reference_fixture(gpu_device):
+    """The robot deployment's call pattern: obstacles from two body cameras (explore=False), then a reveal from the robot
+    pose without a depth image (update_obstacles=False)."""
+    from golden_util import replay_multicam
+    from vlfm_amd.mapping import ObstacleMap
+
+    replay_multicam(lambda **kw: ObstacleMap(device=gpu_device, **kw))

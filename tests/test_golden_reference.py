@@ -109,3 +109,11 @@ def test_committed_fixtures_equal_a_fresh_run_of_the_reference():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "make_golden.py"), "--check"],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_oracle_matches_multicamera_fixture():
+    """explore=False per body camera, then a reveal without depth (reality_policies.py:113-138)."""
+    from golden_util import replay_multicam
+    from oracle.ref_obstacle_map import RefObstacleMap
+
+    replay_multicam(lambda **kw: RefObstacleMap(**kw))
