@@ -108,6 +108,34 @@ def gen_value_map(ref_vm, seed, steps, channels, use_max, fusion, H, W):
     return out
 
 
+def two_camera_script(seed: int, steps: int):
+    """Per step two value-map observations into the SAME map with different optics: the 79-degree / 5 m camera and a
+    narrower 60-degree camera that is only trusted to 2.5 m, yawed 40 degrees to the left (itm_policy.py:204-206 loops over
+    value_map_rgbd; the reference keeps one confidence-cone cache entry per (fov, max_depth), value_map.py:37,339-353)."""
+    from vlfm_amd.synthetic import depth_frame, pose_to_tf
+
+    env = SyntheticEnv(seed)
+    for _ in range(steps):
+        x, y, yaw = env.traj.step()
+        yield [(depth_frame(env.rng, 480, 640), pose_to_tf(x, y, yaw), MIN_DEPTH, MAX_DEPTH, camera_intrinsics(640)[2],
+                env.rng.uniform(0.15, 0.45, size=1)),
+               (depth_frame(env.rng, 480, 640), pose_to_tf(x, y, yaw + 0.7), MIN_DEPTH, 2.5, np.deg2rad(60.0),
+                env.rng.uniform(0.15, 0.45, size=1))]
+
+
+def gen_two_cameras(ref_vm, seed=16, steps=10):
+    vm = ref_vm.ValueMap(1, use_max_confidence=False)
+    hashes = []
+    for cams in two_camera_script(seed, steps):
+        for depth, tf, lo, hi, fov, values in cams:
+            hashes.append(sha(depth))
+            vm.update_map(values, depth.copy(), tf, lo, hi, fov)
+    ci, cv = sparse(vm._map)
+    vmap = np.asarray(vm._value_map, np.float64)
+    return dict(seed=seed, steps=steps, depth_sha256=np.array(hashes), conf_idx=ci, conf_val=cv.astype(np.float32),
+                value_val=vmap.reshape(-1)[ci].astype(np.float32), value_sha=np.array(sha(vmap)))
+
+
 def gen_obstacle_map(ref_om, seed, steps, holes, hole_thresh, kw=None):
     kw = dict(OBSTACLE_KW if kw is None else kw)
     fx, fy, fov = camera_intrinsics(640)
@@ -518,6 +546,7 @@ def generate():
         out[name] = gen_obstacle_map(ref_om, *args)
     out[SYNC_CASE[0]] = gen_sync(ref_vm, ref_om, SYNC_CASE[1], SYNC_CASE[2])
     out["om_multicam"] = gen_multicam(ref_om)
+    out["vm_two_cameras"] = gen_two_cameras(ref_vm)
     out["helpers"] = gen_helpers(geo, img, ref_vm)
     out["detections"] = gen_detections(ref_shim.reference_detections())
     out["object_map"] = gen_object_map(ref_shim.reference_object_map())

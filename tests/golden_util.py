@@ -128,3 +128,29 @@ def replay_multicam(make_map):
     assert np.array_equal(np.asarray(om._map).astype(bool), unpack_plane(g["obstacle_bits"]))
     assert np.array_equal(np.asarray(om._navigable_map).astype(bool), unpack_plane(g["navigable_bits"]))
     assert np.array_equal(np.asarray(om.explored_area).astype(bool), unpack_plane(g["explored_bits"]))
+
+
+def replay_two_cameras(make_map, exact: bool, tol: float = 1e-4):
+    """One value map fed by two cameras with different (fov, max_depth) per step (make_golden.two_camera_script)."""
+    import sys
+
+    if GOLDEN_DIR not in sys.path:
+        sys.path.insert(0, GOLDEN_DIR)
+    import make_golden as mg
+
+    g = load("vm_two_cameras")
+    vm = make_map(1, use_max_confidence=False)
+    k = 0
+    for cams in mg.two_camera_script(int(g["seed"]), int(g["steps"])):
+        for depth, tf, lo, hi, fov, values in cams:
+            assert sha(depth) == str(g["depth_sha256"][k]), "synthetic depth differs from the fixture's input"
+            k += 1
+            vm.update_map(values, depth, tf, lo, hi, fov)
+    conf = dense(g["conf_idx"], g["conf_val"], (1000, 1000), np.float32)
+    if exact:
+        assert np.array_equal(vm._map, conf)
+        assert sha(np.asarray(vm._value_map, np.float64)) == str(g["value_sha"])
+    else:
+        val = dense(g["conf_idx"], g["value_val"], (1000, 1000, 1), np.float64)
+        assert np.array_equal(np.asarray(vm._map) > 0, conf > 0)
+        assert np.abs(vm._map - conf).max() <= tol and np.abs(vm._value_map - val).max() <= tol

@@ -76,3 +76,12 @@ def test_multicamera_obstacle_map_matches_reference_fixture(gpu_device):
     from vlfm_amd.mapping import ObstacleMap
 
     replay_multicam(lambda **kw: ObstacleMap(device=gpu_device, **kw))
+
+
+def test_two_camera_value_map_matches_reference_fixture(gpu_device):
+    """Two cameras with different (fov, max_depth) feeding one value map: one cone template per optics, like the
+    reference's per-(fov, max_depth) confidence-mask cache."""
+    from golden_util import replay_two_cameras
+    from vlfm_amd.mapping import ValueMap
+
+    replay_two_cameras(lambda c, **kw: ValueMap(c, device=gpu_device, **kw), exact=False, tol=TOL)

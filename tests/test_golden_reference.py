@@ -117,3 +117,10 @@ def test_oracle_matches_multicamera_fixture():
     from oracle.ref_obstacle_map import RefObstacleMap
 
     replay_multicam(lambda **kw: RefObstacleMap(**kw))
+
+
+def test_oracle_matches_two_camera_value_map_fixture():
+    from golden_util import replay_two_cameras
+    from oracle.ref_value_map import RefValueMap
+
+    replay_two_cameras(lambda c, **kw: RefValueMap(c, **kw), exact=True)
