@@ -76,3 +76,47 @@ def test_tan_table_and_disc_rows():
         for i in range(2 * r + 1):
             xs = np.where(disc[i])[0]
             assert xs[0] == r - hw[i] and xs[-1] == r + hw[i] and len(xs) == 2 * hw[i] + 1
+
+
+def test_harness_frontier_selection_and_goal_geometry_are_the_scalar_rules_vectorised():
+    """BatchedEpisodes._select / _navigate (host side of the full step) against the scalar rules of policy_step.py."""
+    import numpy as np
+    import torch
+
+    from vlfm_amd.harness import BatchedEpisodes
+    from vlfm_amd.policy_step import FrontierSelector, rho_theta
+
+    class H:  # just the attributes the two methods touch
+        pass
+
+    h = H()
+    h.E = 3
+    h.selectors = [FrontierSelector() for _ in range(3)]
+    wps = np.array([[1.0, 0.0], [2.0, 0.0], [5.0, 5.0], [6.0, 6.0], [7.0, 7.0]])
+    env_of = np.array([0, 0, 2, 2, 2])
+    poses = np.array([[0.0, 0.0, 0.3], [1.0, 1.0, -1.0], [4.0, 4.0, 2.0]])
+    goals = BatchedEpisodes._select(h, wps, env_of, np.array([0.2, 0.3, 0.1, 0.5, 0.4]), poses)
+    assert np.array_equal(goals[0], [2.0, 0.0]) and np.isnan(goals[1]).all() and np.array_equal(goals[2], [6.0, 6.0])
+    # second step: env 0's pursued frontier dropped by less than 0.01 below ... stays; env 2's is gone -> nearest within 0.5 m
+    goals2 = BatchedEpisodes._select(h, np.array([[1.0, 0.0], [2.0, 0.0], [6.2, 6.0], [9.0, 9.0]]),
+                                     np.array([0, 0, 2, 2]), np.array([0.9, 0.295, 0.495, 0.8]), poses)
+    assert np.array_equal(goals2[0], [2.0, 0.0]) and np.array_equal(goals2[2], [6.2, 6.0])
+
+    captured = {}
+
+    class Ctrl:
+        def reset(self, ids):
+            captured["reset"] = list(np.asarray(ids))
+
+        def act_on_depth(self, depth, rt, masks):
+            captured["rt"], captured["masks"] = rt.numpy(), masks.numpy()
+            return torch.zeros(3, 1, dtype=torch.long)
+
+    h.pointnav, h.prev_goals, h.t, h.episode_len = Ctrl(), np.zeros((3, 2)), 5, 500
+    h.prev_goals[0] = goals2[0]  # env 0 keeps its goal -> no reset; env 1 has no goal (stays in place); env 2 moved
+    BatchedEpisodes._navigate(h, torch.zeros(3, 4, 4), goals2, poses)
+    for e in (0, 2):
+        rho, theta = rho_theta(poses[e, :2], poses[e, 2], goals2[e])
+        assert abs(captured["rt"][e, 0] - rho) < 1e-6 and abs(captured["rt"][e, 1] - theta) < 1e-6
+    assert captured["rt"][1, 0] == 0.0                       # no frontier: the goal is the robot's own position
+    assert captured["reset"] == [1, 2] and captured["masks"].tolist() == [True, False, False]
