@@ -112,11 +112,20 @@ class _VitBlock(nn.Module):
         hd = d // self.heads
         h = ops.layernorm_bias(x, c_in, self.layer_norm1.weight, self.layer_norm1.bias, self.layer_norm1.eps)
         x2 = x.view(b * n, d)
+        a = None
         if self.hip_attention and n == ops.VIT_ATTENTION_TOKENS and hd in ops.VIT_ATTENTION_HEADS:
             # native head width: the HIP kernel pads 88 -> 96 in LDS / registers only, so the qkv and projection GEMMs keep
             # their original sizes and the attention output needs no transpose copy
             qkv = F.linear(h.view(b * n, d), self.qkv.weight, self.qkv.bias)
-            x2.addmm_(ops.vit_attention(qkv, b, n, self.heads, hd, float(hd) ** -0.5), self.projection.weight.t())
+            try:
+                a = ops.vit_attention(qkv, b, n, self.heads, hd, float(hd) ** -0.5)
+            except (RuntimeError, AssertionError, IndexError) as exc:   # e.g. the 117 KB LDS opt-in refused on this device
+                import warnings
+
+                warnings.warn(f"vlfm_vit_attention_f16 unavailable ({exc}); using the library attention kernel instead")
+                self.hip_attention = False
+        if a is not None:
+            x2.addmm_(a, self.projection.weight.t())
         elif self._packed is not None:
             wq, bq, wp, hp, scale = self._packed
             q = F.linear(h.view(b * n, d), wq, bq).view(b, n, 3, self.heads, hp).permute(2, 0, 3, 1, 4)
