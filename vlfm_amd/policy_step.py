@@ -424,4 +424,3 @@ def habitat_objectgoal_name(object_id: int, dataset_type: str = "hm3d") -> str:
 
 __all__ = ["ITMPolicyV2Step", "ITMPolicyV3Step", "StepResult", "FrontierSelector", "AcyclicEnforcer", "rho_theta", "get_fov",
            "xyz_yaw_to_tf_matrix", "closest_point_within_threshold", "habitat_objectgoal_name"]
-_ = List  # typing re-export guard for older linters
