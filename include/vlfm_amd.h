@@ -108,6 +108,20 @@ typedef struct {
                                     fill_small_holes, which needs the whole image first) */
 } vlfm_ingest_params;     /* 152 bytes */
 
+/* Undo journal of the speculative single depth pass (fill_small_holes mode).  The pass places every NON-zero texel before
+ * fill_small_holes has run; a valid texel that lies INSIDE a filled hole contour (an "island": the reference's
+ * drawContours(.., -1) covers it, it becomes 1.0 and is dropped, img_utils.py:385-388) must not count.  The pass
+ * therefore records the cell id (row * S + col) of every obstacle bit it is the FIRST to set; for island frames
+ * vlfm_fill_small_holes_batched clears exactly those bits and vlfm_depth_scatter_holes_batched re-places the valid
+ * texels outside the filled area.  d_count must be zero on entry (allocate zeroed; vlfm_fill_small_holes_batched
+ * resets it).  Observations of one call must belong to distinct environment slots when a journal is used. */
+typedef struct {
+    uint32_t* d_cells;    /* [n][capacity] */
+    int32_t* d_count;     /* [n] */
+    int32_t capacity;     /* entries per observation; (2*ceil(reach*ppm)+3)^2 is always enough */
+    int32_t reserved;
+} vlfm_scatter_journal;   /* 24 bytes, HOST struct holding device pointers */
+
 int vlfm_depth_ingest_batched(const float* d_depth, int n, int height, int width,
                               const vlfm_ingest_params* d_params,
                               uint32_t* d_colmax_keys /* [n][W] or NULL */,
@@ -117,6 +131,7 @@ int vlfm_depth_ingest_batched(const float* d_depth, int n, int height, int width
                               uint32_t* d_hole_bits /* OUT [n][H][ceil(W/32)] bit plane of (depth == 0), or NULL */,
                               const uint32_t* d_filled_bits /* IN  [n][H][ceil(W/32)] texels fill_small_holes set to
                                                                1.0 (vlfm_fill_small_holes_batched), or NULL */,
+                              const vlfm_scatter_journal* journal /* host pointer or NULL (see above) */,
                               void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -127,21 +142,29 @@ int vlfm_depth_ingest_batched(const float* d_depth, int n, int height, int width
  * get an all-zero d_filled_bits only if they had holes before (see d_dirty).
  *   d_status   [n][2] the ingest status (word 1 = image has zeros)
  *   d_scratch  vlfm_hole_scratch_bytes(n, H, W, cap_pts, cap_contours) bytes
- *   d_counts   [n][4] int32: (contours traced, contours filled, overflow flag, reserved)
- *   d_counts   [n][4] int32: (contours traced, contours filled, overflow flag, image had zero texels)
- * Single depth pass (what ObstacleMapBatch does): vlfm_depth_ingest_batched with scatter bits 0|2 places every NON-zero
- * texel and writes d_hole_bits; this call decides which zeros become 1.0; vlfm_depth_scatter_holes_batched then places
- * the zeros that survived (depth 0 -> z = min_depth) from the two bit planes, without touching the images again.
- * (Alternative: a second vlfm_depth_ingest_batched call with d_filled_bits and d_colmax_keys = NULL.)
+ *   d_counts   [n][4] int32: (contours traced, contours filled, overflow flags: bit 0 contour scratch, bit 1 journal,
+ *              bit 0 image had zero texels | bit 1 island frame = valid texels inside a filled contour)
+ *   d_params / d_obstacle / map_size / journal: only with a journal (else NULL / NULL / 0 / NULL): the env slot of each
+ *              observation, the obstacle planes and the undo journal of the speculative pass
+ * Single depth pass (what ObstacleMapBatch does): vlfm_depth_ingest_batched with scatter bits 0|2 and a journal places
+ * every NON-zero texel and writes d_hole_bits; this call decides which zeros become 1.0 and, for island frames, takes the
+ * speculative pass's new bits back; vlfm_depth_scatter_holes_batched then places the zeros that survived (depth 0 ->
+ * z = min_depth) from the two bit planes and -- island frames only, which is the one case that reads d_depth again --
+ * the valid texels outside the filled area.
+ * (Alternative without a journal: vlfm_depth_ingest_batched with scatter bit 0 clear, this call, then a second
+ * vlfm_depth_ingest_batched with d_filled_bits and d_colmax_keys = NULL.)
  * ------------------------------------------------------------------------------------------- */
 size_t vlfm_hole_scratch_bytes(int n, int height, int width, int cap_pts, int cap_contours);
 int vlfm_fill_small_holes_batched(const uint32_t* d_hole_bits, const int32_t* d_status, int n, int height, int width,
                                   double area_thresh, void* d_scratch, size_t scratch_bytes, int cap_pts,
-                                  int cap_contours, uint32_t* d_filled_bits, int32_t* d_counts, void* stream);
+                                  int cap_contours, uint32_t* d_filled_bits, int32_t* d_counts,
+                                  const vlfm_ingest_params* d_params, uint32_t* d_obstacle, int map_size,
+                                  const vlfm_scatter_journal* journal, void* stream);
 int vlfm_depth_scatter_holes_batched(const vlfm_ingest_params* d_params, int n, int height, int width,
                                      const uint32_t* d_hole_bits, const uint32_t* d_filled_bits,
                                      const int32_t* d_hole_counts /* d_counts of vlfm_fill_small_holes_batched */,
                                      uint32_t* d_obstacle, int map_size, int pixels_per_meter, int32_t* d_status,
+                                     const float* d_depth /* [n][H][W]: read for island frames only; NULL = never */,
                                      void* stream);
 
 /* ---------------------------------------------------------------------------------------------

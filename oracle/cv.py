@@ -29,7 +29,7 @@ def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "cvport.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(
-            ["gcc", "-O2", "-fPIC", "-shared", "-std=c99", "-ffp-contract=off", "-o", _SO, src, "-lm"]
+            ["gcc", "-O3", "-fPIC", "-shared", "-std=c99", "-ffp-contract=off", "-o", _SO, src, "-lm"]
         )
     return _SO
 

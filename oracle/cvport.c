@@ -664,18 +664,20 @@ void cvp_warp_affine_f64(const double *src, double *dst, int rows, int cols, con
 
 /* ------------------------------------------------------------------ dilate with a kw x kh all-ones kernel, centre anchor */
 void cvp_dilate_rect(const uint8_t *src, uint8_t *dst, int rows, int cols, int kw, int kh) {
+    /* rectangular structuring element, anchor at the centre, border = "no contribution" (cv2's default border value for
+     * dilation never wins a maximum): separable running maxima written as whole-row shifted max passes so that the
+     * compiler vectorises them (full 1000 x 1000 maps, several times per step) */
     int ax = kw / 2, ay = kh / 2;
     uint8_t *tmp = (uint8_t *)malloc((size_t)rows * cols);
     for (int y = 0; y < rows; y++) {
         const uint8_t *s = src + (size_t)y * cols;
         uint8_t *t = tmp + (size_t)y * cols;
-        for (int x = 0; x < cols; x++) {
-            int lo = x - ax, hi = x - ax + kw - 1;
-            if (lo < 0) lo = 0;
-            if (hi > cols - 1) hi = cols - 1;
-            uint8_t m = 0;
-            for (int k = lo; k <= hi; k++) if (s[k] > m) m = s[k];
-            t[x] = m;
+        memcpy(t, s, (size_t)cols);
+        for (int k = 1; k <= ax; k++) {                 /* window [x - ax, x - ax + kw - 1] */
+            for (int x = k; x < cols; x++) { uint8_t v = s[x - k]; if (v > t[x]) t[x] = v; }
+        }
+        for (int k = 1; k <= kw - 1 - ax; k++) {
+            for (int x = 0; x + k < cols; x++) { uint8_t v = s[x + k]; if (v > t[x]) t[x] = v; }
         }
     }
     for (int y = 0; y < rows; y++) {
@@ -686,34 +688,42 @@ void cvp_dilate_rect(const uint8_t *src, uint8_t *dst, int rows, int cols, int k
         memcpy(d, tmp + (size_t)lo * cols, (size_t)cols);
         for (int k = lo + 1; k <= hi; k++) {
             const uint8_t *t = tmp + (size_t)k * cols;
-            for (int x = 0; x < cols; x++) if (t[x] > d[x]) d[x] = t[x];
+            for (int x = 0; x < cols; x++) { uint8_t v = t[x]; if (v > d[x]) d[x] = v; }
         }
     }
     free(tmp);
 }
 
 /* ------------------------------------------------------------------ blur 3x3, u8, BORDER_REFLECT_101, normalized */
+static inline int reflect101_(int i, int n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * n - 2 - i;
+    return i < 0 ? 0 : i;
+}
 void cvp_blur3x3(const uint8_t *src, uint8_t *dst, int rows, int cols) {
-    for (int y = 0; y < rows; y++) {
-        for (int x = 0; x < cols; x++) {
-            int s = 0;
-            for (int dy = -1; dy <= 1; dy++) {
-                int yy = y + dy;
-                if (yy < 0) yy = -yy;
-                if (yy >= rows) yy = 2 * rows - 2 - yy;
-                if (yy < 0) yy = 0;
-                for (int dx = -1; dx <= 1; dx++) {
-                    int xx = x + dx;
-                    if (xx < 0) xx = -xx;
-                    if (xx >= cols) xx = 2 * cols - 2 - xx;
-                    if (xx < 0) xx = 0;
-                    s += src[(size_t)yy * cols + xx];
-                }
-            }
-            int v = cv_round(s * (1. / 9));
-            dst[(size_t)y * cols + x] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
-        }
+    /* sums are integers <= 9 * 255: the rounding of s * (1/9) is tabulated once; horizontal 3-sums per row, then three
+     * rows added -- same values as the direct 9-tap evaluation */
+    static uint8_t lut[9 * 255 + 1];
+    static int have = 0;
+    if (!have) {
+        for (int s = 0; s <= 9 * 255; s++) { int v = cv_round(s * (1. / 9)); lut[s] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
+        have = 1;
     }
+    uint16_t *h = (uint16_t *)malloc((size_t)rows * cols * sizeof(uint16_t));
+    for (int y = 0; y < rows; y++) {
+        const uint8_t *s = src + (size_t)y * cols;
+        uint16_t *t = h + (size_t)y * cols;
+        for (int x = 1; x + 1 < cols; x++) t[x] = (uint16_t)(s[x - 1] + s[x] + s[x + 1]);
+        t[0] = (uint16_t)(s[reflect101_(-1, cols)] + s[0] + s[reflect101_(1, cols)]);
+        if (cols > 1) t[cols - 1] = (uint16_t)(s[reflect101_(cols - 2, cols)] + s[cols - 1] + s[reflect101_(cols, cols)]);
+    }
+    for (int y = 0; y < rows; y++) {
+        const uint16_t *a = h + (size_t)reflect101_(y - 1, rows) * cols, *b = h + (size_t)y * cols,
+                       *c = h + (size_t)reflect101_(y + 1, rows) * cols;
+        uint8_t *d = dst + (size_t)y * cols;
+        for (int x = 0; x < cols; x++) d[x] = lut[a[x] + b[x] + c[x]];
+    }
+    free(h);
 }
 
 /* ------------------------------------------------------------------ findContours (Suzuki-Abe, legacy C implementation semantics)

@@ -117,6 +117,12 @@ def _bresenhamline(start: np.ndarray, end: np.ndarray) -> np.ndarray:
 
 def interpolate_contour(contour: np.ndarray) -> np.ndarray:
     pts = contour.reshape(-1, 2)
+    if len(pts) > 1:
+        # CHAIN_APPROX_NONE contours (the only caller's): consecutive points are 8-neighbours, so every segment's
+        # "bresenhamline" is exactly its end point -- the whole interpolation is the contour rotated by one
+        step = np.abs(np.roll(pts, -1, axis=0) - pts).max(axis=1)
+        if np.all(step == 1):
+            return np.roll(pts, -1, axis=0).reshape((-1, 1, 2))
     segs = [_bresenhamline(pts[i], pts[(i + 1) % len(pts)]) for i in range(len(pts))]
     return np.concatenate(segs).reshape((-1, 1, 2)) if len(segs) else np.zeros((0, 1, 2), pts.dtype)
 

@@ -186,6 +186,116 @@ def gen_multicam(ref_om, seed=15, steps=8):
                 explored_bits=packbits(om.explored_area))
 
 
+def island_script(seed: int = 17):
+    """Depth frames whose zero regions ENCLOSE valid texels inside the obstacle height band ("islands" below the image
+    centre, where a wall 1.5-3 m away sits 0-0.27 m under the camera): fill_small_holes draws each small contour FILLED
+    (img_utils.py:385), so the enclosed valid texels become 1.0 and are dropped as well.  Steps: plain frame; the same
+    pose with a small ring (its island cells were already set by the plain frame and must stay); new poses with a small
+    ring, a ring whose outer contour is too large to fill but whose inner (hole) contour is not, two nested rings, and a
+    ring cut by the image border.  Shared by the generator and the replaying tests."""
+    from vlfm_amd.synthetic import depth_frame, pose_to_tf
+
+    rng = np.random.Generator(np.random.PCG64(seed))
+    yy, xx = np.mgrid[0:480, 0:640]
+
+    def ring(d, cx, cy, r_out, r_in):
+        rr = (xx - cx) ** 2 + (yy - cy) ** 2
+        d[(rr <= r_out ** 2) & (rr > r_in ** 2)] = 0.0
+
+    def wall(z):  # flat wall z metres away + floor, so that rows 240..~290 are inside the 0.61-0.88 m band
+        d = depth_frame(rng, 480, 640)
+        rows = np.arange(480)[:, None] - 240
+        floor = np.where(rows > 0, 0.88 * camera_intrinsics(640)[1] / np.maximum(rows, 1e-9), np.inf)
+        return np.clip((np.minimum(z, floor) - MIN_DEPTH) / (MAX_DEPTH - MIN_DEPTH), 1e-3, 1.0).astype(np.float32) \
+            + 0 * d
+
+    frames = []
+    d0 = wall(2.0)
+    frames.append((d0.copy(), pose_to_tf(0.0, 0.0, 0.0)))
+    d1 = d0.copy(); ring(d1, 320, 262, 30, 14)
+    frames.append((d1, pose_to_tf(0.0, 0.0, 0.0)))
+    d2 = wall(2.5); ring(d2, 200, 265, 36, 20); ring(d2, 470, 258, 22, 9)
+    frames.append((d2, pose_to_tf(0.3, -0.2, 0.6)))
+    d3 = wall(1.8); ring(d3, 320, 250, 215, 150)          # outer area > 100000 px: only the inner contour is filled
+    frames.append((d3, pose_to_tf(-0.4, 0.5, -1.1)))
+    d4 = wall(2.2); ring(d4, 300, 270, 60, 48); ring(d4, 300, 270, 30, 12)   # nested: island ring holds a second ring
+    frames.append((d4, pose_to_tf(1.0, 1.0, 2.4)))
+    d5 = wall(2.0); ring(d5, 5, 262, 40, 22); d5[300:330, 100:160] = 0.0     # ring cut by the border + a plain hole
+    frames.append((d5, pose_to_tf(-1.0, -1.5, 3.0)))
+    frames.append((wall(3.0), pose_to_tf(-1.0, -1.5, 3.0)))                  # a clean frame after island frames
+    return frames
+
+
+def gen_islands(ref_om):
+    fx, fy, fov = camera_intrinsics(640)
+    om = ref_om.ObstacleMap(hole_area_thresh=100000, **OBSTACLE_KW)
+    hashes, fr_xy, per_step = [], [], []
+    for depth, tf in island_script():
+        hashes.append(sha(depth))
+        om.update_map(depth.copy(), tf, MIN_DEPTH, MAX_DEPTH, fx, fy, fov)
+        fr_xy.append(np.asarray(om.frontiers, np.float64).reshape(-1, 2))
+        per_step.append(packbits(om._map))
+    counts, cat = frontier_blob(fr_xy)
+    return dict(depth_sha256=np.array(hashes), frontier_counts=counts, frontiers_xy=cat,
+                obstacle_bits_per_step=np.stack(per_step), navigable_bits=packbits(om._navigable_map),
+                explored_bits=packbits(om.explored_area))
+
+
+EP500_SNAPSHOTS = (100, 250, 500)
+
+
+def quantize16(a: np.ndarray) -> np.ndarray:
+    """[0, 1] floats -> u16 with step 1/65535 (|error| <= 7.7e-6): keeps the 500-step snapshots small; the exact arrays are
+    pinned by SHA-256 digests next to them."""
+    return np.rint(np.clip(np.asarray(a, np.float64), 0.0, 1.0) * 65535.0).astype(np.uint16)
+
+
+def gen_episode500(ref_vm, ref_om):
+    """One full-length episode (500 steps, pointnav_depth_hm3d.yaml:14) through THE REFERENCE'S ObstacleMap + ValueMap in
+    the rooms-and-pillars world of world500.py: 13-22 simultaneous frontiers for most of the run, free-standing pillars
+    and non-convex blocks inside the view cone, an explored area that closes around obstacles.  Per step: frontier
+    pixels (bit-exact bar) and sort_waypoints values; at steps 100 / 250 / 500: all five planes."""
+    import world500 as w5
+
+    fx, fy, fov = camera_intrinsics(w5.W)
+    om = ref_om.ObstacleMap(**OBSTACLE_KW)
+    vm = ref_vm.ValueMap(1, use_max_confidence=False)
+    actions = w5.plan_actions()
+    digests, fr_px, sorted_vals, sorted_idx = [], [], [], []
+    out = dict(actions=actions, snapshots=np.array(EP500_SNAPSHOTS, np.int32))
+    for i, depth, tf, values in w5.episode(actions):
+        digests.append(np.frombuffer(hashlib.sha256(depth.tobytes()).digest()[:8], np.uint64)[0])
+        om.update_map(depth.copy(), tf, MIN_DEPTH, MAX_DEPTH, fx, fy, fov)
+        vm.update_map(values, depth.copy(), tf, MIN_DEPTH, MAX_DEPTH, fov)
+        px = np.asarray(om._frontiers_px, np.float64).reshape(-1, 2)
+        fr_px.append(px)
+        if len(px):
+            s_wp, s_val = vm.sort_waypoints(om.frontiers, 0.5)
+            # the permutation sort_waypoints applied, recovered by matching rows (frontiers of one step are distinct)
+            idx = [int(np.flatnonzero((om.frontiers == p).all(axis=1))[0]) for p in np.asarray(s_wp)]
+            sorted_idx.append(np.array(idx, np.int16))
+            sorted_vals.append(np.asarray(s_val, np.float64))
+        step = i + 1
+        if step in EP500_SNAPSHOTS:
+            conf = np.asarray(vm._map, np.float32)
+            val = np.asarray(vm._value_map, np.float64)[:, :, 0]
+            support = conf > 0
+            assert not np.any(val[~support])
+            out[f"s{step}_support"] = packbits(support)
+            out[f"s{step}_conf_q"] = quantize16(conf[support])
+            out[f"s{step}_value_q"] = quantize16(val[support])
+            out[f"s{step}_conf_sha"] = np.array(sha(conf))
+            out[f"s{step}_value_sha"] = np.array(sha(val))
+            out[f"s{step}_obstacle"] = packbits(om._map)
+            out[f"s{step}_navigable"] = packbits(om._navigable_map)
+            out[f"s{step}_explored"] = packbits(om.explored_area)
+    counts, cat = frontier_blob(fr_px)
+    out.update(depth_digest=np.array(digests, np.uint64), frontier_counts=counts, frontiers_px=cat,
+               sorted_idx=np.concatenate(sorted_idx), sorted_values=np.concatenate(sorted_vals),
+               value_dtype=str(vm._value_map.dtype), **OBSTACLE_KW)
+    return out
+
+
 def gen_sync(ref_vm, ref_om, seed, steps):
     """reality-style ValueMap(obstacle_map=...) (value_map.py:369-375): full-map zeroing by the explored area."""
     fx, fy, fov = camera_intrinsics(640)
@@ -535,9 +645,22 @@ def gen_pointnav():
                 state_dict_shapes=np.array([str(tuple(policy.state_dict()[k].shape)) for k in keys]))
 
 
-def generate():
+def _ep500_worker():
     from oracle import ref_shim
 
+    ref_vm, ref_om, _, _ = ref_shim.reference_modules()
+    return gen_episode500(ref_vm, ref_om)
+
+
+def generate():
+    from concurrent.futures import ProcessPoolExecutor
+    import multiprocessing
+
+    from oracle import ref_shim
+
+    # the 500-step episode takes about a minute of the reference's full-map NumPy passes: its own process, beside the rest
+    pool = ProcessPoolExecutor(1, mp_context=multiprocessing.get_context("spawn"))
+    ep500 = pool.submit(_ep500_worker)
     ref_vm, ref_om, geo, img = ref_shim.reference_modules()
     out = {}
     for name, args in VM_CASES.items():
@@ -546,6 +669,7 @@ def generate():
         out[name] = gen_obstacle_map(ref_om, *args)
     out[SYNC_CASE[0]] = gen_sync(ref_vm, ref_om, SYNC_CASE[1], SYNC_CASE[2])
     out["om_multicam"] = gen_multicam(ref_om)
+    out["om_islands"] = gen_islands(ref_om)
     out["vm_two_cameras"] = gen_two_cameras(ref_vm)
     out["helpers"] = gen_helpers(geo, img, ref_vm)
     out["detections"] = gen_detections(ref_shim.reference_detections())
@@ -556,6 +680,8 @@ def generate():
         out[name] = gen_policy(name)
     out["api_signatures"] = gen_api()
     out["pointnav"] = gen_pointnav()
+    out["ep500"] = ep500.result()
+    pool.shutdown()
     return out
 
 

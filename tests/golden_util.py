@@ -130,6 +130,98 @@ def replay_multicam(make_map):
     assert np.array_equal(np.asarray(om.explored_area).astype(bool), unpack_plane(g["explored_bits"]))
 
 
+def replay_islands(make_map):
+    """Obstacle map over make_golden.island_script(): valid texels enclosed by small depth holes are dropped together with
+    the hole (fill_small_holes draws the contour filled); per-step obstacle planes, frontiers and final planes bit-exact."""
+    import sys
+
+    if GOLDEN_DIR not in sys.path:
+        sys.path.insert(0, GOLDEN_DIR)
+    import make_golden as mg
+    from vlfm_amd.synthetic import MAX_DEPTH, MIN_DEPTH, camera_intrinsics
+
+    g = load("om_islands")
+    fx, fy, fov = camera_intrinsics(640)
+    om = make_map(hole_area_thresh=100000, **mg.OBSTACLE_KW)
+    offs = np.concatenate([[0], np.cumsum(g["frontier_counts"])])
+    for k, (depth, tf) in enumerate(mg.island_script()):
+        assert sha(depth) == str(g["depth_sha256"][k]), "synthetic depth differs from the fixture's input"
+        om.update_map(depth, tf, MIN_DEPTH, MAX_DEPTH, fx, fy, fov)
+        assert np.array_equal(np.asarray(om._map).astype(bool), unpack_plane(g["obstacle_bits_per_step"][k])), f"step {k}"
+        got = np.asarray(om.frontiers, np.float64).reshape(-1, 2)
+        assert np.array_equal(got, g["frontiers_xy"][offs[k]:offs[k + 1]]), f"step {k}"
+    assert np.array_equal(np.asarray(om._navigable_map).astype(bool), unpack_plane(g["navigable_bits"]))
+    assert np.array_equal(np.asarray(om.explored_area).astype(bool), unpack_plane(g["explored_bits"]))
+
+
+def replay_episode500(make_om, make_vm, exact: bool, tol: float = 1e-4, steps: int = 500, on_step=None):
+    """The full-length episode of tests/golden/world500.py against what THE REFERENCE'S ObstacleMap + ValueMap produced
+    (tests/golden/ep500.npz).  Every step: frontier pixels and world coordinates bit-exact, sort_waypoints values (exact
+    for the oracle, within ``tol`` for the HIP path, same order up to values closer than the tolerance).  Steps 100 /
+    250 / 500: obstacle / navigable / explored planes bit-exact, confidence / value maps exact (digests) or within
+    ``tol`` with identical support."""
+    import sys
+
+    if GOLDEN_DIR not in sys.path:
+        sys.path.insert(0, GOLDEN_DIR)
+    import make_golden as mg
+    import world500 as w5
+    from vlfm_amd.synthetic import MAX_DEPTH, MIN_DEPTH, camera_intrinsics
+
+    g = load("ep500")
+    fx, fy, fov = camera_intrinsics(w5.W)
+    om = make_om(**mg.OBSTACLE_KW)
+    vm = make_vm(1, use_max_confidence=False)
+    offs = np.concatenate([[0], np.cumsum(g["frontier_counts"])])
+    qstep = 0.5 / 65535.0   # the snapshots are quantised to u16: |q(ref) - ref| <= qstep
+    worst = 0.0
+    for i, depth, tf, values in w5.episode(g["actions"][:steps]):
+        digest = np.frombuffer(hashlib.sha256(depth.tobytes()).digest()[:8], np.uint64)[0]
+        assert digest == g["depth_digest"][i], "regenerated depth frame differs from the fixture's input"
+        om.update_map(depth, tf, MIN_DEPTH, MAX_DEPTH, fx, fy, fov)
+        vm.update_map(values, depth, tf, MIN_DEPTH, MAX_DEPTH, fov)
+        want_px = g["frontiers_px"][offs[i]:offs[i + 1]]
+        got_px = np.asarray(om._frontiers_px, np.float64).reshape(-1, 2)
+        assert np.array_equal(got_px, want_px), f"frontier pixels differ at step {i}"
+        if len(want_px):
+            want_xy = np.asarray(om.frontiers, np.float64).reshape(-1, 2)
+            q = want_px.copy()
+            q[:, 0] = 1000 - q[:, 0]
+            assert np.array_equal(want_xy, ((q - 500) / 20)[:, ::-1]), f"step {i}"  # base_map.py:48-60
+            s_wp, s_val = vm.sort_waypoints(om.frontiers, 0.5)
+            ref_val = g["sorted_values"][offs[i]:offs[i + 1]]
+            ref_wp = want_xy[g["sorted_idx"][offs[i]:offs[i + 1]]]
+            s_wp, s_val = np.asarray(s_wp), np.asarray(s_val, np.float64)
+            if exact:
+                assert np.array_equal(s_val, ref_val) and np.array_equal(s_wp, ref_wp), f"step {i}"
+            else:
+                assert np.abs(s_val - ref_val).max() <= tol, f"sort_waypoints values at step {i}"
+                worst = max(worst, float(np.abs(s_val - ref_val).max()))
+                for r in np.flatnonzero((s_wp != ref_wp).any(axis=1)):   # same order up to near-ties
+                    j = int(np.flatnonzero((ref_wp == s_wp[r]).all(axis=1))[0])
+                    assert abs(ref_val[j] - ref_val[r]) <= 2 * tol, f"sort order differs at step {i}"
+        if on_step is not None:
+            on_step(i, om, vm)
+        step = i + 1
+        if step in g["snapshots"]:
+            for name, plane in (("obstacle", om._map), ("navigable", om._navigable_map), ("explored", om.explored_area)):
+                assert np.array_equal(np.asarray(plane).astype(bool), unpack_plane(g[f"s{step}_{name}"])), \
+                    f"{name} plane at step {step}"
+            conf = np.asarray(vm._map, np.float32)
+            val = np.asarray(vm._value_map, np.float64).reshape(1000, 1000)
+            if exact:
+                assert sha(conf) == str(g[f"s{step}_conf_sha"]) and sha(val) == str(g[f"s{step}_value_sha"]), step
+            else:
+                support = unpack_plane(g[f"s{step}_support"])
+                assert np.array_equal(conf > 0, support), f"confidence support at step {step}"
+                assert not np.any(val[~support])
+                ec = np.abs(conf[support] - g[f"s{step}_conf_q"] / 65535.0).max()
+                ev = np.abs(val[support] - g[f"s{step}_value_q"] / 65535.0).max()
+                assert ec <= tol - qstep and ev <= tol - qstep, (step, ec, ev)
+                worst = max(worst, float(ec), float(ev))
+    return worst
+
+
 def replay_two_cameras(make_map, exact: bool, tol: float = 1e-4):
     """One value map fed by two cameras with different (fov, max_depth) per step (make_golden.two_camera_script)."""
     import sys

@@ -78,6 +78,27 @@ def test_multicamera_obstacle_map_matches_reference_fixture(gpu_device):
     replay_multicam(lambda **kw: ObstacleMap(device=gpu_device, **kw))
 
 
+def test_depth_islands_inside_small_holes_match_reference_fixture(gpu_device):
+    """fill_small_holes draws each small zero-region contour FILLED, so valid texels it encloses are dropped too
+    (img_utils.py:385-388): the speculative single depth pass has to take their obstacle bits back."""
+    from golden_util import replay_islands
+    from vlfm_amd.mapping import ObstacleMap
+
+    replay_islands(lambda **kw: ObstacleMap(device=gpu_device, **kw))
+
+
+def test_500_step_episode_matches_reference_fixture(gpu_device):
+    """BASELINE's own episode length (500 steps): frontier pixels bit-exact at every step (13-22 simultaneous frontiers),
+    planes bit-exact and float maps within 1e-4 at steps 100 / 250 / 500 -- f32 maps on the device against the
+    reference's f64-promoted value map over the whole episode."""
+    from golden_util import replay_episode500
+    from vlfm_amd.mapping import ObstacleMap, ValueMap
+
+    worst = replay_episode500(lambda **kw: ObstacleMap(device=gpu_device, **kw),
+                              lambda c, **kw: ValueMap(c, device=gpu_device, **kw), exact=False, tol=TOL)
+    print(f"ep500: max abs deviation of conf / value / waypoint values over the episode = {worst:.3e}")
+
+
 def test_two_camera_value_map_matches_reference_fixture(gpu_device):
     """Two cameras with different (fov, max_depth) feeding one value map: one cone template per optics, like the
     reference's per-(fov, max_depth) confidence-mask cache."""

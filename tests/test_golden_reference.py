@@ -124,3 +124,20 @@ def test_oracle_matches_two_camera_value_map_fixture():
     from oracle.ref_value_map import RefValueMap
 
     replay_two_cameras(lambda c, **kw: RefValueMap(c, **kw), exact=True)
+
+
+def test_oracle_matches_depth_island_fixture():
+    from golden_util import replay_islands
+    from oracle.ref_obstacle_map import RefObstacleMap
+
+    replay_islands(lambda **kw: RefObstacleMap(**kw))
+
+
+def test_oracle_reproduces_the_500_step_episode_fixture():
+    """Full episode length of the reference (pointnav_depth_hm3d.yaml:14): 13-22 simultaneous frontiers, pillars and
+    non-convex blocks in the cone; every step bit-exact, maps at steps 100 / 250 / 500 by digest."""
+    from golden_util import replay_episode500
+    from oracle.ref_obstacle_map import RefObstacleMap
+    from oracle.ref_value_map import RefValueMap
+
+    replay_episode500(lambda **kw: RefObstacleMap(**kw), lambda c, **kw: RefValueMap(c, **kw), exact=True)

@@ -46,21 +46,45 @@ class FogParams(ctypes.Structure):
                 ("rot_s", ctypes.c_double), ("line_len", ctypes.c_double), ("poly", ctypes.c_longlong * (2 * FOG_MAX_POLY))]
 
 
+class ScatterJournal(ctypes.Structure):
+    _fields_ = [("d_cells", ctypes.c_void_p), ("d_count", ctypes.c_void_p), ("capacity", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
+assert ctypes.sizeof(ScatterJournal) == 24
 assert ctypes.sizeof(VmPose) == 64 and ctypes.sizeof(IngestParams) == 152 and ctypes.sizeof(FogParams) == 48 + 16 * FOG_MAX_POLY
 
 
 def build(verbose: bool = False) -> str:
-    """Compile every HIP/C++ source under vlfm_amd/csrc for gfx950 into vlfm_amd/libvlfm_amd.so (in-tree)."""
+    """Compile every HIP/C++ source under vlfm_amd/csrc for gfx950 into vlfm_amd/libvlfm_amd.so (in-tree).  One object
+    per source (rebuilt only when the source or a header changed, compiled in parallel), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
+
     csrc = os.path.join(_HERE, "csrc")
     srcs = [os.path.join(csrc, s) for s in SOURCES if os.path.exists(os.path.join(csrc, s))]
-    deps = srcs + [os.path.join(csrc, h) for h in os.listdir(csrc) if h.endswith(".h")] + [
+    hdrs = [os.path.join(csrc, h) for h in os.listdir(csrc) if h.endswith(".h")] + [
         os.path.join(_HERE, "..", "include", "vlfm_amd.h")]
-    if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+    hdr_time = max(os.path.getmtime(h) for h in hdrs)
+    objdir = os.path.join(csrc, "build")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        if not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            cmd = ["hipcc"] + flags + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as pool:
+        objs = list(pool.map(compile_one, srcs))
+    if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(o) for o in objs):
         return LIB_PATH
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-o", LIB_PATH] + srcs
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     return LIB_PATH
 
@@ -86,11 +110,12 @@ def lib() -> ctypes.CDLL:
         L.vlfm_tan_table_host.argtypes = [cd, ci, vp]
         L.vlfm_disc_rows_host.argtypes = [ci, vp]
         L.vlfm_cone_template_build.argtypes = [vp, vp, ci, ci, vp, vp, vp]
-        L.vlfm_depth_ingest_batched.argtypes = [vp, ci, ci, ci, vp, vp, vp, ci, ci, vp, vp, vp, vp]
+        L.vlfm_depth_ingest_batched.argtypes = [vp, ci, ci, ci, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp]
         L.vlfm_hole_scratch_bytes.argtypes = [ci, ci, ci, ci, ci]
         L.vlfm_hole_scratch_bytes.restype = ctypes.c_size_t
-        L.vlfm_fill_small_holes_batched.argtypes = [vp, vp, ci, ci, ci, cd, vp, ctypes.c_size_t, ci, ci, vp, vp, vp]
-        L.vlfm_depth_scatter_holes_batched.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp, ci, ci, vp, vp]
+        L.vlfm_fill_small_holes_batched.argtypes = [vp, vp, ci, ci, ci, cd, vp, ctypes.c_size_t, ci, ci, vp, vp, vp, vp,
+                                                    ci, vp, vp]
+        L.vlfm_depth_scatter_holes_batched.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp, ci, ci, vp, vp, vp]
         L.vlfm_layernorm_bias_f16.argtypes = [vp, vp, vp, vp, vp, ci, ci, ctypes.c_float, vp]
         L.vlfm_vit_attention_f16.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.c_float, vp]
         L.vlfm_value_map_scratch_bytes.argtypes = [ci, ci]

@@ -33,9 +33,15 @@ struct HoleArgs {
     int2* pts;               // [n][cap_pts]
     int* starts;             // [n][cap_contours]
     int* lens;               // [n][cap_contours]
-    int* counts;             // [n][4]: contours, filled contours, overflow, filled-plane-dirty
+    int* counts;             // [n][4]: contours, filled contours, overflow, bit 0 image had zeros | bit 1 island frame
     int H, W, hw, cap_pts, cap_contours;
     double area_thresh;
+    // undo journal of the speculative scatter pass (depth_ingest.hip), or null
+    const vlfm_ingest_params* prm;  // [n] (env slot of each observation)
+    unsigned* obstacle;             // [n_envs][S][stride]
+    unsigned* journal;              // [n][journal_cap]
+    int* journal_count;             // [n]
+    int journal_cap, S, stride;
 };
 
 __global__ __launch_bounds__(256) void fill_small_holes_kernel(HoleArgs a) {
@@ -52,7 +58,10 @@ __global__ __launch_bounds__(256) void fill_small_holes_kernel(HoleArgs a) {
             for (int i = tid; i < plane_words; i += nth) filled[i] = 0u;
         }
         __syncthreads();
-        if (tid == 0) { counts[0] = 0; counts[1] = 0; counts[2] = 0; counts[3] = 0; }
+        if (tid == 0) {
+            counts[0] = 0; counts[1] = 0; counts[2] = 0; counts[3] = 0;
+            if (a.journal_count) a.journal_count[obs] = 0;  // nothing to take back: the speculative pass stands
+        }
         return;
     }
     unsigned* traced = a.traced + poff;
@@ -134,10 +143,38 @@ __global__ __launch_bounds__(256) void fill_small_holes_kernel(HoleArgs a) {
             for (int y = tid; y < a.H; y += nth) filled[y * a.hw + a.hw - 1] &= tail;
         }
     }
+    __threadfence();
+    __syncthreads();
+    // Valid texels inside a filled contour ("islands")?  The reference's drawContours(.., -1) covers them, so they become
+    // 1.0 and are dropped (img_utils.py:385-388), but the speculative pass has already placed them.  Take back every
+    // obstacle bit that pass was the first to set (its journal); hole_scatter_kernel then re-places the valid texels
+    // outside the filled area from the image.  (Bits that were set before this step are not in the journal and stay.)
+    int island = 0, joverflow = 0;
+    if (a.journal && !overflow) {
+        const unsigned* holes = a.holes + poff;
+        int any = 0;
+        for (int i = tid; i < plane_words; i += nth) any |= (filled[i] & ~holes[i]) != 0u;
+        island = __syncthreads_or(any);
+        if (island) {
+            const int nj_raw = a.journal_count[obs];
+            joverflow = nj_raw > a.journal_cap;
+            const int nj = min(nj_raw, a.journal_cap);
+            unsigned* grid = a.obstacle + (size_t)a.prm[obs].env * a.S * a.stride;
+            const unsigned* jr = a.journal + (size_t)obs * a.journal_cap;
+            for (int i = tid; i < nj; i += nth) {
+                const unsigned cell = jr[i];
+                const unsigned row = cell / (unsigned)a.S, col = cell % (unsigned)a.S;
+                atomicAnd(&grid[(size_t)row * a.stride + (col >> 5)], ~(1u << (col & 31)));
+            }
+            __threadfence();
+        }
+    }
     __syncthreads();
     if (tid == 0) {
-        counts[0] = n_contours; counts[1] = n_filled; counts[2] = overflow; counts[3] = 1;
+        counts[0] = n_contours; counts[1] = n_filled; counts[2] = overflow | (joverflow ? 2 : 0);
+        counts[3] = 1 | (island ? 2 : 0);
         a.status[2 * obs + 1] = 0;  // consumed
+        if (a.journal_count) a.journal_count[obs] = 0;
     }
 }
 
@@ -168,7 +205,8 @@ extern "C" size_t vlfm_hole_scratch_bytes(int n, int height, int width, int cap_
 extern "C" int vlfm_fill_small_holes_batched(const uint32_t* d_hole_bits, const int32_t* d_status, int n, int height,
                                              int width, double area_thresh, void* d_scratch, size_t scratch_bytes,
                                              int cap_pts, int cap_contours, uint32_t* d_filled_bits, int32_t* d_counts,
-                                             void* stream) {
+                                             const vlfm_ingest_params* d_params, uint32_t* d_obstacle, int map_size,
+                                             const vlfm_scatter_journal* journal, void* stream) {
     if (n == 0) return VLFM_OK;
     if (!d_hole_bits || !d_status || !d_scratch || !d_filled_bits || !d_counts || n < 0 || height <= 0 || width <= 0 ||
         width > 2048 || cap_pts <= 0 || cap_contours <= 0)
@@ -185,6 +223,14 @@ extern "C" int vlfm_fill_small_holes_batched(const uint32_t* d_hole_bits, const 
     a.counts = d_counts;
     a.H = height; a.W = width; a.hw = (width + 31) / 32; a.cap_pts = cap_pts; a.cap_contours = cap_contours;
     a.area_thresh = area_thresh;
+    a.prm = nullptr; a.obstacle = nullptr; a.journal = nullptr; a.journal_count = nullptr; a.journal_cap = 0;
+    a.S = map_size; a.stride = (map_size + 31) / 32;
+    if (journal && journal->d_cells && journal->d_count && journal->capacity > 0) {
+        if (!d_params || !d_obstacle || map_size <= 0)
+            return fail(VLFM_ERR_INVALID, "fill_small_holes_batched: a journal needs d_params, d_obstacle and map_size");
+        a.prm = d_params; a.obstacle = d_obstacle;
+        a.journal = journal->d_cells; a.journal_count = journal->d_count; a.journal_cap = journal->capacity;
+    }
     VLFM_TIMED("fill_small_holes_kernel", stream);
     VLFM_KLAUNCH(fill_small_holes_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("fill_small_holes_kernel");

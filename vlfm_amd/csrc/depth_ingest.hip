@@ -46,6 +46,9 @@ struct IngestArgs {
     unsigned* hole_bits;            // [n][H][hw] OUT: bit plane of (depth == 0), or null
     const unsigned* filled_bits;    // [n][H][hw] IN: fill_small_holes' result (texel -> 1.0), or null
     int hw;                         // words per image row in hole/filled planes = ceil(W/32)
+    unsigned* journal;              // [n][journal_cap] cell ids (row * S + col) of obstacle bits NEWLY set by this pass, or null
+    int* journal_count;             // [n]
+    int journal_cap;
     int H, W, W4, S, stride;
     int cols_per_block;             // float4 column groups handled by one workgroup in x
     int ry;                         // rows advanced per iteration (= blockDim.x / cols_per_block)
@@ -142,7 +145,17 @@ __device__ inline void scatter_point(const IngestArgs& a, const vlfm_ingest_para
     // us skip the device-scope atomic: in steady state almost every in-band point re-observes a known obstacle cell.
     unsigned* word = &grid[(size_t)row * a.stride + (col >> 5)];
     const unsigned bit = 1u << (col & 31);
-    if (!(*word & bit)) atomicOr(word, bit);
+    if (!(*word & bit)) {
+        const unsigned old = atomicOr(word, bit);
+        // Speculative single pass (fill_small_holes not evaluated yet): remember every bit this pass is the first to set.
+        // If the image turns out to hold valid texels INSIDE a filled hole contour ("islands": the reference rewrites
+        // them to 1.0 -> dropped, img_utils.py:385-388), fill_small_holes_kernel takes exactly these bits back and
+        // hole_scatter_kernel re-places the texels that survive.
+        if (!HOLE_PASS && a.journal && !(old & bit)) {
+            const int k = atomicAdd(&a.journal_count[obs], 1);
+            if (k < a.journal_cap) a.journal[(size_t)obs * a.journal_cap + k] = (unsigned)(row * a.S + col);
+        }
+    }
 }
 
 // Work decomposition: a workgroup owns CG float4 column groups (CG*4 image columns, CG*16 contiguous bytes per row) and
@@ -253,15 +266,30 @@ __global__ __launch_bounds__(256) void hole_scatter_kernel(IngestArgs a, const i
     if (i >= a.H * a.hw) return;
     const vlfm_ingest_params p = a.prm[obs];
     if (!(p.scatter & 1) || (p.scatter & 2)) return;
-    unsigned w = a.hole_bits[(size_t)obs * a.H * a.hw + i] & ~a.filled_bits[(size_t)obs * a.H * a.hw + i];
-    if (!w) return;
-    const HeightBand band = make_band(p, a.W, a.H);
-    unsigned* grid = a.obstacle + (size_t)p.env * a.S * a.stride;
+    const unsigned hole = a.hole_bits[(size_t)obs * a.H * a.hw + i], filled = a.filled_bits[(size_t)obs * a.H * a.hw + i];
+    unsigned w = hole & ~filled;
     const int v = i / a.hw, u0 = (i % a.hw) * 32;
+    const HeightBand band = make_band(p, a.W, a.H);
+    // Island frame (counts[3] bit 1): the speculative pass placed valid texels that lie inside a filled hole contour;
+    // its newly set bits were taken back by fill_small_holes_kernel, so every valid texel OUTSIDE the filled area is
+    // placed again here, from the image (rows that cannot reach the height band are skipped).
+    unsigned redo = 0u;
+    if ((counts[(size_t)obs * 4 + 3] & 2) && a.depth && row_may_hit(band, v, a.H)) {
+        redo = ~hole & ~filled;
+        if (u0 + 32 > a.W) redo &= (a.W - u0 >= 32) ? 0xFFFFFFFFu : ((1u << (a.W - u0)) - 1u);
+    }
+    if (!(w | redo)) return;
+    unsigned* grid = a.obstacle + (size_t)p.env * a.S * a.stride;
     while (w) {
         const int b = __builtin_ctz(w);
         w &= w - 1u;
         if (u0 + b < a.W) scatter_point<true>(a, p, band, grid, obs, u0 + b, v, 0.0f, false);
+    }
+    const float* row = a.depth ? a.depth + ((size_t)obs * a.H + v) * a.W + u0 : nullptr;
+    while (redo) {
+        const int b = __builtin_ctz(redo);
+        redo &= redo - 1u;
+        scatter_point<true>(a, p, band, grid, obs, u0 + b, v, row[b], false);
     }
 }
 
@@ -272,13 +300,14 @@ using namespace vlfm;
 extern "C" int vlfm_depth_scatter_holes_batched(const vlfm_ingest_params* d_params, int n, int height, int width,
                                                 const uint32_t* d_hole_bits, const uint32_t* d_filled_bits,
                                                 const int32_t* d_hole_counts, uint32_t* d_obstacle, int map_size,
-                                                int pixels_per_meter, int32_t* d_status, void* stream) {
+                                                int pixels_per_meter, int32_t* d_status, const float* d_depth,
+                                                void* stream) {
     if (n == 0) return VLFM_OK;
     if (!d_params || !d_hole_bits || !d_filled_bits || !d_hole_counts || !d_obstacle || !d_status || n < 0 ||
         height <= 0 || width <= 0)
         return fail(VLFM_ERR_INVALID, "depth_scatter_holes_batched: bad argument");
     IngestArgs a{};
-    a.prm = d_params; a.obstacle = d_obstacle; a.status = d_status;
+    a.prm = d_params; a.obstacle = d_obstacle; a.status = d_status; a.depth = d_depth;
     a.hole_bits = const_cast<uint32_t*>(d_hole_bits); a.filled_bits = d_filled_bits; a.hw = (width + 31) / 32;
     a.H = height; a.W = width; a.W4 = width / 4; a.S = map_size; a.stride = (map_size + 31) / 32;
     a.ppm = (double)pixels_per_meter;
@@ -291,7 +320,8 @@ extern "C" int vlfm_depth_scatter_holes_batched(const vlfm_ingest_params* d_para
 extern "C" int vlfm_depth_ingest_batched(const float* d_depth, int n, int height, int width,
                                          const vlfm_ingest_params* d_params, uint32_t* d_colmax_keys, uint32_t* d_obstacle,
                                          int map_size, int pixels_per_meter, int32_t* d_status, uint32_t* d_hole_bits,
-                                         const uint32_t* d_filled_bits, void* stream) {
+                                         const uint32_t* d_filled_bits, const vlfm_scatter_journal* journal,
+                                         void* stream) {
     if (n == 0) return VLFM_OK;
     if (!d_depth || !d_params || !d_status || n < 0 || height <= 0 || width <= 0)
         return fail(VLFM_ERR_INVALID, "depth_ingest_batched: bad argument");
@@ -302,6 +332,10 @@ extern "C" int vlfm_depth_ingest_batched(const float* d_depth, int n, int height
     a.depth = d_depth; a.prm = d_params; a.colmax_keys = reinterpret_cast<unsigned*>(d_colmax_keys);
     a.obstacle = d_obstacle; a.status = d_status;
     a.hole_bits = d_hole_bits; a.filled_bits = d_filled_bits; a.hw = (width + 31) / 32;
+    a.journal = nullptr; a.journal_count = nullptr; a.journal_cap = 0;
+    if (journal && journal->d_cells && journal->d_count && journal->capacity > 0) {
+        a.journal = journal->d_cells; a.journal_count = journal->d_count; a.journal_cap = journal->capacity;
+    }
     a.H = height; a.W = width; a.W4 = width / 4; a.S = map_size; a.stride = (map_size + 31) / 32;
     a.ppm = (double)pixels_per_meter;
     a.cols_per_block = CG; a.ry = RL;

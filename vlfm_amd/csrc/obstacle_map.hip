@@ -752,6 +752,8 @@ struct FrontierScratch {
     int cap_pts, cap_contours, cap_frontiers;
     double area_thresh;
     unsigned lds_bytes;  // dynamic LDS available for the window copy of the border walk
+    int* fog_status;        // [n_envs][4] of fog_of_war_kernel: word 0 = contour scratch overflow (sticky; consumed here)
+    const int* sel_status;  // [n_envs][4] of explored_select_kernel: word 0 = contour scratch overflow
 };
 
 __device__ inline unsigned ring_all_set(const unsigned* plane, int S, int stride, int tid, int nth) {
@@ -1067,7 +1069,13 @@ __global__ __launch_bounds__(256) void frontier_kernel(const FogParams* __restri
     VLFM_PHASE(2, 5);
     if (tid == 0) {
         out_n[0] = np < sc.cap_frontiers ? np : sc.cap_frontiers;
-        out_n[1] = sh_i[9] || np > sc.cap_frontiers;
+        // one flag for the whole explore pipeline of this environment: a capacity overflow in the fog-of-war or the
+        // component-selection kernel leaves the explored area short of the reference's, so it must surface on the same
+        // read-back path as this kernel's own overflow (ObstacleMapBatch._read_frontiers raises)
+        int* fog_st = sc.fog_status + (size_t)P.env * 4;
+        const int upstream = fog_st[0] | sc.sel_status[(size_t)P.env * 4];
+        fog_st[0] = 0;
+        out_n[1] = sh_i[9] || np > sc.cap_frontiers || upstream != 0;
         out_n[2] = nc; out_n[3] = npts_all;
     }
 }
@@ -1215,7 +1223,8 @@ extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, in
     {
         FrontierScratch fr{planes[4], planes[5], planes[0], planes[1], planes[2], planes[3], pts, starts, lens,
                            (unsigned char*)(base + L.off_bad), (int*)(base + L.off_pieces), d_frontiers, d_counts,
-                           cap_pts, cap_contours, cap_frontiers, area_thresh_px, kWalkLdsBytes};
+                           cap_pts, cap_contours, cap_frontiers, area_thresh_px, kWalkLdsBytes, status,
+                           status + (size_t)n_envs * 4};
         {
             VLFM_TIMED("frontier_prepare_kernel", s);
             VLFM_KLAUNCH(frontier_prepare_kernel, dim3((map_size * stride + 255) / 256, 1, n), dim3(256), 0, s, d_prm, mp,

@@ -121,6 +121,9 @@ class ObstacleMapBatch:
         fill = update_obstacles and self._hole_area_thresh != -1
         if fill:
             prm["scatter"] |= 4  # zero texels wait for fill_small_holes
+            # the speculative pass journals the bits it sets per observation; two observations of one slot in the same
+            # launch would hide each other's first-time bits (the reference's multi-camera loop is sequential anyway)
+            assert len(np.unique(prm["env"])) == n, "one observation per environment slot and call"
         with torch.cuda.device(self.device):
             d_prm = self._ring_ingest.upload(prm)
             if not fill:
@@ -130,35 +133,43 @@ class ObstacleMapBatch:
                                                        keys.data_ptr() if keys is not None else None,
                                                        self.obstacle_bits.data_ptr() if update_obstacles else None,
                                                        self.size, self.pixels_per_meter, self.status.data_ptr(),
-                                                       None, None, _stream_ptr()), "depth_ingest")
+                                                       None, None, None, _stream_ptr()), "depth_ingest")
             else:
                 # fill_small_holes (img_utils.py:361-390) sits between reading the depth and scattering it, but it only
-                # decides the fate of ZERO texels: the single streaming pass places every non-zero texel (scatter bit
-                # 2), reduces the column maxima and emits the (depth == 0) bit plane + "has zeros" flag; the hole
-                # kernel exits immediately for images without zeros; the zeros that survive it (large holes keep depth 0
-                # -> z = min_depth) are then placed from the two bit planes.  The images are read exactly once.
-                holes, filled, scratch, counts = self._hole_buffers(n, H, W)
+                # decides the fate of texels inside zero regions: the single streaming pass SPECULATIVELY places every
+                # non-zero texel (journalling the obstacle bits it is the first to set), reduces the column maxima and
+                # emits the (depth == 0) bit plane + "has zeros" flag; the hole kernel exits immediately for images
+                # without zeros; the zeros that survive it (large holes keep depth 0 -> z = min_depth) are then placed
+                # from the two bit planes.  Only an "island" frame -- valid texels enclosed by a small hole, which the
+                # reference's filled contour rewrites to 1.0 (img_utils.py:385-388) -- has its journalled bits taken
+                # back and its valid texels outside the filled area placed again; every other image is read exactly once.
+                # reach of a texel in the map plane: |(z, x, y)| <= max_depth * sqrt(1 + (W/2fx)^2 + (H/2fy)^2)
+                reach = max_depth * float(np.sqrt(1.0 + (W / 2 / fx) ** 2 + (H / 2 / fy) ** 2)) * self.pixels_per_meter
+                cap = int(min(self.size * self.size, (2 * int(np.ceil(reach)) + 3) ** 2))
+                holes, filled, scratch, counts, journal = self._hole_buffers(n, H, W, cap)
+                jref = ctypes.byref(journal)
                 _lib.check(L.vlfm_depth_ingest_batched(depth.data_ptr(), n, H, W, d_prm.data_ptr(),
                                                        keys.data_ptr() if keys is not None else None,
                                                        self.obstacle_bits.data_ptr(), self.size,
                                                        self.pixels_per_meter, self.status.data_ptr(),
-                                                       holes.data_ptr(), None, _stream_ptr()), "depth_ingest")
+                                                       holes.data_ptr(), None, jref, _stream_ptr()), "depth_ingest")
                 _lib.check(L.vlfm_fill_small_holes_batched(holes.data_ptr(), self.status.data_ptr(), n, H, W,
                                                            float(self._hole_area_thresh), scratch.data_ptr(),
                                                            scratch.numel(), self.HOLE_CAP_PTS, self.HOLE_CAP_CONTOURS,
-                                                           filled.data_ptr(), counts.data_ptr(), _stream_ptr()),
-                           "fill_small_holes")
+                                                           filled.data_ptr(), counts.data_ptr(), d_prm.data_ptr(),
+                                                           self.obstacle_bits.data_ptr(), self.size, jref,
+                                                           _stream_ptr()), "fill_small_holes")
                 _lib.check(L.vlfm_depth_scatter_holes_batched(d_prm.data_ptr(), n, H, W, holes.data_ptr(),
                                                               filled.data_ptr(), counts.data_ptr(),
                                                               self.obstacle_bits.data_ptr(), self.size,
                                                               self.pixels_per_meter, self.status.data_ptr(),
-                                                              _stream_ptr()), "depth_scatter_holes")
+                                                              depth.data_ptr(), _stream_ptr()), "depth_scatter_holes")
         return keys
 
-    def _hole_buffers(self, n: int, H: int, W: int):
+    def _hole_buffers(self, n: int, H: int, W: int, journal_cap: int):
         import torch
 
-        key = (max(n, self.n_envs), H, W)
+        key = (max(n, self.n_envs), H, W, journal_cap)
         if getattr(self, "_hole_key", None) != key:
             m, hw = key[0], (W + 31) // 32
             self._hole_bits = torch.zeros((m, H, hw), dtype=torch.int32, device=self.device)
@@ -166,8 +177,12 @@ class ObstacleMapBatch:
             nbytes = _lib.lib().vlfm_hole_scratch_bytes(m, H, W, self.HOLE_CAP_PTS, self.HOLE_CAP_CONTOURS)
             self._hole_scratch = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
             self._hole_counts = torch.zeros((m, 4), dtype=torch.int32, device=self.device)
+            self._journal_cells = torch.empty((m, journal_cap), dtype=torch.int32, device=self.device)
+            self._journal_count = torch.zeros(m, dtype=torch.int32, device=self.device)
+            self._journal = _lib.ScatterJournal(self._journal_cells.data_ptr(), self._journal_count.data_ptr(),
+                                                journal_cap, 0)
             self._hole_key = key
-        return self._hole_bits, self._filled_bits, self._hole_scratch, self._hole_counts
+        return self._hole_bits, self._filled_bits, self._hole_scratch, self._hole_counts, self._journal
 
     # ------------------------------------------------------------------------------------------ step, part 2
     def fog_params(self, tf, max_depth: float, topdown_fov: float, env_ids=None, explore=None):
@@ -262,7 +277,8 @@ class ObstacleMapBatch:
         if getattr(self, "_hole_key", None) is not None:
             hc = self._hole_counts.cpu().numpy()
             if (hc[:, 2] != 0).any():
-                raise RuntimeError("fill_small_holes scratch capacity exceeded (HOLE_CAP_PTS/HOLE_CAP_CONTOURS)")
+                raise RuntimeError("fill_small_holes scratch capacity exceeded (HOLE_CAP_PTS/HOLE_CAP_CONTOURS or the "
+                                   "scatter journal)")
 
 
 class ObstacleMap(BaseMap):

@@ -40,7 +40,10 @@ def _bytes_to_device(buf, device):
 class UploadRing:
     """Small per-step parameter blocks (poses, ingest parameters) go to HBM through a ring of pinned host buffers with
     asynchronous copies on the compute stream, so a step never blocks on a pageable H2D copy.  A slot is reused only
-    after the copy that last read it has completed (event check).  The host-side fill is a plain single-threaded
+    after the copy that last read it has completed (event check).  A ring belongs to ONE stream: the device buffer of a
+    slot is handed to kernels launched on the stream that was current at upload(); with ``slots`` uploads in flight on
+    a second stream the oldest kernel could still be reading the buffer being overwritten.  The map classes keep one ring
+    per purpose and are driven from one stream each (harness: obstacle rings on the side stream, value rings on main).  The host-side fill is a plain single-threaded
     NumPy memcpy into the pinned buffer: a torch CPU copy of >= 32 K elements would fan out over the OpenMP pool, whose
     spinning workers can exhaust a container's CPU quota and stall the whole process until the next scheduler period."""
 
@@ -260,7 +263,7 @@ class ValueMapBatch:
             d_prm = self._rings(n).upload(prm)
             _lib.check(_lib.lib().vlfm_depth_ingest_batched(depth.data_ptr(), n, H, W, d_prm.data_ptr(),
                                                            colmax.data_ptr(), None, self.size, self.pixels_per_meter,
-                                                           status.data_ptr(), None, None, _stream_ptr()),
+                                                           status.data_ptr(), None, None, None, _stream_ptr()),
                        "depth_ingest")
         return colmax[:n]
 
@@ -280,21 +283,30 @@ class ValueMapBatch:
             d_vals = torch.from_numpy(
                 np.ascontiguousarray(np.asarray(values, np.float64).reshape(-1, self.channels))).to(self.device)
         n = d_vals.shape[0]
+        # Host prologue FIRST: a camera outside the map (AssertionError, img_utils.py:43) or a bad slot list must fail before
+        # any column maximum is reduced into the key buffer -- keys are only re-zeroed by a completed update, and stale keys
+        # would max-merge this frame's depth profile into the next one.  Keys handed in by a shared depth ingest are
+        # zeroed on that error path for the same reason.
+        try:
+            W = colmax.shape[-1] if colmax is not None else int(depth.shape[-1])
+            d_tmpl, d_bits, T = _TEMPLATES.template(self.device, fov, max_depth, self.pixels_per_meter,
+                                                    self._min_confidence)
+            d_tan = _TEMPLATES.tan_table(self.device, fov, W)
+            pose = pose_params(tf_camera_to_episodic, env_ids, self.size, self.pixels_per_meter, T)
+            # one launch fuses every observation concurrently: two observations of the SAME slot (the reference's
+            # multi-camera loop, reality_policies.py:113-141, is sequential) must go through separate calls
+            assert len(np.unique(pose["env"])) == len(pose), "one observation per environment slot and call"
+            assert int(pose["env"].max()) < self.n_envs and int(pose["env"].min()) >= 0, "environment slot out of range"
+        except Exception:
+            if colmax is not None:
+                colmax.zero_()
+            raise
         if colmax is None:
             if not torch.is_tensor(depth):
                 depth = torch.from_numpy(np.ascontiguousarray(depth, np.float32)).to(self.device)
             depth = depth.reshape(n, depth.shape[-2], depth.shape[-1]).contiguous()
             assert depth.dtype == torch.float32
             colmax = self.column_max(depth)
-        W = colmax.shape[-1]
-        d_tmpl, d_bits, T = _TEMPLATES.template(self.device, fov, max_depth, self.pixels_per_meter,
-                                                self._min_confidence)
-        d_tan = _TEMPLATES.tan_table(self.device, fov, W)
-        pose = pose_params(tf_camera_to_episodic, env_ids, self.size, self.pixels_per_meter, T)
-        # one launch fuses every observation concurrently: two observations of the SAME slot (the reference's multi-camera
-        # loop, reality_policies.py:113-141, is sequential) must go through separate calls
-        assert len(np.unique(pose["env"])) == len(pose), "one observation per environment slot and call"
-        assert int(pose["env"].max()) < self.n_envs and int(pose["env"].min()) >= 0, "environment slot out of range"
         L = _lib.lib()
         with torch.cuda.device(self.device):
             ring = self._rings(n)
