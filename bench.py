@@ -1,28 +1,38 @@
 #!/usr/bin/env python
 """bench.py -- env-steps/s of the VLFM perception + value-map hot path on N MI355X GPUs of one node.
 
-    python bench.py --gpus 1 --steps 50 --warmup 5
+    python bench.py --gpus 1 --steps 30 --warmup 5
+    python bench.py --gpus 8 --steps 30 --warmup 5            # re-executes itself under torch.distributed.run, 8 ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W                 # what the driver does; same code path from there on
 
 One "step" = one ITMPolicyV2 perception+mapping step for every resident environment (BASELINE.json metric
 "env-steps/s (VLM+value-map update), 640x480 RGB-D"): batched in-process BLIP-2 ITC cosine at the full ViT-g/14
-geometry (random-init weights: no checkpoints offline), one depth-ingest pass, ObstacleMap update (when built),
-ValueMap.update_map and frontier scoring (sort_waypoints) -- see vlfm_amd/harness.py.  Observations are synthetic and
-already resident in HBM when the timed region starts.  Episodes are independent: env e lives on rank e mod N
-(weak scaling, --envs per GPU fixed), the only collective is the final metric all-reduce.
+geometry (random-init weights: no checkpoints offline), one depth-ingest pass, ObstacleMap update, ValueMap.update_map
+and frontier scoring (sort_waypoints) -- see vlfm_amd/harness.py.  Observations are synthetic and already resident in
+HBM when the timed region starts; before the warm-up every episode is advanced by --preroll map-only steps so that the
+timed steps see a mid-episode map (explored area, obstacle planes, contour lengths), not an empty world.  Episodes are
+independent: rank r owns the contiguous block of environments [r * envs, (r + 1) * envs) (weak scaling, --envs per GPU
+fixed); the only collectives are the two metric all-reduces at the end (RCCL).
 
 Prints ONE JSON line (rank 0) with the driver's keys plus:
-  roofline      dominant HIP map kernel: algorithmic bytes per launch / mean launch time (HIP events on the launch
-                stream, inside the timed region) vs the 8 TB/s HBM peak
-  cpu_baseline  the reference-faithful CPU path (oracle/ NumPy+C restatement of the maps + the same ITC graph in fp32
-                on the host cores), timed on rank 0 at N=1 on a bounded sample
+  roofline      the map-fusion kernel (value_map_update_fused_kernel): `frac` = algorithmic bytes per launch (SURVEY.md
+                8d) / mean launch time (dispatch timestamps on the launch stream, inside the timed region) / 8 TB/s, AND
+                next to it the bytes the launch really has to move (`necessary_bytes_per_launch`: cells stored x 20 B +
+                keys, counted in this run), the PMC-measured HBM traffic when profiles/pmc_traffic.json holds this kernel
+                at this configuration, their fractions of the peak, and `bound` set from that evidence
+  small_batch   the reference's own geometries (configs[1], [2], [3], [4] per GPU), PCIe-inclusive rate, map-kernel times
+                at episode steps 25 / 250 / 475
+  cpu_baseline  the reference-faithful CPU path (oracle/ NumPy+C restatement of the maps + the same ITC graph in fp32 on
+                the host cores): 20 warm-up + 5 x 40 timed map steps on 1 core (median of the 5), the same on every usable
+                core at once (whole box), BLIP-2 fp32 on the quota's threads; rank 0 at N=1 only
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -30,8 +40,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md
 
-def parse_args():
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -39,22 +51,45 @@ def parse_args():
     ap.add_argument("--envs", type=int, default=256,
                     help="environments resident per GPU (weak scaling).  BASELINE configs[3]/[4] use 8 and 16 per GPU; "
                          "288 GB of HBM holds far more, and the batched BLIP-2 forward and the map kernels only reach "
-                         "their efficient regime at >= 64 (the 8/GPU and 1/GPU figures are reported alongside)")
-    ap.add_argument("--no-small", action="store_true", help="skip the 8-env and 1-env side measurements")
-    ap.add_argument("--no-full", action="store_true",
-                    help="skip the configs[2] side run (8 envs: BLIP-2 + detector + MobileSAM + maps + frontier selection; the "
-                         "detector/segmenter are random-init stand-ins of the YOLOv7-E6E / MobileSAM class: a side figure)")
-    ap.add_argument("--with-full", action="store_true", help="(default now; kept for old command lines)")
+                         "their efficient regime at >= 64 (the 8/GPU, 16/GPU-HD and 1/GPU figures are reported alongside)")
+    ap.add_argument("--preroll", type=int, default=150,
+                    help="map-only steps every episode is advanced by before the warm-up (mid-episode map state)")
+    ap.add_argument("--no-small", action="store_true", help="skip the side measurements (small batches, config 5, PCIe)")
+    ap.add_argument("--no-full", action="store_true", help="skip the configs[2] full-step side runs")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--no-blip2", action="store_true", help="map kernels only (NOT the headline metric)")
     ap.add_argument("--no-obstacle", action="store_true")
     ap.add_argument("--sync-explored", action="store_true", help="config 5: value map synchronised with explored area")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=2, help="BLIP-2 fp32 forwards timed on the host")
     ap.add_argument("--no-overlap", action="store_true", help="run the obstacle pipeline on the BLIP-2 stream")
     ap.add_argument("--host-profile", action="store_true", help="cProfile the timed region (stderr), for tuning")
-    return ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher + process group + barriers + metric all-reduce around a stub step: no GPU work "
+                         "(backend gloo when no GPU is visible) -- the multi-rank plumbing test of tests/")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def relaunch_under_torchrun(gpus: int) -> None:
+    """`python bench.py --gpus N` without a torchrun environment: become `python -m torch.distributed.run ... bench.py
+    <same arguments>`, one rank per GPU, rendezvous on 127.0.0.1.  Never returns."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, env)
 
 
 def usable_cores() -> int:
@@ -78,83 +113,119 @@ def usable_cores() -> int:
     return n
 
 
-def cpu_baseline(args, with_blip2: bool):
-    """Reference-faithful CPU path on the host cores: oracle maps (NumPy + oracle/libcvport.so) and the same BLIP-2
-    ITC graph in fp32 through PyTorch-CPU (the reference's own fallback device, vlfm/vlm/blip2itm.py:26-27)."""
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def _cpu_map_runs(height: int, width: int, with_obstacle: bool, warm: int, runs: int, per_run: int, env_id: int = 0,
+                  stages: bool = False):
+    """The oracle's maps on ONE core: ``warm`` untimed steps (they populate the confidence-mask cache, value_map.py:37),
+    then ``runs`` x ``per_run`` timed steps of the same episode.  Returns (seconds per step of each run, stage seconds)."""
     import numpy as np
-    import torch
 
+    from oracle.ref_obstacle_map import RefObstacleMap
     from oracle.ref_value_map import RefValueMap
-    from vlfm_amd.synthetic import MAX_DEPTH, MIN_DEPTH, SyntheticEnv, camera_intrinsics, rgb_frame
+    from vlfm_amd.synthetic import MAX_DEPTH, MIN_DEPTH, SyntheticEnv, camera_intrinsics
 
-    cores = min(usable_cores(), 16)  # more intra-op threads than this only oversubscribes the fp32 GEMMs
-    torch.set_num_threads(cores)
-    fov = camera_intrinsics(args.width)[2]
-    env = SyntheticEnv(0, args.height, args.width)
+    fx, fy, fov = camera_intrinsics(width)
+    env = SyntheticEnv(env_id, height, width)
     vm = RefValueMap(1, use_max_confidence=False)
-    om = None
-    try:
-        from oracle.ref_obstacle_map import RefObstacleMap
-
-        if not args.no_obstacle:
-            om = RefObstacleMap(min_height=0.61, max_height=0.88, agent_radius=0.18, area_thresh=1.5)
-    except ImportError:
-        om = None
-    fx, fy, _ = camera_intrinsics(args.width)
-    # per-stage CPU times (SURVEY.md 8d): wrap the oracle's stage functions with wall-clock accumulators
+    om = RefObstacleMap(min_height=0.61, max_height=0.88, agent_radius=0.18, area_thresh=1.5) if with_obstacle else None
     stage_s: dict = {}
+    restore = []
+    if stages:
+        import oracle.ref_obstacle_map as rom_
+        import oracle.ref_value_map as rvm_
 
-    def timed(mod, name, label):
-        fn = getattr(mod, name)
+        def timed(mod, name, label):
+            fn = getattr(mod, name)
 
-        def wrapper(*a, **k):
-            t0 = time.perf_counter()
-            try:
-                return fn(*a, **k)
-            finally:
-                stage_s[label] = stage_s.get(label, 0.0) + time.perf_counter() - t0
+            def wrapper(*a, **k):
+                t0 = time.perf_counter()
+                try:
+                    return fn(*a, **k)
+                finally:
+                    stage_s[label] = stage_s.get(label, 0.0) + time.perf_counter() - t0
 
-        setattr(mod, name, wrapper)
-        return fn
+            setattr(mod, name, wrapper)
+            restore.append((mod, name, fn))
 
-    import oracle.ref_obstacle_map as rom_
-    import oracle.ref_value_map as rvm_
+        timed(rvm_.RefValueMap, "_process_local_data", "depth profile + polygon cut")
+        timed(rvm_, "rotate_about_centre", "rotate (warpAffine)")
+        timed(rvm_, "paste_centred", "place")
+        timed(rvm_.RefValueMap, "_fuse_new_data", "fuse (full-map NumPy passes)")
+        timed(rvm_.RefValueMap, "sort_waypoints", "sort_waypoints")
+        timed(rom_, "fill_small_holes", "fill_small_holes")
+        timed(rom_, "unproject", "unproject")
+        timed(rom_, "apply_tf", "transform_points")
+        timed(rom_, "reveal_fog_of_war", "reveal_fog_of_war")
+        timed(rom_, "detect_frontier_waypoints", "detect_frontier_waypoints")
 
-    restore = [(rvm_.RefValueMap, "_process_local_data", timed(rvm_.RefValueMap, "_process_local_data", "depth profile + polygon cut")),
-               (rvm_, "rotate_about_centre", timed(rvm_, "rotate_about_centre", "rotate (warpAffine)")),
-               (rvm_, "paste_centred", timed(rvm_, "paste_centred", "place")),
-               (rvm_.RefValueMap, "_fuse_new_data", timed(rvm_.RefValueMap, "_fuse_new_data", "fuse (full-map NumPy passes)")),
-               (rvm_.RefValueMap, "sort_waypoints", timed(rvm_.RefValueMap, "sort_waypoints", "sort_waypoints")),
-               (rom_, "fill_small_holes", timed(rom_, "fill_small_holes", "fill_small_holes")),
-               (rom_, "unproject", timed(rom_, "unproject", "unproject")),
-               (rom_, "apply_tf", timed(rom_, "apply_tf", "transform_points")),
-               (rom_, "reveal_fog_of_war", timed(rom_, "reveal_fog_of_war", "reveal_fog_of_war")),
-               (rom_, "detect_frontier_waypoints", timed(rom_, "detect_frontier_waypoints", "detect_frontier_waypoints"))]
-    # maps: warm-up populates the confidence-mask cache, then a bounded timed sample
-    n_map = 60
-    obs = [env.observe() for _ in range(n_map + 5)]
-    t_map = 0.0
-    for i, (depth, tf, values) in enumerate(obs):
+    def one():
+        depth, tf, values = env.observe()
         t0 = time.perf_counter()
         if om is not None:
             om.update_map(depth, tf, MIN_DEPTH, MAX_DEPTH, fx, fy, fov)
         vm.update_map(values, depth.copy(), tf, MIN_DEPTH, MAX_DEPTH, fov)
         if om is not None and len(om.frontiers):
             vm.sort_waypoints(om.frontiers, 0.5)
-        dt = time.perf_counter() - t0
-        if i >= 5:
-            t_map += dt
-        else:
-            stage_s.clear()  # warm-up steps do not count
-    for owner, name, fn in restore:
-        setattr(owner, name, fn)
-    map_s = t_map / n_map
+        return time.perf_counter() - t0
+
+    for _ in range(warm):
+        one()
+    stage_s.clear()
+    per = []
+    for _ in range(runs):
+        per.append(float(np.sum([one() for _ in range(per_run)]) / per_run))
+    for mod, name, fn in restore:
+        setattr(mod, name, fn)
+    return per, {k: v / (runs * per_run) for k, v in stage_s.items()}
+
+
+def _cpu_worker(job):
+    height, width, with_obstacle, env_id = job
+    import torch
+
+    torch.set_num_threads(1)
+    per, _ = _cpu_map_runs(height, width, with_obstacle, warm=10, runs=1, per_run=40, env_id=env_id)
+    return per[0]
+
+
+def cpu_baseline(args, with_blip2: bool):
+    """Reference-faithful CPU path on the host cores (SURVEY.md 8d protocol): oracle maps (NumPy + oracle/libcvport.so)
+    single-process on 1 core -- the reference is single-env, single-threaded (vlfm_objectnav_hm3d.yaml:34,46-48) -- 20
+    warm-up + 5 runs x 40 timed steps, median of the 5; the same on every usable core at once (one env per process) for
+    the whole-box figure; and the same BLIP-2 ITC graph in fp32 through PyTorch-CPU (the reference's own fallback device,
+    vlfm/vlm/blip2itm.py:26-27)."""
+    import multiprocessing
+
+    import numpy as np
+    import torch
+
+    from vlfm_amd.synthetic import rgb_frame
+
+    quota = usable_cores()
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(1)
+    per, stage = _cpu_map_runs(args.height, args.width, not args.no_obstacle, warm=20, runs=5, per_run=40, stages=True)
+    map_s = float(np.median(per))
+    # whole box: one single-env process per usable core, all running at once
+    try:
+        ctx = multiprocessing.get_context("spawn")
+        t0 = time.perf_counter()
+        with ctx.Pool(quota) as pool:
+            per_proc = pool.map(_cpu_worker, [(args.height, args.width, not args.no_obstacle, 100 + i) for i in range(quota)])
+        box = {"processes": quota, "maps_env_steps_per_s": round(float(sum(1.0 / p for p in per_proc)), 2),
+               "ms_per_step_per_process": round(float(np.median(per_proc)) * 1e3, 2),
+               "wall_s": round(time.perf_counter() - t0, 1)}
+    except Exception as exc:  # noqa: BLE001
+        box = {"error": f"{type(exc).__name__}: {exc}"[:200]}
     blip_s = 0.0
+    threads = min(quota, 16)  # more intra-op threads than this only oversubscribes the fp32 GEMMs
     if with_blip2:
-        from vlfm_amd.vlm.blip2itm import Blip2ITCConfig, Blip2ITCModel
-        from vlfm_amd.vlm.ops import CLIP_MEAN, CLIP_STD
         from PIL import Image
 
+        from vlfm_amd.vlm.blip2itm import Blip2ITCConfig, Blip2ITCModel
+        from vlfm_amd.vlm.ops import CLIP_MEAN, CLIP_STD
+
+        torch.set_num_threads(threads)
         model = Blip2ITCModel(Blip2ITCConfig()).eval()
         with torch.no_grad():  # throughput does not depend on the weight values: cheap deterministic fill, no RNG
             for p in model.parameters():
@@ -181,48 +252,170 @@ def cpu_baseline(args, with_blip2: bool):
                 if i > 0:
                     times.append(time.perf_counter() - t0)
         blip_s = float(np.mean(times))
+        torch.set_num_threads(1)
     total = map_s + blip_s
     return {
-        "value": round(1.0 / total, 3), "unit": "env-steps/s", "cores": cores, "kind": "port",
-        "sample": (f"1 env, {n_map} timed map steps (oracle ValueMap{'+ObstacleMap' if om is not None else ''}, "
-                   f"{map_s * 1e3:.1f} ms/step on 1 core)"
-                   + (f" + {args.cpu_steps} BLIP-2 ITC fp32 forwards on {cores} torch threads ({blip_s * 1e3:.0f} ms/frame)"
+        "value": round(1.0 / total, 3), "unit": "env-steps/s", "cores": threads if with_blip2 else 1, "kind": "port",
+        "sample": (f"1 env: 20 warm-up + 5 runs x 40 timed map steps (oracle ValueMap{'' if args.no_obstacle else '+ObstacleMap'}"
+                   f"+sort_waypoints) on 1 core, median of the 5 runs = {map_s * 1e3:.1f} ms/step"
+                   + (f"; + {args.cpu_steps} BLIP-2 ITC fp32 forwards on {threads} torch threads ({blip_s * 1e3:.0f} ms/frame)"
                       if with_blip2 else " (BLIP-2 leg skipped)")),
-        "maps_only_env_steps_per_s": round(1.0 / map_s, 2),
-        "map_stage_ms_per_step": {k: round(v / n_map * 1e3, 3) for k, v in sorted(stage_s.items(), key=lambda kv: -kv[1])},
+        "host": {"affinity_cores": affinity, "cgroup_quota_cores": quota},
+        "maps_1core_env_steps_per_s": round(1.0 / map_s, 2),
+        "maps_1core_runs_ms": [round(p * 1e3, 2) for p in per],
+        "whole_box": box,
+        "map_stage_ms_per_step": {k: round(v * 1e3, 3) for k, v in sorted(stage.items(), key=lambda kv: -kv[1])},
     }
 
 
-def main():
-    args = parse_args()
-    import numpy as np
+# ------------------------------------------------------------------------------------------------ roofline helpers
+MAP_KERNELS = ("depth_ingest_kernel", "depth_scatter_kernel", "depth_ingest_scatter_kernel", "fill_small_holes_kernel",
+               "hole_scatter_kernel", "value_map_update_fused_kernel", "visible_mask_kernel", "value_map_fuse_kernel",
+               "mask_unexplored_kernel", "sort_waypoints_kernel", "resample_h_kernel", "resample_v_norm_kernel",
+               "itc_head_kernel", "navigable_kernel", "fog_of_war_kernel", "explored_select_kernel",
+               "frontier_prepare_kernel", "frontier_kernel")
+
+
+def read_kernel_ms():
+    from vlfm_amd import _lib
+
+    out = {}
+    for k in MAP_KERNELS:
+        ms, n = _lib.profile_read(k)
+        if n:
+            out[k] = ms
+    return out
+
+
+def load_pmc():
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except (OSError, ValueError):
+        return {}
+
+
+def count_stored_cells(sim) -> float:
+    """Cells one value-map update of the CURRENT step really stores, per observation (mean): the same frames and poses
+    fused with fusion_type 'replace' into an empty scratch map leave a non-zero confidence exactly in the cells the
+    launch writes (new confidence != 0).  Outside the timed region."""
+    import torch
+
+    from vlfm_amd.mapping.value_map import ValueMapBatch
+    from vlfm_amd.synthetic import MAX_DEPTH, MIN_DEPTH
+
+    n = min(sim.E, 16)
+    k = sim.t % sim.depth_pool.shape[0]
+    depth = sim.depth_pool[k][:n].to(sim.device)
+    tf = sim.tf_table[sim.t % sim.episode_len][:n]
+    scratch = ValueMapBatch(n, 1, sim.S, use_max_confidence=False, fusion_type="replace", device=sim.device)
+    scratch.update(torch.full((n, 1), 0.3, dtype=torch.float64), depth, tf, MIN_DEPTH, MAX_DEPTH, sim.fov)
+    return float((scratch.conf != 0).sum().item()) / n
+
+
+def map_roofline(kms, E, H, W, sync, stored_cells, pmc):
+    """Per HBM kernel: SURVEY.md 8d algorithmic bytes, the bytes the launch must really move, PMC traffic if committed."""
+    T, S = 2 * int(5.0 * 20) + 1, 1000
+    table = {}
+
+    def entry(name, algorithmic, necessary, note):
+        if name not in kms:
+            return
+        sec = kms[name] * 1e-3
+        rec = {"launch_ms": round(kms[name], 5), "algorithmic_bytes_per_launch": int(algorithmic),
+               "achieved": round(algorithmic / sec / 1e9, 1), "frac": round(algorithmic / sec / 1e9 / HBM_PEAK_GBS, 4),
+               "necessary_bytes_per_launch": int(necessary),
+               "necessary_frac": round(necessary / sec / 1e9 / HBM_PEAK_GBS, 4), "necessary_note": note}
+        p = pmc.get(f"{name}@E={E},{W}x{H}" + (",sync" if sync else ""))
+        if p:
+            rec["traffic"] = p["bytes_per_launch"]
+            rec["traffic_frac"] = round(p["bytes_per_launch"] / sec / 1e9 / HBM_PEAK_GBS, 4)
+        table[name] = rec
+
+    depth_bytes = 4 * H * W
+    # one pass reads every texel once for both maps (the reference reads the image twice: SURVEY 8d prices 4*H*W per map)
+    entry("depth_ingest_scatter_kernel", E * 2 * depth_bytes, E * (depth_bytes + 4 * W),
+          "4*H*W texel reads + W column-max keys; obstacle-bit atomics not counted")
+    entry("depth_ingest_kernel", E * depth_bytes, E * (depth_bytes + 4 * W), "4*H*W texel reads + W keys")
+    entry("depth_scatter_kernel", E * depth_bytes, E * depth_bytes // 2, "only rows that can reach the height band are read")
+    window = 4 * T * T + 8 * T * T + 8 * T * T                      # template + conf RMW + value RMW (C = 1)
+    full = S * S + 8 * S * S + 8 * S * S + 4 * T * T                # explored + full-map conf/value RMW + template
+    need = stored_cells * (16 + 4) + 4 * W + ((2 * S * ((S + 31) // 32) * 4) if sync else 0)
+    entry("value_map_update_fused_kernel", E * (full if sync else window), E * need,
+          "cells stored x (8 B conf RMW + 8 B value RMW + 4 B template tap) + W keys"
+          + (" + explored and written bit planes" if sync else ""))
+    entry("value_map_fuse_kernel", E * window, E * (stored_cells * 20 + 5632), "cells stored x 20 B + visibility plane")
+    entry("mask_unexplored_kernel", E * (S * S + 8 * S * S + 8 * S * S), E * S * 125, "explored bit plane only when nothing is cleared")
+    return table
+
+
+# ------------------------------------------------------------------------------------------------ dry run
+def dry_run(args) -> None:
+    """The multi-rank plumbing without any GPU work: same launcher, same process-group init, same barriers and metric
+    all-reduces as the real run around a stub step (tests/test_distributed_cpu.py drives this with --gpus 2 on CPU)."""
     import torch
 
     from vlfm_amd import distributed as D
 
     rank, local_rank, world = D.world()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    use_gpu = torch.cuda.is_available()
+    device = torch.device(f"cuda:{local_rank}") if use_gpu else torch.device("cpu")
+    D.init("nccl" if use_gpu else "gloo", device if use_gpu else None)
+    ids = D.shard_env_ids(rank, world, args.envs)
+    D.barrier(device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001)
+    D.barrier(device)
+    elapsed = time.perf_counter() - t0
+    elapsed_max, (env_steps, id_sum) = D.reduce_metrics(elapsed, [float(len(ids) * args.steps), float(sum(ids))], device)
+    if rank == 0:
+        print(json.dumps({"metric": "env-steps/s (DRY RUN: stub step, no GPU work)", "dry_run": True,
+                          "value": round(env_steps / elapsed_max, 2), "unit": "env-steps/s", "n_gpus": world,
+                          "ranks": world, "backend": "nccl (RCCL)" if use_gpu else "gloo", "steps": args.steps,
+                          "warmup": args.warmup, "global_envs": args.envs * world, "env_id_checksum": id_sum,
+                          "scaling": "weak"}), flush=True)
+    D.shutdown()
+
+
+# ------------------------------------------------------------------------------------------------ main
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args.gpus)
+    if args.dry_run:
+        return dry_run(args)
+    import torch
+    import torch.distributed as dist
+
+    from vlfm_amd import distributed as D
+
+    rank, local_rank, world = D.world()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU"
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
     D.init("nccl", device)  # backend "nccl" is RCCL on ROCm; only the metric all-reduces use it
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.set_num_threads(1)  # the GPU leg has no CPU tensor math; idle OpenMP spinners would only eat the CPU quota
 
+    from vlfm_amd import _lib
     from vlfm_amd.harness import BatchedEpisodes
 
-    have_obstacle = os.path.exists(os.path.join(ROOT, "vlfm_amd", "mapping", "obstacle_map.py")) and not args.no_obstacle
-    sim = BatchedEpisodes(args.envs, device=device, height=args.height, width=args.width,
-                          env_offset=D.shard_env_ids(rank, world, args.envs)[0],
-                          use_blip2=not args.no_blip2, obstacle=have_obstacle, sync_explored=args.sync_explored,
-                          overlap=not args.no_overlap)
+    have_obstacle = not args.no_obstacle
+    common = dict(device=device, height=args.height, width=args.width, obstacle=have_obstacle,
+                  overlap=not args.no_overlap)
+    sim = BatchedEpisodes(args.envs, env_offset=D.shard_env_ids(rank, world, args.envs)[0],
+                          use_blip2=not args.no_blip2, sync_explored=args.sync_explored, **common)
+    if sim.blip2 is not None:
+        sim.blip2.strict_hip_attention = True  # a silent library fallback would change what is being measured
 
     def barrier():
         D.barrier(device)
 
+    sim.fast_forward(args.preroll)
     for _ in range(args.warmup):
         sim.step()
-    from vlfm_amd import _lib
-
-    _lib.lib().vlfm_profile_enable(1)  # HIP events around every kernel launch of libvlfm_amd, on its launch stream
+    first_timed_step = sim.t
+    _lib.lib().vlfm_profile_enable(1)  # dispatch-timestamp events around every kernel launch of libvlfm_amd
     prof = None
     if args.host_profile:
         import cProfile
@@ -238,6 +431,7 @@ def main():
         prof.disable()
     barrier()
     elapsed = time.perf_counter() - t0
+    sim.check()  # a capacity overflow or an off-map obstacle point inside the timed region fails the benchmark
     if prof is not None and rank == 0:
         import pstats
 
@@ -246,181 +440,51 @@ def main():
     elapsed_max, (env_steps,) = D.reduce_metrics(elapsed, [float(args.envs * args.steps)], device)
 
     torch.cuda.synchronize(device)
-    kms = {}
-    for kname in ("depth_ingest_kernel", "depth_scatter_kernel", "depth_ingest_scatter_kernel", "fill_small_holes_kernel",
-                  "hole_scatter_kernel",
-                  "visible_mask_kernel", "value_map_fuse_kernel", "sort_waypoints_kernel",
-                  "mask_unexplored_kernel", "resample_h_kernel", "resample_v_norm_kernel", "itc_head_kernel",
-                  "navigable_kernel", "fog_of_war_kernel", "explored_select_kernel", "frontier_kernel"):
-        ms, n = _lib.profile_read(kname)
-        if n:
-            kms[kname] = ms
+    kms = read_kernel_ms()
     _lib.lib().vlfm_profile_enable(0)
     if rank == 0:
         H, W, E = args.height, args.width, args.envs
-        T = 2 * int(5.0 * 20) + 1
-        S = 1000
-        # Algorithmic bytes per launch (DESIGN.md "Kernels"), E observations per launch:
-        #   depth ingest     reads every depth texel once: 4*H*W  (+ <= H*W scattered obstacle bytes, not counted)
-        #   map fusion       template read 4*T^2 + conf RMW 8*T^2 + value RMW 8*C*T^2  (C = 1)
-        #   mask unexplored  (obstacle-synchronised mode) explored S^2 + conf RMW 8*S^2 + value RMW 8*C*S^2
-        per_kernel = {}
-
-        def entry(name, nbytes):
-            if name in kms:
-                gbs = nbytes / (kms[name] * 1e-3) / 1e9
-                per_kernel[name] = {"algorithmic_bytes_per_launch": nbytes, "launch_ms": round(kms[name], 5),
-                                    "achieved": round(gbs, 1), "frac": round(gbs / 8000.0, 4)}
-
-        entry("depth_ingest_kernel", E * 4 * H * W)
-        entry("depth_scatter_kernel", E * 4 * H * W)
-        # one pass that replaces BOTH of the reference's reads of the depth image (column maximum for the value map,
-        # unprojection for the obstacle map): SURVEY.md 8d prices them at 4*H*W each
-        entry("depth_ingest_scatter_kernel", E * 8 * H * W)
-        entry("value_map_fuse_kernel", E * (4 * T * T + 8 * T * T + 8 * T * T))
-        entry("mask_unexplored_kernel", E * (S * S + 8 * S * S + 8 * S * S))
+        stored = count_stored_cells(sim)
+        per_kernel = map_roofline(kms, E, H, W, args.sync_explored, stored, load_pmc())
         # the kernel BASELINE.json's north_star names for the roofline target is the map-fusion kernel
-        name = "value_map_fuse_kernel"
+        name = "value_map_update_fused_kernel" if "value_map_update_fused_kernel" in per_kernel else "value_map_fuse_kernel"
         head = per_kernel[name]
-        roofline = {"bound": "hbm", "kernel": name, "achieved": head["achieved"], "peak": 8000.0, "unit": "GB/s",
-                    "frac": head["frac"], "traffic": None,
+        real = head.get("traffic_frac", head["necessary_frac"])
+        roofline = {"bound": "hbm" if real >= 0.3 else "latency", "priced_against": "hbm", "kernel": name,
+                    "achieved": head["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["frac"],
+                    "traffic": head.get("traffic"), "traffic_frac": head.get("traffic_frac"),
+                    "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of tools/pmc_traffic.sh; null = not "
+                                      "collected for this kernel / configuration)",
                     "algorithmic_bytes_per_launch": head["algorithmic_bytes_per_launch"],
-                    "launch_ms": head["launch_ms"], "hbm_kernels": per_kernel,
-                    "all_kernels_ms": {k: round(v, 5) for k, v in kms.items()}}
-        # HBM traffic of the roofline kernel from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in separate runs, corrected
-        # as /opt/skills/guides/MI355X_MICROARCH.md prescribes): collected offline by tools/pmc_traffic.sh on the GPU box
-        # and committed under profiles/; valid only for the same E / geometry
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            rec = pmc.get(f"value_map_fuse_kernel@E={E},{W}x{H}")
-            if rec:
-                traffic = rec["bytes_per_launch"]
-        except (OSError, ValueError, KeyError):
-            pass
-        roofline["traffic"] = traffic
+                    "necessary_bytes_per_launch": head["necessary_bytes_per_launch"],
+                    "necessary_frac": head["necessary_frac"], "stored_cells_per_observation": round(stored, 1),
+                    "launch_ms": head["launch_ms"],
+                    "bound_evidence": ("`frac` prices the reference's whole 201x201 window (SURVEY 8d); the launch only has to "
+                                       "move `necessary_bytes_per_launch` (the visible cone is a fraction of the window), so the "
+                                       "honest HBM fraction is `necessary_frac` / `traffic_frac`; below 0.3 the kernel is "
+                                       "bound by its dependent-load chain and launch latency, not by bandwidth"),
+                    "hbm_kernels": per_kernel, "all_kernels_ms": {k: round(v, 5) for k, v in kms.items()}}
         out = {
             "metric": "env-steps/s (VLM+value-map update), 640x480 RGB-D",
             "value": round(env_steps / elapsed_max, 2), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 maps / f16 ViT-g + f32 Q-Former", "data": "synthetic",
+            "ranks": world, "backend": "nccl (RCCL)" if dist.is_initialized() else "single process, no process group",
             "config": {"workload": ("configs[1] step (BLIP-2 ITC cosine + ValueMap fusion"
                                     + (" + ObstacleMap update" if have_obstacle else "")
                                     + " + sort_waypoints) for every resident env, envs sharded over GPUs as in configs[3]"
                                     if not args.no_blip2 else "MAP KERNELS ONLY (no VLM) -- not the headline metric"),
                        "envs_per_gpu": E, "global_envs": E * world, "rgbd": f"{W}x{H}", "map": "1000x1000 @ 20 px/m",
+                       "episode_steps_timed": [first_timed_step, first_timed_step + args.steps - 1],
                        "blip2": "ViT-g/14 39 blocks + Q-Former 12 layers, random-init" if not args.no_blip2 else None,
-                       "parallelism": f"env-sharded x{world}, metric all-reduce only"},
+                       "attention_path": (sim.blip2.attention_path if sim.blip2 is not None else None),
+                       "value_map_update": "split (3 launches)" if sim.values.split_update else "single launch",
+                       "parallelism": f"env-sharded x{world} (contiguous blocks), metric all-reduce only"},
             "roofline": roofline,
         }
-        if world == 1 and not args.no_small and not args.no_blip2:
-            # the reference's own geometry: configs[3] keeps 8 envs per GPU, configs[1] a single env (batch 1)
-            side = {}
-
-            def leg(name, fn):
-                """A side measurement must never cost the headline: a failure is recorded, not raised."""
-                try:
-                    fn()
-                except Exception as exc:  # noqa: BLE001
-                    side[name + " (FAILED)"] = f"{type(exc).__name__}: {exc}"[:300]
-                torch.cuda.synchronize(device)
-
-            def leg_small():
-                for e_small in ((128, 8, 1) if args.envs != 128 else (8, 1)):
-                    small = BatchedEpisodes(e_small, device=device, height=args.height, width=args.width,
-                                            blip2=sim.blip2, obstacle=have_obstacle, overlap=not args.no_overlap)
-                    for _ in range(3):
-                        small.step()
-                    torch.cuda.synchronize(device)
-                    ts = time.perf_counter()
-                    n_small = 20
-                    for _ in range(n_small):
-                        small.step()
-                    torch.cuda.synchronize(device)
-                    dt = (time.perf_counter() - ts) / n_small
-                    side[f"envs_per_gpu={e_small}"] = {"value": round(e_small / dt, 2), "unit": "env-steps/s",
-                                                       "ms_per_step": round(dt * 1e3, 3)}
-                    del small
-
-            leg("small batches", leg_small)
-
-            def leg_host():
-                # what the rate becomes when the frames arrive as HOST buffers every step (the reference's API hands over
-                # numpy arrays): same workload, depth + rgb uploaded from pinned memory inside the timed region
-                host = BatchedEpisodes(args.envs, device=device, height=args.height, width=args.width, blip2=sim.blip2,
-                                       obstacle=have_obstacle, overlap=not args.no_overlap, host_inputs=True)
-                for _ in range(2):
-                    host.step()
-                torch.cuda.synchronize(device)
-                ts = time.perf_counter()
-                for _ in range(8):
-                    host.step()
-                torch.cuda.synchronize(device)
-                dt = (time.perf_counter() - ts) / 8
-                side[f"pcie_inclusive, envs_per_gpu={args.envs}"] = {
-                    "value": round(args.envs / dt, 2), "unit": "env-steps/s", "ms_per_step": round(dt * 1e3, 3),
-                    "upload_bytes_per_step": int(args.envs * (4 * args.height * args.width + 3 * args.height * args.width))}
-                del host
-
-            leg("pcie_inclusive", leg_host)
-
-            def leg_full():
-                from vlfm_amd.pointnav import WrappedPointNavResNetPolicy
-                from vlfm_amd.vlm.sam import MobileSAM
-                from vlfm_amd.vlm.yolov7 import YOLOv7
-
-                full = BatchedEpisodes(8, device=device, height=args.height, width=args.width, blip2=sim.blip2,
-                                       obstacle=have_obstacle, overlap=not args.no_overlap,
-                                       detector=YOLOv7(device=device), sam=MobileSAM(device=device),
-                                       select_frontiers=True,
-                                       pointnav=WrappedPointNavResNetPolicy(None, device=device, n_envs=8,
-                                                                            discrete_actions=True))
-                for _ in range(3):
-                    full.step()
-                torch.cuda.synchronize(device)
-                ts = time.perf_counter()
-                for _ in range(20):
-                    full.step()
-                torch.cuda.synchronize(device)
-                dt = (time.perf_counter() - ts) / 20
-                side["configs[2] full step, envs_per_gpu=8"] = {
-                    "value": round(8 / dt, 2), "unit": "env-steps/s", "ms_per_step": round(dt * 1e3, 3),
-                    "controller": "PointNav ResNet-18-GN + LSTM, random-init, discrete head",
-                    "detector": full.detector.weights, "segmenter": "MobileSAM (TinyViT-5M) random-init, 1 box for every "
-                                                                    "4th env-step"}
-                del full
-
-            def leg_gdino():
-                # ... and with the open-vocabulary detector the config names (what the reference uses for non-COCO
-                # targets): GroundingDINO at its real geometry (HF Swin-T + BERT-base, random-init), HIP MsDeformAttn
-                from vlfm_amd.pointnav import WrappedPointNavResNetPolicy
-                from vlfm_amd.vlm.grounding_dino import GroundingDINO
-                from vlfm_amd.vlm.sam import MobileSAM
-
-                full = BatchedEpisodes(8, device=device, height=args.height, width=args.width, blip2=sim.blip2,
-                                       obstacle=have_obstacle, overlap=not args.no_overlap,
-                                       detector=GroundingDINO(device=device), sam=MobileSAM(device=device),
-                                       select_frontiers=True,
-                                       pointnav=WrappedPointNavResNetPolicy(None, device=device, n_envs=8,
-                                                                            discrete_actions=True))
-                for _ in range(2):
-                    full.step()
-                torch.cuda.synchronize(device)
-                ts = time.perf_counter()
-                for _ in range(10):
-                    full.step()
-                torch.cuda.synchronize(device)
-                dt = (time.perf_counter() - ts) / 10
-                side["configs[2] full step with GroundingDINO, envs_per_gpu=8"] = {
-                    "value": round(8 / dt, 2), "unit": "env-steps/s", "ms_per_step": round(dt * 1e3, 3),
-                    "detector": "GroundingDINO (HF Swin-T + BERT-base geometry, 172 M parameters) " + full.detector.weights}
-                del full
-
-            if not args.no_full:
-                leg("configs[2] full step", leg_full)
-                leg("configs[2] full step with GroundingDINO", leg_gdino)
-            out["small_batch"] = side
+        if world == 1 and not args.no_small:
+            out["small_batch"] = side_legs(args, sim, device, common)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, with_blip2=not args.no_blip2)
@@ -428,6 +492,143 @@ def main():
                 out["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         print(json.dumps(out), flush=True)
     D.shutdown()
+
+
+def side_legs(args, sim, device, common):
+    """The reference's own geometries next to the headline; a failure is recorded, never raised."""
+    import torch
+
+    from vlfm_amd import _lib
+    from vlfm_amd.harness import BatchedEpisodes
+
+    side = {}
+
+    def leg(name, fn):
+        try:
+            fn()
+        except Exception as exc:  # noqa: BLE001
+            side[name + " (FAILED)"] = f"{type(exc).__name__}: {exc}"[:300]
+        torch.cuda.synchronize(device)
+
+    def timed(s, warm, n):
+        for _ in range(warm):
+            s.step()
+        torch.cuda.synchronize(device)
+        ts = time.perf_counter()
+        for _ in range(n):
+            s.step()
+        torch.cuda.synchronize(device)
+        s.check()
+        return (time.perf_counter() - ts) / n
+
+    blip2 = sim.blip2
+
+    def leg_small():
+        if blip2 is None:
+            return
+        for e_small in ((128, 8, 1) if args.envs != 128 else (8, 1)):
+            small = BatchedEpisodes(e_small, blip2=blip2, **common)
+            small.fast_forward(args.preroll)
+            dt = timed(small, 3, 20)
+            side[f"envs_per_gpu={e_small}" + (" (configs[3] per-GPU geometry)" if e_small == 8 else
+                                             " (configs[1])" if e_small == 1 else "")] = {
+                "value": round(e_small / dt, 2), "unit": "env-steps/s", "ms_per_step": round(dt * 1e3, 3)}
+            del small
+
+    def leg_cfg5():
+        # BASELINE configs[4] per GPU: 16 envs, 1280x720, value map synchronised with the explored area (full-map mode):
+        # north_star's "HBM-bound map-fusion stress".  With BLIP-2 (env-steps/s) and the map kernels' own times.
+        hd = dict(common, height=720, width=1280)
+        s5 = BatchedEpisodes(16, blip2=blip2, use_blip2=blip2 is not None, sync_explored=True, **hd)
+        s5.fast_forward(args.preroll)
+        for _ in range(3):
+            s5.step()
+        _lib.lib().vlfm_profile_enable(1)
+        dt = timed(s5, 0, 20)
+        kms5 = read_kernel_ms()
+        _lib.lib().vlfm_profile_enable(0)
+        stored = count_stored_cells(s5)
+        side["configs[4] per-GPU geometry: 16 envs, 1280x720, explored-area sync"] = {
+            "value": round(16 / dt, 2), "unit": "env-steps/s", "ms_per_step": round(dt * 1e3, 3),
+            "value_map_update": "split (3 launches)" if s5.values.split_update else "single launch",
+            "stored_cells_per_observation": round(stored, 1),
+            "hbm_kernels": map_roofline(kms5, 16, 720, 1280, True, stored, load_pmc()),
+            "all_kernels_ms": {k: round(v, 5) for k, v in kms5.items()}}
+        del s5
+
+    def leg_episode_phases():
+        # how the map kernels' launch times move through a 500-step episode (explored area and contours grow)
+        ph = BatchedEpisodes(min(args.envs, 64), use_blip2=False, **common)
+        table = {}
+        for target in (25, 250, 475):
+            ph.fast_forward(target - 5 - ph.t)
+            _lib.lib().vlfm_profile_enable(1)
+            ph.fast_forward(10)
+            torch.cuda.synchronize(device)
+            table[f"episode steps {target - 5}-{target + 4}"] = {k: round(v, 5) for k, v in read_kernel_ms().items()}
+            _lib.lib().vlfm_profile_enable(0)
+        ph.check()
+        side[f"map kernel launch ms by episode phase, {ph.E} envs"] = table
+        del ph
+
+    def leg_host():
+        # what the rate becomes when the frames arrive as HOST buffers every step (the reference's API hands over
+        # numpy arrays): same workload, depth + rgb uploaded from pinned memory inside the timed region
+        if blip2 is None:
+            return
+        host = BatchedEpisodes(args.envs, blip2=blip2, host_inputs=True, **common)
+        host.fast_forward(min(args.preroll, 20))
+        dt = timed(host, 2, 8)
+        side[f"pcie_inclusive, envs_per_gpu={args.envs}"] = {
+            "value": round(args.envs / dt, 2), "unit": "env-steps/s", "ms_per_step": round(dt * 1e3, 3),
+            "upload_bytes_per_step": int(args.envs * (4 * args.height * args.width + 3 * args.height * args.width))}
+        del host
+
+    def full_step(n_envs, detector, tag, warm, n):
+        from vlfm_amd.pointnav import WrappedPointNavResNetPolicy
+        from vlfm_amd.vlm.sam import MobileSAM
+
+        full = BatchedEpisodes(n_envs, blip2=blip2, detector=detector, sam=MobileSAM(device=device, allow_random_init=True),
+                               select_frontiers=True,
+                               pointnav=WrappedPointNavResNetPolicy(None, device=device, n_envs=n_envs,
+                                                                    discrete_actions=True), **common)
+        full.fast_forward(min(args.preroll, 40))
+        dt = timed(full, warm, n)
+        side[f"configs[2] full step{tag}, envs_per_gpu={n_envs}"] = {
+            "value": round(n_envs / dt, 2), "unit": "env-steps/s", "ms_per_step": round(dt * 1e3, 3),
+            "controller": "PointNav ResNet-18-GN + LSTM, random-init, discrete head",
+            "detector": getattr(detector, "description", detector.weights),
+            "segmenter": "MobileSAM (TinyViT-5M) random-init, 1 box for every 4th env-step"}
+        del full
+
+    def leg_full():
+        if blip2 is None:
+            return
+        from vlfm_amd.vlm.yolov7 import YOLOv7
+
+        det = YOLOv7(device=device, allow_random_init=True)
+        for n_envs in (8, 64, 128):
+            full_step(n_envs, det, "", 3, 12 if n_envs > 8 else 20)
+
+    def leg_gdino():
+        # the open-vocabulary detector the config names (what the reference uses for non-COCO targets): GroundingDINO at
+        # its real geometry (HF Swin-T + BERT-base, random-init), HIP MsDeformAttn
+        if blip2 is None:
+            return
+        from vlfm_amd.vlm.grounding_dino import GroundingDINO
+
+        det = GroundingDINO(device=device, allow_random_init=True)
+        for n_envs in (8, 64):
+            full_step(n_envs, det, " with GroundingDINO", 2, 8)
+
+    leg("small batches", leg_small)
+    leg("config 5", leg_cfg5)
+    leg("episode phases", leg_episode_phases)
+    leg("pcie_inclusive", leg_host)
+    if not args.no_full:
+        leg("configs[2] full step", leg_full)
+        leg("configs[2] full step with GroundingDINO", leg_gdino)
+    return side
 
 
 if __name__ == "__main__":

@@ -191,6 +191,22 @@ int vlfm_value_map_update_batched(uint32_t* d_colmax_keys, int width, const doub
                                   int use_max_confidence, int fusion_type,
                                   const uint32_t* d_explored_bits, void* d_scratch, void* stream);
 
+/* The same update in ONE launch (what ValueMapBatch uses): every workgroup rasterises the depth-profile polygon of its
+ * observation into LDS itself, so no visibility plane goes through HBM and no scratch is needed.
+ *   d_written_bits [n_envs][S][ceil(S/32)] bit plane, zero at reset, owned by the caller and maintained by this call:
+ *              bit = the cell has received a confidence.  Required with d_explored_bits (NULL otherwise): the full-map
+ *              half of _fuse_new_data (value_map.py:369-375) then clears exactly the cells in (written & ~explored) --
+ *              no call to vlfm_value_map_mask_unexplored_batched.  Observations of one call must belong to distinct
+ *              environment slots.
+ *   d_counters [n] int32, zero on entry and zero again on exit (hand-over of the column-max key buffer). */
+int vlfm_value_map_update_fused_batched(uint32_t* d_colmax_keys, int width, const double* d_tan,
+                                        const float* d_template, const uint32_t* d_template_bits, int template_size,
+                                        const vlfm_vm_pose* d_pose, const double* d_values, int n,
+                                        float* d_conf, float* d_value, int map_size, int channels, int pixels_per_meter,
+                                        double min_depth, double max_depth, int use_max_confidence, int fusion_type,
+                                        const uint32_t* d_explored_bits, uint32_t* d_written_bits, int32_t* d_counters,
+                                        void* stream);
+
 /* Full-map half of _fuse_new_data when an obstacle map is attached (value_map.py:369-375): conf = value = 0 wherever
  * explored == 0, over rows [row_lo, row_hi) of the listed environment slots.  The reference sweeps the whole map; rows
  * that no update window has ever touched are zero already, so a host that tracks the union of its update windows may

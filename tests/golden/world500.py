@@ -57,11 +57,11 @@ WAYPOINTS = [(0.6, 2.0), (3.4, 2.0), (5.4, 2.0), (6.9, 3.9), (8.9, 4.2), (8.9, 7
              (8.6, -5.9), (9.2, -5.7), (9.2, -2.2), (5.4, -2.0), (3.4, -2.0), (3.0, -0.6), (0.0, 0.0)]
 
 
-def wall_profile(x: float, y: float, k: int) -> np.ndarray:
-    """(W,) f32 depth along the optical axis of the nearest box face per image column (inf where nothing is hit)."""
-    fx = camera_intrinsics(W)[0]
+def wall_profile(x: float, y: float, k: int, width: int = W) -> np.ndarray:
+    """(width,) f32 depth along the optical axis of the nearest box face per image column (inf where nothing is hit)."""
+    fx = camera_intrinsics(width)[0]
     c, s = HEADINGS[k]
-    m = -(np.arange(W, dtype=np.float64) - W // 2) / fx        # geometry_utils.py:216-236: y_cam = -(u - W//2) z / fx
+    m = -(np.arange(width, dtype=np.float64) - width // 2) / fx        # geometry_utils.py:216-236: y_cam = -(u - W//2) z / fx
     dx, dy = (c - s * m)[:, None], (s + c * m)[:, None]        # world direction of (1, m): parameter t == z
     tiny = 1e-12
     dx = np.where(np.abs(dx) < tiny, tiny, dx)
@@ -74,9 +74,9 @@ def wall_profile(x: float, y: float, k: int) -> np.ndarray:
     return np.where(hit, tmin, np.inf).min(axis=1).astype(np.float32)
 
 
-def depth_from_profile(wall: np.ndarray) -> np.ndarray:
-    fy = camera_intrinsics(W)[1]
-    rows = np.arange(H)[:, None] - H // 2
+def depth_from_profile(wall: np.ndarray, height: int = H) -> np.ndarray:
+    fy = camera_intrinsics(len(wall))[1]
+    rows = np.arange(height)[:, None] - height // 2
     floor = np.where(rows > 0, CAMERA_HEIGHT * fy / np.maximum(rows, 1e-9), np.inf)
     d = np.minimum(wall.astype(np.float64)[None, :], floor)
     return np.clip((d - MIN_DEPTH) / (MAX_DEPTH - MIN_DEPTH), 1e-3, 1.0).astype(np.float32)

@@ -78,7 +78,7 @@ def test_yolov7_pipeline(gpu_device):
     from vlfm_amd.vlm.coco_classes import COCO_CLASSES
     from vlfm_amd.vlm.yolov7 import YOLOv7, YOLOv7Client
 
-    model = YOLOv7(device=gpu_device, width=16)
+    model = YOLOv7(device=gpu_device, width=16, allow_random_init=True)
     with torch.no_grad():   # make the random net emit confident boxes
         for d in model.model.detect:
             d.bias.fill_(0.0)
@@ -105,7 +105,7 @@ def test_yolov7_pipeline(gpu_device):
                                     nms_fn=lambda bx, s, t, m: torch.from_numpy(ref_nms(bx.numpy(), s.numpy(), t))[:m])
     for x, y in zip(a, b):
         assert torch.equal(x.cpu(), y)
-    c = YOLOv7Client(port=12184, device=gpu_device, width=16)
+    c = YOLOv7Client(port=12184, device=gpu_device, width=16, allow_random_init=True)
     assert isinstance(c.predict(imgs[0]).to_json()["phrases"], list)
 
 
@@ -147,7 +147,7 @@ def test_grounding_dino_wrapper(gpu_device):
 def test_mobile_sam_wrapper(gpu_device):
     from vlfm_amd.vlm.sam import MobileSAM, MobileSAMClient
 
-    sam = MobileSAM(device=gpu_device)
+    sam = MobileSAM(device=gpu_device, allow_random_init=True)
     rng = np.random.default_rng(8)
     img = rng.integers(0, 256, size=(480, 640, 3), dtype=np.uint8)
     mask = sam.segment_bbox(img, [100, 120, 400, 380])
@@ -157,7 +157,7 @@ def test_mobile_sam_wrapper(gpu_device):
     masks = sam.segment_bboxes(imgs, boxes)
     assert masks.shape == (2, 2, 480, 640) and masks.dtype == torch.bool
     assert np.array_equal(masks[0, 0].cpu().numpy(), mask)              # batched == single
-    c = MobileSAMClient(port=12183, device=gpu_device)
+    c = MobileSAMClient(port=12183, device=gpu_device, allow_random_init=True)
     assert c.segment_bbox(img, [100, 120, 400, 380]).shape == (480, 640)
 
 
@@ -179,3 +179,83 @@ def test_ms_deform_attn_matches_hf_pytorch_path(gpu_device):
     got = det_ops.ms_deform_attn(value.to(gpu_device), shapes, start.to(gpu_device), loc.to(gpu_device), w.to(gpu_device)).cpu()
     assert got.shape == want.shape == (B, Q, heads * D)
     assert torch.allclose(got, want, atol=1e-5, rtol=1e-5), float((got - want).abs().max())
+
+
+def test_yolov7_torchscript_weights_path_and_no_silent_fallback(gpu_device, tmp_path):
+    """The weights route of YOLOv7 (yolov7.py:35-38 in the reference): a TorchScript export of the detector whose output is
+    the inference tensor [B, N, 85].  Exercised with a traced stand-in: loaded through ``weights=`` it must give the same
+    detections as the eager module; a missing path, a non-TorchScript file or no weights at all must raise."""
+    from vlfm_amd.vlm.yolov7 import YOLOv7, YoloV7E6EClassNet
+
+    torch.manual_seed(3)
+    with torch.device(gpu_device):
+        net = YoloV7E6EClassNet(width=16).eval()
+    with torch.no_grad():   # make some candidates pass the confidence threshold
+        for m in net.detect:
+            m.bias.view(3, -1)[:, 4] += 6.0
+    example = torch.rand(1, 3, 448, 640, device=gpu_device)
+    path = str(tmp_path / "stand_in.torchscript.pt")
+    torch.jit.trace(net, example).save(path)
+    loaded = YOLOv7(weights=path, device=gpu_device, half_precision=False)
+    assert loaded.weights == f"torchscript:{path}"
+    eager = YOLOv7(device=gpu_device, width=16, allow_random_init=True, half_precision=False)
+    eager.model = net
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    a, b = loaded.predict(img), eager.predict(img)
+    assert a.num_detections == b.num_detections and a.num_detections > 0
+    assert torch.allclose(a.boxes, b.boxes, atol=1e-5) and a.phrases == b.phrases
+    assert "conv GFLOPs" in eager.description and eager.stand_in_gflops > 0
+    with pytest.raises(FileNotFoundError):
+        YOLOv7(weights=str(tmp_path / "nope.pt"), device=gpu_device)
+    bogus = tmp_path / "pickled.pt"
+    torch.save({"model": "not torchscript"}, str(bogus))
+    with pytest.raises(ValueError, match="TorchScript"):
+        YOLOv7(weights=str(bogus), device=gpu_device)
+    with pytest.raises(ValueError, match="allow_random_init"):
+        YOLOv7(device=gpu_device)
+
+
+def test_detectors_and_segmenter_refuse_unusable_weights(gpu_device, tmp_path):
+    from vlfm_amd.vlm.grounding_dino import GroundingDINO
+    from vlfm_amd.vlm.sam import MobileSAM
+
+    with pytest.raises(ValueError, match="allow_random_init"):
+        GroundingDINO(device=gpu_device)
+    pth = tmp_path / "groundingdino_swint_ogc.pth"
+    torch.save({"model": {}}, str(pth))
+    with pytest.raises(ValueError, match="convert_grounding_dino_to_hf"):
+        GroundingDINO(config_path="GroundingDINO_SwinT_OGC.py", weights_path=str(pth), device=gpu_device)
+    with pytest.raises(FileNotFoundError):
+        GroundingDINO(weights_path=str(tmp_path / "missing.pth"), device=gpu_device)
+    with pytest.raises(ValueError, match="allow_random_init"):
+        MobileSAM(device=gpu_device)
+    with pytest.raises(FileNotFoundError):
+        MobileSAM(sam_checkpoint=str(tmp_path / "mobile_sam.pt"), device=gpu_device)
+
+
+def test_mobile_sam_loads_a_checkpoint_and_matches_the_oracle(gpu_device, tmp_path):
+    """sam.py:35-38: ``sam_checkpoint`` must load.  A synthetic mobile_sam.pt (the file's keys and shapes) goes through the
+    constructor; the full segment_bbox pipeline on the GPU (HIP preprocessing, TinyViT, box prompt, decoder, two bilinear
+    resizes, threshold) is compared with the oracle's network fed the same preprocessed pixels."""
+    from oracle import ref_mobile_sam as ref
+    from vlfm_amd.vlm import ops
+    from vlfm_amd.vlm.sam import MobileSAM
+
+    sd = ref.synthetic_checkpoint(11)
+    path = str(tmp_path / "mobile_sam.pt")
+    torch.save(sd, path)
+    sam = MobileSAM(sam_checkpoint=path, device=gpu_device)
+    assert "mobile_sam.pt" in sam.weights
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    box = [192, 144, 448, 384]
+    got = sam.segment_bbox(img, box)
+    pix, (oh, ow) = ops.preprocess_sam(torch.from_numpy(img).to(gpu_device)[None])
+    boxes_1024 = torch.tensor([box], dtype=torch.float32) * torch.tensor([ow / 640, oh / 480, ow / 640, oh / 480])
+    low = ref.predict_low_res(sd, pix.float().cpu(), boxes_1024)[None]
+    m = torch.nn.functional.interpolate(low, (1024, 1024), mode="bilinear", align_corners=False)[..., :oh, :ow]
+    want = (torch.nn.functional.interpolate(m, (480, 640), mode="bilinear", align_corners=False) > 0)[0, 0].numpy()
+    assert got.shape == want.shape == (480, 640)
+    assert (got != want).mean() <= 2e-3, (got != want).mean()    # fp32 on both sides; only logits within ~1e-4 of 0 may flip
+    assert 0.02 < want.mean() < 0.98

@@ -74,3 +74,32 @@ def test_shard_helpers():
     assert [D.owner_of(e, 16) for e in (0, 15, 16, 127)] == [0, 0, 1, 7]
     t, v = D.reduce_metrics(1.25, [3.0, 4.0], "cpu")                     # single process: identity
     assert t == 1.25 and v == [3.0, 4.0]
+
+
+def test_bench_launches_its_own_ranks_dry_run():
+    """`python bench.py --gpus 2` with no torchrun environment must re-execute itself under torch.distributed.run with two
+    ranks (not silently run one): the dry run goes through exactly that launcher, the process-group init, the barriers and
+    the MAX/SUM metric all-reduces of the real benchmark, with gloo standing in for RCCL on this CPU-only box."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["CUDA_VISIBLE_DEVICES"] = env["HIP_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3",
+                        "--envs", "4"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                                      # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["dry_run"] is True
+    assert out["global_envs"] == 8 and out["env_id_checksum"] == sum(range(8))   # both shards took part in the SUM
+
+
+def test_bench_refuses_a_rank_count_that_does_not_match_gpus():
+    import subprocess
+
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999",
+               CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True,
+                       text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr

@@ -183,3 +183,42 @@ def test_fill_small_holes_batched_and_clean_frames(gpu_device):
     for e in range(3):
         assert np.array_equal(obst[e], refs[e]._map.astype(bool)), f"slot {e}"
         assert np.array_equal(batch.explored[e].cpu().numpy().astype(bool), refs[e].explored_area.astype(bool))
+
+
+def _world500_frames(n):
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import world500 as w5
+
+    return [(d, tf) for _, d, tf, _ in w5.episode(w5.plan_actions()[:n])]
+
+
+@pytest.mark.parametrize("caps", [dict(CAP_FRONTIERS=2), dict(CAP_PTS=96), dict(CAP_CONTOURS=2)])
+def test_scratch_capacity_overflow_raises_instead_of_a_silent_wrong_map(gpu_device, caps):
+    """CAP_PTS / CAP_CONTOURS / CAP_FRONTIERS are fixed scratch sizes: when a step needs more (here: deliberately tiny
+    capacities in a world with a dozen frontiers) the frontier read-back of that step must raise, whichever kernel of the
+    explore pipeline (fog of war, component selection, frontier extraction) ran out."""
+    import torch
+
+    from vlfm_amd.mapping.obstacle_map import ObstacleMapBatch
+
+    Tiny = type("Tiny", (ObstacleMapBatch,), caps)
+    ob = Tiny(1, min_height=0.61, max_height=0.88, agent_radius=0.18, area_thresh=1.5, device=gpu_device)
+    with pytest.raises(RuntimeError, match="capacity"):
+        for depth, tf in _world500_frames(40):
+            ob.ingest(torch.from_numpy(depth[None]).to(gpu_device), tf[None], MIN_DEPTH, MAX_DEPTH, FX, FY)
+            ob.update_after_ingest(tf[None], MAX_DEPTH, FOV)
+            ob.frontiers_px()
+
+
+def test_harness_surfaces_off_map_obstacle_points_at_episode_end(gpu_device):
+    """A 10 m x 10 m map (size 200) is too small for 5 m of depth range around a moving agent: the scatter flags the
+    reference's IndexError (obstacle_map.py:101); the batched harness must raise it no later than the episode end."""
+    from vlfm_amd.harness import BatchedEpisodes
+
+    sim = BatchedEpisodes(2, device=gpu_device, use_blip2=False, map_size=200, episode_len=25)
+    with pytest.raises(IndexError):
+        for _ in range(26):
+            sim.step()

@@ -103,3 +103,60 @@ def test_config5_hd_sync_invariants(gpu_device):
         assert float(vb.value[..., 0][~expl].abs().max()) == 0.0
     assert (vb.conf > 0).any() and bool(ob.explored.bool().any())
     ob.check_status()
+
+
+def test_config5_hd_sync_16_envs_against_the_oracle(gpu_device):
+    """BASELINE configs[4] geometry per GPU for real: 1280x720 depth, 16 environments in ONE batch, value map synchronised
+    with the obstacle map's explored area (value_map.py:369-375 -- the full-map mode), 20 steps in the rooms-and-pillars
+    world of tests/golden/world500.py (environment e walks the tour from its 30e-th pose); slots 0, 7 and 15 are checked
+    against RefValueMap(obstacle_map=RefObstacleMap) fed the same frames: planes and frontiers bit-exact every step,
+    confidence / value maps within 1e-4 with identical support."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import world500 as w5
+    from oracle.ref_obstacle_map import RefObstacleMap
+    from oracle.ref_value_map import RefValueMap
+    from vlfm_amd.mapping import ObstacleMapBatch, ValueMapBatch
+
+    E, steps, H, W = 16, 20, 720, 1280
+    fx, fy, fov = camera_intrinsics(W)
+    probe = [0, 7, 15]
+    poses = w5.integrate(w5.plan_actions())
+    ob = ObstacleMapBatch(E, device=gpu_device, **KW)
+    vb = ValueMapBatch(E, 1, use_max_confidence=False, device=gpu_device, explored_bits=ob.explored_bits)
+    refs = {}
+    for e in probe:
+        rom = RefObstacleMap(**KW)
+        refs[e] = (rom, RefValueMap(1, use_max_confidence=False, obstacle_map=rom))
+    rng = np.random.default_rng(5)
+    worst, n_frontiers = 0.0, 0
+    for t in range(steps):
+        at = [poses[30 * e + t] for e in range(E)]
+        depth = np.stack([w5.depth_from_profile(w5.wall_profile(x, y, k, W), H) for (x, y, k) in at])
+        tf = np.stack([w5.tf_of(x, y, k) for (x, y, k) in at])
+        vals = rng.uniform(0.15, 0.45, (E, 1))
+        d = torch.from_numpy(depth).to(gpu_device)
+        keys = ob.ingest(d, tf, MIN_DEPTH, MAX_DEPTH, fx, fy, want_colmax=True)
+        ob.update_after_ingest(tf, MAX_DEPTH, fov)
+        vb.update(vals, None, tf, MIN_DEPTH, MAX_DEPTH, fov, colmax=keys)
+        fr = ob.frontiers_px()
+        obst = ob._unpack(ob.obstacle_bits)
+        for e in probe:
+            rom, rvm = refs[e]
+            rom.update_map(depth[e].copy(), tf[e], MIN_DEPTH, MAX_DEPTH, fx, fy, fov)
+            rvm.update_map(vals[e], depth[e].copy(), tf[e], MIN_DEPTH, MAX_DEPTH, fov)
+            where = f"slot {e} step {t}"
+            assert np.array_equal(obst[e].cpu().numpy().astype(bool), rom._map.astype(bool)), where
+            assert np.array_equal(ob.explored[e].cpu().numpy().astype(bool), rom.explored_area.astype(bool)), where
+            assert np.array_equal(fr[e].reshape(-1, 2), np.asarray(rom._frontiers_px, np.float64).reshape(-1, 2)), where
+            conf, val = vb.conf[e].cpu().numpy(), vb.value[e].cpu().numpy()
+            assert np.array_equal(conf > 0, rvm._map > 0), where
+            ec, ev = np.abs(conf - rvm._map).max(), np.abs(val - rvm._value_map).max()
+            assert ec <= 1e-4 and ev <= 1e-4, (where, ec, ev)
+            worst = max(worst, float(ec), float(ev))
+            n_frontiers += len(rom._frontiers_px)
+    ob.check_status()
+    assert all(refs[e][0].explored_area.sum() > 3000 for e in probe) and n_frontiers > 60
+    print(f"config 5 (16 x 1280x720, explored-area sync): max abs deviation over 20 steps = {worst:.3e}")

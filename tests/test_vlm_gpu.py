@@ -79,7 +79,7 @@ def test_blip2_client_signature_and_full_geometry(gpu_device):
     """BLIP2ITMClient(port).cosine(image, txt) -> float at the real ViT-g/14 geometry (random weights)."""
     from vlfm_amd.vlm.blip2itm import BLIP2ITMClient
 
-    client = BLIP2ITMClient(port=12182, device=gpu_device)
+    client = BLIP2ITMClient(port=12182, device=gpu_device, allow_random_init=True)
     rng = np.random.default_rng(0)
     img = rng.integers(0, 256, size=(480, 640, 3), dtype=np.uint8)
     c = client.cosine(img, "Seems like there is a target_object ahead.".replace("target_object", "bed"))
@@ -166,7 +166,7 @@ def test_vit_fast_path_full_geometry_vs_plain(gpu_device):
     PyTorch path on the same f16 weights."""
     from vlfm_amd.vlm.blip2itm import BLIP2ITM
 
-    m = BLIP2ITM(device=gpu_device).model
+    m = BLIP2ITM(device=gpu_device, allow_random_init=True).model
     g = torch.Generator(device=gpu_device).manual_seed(2)
     with torch.no_grad():
         for n, p in m.named_parameters():
@@ -225,3 +225,47 @@ def test_qformer_split_kv_projection_is_f32_grade(gpu_device):
     want_k = torch.nn.functional.linear(tokens16.double(), cross[0].key.weight.detach().double().cpu(),
                                         cross[0].key.bias.detach().double().cpu())
     assert (k.double().cpu() - want_k).abs().max() <= 2e-5
+
+
+def test_blip2_full_geometry_fp16_hip_path_vs_fp32_on_the_gpu(gpu_device):
+    """ViT-g/14 + Q-Former at the REAL geometry, batch 2: the product path (f16 ViT with the HIP attention / LayerNorm
+    kernels and deferred biases, f32 Q-Former with the split K/V projections, HIP ITC head) against the plain PyTorch graph
+    of the same weights evaluated entirely in fp32 on the GPU.  Bar: |cosine difference| <= 5e-3."""
+    from vlfm_amd.vlm import ops
+    from vlfm_amd.vlm.blip2itm import BLIP2ITM, Blip2ITCModel, blip_caption
+
+    fast = BLIP2ITM(device=gpu_device, allow_random_init=True, seed=7)
+    fast.strict_hip_attention = True
+    g = torch.Generator(device=gpu_device).manual_seed(4)
+    with torch.no_grad():   # random-init at 0.02 gives near-degenerate cosines: spread the weights, add biases
+        for n, p in fast.model.named_parameters():
+            if p.dim() > 1:
+                p.mul_(2.5)
+            elif "norm" not in n.lower():
+                p.copy_((torch.randn(p.shape, generator=g, device=gpu_device) * 0.05).to(p.dtype))
+    fast.model.weights_changed()
+    for blk in fast.model.blocks:
+        blk.pack_heads()
+    fast._text_cache.clear()
+    fast._proj_t = None
+    with torch.device(gpu_device):
+        ref = Blip2ITCModel(fast.cfg)
+    with torch.no_grad():
+        for (n1, p1), (n2, p2) in zip(fast.model.named_parameters(), ref.named_parameters()):
+            assert n1 == n2
+            p2.copy_(p1.float())   # the f16 ViT weights are exactly representable: both sides hold the same numbers
+    ref.eval()
+    ref.deferred_bias = False
+    ref.split_kv = False
+    rng = np.random.default_rng(1)
+    imgs = torch.from_numpy(rng.integers(0, 256, size=(2, 480, 640, 3), dtype=np.uint8)).to(gpu_device)
+    txt = "Seems like there is a potted plant ahead."
+    got = fast.cosine_batch(imgs, [txt]).float().cpu()
+    assert fast.attention_path == "hip"
+    pix = ops.preprocess_rgb(imgs, fast.cfg.image_size, torch.float32)
+    ids = torch.tensor([fast.tokenizer(blip_caption(txt))], device=gpu_device)
+    with torch.inference_mode():
+        want = ref.itc_reference_head(ref.query_features(ref.vision_tokens(pix)), ref.text_feature(ids)).float().cpu()
+    print(f"BLIP-2 full geometry: f16 HIP path {got.tolist()} vs fp32 {want.tolist()}")
+    assert float(want.abs().max()) > 1e-3 and float((want[0] - want[1]).abs()) > 1e-4   # not a degenerate comparison
+    assert torch.allclose(got, want, atol=5e-3, rtol=0), (got, want)

@@ -5,7 +5,7 @@ import torch
 torch.set_num_threads(1)  # idle OpenMP spinners exhaust the container's CPU quota
 from vlfm_amd.vlm.grounding_dino import GroundingDINO
 dev = torch.device("cuda:0")
-g = GroundingDINO(device=dev)
+g = GroundingDINO(device=dev, allow_random_init=True)
 cap = "chair . bed . potted plant . toilet . tv . couch ."
 for B in (int(a) for a in (sys.argv[1:] or ["8"])):
     img = torch.randint(0, 256, (B, 480, 640, 3), dtype=torch.uint8, device=dev)

@@ -25,12 +25,13 @@ def per_kernel(db):
     return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
 
 
-def main(E, W, H):
+def main(E, W, H, sync=False):
     out_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     out = json.load(open(out_path)) if os.path.exists(out_path) else {}
     fetch = per_kernel(os.path.join(ROOT, "gpurun_out", "pmc_fetch", "pmc_results.db"))
     write = per_kernel(os.path.join(ROOT, "gpurun_out", "pmc_write", "pmc_results.db"))
-    names = {"value_map_fuse_kernel": "value_map_fuse_kernel", "depth_ingest_kernel<false>": "depth_ingest_kernel",
+    names = {"value_map_update_fused_kernel": "value_map_update_fused_kernel",
+             "value_map_fuse_kernel": "value_map_fuse_kernel", "depth_ingest_kernel<false>": "depth_ingest_kernel",
              "depth_ingest_kernel<true>": "depth_ingest_scatter_kernel", "mask_unexplored_kernel": "mask_unexplored_kernel",
              "visible_mask_kernel": "visible_mask_kernel"}
     for frag, label in names.items():
@@ -45,10 +46,12 @@ def main(E, W, H):
                else "none applied (4 B/lane RMW: uncalibrated; x2 is the upper bound)",
                "bytes_per_launch": round((2 * fetch_b if wide else fetch_b) + write_b),
                "bytes_per_launch_upper": round(2 * fetch_b + write_b)}
-        out[f"{label}@E={E},{W}x{H}"] = rec
+        out[f"{label}@E={E},{W}x{H}" + (",sync" if sync else "")] = rec
         print(label, rec)
     json.dump(out, open(out_path, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]) if len(sys.argv) > 1 else 128, 640, 480)
+    a = sys.argv[1:]
+    main(int(a[0]) if len(a) > 0 else 256, int(a[1]) if len(a) > 1 else 640, int(a[2]) if len(a) > 2 else 480,
+         sync=len(a) > 3 and a[3] != "")

@@ -5,7 +5,7 @@ import torch
 from vlfm_amd.harness import BatchedEpisodes
 from vlfm_amd.vlm.blip2itm import BLIP2ITM
 dev = torch.device("cuda:0"); torch.set_num_threads(1)
-blip = BLIP2ITM(device=dev)
+blip = BLIP2ITM(device=dev, allow_random_init=True)
 for E in (1, 8, 16):
     for graph in (False, True):
         sim = BatchedEpisodes(E, device=dev, blip2=blip, graph_blip2=graph)

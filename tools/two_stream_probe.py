@@ -6,7 +6,7 @@ import torch
 from vlfm_amd.vlm.blip2itm import BLIP2ITM
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 dev = torch.device("cuda:0")
-m = BLIP2ITM(device=dev).model
+m = BLIP2ITM(device=dev, allow_random_init=True).model
 pat = torch.randn(E, 256, 588, device=dev, dtype=torch.float16)
 def fwd(x):
     return m.query_features(m.vision_tokens(x))

@@ -5,7 +5,7 @@ import torch
 from vlfm_amd.vlm.blip2itm import BLIP2ITM
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 dev = torch.device("cuda:0")
-blip = BLIP2ITM(device=dev)
+blip = BLIP2ITM(device=dev, allow_random_init=True)
 m = blip.model
 with torch.no_grad():
     for n, p in m.named_parameters():

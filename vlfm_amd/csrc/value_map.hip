@@ -214,49 +214,20 @@ __device__ inline bool fuse_cell(const UpdateArgs& a, float nw, float old, const
     return true;
 }
 
+// The fuse of one 8-row tile of the template window by 4 wavefronts (see the comment above): shared by the split path
+// (value_map_fuse_kernel) and the single-launch path (value_map_update_fused_kernel).  `written`, when given, is the
+// environment's bit plane of cells that hold (or may hold) a non-zero confidence: every cell stored here gets its bit.
 template <int C_STATIC>
-__global__ __launch_bounds__(256) void value_map_fuse_kernel(UpdateArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned* vis = reinterpret_cast<unsigned*>(smem);
+__device__ inline void fuse_tile(const UpdateArgs& a, const vlfm_vm_pose& pose, const unsigned* vis, const int4 box,
+                                 int row_begin, int tid, unsigned* written) {
     const int T = a.T, S = a.S;
     const int words = (T + 31) >> 5;
-    const int obs = blockIdx.y;
-    const int row_begin = blockIdx.x * ROWS_PER_TILE;
-    const int tid = threadIdx.x;
-    // Independent loads first, branches afterwards: pose, the cone's dst bounding box and this thread's share of the
-    // visibility plane are all in flight together (one memory round trip instead of three).
-    const unsigned* blk = a.visible + (size_t)obs * a.vis_stride;
-    const uint4* vsrc = reinterpret_cast<const uint4*>(blk + VIS_META_WORDS);
-    const int n_vec = (a.vis_stride - VIS_META_WORDS) / 4;
-    constexpr int VEC_PER_THREAD = 2;  // 2 x 256 x 16 B = 8 KB >= 5.6 KB (T = 201); larger templates loop below
-    uint4 vreg[VEC_PER_THREAD];
-#pragma unroll
-    for (int k = 0; k < VEC_PER_THREAD; k++) {
-        const int i = tid + k * 256;
-        vreg[k] = vsrc[i < n_vec ? i : 0];
-    }
-    const vlfm_vm_pose pose = a.pose[obs];
-    const int4 box = *reinterpret_cast<const int4*>(blk);  // dst bounding box of the visible cone (visible_mask_kernel)
-    // whole tile clipped away by place_img_in_img, or outside the cone: no non-zero tap
-    if (pose.row0 + min(row_begin + ROWS_PER_TILE, T) <= 0 || pose.row0 + row_begin >= S) return;
-    if (row_begin > box.y || row_begin + ROWS_PER_TILE <= box.x || box.z > box.w) return;
-    {
-        uint4* dst = reinterpret_cast<uint4*>(vis);
-#pragma unroll
-        for (int k = 0; k < VEC_PER_THREAD; k++) {
-            const int i = tid + k * 256;
-            if (i < n_vec) dst[i] = vreg[k];
-        }
-        for (int i = tid + VEC_PER_THREAD * 256; i < n_vec; i += 256) dst[i] = vsrc[i];
-    }
-    __syncthreads();
-
     const int C = C_STATIC > 0 ? C_STATIC : a.C;
     float* conf = a.conf + (size_t)pose.env * S * S;
     float* value = a.value + (size_t)pose.env * S * S * C;
     const int ex_stride = (S + 31) >> 5;
     const unsigned* explored = a.explored ? a.explored + (size_t)pose.env * S * ex_stride : nullptr;
-    const double* vals = a.values + (size_t)obs * C;
+    const double* vals = a.values + (size_t)pose.reserved * C;
     const float* __restrict__ tmpl = a.tmpl;
     const int lane = tid & 63, wave = tid >> 6;
 
@@ -316,14 +287,30 @@ __global__ __launch_bounds__(256) void value_map_fuse_kernel(UpdateArgs a) {
         // ---- phase C: fuse and write back
 #pragma unroll
         for (int k = 0; k < ROWS_PER_WAVE; k++) {
-            if (!act[k]) continue;
-            if (C_STATIC == 1) {
+            bool stored = false;
+            if (act[k] && C_STATIC == 1) {
                 float c_out, v_out;
                 if (fuse_cell<1>(a, nw[k], old[k], &oldv1[k], vals, c_out, &v_out)) {
                     conf[cell[k]] = c_out;
                     value[cell[k]] = v_out;
+                    stored = true;
                 }
-            } else {
+            }
+            if (written && C_STATIC == 1) {
+                // lanes are consecutive map columns: the stores of this row form at most three 32-cell words of the plane;
+                // the lowest storing lane of each word ORs the word's bits in, and only when the plane does not show them yet
+                const unsigned long long m = __ballot(stored);
+                if (stored) {
+                    const int lo = lane - (mc & 31);  // lane that holds bit 0 of this lane's word (may lie outside the wave)
+                    const unsigned wm = lo >= 0 ? (unsigned)(m >> lo) : (unsigned)(m << (-lo));
+                    if ((mc & 31) == __builtin_ctz(wm)) {
+                        unsigned* wp = written + (size_t)(pose.row0 + row_begin + k) * ex_stride + (mc >> 5);
+                        if ((*wp & wm) != wm) atomicOr(wp, wm);
+                    }
+                }
+            }
+            if (!act[k] || C_STATIC == 1) continue;
+            {
                 // the keep/skip decision and the new confidence do not depend on the channel
                 float c_out = 0.0f;
                 bool wrote = false;
@@ -334,9 +321,268 @@ __global__ __launch_bounds__(256) void value_map_fuse_kernel(UpdateArgs a) {
                     if (!wrote) break;
                     value[cell[k] * C + c] = nv;
                 }
-                if (wrote) conf[cell[k]] = c_out;
+                if (wrote) {
+                    conf[cell[k]] = c_out;
+                    if (written) atomicOr(written + (size_t)(pose.row0 + row_begin + k) * ex_stride + (mc >> 5), 1u << (mc & 31));
+                }
             }
         }
+    }
+}
+
+template <int C_STATIC>
+__global__ __launch_bounds__(256) void value_map_fuse_kernel(UpdateArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned* vis = reinterpret_cast<unsigned*>(smem);
+    const int T = a.T, S = a.S;
+    const int words = (T + 31) >> 5;
+    const int obs = blockIdx.y;
+    const int row_begin = blockIdx.x * ROWS_PER_TILE;
+    const int tid = threadIdx.x;
+    // Independent loads first, branches afterwards: pose, the cone's dst bounding box and this thread's share of the
+    // visibility plane are all in flight together (one memory round trip instead of three).
+    const unsigned* blk = a.visible + (size_t)obs * a.vis_stride;
+    const uint4* vsrc = reinterpret_cast<const uint4*>(blk + VIS_META_WORDS);
+    const int n_vec = (a.vis_stride - VIS_META_WORDS) / 4;
+    constexpr int VEC_PER_THREAD = 2;  // 2 x 256 x 16 B = 8 KB >= 5.6 KB (T = 201); larger templates loop below
+    uint4 vreg[VEC_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < VEC_PER_THREAD; k++) {
+        const int i = tid + k * 256;
+        vreg[k] = vsrc[i < n_vec ? i : 0];
+    }
+    const vlfm_vm_pose pose = a.pose[obs];
+    vlfm_vm_pose pose_obs = pose;
+    pose_obs.reserved = obs;  // fuse_tile reads the observation's values through it
+    const int4 box = *reinterpret_cast<const int4*>(blk);  // dst bounding box of the visible cone (visible_mask_kernel)
+    // whole tile clipped away by place_img_in_img, or outside the cone: no non-zero tap
+    if (pose.row0 + min(row_begin + ROWS_PER_TILE, T) <= 0 || pose.row0 + row_begin >= S) return;
+    if (row_begin > box.y || row_begin + ROWS_PER_TILE <= box.x || box.z > box.w) return;
+    {
+        uint4* dst = reinterpret_cast<uint4*>(vis);
+#pragma unroll
+        for (int k = 0; k < VEC_PER_THREAD; k++) {
+            const int i = tid + k * 256;
+            if (i < n_vec) dst[i] = vreg[k];
+        }
+        for (int i = tid + VEC_PER_THREAD * 256; i < n_vec; i += 256) dst[i] = vsrc[i];
+    }
+    __syncthreads();
+
+    fuse_tile<C_STATIC>(a, pose_obs, vis, box, row_begin, tid, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------ single-launch update
+// ValueMap.update_map for n observations in ONE launch: grid = (G, n), 256 threads.  Every workgroup of an observation
+//   1. turns the column-max keys into the depth-profile polygon and rasterises it into LDS (the same arithmetic as
+//      visible_mask_kernel; G-fold redundant, but LDS-only work of a few microseconds -- what it buys is that no
+//      visibility plane travels through HBM and no second and third launch sit on the step's critical path);
+//   2. (obstacle-map-synchronised mode, value_map.py:369-375) clears its share of the cells that hold a value but are
+//      no longer explored.  Instead of sweeping conf/value (17 MB per environment in the reference's formulation) it
+//      intersects two bit planes: `written` (cells that ever received a confidence; maintained by step 3) and the
+//      obstacle map's `explored` -- 250 KB per environment, and only the cells in (written & ~explored) are touched.
+//      Cells fused in step 3 are explored, cells cleared here are not: the two steps never meet, no ordering is needed;
+//   3. fuses the row tiles g, g + G, ... of the 201 x 201 window (fuse_tile).
+// The last workgroup of an observation to have read the keys hands the key buffer back zeroed (depth ingest's contract).
+struct FusedExtra {
+    unsigned* written;   // [n_envs][S][ceil(S/32)] or null
+    int* counters;       // [n] zero on entry, zero again on exit
+};
+
+constexpr int LONG_EDGE = 24;      // edges longer than this (Chebyshev) are rasterised by the whole workgroup
+constexpr int LONG_EDGE_CAP = 16;
+
+// One long polygon edge, all threads of the workgroup: boundary pixels through the closed form of the 8-connected line
+// iterator (pixel i of the walk has minor offset (2 dy i + dx - 1) / (2 dx) -- checked against the iterative form for
+// every dx, dy <= 260), scanline crossings through xs + (y - y0) * dxdy.  Both endpoints must lie inside the image
+// (no clipping); same bits as raster_edge.
+__device__ inline void raster_edge_coop(const LdsBitmap& bm, int ax, int ay, int bx, int by, int tid, int nth) {
+    {
+        int x0 = ax, y0 = ay, dx = bx - ax, dy = by - ay;
+        if (dx < 0) { dx = -dx; dy = -dy; x0 = bx; y0 = by; }
+        int sy = 1;
+        if (dy < 0) { dy = -dy; sy = -1; }
+        const bool vert = dy > dx;
+        const int major = vert ? dy : dx, minor = vert ? dx : dy;
+        for (int i = tid; i <= major; i += nth) {
+            const int m = major > 0 ? (2 * minor * i + major - 1) / (2 * major) : 0;
+            const int px = vert ? x0 + m : x0 + i;
+            const int py = vert ? y0 + sy * i : y0 + sy * m;
+            bm_or(bm, py, px);
+        }
+    }
+    if (ay == by) return;
+    const long long fax = (long long)ax << XY_SHIFT, fbx = (long long)bx << XY_SHIFT;
+    const long long dxdy = (fbx - fax) / (long long)(by - ay);
+    int y0, y1;
+    long long xs;
+    if (ay < by) { y0 = ay; y1 = by; xs = fax; } else { y0 = by; y1 = ay; xs = fbx; }
+    for (int y = y0 + tid; y < y1; y += nth) {
+        const long long c = xs + (long long)(y - y0) * dxdy;
+        const long long px = c >> XY_SHIFT;
+        if ((c & (XY_ONE - 1)) == 0 && px >= 0 && px < bm.cols) bm_or(bm, y, (int)px);
+        long long first = px + 1;
+        if (first < 0) first = 0;
+        if (first < bm.cols) bm_toggle_local(bm, y, (int)first);
+    }
+}
+
+template <int C_STATIC>
+__global__ __launch_bounds__(256) void value_map_update_fused_kernel(UpdateArgs a, FusedExtra fx) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int T = a.T, W = a.W, S = a.S;
+    const int words = (T + 31) >> 5;
+    const int n_vert = W + 2;
+    unsigned* solid = reinterpret_cast<unsigned*>(smem);
+    unsigned* parity = solid + T * words;      // after the resolve: the visible plane
+    int2* vert = reinterpret_cast<int2*>(parity + T * words + ((2 * T * words) & 1));
+    __shared__ int sh_long[LONG_EDGE_CAP];
+    __shared__ int sh_n_long, sh_last;
+    __shared__ int sh_box[4];
+    __shared__ int4 sh_dbox;
+    const int obs = blockIdx.y, g = blockIdx.x, G = gridDim.x;
+    const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63;
+
+    vlfm_vm_pose pose = a.pose[obs];
+    pose.reserved = obs;  // fuse_tile reads the observation's values through it
+    const int ex_stride = (S + 31) >> 5;
+    // step 2's first loads are independent of everything else: issue them before the raster so that they travel under it
+    unsigned* written = fx.written ? fx.written + (size_t)pose.env * S * ex_stride : nullptr;
+    const int plane_words = S * ex_stride;
+    const int my_word = g * nth + tid;
+    unsigned wr0 = 0u;
+    if (written && a.explored && my_word < plane_words) wr0 = written[my_word];
+
+    LdsBitmap bm;
+    bm.solid = solid; bm.parity = parity; bm.rows = T; bm.cols = T; bm.words = words;
+    for (int i = tid; i < 2 * T * words; i += nth) solid[i] = 0u;
+    if (tid == 0) { sh_n_long = 0; sh_box[0] = T; sh_box[1] = -1; sh_box[2] = T; sh_box[3] = -1; }
+    const unsigned* cm = a.colmax + (size_t)obs * W;
+    for (int i = tid; i < W; i += nth) {
+        const unsigned key = cm[i];
+        const float raw = __uint_as_float((key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key);
+        const float d = __fadd_rn(__fmul_rn(raw, a.depth_scale), a.depth_offset);        // f32 (value_map.py:234)
+        const float xr = __fadd_rn(__fmul_rn(d, a.ppm_f), a.half_t_f);                   // f32 (:248)
+        const double yl = __dadd_rn(__dmul_rn(__dmul_rn((double)d, a.tan_tab[i]), a.ppm_d), a.half_t_d);  // f64 (:242,249)
+        vert[i + 1] = make_int2((int)(long long)yl, (int)(long long)xr);                 // astype(int): truncation
+    }
+    if (tid == 0) {
+        vert[0] = make_int2(0, T - 1);
+        vert[W + 1] = make_int2(T - 1, T - 1);
+    }
+    __syncthreads();
+    // the keys have been read: the last workgroup of this observation to get here zeroes them for the next depth ingest
+    if (tid == 0) {
+        __threadfence();
+        sh_last = atomicAdd(&fx.counters[obs], 1) == G - 1;
+    }
+    for (int i = tid; i < n_vert; i += nth) {
+        const int2 p0 = vert[i == 0 ? n_vert - 1 : i - 1], p1 = vert[i];
+        const int len = max(abs(p1.x - p0.x), abs(p1.y - p0.y));
+        const bool inside = (unsigned)p0.x < (unsigned)T && (unsigned)p0.y < (unsigned)T && (unsigned)p1.x < (unsigned)T &&
+                            (unsigned)p1.y < (unsigned)T;
+        if (len > LONG_EDGE && inside) {
+            const int k = atomicAdd(&sh_n_long, 1);
+            if (k < LONG_EDGE_CAP) { sh_long[k] = i; continue; }
+        }
+        raster_edge(bm, (long long)p0.x << XY_SHIFT, p0.y, (long long)p1.x << XY_SHIFT, p1.y);
+    }
+    __syncthreads();
+    {
+        const int n_long = min(sh_n_long, LONG_EDGE_CAP);
+        for (int k = 0; k < n_long; k++) {
+            const int i = sh_long[k];
+            const int2 p0 = vert[i == 0 ? n_vert - 1 : i - 1], p1 = vert[i];
+            raster_edge_coop(bm, p0.x, p0.y, p1.x, p1.y, tid, nth);
+        }
+    }
+    if (sh_last) {
+        unsigned* cmw = a.colmax + (size_t)obs * W;
+        for (int i = tid; i < W; i += nth) cmw[i] = 0u;
+        if (tid == 0) fx.counters[obs] = 0;
+    }
+    __syncthreads();
+    // resolve (one lane per row) fused with visible = (template > 0) & ~beyond-the-profile, and the source bounding box
+    {
+        int r_lo = T, r_hi = -1, c_lo = T, c_hi = -1;
+        for (int y = tid; y < T; y += nth) {
+            unsigned carry = 0;
+            for (int w = 0; w < words; w++) {
+                const int i = y * words + w;
+                unsigned p = parity[i];
+                p ^= p << 1; p ^= p << 2; p ^= p << 4; p ^= p << 8; p ^= p << 16;
+                if (carry) p = ~p;
+                carry = p >> 31;
+                const unsigned v = a.tmpl_bits[i] & ~(p | solid[i]);
+                parity[i] = v;
+                if (v) {
+                    r_lo = min(r_lo, y); r_hi = max(r_hi, y);
+                    c_lo = min(c_lo, w * 32 + __builtin_ctz(v)); c_hi = max(c_hi, w * 32 + 31 - __builtin_clz(v));
+                }
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            r_lo = min(r_lo, __shfl_xor(r_lo, off, 64)); r_hi = max(r_hi, __shfl_xor(r_hi, off, 64));
+            c_lo = min(c_lo, __shfl_xor(c_lo, off, 64)); c_hi = max(c_hi, __shfl_xor(c_hi, off, 64));
+        }
+        if (lane == 0 && r_hi >= 0) {
+            atomicMin(&sh_box[0], r_lo); atomicMax(&sh_box[1], r_hi); atomicMin(&sh_box[2], c_lo); atomicMax(&sh_box[3], c_hi);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // destination (rotated) bounding box of everything that can receive a non-zero tap (see visible_mask_kernel)
+        int4 m;
+        if (sh_box[1] < 0) {
+            m = make_int4(1, 0, 1, 0);
+        } else {
+            const double a0 = pose.inv_affine[0], a1 = pose.inv_affine[1], a2 = pose.inv_affine[2];
+            const double a3 = pose.inv_affine[3], a4 = pose.inv_affine[4], a5 = pose.inv_affine[5];
+            const double det = a0 * a4 - a1 * a3;
+            double xlo = 1e30, xhi = -1e30, ylo = 1e30, yhi = -1e30;
+            for (int k = 0; k < 4; k++) {
+                const double sx = (k & 1) ? sh_box[3] + 1.0 : sh_box[2] - 1.0, sy = (k & 2) ? sh_box[1] + 1.0 : sh_box[0] - 1.0;
+                const double dx = (a4 * (sx - a2) - a1 * (sy - a5)) / det, dy = (-a3 * (sx - a2) + a0 * (sy - a5)) / det;
+                xlo = fmin(xlo, dx); xhi = fmax(xhi, dx); ylo = fmin(ylo, dy); yhi = fmax(yhi, dy);
+            }
+            if (!(fabs(det) > 1e-9) || !(xlo == xlo) || !(ylo == ylo)) { xlo = ylo = 0; xhi = yhi = T; }
+            m = make_int4(max(0, (int)floor(ylo) - 2), min(T - 1, (int)ceil(yhi) + 2), max(0, (int)floor(xlo) - 2),
+                          min(T - 1, (int)ceil(xhi) + 2));
+        }
+        sh_dbox = m;
+    }
+    // ---- step 2: cells that hold a value but are not explored any more (value_map.py:369-375)
+    if (written && a.explored) {
+        const unsigned* explored = a.explored + (size_t)pose.env * S * ex_stride;
+        float* conf = a.conf + (size_t)pose.env * S * S;
+        const int C = C_STATIC > 0 ? C_STATIC : a.C;
+        float* value = a.value + (size_t)pose.env * S * S * C;
+        for (int i = my_word; i < plane_words; i += G * nth) {
+            const unsigned wr = i == my_word ? wr0 : written[i];
+            if (!wr) continue;
+            unsigned dead = wr & ~explored[i];
+            if (!dead) continue;
+            atomicAnd(&written[i], ~dead);
+            const int row = i / ex_stride, c0 = (i - row * ex_stride) * 32;
+            while (dead) {
+                const int b = __builtin_ctz(dead);
+                dead &= dead - 1u;
+                const size_t cell = (size_t)row * S + c0 + b;
+                conf[cell] = 0.0f;
+                for (int c = 0; c < C; c++) value[cell * C + c] = 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- step 3: rotate + place + fuse, tiles g, g + G, ...
+    const int4 box = sh_dbox;
+    if (box.z > box.w) return;
+    const int tiles = (T + ROWS_PER_TILE - 1) / ROWS_PER_TILE;
+    for (int t = g; t < tiles; t += G) {
+        const int row_begin = t * ROWS_PER_TILE;
+        if (pose.row0 + min(row_begin + ROWS_PER_TILE, T) <= 0 || pose.row0 + row_begin >= S) continue;
+        if (row_begin > box.y || row_begin + ROWS_PER_TILE <= box.x) continue;
+        fuse_tile<C_STATIC>(a, pose, parity, box, row_begin, tid, written);
     }
 }
 
@@ -515,6 +761,51 @@ extern "C" int vlfm_value_map_update_batched(uint32_t* d_colmax_keys, int width,
     else
         VLFM_KLAUNCH(value_map_fuse_kernel<0>, dim3(tiles, n), dim3(256), lds_fuse, (hipStream_t)stream, a);
     return check_launch("value_map_fuse_kernel");
+}
+
+extern "C" int vlfm_value_map_update_fused_batched(uint32_t* d_colmax_keys, int width, const double* d_tan,
+                                                   const float* d_template, const uint32_t* d_template_bits,
+                                                   int template_size, const vlfm_vm_pose* d_pose,
+                                                   const double* d_values, int n, float* d_conf, float* d_value,
+                                                   int map_size, int channels, int pixels_per_meter, double min_depth,
+                                                   double max_depth, int use_max_confidence, int fusion_type,
+                                                   const uint32_t* d_explored_bits, uint32_t* d_written_bits,
+                                                   int32_t* d_counters, void* stream) {
+    if (n == 0) return VLFM_OK;
+    if (!d_colmax_keys || !d_tan || !d_template || !d_template_bits || !d_pose || !d_values || !d_conf || !d_value ||
+        !d_counters || n < 0 || width <= 0 || template_size <= 0 || map_size <= 0 || channels <= 0 || fusion_type < 0 ||
+        fusion_type > 2)
+        return fail(VLFM_ERR_INVALID, "value_map_update_fused_batched: bad argument");
+    if ((d_explored_bits == nullptr) != (d_written_bits == nullptr))
+        return fail(VLFM_ERR_INVALID, "value_map_update_fused_batched: d_explored_bits and d_written_bits go together");
+    UpdateArgs a;
+    a.colmax = reinterpret_cast<unsigned*>(d_colmax_keys); a.tan_tab = d_tan; a.tmpl = d_template;
+    a.tmpl_bits = d_template_bits; a.pose = d_pose; a.values = d_values;
+    a.conf = d_conf; a.value = d_value; a.explored = d_explored_bits;
+    a.W = width; a.T = template_size; a.S = map_size; a.C = channels;
+    a.vis_stride = 0; a.visible = nullptr;
+    a.depth_scale = (float)(max_depth - min_depth);
+    a.depth_offset = (float)min_depth;
+    a.ppm_f = (float)pixels_per_meter;
+    a.half_t_f = (float)(template_size / 2.0);
+    a.ppm_d = (double)pixels_per_meter;
+    a.half_t_d = template_size / 2.0;
+    a.use_max_conf = use_max_confidence; a.fusion = fusion_type;
+    FusedExtra fx{d_written_bits, d_counters};
+    const int T = template_size, words = (T + 31) >> 5;
+    const size_t lds = (size_t)(2 * T * words + ((2 * T * words) & 1)) * 4 + (size_t)(width + 2) * sizeof(int2);
+    if (lds > 64 * 1024) return fail(VLFM_ERR_CAPACITY, "value_map_update_fused_batched: template/width too large for LDS");
+    const int tiles = (T + ROWS_PER_TILE - 1) / ROWS_PER_TILE;
+    // workgroups per observation: ~2048 in flight over all observations, at least 2, at most one per row tile
+    int G = (2048 + n - 1) / n;
+    if (G > tiles) G = tiles;
+    if (G < 2) G = 2;
+    VLFM_TIMED("value_map_update_fused_kernel", stream);
+    if (channels == 1)
+        VLFM_KLAUNCH(value_map_update_fused_kernel<1>, dim3(G, n), dim3(256), lds, (hipStream_t)stream, a, fx);
+    else
+        VLFM_KLAUNCH(value_map_update_fused_kernel<0>, dim3(G, n), dim3(256), lds, (hipStream_t)stream, a, fx);
+    return check_launch("value_map_update_fused_kernel");
 }
 
 extern "C" int vlfm_value_map_mask_unexplored_batched(const vlfm_mask_job* d_jobs, int n, int max_rows,

@@ -9,8 +9,8 @@ per-step hot path of ITMPolicyV2 (vlfm/policy/itm_policy.py:251-261):
                         -> ValueMap.update_map          (itm_policy.py:204-206)            [one launch for all envs]
     _explore            -> ValueMap.sort_waypoints      (itm_policy.py:263-267)            [disc medians per frontier]
 
-Episodes are independent, so multi-GPU scaling is pure sharding (env e -> rank e mod world); the only collective is the
-metric all-reduce in bench.py.
+Episodes are independent, so multi-GPU scaling is pure sharding (contiguous blocks: env e -> rank e // envs_per_rank,
+vlfm_amd/distributed.py); the only collective is the metric all-reduce in bench.py.
 """
 from __future__ import annotations
 
@@ -69,7 +69,7 @@ class BatchedEpisodes:
         if use_blip2 and blip2 is None:
             from .vlm.blip2itm import BLIP2ITM
 
-            self.blip2 = BLIP2ITM(device=self.device)
+            self.blip2 = BLIP2ITM(device=self.device, allow_random_init=True)  # synthetic-episode harness: throughput only
         # small batches are launch-bound: replay the BLIP-2 forward from a captured HIP graph
         self.graph_blip2 = (n_envs <= 4) if graph_blip2 is None else graph_blip2  # measured: +43 % at 1 env, none at 8
         self.stub_rng = np.random.Generator(np.random.PCG64(7 + env_offset))
@@ -147,8 +147,30 @@ class BatchedEpisodes:
             self.pointnav.reset(np.flatnonzero(fresh))
         return self.pointnav.act_on_depth(depth, rt, torch.from_numpy(~fresh))
 
+    def fast_forward(self, n_steps: int) -> None:
+        """Advance every episode by ``n_steps`` MAP-ONLY steps (stub cosines instead of the BLIP-2 forward, no detector /
+        segmenter / controller): brings explored area, obstacle planes and contour lengths to a mid-episode state cheaply
+        before a measurement, instead of timing the empty world of an episode's first steps."""
+        saved = (self.blip2, self.detector, self.sam, self.selectors, self.pointnav)
+        self.blip2 = self.detector = self.sam = self.selectors = self.pointnav = None
+        try:
+            for _ in range(n_steps):
+                self.step()
+        finally:
+            self.blip2, self.detector, self.sam, self.selectors, self.pointnav = saved
+
+    def check(self) -> None:
+        """Raise what the reference would have raised inside the steps since the last check: IndexError for an obstacle
+        point off the map (obstacle_map.py:101; the policy turns it into STOP, base_objectnav_policy.py:157-162), RuntimeError
+        for an exhausted scratch capacity (never a silent wrong map).  Frontier-pipeline overflows already raise on the
+        per-step frontier read-back; this adds the sticky flags of the depth passes.  One small D2H copy + sync: called
+        at every episode end by step() and by the benchmark after its timed region, not per step."""
+        if self.obstacles is not None:
+            self.obstacles.check_status()
+
     def step(self) -> None:
         if self.t and self.t % self.episode_len == 0:
+            self.check()
             self.reset()
         k = self.t % self.depth_pool.shape[0]
         if self.host_inputs:

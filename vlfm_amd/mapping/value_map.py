@@ -213,6 +213,11 @@ class ValueMapBatch:
         self._status = None
         self._ring = None
         self._vis = None
+        # single-launch update (csrc/value_map.hip: value_map_update_fused_kernel) unless VLFM_VM_SPLIT=1 asks for the
+        # three-launch form (mask_unexplored + visible_mask + fuse) it replaced -- kept for A/B measurements
+        self.split_update = os.environ.get("VLFM_VM_SPLIT", "0") == "1"
+        self._written = None   # [n_envs,S,ceil(S/32)] cells that ever received a confidence (explored-synchronised mode)
+        self._counters = None
         self._wp_out = self._wp_host = self._wp_cells = None
 
     # ------------------------------------------------------------------------------------------ helpers
@@ -222,12 +227,16 @@ class ValueMapBatch:
             self.value.zero_()
             self._row_lo[:] = self.size
             self._row_hi[:] = 0
+            if self._written is not None:
+                self._written.zero_()
         else:
             idx = list(env_ids)
             self.conf[idx] = 0
             self.value[idx] = 0
             self._row_lo[idx] = self.size
             self._row_hi[idx] = 0
+            if self._written is not None:
+                self._written[idx] = 0
 
     def _rings(self, n: int):
         if self._ring is None or self._ring.nbytes < max(n, self.n_envs) * 256:
@@ -316,6 +325,28 @@ class ValueMapBatch:
                 ex = self.explored_bits
                 assert ex.dtype == torch.int32 and ex.is_contiguous() and ex.shape[-2] == self.size
                 explored_ptr = ex.data_ptr()
+            if not self.split_update:
+                written_ptr = None
+                if explored_ptr is not None:
+                    if self._written is None:
+                        # conf may already hold values (an obstacle map attached mid-episode): start from conf != 0
+                        self._written = torch.zeros((self.n_envs, self.size, (self.size + 31) // 32), dtype=torch.int32,
+                                                    device=self.device)
+                        if bool((self.conf != 0).any()):
+                            _lib.check(L.vlfm_bits_pack((self.conf != 0).to(torch.uint8).contiguous().data_ptr(),
+                                                        self._written.data_ptr(), self.n_envs, self.size, self.size,
+                                                        _stream_ptr()), "bits_pack")
+                    written_ptr = self._written.data_ptr()
+                if self._counters is None or self._counters.numel() < n:
+                    self._counters = torch.zeros(max(n, self.n_envs), dtype=torch.int32, device=self.device)
+                _lib.check(L.vlfm_value_map_update_fused_batched(
+                    colmax.data_ptr(), W, d_tan.data_ptr(), d_tmpl.data_ptr(), d_bits.data_ptr(), T, d_pose.data_ptr(),
+                    d_vals.data_ptr(), n, self.conf.data_ptr(), self.value.data_ptr(), self.size, self.channels,
+                    self.pixels_per_meter, float(min_depth), float(max_depth), int(self.use_max_confidence),
+                    _lib.FUSION_TYPES[self.fusion_type], explored_ptr, written_ptr, self._counters.data_ptr(),
+                    _stream_ptr()), "value_map_update_fused")
+                return
+            if explored_ptr is not None:
                 slots = np.unique(pose["env"])
                 jobs = np.zeros(len(slots), MASK_JOB_DTYPE)
                 jobs["env"] = slots

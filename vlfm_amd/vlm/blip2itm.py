@@ -74,6 +74,7 @@ class _VitBlock(nn.Module):
 
         self._packed = None
         self.hip_attention = True  # vlfm_vit_attention_f16 at the ViT-g shape (257 tokens, 88-wide heads)
+        self.strict_hip_attention = False  # True: a failing HIP launch raises (bench.py) instead of falling back
 
     def pack_heads(self, multiple: int = 32) -> None:
         """Inference-time repacking for the attention kernel: the 88-wide heads of ViT-g are zero-padded to the next
@@ -120,6 +121,8 @@ class _VitBlock(nn.Module):
             try:
                 a = ops.vit_attention(qkv, b, n, self.heads, hd, float(hd) ** -0.5)
             except (RuntimeError, AssertionError, IndexError) as exc:   # e.g. the 117 KB LDS opt-in refused on this device
+                if self.strict_hip_attention:
+                    raise
                 import warnings
 
                 warnings.warn(f"vlfm_vit_attention_f16 unavailable ({exc}); using the library attention kernel instead")
@@ -491,7 +494,7 @@ class BLIP2ITM:
 
     def __init__(self, name: str = "blip2_image_text_matching", model_type: str = "pretrain", device=None,
                  model_dir: Optional[str] = None, config: Optional[Blip2ITCConfig] = None,
-                 vision_dtype: torch.dtype = torch.float16, seed: int = 0) -> None:
+                 vision_dtype: torch.dtype = torch.float16, seed: int = 0, allow_random_init: bool = False) -> None:
         from ..mapping.base_map import require_gpu
         from .. import _lib
 
@@ -504,6 +507,11 @@ class BLIP2ITM:
             self.model = Blip2ITCModel(self.cfg)
             self._load_pretrained(model_dir)
             self.weights = f"pretrained:{model_dir}"
+        elif not (allow_random_init or config is not None):
+            # the reference downloads its weights through LAVIS (blip2itm.py:29-34); a scorer that silently runs on random
+            # weights would steer the value map with noise
+            raise ValueError("BLIP2ITM needs model_dir / BLIP2ITM_MODEL_DIR (a Salesforce/blip2-itm-vit-g checkpoint directory); "
+                             "pass allow_random_init=True for a randomly initialised network (benchmarks / geometry tests only)")
         else:
             with torch.device(self.device):  # allocate and initialise the 1.2 B parameters directly in HBM
                 self.model = Blip2ITCModel(self.cfg)
@@ -518,6 +526,23 @@ class BLIP2ITM:
         self._proj_t = None
         self.two_stream_min = None    # e.g. 64: run batches of at least that many images as two halves on two streams
         self._side_stream = None
+
+    @property
+    def strict_hip_attention(self) -> bool:
+        return all(blk.strict_hip_attention for blk in self.model.blocks)
+
+    @strict_hip_attention.setter
+    def strict_hip_attention(self, on: bool) -> None:
+        """True: a failing vlfm_vit_attention_f16 launch raises instead of switching the block to the library kernel."""
+        for blk in self.model.blocks:
+            blk.strict_hip_attention = bool(on)
+
+    @property
+    def attention_path(self) -> str:
+        """Which attention kernel the ViT blocks run with on the fast path: "hip" (vlfm_vit_attention_f16 in every block),
+        "library" (scaled_dot_product_attention in every block) or "mixed"."""
+        flags = {bool(blk.hip_attention) for blk in self.model.blocks}
+        return "hip" if flags == {True} else "library" if flags == {False} else "mixed"
 
     def _load_pretrained(self, model_dir: str) -> None:
         from safetensors.torch import load_file

@@ -59,9 +59,16 @@ def preprocess_caption(caption: str) -> str:
 
 
 class GroundingDINO:
+    """grounding_dino.py:22-74.  The reference hands ``config_path`` / ``weights_path`` (GroundingDINO_SwinT_OGC.py,
+    groundingdino_swint_ogc.pth) to the un-vendored groundingdino package.  Here the network is transformers'
+    ``GroundingDinoForObjectDetection``: ``model_dir`` (or ``GROUNDING_DINO_MODEL_DIR``; ``weights_path`` may also name
+    such a directory) is a checkpoint in transformers' format -- e.g. ``IDEA-Research/grounding-dino-tiny``, which IS
+    groundingdino_swint_ogc converted by transformers' convert_grounding_dino_to_hf.py.  An original ``.pth`` is refused
+    with that instruction instead of being ignored, and random weights need ``allow_random_init=True``."""
+
     def __init__(self, config_path: Optional[str] = None, weights_path: Optional[str] = None, caption: str = CLASSES,
                  box_threshold: float = 0.35, text_threshold: float = 0.25, device=None, model_dir: Optional[str] = None,
-                 hf_config=None, seed: int = 0) -> None:
+                 hf_config=None, seed: int = 0, allow_random_init: bool = False) -> None:
         from transformers import GroundingDinoConfig, GroundingDinoForObjectDetection
 
         from ..mapping.base_map import require_gpu
@@ -69,6 +76,18 @@ class GroundingDINO:
         self.device = require_gpu(device)
         self.caption, self.box_threshold, self.text_threshold = caption, box_threshold, text_threshold
         model_dir = model_dir or os.environ.get("GROUNDING_DINO_MODEL_DIR")
+        if not model_dir and weights_path:
+            if os.path.isdir(weights_path):
+                model_dir = weights_path
+            elif not os.path.exists(weights_path):
+                raise FileNotFoundError(f"GroundingDINO weights {weights_path!r} not found")
+            else:
+                raise ValueError(
+                    f"{weights_path!r} is a checkpoint of the groundingdino package; this class runs transformers' "
+                    "GroundingDinoForObjectDetection.  Convert it once with transformers' convert_grounding_dino_to_hf.py "
+                    "(or download IDEA-Research/grounding-dino-tiny, the converted groundingdino_swint_ogc) and pass the "
+                    "directory as model_dir / GROUNDING_DINO_MODEL_DIR" + (f" (config_path {config_path!r} is not needed)"
+                                                                          if config_path else ""))
         if model_dir:
             from transformers import AutoTokenizer
 
@@ -77,13 +96,17 @@ class GroundingDINO:
             self.tokenizer = lambda t: tok(t)["input_ids"]
             self.decode = tok.decode
             self.weights = f"pretrained:{model_dir}"
-        else:
+        elif allow_random_init or hf_config is not None:
             torch.manual_seed(seed)
             cfg = hf_config or GroundingDinoConfig()
             self.model = GroundingDinoForObjectDetection(cfg)
             wt = WordTokenizer(cfg.text_config.vocab_size, cfg.max_text_len)
             self.tokenizer, self.decode = wt, wt.decode
             self.weights = "random-init"
+        else:
+            raise ValueError("GroundingDINO needs model_dir / GROUNDING_DINO_MODEL_DIR (a transformers-format checkpoint); "
+                             "pass allow_random_init=True for a randomly initialised network (benchmarks only)")
+        self.description = f"GroundingDINO (HF Swin-T + BERT-base geometry, 172 M parameters) {self.weights}"
         self.model.eval().to(self.device)
         self.hip_deform_attn = det_ops.patch_hf_deformable_attention(self.model)  # HIP MsDeformAttn
 

@@ -8,8 +8,9 @@ encoder -> 256x64x64 embedding, box prompt -> prompt encoder -> two-way mask dec
 
 Network: TinyViT-5M encoder (written here from the published architecture: embed dims 64/128/160/320, depths 2/2/6/2,
 heads 2/4/5/10, windows 7/7/14/7, MBConv stem stage, SAM neck) + HF ``transformers`` SAM prompt encoder / mask decoder
-(same design as SAM ViT-*).  ``mobile_sam.pt`` is not available offline -> random-init; preprocessing is the Pillow-exact HIP
-resampler of csrc/vlm_ops.hip."""
+(same design as SAM ViT-*).  ``mobile_sam.pt`` loads through :func:`load_mobile_sam_state_dict` (strict key map, tested
+on a synthetic state dict with the checkpoint's names and shapes -- the file itself is not available offline);
+preprocessing is the Pillow-exact HIP resampler of csrc/vlm_ops.hip."""
 from __future__ import annotations
 
 from typing import Any, Dict, List, Optional
@@ -23,8 +24,21 @@ from . import ops
 
 
 class _ConvBN(nn.Sequential):
+    """conv (no bias) + BatchNorm; sub-module names ``c`` / ``bn`` as in the MobileSAM checkpoint."""
+
     def __init__(self, a: int, b: int, ks: int = 1, stride: int = 1, pad: int = 0, groups: int = 1):
-        super().__init__(nn.Conv2d(a, b, ks, stride, pad, groups=groups, bias=False), nn.BatchNorm2d(b))
+        super().__init__()
+        self.add_module("c", nn.Conv2d(a, b, ks, stride, pad, groups=groups, bias=False))
+        self.add_module("bn", nn.BatchNorm2d(b))
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self, dim: int):
+        super().__init__()
+        self.seq = nn.Sequential(_ConvBN(3, dim // 2, 3, 2, 1), nn.GELU(), _ConvBN(dim // 2, dim, 3, 2, 1))
+
+    def forward(self, x):
+        return self.seq(x)
 
 
 class _MBConv(nn.Module):
@@ -62,14 +76,24 @@ class _WindowAttention(nn.Module):
                 o = (abs(p1[0] - p2[0]), abs(p1[1] - p2[1]))
                 idx.append(offs.setdefault(o, len(offs)))
         self.attention_biases = nn.Parameter(torch.zeros(heads, len(offs)))
-        self.register_buffer("bias_idx", torch.tensor(idx).view(len(pts), len(pts)), persistent=False)
+        self.register_buffer("attention_bias_idxs", torch.tensor(idx).view(len(pts), len(pts)), persistent=False)
 
     def forward(self, x):  # [B*, N, C]
         b, n, c = x.shape
         q, k, v = self.qkv(self.norm(x)).view(b, n, self.heads, 3 * self.kd).split(self.kd, dim=3)
-        bias = self.attention_biases[:, self.bias_idx].unsqueeze(0).to(x.dtype)
+        bias = self.attention_biases[:, self.attention_bias_idxs].unsqueeze(0).to(x.dtype)
         a = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), attn_mask=bias)
         return self.proj(a.transpose(1, 2).reshape(b, n, c))
+
+
+class _Mlp(nn.Module):
+    def __init__(self, dim: int, hidden: int):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+        self.fc1, self.fc2 = nn.Linear(dim, hidden), nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(F.gelu(self.fc1(self.norm(x))))
 
 
 class _TinyViTBlock(nn.Module):
@@ -77,9 +101,8 @@ class _TinyViTBlock(nn.Module):
         super().__init__()
         self.window = window
         self.attn = _WindowAttention(dim, heads, window)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
         self.local_conv = _ConvBN(dim, dim, 3, 1, 1, dim)
-        self.mlp_norm = nn.LayerNorm(dim)
-        self.fc1, self.fc2 = nn.Linear(dim, int(dim * mlp_ratio)), nn.Linear(int(dim * mlp_ratio), dim)
 
     def forward(self, x):  # [B, C, H, W]
         b, c, h, w = x.shape
@@ -94,8 +117,23 @@ class _TinyViTBlock(nn.Module):
         x = x + t.permute(0, 3, 1, 2)
         x = self.local_conv(x)
         t = x.permute(0, 2, 3, 1)
-        t = t + self.fc2(F.gelu(self.fc1(self.mlp_norm(t))))
+        t = t + self.mlp(t)
         return t.permute(0, 3, 1, 2)
+
+
+class _Stage(nn.Module):
+    """``blocks`` + optional ``downsample``: layers.0 is the MBConv stage, layers.1-3 the windowed-attention stages."""
+
+    def __init__(self, blocks: List[nn.Module], downsample: Optional[nn.Module]):
+        super().__init__()
+        self.blocks = nn.ModuleList(blocks)
+        if downsample is not None:
+            self.downsample = downsample
+
+    def forward(self, x):
+        for blk in self.blocks:
+            x = blk(x)
+        return self.downsample(x) if hasattr(self, "downsample") else x
 
 
 class _LayerNorm2d(nn.Module):
@@ -110,40 +148,140 @@ class _LayerNorm2d(nn.Module):
 
 
 class TinyViT(nn.Module):
-    """TinyViT-5M as configured by MobileSAM (img 1024 -> 256 x 64 x 64)."""
+    """TinyViT-5M as configured by MobileSAM (img 1024 -> 256 x 64 x 64).  Module names follow the ``image_encoder.*`` keys
+    of ``mobile_sam.pt`` one to one (patch_embed.seq.N.{c,bn}, layers.N.blocks.M.{conv1..3 | attn,mlp,local_conv},
+    layers.N.downsample.conv1..3, norm_head, head, neck.0-3), so the checkpoint's encoder loads by prefix stripping; the
+    classification head (norm_head / head) is carried only because the checkpoint has it."""
 
-    def __init__(self, dims=(64, 128, 160, 320), depths=(2, 2, 6, 2), heads=(2, 4, 5, 10), windows=(7, 7, 14, 7)):
+    def __init__(self, dims=(64, 128, 160, 320), depths=(2, 2, 6, 2), heads=(2, 4, 5, 10), windows=(7, 7, 14, 7),
+                 num_classes: int = 1000):
         super().__init__()
-        self.patch_embed = nn.Sequential(_ConvBN(3, dims[0] // 2, 3, 2, 1), nn.GELU(), _ConvBN(dims[0] // 2, dims[0], 3, 2, 1))
-        stages: List[nn.Module] = [nn.Sequential(*[_MBConv(dims[0]) for _ in range(depths[0])]),
-                                   _PatchMerging(dims[0], dims[1])]
+        self.patch_embed = _PatchEmbed(dims[0])
+        layers: List[nn.Module] = [_Stage([_MBConv(dims[0]) for _ in range(depths[0])], _PatchMerging(dims[0], dims[1]))]
         for i in range(1, 4):
-            stages.append(nn.Sequential(*[_TinyViTBlock(dims[i], heads[i], windows[i]) for _ in range(depths[i])]))
-            if i < 3:
-                stages.append(_PatchMerging(dims[i], dims[i + 1]))
-        self.stages = nn.Sequential(*stages)
+            layers.append(_Stage([_TinyViTBlock(dims[i], heads[i], windows[i]) for _ in range(depths[i])],
+                                 _PatchMerging(dims[i], dims[i + 1]) if i < 3 else None))
+        self.layers = nn.ModuleList(layers)
+        self.norm_head = nn.LayerNorm(dims[3])
+        self.head = nn.Linear(dims[3], num_classes)
         self.neck = nn.Sequential(nn.Conv2d(dims[3], 256, 1, bias=False), _LayerNorm2d(256),
                                   nn.Conv2d(256, 256, 3, padding=1, bias=False), _LayerNorm2d(256))
 
     def forward(self, x):
-        return (self.neck(self.stages(self.patch_embed(x))),)
+        x = self.patch_embed(x)
+        for layer in self.layers:
+            x = layer(x)
+        return (self.neck(x),)
+
+
+# mobile_sam.pt (segment-anything layout) -> transformers.SamModel names for the prompt encoder and the mask decoder
+_SAM_RENAMES = (
+    ("prompt_encoder.pe_layer.positional_encoding_gaussian_matrix", "prompt_encoder.shared_embedding.positional_embedding"),
+    ("prompt_encoder.point_embeddings.", "prompt_encoder.point_embed."),
+    ("prompt_encoder.mask_downscaling.0.", "prompt_encoder.mask_embed.conv1."),
+    ("prompt_encoder.mask_downscaling.1.", "prompt_encoder.mask_embed.layer_norm1."),
+    ("prompt_encoder.mask_downscaling.3.", "prompt_encoder.mask_embed.conv2."),
+    ("prompt_encoder.mask_downscaling.4.", "prompt_encoder.mask_embed.layer_norm2."),
+    ("prompt_encoder.mask_downscaling.6.", "prompt_encoder.mask_embed.conv3."),
+    ("mask_decoder.output_upscaling.0.", "mask_decoder.upscale_conv1."),
+    ("mask_decoder.output_upscaling.1.", "mask_decoder.upscale_layer_norm."),
+    ("mask_decoder.output_upscaling.3.", "mask_decoder.upscale_conv2."),
+    ("mask_decoder.transformer.norm_final_attn.", "mask_decoder.transformer.layer_norm_final_attn."),
+    (".layers.0.", ".proj_in."), (".layers.1.", ".layers.0."), (".layers.2.", ".proj_out."),   # 3-layer MLP heads only
+    (".norm1.", ".layer_norm1."), (".norm2.", ".layer_norm2."), (".norm3.", ".layer_norm3."), (".norm4.", ".layer_norm4."),
+)
+
+
+def mobile_sam_key_map(checkpoint_keys) -> Dict[str, List[str]]:
+    """checkpoint key -> model keys it fills (``model`` = SamModel whose vision_encoder is :class:`TinyViT`)."""
+    out: Dict[str, List[str]] = {}
+    for k in checkpoint_keys:
+        if k.startswith("image_encoder."):
+            if k.endswith("attention_bias_idxs"):   # derived index table, rebuilt by the module
+                continue
+            out[k] = ["vision_encoder." + k[len("image_encoder."):]]
+            continue
+        t = k
+        mlp_head = ("output_hypernetworks_mlps" in k) or ("iou_prediction_head" in k)
+        for a, b in _SAM_RENAMES:
+            if a.startswith(".layers.") and not mlp_head:
+                continue
+            if a in t:
+                t = t.replace(a, b, 1)
+                if a.startswith(".layers."):
+                    break
+        out[k] = [t]
+        if t == "prompt_encoder.shared_embedding.positional_embedding":
+            out[k].append("shared_image_embedding.positional_embedding")   # the same Gaussian matrix encodes the image grid
+    return out
+
+
+def build_mobile_sam_model():
+    """transformers.SamModel (prompt encoder + two-way mask decoder: same design as SAM ViT-*) around TinyViT."""
+    from transformers import SamConfig, SamModel
+
+    cfg = SamConfig()
+    cfg.vision_config.num_hidden_layers = 1  # the HF ViT encoder is replaced below; keep its construction cheap
+    cfg.mask_decoder_config.layer_norm_eps = 1e-5  # segment-anything's decoder uses nn.LayerNorm's default, not HF's 1e-6
+    model = SamModel(cfg)
+    model.vision_encoder = TinyViT()
+    return model.eval()
+
+
+def load_mobile_sam_state_dict(model, state_dict) -> Dict[str, Any]:
+    """Load ``mobile_sam.pt`` (a plain state dict of mobile_sam's ``Sam``: image_encoder.* TinyViT, prompt_encoder.*,
+    mask_decoder.*) into ``model``.  Strict both ways: every checkpoint tensor must land on a model tensor of the same
+    shape, and every model tensor must be filled -- anything else raises."""
+    if "model" in state_dict and isinstance(state_dict["model"], dict):
+        state_dict = state_dict["model"]
+    own = model.state_dict()
+    kmap = mobile_sam_key_map(state_dict.keys())
+    filled, problems = set(), []
+    with torch.no_grad():
+        for k, targets in kmap.items():
+            v = state_dict[k]
+            for t in targets:
+                if t not in own:
+                    problems.append(f"{k} -> {t}: no such tensor in the model")
+                elif tuple(own[t].shape) != tuple(v.shape):
+                    problems.append(f"{k} -> {t}: shape {tuple(v.shape)} vs {tuple(own[t].shape)}")
+                else:
+                    own[t].copy_(v)
+                    filled.add(t)
+    missing = [t for t in own if t not in filled]
+    if problems or missing:
+        raise RuntimeError("mobile_sam checkpoint does not fit the model: " + "; ".join(problems[:8])
+                           + (f"; model tensors left unfilled: {missing[:8]} (+{max(0, len(missing) - 8)})" if missing else ""))
+    return {"tensors_loaded": len(kmap), "model_tensors_filled": len(filled)}
 
 
 class MobileSAM:
+    """sam.py:24-57.  ``sam_checkpoint`` is the reference's ``data/mobile_sam.pt``; a path that is given MUST load (a
+    segmenter that silently falls back to random weights hands noise masks to the object map).  Benchmarks and shape
+    tests opt into random weights explicitly with ``allow_random_init=True``."""
+
     def __init__(self, sam_checkpoint: Optional[str] = None, model_type: str = "vit_t", device: Optional[Any] = None,
-                 seed: int = 0) -> None:
-        from transformers import SamConfig, SamModel
+                 seed: int = 0, allow_random_init: bool = False) -> None:
+        import os
 
         from ..mapping.base_map import require_gpu
 
         self.device = require_gpu(device)
+        assert model_type == "vit_t", "MobileSAM is the TinyViT ('vit_t') variant of SAM (sam.py:30)"
+        sam_checkpoint = sam_checkpoint or os.environ.get("MOBILE_SAM_CHECKPOINT")   # sam.py:72-74 reads the same variable
         torch.manual_seed(seed)
-        cfg = SamConfig()
-        cfg.vision_config.num_hidden_layers = 1  # the HF ViT encoder is replaced below; keep its construction cheap
-        self.model = SamModel(cfg)
-        self.model.vision_encoder = TinyViT()
-        self.model.eval().to(self.device)
-        self.weights = "random-init" if not sam_checkpoint else f"unavailable offline: {sam_checkpoint}"
+        self.model = build_mobile_sam_model()
+        if sam_checkpoint:
+            if not os.path.isfile(sam_checkpoint):
+                raise FileNotFoundError(f"MobileSAM checkpoint {sam_checkpoint!r} not found")
+            report = load_mobile_sam_state_dict(self.model, torch.load(sam_checkpoint, map_location="cpu"))
+            self.weights = f"{sam_checkpoint} ({report['tensors_loaded']} tensors)"
+        elif allow_random_init:
+            self.weights = "random-init (allow_random_init=True: benchmark / shape tests only)"
+        else:
+            raise ValueError("MobileSAM needs sam_checkpoint (the reference's data/mobile_sam.pt) or MOBILE_SAM_CHECKPOINT; "
+                             "pass allow_random_init=True for a randomly initialised network (benchmarks only)")
+        self.model.to(self.device)
         self.mask_threshold = 0.0
 
     @torch.inference_mode()

@@ -6,9 +6,10 @@ height -- with the preprocessing and the NMS as HIP kernels (csrc/detect_ops.hip
 environments (``predict_batch``).  ``YOLOv7Client`` keeps the client signature; the model lives in this process.
 
 Network: the reference loads the pretrained ``yolov7-e6e.pt`` through the un-vendored yolov7 repository [ext]; neither
-exists offline.  ``weights`` may name a TorchScript export of that model (what the reference's TracedModel produces); without
-it a random-init detector of the same I/O contract and the same head geometry (strides 8/16/32/64, 3 anchors each, 85
-channels -> 17 850 candidates at 448x640) stands in, so that throughput is measured on an E6E-class convolutional load."""
+exists offline.  ``weights`` names a TorchScript export of that model (``export.py --grid`` of the yolov7 repository: output
+[B, N, 85]); a path that is given must load.  Only with ``allow_random_init=True`` a random-init detector of the same I/O
+contract and the same head geometry (strides 8/16/32/64, 3 anchors each, 85 channels -> 17 850 candidates at 448x640)
+stands in, so that throughput is measured on an E6E-class convolutional load whose GFLOPs are stated next to E6E's."""
 from __future__ import annotations
 
 import os
@@ -122,28 +123,80 @@ class YoloV7E6EClassNet(nn.Module):
         return torch.cat(z, 1)
 
 
+E6E_PUBLISHED = {"params_M": 151.7, "gflops_at_1280x1280": 843.2}  # yolov7 README, YOLOv7-E6E row [ext]
+
+
+def conv_gflops(model: nn.Module, example: torch.Tensor) -> float:
+    """FLOPs (2 x MACs) of the convolutions of one forward of ``model`` on ``example``, in GFLOP (hooks; eager modules
+    only: a TorchScript module returns 0)."""
+    total = [0.0]
+    hooks = []
+
+    def hook(m, inp, out):
+        k = m.kernel_size[0] * m.kernel_size[1] * (m.in_channels // m.groups)
+        total[0] += 2.0 * out.numel() * k
+
+    for m in model.modules():
+        if isinstance(m, nn.Conv2d):
+            hooks.append(m.register_forward_hook(hook))
+    with torch.inference_mode():
+        model(example)
+    for h in hooks:
+        h.remove()
+    return total[0] / 1e9
+
+
 class YOLOv7:
-    """yolov7.py:28-110 (+ ``predict_batch`` for the batched harness)."""
+    """yolov7.py:28-110 (+ ``predict_batch`` for the batched harness).
+
+    ``weights``: the reference hands ``yolov7-e6e.pt`` to the yolov7 repository's ``attempt_load`` (yolov7.py:35), which
+    unpickles that repository's own model classes -- impossible without the repository.  What this class loads instead is
+    a TorchScript export of the same network whose output is the inference tensor [B, N, 85] (``python export.py
+    --weights yolov7-e6e.pt --grid --img-size 448 640`` in the yolov7 repository writes ``yolov7-e6e.torchscript.pt``);
+    ``YOLOV7_TORCHSCRIPT`` names it when the argument is omitted.  A path that is given must exist and must be
+    TorchScript: there is no silent fallback.  ``allow_random_init=True`` builds the E6E-class stand-in network with
+    random weights -- for benchmarks and pipeline tests only; ``description`` states its convolution GFLOPs next to the
+    published YOLOv7-E6E figure so that "full step" throughput numbers can be read."""
 
     def __init__(self, weights: Optional[str] = None, image_size: int = 640, half_precision: bool = True, device=None,
-                 width: int = 80) -> None:
+                 width: int = 80, allow_random_init: bool = False) -> None:
         from ..mapping.base_map import require_gpu
 
         self.device = require_gpu(device)
         self.half_precision = half_precision
         self.image_size = image_size
+        self.in_hw = (int(self.image_size * 0.7), self.image_size)  # (448, 640) (yolov7.py:73)
         weights = weights or os.environ.get("YOLOV7_TORCHSCRIPT")
-        if weights and os.path.exists(weights):
-            self.model = torch.jit.load(weights, map_location=self.device).eval()
+        e6e_here = E6E_PUBLISHED["gflops_at_1280x1280"] * (self.in_hw[0] * self.in_hw[1]) / (1280.0 * 1280.0)
+        if weights:
+            if not os.path.isfile(weights):
+                raise FileNotFoundError(f"YOLOv7 weights {weights!r} not found")
+            try:
+                self.model = torch.jit.load(weights, map_location=self.device).eval()
+            except Exception as exc:  # noqa: BLE001 -- a pickled yolov7 checkpoint, not TorchScript
+                raise ValueError(
+                    f"{weights!r} is not a TorchScript module ({type(exc).__name__}).  yolov7's .pt checkpoints pickle the "
+                    "yolov7 repository's own classes and can only be opened with that repository; export it once with "
+                    "`python export.py --weights yolov7-e6e.pt --grid --img-size 448 640` and pass the resulting "
+                    "*.torchscript.pt (or set YOLOV7_TORCHSCRIPT)") from exc
             self.weights = f"torchscript:{weights}"
-        else:
+            self.description = self.weights
+        elif allow_random_init:
             with torch.device(self.device):
                 self.model = YoloV7E6EClassNet(width=width)
             self.model.eval()
             self.weights = "random-init (E6E-class stand-in)"
+            g = conv_gflops(self.model, torch.zeros((1, 3) + self.in_hw, device=self.device))
+            self.description = (f"random-init E6E-class stand-in, width {width}: {g:.1f} conv GFLOPs per {self.in_hw[1]}x"
+                                f"{self.in_hw[0]} frame (published YOLOv7-E6E: {E6E_PUBLISHED['gflops_at_1280x1280']} GFLOPs at "
+                                f"1280x1280 = {e6e_here:.1f} at this input size, {E6E_PUBLISHED['params_M']} M parameters); "
+                                f"stand-in / E6E = {g / e6e_here:.2f}")
+            self.stand_in_gflops, self.e6e_gflops = g, e6e_here
+        else:
+            raise ValueError("YOLOv7 needs `weights` (a TorchScript export of yolov7-e6e, see the class docstring) or "
+                             "YOLOV7_TORCHSCRIPT; pass allow_random_init=True for the random-init stand-in (benchmarks only)")
         if self.half_precision:
             self.model.half()
-        self.in_hw = (int(self.image_size * 0.7), self.image_size)  # (448, 640) (yolov7.py:73)
 
     @torch.inference_mode()
     def predict_batch(self, images_u8: torch.Tensor, conf_thres: float = 0.25, iou_thres: float = 0.45,
