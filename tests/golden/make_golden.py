@@ -652,6 +652,42 @@ def _ep500_worker():
     return gen_episode500(ref_vm, ref_om)
 
 
+EPISODE_LOG_SAMPLE = {"failure_cause": "did_not_fail", "success": 1, "spl": 0.73, "distance_to_goal": 0.4,
+                      "num_steps": 212, "target_object": "potted plant", "traveled_stairs": False,
+                      "nested": {"rho_theta": [1.5, -0.25], "stop_called": True}}
+
+
+def gen_episode_log():
+    """THE REFERENCE'S log_saver (vlfm/utils/log_saver.py -- standard library only, runs here as it is): the bytes and the
+    file name of one episode log, the skip-if-present rule and is_evaluated."""
+    import importlib.util
+    import tempfile
+
+    spec = importlib.util.spec_from_file_location("ref_log_saver", "/root/reference/vlfm/utils/log_saver.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    import contextlib
+    import io
+
+    with tempfile.TemporaryDirectory() as d:
+        old = os.environ.get("ZSOS_LOG_DIR")
+        os.environ["ZSOS_LOG_DIR"] = os.path.join(d, "logs")
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                before = mod.is_evaluated(17, "scene_a")
+                mod.log_episode(17, "scene_a", EPISODE_LOG_SAMPLE)
+                mod.log_episode(17, "scene_a", {"failure_cause": "overwritten?"})   # must be skipped
+                after = mod.is_evaluated(17, "scene_a")
+            names = sorted(os.listdir(os.environ["ZSOS_LOG_DIR"]))
+            text = open(os.path.join(os.environ["ZSOS_LOG_DIR"], names[0])).read()
+        finally:
+            if old is None:
+                del os.environ["ZSOS_LOG_DIR"]
+            else:
+                os.environ["ZSOS_LOG_DIR"] = old
+    return dict(file_names=np.array(names), text=np.array(text), evaluated_before=before, evaluated_after=after)
+
+
 def generate():
     from concurrent.futures import ProcessPoolExecutor
     import multiprocessing
@@ -680,6 +716,7 @@ def generate():
         out[name] = gen_policy(name)
     out["api_signatures"] = gen_api()
     out["pointnav"] = gen_pointnav()
+    out["episode_log"] = gen_episode_log()
     out["ep500"] = ep500.result()
     pool.shutdown()
     return out

@@ -120,3 +120,33 @@ def test_harness_frontier_selection_and_goal_geometry_are_the_scalar_rules_vecto
         assert abs(captured["rt"][e, 0] - rho) < 1e-6 and abs(captured["rt"][e, 1] - theta) < 1e-6
     assert captured["rt"][1, 0] == 0.0                       # no frontier: the goal is the robot's own position
     assert captured["reset"] == [1, 2] and captured["masks"].tolist() == [True, False, False]
+
+
+def test_episode_log_matches_the_reference_log_saver_fixture(tmp_path, monkeypatch, capsys):
+    """vlfm/utils/log_saver.py:9-44: same file name, same bytes, never overwrites, is_evaluated semantics --
+    against what the reference's own module wrote (tests/golden/episode_log.npz)."""
+    import os
+    import sys
+    import time
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden as mg
+    from golden_util import load
+    from vlfm_amd.utils.log_saver import is_evaluated, log_episode
+
+    g = load("episode_log")
+    monkeypatch.setenv("ZSOS_LOG_DIR", str(tmp_path / "logs"))
+    assert is_evaluated(17, "scene_a") == bool(g["evaluated_before"]) is False
+    log_episode(17, "scene_a", mg.EPISODE_LOG_SAMPLE)
+    log_episode(17, "scene_a", {"failure_cause": "overwritten?"})
+    assert is_evaluated(17, "scene_a") == bool(g["evaluated_after"]) is True
+    names = sorted(os.listdir(tmp_path / "logs"))
+    assert names == [str(n) for n in g["file_names"]]
+    assert open(tmp_path / "logs" / names[0]).read() == str(g["text"])
+    assert "Logging episode 0017" in capsys.readouterr().out
+    # empty files older than five minutes are swept, fresh ones are kept and count as "being evaluated"
+    stale, fresh = tmp_path / "logs" / "3_scene_b.json", tmp_path / "logs" / "4_scene_b.json"
+    stale.write_text("")
+    fresh.write_text("")
+    os.utime(stale, (time.time() - 400, time.time() - 400))
+    assert is_evaluated(4, "scene_b") and not stale.exists() and not is_evaluated(3, "scene_b")

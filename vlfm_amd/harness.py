@@ -46,6 +46,7 @@ class BatchedEpisodes:
         self.values = ValueMapBatch(n_envs, 1, map_size, use_max_confidence=False, device=self.device)
         self.n_frontiers = n_frontiers
         self.t = 0
+        self.episodes_done = 0
         # synthetic observations live in HBM before the timed region starts (bench contract): a small pool of
         # distinct frames per env, cycled; the scripted poses of a whole episode are tabulated up front as well
         rng = np.random.Generator(np.random.PCG64(99991 + env_offset))
@@ -168,9 +169,35 @@ class BatchedEpisodes:
         if self.obstacles is not None:
             self.obstacles.check_status()
 
+    def _log_finished_episodes(self) -> None:
+        """One JSON file per finished episode in the reference's log format (vlfm/utils/log_saver.py:9-22) when
+        ZSOS_LOG_DIR is set: what the reference's eval loop writes through episode_stats_logger.log_episode_stats."""
+        import os
+
+        if "ZSOS_LOG_DIR" not in os.environ:
+            return
+        from .utils.log_saver import is_evaluated, log_episode
+
+        n_fr = self.obstacles.frontiers_px() if self.obstacles is not None and self.obstacles.frontiers_ready else None
+        best = None
+        if self.last_frontier_values is not None and len(self.last_frontier_values):
+            best = float(np.max(self.last_frontier_values))
+        for e, env_id in enumerate(self.env_ids):
+            episode_id = self.episodes_done * len(self.env_ids) + e
+            scene = f"synthetic{env_id:04d}"
+            if is_evaluated(episode_id, scene):
+                continue
+            log_episode(episode_id, scene, {
+                "target_object": self.targets[e], "num_steps": int(self.episode_len),
+                "final_pose": [float(v) for v in self.pose_table[(self.t - 1) % self.episode_len][e]],
+                "num_frontiers": int(len(n_fr[e])) if n_fr is not None else 0,
+                "best_frontier_value_last_step": best})
+
     def step(self) -> None:
         if self.t and self.t % self.episode_len == 0:
             self.check()
+            self._log_finished_episodes()
+            self.episodes_done += 1
             self.reset()
         k = self.t % self.depth_pool.shape[0]
         if self.host_inputs:
