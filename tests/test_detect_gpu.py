@@ -190,9 +190,10 @@ def test_yolov7_torchscript_weights_path_and_no_silent_fallback(gpu_device, tmp_
     torch.manual_seed(3)
     with torch.device(gpu_device):
         net = YoloV7E6EClassNet(width=16).eval()
-    with torch.no_grad():   # make some candidates pass the confidence threshold
+    with torch.no_grad():   # make the random net emit confident boxes
         for m in net.detect:
-            m.bias.view(3, -1)[:, 4] += 6.0
+            m.bias.fill_(0.0)
+            m.bias.view(3, 85)[:, 4] = 1.5
     example = torch.rand(1, 3, 448, 640, device=gpu_device)
     path = str(tmp_path / "stand_in.torchscript.pt")
     torch.jit.trace(net, example).save(path)

@@ -195,7 +195,7 @@ def _world500_frames(n):
     return [(d, tf) for _, d, tf, _ in w5.episode(w5.plan_actions()[:n])]
 
 
-@pytest.mark.parametrize("caps", [dict(CAP_FRONTIERS=2), dict(CAP_PTS=96), dict(CAP_CONTOURS=2)])
+@pytest.mark.parametrize("caps", [dict(CAP_FRONTIERS=2, READ_FRONTIERS=2), dict(CAP_PTS=96), dict(CAP_CONTOURS=2)])
 def test_scratch_capacity_overflow_raises_instead_of_a_silent_wrong_map(gpu_device, caps):
     """CAP_PTS / CAP_CONTOURS / CAP_FRONTIERS are fixed scratch sizes: when a step needs more (here: deliberately tiny
     capacities in a world with a dozen frontiers) the frontier read-back of that step must raise, whichever kernel of the

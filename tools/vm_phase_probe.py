@@ -1,0 +1,39 @@
+"""Where does value_map_update_fused_kernel spend its time?  Builds a diagnostic library with -DVLFM_PHASE_TIMING
+(only value_map.hip is recompiled, the other objects come from vlfm_amd/csrc/build) and prints the per-phase microseconds
+of workgroup (0, 0), averaged over steps, for a few batch geometries.
+    python tools/vm_phase_probe.py"""
+import ctypes, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+csrc = os.path.join(ROOT, "vlfm_amd", "csrc")
+out = os.path.join(ROOT, "gpurun_out", "libvlfm_amd_vmphase.so")
+os.makedirs(os.path.dirname(out), exist_ok=True)
+from vlfm_amd import _lib
+_lib.build()
+obj = os.path.join(ROOT, "gpurun_out", "value_map_phase.o")
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-DVLFM_PHASE_TIMING",
+                       "-c", os.path.join(csrc, "value_map.hip"), "-o", obj])
+objs = [os.path.join(csrc, "build", f) for f in os.listdir(os.path.join(csrc, "build")) if f.endswith(".o") and not f.startswith("value_map")]
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, obj] + objs)
+os.environ["VLFM_LIB_PATH"] = out
+import importlib
+importlib.reload(_lib)
+import numpy as np, torch
+from vlfm_amd.harness import BatchedEpisodes
+names = ["keys->vertices", "short edges", "long edges (coop)", "resolve+visible+bbox", "dst box (1 lane)", "mask (written&~explored)", "fuse tiles"]
+for (E, H, W, sync) in [(256, 480, 640, False), (16, 720, 1280, True), (8, 480, 640, False), (1, 480, 640, False)]:
+    sim = BatchedEpisodes(E, device=torch.device("cuda:0"), use_blip2=False, overlap=False, height=H, width=W, sync_explored=sync)
+    sim.fast_forward(60)
+    acc = np.zeros(7); n = 0
+    _lib.lib().vlfm_profile_enable(1)
+    for _ in range(20):
+        sim.fast_forward(1); torch.cuda.synchronize()
+        buf = np.zeros(16, np.int64)
+        _lib.lib().vlfm_debug_vm_phase_clocks(ctypes.c_void_p(buf.ctypes.data))
+        d = np.diff(buf[:8]) * 0.01
+        if (d >= 0).all() and d.sum() < 1e4:
+            acc += d; n += 1
+    ms, cnt = _lib.profile_read("value_map_update_fused_kernel")
+    _lib.lib().vlfm_profile_enable(0)
+    print(f"E={E} {W}x{H} sync={sync}: kernel {ms * 1e3:.1f} us; workgroup (0,0): " + ", ".join(f"{nm}={a / max(n, 1):.1f}" for nm, a in zip(names, acc)) + f" (sum {acc.sum() / max(n, 1):.1f} us)")
+    del sim

@@ -389,6 +389,19 @@ struct FusedExtra {
     int* counters;       // [n] zero on entry, zero again on exit
 };
 
+// Optional phase timing of the single-launch update (compile with -DVLFM_PHASE_TIMING; tools/vm_phase_probe.py): thread 0
+// of workgroup (0, 0) stamps the constant-rate 100 MHz counter at phase boundaries.  Zero cost otherwise.
+#ifdef VLFM_PHASE_TIMING
+__device__ long long g_vm_phase[16];
+#define VM_PHASE(k)                                                                                       \
+    do {                                                                                                  \
+        __syncthreads();                                                                                  \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_vm_phase[k] = wall_clock64();        \
+    } while (0)
+#else
+#define VM_PHASE(k) do {} while (0)
+#endif
+
 constexpr int LONG_EDGE = 24;      // edges longer than this (Chebyshev) are rasterised by the whole workgroup
 constexpr int LONG_EDGE_CAP = 16;
 
@@ -453,6 +466,7 @@ __global__ __launch_bounds__(256) void value_map_update_fused_kernel(UpdateArgs 
     unsigned wr0 = 0u;
     if (written && a.explored && my_word < plane_words) wr0 = written[my_word];
 
+    VM_PHASE(0);
     LdsBitmap bm;
     bm.solid = solid; bm.parity = parity; bm.rows = T; bm.cols = T; bm.words = words;
     for (int i = tid; i < 2 * T * words; i += nth) solid[i] = 0u;
@@ -471,6 +485,7 @@ __global__ __launch_bounds__(256) void value_map_update_fused_kernel(UpdateArgs 
         vert[W + 1] = make_int2(T - 1, T - 1);
     }
     __syncthreads();
+    VM_PHASE(1);
     // the keys have been read: the last workgroup of this observation to get here zeroes them for the next depth ingest
     if (tid == 0) {
         __threadfence();
@@ -488,6 +503,7 @@ __global__ __launch_bounds__(256) void value_map_update_fused_kernel(UpdateArgs 
         raster_edge(bm, (long long)p0.x << XY_SHIFT, p0.y, (long long)p1.x << XY_SHIFT, p1.y);
     }
     __syncthreads();
+    VM_PHASE(2);
     {
         const int n_long = min(sh_n_long, LONG_EDGE_CAP);
         for (int k = 0; k < n_long; k++) {
@@ -502,6 +518,7 @@ __global__ __launch_bounds__(256) void value_map_update_fused_kernel(UpdateArgs 
         if (tid == 0) fx.counters[obs] = 0;
     }
     __syncthreads();
+    VM_PHASE(3);
     // resolve (one lane per row) fused with visible = (template > 0) & ~beyond-the-profile, and the source bounding box
     {
         int r_lo = T, r_hi = -1, c_lo = T, c_hi = -1;
@@ -530,6 +547,7 @@ __global__ __launch_bounds__(256) void value_map_update_fused_kernel(UpdateArgs 
         }
     }
     __syncthreads();
+    VM_PHASE(4);
     if (tid == 0) {
         // destination (rotated) bounding box of everything that can receive a non-zero tap (see visible_mask_kernel)
         int4 m;
@@ -551,6 +569,7 @@ __global__ __launch_bounds__(256) void value_map_update_fused_kernel(UpdateArgs 
         }
         sh_dbox = m;
     }
+    VM_PHASE(5);
     // ---- step 2: cells that hold a value but are not explored any more (value_map.py:369-375)
     if (written && a.explored) {
         const unsigned* explored = a.explored + (size_t)pose.env * S * ex_stride;
@@ -574,6 +593,7 @@ __global__ __launch_bounds__(256) void value_map_update_fused_kernel(UpdateArgs 
         }
     }
     __syncthreads();
+    VM_PHASE(6);
     // ---- step 3: rotate + place + fuse, tiles g, g + G, ...
     const int4 box = sh_dbox;
     if (box.z > box.w) return;
@@ -584,6 +604,7 @@ __global__ __launch_bounds__(256) void value_map_update_fused_kernel(UpdateArgs 
         if (row_begin > box.y || row_begin + ROWS_PER_TILE <= box.x) continue;
         fuse_tile<C_STATIC>(a, pose, parity, box, row_begin, tid, written);
     }
+    VM_PHASE(7);
 }
 
 // ------------------------------------------------------------------------------------------------ full-map mask
@@ -762,6 +783,12 @@ extern "C" int vlfm_value_map_update_batched(uint32_t* d_colmax_keys, int width,
         VLFM_KLAUNCH(value_map_fuse_kernel<0>, dim3(tiles, n), dim3(256), lds_fuse, (hipStream_t)stream, a);
     return check_launch("value_map_fuse_kernel");
 }
+
+#ifdef VLFM_PHASE_TIMING
+extern "C" int vlfm_debug_vm_phase_clocks(long long* h_out /* [16] */) {
+    return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(vlfm::g_vm_phase), sizeof(long long) * 16) == hipSuccess ? VLFM_OK : VLFM_ERR_HIP;
+}
+#endif
 
 extern "C" int vlfm_value_map_update_fused_batched(uint32_t* d_colmax_keys, int width, const double* d_tan,
                                                    const float* d_template, const uint32_t* d_template_bits,
