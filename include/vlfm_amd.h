@@ -198,14 +198,17 @@ int vlfm_value_map_update_batched(uint32_t* d_colmax_keys, int width, const doub
  *              half of _fuse_new_data (value_map.py:369-375) then clears exactly the cells in (written & ~explored) --
  *              no call to vlfm_value_map_mask_unexplored_batched.  Observations of one call must belong to distinct
  *              environment slots.
- *   d_counters [n] int32, zero on entry and zero again on exit (hand-over of the column-max key buffer). */
+ *   d_counters [n] int32, zero on entry and zero again on exit (hand-over of the column-max key buffer).
+ *   d_conf_quadrant [(T/2+1)^2] f32: rows/cols >= T/2 of the UNMASKED confidence table of vlfm_cone_template_host (the
+ *              table depends on |row - T/2| and |col - T/2| only, value_map.py:343-351).  Staged in LDS so that the rotated
+ *              template taps are LDS reads (required). */
 int vlfm_value_map_update_fused_batched(uint32_t* d_colmax_keys, int width, const double* d_tan,
                                         const float* d_template, const uint32_t* d_template_bits, int template_size,
                                         const vlfm_vm_pose* d_pose, const double* d_values, int n,
                                         float* d_conf, float* d_value, int map_size, int channels, int pixels_per_meter,
                                         double min_depth, double max_depth, int use_max_confidence, int fusion_type,
                                         const uint32_t* d_explored_bits, uint32_t* d_written_bits, int32_t* d_counters,
-                                        void* stream);
+                                        const float* d_conf_quadrant, void* stream);
 
 /* Full-map half of _fuse_new_data when an obstacle map is attached (value_map.py:369-375): conf = value = 0 wherever
  * explored == 0, over rows [row_lo, row_hi) of the listed environment slots.  The reference sweeps the whole map; rows

@@ -20,8 +20,11 @@ import importlib
 importlib.reload(_lib)
 import numpy as np, torch
 from vlfm_amd.harness import BatchedEpisodes
-names = ["keys->vertices", "short edges", "long edges (coop)", "resolve+visible+bbox", "dst box (1 lane)", "mask (written&~explored)", "fuse tiles"]
-for (E, H, W, sync) in [(256, 480, 640, False), (16, 720, 1280, True), (8, 480, 640, False), (1, 480, 640, False)]:
+names = ["keys->vertices", "flattened raster", "key hand-back", "resolve+visible+bbox", "dst box (1 lane)", "mask (written&~explored)", "fuse tiles"]
+for (E, H, W, sync, wgs) in [(256, 480, 640, False, 256), (256, 480, 640, False, 512), (128, 480, 640, False, 256), (128, 480, 640, False, 512),
+                             (64, 480, 640, False, 256), (64, 480, 640, False, 512), (16, 720, 1280, True, 112), (16, 720, 1280, True, 48),
+                             (8, 480, 640, False, 256), (8, 480, 640, False, 24), (1, 480, 640, False, 256), (1, 480, 640, False, 3)]:
+    os.environ["VLFM_VM_TARGET_WGS"] = str(wgs)
     sim = BatchedEpisodes(E, device=torch.device("cuda:0"), use_blip2=False, overlap=False, height=H, width=W, sync_explored=sync)
     sim.fast_forward(60)
     acc = np.zeros(7); n = 0
@@ -35,5 +38,5 @@ for (E, H, W, sync) in [(256, 480, 640, False), (16, 720, 1280, True), (8, 480, 
             acc += d; n += 1
     ms, cnt = _lib.profile_read("value_map_update_fused_kernel")
     _lib.lib().vlfm_profile_enable(0)
-    print(f"E={E} {W}x{H} sync={sync}: kernel {ms * 1e3:.1f} us; workgroup (0,0): " + ", ".join(f"{nm}={a / max(n, 1):.1f}" for nm, a in zip(names, acc)) + f" (sum {acc.sum() / max(n, 1):.1f} us)")
+    print(f"E={E} {W}x{H} sync={sync} target_wgs={wgs}: kernel {ms * 1e3:.1f} us; workgroup (0,0): " + ", ".join(f"{nm}={a / max(n, 1):.1f}" for nm, a in zip(names, acc)) + f" (sum {acc.sum() / max(n, 1):.1f} us)")
     del sim

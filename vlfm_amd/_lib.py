@@ -123,7 +123,7 @@ def lib() -> ctypes.CDLL:
         L.vlfm_value_map_update_batched.argtypes = [vp, ci, vp, vp, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci, cd, cd, ci,
                                                     ci, vp, vp, vp]
         L.vlfm_value_map_update_fused_batched.argtypes = [vp, ci, vp, vp, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci, cd, cd,
-                                                          ci, ci, vp, vp, vp, vp]
+                                                          ci, ci, vp, vp, vp, vp, vp]
         L.vlfm_value_map_mask_unexplored_batched.argtypes = [vp, ci, ci, vp, vp, vp, ci, ci, vp]
         L.vlfm_value_map_sort_waypoints_batched.argtypes = [vp, ci, ci, vp, ci, ci, vp, vp, vp]
         L.vlfm_resample_coeffs_host.argtypes = [ci, ci, vp, vp, ci, ctypes.POINTER(ci)]

@@ -21,6 +21,7 @@
 // moves a truncation boundary.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/vlfm_amd.h"
 #include "profile.h"
@@ -372,8 +373,121 @@ __global__ __launch_bounds__(256) void value_map_fuse_kernel(UpdateArgs a) {
     fuse_tile<C_STATIC>(a, pose_obs, vis, box, row_begin, tid, nullptr);
 }
 
+// The same tile with the template taps taken from LDS (single-launch kernel).  `quad` is the confidence table's
+// (T/2+1)^2 quadrant: the table depends on |row - T/2| and |col - T/2| only (value_map.py:343-351), and a tap is read only
+// where the visible bit -- which already contains the cone sector -- is set, so template[y][x] == quad[|y-T/2|][|x-T/2|] for
+// every tap taken.  With the taps in LDS there is nothing to batch in the first phase: each row's new confidence is finished
+// at once and only one float per row stays live, which keeps the kernel free of register spills at 16 wavefronts.
+template <int C_STATIC>
+__device__ inline void fuse_tile_lds(const UpdateArgs& a, const vlfm_vm_pose& pose, const unsigned* vis, const float* quad,
+                                     const int4 box, int row_begin, int tid, unsigned* written) {
+    const int T = a.T, S = a.S;
+    const int words = (T + 31) >> 5;
+    const int C = C_STATIC > 0 ? C_STATIC : a.C;
+    float* conf = a.conf + (size_t)pose.env * S * S;
+    float* value = a.value + (size_t)pose.env * S * S * C;
+    const int ex_stride = (S + 31) >> 5;
+    const unsigned* explored = a.explored ? a.explored + (size_t)pose.env * S * ex_stride : nullptr;
+    const double* vals = a.values + (size_t)pose.reserved * C;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int cq = T >> 1, Q = cq + 1;
+    constexpr int R = ROWS_PER_TILE;
+    for (int x = wave * 64 + lane; x < T; x += 256) {
+        if (x - lane > box.w || x - lane + 63 < box.z) continue;  // wave-uniform: segment outside the cone's columns
+        const int mc = pose.col0 + x;
+        const bool col_ok = (unsigned)mc < (unsigned)S;
+        const int adelta = __double2int_rn(__dmul_rn(__dmul_rn(pose.inv_affine[0], (double)x), 1024.0));
+        const int bdelta = __double2int_rn(__dmul_rn(__dmul_rn(pose.inv_affine[3], (double)x), 1024.0));
+        float nw[R];
+        // ---- phase A: source coordinates, visibility bits and template taps (all LDS), bilinear blend.  Nothing here waits
+        // on memory, so the rows are NOT interleaved (a full unroll makes the scheduler keep eight rows of f64 temporaries
+        // alive and spill)
+#pragma unroll 1
+        for (int k = 0; k < R; k++) {
+            const int y = row_begin + k;
+            const int X0 = __double2int_rn(__dmul_rn(__dadd_rn(__dmul_rn(pose.inv_affine[1], (double)y), pose.inv_affine[2]), 1024.0)) + 16;
+            const int Y0 = __double2int_rn(__dmul_rn(__dadd_rn(__dmul_rn(pose.inv_affine[4], (double)y), pose.inv_affine[5]), 1024.0)) + 16;
+            const int Xq = (X0 + adelta) >> 5, Yq = (Y0 + bdelta) >> 5;
+            const int sx = Xq >> 5, sy = Yq >> 5;
+            const bool row_ok = y < T && (unsigned)(pose.row0 + y) < (unsigned)S && col_ok;
+            const bool b0 = row_ok && vis_test(vis, words, T, sy, sx), b1 = row_ok && vis_test(vis, words, T, sy, sx + 1);
+            const bool b2 = row_ok && vis_test(vis, words, T, sy + 1, sx), b3 = row_ok && vis_test(vis, words, T, sy + 1, sx + 1);
+            float v = 0.0f;
+            if (b0 | b1 | b2 | b3) {
+                const int qy0 = abs(sy - cq) * Q, qy1 = abs(sy + 1 - cq) * Q, qx0 = abs(sx - cq), qx1 = abs(sx + 1 - cq);
+                const float t0 = b0 ? quad[qy0 + qx0] : 0.0f, t1 = b1 ? quad[qy0 + qx1] : 0.0f;
+                const float t2 = b2 ? quad[qy1 + qx0] : 0.0f, t3 = b3 ? quad[qy1 + qx1] : 0.0f;
+                // BilinearTab_f weights are products of k/32 in float (exact); accumulate in double like remapBilinear<double>
+                const float fx = (float)(Xq & 31) * 0.03125f, fy = (float)(Yq & 31) * 0.03125f;
+                const float w0 = (1.f - fy) * (1.f - fx), w1 = (1.f - fy) * fx, w2 = fy * (1.f - fx), w3 = fy * fx;
+                v = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn((double)t0, (double)w0), __dmul_rn((double)t1, (double)w1)),
+                                                __dmul_rn((double)t2, (double)w2)), __dmul_rn((double)t3, (double)w3));
+            }
+            nw[k] = v;  // curr_map is f32 (value_map.py:316-317); 0 = the cell is not touched
+        }
+        // ---- phase B: issue the map reads of every active pixel
+        float old[R], oldv1[R];
+        int cell[R];
+        unsigned act = 0u;
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const int mr = pose.row0 + row_begin + k;
+            bool on = nw[k] != 0.0f;
+            // new_map[explored == 0] = 0 (:373); the old values of such cells are cleared by the mask step
+            if (explored && on) on = (explored[(size_t)mr * ex_stride + (mc >> 5)] >> (mc & 31)) & 1u;
+            cell[k] = on ? mr * S + mc : 0;
+            act |= on ? (1u << k) : 0u;
+            old[k] = conf[cell[k]];
+            if (C_STATIC == 1) oldv1[k] = value[cell[k]];
+        }
+        // ---- phase C: fuse and write back
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const bool on = (act >> k) & 1u;
+            bool stored = false;
+            if (on && C_STATIC == 1) {
+                float c_out, v_out;
+                if (fuse_cell<1>(a, nw[k], old[k], &oldv1[k], vals, c_out, &v_out)) {
+                    conf[cell[k]] = c_out;
+                    value[cell[k]] = v_out;
+                    stored = true;
+                }
+            }
+            if (written && C_STATIC == 1) {
+                // lanes are consecutive map columns: the stores of this row form at most three 32-cell words of the plane;
+                // the lowest storing lane of each word ORs the word's bits in, and only when the plane does not show them yet
+                const unsigned long long m = __ballot(stored);
+                if (stored) {
+                    const int lo = lane - (mc & 31);
+                    const unsigned wm = lo >= 0 ? (unsigned)(m >> lo) : (unsigned)(m << (-lo));
+                    if ((mc & 31) == __builtin_ctz(wm)) {
+                        unsigned* wp = written + (size_t)(pose.row0 + row_begin + k) * ex_stride + (mc >> 5);
+                        if ((*wp & wm) != wm) atomicOr(wp, wm);
+                    }
+                }
+            }
+            if (!on || C_STATIC == 1) continue;
+            {
+                float c_out = 0.0f;
+                bool wrote = false;
+                for (int c = 0; c < C; c++) {
+                    const float ov = value[(size_t)cell[k] * C + c];
+                    float nv;
+                    wrote = fuse_cell<1>(a, nw[k], old[k], &ov, vals + c, c_out, &nv);
+                    if (!wrote) break;
+                    value[(size_t)cell[k] * C + c] = nv;
+                }
+                if (wrote) {
+                    conf[cell[k]] = c_out;
+                    if (written) atomicOr(written + (size_t)(pose.row0 + row_begin + k) * ex_stride + (mc >> 5), 1u << (mc & 31));
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ single-launch update
-// ValueMap.update_map for n observations in ONE launch: grid = (G, n), 256 threads.  Every workgroup of an observation
+// ValueMap.update_map for n observations in ONE launch: grid = (G, n), 1024 threads.  Every workgroup of an observation
 //   1. turns the column-max keys into the depth-profile polygon and rasterises it into LDS (the same arithmetic as
 //      visible_mask_kernel; G-fold redundant, but LDS-only work of a few microseconds -- what it buys is that no
 //      visibility plane travels through HBM and no second and third launch sit on the step's critical path);
@@ -387,6 +501,7 @@ __global__ __launch_bounds__(256) void value_map_fuse_kernel(UpdateArgs a) {
 struct FusedExtra {
     unsigned* written;   // [n_envs][S][ceil(S/32)] or null
     int* counters;       // [n] zero on entry, zero again on exit
+    const float* quad;   // [(T/2+1)^2] confidence quadrant (unmasked table, rows/cols >= T/2)
 };
 
 // Optional phase timing of the single-launch update (compile with -DVLFM_PHASE_TIMING; tools/vm_phase_probe.py): thread 0
@@ -402,46 +517,111 @@ __device__ long long g_vm_phase[16];
 #define VM_PHASE(k) do {} while (0)
 #endif
 
-constexpr int LONG_EDGE = 24;      // edges longer than this (Chebyshev) are rasterised by the whole workgroup
-constexpr int LONG_EDGE_CAP = 16;
+// ---- polygon raster with the work FLATTENED over the workgroup.
+// raster_edge (raster.h) gives one lane a whole edge: a wavefront then runs for as long as its longest edge, and the profile
+// polygon mixes hundreds of 1-2 pixel edges with a few that cross the whole template (measured: 14 of the kernel's 22 us).
+// Here every edge is cut into independent items -- its boundary pixels (closed form of the 8-connected line iterator:
+// pixel i of the walk has minor offset (2 dy i + dx - 1) / (2 dx), checked against the iterative form for every
+// dx, dy <= 260) and its scanline crossings (xs + (y - y0) * dxdy) -- an exclusive scan of the item counts maps item ->
+// (edge, k), and the items are dealt round-robin to the lanes.  Same bits as raster_edge; edges that need clipping (a
+// vertex outside the T x T image: never for depth in [0, 1]) keep the serial path.
+__device__ inline bool edge_inside(int2 p0, int2 p1, int T) {
+    return (unsigned)p0.x < (unsigned)T && (unsigned)p0.y < (unsigned)T && (unsigned)p1.x < (unsigned)T &&
+           (unsigned)p1.y < (unsigned)T;
+}
 
-// One long polygon edge, all threads of the workgroup: boundary pixels through the closed form of the 8-connected line
-// iterator (pixel i of the walk has minor offset (2 dy i + dx - 1) / (2 dx) -- checked against the iterative form for
-// every dx, dy <= 260), scanline crossings through xs + (y - y0) * dxdy.  Both endpoints must lie inside the image
-// (no clipping); same bits as raster_edge.
-__device__ inline void raster_edge_coop(const LdsBitmap& bm, int ax, int ay, int bx, int by, int tid, int nth) {
-    {
-        int x0 = ax, y0 = ay, dx = bx - ax, dy = by - ay;
-        if (dx < 0) { dx = -dx; dy = -dy; x0 = bx; y0 = by; }
+__device__ inline void raster_item(const LdsBitmap& bm, int2 p0, int2 p1, int k) {
+    int dx = p1.x - p0.x, dy = p1.y - p0.y;
+    const int major = max(abs(dx), abs(dy));
+    if (k <= major) {                       // boundary pixel k of the line walked towards +x (LineIterator, leftToRight)
+        int x0 = p0.x, y0 = p0.y;
+        if (dx < 0) { dx = -dx; dy = -dy; x0 = p1.x; y0 = p1.y; }
         int sy = 1;
         if (dy < 0) { dy = -dy; sy = -1; }
         const bool vert = dy > dx;
-        const int major = vert ? dy : dx, minor = vert ? dx : dy;
-        for (int i = tid; i <= major; i += nth) {
-            const int m = major > 0 ? (2 * minor * i + major - 1) / (2 * major) : 0;
-            const int px = vert ? x0 + m : x0 + i;
-            const int py = vert ? y0 + sy * i : y0 + sy * m;
-            bm_or(bm, py, px);
-        }
+        const int minor = vert ? dx : dy;
+        const int m = major > 0 ? (2 * minor * k + major - 1) / (2 * major) : 0;
+        bm_or(bm, vert ? y0 + sy * k : y0 + sy * m, vert ? x0 + m : x0 + k);
+        return;
     }
-    if (ay == by) return;
-    const long long fax = (long long)ax << XY_SHIFT, fbx = (long long)bx << XY_SHIFT;
-    const long long dxdy = (fbx - fax) / (long long)(by - ay);
-    int y0, y1;
-    long long xs;
-    if (ay < by) { y0 = ay; y1 = by; xs = fax; } else { y0 = by; y1 = ay; xs = fbx; }
-    for (int y = y0 + tid; y < y1; y += nth) {
-        const long long c = xs + (long long)(y - y0) * dxdy;
-        const long long px = c >> XY_SHIFT;
-        if ((c & (XY_ONE - 1)) == 0 && px >= 0 && px < bm.cols) bm_or(bm, y, (int)px);
-        long long first = px + 1;
-        if (first < 0) first = 0;
-        if (first < bm.cols) bm_toggle_local(bm, y, (int)first);
+    // scanline crossing: half-open [min y, max y), 16.16 x advanced by the truncated slope.  |num| < 2^24 and |den| < 2^8, so
+    // the f64 quotient truncates to exactly the integer quotient (its error is far below the 1/|den| gap to an integer).
+    const int s = k - major - 1;
+    const long long num = ((long long)(p1.x - p0.x)) << XY_SHIFT;
+    const long long dxdy = (long long)((double)num / (double)(p1.y - p0.y));
+    const int ylo = min(p0.y, p1.y);
+    const long long xs = ((long long)(p0.y < p1.y ? p0.x : p1.x)) << XY_SHIFT;
+    const long long c = xs + (long long)s * dxdy;
+    const long long px = c >> XY_SHIFT;
+    const int y = ylo + s;
+    if ((c & (XY_ONE - 1)) == 0 && px >= 0 && px < bm.cols) bm_or(bm, y, (int)px);
+    long long first = px + 1;
+    if (first < 0) first = 0;
+    if (first < bm.cols) bm_toggle_local(bm, y, (int)first);
+}
+
+// vert[0 .. n_vert) closed polygon; pref = n_vert + 1 ints of LDS; wave_tot = 8 ints of LDS.  All threads call it.
+__device__ inline void raster_polygon_flat(const LdsBitmap& bm, const int2* vert, int n_vert, int* pref, int* wave_tot,
+                                           int tid, int nth) {
+    const int per = (n_vert + nth - 1) / nth;
+    const int e0 = min(tid * per, n_vert), e1 = min(e0 + per, n_vert);
+    int local = 0;
+    for (int e = e0; e < e1; e++) {
+        const int2 p0 = vert[e == 0 ? n_vert - 1 : e - 1], p1 = vert[e];
+        int cnt = 0;
+        // a zero-length edge (consecutive image columns that fall into the same template cell: most of them) only draws its
+        // own vertex, which the neighbouring non-degenerate edges draw as their end point -- no items
+        if (p0.x == p1.x && p0.y == p1.y) cnt = 0;
+        else if (edge_inside(p0, p1, bm.rows)) cnt = max(abs(p1.x - p0.x), abs(p1.y - p0.y)) + 1 + abs(p1.y - p0.y);
+        else raster_edge(bm, (long long)p0.x << XY_SHIFT, p0.y, (long long)p1.x << XY_SHIFT, p1.y);
+        pref[e] = local;   // exclusive within this lane's chunk; the chunk base is added below
+        local += cnt;
+    }
+    // exclusive scan of the per-lane totals: wavefront shuffle scan, then the wavefront totals through LDS
+    const int lane = tid & 63, wave = tid >> 6;
+    int incl = local;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int base = incl - local;
+    for (int w = 0; w < wave; w++) base += wave_tot[w];
+    for (int e = e0; e < e1; e++) pref[e] += base;
+    if (tid == nth - 1) pref[n_vert] = base + local;
+    __syncthreads();
+    // every lane takes one contiguous run of items: ONE search for the edge of its first item, then a walk
+    const int total = pref[n_vert];
+    const int chunk = (total + nth - 1) / nth;
+    int j = tid * chunk;
+    const int j_end = min(j + chunk, total);
+    if (j < j_end) {
+        int lo = 0, hi = n_vert;             // largest e with pref[e] <= j
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (pref[mid] <= j) lo = mid; else hi = mid;
+        }
+        int next = pref[lo + 1];
+        int2 p0 = vert[lo == 0 ? n_vert - 1 : lo - 1], p1 = vert[lo];
+        int k = j - pref[lo];
+        for (; j < j_end; j++, k++) {
+            while (j >= next) {              // step over exhausted (and item-less) edges
+                lo++;
+                k = j - next;
+                next = pref[lo + 1];
+                p0 = p1;
+                p1 = vert[lo];
+            }
+            raster_item(bm, p0, p1, k);
+        }
     }
 }
 
+constexpr int FUSED_THREADS = 1024;   // 16 wavefronts: the raster's items are spread thin, then 4 tiles are fused at a time
+
 template <int C_STATIC>
-__global__ __launch_bounds__(256) void value_map_update_fused_kernel(UpdateArgs a, FusedExtra fx) {
+__global__ __launch_bounds__(FUSED_THREADS) void value_map_update_fused_kernel(UpdateArgs a, FusedExtra fx) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int T = a.T, W = a.W, S = a.S;
     const int words = (T + 31) >> 5;
@@ -449,14 +629,25 @@ __global__ __launch_bounds__(256) void value_map_update_fused_kernel(UpdateArgs 
     unsigned* solid = reinterpret_cast<unsigned*>(smem);
     unsigned* parity = solid + T * words;      // after the resolve: the visible plane
     int2* vert = reinterpret_cast<int2*>(parity + T * words + ((2 * T * words) & 1));
-    __shared__ int sh_long[LONG_EDGE_CAP];
-    __shared__ int sh_n_long, sh_last;
+    int* pref = reinterpret_cast<int*>(vert + n_vert);      // [n_vert + 1] item prefix sums of the flattened raster
+    const int Q = (T >> 1) + 1;
+    float* quad = reinterpret_cast<float*>(pref + n_vert + 1 + ((n_vert + 1) & 1));  // [Q * Q]
+    __shared__ int sh_wave_tot[FUSED_THREADS / 64];
+    __shared__ int sh_last;
     __shared__ int sh_box[4];
     __shared__ int4 sh_dbox;
     const int obs = blockIdx.y, g = blockIdx.x, G = gridDim.x;
     const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63;
 
-    vlfm_vm_pose pose = a.pose[obs];
+    // the pose is the same for every lane: keep its 16 dwords in scalar registers (the six f64 coefficients alone would
+    // otherwise pin 12 vector registers through the whole fuse loop)
+    vlfm_vm_pose pose;
+    {
+        const int* src = reinterpret_cast<const int*>(a.pose + obs);
+        int* dst = reinterpret_cast<int*>(&pose);
+#pragma unroll
+        for (int u = 0; u < (int)(sizeof(vlfm_vm_pose) / 4); u++) dst[u] = __builtin_amdgcn_readfirstlane(src[u]);
+    }
     pose.reserved = obs;  // fuse_tile reads the observation's values through it
     const int ex_stride = (S + 31) >> 5;
     // step 2's first loads are independent of everything else: issue them before the raster so that they travel under it
@@ -470,9 +661,45 @@ __global__ __launch_bounds__(256) void value_map_update_fused_kernel(UpdateArgs 
     LdsBitmap bm;
     bm.solid = solid; bm.parity = parity; bm.rows = T; bm.cols = T; bm.words = words;
     for (int i = tid; i < 2 * T * words; i += nth) solid[i] = 0u;
-    if (tid == 0) { sh_n_long = 0; sh_box[0] = T; sh_box[1] = -1; sh_box[2] = T; sh_box[3] = -1; }
+    if (tid == 0) { sh_box[0] = T; sh_box[1] = -1; sh_box[2] = T; sh_box[3] = -1; }
     const unsigned* cm = a.colmax + (size_t)obs * W;
-    for (int i = tid; i < W; i += nth) {
+    // Loads in issue order keys + tangents, THEN the quadrant: the vertex arithmetic below only has to wait for the first two
+    // (memory returns in order), and the quadrant's ten loads per lane travel under it.
+    constexpr int KPT = 2;   // keys per lane held in registers (W <= 2048 with 1024 lanes); wider images loop below
+    unsigned key_r[KPT];
+    double tan_r[KPT];
+#pragma unroll
+    for (int u = 0; u < KPT; u++) {
+        const int i = tid + u * nth;
+        key_r[u] = i < W ? cm[i] : 0u;
+        tan_r[u] = i < W ? a.tan_tab[i] : 0.0;
+    }
+    constexpr int QPT = 10;  // quadrant floats per lane in registers ((T/2+1)^2 <= 10240: T <= 201); larger templates loop
+    float quad_r[QPT];
+#pragma unroll
+    for (int u = 0; u < QPT; u++) {
+        const int i = tid + u * nth;
+        quad_r[u] = i < Q * Q ? fx.quad[i] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < KPT; u++) {
+        const int i = tid + u * nth;
+        if (i < W) {
+            const unsigned key = key_r[u];
+            const float raw = __uint_as_float((key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key);
+            const float d = __fadd_rn(__fmul_rn(raw, a.depth_scale), a.depth_offset);
+            const float xr = __fadd_rn(__fmul_rn(d, a.ppm_f), a.half_t_f);
+            const double yl = __dadd_rn(__dmul_rn(__dmul_rn((double)d, tan_r[u]), a.ppm_d), a.half_t_d);
+            vert[i + 1] = make_int2((int)(long long)yl, (int)(long long)xr);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < QPT; u++) {
+        const int i = tid + u * nth;
+        if (i < Q * Q) quad[i] = quad_r[u];
+    }
+    for (int i = tid + QPT * nth; i < Q * Q; i += nth) quad[i] = fx.quad[i];
+    for (int i = tid + KPT * nth; i < W; i += nth) {
         const unsigned key = cm[i];
         const float raw = __uint_as_float((key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key);
         const float d = __fadd_rn(__fmul_rn(raw, a.depth_scale), a.depth_offset);        // f32 (value_map.py:234)
@@ -491,27 +718,8 @@ __global__ __launch_bounds__(256) void value_map_update_fused_kernel(UpdateArgs 
         __threadfence();
         sh_last = atomicAdd(&fx.counters[obs], 1) == G - 1;
     }
-    for (int i = tid; i < n_vert; i += nth) {
-        const int2 p0 = vert[i == 0 ? n_vert - 1 : i - 1], p1 = vert[i];
-        const int len = max(abs(p1.x - p0.x), abs(p1.y - p0.y));
-        const bool inside = (unsigned)p0.x < (unsigned)T && (unsigned)p0.y < (unsigned)T && (unsigned)p1.x < (unsigned)T &&
-                            (unsigned)p1.y < (unsigned)T;
-        if (len > LONG_EDGE && inside) {
-            const int k = atomicAdd(&sh_n_long, 1);
-            if (k < LONG_EDGE_CAP) { sh_long[k] = i; continue; }
-        }
-        raster_edge(bm, (long long)p0.x << XY_SHIFT, p0.y, (long long)p1.x << XY_SHIFT, p1.y);
-    }
-    __syncthreads();
+    raster_polygon_flat(bm, vert, n_vert, pref, sh_wave_tot, tid, nth);
     VM_PHASE(2);
-    {
-        const int n_long = min(sh_n_long, LONG_EDGE_CAP);
-        for (int k = 0; k < n_long; k++) {
-            const int i = sh_long[k];
-            const int2 p0 = vert[i == 0 ? n_vert - 1 : i - 1], p1 = vert[i];
-            raster_edge_coop(bm, p0.x, p0.y, p1.x, p1.y, tid, nth);
-        }
-    }
     if (sh_last) {
         unsigned* cmw = a.colmax + (size_t)obs * W;
         for (int i = tid; i < W; i += nth) cmw[i] = 0u;
@@ -595,15 +803,17 @@ __global__ __launch_bounds__(256) void value_map_update_fused_kernel(UpdateArgs 
     __syncthreads();
     VM_PHASE(6);
     // ---- step 3: rotate + place + fuse, tiles g, g + G, ...
-    const int4 box = sh_dbox;
+    int4 box = sh_dbox;
+    box.x = __builtin_amdgcn_readfirstlane(box.x); box.y = __builtin_amdgcn_readfirstlane(box.y);
+    box.z = __builtin_amdgcn_readfirstlane(box.z); box.w = __builtin_amdgcn_readfirstlane(box.w);
     if (box.z > box.w) return;
-    const int tiles = (T + ROWS_PER_TILE - 1) / ROWS_PER_TILE;
-    for (int t = g; t < tiles; t += G) {
-        const int row_begin = t * ROWS_PER_TILE;
-        if (pose.row0 + min(row_begin + ROWS_PER_TILE, T) <= 0 || pose.row0 + row_begin >= S) continue;
-        if (row_begin > box.y || row_begin + ROWS_PER_TILE <= box.x) continue;
-        fuse_tile<C_STATIC>(a, pose, parity, box, row_begin, tid, written);
-    }
+    // four wavefronts per 8-row tile (fuse_tile's shape), FUSED_THREADS / 256 tiles in flight per workgroup; only tiles
+    // inside the cone's destination rows are dealt out
+    const int tiles_per_pass = nth >> 8, tg = tid >> 8, t_in = tid & 255;
+    const int t_lo = max(box.x, max(0, -pose.row0)) / ROWS_PER_TILE;
+    const int t_hi = min(min(box.y, T - 1), S - 1 - pose.row0) / ROWS_PER_TILE;   // inclusive
+    for (int t = t_lo + g * tiles_per_pass + tg; t <= t_hi; t += G * tiles_per_pass)
+        fuse_tile_lds<C_STATIC>(a, pose, parity, quad, box, t * ROWS_PER_TILE, t_in, written);
     VM_PHASE(7);
 }
 
@@ -797,10 +1007,10 @@ extern "C" int vlfm_value_map_update_fused_batched(uint32_t* d_colmax_keys, int 
                                                    int map_size, int channels, int pixels_per_meter, double min_depth,
                                                    double max_depth, int use_max_confidence, int fusion_type,
                                                    const uint32_t* d_explored_bits, uint32_t* d_written_bits,
-                                                   int32_t* d_counters, void* stream) {
+                                                   int32_t* d_counters, const float* d_conf_quadrant, void* stream) {
     if (n == 0) return VLFM_OK;
     if (!d_colmax_keys || !d_tan || !d_template || !d_template_bits || !d_pose || !d_values || !d_conf || !d_value ||
-        !d_counters || n < 0 || width <= 0 || template_size <= 0 || map_size <= 0 || channels <= 0 || fusion_type < 0 ||
+        !d_counters || !d_conf_quadrant || n < 0 || width <= 0 || template_size <= 0 || map_size <= 0 || channels <= 0 || fusion_type < 0 ||
         fusion_type > 2)
         return fail(VLFM_ERR_INVALID, "value_map_update_fused_batched: bad argument");
     if ((d_explored_bits == nullptr) != (d_written_bits == nullptr))
@@ -818,20 +1028,35 @@ extern "C" int vlfm_value_map_update_fused_batched(uint32_t* d_colmax_keys, int 
     a.ppm_d = (double)pixels_per_meter;
     a.half_t_d = template_size / 2.0;
     a.use_max_conf = use_max_confidence; a.fusion = fusion_type;
-    FusedExtra fx{d_written_bits, d_counters};
+    FusedExtra fx{d_written_bits, d_counters, d_conf_quadrant};
     const int T = template_size, words = (T + 31) >> 5;
-    const size_t lds = (size_t)(2 * T * words + ((2 * T * words) & 1)) * 4 + (size_t)(width + 2) * sizeof(int2);
-    if (lds > 64 * 1024) return fail(VLFM_ERR_CAPACITY, "value_map_update_fused_batched: template/width too large for LDS");
+    const int n_vert = width + 2, Q = T / 2 + 1;
+    const size_t lds = (size_t)(2 * T * words + ((2 * T * words) & 1)) * 4 + (size_t)n_vert * sizeof(int2) +
+                       (size_t)(n_vert + 1 + ((n_vert + 1) & 1)) * sizeof(int) + (size_t)Q * Q * 4;
+    if (lds > 150 * 1024) return fail(VLFM_ERR_CAPACITY, "value_map_update_fused_batched: template/width too large for LDS");
+    if (lds > 64 * 1024) {   // beyond the default dynamic-LDS limit: opt in once per device and kernel
+        static LdsOptIn opt1, opt0;
+        const bool ok = channels == 1 ? opt1.ensure(reinterpret_cast<const void*>(value_map_update_fused_kernel<1>), 150 * 1024)
+                                      : opt0.ensure(reinterpret_cast<const void*>(value_map_update_fused_kernel<0>), 150 * 1024);
+        if (!ok) return fail(VLFM_ERR_HIP, "value_map_update_fused_batched: cannot opt in to large LDS");
+    }
     const int tiles = (T + ROWS_PER_TILE - 1) / ROWS_PER_TILE;
-    // workgroups per observation: ~2048 in flight over all observations, at least 2, at most one per row tile
-    int G = (2048 + n - 1) / n;
-    if (G > tiles) G = tiles;
-    if (G < 2) G = 2;
+    // workgroups per observation: a 1024-thread workgroup fills a CU (register budget), so aim for one per CU over all
+    // observations; more than ceil(tiles / 4) would leave workgroups without a tile
+    int target = 256;
+    if (const char* e = getenv("VLFM_VM_TARGET_WGS")) {  // diagnostic: tools/vm_phase_probe.py sweeps it
+        const int t = atoi(e);
+        if (t > 0) target = t;
+    }
+    int G = (target + n - 1) / n;
+    const int g_max = (tiles + FUSED_THREADS / 256 - 1) / (FUSED_THREADS / 256);
+    if (G > g_max) G = g_max;
+    if (G < 1) G = 1;
     VLFM_TIMED("value_map_update_fused_kernel", stream);
     if (channels == 1)
-        VLFM_KLAUNCH(value_map_update_fused_kernel<1>, dim3(G, n), dim3(256), lds, (hipStream_t)stream, a, fx);
+        VLFM_KLAUNCH(value_map_update_fused_kernel<1>, dim3(G, n), dim3(FUSED_THREADS), lds, (hipStream_t)stream, a, fx);
     else
-        VLFM_KLAUNCH(value_map_update_fused_kernel<0>, dim3(G, n), dim3(256), lds, (hipStream_t)stream, a, fx);
+        VLFM_KLAUNCH(value_map_update_fused_kernel<0>, dim3(G, n), dim3(FUSED_THREADS), lds, (hipStream_t)stream, a, fx);
     return check_launch("value_map_update_fused_kernel");
 }
 

@@ -93,6 +93,7 @@ class _ConeTemplates:
 
     def __init__(self) -> None:
         self._tmpl: Dict[Tuple[Any, ...], Any] = {}
+        self._quad: Dict[Tuple[Any, ...], Any] = {}
         self._tan: Dict[Tuple[Any, ...], Any] = {}
         self._disc: Dict[Tuple[Any, ...], Any] = {}
 
@@ -112,6 +113,9 @@ class _ConeTemplates:
             _lib.check(rc, "cone_template_host")
             assert rc == T
             conf = _confidence_table_numpy(T, fov, min_conf)
+            tab = conf.reshape(T, T)
+            assert np.array_equal(tab, tab[::-1]) and np.array_equal(tab, tab[:, ::-1])  # |row - c|, |col - c| only
+            self._quad[key] = torch.from_numpy(np.ascontiguousarray(tab[T // 2:, T // 2:])).to(device)
             d_conf = torch.from_numpy(conf).to(device)
             d_poly = torch.from_numpy(poly).to(device)
             d_tmpl = torch.empty(T * T, dtype=torch.float32, device=device)
@@ -123,6 +127,11 @@ class _ConeTemplates:
                 torch.cuda.current_stream().synchronize()
             self._tmpl[key] = (d_tmpl, d_bits, T)
         return self._tmpl[key]
+
+    def quadrant(self, device, fov: float, max_depth: float, ppm: int, min_conf: float):
+        """[(T/2+1)^2] f32: the unmasked confidence table's quadrant for the single-launch update's LDS taps."""
+        self.template(device, fov, max_depth, ppm, min_conf)
+        return self._quad[(str(device), float(fov), float(max_depth), int(ppm), float(min_conf))]
 
     def tan_table(self, device, fov: float, width: int):
         import torch
@@ -344,7 +353,8 @@ class ValueMapBatch:
                     d_vals.data_ptr(), n, self.conf.data_ptr(), self.value.data_ptr(), self.size, self.channels,
                     self.pixels_per_meter, float(min_depth), float(max_depth), int(self.use_max_confidence),
                     _lib.FUSION_TYPES[self.fusion_type], explored_ptr, written_ptr, self._counters.data_ptr(),
-                    _stream_ptr()), "value_map_update_fused")
+                    _TEMPLATES.quadrant(self.device, fov, max_depth, self.pixels_per_meter,
+                                        self._min_confidence).data_ptr(), _stream_ptr()), "value_map_update_fused")
                 return
             if explored_ptr is not None:
                 slots = np.unique(pose["env"])
