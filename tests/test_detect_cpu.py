@@ -101,3 +101,60 @@ def test_object_detections_match_reference_fixture():
     assert np.array_equal(np.array(j["logits"]), g["after_conf_logits"]) and j["phrases"] == list(g["after_conf_phrases"])
     assert d.num_detections == int(g["num"])
     assert np.array_equal(ObjectDetections.from_json(j).boxes.numpy(), g["roundtrip_boxes"])
+
+
+def test_gemm_shaped_convolutions_match_conv2d():
+    """det_ops.patch_convs_as_gemm: a kernel == stride (patch embedding) or 1x1 convolution evaluated as one GEMM gives
+    nn.Conv2d's result (up to the summation order), and leaves every other convolution alone."""
+    import torch
+    import torch.nn as nn
+
+    from vlfm_amd.vlm.det_ops import patch_convs_as_gemm
+
+    torch.manual_seed(0)
+    net = nn.ModuleDict({"patch": nn.Conv2d(3, 24, 4, 4), "point": nn.Conv2d(24, 16, 1), "keep3": nn.Conv2d(16, 8, 3, 2, 1),
+                         "grouped": nn.Conv2d(16, 16, 1, groups=2), "ragged": nn.Conv2d(3, 5, (4, 2), (4, 2), bias=False)})
+    x = torch.randn(2, 3, 30, 41)                      # not a multiple of the patch: the remainder is dropped, as conv does
+    want = {k: None for k in net}
+    with torch.no_grad():
+        p = net["patch"](x)
+        want = dict(patch=p, point=net["point"](p), keep3=net["keep3"](net["point"](p)), grouped=net["grouped"](net["point"](p)),
+                    ragged=net["ragged"](x))
+        assert patch_convs_as_gemm(net) == 3           # patch, point, ragged; the 3x3 and the grouped one are left alone
+        p = net["patch"](x)
+        got = dict(patch=p, point=net["point"](p), keep3=net["keep3"](net["point"](p)), grouped=net["grouped"](net["point"](p)),
+                   ragged=net["ragged"](x))
+    for k in want:
+        assert got[k].shape == want[k].shape, k
+        assert torch.allclose(got[k], want[k], atol=1e-5, rtol=1e-5), k
+
+
+def test_text_branch_cache_returns_the_same_features():
+    import torch
+    from transformers import GroundingDinoConfig, GroundingDinoForObjectDetection
+
+    from vlfm_amd.vlm.det_ops import cache_text_branch
+
+    tiny = GroundingDinoConfig(num_queries=10, d_model=32, encoder_layers=1, decoder_layers=2, encoder_ffn_dim=64,
+                               decoder_ffn_dim=64, encoder_attention_heads=2, decoder_attention_heads=2,
+                               backbone_config={"model_type": "swin", "embed_dim": 16, "depths": [1, 1, 1, 1],
+                                                "num_heads": [1, 2, 2, 2], "window_size": 4,
+                                                "out_features": ["stage2", "stage3", "stage4"]},
+                               text_config={"model_type": "bert", "hidden_size": 32, "num_hidden_layers": 1,
+                                            "num_attention_heads": 2, "intermediate_size": 64, "vocab_size": 3000,
+                                            "max_position_embeddings": 64})
+    torch.manual_seed(0)
+    model = GroundingDinoForObjectDetection(tiny).eval()
+    calls = []
+    plain = model.model.text_backbone.forward
+    model.model.text_backbone.forward = lambda *a, **k: (calls.append(1), plain(*a, **k))[1]
+    cache_text_branch(model)
+    pix = torch.randn(1, 3, 96, 128)
+    ids = torch.tensor([[101, 2100, 1012, 2200, 1012, 102]])
+    with torch.inference_mode():
+        a = model(pixel_values=pix, input_ids=ids, attention_mask=torch.ones_like(ids))
+        b = model(pixel_values=pix, input_ids=ids, attention_mask=torch.ones_like(ids))
+        other = torch.tensor([[101, 2300, 1012, 102, 0, 0]])
+        model(pixel_values=pix, input_ids=other, attention_mask=(other != 0).long())
+    assert len(calls) == 2                             # second identical caption: no BERT forward
+    assert torch.equal(a.logits, b.logits) and torch.equal(a.pred_boxes, b.pred_boxes)

@@ -180,3 +180,58 @@ def patch_hf_deformable_attention(model) -> int:
             mod.forward = forward
             n += 1
     return n
+
+
+def patch_convs_as_gemm(model) -> int:
+    """Evaluate the GEMM-shaped convolutions of ``model`` (GroundingDINO: the Swin patch embedding, kernel == stride, and the
+    1x1 ``input_proj`` convolutions) as one matrix multiplication each.  For these f32 shapes MIOpen falls back to its
+    ``naive_conv`` kernel (13 % of the detector's GPU time in rocprofv3); a patch / pointwise convolution IS a GEMM over
+    the unfolded pixels, and hipBLASLt runs it at the f32 MFMA rate.  Same arithmetic up to the summation order of the
+    reduction (checked against nn.Conv2d in tests/test_detect_cpu.py).  Returns the number of modules patched."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    n = 0
+    for mod in model.modules():
+        if not isinstance(mod, nn.Conv2d) or mod.groups != 1 or mod.dilation != (1, 1) or mod.padding not in ((0, 0), "valid"):
+            continue
+        kh, kw = mod.kernel_size
+        if mod.stride != (kh, kw) and not (kh == kw == 1 and mod.stride == (1, 1)):
+            continue
+
+        def forward(x, _m=mod, _kh=kh, _kw=kw):
+            b, c, h, w = x.shape
+            oh, ow = h // _kh, w // _kw
+            if _kh == 1 and _kw == 1:
+                rows = x.permute(0, 2, 3, 1).reshape(b * h * w, c)
+            else:   # non-overlapping patches: [B, C, oh, kh, ow, kw] -> rows of (c, kh, kw), the weight's own order
+                rows = x[:, :, :oh * _kh, :ow * _kw].reshape(b, c, oh, _kh, ow, _kw).permute(0, 2, 4, 1, 3, 5) \
+                    .reshape(b * oh * ow, c * _kh * _kw)
+            y = F.linear(rows, _m.weight.reshape(_m.out_channels, -1), _m.bias)
+            return y.view(b, oh, ow, _m.out_channels).permute(0, 3, 1, 2)
+
+        mod.forward = forward
+        n += 1
+    return n
+
+
+def cache_text_branch(model) -> None:
+    """GroundingDINO's caption is constant for an episode (the class list), yet HF's forward re-runs BERT on it for every
+    frame.  Memoise ``model.model.text_backbone`` on the bytes of its integer / mask inputs: one BERT forward per distinct
+    (caption batch), then a dictionary hit."""
+    backbone = model.model.text_backbone
+    plain = backbone.forward
+    cache = {}
+
+    def forward(input_ids, attention_mask=None, token_type_ids=None, position_ids=None, **kw):
+        if not (torch.is_tensor(input_ids) and not torch.is_grad_enabled()):
+            return plain(input_ids, attention_mask, token_type_ids, position_ids, **kw)
+        key = tuple((t.shape, t.dtype, t.detach().cpu().numpy().tobytes()) if torch.is_tensor(t) else t
+                    for t in (input_ids, attention_mask, token_type_ids, position_ids)) + tuple(sorted(kw.items()))
+        if key not in cache:
+            if len(cache) > 64:
+                cache.clear()
+            cache[key] = plain(input_ids, attention_mask, token_type_ids, position_ids, **kw)
+        return cache[key]
+
+    backbone.forward = forward

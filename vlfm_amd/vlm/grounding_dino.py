@@ -109,6 +109,8 @@ class GroundingDINO:
         self.description = f"GroundingDINO (HF Swin-T + BERT-base geometry, 172 M parameters) {self.weights}"
         self.model.eval().to(self.device)
         self.hip_deform_attn = det_ops.patch_hf_deformable_attention(self.model)  # HIP MsDeformAttn
+        self.gemm_convs = det_ops.patch_convs_as_gemm(self.model)   # patch-embed / 1x1 convolutions as GEMMs
+        det_ops.cache_text_branch(self.model)                       # the caption is constant over an episode
 
     @torch.inference_mode()
     def predict_batch(self, images_u8: torch.Tensor, captions: Sequence[str]) -> List[ObjectDetections]:
