@@ -226,7 +226,7 @@ def cache_text_branch(model) -> None:
     def forward(input_ids, attention_mask=None, token_type_ids=None, position_ids=None, **kw):
         if not (torch.is_tensor(input_ids) and not torch.is_grad_enabled()):
             return plain(input_ids, attention_mask, token_type_ids, position_ids, **kw)
-        key = tuple((t.shape, t.dtype, t.detach().cpu().numpy().tobytes()) if torch.is_tensor(t) else t
+        key = tuple((t.shape, t.dtype, str(t.device), t.detach().cpu().numpy().tobytes()) if torch.is_tensor(t) else t
                     for t in (input_ids, attention_mask, token_type_ids, position_ids)) + tuple(sorted(kw.items()))
         if key not in cache:
             if len(cache) > 64:
