@@ -152,9 +152,13 @@ def test_text_branch_cache_returns_the_same_features():
     pix = torch.randn(1, 3, 96, 128)
     ids = torch.tensor([[101, 2100, 1012, 2200, 1012, 102]])
     with torch.inference_mode():
+        model.vlfm_text_key = ("chair . bed .",)
         a = model(pixel_values=pix, input_ids=ids, attention_mask=torch.ones_like(ids))
         b = model(pixel_values=pix, input_ids=ids, attention_mask=torch.ones_like(ids))
         other = torch.tensor([[101, 2300, 1012, 102, 0, 0]])
+        model.vlfm_text_key = ("tv .",)
         model(pixel_values=pix, input_ids=other, attention_mask=(other != 0).long())
-    assert len(calls) == 2                             # second identical caption: no BERT forward
+        model.vlfm_text_key = None                     # no announced caption: the backbone runs as usual
+        model(pixel_values=pix, input_ids=other, attention_mask=(other != 0).long())
+    assert len(calls) == 3                             # second identical caption: no BERT forward
     assert torch.equal(a.logits, b.logits) and torch.equal(a.pred_boxes, b.pred_boxes)

@@ -217,17 +217,19 @@ def patch_convs_as_gemm(model) -> int:
 
 def cache_text_branch(model) -> None:
     """GroundingDINO's caption is constant for an episode (the class list), yet HF's forward re-runs BERT on it for every
-    frame.  Memoise ``model.model.text_backbone`` on the bytes of its integer / mask inputs: one BERT forward per distinct
-    (caption batch), then a dictionary hit."""
+    frame.  Memoise ``model.model.text_backbone`` per caption batch: the caller announces the captions it is about to run
+    through ``model.vlfm_text_key`` (a hashable, host-side value -- no device read-back, so the lookup is legal inside a
+    HIP-graph capture); without a key the backbone runs as usual."""
     backbone = model.model.text_backbone
     plain = backbone.forward
     cache = {}
+    model.vlfm_text_key = None
 
     def forward(input_ids, attention_mask=None, token_type_ids=None, position_ids=None, **kw):
-        if not (torch.is_tensor(input_ids) and not torch.is_grad_enabled()):
+        key = model.vlfm_text_key
+        if key is None or torch.is_grad_enabled():
             return plain(input_ids, attention_mask, token_type_ids, position_ids, **kw)
-        key = tuple((t.shape, t.dtype, str(t.device), t.detach().cpu().numpy().tobytes()) if torch.is_tensor(t) else t
-                    for t in (input_ids, attention_mask, token_type_ids, position_ids)) + tuple(sorted(kw.items()))
+        key = (key, str(input_ids.device), tuple(input_ids.shape), tuple(sorted(kw.items())))
         if key not in cache:
             if len(cache) > 64:
                 cache.clear()
@@ -235,3 +237,4 @@ def cache_text_branch(model) -> None:
         return cache[key]
 
     backbone.forward = forward
+
