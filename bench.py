@@ -122,10 +122,22 @@ def _cpu_map_runs(height: int, width: int, with_obstacle: bool, warm: int, runs:
 
     from oracle.ref_obstacle_map import RefObstacleMap
     from oracle.ref_value_map import RefValueMap
-    from vlfm_amd.synthetic import MAX_DEPTH, MIN_DEPTH, SyntheticEnv, camera_intrinsics
+    from vlfm_amd.synthetic import (MAX_DEPTH, MIN_DEPTH, camera_intrinsics, depth_from_profile, integrate, plan_actions,
+                                    tf_of, wall_profile)
 
     fx, fy, fov = camera_intrinsics(width)
-    env = SyntheticEnv(env_id, height, width)
+    # the same rooms-and-pillars episode the GPU harness steps through (environment env_id's tour offset)
+    poses = integrate(plan_actions(1000))[(37 * env_id) % 500:]
+    rng = np.random.Generator(np.random.PCG64(7 + env_id))
+    cursor = [0]
+
+    class env:  # noqa: N801 -- one observation per call, like SyntheticEnv.observe
+        @staticmethod
+        def observe():
+            x, y, k = poses[cursor[0]]
+            cursor[0] += 1
+            return (depth_from_profile(wall_profile(x, y, k, width), height), tf_of(x, y, k), rng.uniform(0.15, 0.45, size=1))
+
     vm = RefValueMap(1, use_max_confidence=False)
     om = RefObstacleMap(min_height=0.61, max_height=0.88, agent_radius=0.18, area_thresh=1.5) if with_obstacle else None
     stage_s: dict = {}
@@ -304,8 +316,7 @@ def count_stored_cells(sim) -> float:
     from vlfm_amd.synthetic import MAX_DEPTH, MIN_DEPTH
 
     n = min(sim.E, 16)
-    k = sim.t % sim.depth_pool.shape[0]
-    depth = sim.depth_pool[k][:n].to(sim.device)
+    depth = sim.current_depth(n)
     tf = sim.tf_table[sim.t % sim.episode_len][:n]
     scratch = ValueMapBatch(n, 1, sim.S, use_max_confidence=False, fusion_type="replace", device=sim.device)
     scratch.update(torch.full((n, 1), 0.3, dtype=torch.float64), depth, tf, MIN_DEPTH, MAX_DEPTH, sim.fov)
@@ -412,6 +423,7 @@ def main():
         D.barrier(device)
 
     sim.fast_forward(args.preroll)
+    sim.prepare(args.warmup + args.steps)   # rooms world: the window's depth frames are rendered before the clock starts
     for _ in range(args.warmup):
         sim.step()
     first_timed_step = sim.t
@@ -476,6 +488,9 @@ def main():
                                     + " + sort_waypoints) for every resident env, envs sharded over GPUs as in configs[3]"
                                     if not args.no_blip2 else "MAP KERNELS ONLY (no VLM) -- not the headline metric"),
                        "envs_per_gpu": E, "global_envs": E * world, "rgbd": f"{W}x{H}", "map": "1000x1000 @ 20 px/m",
+                       "world": ("rooms-and-pillars world ray-cast per environment (vlfm_amd/synthetic.py), tour offset 37*env mod 500"
+                                 if sim.rooms is not None else "per-frame random wall profiles (SURVEY 8d)"),
+                       "frontiers_per_env_last_step": sim.frontier_stats(),
                        "episode_steps_timed": [first_timed_step, first_timed_step + args.steps - 1],
                        "blip2": "ViT-g/14 39 blocks + Q-Former 12 layers, random-init" if not args.no_blip2 else None,
                        "attention_path": (sim.blip2.attention_path if sim.blip2 is not None else None),
@@ -511,6 +526,7 @@ def side_legs(args, sim, device, common):
         torch.cuda.synchronize(device)
 
     def timed(s, warm, n):
+        s.prepare(warm + n)
         for _ in range(warm):
             s.step()
         torch.cuda.synchronize(device)
@@ -541,6 +557,7 @@ def side_legs(args, sim, device, common):
         hd = dict(common, height=720, width=1280)
         s5 = BatchedEpisodes(16, blip2=blip2, use_blip2=blip2 is not None, sync_explored=True, **hd)
         s5.fast_forward(args.preroll)
+        s5.prepare(23)
         for _ in range(3):
             s5.step()
         _lib.lib().vlfm_profile_enable(1)

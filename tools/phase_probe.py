@@ -3,14 +3,28 @@
           -o gpurun_out/libvlfm_amd_phase.so vlfm_amd/csrc/*.hip vlfm_amd/csrc/host.cpp
     VLFM_LIB_PATH=$PWD/gpurun_out/libvlfm_amd_phase.so python tools/phase_probe.py 8
 Prints per-phase microseconds of workgroup 0 (100 MHz wall clock) averaged over steps."""
-import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import ctypes, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from vlfm_amd import _lib
+if "VLFM_LIB_PATH" not in os.environ:   # build the diagnostic library here: only obstacle_map.hip is recompiled
+    _lib.build()
+    csrc = os.path.join(ROOT, "vlfm_amd", "csrc")
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    obj, out = os.path.join(ROOT, "gpurun_out", "obstacle_map_phase.o"), os.path.join(ROOT, "gpurun_out", "libvlfm_amd_phase.so")
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+                           "-DVLFM_PHASE_TIMING", "-c", os.path.join(csrc, "obstacle_map.hip"), "-o", obj])
+    objs = [os.path.join(csrc, "build", f) for f in os.listdir(os.path.join(csrc, "build"))
+            if f.endswith(".o") and not f.startswith("obstacle_map")]
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, obj] + objs)
+    os.environ["VLFM_LIB_PATH"] = out
+    import importlib
+    importlib.reload(_lib)
+import numpy as np, torch
 from vlfm_amd.harness import BatchedEpisodes
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 sim = BatchedEpisodes(E, device=torch.device("cuda:0"), use_blip2=False, overlap=False)
-for _ in range(14): sim.step()
+sim.fast_forward(int(sys.argv[2]) if len(sys.argv) > 2 else 150)
 acc = np.zeros((3, 16)); n = 0
 walk = np.zeros(3)
 w0 = np.zeros(3, np.int64); _lib.lib().vlfm_debug_walk_stats(ctypes.c_void_p(w0.ctypes.data))  # reset

@@ -13,7 +13,7 @@ cos = torch.full((E, 1), 0.3, device="cuda:0", dtype=torch.float64)
 for i in range(steps):
     t0 = time.perf_counter()
     k = sim.t % 4
-    depth = sim.depth_pool[k]; tf = sim.tf_table[sim.t % 500]
+    depth = sim.current_depth(sim.E); tf = sim.tf_table[sim.t % 500]
     if mode in ("ingest", "obst", "obst_read", "full", "nav") or mode.startswith("sub"):
         colmax = sim.obstacles.ingest(depth, tf, MIN_DEPTH, MAX_DEPTH, sim.fx, sim.fy, want_colmax=True)
     if mode in ("obst", "obst_read", "full"):
