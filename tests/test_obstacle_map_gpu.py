@@ -218,7 +218,7 @@ def test_harness_surfaces_off_map_obstacle_points_at_episode_end(gpu_device):
     reference's IndexError (obstacle_map.py:101); the batched harness must raise it no later than the episode end."""
     from vlfm_amd.harness import BatchedEpisodes
 
-    sim = BatchedEpisodes(2, device=gpu_device, use_blip2=False, map_size=200, episode_len=25)
+    sim = BatchedEpisodes(2, device=gpu_device, use_blip2=False, map_size=200, episode_len=25, world="random")
     with pytest.raises(IndexError):
         for _ in range(26):
             sim.step()
