@@ -27,7 +27,7 @@ for (E, H, W, sync, wgs) in [(256, 480, 640, False, 256), (256, 480, 640, False,
     os.environ["VLFM_VM_TARGET_WGS"] = str(wgs)
     sim = BatchedEpisodes(E, device=torch.device("cuda:0"), use_blip2=False, overlap=False, height=H, width=W, sync_explored=sync)
     sim.fast_forward(60)
-    acc = np.zeros(7); n = 0
+    acc = np.zeros(7); n = 0; tile = np.zeros(3)
     _lib.lib().vlfm_profile_enable(1)
     for _ in range(20):
         sim.fast_forward(1); torch.cuda.synchronize()
@@ -36,7 +36,8 @@ for (E, H, W, sync, wgs) in [(256, 480, 640, False, 256), (256, 480, 640, False,
         d = np.diff(buf[:8]) * 0.01
         if (d >= 0).all() and d.sum() < 1e4:
             acc += d; n += 1
+            tile += np.diff(buf[8:12]) * 0.01
     ms, cnt = _lib.profile_read("value_map_update_fused_kernel")
     _lib.lib().vlfm_profile_enable(0)
-    print(f"E={E} {W}x{H} sync={sync} target_wgs={wgs}: kernel {ms * 1e3:.1f} us; workgroup (0,0): " + ", ".join(f"{nm}={a / max(n, 1):.1f}" for nm, a in zip(names, acc)) + f" (sum {acc.sum() / max(n, 1):.1f} us)")
+    print(f"E={E} {W}x{H} sync={sync} target_wgs={wgs}: kernel {ms * 1e3:.1f} us; workgroup (0,0): " + ", ".join(f"{nm}={a / max(n, 1):.1f}" for nm, a in zip(names, acc)) + f" (sum {acc.sum() / max(n, 1):.1f} us); wave 0, last batch: taps {tile[0] / max(n, 1):.2f}")
     del sim

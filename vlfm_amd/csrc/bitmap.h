@@ -219,6 +219,26 @@ __device__ inline int follow_border_padded(const Bits& img, unsigned* traced, un
 
 // RETR_EXTERNAL scan of rows [y_lo, y_hi] by one wavefront (all 64 lanes must call).  `traced`/`neg` must be zero in
 // that row range on entry.  stride <= 64 words (maps up to 2048 columns).
+//
+// A border start is a set pixel with a clear west neighbour that is not labelled yet and whose nearest labelled pixel to
+// the left in the row (lnbd) does not carry a positive label.  A mid-episode explored area has a handful of outer borders
+// but thousands of run starts (every ragged row, every pillar), so the candidates are NOT visited one by one: each lane
+// decides all the run starts of its word at once -- "the nearest label below this bit is positive" is a flood of the
+// positive labels upwards through the unlabelled bits (5 shift/AND/OR steps), with the state entering the word taken from
+// the nearest lower word that holds a label (two ballots) -- and the wavefront only stops at rows where a start survives.
+// Rows without a surviving start cost three LDS reads and a ballot; after a walk the row is re-evaluated with the new
+// labels, for the candidates to the right of the one just traced (the sequential scan never revisits earlier ones).
+__device__ inline unsigned fill_up_through(unsigned seed, unsigned open) {
+    // bits reachable from `seed` moving towards higher bit positions through consecutive `open` bits (seed bits included)
+    unsigned f = seed, m = open;
+    f |= m & (f << 1); m &= m << 1;
+    f |= m & (f << 2); m &= m << 2;
+    f |= m & (f << 4); m &= m << 4;
+    f |= m & (f << 8); m &= m << 8;
+    f |= m & (f << 16);
+    return f;
+}
+
 __device__ inline void scan_external(const Bits& img, unsigned* traced, unsigned* neg, int y_lo, int y_hi, int method,
                                      ContourSink& sink) {
     const int lane = threadIdx.x & 63;
@@ -226,58 +246,59 @@ __device__ inline void scan_external(const Bits& img, unsigned* traced, unsigned
     if (y_hi > img.rows - 1) y_hi = img.rows - 1;
     for (int y = y_lo; y <= y_hi; y++) {
         const unsigned* row = img.w + (size_t)y * img.stride;
-        unsigned w = lane < img.stride ? row[lane] : 0u;
+        const size_t roww = (size_t)y * img.stride;
+        const unsigned w = lane < img.stride ? row[lane] : 0u;
         const unsigned left = __shfl_up(w, 1, 64);
         const unsigned carry = lane > 0 ? (left >> 31) : 0u;
-        unsigned starts = w & ~((w << 1) | carry);
-        unsigned long long any = __ballot(starts != 0u);
-        while (any) {
-            const int L = __builtin_ctzll(any);
-            const unsigned sL = __shfl(starts, L, 64);
-            const int bit = __builtin_ctz(sL);
-            const int x = L * 32 + bit;
-            if (lane == L) starts &= starts - 1;  // consume the candidate
-            // already on a traced border?
-            const size_t roww = (size_t)y * img.stride;
-            const unsigned tw_here = traced[roww + (x >> 5)];
-            if (!((tw_here >> (x & 31)) & 1u)) {
-                // lnbd: nearest labelled pixel to the left in this row; positive label => we are inside a component
-                unsigned tw = lane < img.stride ? traced[roww + lane] : 0u;
-                if (lane > (x >> 5)) tw = 0u;
-                else if (lane == (x >> 5)) tw &= (1u << (x & 31)) - 1u;
-                const unsigned long long have = __ballot(tw != 0u);
-                bool inside = false;
-                if (have) {
-                    const int Lh = 63 - __builtin_clzll(have);
-                    const unsigned twh = __shfl(tw, Lh, 64);
-                    const int xb = Lh * 32 + (31 - __builtin_clz(twh));
-                    inside = !((neg[roww + (xb >> 5)] >> (xb & 31)) & 1u);
-                }
-                if (!inside) {
-                    int n = 0;
-                    if (lane == 0) {
-                        const int room = sink.cap_pts - sink.n_pts;
-#ifdef VLFM_PHASE_TIMING
-                        const long long t0_ = wall_clock64();
-#endif
-                        n = follow_border(img, traced, neg, x, y, method, sink.pts + sink.n_pts, room > 0 ? room : 0);
-#ifdef VLFM_PHASE_TIMING
-                        g_walk_ticks += wall_clock64() - t0_; g_walk_points += n; g_walk_calls += 1;
-#endif
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    n = __shfl(n, 0, 64);
-                    if (sink.n_contours < sink.cap_contours && sink.n_pts + n <= sink.cap_pts) {
-                        if (lane == 0) { sink.start[sink.n_contours] = sink.n_pts; sink.len[sink.n_contours] = n; }
-                    } else {
-                        sink.overflow = 1;
-                    }
-                    sink.n_contours++;
-                    sink.n_pts += n;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                }
+        const unsigned starts = w & ~((w << 1) | carry);
+        if (__ballot(starts != 0u) == 0ull) continue;
+        int x_done = -1;   // candidates at or left of this column have been decided
+        for (;;) {
+            const unsigned tw = lane < img.stride ? traced[roww + lane] : 0u;
+            const unsigned ng = lane < img.stride ? neg[roww + lane] : 0u;
+            const unsigned pos = tw & ~ng;
+            // state entering this word: label kind of the highest labelled bit of the nearest lower word that has one
+            const unsigned long long have = __ballot(tw != 0u);
+            const unsigned long long top_pos = __ballot(tw != 0u && ((pos >> (31 - __builtin_clz(tw | 1u))) & 1u));
+            const unsigned long long lower = have & ((1ull << lane) - 1ull);
+            unsigned enter = 0u;
+            if (lower) enter = (unsigned)(top_pos >> (63 - __builtin_clzll(lower))) & 1u;
+            // inside[x] = the nearest labelled bit below x (in this word, else the entering state) is positive
+            unsigned seed = pos << 1;                       // a positive label at bit b covers bits b+1 ...
+            if (enter) seed |= 1u;                          // ... and the entering state covers bit 0 ...
+            const unsigned inside = fill_up_through(seed & ~tw, ~tw);   // ... upwards through unlabelled bits only
+            unsigned need = starts & ~tw & ~inside;
+            if (x_done >= 0) {                              // only candidates to the right of the last traced start
+                const int wd = x_done >> 5;
+                if (lane < wd) need = 0u;
+                else if (lane == wd) need &= ~((2u << (x_done & 31)) - 1u);
             }
-            any = __ballot(starts != 0u);
+            const unsigned long long any = __ballot(need != 0u);
+            if (!any) break;
+            const int L = __builtin_ctzll(any);
+            const int x = L * 32 + __builtin_ctz(__shfl(need, L, 64));
+            int n = 0;
+            if (lane == 0) {
+                const int room = sink.cap_pts - sink.n_pts;
+#ifdef VLFM_PHASE_TIMING
+                const long long t0_ = wall_clock64();
+#endif
+                n = follow_border(img, traced, neg, x, y, method, sink.pts + sink.n_pts, room > 0 ? room : 0);
+#ifdef VLFM_PHASE_TIMING
+                g_walk_ticks += wall_clock64() - t0_; g_walk_points += n; g_walk_calls += 1;
+#endif
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            n = __shfl(n, 0, 64);
+            if (sink.n_contours < sink.cap_contours && sink.n_pts + n <= sink.cap_pts) {
+                if (lane == 0) { sink.start[sink.n_contours] = sink.n_pts; sink.len[sink.n_contours] = n; }
+            } else {
+                sink.overflow = 1;
+            }
+            sink.n_contours++;
+            sink.n_pts += n;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            x_done = x;
         }
     }
 }

@@ -373,6 +373,24 @@ __global__ __launch_bounds__(256) void value_map_fuse_kernel(UpdateArgs a) {
     fuse_tile<C_STATIC>(a, pose_obs, vis, box, row_begin, tid, nullptr);
 }
 
+// Optional phase timing of the single-launch update (compile with -DVLFM_PHASE_TIMING; tools/vm_phase_probe.py): thread 0
+// of workgroup (0, 0) stamps the constant-rate 100 MHz counter at phase boundaries.  Zero cost otherwise.
+#ifdef VLFM_PHASE_TIMING
+__device__ long long g_vm_phase[16];
+#define VM_PHASE(k)                                                                                       \
+    do {                                                                                                  \
+        __syncthreads();                                                                                  \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_vm_phase[k] = wall_clock64();        \
+    } while (0)
+#define VM_STAMP(k)                                                                                       \
+    do {                                                                                                  \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_vm_phase[k] = wall_clock64();        \
+    } while (0)
+#else
+#define VM_PHASE(k) do {} while (0)
+#define VM_STAMP(k) do {} while (0)
+#endif
+
 // The same tile with the template taps taken from LDS (single-launch kernel).  `quad` is the confidence table's
 // (T/2+1)^2 quadrant: the table depends on |row - T/2| and |col - T/2| only (value_map.py:343-351), and a tap is read only
 // where the visible bit -- which already contains the cone sector -- is set, so template[y][x] == quad[|y-T/2|][|x-T/2|] for
@@ -380,7 +398,7 @@ __global__ __launch_bounds__(256) void value_map_fuse_kernel(UpdateArgs a) {
 // at once and only one float per row stays live, which keeps the kernel free of register spills at 16 wavefronts.
 template <int C_STATIC>
 __device__ inline void fuse_tile_lds(const UpdateArgs& a, const vlfm_vm_pose& pose, const unsigned* vis, const float* quad,
-                                     const int4 box, int row_begin, int tid, unsigned* written) {
+                                     const int2* row_xy0, const int4 box, int row_begin, int tid, unsigned* written) {
     const int T = a.T, S = a.S;
     const int words = (T + 31) >> 5;
     const int C = C_STATIC > 0 ? C_STATIC : a.C;
@@ -391,39 +409,69 @@ __device__ inline void fuse_tile_lds(const UpdateArgs& a, const vlfm_vm_pose& po
     const double* vals = a.values + (size_t)pose.reserved * C;
     const int lane = tid & 63, wave = tid >> 6;
     const int cq = T >> 1, Q = cq + 1;
-    constexpr int R = ROWS_PER_TILE;
+    constexpr int R = ROWS_PER_TILE / 2;   // rows per batch: two batches per tile keep the batch's state in registers
     for (int x = wave * 64 + lane; x < T; x += 256) {
         if (x - lane > box.w || x - lane + 63 < box.z) continue;  // wave-uniform: segment outside the cone's columns
         const int mc = pose.col0 + x;
         const bool col_ok = (unsigned)mc < (unsigned)S;
         const int adelta = __double2int_rn(__dmul_rn(__dmul_rn(pose.inv_affine[0], (double)x), 1024.0));
         const int bdelta = __double2int_rn(__dmul_rn(__dmul_rn(pose.inv_affine[3], (double)x), 1024.0));
-        float nw[R];
-        // ---- phase A: source coordinates, visibility bits and template taps (all LDS), bilinear blend.  Nothing here waits
-        // on memory, so the rows are NOT interleaved (a full unroll makes the scheduler keep eight rows of f64 temporaries
-        // alive and spill)
+        VM_STAMP(8);
 #pragma unroll 1
+      for (int half = 0; half < 2; half++) {
+        const int row_base = row_begin + half * R;
+        float nw[R];
+        // ---- phase A: source coordinates, visibility bits and template taps (all LDS), bilinear blend.  Two sweeps over
+        // the tile's rows, WITHOUT per-lane branches: (1) every lane issues its four bit-plane reads at clamped addresses --
+        // 32 independent LDS reads, one wait (a short-circuit `ok && test(...)` made the compiler emit one exec-masked
+        // branch and one full LDS round trip per tap: 3.6 us of this phase's 4.3); (2) the taps + blend of a row run only
+        // where the wavefront has a visible tap (ballot: most 64-column segments of a row miss the cone).  The row part of
+        // cv::warpAffine's fixed-point source coordinate is the same for every lane: it comes from a per-workgroup table.
+        int xq[R], yq[R];
+        unsigned bits = 0u;
+#pragma unroll
         for (int k = 0; k < R; k++) {
-            const int y = row_begin + k;
-            const int X0 = __double2int_rn(__dmul_rn(__dadd_rn(__dmul_rn(pose.inv_affine[1], (double)y), pose.inv_affine[2]), 1024.0)) + 16;
-            const int Y0 = __double2int_rn(__dmul_rn(__dadd_rn(__dmul_rn(pose.inv_affine[4], (double)y), pose.inv_affine[5]), 1024.0)) + 16;
-            const int Xq = (X0 + adelta) >> 5, Yq = (Y0 + bdelta) >> 5;
-            const int sx = Xq >> 5, sy = Yq >> 5;
+            const int y = row_base + k;
+            const int2 r0c = row_xy0[y < T ? y : 0];
+            xq[k] = (r0c.x + adelta) >> 5; yq[k] = (r0c.y + bdelta) >> 5;
+            const int sx = xq[k] >> 5, sy = yq[k] >> 5;
             const bool row_ok = y < T && (unsigned)(pose.row0 + y) < (unsigned)S && col_ok;
-            const bool b0 = row_ok && vis_test(vis, words, T, sy, sx), b1 = row_ok && vis_test(vis, words, T, sy, sx + 1);
-            const bool b2 = row_ok && vis_test(vis, words, T, sy + 1, sx), b3 = row_ok && vis_test(vis, words, T, sy + 1, sx + 1);
+            const bool vx0 = (unsigned)sx < (unsigned)T, vx1 = (unsigned)(sx + 1) < (unsigned)T;
+            const bool vy0 = (unsigned)sy < (unsigned)T, vy1 = (unsigned)(sy + 1) < (unsigned)T;
+            const int r0 = vy0 ? sy * words : 0, r1 = vy1 ? (sy + 1) * words : 0;
+            const int c0 = vx0 ? (sx >> 5) : 0, c1 = vx1 ? ((sx + 1) >> 5) : 0;
+            const unsigned w00 = vis[r0 + c0], w01 = vis[r0 + c1], w10 = vis[r1 + c0], w11 = vis[r1 + c1];
+            const unsigned b0 = (row_ok && vy0 && vx0) ? ((w00 >> (sx & 31)) & 1u) : 0u;
+            const unsigned b1 = (row_ok && vy0 && vx1) ? ((w01 >> ((sx + 1) & 31)) & 1u) : 0u;
+            const unsigned b2 = (row_ok && vy1 && vx0) ? ((w10 >> (sx & 31)) & 1u) : 0u;
+            const unsigned b3 = (row_ok && vy1 && vx1) ? ((w11 >> ((sx + 1) & 31)) & 1u) : 0u;
+            bits |= (b0 | (b1 << 1) | (b2 << 2) | (b3 << 3)) << (4 * k);
+        }
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const unsigned bk = (bits >> (4 * k)) & 15u;
             float v = 0.0f;
-            if (b0 | b1 | b2 | b3) {
-                const int qy0 = abs(sy - cq) * Q, qy1 = abs(sy + 1 - cq) * Q, qx0 = abs(sx - cq), qx1 = abs(sx + 1 - cq);
-                const float t0 = b0 ? quad[qy0 + qx0] : 0.0f, t1 = b1 ? quad[qy0 + qx1] : 0.0f;
-                const float t2 = b2 ? quad[qy1 + qx0] : 0.0f, t3 = b3 ? quad[qy1 + qx1] : 0.0f;
+            if (__ballot(bk != 0u) != 0ull) {
+                const int sx = xq[k] >> 5, sy = yq[k] >> 5;
+                const int qy0 = min(abs(sy - cq), cq) * Q, qy1 = min(abs(sy + 1 - cq), cq) * Q;
+                const int qx0 = min(abs(sx - cq), cq), qx1 = min(abs(sx + 1 - cq), cq);
+                const float q0 = quad[qy0 + qx0], q1 = quad[qy0 + qx1], q2 = quad[qy1 + qx0], q3 = quad[qy1 + qx1];
+                const float t0 = (bk & 1u) ? q0 : 0.0f, t1 = (bk & 2u) ? q1 : 0.0f, t2 = (bk & 4u) ? q2 : 0.0f, t3 = (bk & 8u) ? q3 : 0.0f;
                 // BilinearTab_f weights are products of k/32 in float (exact); accumulate in double like remapBilinear<double>
-                const float fx = (float)(Xq & 31) * 0.03125f, fy = (float)(Yq & 31) * 0.03125f;
+                const float fx = (float)(xq[k] & 31) * 0.03125f, fy = (float)(yq[k] & 31) * 0.03125f;
                 const float w0 = (1.f - fy) * (1.f - fx), w1 = (1.f - fy) * fx, w2 = fy * (1.f - fx), w3 = fy * fx;
                 v = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn((double)t0, (double)w0), __dmul_rn((double)t1, (double)w1)),
                                                 __dmul_rn((double)t2, (double)w2)), __dmul_rn((double)t3, (double)w3));
             }
             nw[k] = v;  // curr_map is f32 (value_map.py:316-317); 0 = the cell is not touched
+        }
+        VM_STAMP(9);
+        {   // nothing visible in this wavefront's 64 columns x R rows (three quarters of the cone's bounding box): no map
+            // access at all -- the dummy reads of an all-idle wavefront would still cost it a full memory round trip
+            bool any_on = false;
+#pragma unroll
+            for (int k = 0; k < R; k++) any_on |= nw[k] != 0.0f;
+            if (__ballot(any_on) == 0ull) continue;
         }
         // ---- phase B: issue the map reads of every active pixel
         float old[R], oldv1[R];
@@ -431,15 +479,17 @@ __device__ inline void fuse_tile_lds(const UpdateArgs& a, const vlfm_vm_pose& po
         unsigned act = 0u;
 #pragma unroll
         for (int k = 0; k < R; k++) {
-            const int mr = pose.row0 + row_begin + k;
+            const int mr = pose.row0 + row_base + k;
             bool on = nw[k] != 0.0f;
-            // new_map[explored == 0] = 0 (:373); the old values of such cells are cleared by the mask step
-            if (explored && on) on = (explored[(size_t)mr * ex_stride + (mc >> 5)] >> (mc & 31)) & 1u;
+            // new_map[explored == 0] = 0 (:373); the old values of such cells are cleared by the mask step.  Branch-free:
+            // inactive lanes read word 0
+            if (explored) on = on && ((explored[on ? (size_t)mr * ex_stride + (mc >> 5) : 0] >> (mc & 31)) & 1u);
             cell[k] = on ? mr * S + mc : 0;
             act |= on ? (1u << k) : 0u;
             old[k] = conf[cell[k]];
             if (C_STATIC == 1) oldv1[k] = value[cell[k]];
         }
+        VM_STAMP(10);
         // ---- phase C: fuse and write back
 #pragma unroll
         for (int k = 0; k < R; k++) {
@@ -461,7 +511,7 @@ __device__ inline void fuse_tile_lds(const UpdateArgs& a, const vlfm_vm_pose& po
                     const int lo = lane - (mc & 31);
                     const unsigned wm = lo >= 0 ? (unsigned)(m >> lo) : (unsigned)(m << (-lo));
                     if ((mc & 31) == __builtin_ctz(wm)) {
-                        unsigned* wp = written + (size_t)(pose.row0 + row_begin + k) * ex_stride + (mc >> 5);
+                        unsigned* wp = written + (size_t)(pose.row0 + row_base + k) * ex_stride + (mc >> 5);
                         if ((*wp & wm) != wm) atomicOr(wp, wm);
                     }
                 }
@@ -479,10 +529,12 @@ __device__ inline void fuse_tile_lds(const UpdateArgs& a, const vlfm_vm_pose& po
                 }
                 if (wrote) {
                     conf[cell[k]] = c_out;
-                    if (written) atomicOr(written + (size_t)(pose.row0 + row_begin + k) * ex_stride + (mc >> 5), 1u << (mc & 31));
+                    if (written) atomicOr(written + (size_t)(pose.row0 + row_base + k) * ex_stride + (mc >> 5), 1u << (mc & 31));
                 }
             }
         }
+      }
+        VM_STAMP(11);
     }
 }
 
@@ -503,19 +555,6 @@ struct FusedExtra {
     int* counters;       // [n] zero on entry, zero again on exit
     const float* quad;   // [(T/2+1)^2] confidence quadrant (unmasked table, rows/cols >= T/2)
 };
-
-// Optional phase timing of the single-launch update (compile with -DVLFM_PHASE_TIMING; tools/vm_phase_probe.py): thread 0
-// of workgroup (0, 0) stamps the constant-rate 100 MHz counter at phase boundaries.  Zero cost otherwise.
-#ifdef VLFM_PHASE_TIMING
-__device__ long long g_vm_phase[16];
-#define VM_PHASE(k)                                                                                       \
-    do {                                                                                                  \
-        __syncthreads();                                                                                  \
-        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_vm_phase[k] = wall_clock64();        \
-    } while (0)
-#else
-#define VM_PHASE(k) do {} while (0)
-#endif
 
 // ---- polygon raster with the work FLATTENED over the workgroup.
 // raster_edge (raster.h) gives one lane a whole edge: a wavefront then runs for as long as its longest edge, and the profile
@@ -632,6 +671,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void value_map_update_fused_kernel(U
     int* pref = reinterpret_cast<int*>(vert + n_vert);      // [n_vert + 1] item prefix sums of the flattened raster
     const int Q = (T >> 1) + 1;
     float* quad = reinterpret_cast<float*>(pref + n_vert + 1 + ((n_vert + 1) & 1));  // [Q * Q]
+    int2* row_xy0 = reinterpret_cast<int2*>(quad + Q * Q + ((Q * Q) & 1));          // [T] row part of the source coordinate
     __shared__ int sh_wave_tot[FUSED_THREADS / 64];
     __shared__ int sh_last;
     __shared__ int sh_box[4];
@@ -662,6 +702,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void value_map_update_fused_kernel(U
     bm.solid = solid; bm.parity = parity; bm.rows = T; bm.cols = T; bm.words = words;
     for (int i = tid; i < 2 * T * words; i += nth) solid[i] = 0u;
     if (tid == 0) { sh_box[0] = T; sh_box[1] = -1; sh_box[2] = T; sh_box[3] = -1; }
+    for (int y = tid; y < T; y += nth)   // cv::warpAffine: X0 = round((M01 y + M02) * 1024) + 16, Y0 likewise (AB_BITS = 10)
+        row_xy0[y] = make_int2(
+            __double2int_rn(__dmul_rn(__dadd_rn(__dmul_rn(pose.inv_affine[1], (double)y), pose.inv_affine[2]), 1024.0)) + 16,
+            __double2int_rn(__dmul_rn(__dadd_rn(__dmul_rn(pose.inv_affine[4], (double)y), pose.inv_affine[5]), 1024.0)) + 16);
     const unsigned* cm = a.colmax + (size_t)obs * W;
     // Loads in issue order keys + tangents, THEN the quadrant: the vertex arithmetic below only has to wait for the first two
     // (memory returns in order), and the quadrant's ten loads per lane travel under it.
@@ -813,7 +857,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void value_map_update_fused_kernel(U
     const int t_lo = max(box.x, max(0, -pose.row0)) / ROWS_PER_TILE;
     const int t_hi = min(min(box.y, T - 1), S - 1 - pose.row0) / ROWS_PER_TILE;   // inclusive
     for (int t = t_lo + g * tiles_per_pass + tg; t <= t_hi; t += G * tiles_per_pass)
-        fuse_tile_lds<C_STATIC>(a, pose, parity, quad, box, t * ROWS_PER_TILE, t_in, written);
+        fuse_tile_lds<C_STATIC>(a, pose, parity, quad, row_xy0, box, t * ROWS_PER_TILE, t_in, written);
     VM_PHASE(7);
 }
 
@@ -1032,7 +1076,8 @@ extern "C" int vlfm_value_map_update_fused_batched(uint32_t* d_colmax_keys, int 
     const int T = template_size, words = (T + 31) >> 5;
     const int n_vert = width + 2, Q = T / 2 + 1;
     const size_t lds = (size_t)(2 * T * words + ((2 * T * words) & 1)) * 4 + (size_t)n_vert * sizeof(int2) +
-                       (size_t)(n_vert + 1 + ((n_vert + 1) & 1)) * sizeof(int) + (size_t)Q * Q * 4;
+                       (size_t)(n_vert + 1 + ((n_vert + 1) & 1)) * sizeof(int) + (size_t)(Q * Q + ((Q * Q) & 1)) * 4 +
+                       (size_t)T * sizeof(int2);
     if (lds > 150 * 1024) return fail(VLFM_ERR_CAPACITY, "value_map_update_fused_batched: template/width too large for LDS");
     if (lds > 64 * 1024) {   // beyond the default dynamic-LDS limit: opt in once per device and kernel
         static LdsOptIn opt1, opt0;
