@@ -287,6 +287,13 @@ int vlfm_layernorm_bias_f16(const void* d_x, const float* d_channel_bias, const 
 int vlfm_vit_attention_f16(const void* d_qkv, void* d_out, int batch, int tokens, int heads, int head_dim, float scale,
                            void* stream);
 
+/* C[M][N] = epilogue(X[M][K] . W[N][K]^T + bias[N]): f16 operands and result, f32 accumulation on the matrix cores
+ * (hand-written MFMA kernel, csrc/gemm_f16.hip).  epilogue 0 = bias only, 1 = bias + EXACT (erf) GELU on the f32
+ * accumulator -- the fc1 + GELU of the ViT-g MLP inside the forward of blip2itm.py:52 in one pass (hipBLASLt's fused GELU is
+ * the tanh approximation).  K % 64 == 0, N % 8 == 0; d_bias may be NULL. */
+int vlfm_gemm_f16_nt(const void* d_x, const void* d_w, const void* d_bias, void* d_c, int m, int n, int k, int epilogue,
+                     void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Detector-side kernels (vlfm/vlm/yolov7.py:50-110, vlfm/vlm/grounding_dino.py:38-74)
  * ------------------------------------------------------------------------------------------- */
