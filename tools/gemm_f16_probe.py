@@ -39,3 +39,10 @@ for name, N, K, gelu in [("fc1+gelu", 6144, 1408, True), ("qkv", 4224, 1408, Fal
     print(f"{name:9s} M={M} N={N} K={K}: library {t_lib*1e6:7.1f} us (GEMM alone {t_gemm_only*1e6:7.1f} us = {fl/t_gemm_only/1e15:.2f} PF)  ours {t_ours*1e6:7.1f} us = {fl/t_ours/1e15:.2f} PF")
     got = ours(x, w, b, 1 if gelu else 0).float(); want = F.linear(x, w, b).float(); want = F.gelu(want) if gelu else want
     print("           max|ours - library| =", (got - want).abs().max().item())
+
+for exp in ("1", "2", "3"):
+    os.environ["VLFM_GEMM_EXP"] = exp
+    x = (torch.randn(M, 1408, device=dev) * 0.5).half(); w = (torch.randn(4224, 1408, device=dev) * 0.03).half(); b = torch.randn(4224, device=dev).half()
+    t = timeit(lambda: ours(x, w, b, 0))
+    print(f"experiment {exp} (1 = no load wait [wrong results], 2 = setprio, 3 = both) qkv shape: {t*1e6:.1f} us = {2.0*M*4224*1408/t/1e15:.2f} PF")
+del os.environ["VLFM_GEMM_EXP"]

@@ -20,6 +20,7 @@
 //     conflict-free 8-byte writes, 16-byte reads) and stores 256-byte row segments with 16 B per lane.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/vlfm_amd.h"
 #include "profile.h"
@@ -100,7 +101,7 @@ __device__ inline void mma_half(const half8 (&fa)[8], const half8 (&fb)[4], floa
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
 }
 
-template <int EPI>
+template <int EPI, int EXP = 0>
 __global__ __launch_bounds__(512) void gemm_f16_nt_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     lds_ptr lds = (lds_ptr)smem;
@@ -139,18 +140,22 @@ __global__ __launch_bounds__(512) void gemm_f16_nt_kernel(GemmArgs a) {
         const int cur = (t & 1) * BUF;
         read_frags(smem, cur, 1, wn, wm, lane, fa1, fb1);     // second half of tile t: in flight under the MFMAs below
         __builtin_amdgcn_sched_barrier(0);
+        if (EXP & 2) __builtin_amdgcn_s_setprio(1);
         mma_half(fa0, fb0, acc);
+        if (EXP & 2) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_waitcnt(0xC07F);    // every LDS read of tile t by this wavefront has returned
         if (t + 1 < NT) {
-            __builtin_amdgcn_s_waitcnt(0x0F70);  // ... and its share of tile t + 1 has landed (nothing newer is in flight)
+            if (!(EXP & 1)) __builtin_amdgcn_s_waitcnt(0x0F70);  // ... and its share of tile t + 1 has landed (nothing newer is in flight)
             __builtin_amdgcn_s_barrier();                      // ... for everybody: buffer `cur` is free, the other one is complete
             asm volatile("" ::: "memory");
             if (t + 2 < NT) stage_tile(a, lds, cur, n0, m0, (t + 2) * GK, wave, lane);
             read_frags(smem, cur ^ BUF, 0, wn, wm, lane, fa0, fb0);  // first half of tile t + 1: in flight under the MFMAs below
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (EXP & 2) __builtin_amdgcn_s_setprio(1);
         mma_half(fa1, fb1, acc);
+        if (EXP & 2) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_waitcnt(0xC07F);
     }
@@ -208,6 +213,16 @@ extern "C" int vlfm_gemm_f16_nt(const void* d_x, const void* d_w, const void* d_
                                   : opt1.ensure(reinterpret_cast<const void*>(gemm_f16_nt_kernel<EPI_BIAS_GELU>), GEMM_LDS);
     if (!ok) return fail(VLFM_ERR_HIP, "gemm_f16_nt: cannot opt in to the LDS size");
     const dim3 grid(a.tiles_m * a.tiles_n), block(512);
+    if (const char* e = getenv("VLFM_GEMM_EXP")) {   // experiments (tools/gemm_f16_probe.py): 1 = no load wait (WRONG results), 2 = setprio
+        const int x = atoi(e);
+        static LdsOptIn o1, o2, o3;
+        if (x == 1 && o1.ensure(reinterpret_cast<const void*>(gemm_f16_nt_kernel<EPI_BIAS, 1>), GEMM_LDS)) {
+            VLFM_KLAUNCH((gemm_f16_nt_kernel<EPI_BIAS, 1>), grid, block, GEMM_LDS, (hipStream_t)stream, a); return check_launch("gemm exp1"); }
+        if (x == 2 && o2.ensure(reinterpret_cast<const void*>(gemm_f16_nt_kernel<EPI_BIAS, 2>), GEMM_LDS)) {
+            VLFM_KLAUNCH((gemm_f16_nt_kernel<EPI_BIAS, 2>), grid, block, GEMM_LDS, (hipStream_t)stream, a); return check_launch("gemm exp2"); }
+        if (x == 3 && o3.ensure(reinterpret_cast<const void*>(gemm_f16_nt_kernel<EPI_BIAS, 3>), GEMM_LDS)) {
+            VLFM_KLAUNCH((gemm_f16_nt_kernel<EPI_BIAS, 3>), grid, block, GEMM_LDS, (hipStream_t)stream, a); return check_launch("gemm exp3"); }
+    }
     VLFM_TIMED("gemm_f16_nt_kernel", stream);
     if (epilogue == 0) VLFM_KLAUNCH(gemm_f16_nt_kernel<EPI_BIAS>, grid, block, GEMM_LDS, (hipStream_t)stream, a);
     else VLFM_KLAUNCH(gemm_f16_nt_kernel<EPI_BIAS_GELU>, grid, block, GEMM_LDS, (hipStream_t)stream, a);
