@@ -30,6 +30,22 @@ def test_preprocess_matches_pil_bit_exact(gpu_device, shape):
     assert torch.equal(pat, want_pat)
 
 
+@pytest.mark.parametrize("case", [(9, 480, 640, 224, 14, torch.float16), (2, 720, 1280, 224, 14, torch.bfloat16),
+                                  (5, 120, 160, 56, 0, torch.float32), (3, 96, 128, 224, 14, torch.float16),
+                                  (70, 48, 64, 30, 0, torch.float32)])
+def test_preprocess_one_launch_equals_two_launch(gpu_device, case, monkeypatch):
+    """The fused resampler (u8 intermediate in LDS) against the two-launch form it replaced, on downscaling, upscaling,
+    band counts from 1 to 28 and every output type: identical bits.  (PIL itself is the judge of both in the test above.)"""
+    from vlfm_amd.vlm import ops
+
+    n, H, W, out, patch, dt = case
+    img = torch.randint(0, 256, (n, H, W, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(3)).to(gpu_device)
+    got = ops.preprocess_rgb(img, out, dt, patch_size=patch)
+    monkeypatch.setenv("VLFM_PREPROCESS_TWO_PASS", "1")
+    want = ops.preprocess_rgb(img, out, dt, patch_size=patch)
+    assert torch.equal(got, want)
+
+
 def test_itc_head_vs_fp32_reference(gpu_device):
     from vlfm_amd.vlm import ops
 

@@ -31,5 +31,5 @@ for (n, H, W, out, patch, dt) in [(256, 480, 640, 224, 14, torch.float16), (16, 
     same = torch.equal(got, want)
     mb = (img.numel() + got.numel() * got.element_size()) / 1e6
     print(f"{n}x{H}x{W}->{out} patch {patch} {dt}: equal={same}  two-pass {t_old:.1f} us  fused {t_new:.1f} us "
-          f"({mb / t_new * 1e-3 * 1e3:.2f} GB/s over {mb:.0f} MB)", flush=True)
+          f"({mb / t_new:.2f} TB/s over {mb:.0f} MB)", flush=True)
     assert same

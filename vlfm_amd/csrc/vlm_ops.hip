@@ -495,6 +495,7 @@ extern "C" int vlfm_preprocess_rgb_batched(const uint8_t* d_rgb, int n, int heig
         auto lds_of = [&](int R) { return (size_t)3 * 256 * 4 + (size_t)2 * PF_GROUPS * PF_ROW_BYTES + (size_t)3 * span(R) * OP; };
         int R = out_size < 32 ? out_size : 32;
         while (R > 1 && lds_of(R) > 80 * 1024) R--;            // two workgroups per CU
+        while (R > 8 && (long)((out_size + R - 1) / R) * n < 512) R = (R + 1) / 2;   // few frames: shorter bands fill the CUs
         const int bands = (out_size + R - 1) / R;
         R = (out_size + bands - 1) / bands;                       // equal bands
         const size_t lds = lds_of(R);
