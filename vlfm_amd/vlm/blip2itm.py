@@ -75,6 +75,9 @@ class _VitBlock(nn.Module):
         self._packed = None
         self.hip_attention = True  # vlfm_vit_attention_f16 at the ViT-g shape (257 tokens, 88-wide heads)
         self.strict_hip_attention = False  # True: a failing HIP launch raises (bench.py) instead of falling back
+        # fc1 + exact GELU in one hand-written MFMA kernel once the GEMM has this many rows (below, the library's smaller
+        # tiles win: tools/gemm_f16_probe.py); 0 = always the library GEMM + a separate GELU pass
+        self.hip_mlp_min_rows = 32 * 257
 
     def pack_heads(self, multiple: int = 32) -> None:
         """Inference-time repacking for the attention kernel: the 88-wide heads of ViT-g are zero-padded to the next
@@ -139,7 +142,11 @@ class _VitBlock(nn.Module):
             a = F.scaled_dot_product_attention(q[0], q[1], q[2]).transpose(1, 2).reshape(b * n, d)
             x2.addmm_(a, self.projection.weight.t())
         h = ops.layernorm_bias(x, c_mid, self.layer_norm2.weight, self.layer_norm2.bias, self.layer_norm2.eps)
-        x2.addmm_(F.gelu(F.linear(h, self.fc1.weight, self.fc1.bias)).view(b * n, -1), self.fc2.weight.t())
+        if self.hip_mlp_min_rows and b * n >= self.hip_mlp_min_rows and self.fc1.weight.dtype == torch.float16:
+            act = ops.linear_gelu(h.view(b * n, d), self.fc1.weight, self.fc1.bias)   # GELU in the GEMM epilogue
+        else:
+            act = F.gelu(F.linear(h, self.fc1.weight, self.fc1.bias)).view(b * n, -1)
+        x2.addmm_(act, self.fc2.weight.t())
         return x
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:

@@ -127,6 +127,21 @@ def layernorm_bias(x: torch.Tensor, channel_bias, weight: torch.Tensor, bias: to
     return y
 
 
+def linear_gelu(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """gelu(x @ weight.T + bias), exact (erf) form, f16 in / f16 out with f32 accumulation: the hand-written MFMA GEMM of
+    csrc/gemm_f16.hip with the activation in its epilogue (hipBLASLt only fuses the tanh approximation, so the library path
+    is a GEMM plus a separate pass over the 4x-wide activation).  x [M, K], weight [N, K], bias [N]; K % 32 == 0, N % 8 == 0."""
+    assert x.is_cuda and x.dtype == torch.float16 and x.is_contiguous() and x.dim() == 2
+    assert weight.dtype == torch.float16 and weight.is_contiguous() and weight.shape[1] == x.shape[1]
+    assert bias is None or (bias.dtype == torch.float16 and bias.is_contiguous())
+    M, K = x.shape
+    N = weight.shape[0]
+    out = torch.empty((M, N), dtype=torch.float16, device=x.device)
+    _lib.check(_lib.lib().vlfm_gemm_f16_nt(x.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                           out.data_ptr(), M, N, K, 1, _stream()), "gemm_f16_nt")
+    return out
+
+
 VIT_ATTENTION_TOKENS, VIT_ATTENTION_HEADS = 257, (88, 96)
 
 
