@@ -46,6 +46,40 @@ def test_preprocess_one_launch_equals_two_launch(gpu_device, case, monkeypatch):
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("shape", [(300, 264, 128), (1000, 776, 1408), (130, 8, 64), (2570, 6144, 1408)])
+def test_linear_gelu_kernel_vs_fp32_reference(gpu_device, shape, monkeypatch):
+    """vlfm_gemm_f16_nt (hand-written MFMA GEMM, exact-form GELU in the epilogue) against x @ w.T + b -> F.gelu in fp32:
+    ragged M / N tails, one and many K-tiles, asymmetric data (a transposed operand or a swapped tile would show), both
+    schedules.  Tolerance: f16 output rounding (2^-11 relative) plus the f32 accumulation order."""
+    import torch.nn.functional as F
+
+    from vlfm_amd.vlm import ops
+
+    M, N, K = shape
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(M, K, generator=g) * 0.5).half().to(gpu_device)
+    w = (torch.randn(N, K, generator=g) * 0.05).half().to(gpu_device)
+    b = torch.randn(N, generator=g).half().to(gpu_device)
+    want = F.gelu(x.float() @ w.float().t() + b.float())
+    for variant in ("", "1"):
+        if variant:
+            monkeypatch.setenv("VLFM_GEMM_VARIANT", variant)
+        got = ops.linear_gelu(x, w, b).float()
+        err = (got - want).abs()
+        assert float((err - 1e-3 * want.abs()).max()) <= 1e-3, (variant, float(err.max()))
+    # the activation alone over its whole range (x = v e_0, w = e_0: the GEMM returns gelu(v) for every output column),
+    # against float64 -- including the negative tail, where an f32 "1 + erf" would cancel
+    v = torch.linspace(-11, 11, 2816).half()
+    xe = torch.zeros(2816, 64, dtype=torch.float16)
+    xe[:, 0] = v
+    we = torch.zeros(8, 64, dtype=torch.float16)
+    we[:, 0] = 1.0
+    got = ops.linear_gelu(xe.to(gpu_device), we.to(gpu_device), None).cpu().double()
+    ref = F.gelu(v.double())
+    assert torch.equal(got[:, 0], got[:, 7])
+    assert float(((got[:, 0] - ref).abs() - 2.0 ** -11 * ref.abs()).max()) <= 1e-7
+
+
 def test_itc_head_vs_fp32_reference(gpu_device):
     from vlfm_amd.vlm import ops
 

@@ -4,20 +4,24 @@
 // the library path pays a separate 5.4 TB/s elementwise pass over the 808 MB activation; here the GELU runs on the f32
 // accumulators in the epilogue and the activation is written once.
 //
-// Structure (one workgroup = 256 x 256 output tile, 8 wavefronts as 2 (n) x 4 (m), K-step 64):
+// Structure (one workgroup = 256 x 256 output tile, 8 wavefronts as 2 (n) x 4 (m), K-tile 64):
 //   * both operands are K-contiguous ("NT" GEMM): a K-tile of W and of X is 256 rows x 128 B each.  They are staged by
 //     global_load_lds (16 B per lane, no registers, no ds_write): a wavefront's instruction fills 8 rows x 128 B of LDS
 //     linearly; the 16-byte slot a lane FETCHES is permuted within its row (slot ^ ((row >> 1) & 7)), so that the MFMA
-//     fragment reads -- 16 lanes x 16 B from 16 consecutive rows -- hit 16 different bank groups (rows r and r + 1 differ
-//     in the upper / lower half of the 256-byte bank row, pairs differ in the slot): conflict-free ds_read_b128, while the
-//     8 lanes of a row still read one whole 128-byte line of global memory.
-//   * two LDS buffers (128 KB); tile t + 2 is requested as soon as every wavefront has finished reading tile t, one
-//     s_barrier per K-tile; the wait in front of it is for exactly the loads of tile t + 1 (nothing newer is in flight).
-//   * the MFMA operand fragments are software-pipelined through two register stages of half a K-tile each: the ds_reads of
-//     the next half are issued in front of the 32 MFMAs of the current half.
+//     fragment reads -- the four 16-lane groups of ds_read_b128, 16 B from 16 different rows each -- hit 16 different bank
+//     groups: conflict-free, while the 8 lanes of a row still read one whole 128-byte line of global memory.
+//   * two LDS buffers (128 KB, one workgroup per CU, two wavefronts per SIMD).
 //   * operand roles are swapped (A-operand = W rows, B-operand = X rows): a lane then holds 4 CONSECUTIVE n of one m, i.e.
 //     8 contiguous bytes of the output row after conversion; the epilogue transposes through LDS (row stride 272 B:
 //     conflict-free 8-byte writes, 16-byte reads) and stores 256-byte row segments with 16 B per lane.
+//   * the schedule is a PING-PONG between the two wavefronts of a SIMD (gemm_f16_nt_kernel below); the lock-step form it
+//     replaced is kept as gemm_f16_nt_lockstep_kernel for A/B runs.
+// Measured at 256 images (tools/gemm_f16_probe.py, tools/mlp_probe.py; DESIGN.md section 6c has the table): fc1 + GELU 1.11-1.16 ms
+// against 1.41-1.45 ms for hipBLASLt + the GELU pass on random data, 1.19 against 1.24 ms on the network's own activations; as a
+// plain GEMM 1.0-1.1 PFLOP/s, i.e. 5-10 % BELOW hipBLASLt -- so only the fused fc1 uses it (vlfm_amd/vlm/ops.py:linear_gelu).
+// Tried and removed: two workgroups per CU on 256 x 128 tiles with 64-byte rows (hides the epilogue completely but the main loop
+// drops to 0.88 PFLOP/s), the ping-pong with K-steps of 32 in a ring of four stages (no gain: prefetch distance is not the
+// limiter), the loads issued between the MFMAs (10x slower).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -53,6 +57,7 @@ struct GemmArgs {
     _Float16* c;           // [M][N]
     int M, N, K;
     int tiles_m, tiles_n;
+    int group_m;          // tile order of the ping-pong kernel: m-tiles per group (1 = plain n-fastest order)
 };
 
 // Exact-form GELU, 0.5 v (1 + erf(v / sqrt 2)), without the library erff (two polynomial branches + exp, ~36 VALU instructions
@@ -118,8 +123,45 @@ __device__ inline void mma_half(const half8 (&fa)[8], const half8 (&fb)[4], floa
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
 }
 
-template <int EPI, int EXP = 0>
-__global__ __launch_bounds__(512) void gemm_f16_nt_kernel(GemmArgs a) {
+// Epilogue of one wavefront: bias (+ exact GELU) on the f32 accumulators, f16, transpose through a wavefront-private LDS region
+// (it aliases the operand buffers: the caller guarantees that every wavefront is past its last operand read), 16-byte stores.
+template <int EPI>
+__device__ inline void store_tile(const GemmArgs& a, unsigned char* smem, const floatx4 (&acc)[8][4], int wave, int wn, int wm,
+                                  int lane, int m0, int n0) {
+    unsigned char* stg = smem + wave * EPI_WAVE;
+    const int g4 = (lane >> 4) * 4, c16 = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int nl = i * 16 + g4;                    // 4 consecutive n of this lane, wavefront-local
+        float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+        if (a.bias) {
+            const int n = min(n0 + wn * 128 + nl, a.N - 4);
+            const half4 bv = *reinterpret_cast<const half4*>(a.bias + n);
+            b0 = (float)bv[0]; b1 = (float)bv[1]; b2 = (float)bv[2]; b3 = (float)bv[3];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float v0 = acc[i][j][0] + b0, v1 = acc[i][j][1] + b1, v2 = acc[i][j][2] + b2, v3 = acc[i][j][3] + b3;
+            if (EPI == EPI_BIAS_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+            const half4 h = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
+            *reinterpret_cast<half4*>(stg + (j * 16 + c16) * EPI_ROW + nl * 2) = h;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // wavefront-private region: no workgroup barrier needed
+    const int rsub = lane >> 4, chunk = lane & 15;
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+        const int row = it * 4 + rsub;
+        const uint4 v = *reinterpret_cast<const uint4*>(stg + row * EPI_ROW + chunk * 16);
+        const int m = m0 + wm * 64 + row, n = n0 + wn * 128 + chunk * 8;
+        if (m < a.M && n + 8 <= a.N) *reinterpret_cast<uint4*>(a.c + (size_t)m * a.N + n) = v;
+    }
+}
+
+// Lock-step schedule (the first form; kept as the A/B baseline, VLFM_GEMM_VARIANT=1): all 8 wavefronts move through the K-tile
+// together, two fragment register sets, one barrier per K-tile.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_f16_nt_lockstep_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     lds_ptr lds = (lds_ptr)smem;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -157,203 +199,112 @@ __global__ __launch_bounds__(512) void gemm_f16_nt_kernel(GemmArgs a) {
         const int cur = (t & 1) * BUF;
         read_frags(smem, cur, 1, wn, wm, lane, fa1, fb1);     // second half of tile t: in flight under the MFMAs below
         __builtin_amdgcn_sched_barrier(0);
-        if (EXP & 2) __builtin_amdgcn_s_setprio(1);
         mma_half(fa0, fb0, acc);
-        if (EXP & 2) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_waitcnt(0xC07F);    // every LDS read of tile t by this wavefront has returned
         if (t + 1 < NT) {
-            if (!(EXP & 1)) __builtin_amdgcn_s_waitcnt(0x0F70);  // ... and its share of tile t + 1 has landed (nothing newer is in flight)
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // ... and its share of tile t + 1 has landed (nothing newer is in flight)
             __builtin_amdgcn_s_barrier();                      // ... for everybody: buffer `cur` is free, the other one is complete
             asm volatile("" ::: "memory");
             if (t + 2 < NT) stage_tile(a, lds, cur, n0, m0, (t + 2) * GK, wave, lane);
             read_frags(smem, cur ^ BUF, 0, wn, wm, lane, fa0, fb0);  // first half of tile t + 1: in flight under the MFMAs below
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (EXP & 2) __builtin_amdgcn_s_setprio(1);
         mma_half(fa1, fb1, acc);
-        if (EXP & 2) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_waitcnt(0xC07F);
     }
 
-    // ---- epilogue: bias (+ exact GELU) on the f32 accumulators, f16, transpose through LDS, 16-byte stores
     __builtin_amdgcn_s_barrier();   // every wavefront is done with the operand buffers
     asm volatile("" ::: "memory");
-    unsigned char* stg = smem + wave * EPI_WAVE;
-    const int g4 = (lane >> 4) * 4, c16 = lane & 15;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int nl = i * 16 + g4;                    // 4 consecutive n of this lane, wavefront-local
-        float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-        if (a.bias) {
-            const int n = min(n0 + wn * 128 + nl, a.N - 4);
-            const half4 bv = *reinterpret_cast<const half4*>(a.bias + n);
-            b0 = (float)bv[0]; b1 = (float)bv[1]; b2 = (float)bv[2]; b3 = (float)bv[3];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            float v0 = acc[i][j][0] + b0, v1 = acc[i][j][1] + b1, v2 = acc[i][j][2] + b2, v3 = acc[i][j][3] + b3;
-            if (EPI == EPI_BIAS_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
-            const half4 h = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
-            *reinterpret_cast<half4*>(stg + (j * 16 + c16) * EPI_ROW + nl * 2) = h;
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);   // wavefront-private region: no workgroup barrier needed
-    const int rsub = lane >> 4, chunk = lane & 15;
-#pragma unroll
-    for (int it = 0; it < 16; it++) {
-        const int row = it * 4 + rsub;
-        const uint4 v = *reinterpret_cast<const uint4*>(stg + row * EPI_ROW + chunk * 16);
-        const int m = m0 + wm * 64 + row, n = n0 + wn * 128 + chunk * 8;
-        if (m < a.M && n + 8 <= a.N) *reinterpret_cast<uint4*>(a.c + (size_t)m * a.N + n) = v;
-    }
+    store_tile<EPI>(a, smem, acc, wave, wn, wm, lane, m0, n0);
 }
 
 
-// ------------------------------------------------------------------------------------------------ two workgroups per CU
-// Same wavefront tile (128 n x 64 m, 8 + 4 fragments, 32 MFMAs per K-step of 32) but a workgroup is 4 wavefronts on a
-// 256 (n) x 128 (m) output tile with a K-tile of 32 in a ring of three 24 KB LDS stages: 72 KB, so TWO workgroups share a CU.
-// The two wavefronts of a SIMD then belong to different workgroups with unrelated phases: the barrier + staging + fragment
-// reads of one, and above all its EPILOGUE (bias, erf-GELU, f16, LDS transpose, stores: ~30 VALU instructions per output
-// value in which the one-workgroup form leaves the matrix pipe idle), run under the MFMAs of the other.
-//   iteration t:  wait own fragment reads of tile t | request tile t + 2 into the stage tile t - 1 lived in (everybody finished
-//   reading it before the previous barrier) | wait tile t + 1 (the 6 newest loads may stay in flight) | barrier | issue the
-//   fragment reads of tile t + 1 | 32 MFMAs on tile t.
-// Staged rows are 64 B: a bank row holds 4 of them, the slot permutation is [0,3,2,1][(row >> 2) & 3] (conflict-free for the
-// four lane groups of ds_read_b128, checked exhaustively).
-constexpr int G2_K = 32;
-constexpr int G2_ROWB = G2_K * 2;            // 64 B
-constexpr int G2_TN = 256, G2_TM = 128;
-constexpr int G2_W = G2_TN * G2_ROWB;        // 16 KB
-constexpr int G2_STAGE = (G2_TN + G2_TM) * G2_ROWB;   // 24 KB
-constexpr int G2_LDS = 3 * G2_STAGE;         // 72 KB (>= 4 epilogue regions of 17 KB)
-static_assert(4 * EPI_WAVE <= G2_LDS, "epilogue staging fits the operand ring");
-
-__device__ inline int g2_perm(int r) { return (0x6Cu >> (2 * ((r >> 2) & 3))) & 3; }   // [0,3,2,1]
-
-__device__ inline void g2_stage(const GemmArgs& a, lds_ptr lds, int buf, int n0, int m0, int k0, int wave, int lane) {
-    const int sub = lane >> 2, p = lane & 3;
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-        const int q = wave * 6 + j;                      // 24 chunks of 16 rows: 16 of W, 8 of X
-        const bool is_w = q < 16;                        // uniform
-        const int r = (is_w ? q : q - 16) * 16 + sub;
-        const int s = p ^ g2_perm(r);
-        const int row = is_w ? min(n0 + r, a.N - 1) : min(m0 + r, a.M - 1);
-        const _Float16* g = (is_w ? a.w : a.x) + (size_t)row * a.K + k0 + s * 8;
-        const int dst = __builtin_amdgcn_readfirstlane(buf + q * 1024);   // W chunks, then X chunks: q * 1 KB either way
-        __builtin_amdgcn_global_load_lds((gbl_ptr)g, lds + dst, 16, 0, 0);
-    }
-}
-
-__device__ inline void g2_read_frags(const unsigned char* smem, int buf, int wn, int wm, int lane, half8 (&fa)[8], half8 (&fb)[4]) {
-    const int r16 = lane & 15, s = lane >> 4;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int R = wn * 128 + i * 16 + r16;
-        fa[i] = *reinterpret_cast<const half8*>(smem + buf + R * G2_ROWB + ((s ^ g2_perm(R)) << 4));
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int R = wm * 64 + j * 16 + r16;
-        fb[j] = *reinterpret_cast<const half8*>(smem + buf + G2_W + R * G2_ROWB + ((s ^ g2_perm(R)) << 4));
-    }
-}
-
+// ------------------------------------------------------------------------------------------------ ping-pong schedule
+// Same tile, staging and fragments as the lock-step kernel, but the two wavefronts of a SIMD (w and w + 4) never do the same thing
+// at the same time.  PMC counters of the lock-step form (tools/gemm_pmc.sh): the matrix pipe is busy 46-51 % of the cycles against
+// 67 % for hipBLASLt's kernel, with the same MFMA count, fewer bank conflicts and similar LDS activity -- what is lost is the time in
+// which BOTH wavefronts of a SIMD are behind the same barrier issuing loads and waiting for fragments.  Here a K-tile is four phases
+// per wavefront -- fragments of half 0 | 32 MFMAs | fragments of half 1 | 32 MFMAs -- each closed by the workgroup barrier, and
+// wavefronts 4-7 run ONE PHASE BEHIND wavefronts 0-3 (one extra barrier in front of their loop, one behind the others'): whenever
+// one wavefront of a SIMD waits for LDS, its partner is in the matrix pipe.  One fragment register set instead of two.
+//   tile t + 1 is requested at the start of "fragments of half 0" of tile t into the other LDS buffer (every wavefront finished
+//   reading tile t - 1 at least one barrier earlier, the late group included) and awaited at the end of "fragments of half 1".
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_f16_nt2_kernel(GemmArgs a) {
+__global__ __launch_bounds__(512) void gemm_f16_nt_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     lds_ptr lds = (lds_ptr)smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave >> 1, wm = wave & 1;
+    const int wn = wave >> 2, wm = wave & 3;
+    const int late = wn;                               // wavefronts 4-7: one phase behind
     const int nwg = a.tiles_m * a.tiles_n;
     int bid = blockIdx.x;
-    {   // every XCD gets a contiguous range of tiles ...
+    {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    // ... walked in groups of 8 m-tiles with n slowest inside a group: the 64 tiles an XCD works on at one time are about
-    // 8 (m) x 8 (n), i.e. 16 operand panels instead of 24 + 3
+    // ... walked in groups of GM m-tiles, m fastest: the 32 tiles an XCD works on at one time are GM (m) x 32 / GM (n), i.e.
+    // GM + 32 / GM operand panels per K-step instead of 24 + 2, and the X panels of a group stay in the L2 while n advances
     int tm, tn;
     {
-        const int per_group = 8 * a.tiles_n, grp = bid / per_group, in = bid - grp * per_group;
-        const int rows = min(8, a.tiles_m - grp * 8);
+        const int GM = a.group_m;
+        const int per_group = GM * a.tiles_n, grp = bid / per_group, in = bid - grp * per_group;
+        const int rows = min(GM, a.tiles_m - grp * GM);
         tn = in / rows;
-        tm = grp * 8 + (in - tn * rows);
+        tm = grp * GM + (in - tn * rows);
     }
-    const int m0 = tm * G2_TM, n0 = tn * G2_TN;
-    const int NT = a.K / G2_K;
+    const int m0 = tm * GB, n0 = tn * GB;
+    const int NT = a.K / GK;
 
     floatx4 acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-    half8 fa0[8], fb0[4], fa1[8], fb1[4];
+    half8 fa[8], fb[4];
 
-    g2_stage(a, lds, 0, n0, m0, 0, wave, lane);
-    if (NT > 1) g2_stage(a, lds, G2_STAGE, n0, m0, G2_K, wave, lane);
-    if (NT > 1) __builtin_amdgcn_s_waitcnt(0x0F76);   // vmcnt(6): tile 0 has landed
-    else __builtin_amdgcn_s_waitcnt(0x0F70);
+    stage_tile(a, lds, 0, n0, m0, 0, wave, lane);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    g2_read_frags(smem, 0, wn, wm, lane, fa0, fb0);
+    if (late) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
 
-    auto step = [&](int t, half8 (&fa)[8], half8 (&fb)[4], half8 (&na)[8], half8 (&nb)[4]) {
-        __builtin_amdgcn_s_waitcnt(0xC07F);                                      // fragments of tile t are here
-        if (t + 1 < NT) {
-            if (t + 2 < NT) {
-                g2_stage(a, lds, ((t + 2) % 3) * G2_STAGE, n0, m0, (t + 2) * G2_K, wave, lane);
-                __builtin_amdgcn_s_waitcnt(0x0F76);                              // tile t + 1 landed (tile t + 2 may fly)
-            } else {
-                __builtin_amdgcn_s_waitcnt(0x0F70);
-            }
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            g2_read_frags(smem, ((t + 1) % 3) * G2_STAGE, wn, wm, lane, na, nb);
-        }
+    for (int t = 0; t < NT; t++) {
+        const int cur = (t & 1) * BUF;
+        // ---- fragments of half 0 (+ request tile t + 1)
+        if (t + 1 < NT) stage_tile(a, lds, cur ^ BUF, n0, m0, (t + 1) * GK, wave, lane);
+        read_frags(smem, cur, 0, wn, wm, lane, fa, fb);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // ---- 32 MFMAs
         __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
         mma_half(fa, fb, acc);
+        __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-    };
-    for (int t = 0; t < NT; t += 2) {
-        step(t, fa0, fb0, fa1, fb1);
-        if (t + 1 < NT) step(t + 1, fa1, fb1, fa0, fb0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // ---- fragments of half 1 (+ tile t + 1 has landed, as far as this wavefront's share goes)
+        read_frags(smem, cur, 1, wn, wm, lane, fa, fb);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // ---- 32 MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        mma_half(fa, fb, acc);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     }
+    if (!late) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }   // the late group's last MFMA phase: its LDS reads are over
 
-    // ---- epilogue (as above; the wavefront tile is the same)
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    unsigned char* stg = smem + wave * EPI_WAVE;
-    const int g4 = (lane >> 4) * 4, c16 = lane & 15;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int nl = i * 16 + g4;
-        float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-        if (a.bias) {
-            const int n = min(n0 + wn * 128 + nl, a.N - 4);
-            const half4 bv = *reinterpret_cast<const half4*>(a.bias + n);
-            b0 = (float)bv[0]; b1 = (float)bv[1]; b2 = (float)bv[2]; b3 = (float)bv[3];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            float v0 = acc[i][j][0] + b0, v1 = acc[i][j][1] + b1, v2 = acc[i][j][2] + b2, v3 = acc[i][j][3] + b3;
-            if (EPI == EPI_BIAS_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
-            const half4 h = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
-            *reinterpret_cast<half4*>(stg + (j * 16 + c16) * EPI_ROW + nl * 2) = h;
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    const int rsub = lane >> 4, chunk = lane & 15;
-#pragma unroll
-    for (int it = 0; it < 16; it++) {
-        const int row = it * 4 + rsub;
-        const uint4 v = *reinterpret_cast<const uint4*>(stg + row * EPI_ROW + chunk * 16);
-        const int m = m0 + wm * 64 + row, n = n0 + wn * 128 + chunk * 8;
-        if (m < a.M && n + 8 <= a.N) *reinterpret_cast<uint4*>(a.c + (size_t)m * a.N + n) = v;
-    }
+    store_tile<EPI>(a, smem, acc, wave, wn, wm, lane, m0, n0);
 }
 
 }  // namespace vlfm
@@ -365,44 +316,33 @@ using namespace vlfm;
 extern "C" int vlfm_gemm_f16_nt(const void* d_x, const void* d_w, const void* d_bias, void* d_c, int m, int n, int k,
                                 int epilogue, void* stream) {
     if (m == 0 || n == 0) return VLFM_OK;
-    if (!d_x || !d_w || !d_c || m < 0 || n < 0 || k <= 0 || (k % G2_K) != 0 || (n % 8) != 0 || epilogue < 0 || epilogue > 1)
-        return fail(VLFM_ERR_INVALID, "gemm_f16_nt: K must be a multiple of 32, N of 8, epilogue 0 or 1");
+    if (!d_x || !d_w || !d_c || m < 0 || n < 0 || k <= 0 || (k % GK) != 0 || (n % 8) != 0 || epilogue < 0 || epilogue > 1)
+        return fail(VLFM_ERR_INVALID, "gemm_f16_nt: K must be a multiple of 64, N of 8, epilogue 0 or 1");
     GemmArgs a;
     a.x = (const _Float16*)d_x; a.w = (const _Float16*)d_w; a.bias = (const _Float16*)d_bias; a.c = (_Float16*)d_c;
     a.M = m; a.N = n; a.K = k;
     a.tiles_m = (m + GB - 1) / GB; a.tiles_n = (n + GB - 1) / GB;
-    static LdsOptIn opt0, opt1;
-    const bool ok = epilogue == 0 ? opt0.ensure(reinterpret_cast<const void*>(gemm_f16_nt_kernel<EPI_BIAS>), GEMM_LDS)
-                                  : opt1.ensure(reinterpret_cast<const void*>(gemm_f16_nt_kernel<EPI_BIAS_GELU>), GEMM_LDS);
-    if (!ok) return fail(VLFM_ERR_HIP, "gemm_f16_nt: cannot opt in to the LDS size");
-    const char* ev = getenv("VLFM_GEMM_VARIANT");   // 1: 256 x 256 tiles, one workgroup per CU; 2: 256 x 128, two per CU
-    const int variant = ev ? atoi(ev) : ((k % GK) == 0 ? 1 : 2);
-    if (variant == 2 && (k % G2_K) == 0) {   // two workgroups per CU (256 x 128 tiles)
-        a.tiles_m = (m + G2_TM - 1) / G2_TM; a.tiles_n = (n + G2_TN - 1) / G2_TN;
-        static LdsOptIn p0, p1;
-        const bool ok2 = epilogue == 0 ? p0.ensure(reinterpret_cast<const void*>(gemm_f16_nt2_kernel<EPI_BIAS>), G2_LDS)
-                                       : p1.ensure(reinterpret_cast<const void*>(gemm_f16_nt2_kernel<EPI_BIAS_GELU>), G2_LDS);
-        if (!ok2) return fail(VLFM_ERR_HIP, "gemm_f16_nt: cannot opt in to the LDS size");
-        const dim3 grid2(a.tiles_m * a.tiles_n), block2(256);
-        VLFM_TIMED("gemm_f16_nt2_kernel", stream);
-        if (epilogue == 0) VLFM_KLAUNCH(gemm_f16_nt2_kernel<EPI_BIAS>, grid2, block2, G2_LDS, (hipStream_t)stream, a);
-        else VLFM_KLAUNCH(gemm_f16_nt2_kernel<EPI_BIAS_GELU>, grid2, block2, G2_LDS, (hipStream_t)stream, a);
-        return check_launch("gemm_f16_nt2_kernel");
-    }
-    if ((k % GK) != 0) return fail(VLFM_ERR_INVALID, "gemm_f16_nt: the one-workgroup-per-CU variant needs K % 64 == 0");
+    // tile order (diagnostic override VLFM_GEMM_GROUP_M): groups of 8 m-tiles when there are many n-tiles (fc1, qkv), plain
+    // n-fastest order otherwise (measured: fc2 / projection shapes, 6 n-tiles, lose 5-8 % to the grouping)
+    const char* eg = getenv("VLFM_GEMM_GROUP_M");
+    a.group_m = eg ? atoi(eg) : (a.tiles_n >= 12 ? 8 : 1);
+    if (a.group_m < 1) a.group_m = 1;
+    const char* ev = getenv("VLFM_GEMM_VARIANT");   // 1 = the lock-step kernel (A/B baseline of tools/gemm_f16_probe.py)
+    const bool lockstep = ev && atoi(ev) == 1;
+    const void* fn = lockstep ? (epilogue == 0 ? reinterpret_cast<const void*>(gemm_f16_nt_lockstep_kernel<EPI_BIAS>)
+                                               : reinterpret_cast<const void*>(gemm_f16_nt_lockstep_kernel<EPI_BIAS_GELU>))
+                              : (epilogue == 0 ? reinterpret_cast<const void*>(gemm_f16_nt_kernel<EPI_BIAS>)
+                                               : reinterpret_cast<const void*>(gemm_f16_nt_kernel<EPI_BIAS_GELU>));
+    static LdsOptIn opt[4];
+    if (!opt[(lockstep ? 2 : 0) + epilogue].ensure(fn, GEMM_LDS)) return fail(VLFM_ERR_HIP, "gemm_f16_nt: cannot opt in to the LDS size");
     const dim3 grid(a.tiles_m * a.tiles_n), block(512);
-    if (const char* e = getenv("VLFM_GEMM_EXP")) {   // experiments (tools/gemm_f16_probe.py): 1 = no load wait (WRONG results), 2 = setprio
-        const int x = atoi(e);
-        static LdsOptIn o1, o2, o3;
-        if (x == 1 && o1.ensure(reinterpret_cast<const void*>(gemm_f16_nt_kernel<EPI_BIAS, 1>), GEMM_LDS)) {
-            VLFM_KLAUNCH((gemm_f16_nt_kernel<EPI_BIAS, 1>), grid, block, GEMM_LDS, (hipStream_t)stream, a); return check_launch("gemm exp1"); }
-        if (x == 2 && o2.ensure(reinterpret_cast<const void*>(gemm_f16_nt_kernel<EPI_BIAS, 2>), GEMM_LDS)) {
-            VLFM_KLAUNCH((gemm_f16_nt_kernel<EPI_BIAS, 2>), grid, block, GEMM_LDS, (hipStream_t)stream, a); return check_launch("gemm exp2"); }
-        if (x == 3 && o3.ensure(reinterpret_cast<const void*>(gemm_f16_nt_kernel<EPI_BIAS, 3>), GEMM_LDS)) {
-            VLFM_KLAUNCH((gemm_f16_nt_kernel<EPI_BIAS, 3>), grid, block, GEMM_LDS, (hipStream_t)stream, a); return check_launch("gemm exp3"); }
-    }
     VLFM_TIMED("gemm_f16_nt_kernel", stream);
-    if (epilogue == 0) VLFM_KLAUNCH(gemm_f16_nt_kernel<EPI_BIAS>, grid, block, GEMM_LDS, (hipStream_t)stream, a);
-    else VLFM_KLAUNCH(gemm_f16_nt_kernel<EPI_BIAS_GELU>, grid, block, GEMM_LDS, (hipStream_t)stream, a);
+    if (lockstep) {
+        if (epilogue == 0) VLFM_KLAUNCH(gemm_f16_nt_lockstep_kernel<EPI_BIAS>, grid, block, GEMM_LDS, (hipStream_t)stream, a);
+        else VLFM_KLAUNCH(gemm_f16_nt_lockstep_kernel<EPI_BIAS_GELU>, grid, block, GEMM_LDS, (hipStream_t)stream, a);
+    } else {
+        if (epilogue == 0) VLFM_KLAUNCH(gemm_f16_nt_kernel<EPI_BIAS>, grid, block, GEMM_LDS, (hipStream_t)stream, a);
+        else VLFM_KLAUNCH(gemm_f16_nt_kernel<EPI_BIAS_GELU>, grid, block, GEMM_LDS, (hipStream_t)stream, a);
+    }
     return check_launch("gemm_f16_nt_kernel");
 }
