@@ -274,8 +274,9 @@ __global__ __launch_bounds__(512) void gemm_f16_nt_kernel(GemmArgs a) {
     for (int t = 0; t < NT; t++) {
         const int cur = (t & 1) * BUF;
         // ---- fragments of half 0 (+ request tile t + 1)
+        read_frags(smem, cur, 0, wn, wm, lane, fa, fb);       // first, so that the fragments travel while the loads below issue
+        __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < NT) stage_tile(a, lds, cur ^ BUF, n0, m0, (t + 1) * GK, wave, lane);
-        read_frags(smem, cur, 0, wn, wm, lane, fa, fb);
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
