@@ -37,7 +37,8 @@ for _ in range(20):
     acc[:, :15] += d; n += 1
     w = np.zeros(3, np.int64); _lib.lib().vlfm_debug_walk_stats(ctypes.c_void_p(w.ctypes.data)); walk += w
 names = {0: ["cone raster", "window+masks", "obst contours", "shadow pts", "cut lines", "visible contours+pick", "fill", "dilate+OR"],
-         1: ["zero+scan+pick"], 2: ["dilate5 full planes", "small-unexplored filter", "border chain", "bad flags", "pieces+midpoints"]}
+         1: ["window copy", "scan+walk", "offset+pick", "publish"],
+         2: ["dilate5 full planes", "small-unexplored filter", "window copy", "scan+walk", "offset", "bad flags", "pieces", "midpoints"]}
 for k, nm in names.items():
     print(["fog_of_war", "explored_select", "frontier"][k], " ".join(f"{a}={acc[k, i] / n:.0f}us" for i, a in enumerate(nm)))
 print(f"border walks, all envs and scans: {walk[0] * 0.01 / n / E:.0f} us per env-step inside follow_border, "

@@ -130,8 +130,14 @@ __device__ long long g_phase_clock[3][16];
         __syncthreads();                                                                          \
         if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_clock[kernel_id][k] = wall_clock64();    \
     } while (0)
+// the same without the barrier, for a stamp inside single-wavefront code
+#define VLFM_STAMP(kernel_id, k)                                                                  \
+    do {                                                                                          \
+        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_phase_clock[kernel_id][k] = wall_clock64(); \
+    } while (0)
 #else
 #define VLFM_PHASE(kernel_id, k) do {} while (0)
+#define VLFM_STAMP(kernel_id, k) do {} while (0)
 #endif
 
 // ================================================================================================ drawing helpers
@@ -674,6 +680,7 @@ __global__ __launch_bounds__(256) void explored_select_kernel(const FogParams* _
     }
     __threadfence();
     __syncthreads();
+    VLFM_PHASE(1, 1);
     int2* pts = sc.pts + (size_t)P.env * sc.cap_pts;
     int* cstart = sc.starts + (size_t)P.env * sc.cap_contours;
     int* clen = sc.lens + (size_t)P.env * sc.cap_contours;
@@ -685,6 +692,7 @@ __global__ __launch_bounds__(256) void explored_select_kernel(const FogParams* _
         if (in_lds) {
             Bits b{L_img + pw + 1, pw, wrows, wwords * 32, 1};
             scan_external(b, L_tr + pw + 1, L_ng + pw + 1, 0, wrows - 1, 2, sink);
+            VLFM_STAMP(1, 2);
             const int npt = sink.n_pts < sc.cap_pts ? sink.n_pts : sc.cap_pts;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             for (int i = lane; i < npt; i += 64) { int2 q = pts[i]; q.x += w_lo * 32; q.y += y_lo; pts[i] = q; }  // -> image coords
@@ -707,11 +715,12 @@ __global__ __launch_bounds__(256) void explored_select_kernel(const FogParams* _
             }
         }
         if (lane == 0) { sh_i[0] = sink.n_contours; sh_i[1] = sink.overflow; sh_i[2] = chosen; }
+        VLFM_STAMP(1, 3);
     }
     __threadfence();
     __syncthreads();
     if (tid == 0) { status[0] = sh_i[1]; status[1] = sh_i[0]; status[2] = sh_i[2]; status[3] = 0; }
-    VLFM_PHASE(1, 1);
+    VLFM_PHASE(1, 4);
     if (sh_i[1] || sh_i[0] <= 1) return;
     // redraw the chosen outline filled on an empty plane (global-memory bitmaps; rare path)
     const int chosen = sh_i[2];
@@ -924,6 +933,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(const FogParams* __restri
             __threadfence();
         }
         __syncthreads();
+        VLFM_PHASE(2, 3);
         if (wave == 0) {
             ContourSink sink;
             sink.pts = pts; sink.start = cstart; sink.len = clen; sink.cap_pts = sc.cap_pts; sink.cap_contours = sc.cap_contours;
@@ -931,6 +941,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(const FogParams* __restri
             if (in_lds) {
                 Bits b{L_img + pw + 1, pw, wrows, wwords * 32, 1};
                 scan_external(b, L_tr + pw + 1, L_ng + pw + 1, 0, wrows - 1, 1, sink);
+                VLFM_STAMP(2, 4);
                 const int npt = sink.n_pts < sc.cap_pts ? sink.n_pts : sc.cap_pts;
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 for (int i = lane; i < npt; i += 64) { int2 q = pts[i]; q.x += w_lo * 32; q.y += y_lo; pts[i] = q; }
@@ -946,7 +957,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(const FogParams* __restri
     __syncthreads();
     const int nc = sh_i[5], npts_all = sh_i[6];
     if (sh_i[7]) { if (tid == 0) { out_n[0] = 0; out_n[1] = 1; } return; }
-    VLFM_PHASE(2, 3);
+    VLFM_PHASE(2, 5);
     // ---- d. a chain point is "bad" when no unexplored-navigable cell lies in its 3x3 neighbourhood
     //         (cv2.blur 3x3, BORDER_REFLECT_101, of 255*(navigable & ~filtered) is zero there)
     // the flags are consumed by a single lane below: keep them in LDS (the walk window is free again) when they fit
@@ -968,53 +979,79 @@ __global__ __launch_bounds__(256) void frontier_kernel(const FogParams* __restri
     }
     __threadfence();
     __syncthreads();
-    VLFM_PHASE(2, 4);
+    VLFM_PHASE(2, 6);
     // ---- e. frontier runs + arc-length midpoints.  Contours in OpenCV order (reverse discovery); the chain handed to
     // contour_to_frontiers is the contour rotated by one (interpolate_contour emits end points only).
-    // Thread 0 lists the kept pieces; then one thread per piece computes its midpoint.
-    if (tid == 0) {
+    // Wavefront 0 lists the kept pieces, 64 chain positions at a time (a serial pass over a 2 300-point chain took 370 us);
+    // then the midpoints are computed piece by piece.
+    if (wave == 0) {
         // np.split(chain, bad) -> pieces [0,b0) [b0,b1) ... [b_last,n); a piece is kept when it has more than two
         // points (its leading bad point is then dropped) -- or is the head piece of a chain whose ends both lie on a
         // frontier (front_last_split), in which case the LAST kept piece is finally glued in front of it.
-        int np = 0, overflow = 0;
+        // Boundary k (the k-th bad position, and finally j == n) closes piece k = [previous boundary or 0, boundary): everything
+        // a piece needs is the previous boundary and its ordinal, i.e. a ballot and two popcounts per 64 positions.
+        int np = 0, overflow = 0;   // uniform
+        const unsigned long long below = (1ull << lane) - 1ull;
         for (int c = nc - 1; c >= 0; c--) {
             const int n = clen[c], base = cstart[c];
             if (n < 2) continue;  // a single-pixel contour interpolates to nothing
             auto is_bad = [&](int j) { return bad[base + (j + 1 == n ? 0 : j + 1)] != 0; };  // chain rotated by one
             int nbad = 0, first_bad = -1, last_bad = -1;
-            for (int j = 0; j < n; j++)
-                if (is_bad(j)) { if (first_bad < 0) first_bad = j; last_bad = j; nbad++; }
-            const bool fls = nbad > 0 && first_bad != 0 && last_bad < n - 2;
-            int piece_s = 0, idx = 0, first_slot = -1, kept = 0;
-            for (int j = 0; j <= n; j++) {
-                if (j == n || is_bad(j)) {
-                    const int len = j - piece_s;
-                    if (len > 2 || (idx == 0 && fls)) {
-                        if (np < sc.cap_contours) {
-                            int* pc = pieces + 6 * np;
-                            pc[0] = base; pc[1] = n;
-                            pc[2] = idx == 0 ? piece_s : piece_s + 1; pc[3] = idx == 0 ? len : len - 1;
-                            pc[4] = 0; pc[5] = 0;
-                            if (kept == 0) first_slot = np;
-                            np++; kept++;
-                        } else overflow = 1;
-                    }
-                    piece_s = j;
-                    idx++;
+            for (int j0 = 0; j0 < n; j0 += 64) {
+                const int j = j0 + lane;
+                const unsigned long long m = __ballot(j < n && is_bad(j));
+                if (m) {
+                    if (first_bad < 0) first_bad = j0 + __builtin_ctzll(m);
+                    last_bad = j0 + 63 - __builtin_clzll(m);
+                    nbad += __builtin_popcountll(m);
                 }
             }
+            const bool fls = nbad > 0 && first_bad != 0 && last_bad < n - 2;
+            const int np_base = np;
+            int prev_boundary = 0, ordinal = 0;   // carried across the 64-position chunks (uniform)
+            for (int j0 = 0; j0 <= n; j0 += 64) {
+                const int j = j0 + lane;
+                const bool boundary = j == n || (j < n && is_bad(j));
+                const unsigned long long m = __ballot(boundary);
+                if (!m) continue;
+                const unsigned long long lower = m & below;
+                const int start = lower ? j0 + 63 - __builtin_clzll(lower) : prev_boundary;
+                const int idx = ordinal + __builtin_popcountll(lower);
+                const int len = j - start;
+                const bool keep = boundary && (len > 2 || (idx == 0 && fls));
+                const unsigned long long km = __ballot(keep);
+                const int slot = np + __builtin_popcountll(km & below);
+                if (keep) {
+                    if (slot < sc.cap_contours) {
+                        int* pc = pieces + 6 * slot;
+                        pc[0] = base; pc[1] = n;
+                        pc[2] = idx == 0 ? start : start + 1; pc[3] = idx == 0 ? len : len - 1;
+                        pc[4] = 0; pc[5] = 0;
+                    }
+                }
+                np += __builtin_popcountll(km);
+                if (np > sc.cap_contours) { np = sc.cap_contours; overflow = 1; }
+                prev_boundary = j0 + 63 - __builtin_clzll(m);
+                ordinal += __builtin_popcountll(m);
+            }
+            const int kept = np - np_base;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (kept > 1 && fls) {  // kept[0] = concat(kept.pop(), kept[0])
-                int* head = pieces + 6 * first_slot;
-                int* tail = pieces + 6 * (np - 1);
-                const int hs = head[2], hl = head[3];
-                head[2] = tail[2]; head[3] = tail[3]; head[4] = hs; head[5] = hl;
+                if (lane == 0) {
+                    int* head = pieces + 6 * np_base;
+                    int* tail = pieces + 6 * (np - 1);
+                    const int hs = head[2], hl = head[3];
+                    head[2] = tail[2]; head[3] = tail[3]; head[4] = hs; head[5] = hl;
+                }
                 np--;
             }
         }
-        sh_i[8] = np; sh_i[9] = overflow;
+        if (lane == 0) { sh_i[8] = np; sh_i[9] = overflow; }
     }
     __threadfence();
     __syncthreads();
+    VLFM_PHASE(2, 7);
     const int np = sh_i[8];
     // get_frontier_midpoint per piece.  The arc-length cumsum is sequential by definition (np.cumsum's rounding order), but
     // the segment lengths are not: all lanes compute them (f64 sqrt, chain indexing) into LDS, then one lane only adds.
@@ -1066,7 +1103,7 @@ __global__ __launch_bounds__(256) void frontier_kernel(const FogParams* __restri
             __syncthreads();
         }
     }
-    VLFM_PHASE(2, 5);
+    VLFM_PHASE(2, 8);
     if (tid == 0) {
         out_n[0] = np < sc.cap_frontiers ? np : sc.cap_frontiers;
         // one flag for the whole explore pipeline of this environment: a capacity overflow in the fog-of-war or the
