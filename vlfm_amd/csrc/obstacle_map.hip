@@ -20,6 +20,7 @@
 
 #include "../../include/vlfm_amd.h"
 #include "bitmap.h"
+#include "border_parallel.h"
 #include "profile.h"
 #include "raster.h"
 #include "status.h"
@@ -641,9 +642,11 @@ struct SelectScratch {
     int2* pts; int* starts; int* lens; int* status;  // status [n_envs][4]: overflow, n contours, chosen, refilled
     int cap_pts, cap_contours;
     unsigned lds_bytes;                    // dynamic LDS available for the window copy
+    unsigned* walk_jd; int* walk_pixbase;  // parallel border follower (border_parallel.h): [n_envs][2 * walk_states], [n_envs][cap_pts]
+    int walk_states;
 };
 
-__global__ __launch_bounds__(256) void explored_select_kernel(const FogParams* __restrict__ prm, MapPlanes mp,
+__global__ __launch_bounds__(1024) void explored_select_kernel(const FogParams* __restrict__ prm, MapPlanes mp,
                                                               SelectScratch sc, const int* __restrict__ bbox) {
     const FogParams& P = prm[blockIdx.x];
     if (P.n_poly <= 0) return;
@@ -685,19 +688,28 @@ __global__ __launch_bounds__(256) void explored_select_kernel(const FogParams* _
     int* cstart = sc.starts + (size_t)P.env * sc.cap_contours;
     int* clen = sc.lens + (size_t)P.env * sc.cap_contours;
     int* status = sc.status + (size_t)P.env * 4;
+    __shared__ int sh_wg[WG_SH_INTS];
+    ContourSink sink;
+    sink.pts = pts; sink.start = cstart; sink.len = clen; sink.cap_pts = sc.cap_pts; sink.cap_contours = sc.cap_contours;
+    sink.n_pts = 0; sink.n_contours = 0; sink.overflow = 0;
+    if (in_lds) {   // the whole workgroup follows the borders (border_parallel.h); tables in the global planes this path leaves free
+        Bits b{L_img + pw + 1, pw, wrows, wwords * 32, 1};
+        WalkTables T;
+        T.bmask = traced; T.wprefix = reinterpret_cast<int*>(neg);
+        T.next = reinterpret_cast<int*>(sc.fill_solid + eoff); T.sinfo = sc.fill_par + eoff;
+        T.jd0 = sc.walk_jd + (size_t)P.env * 2 * sc.walk_states; T.jd1 = T.jd0 + sc.walk_states;
+        T.pixbase = sc.walk_pixbase + (size_t)P.env * sc.cap_pts;
+        T.cap_bp = sc.cap_pts; T.cap_states = min(sc.walk_states, S * stride);
+        T.wrows = wrows; T.wwords = wwords;
+        wg_scan_external(b, L_tr + pw + 1, L_ng + pw + 1, 2, sink, T, sh_wg);
+        VLFM_STAMP(1, 2);
+        const int npt = sink.n_pts < sc.cap_pts ? sink.n_pts : sc.cap_pts;
+        for (int i = tid; i < npt; i += nth) { int2 q = pts[i]; q.x += w_lo * 32; q.y += y_lo; pts[i] = q; }  // -> image coords
+        __threadfence();
+        __syncthreads();
+    }
     if (wave == 0) {
-        ContourSink sink;
-        sink.pts = pts; sink.start = cstart; sink.len = clen; sink.cap_pts = sc.cap_pts; sink.cap_contours = sc.cap_contours;
-        sink.n_pts = 0; sink.n_contours = 0; sink.overflow = 0;
-        if (in_lds) {
-            Bits b{L_img + pw + 1, pw, wrows, wwords * 32, 1};
-            scan_external(b, L_tr + pw + 1, L_ng + pw + 1, 0, wrows - 1, 2, sink);
-            VLFM_STAMP(1, 2);
-            const int npt = sink.n_pts < sc.cap_pts ? sink.n_pts : sc.cap_pts;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            for (int i = lane; i < npt; i += 64) { int2 q = pts[i]; q.x += w_lo * 32; q.y += y_lo; pts[i] = q; }  // -> image coords
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        } else {
+        if (!in_lds) {
             Bits b{expl, stride, S, S};
             scan_external(b, traced, neg, y_lo, y_hi, 2, sink);
         }
@@ -763,6 +775,8 @@ struct FrontierScratch {
     unsigned lds_bytes;  // dynamic LDS available for the window copy of the border walk
     int* fog_status;        // [n_envs][4] of fog_of_war_kernel: word 0 = contour scratch overflow (sticky; consumed here)
     const int* sel_status;  // [n_envs][4] of explored_select_kernel: word 0 = contour scratch overflow
+    unsigned* walk_jd; int* walk_pixbase;  // parallel border follower, as in SelectScratch
+    int walk_states;
 };
 
 __device__ inline unsigned ring_all_set(const unsigned* plane, int S, int stride, int tid, int nth) {
@@ -804,7 +818,7 @@ __global__ __launch_bounds__(256) void frontier_prepare_kernel(const FogParams* 
     unexplored[eoff + idx] = nv & ~acc;
 }
 
-__global__ __launch_bounds__(256) void frontier_kernel(const FogParams* __restrict__ prm, MapPlanes mp, FrontierScratch sc,
+__global__ __launch_bounds__(1024) void frontier_kernel(const FogParams* __restrict__ prm, MapPlanes mp, FrontierScratch sc,
                                                        const int* __restrict__ bbox) {
     const FogParams& P = prm[blockIdx.x];
     if (P.n_poly <= 0) return;
@@ -870,10 +884,11 @@ __global__ __launch_bounds__(256) void frontier_kernel(const FogParams* __restri
             }
             // 64-bit sum through two 32-bit shared atomics is awkward; use a global-memory-free tree: wave shuffle + LDS
             for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
-            __shared__ long long wsum[4];
+            __shared__ long long wsum[16];
             if (lane == 0) wsum[wave] = part;
             __syncthreads();
-            const long long twice = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            long long twice = 0;
+            for (int w = 0; w < (nth + 63) / 64; w++) twice += wsum[w];
             const double area = fabs((double)twice * 0.5);
             if (!(area < sc.area_thresh)) { __syncthreads(); continue; }
             // mask = filled outline; keep it only if every covered cell is unexplored-navigable
@@ -934,22 +949,27 @@ __global__ __launch_bounds__(256) void frontier_kernel(const FogParams* __restri
         }
         __syncthreads();
         VLFM_PHASE(2, 3);
-        if (wave == 0) {
-            ContourSink sink;
-            sink.pts = pts; sink.start = cstart; sink.len = clen; sink.cap_pts = sc.cap_pts; sink.cap_contours = sc.cap_contours;
-            sink.n_pts = 0; sink.n_contours = 0; sink.overflow = 0;
-            if (in_lds) {
-                Bits b{L_img + pw + 1, pw, wrows, wwords * 32, 1};
-                scan_external(b, L_tr + pw + 1, L_ng + pw + 1, 0, wrows - 1, 1, sink);
-                VLFM_STAMP(2, 4);
-                const int npt = sink.n_pts < sc.cap_pts ? sink.n_pts : sc.cap_pts;
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                for (int i = lane; i < npt; i += 64) { int2 q = pts[i]; q.x += w_lo * 32; q.y += y_lo; pts[i] = q; }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            } else {
-                Bits b{ed, stride, S, S};
-                scan_external(b, traced, neg, y_lo, y_hi, 1, sink);
-            }
+        ContourSink sink;
+        sink.pts = pts; sink.start = cstart; sink.len = clen; sink.cap_pts = sc.cap_pts; sink.cap_contours = sc.cap_contours;
+        sink.n_pts = 0; sink.n_contours = 0; sink.overflow = 0;
+        if (in_lds) {   // the whole workgroup follows the border (border_parallel.h)
+            __shared__ int sh_wg[WG_SH_INTS];
+            Bits b{L_img + pw + 1, pw, wrows, wwords * 32, 1};
+            WalkTables T;
+            T.bmask = traced; T.wprefix = reinterpret_cast<int*>(neg);
+            T.next = reinterpret_cast<int*>(sc.fill_solid + eoff); T.sinfo = sc.fill_par + eoff;
+            T.jd0 = sc.walk_jd + (size_t)P.env * 2 * sc.walk_states; T.jd1 = T.jd0 + sc.walk_states;
+            T.pixbase = sc.walk_pixbase + (size_t)P.env * sc.cap_pts;
+            T.cap_bp = sc.cap_pts; T.cap_states = min(sc.walk_states, S * stride);
+            T.wrows = wrows; T.wwords = wwords;
+            wg_scan_external(b, L_tr + pw + 1, L_ng + pw + 1, 1, sink, T, sh_wg);
+            VLFM_STAMP(2, 4);
+            const int npt = sink.n_pts < sc.cap_pts ? sink.n_pts : sc.cap_pts;
+            for (int i = tid; i < npt; i += nth) { int2 q = pts[i]; q.x += w_lo * 32; q.y += y_lo; pts[i] = q; }
+            if (tid == 0) { sh_i[5] = sink.n_contours; sh_i[6] = sink.n_pts; sh_i[7] = sink.overflow; }
+        } else if (wave == 0) {
+            Bits b{ed, stride, S, S};
+            scan_external(b, traced, neg, y_lo, y_hi, 1, sink);
             if (lane == 0) { sh_i[5] = sink.n_contours; sh_i[6] = sink.n_pts; sh_i[7] = sink.overflow; }
         }
     }
@@ -1175,7 +1195,7 @@ constexpr unsigned kWalkLdsBytes = 144 * 1024;
 
 struct ScratchLayout {
     size_t plane_words, total;
-    size_t off_planes[6], off_pts, off_lines, off_starts, off_lens, off_bad, off_pieces, off_status;
+    size_t off_planes[6], off_pts, off_lines, off_starts, off_lens, off_bad, off_pieces, off_status, off_pixbase;
 };
 ScratchLayout layout(int n_envs, int S, int cap_pts, int cap_contours) {
     ScratchLayout L;
@@ -1191,6 +1211,7 @@ ScratchLayout layout(int n_envs, int S, int cap_pts, int cap_contours) {
     L.off_bad = take((size_t)n_envs * cap_pts);
     L.off_pieces = take((size_t)n_envs * cap_contours * 6 * 4);
     L.off_status = take((size_t)n_envs * 16 * 4);
+    L.off_pixbase = take((size_t)n_envs * cap_pts * 4);
     L.total = o;
     return L;
 }
@@ -1250,10 +1271,13 @@ extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, in
         if (!opt_select.ensure(reinterpret_cast<const void*>(explored_select_kernel), kWalkLdsBytes) ||
             !opt_frontier.ensure(reinterpret_cast<const void*>(frontier_kernel), kWalkLdsBytes))
             return fail(VLFM_ERR_HIP, "obstacle_map_update_batched: cannot opt in to 144 KB of LDS");
+        // the fog kernel's line list (cap_pts x int4 per environment) is free from here on: two pointer-jumping buffers of
+        // 2 * cap_pts words for the parallel border follower
         SelectScratch ss{planes[0], planes[1], planes[2], planes[3], pts, starts, lens, status + (size_t)n_envs * 4,
-                         cap_pts, cap_contours, kWalkLdsBytes};
+                         cap_pts, cap_contours, kWalkLdsBytes, (unsigned*)lines, (int*)(base + L.off_pixbase),
+                         2 * cap_pts > 65535 ? 65535 : 2 * cap_pts};
         VLFM_TIMED("explored_select_kernel", s);
-        VLFM_KLAUNCH(explored_select_kernel, dim3(n), dim3(256), kWalkLdsBytes, s, d_prm, mp, ss, (const int*)d_bbox);
+        VLFM_KLAUNCH(explored_select_kernel, dim3(n), dim3(1024), kWalkLdsBytes, s, d_prm, mp, ss, (const int*)d_bbox);
     }
     rc = check_launch("explored_select_kernel");
     if (rc != VLFM_OK) return rc;
@@ -1261,14 +1285,15 @@ extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, in
         FrontierScratch fr{planes[4], planes[5], planes[0], planes[1], planes[2], planes[3], pts, starts, lens,
                            (unsigned char*)(base + L.off_bad), (int*)(base + L.off_pieces), d_frontiers, d_counts,
                            cap_pts, cap_contours, cap_frontiers, area_thresh_px, kWalkLdsBytes, status,
-                           status + (size_t)n_envs * 4};
+                           status + (size_t)n_envs * 4, (unsigned*)lines, (int*)(base + L.off_pixbase),
+                           2 * cap_pts > 65535 ? 65535 : 2 * cap_pts};
         {
             VLFM_TIMED("frontier_prepare_kernel", s);
             VLFM_KLAUNCH(frontier_prepare_kernel, dim3((map_size * stride + 255) / 256, 1, n), dim3(256), 0, s, d_prm, mp,
                          planes[4], planes[5]);
         }
         VLFM_TIMED("frontier_kernel", s);
-        VLFM_KLAUNCH(frontier_kernel, dim3(n), dim3(256), kWalkLdsBytes, s, d_prm, mp, fr, (const int*)d_bbox);
+        VLFM_KLAUNCH(frontier_kernel, dim3(n), dim3(1024), kWalkLdsBytes, s, d_prm, mp, fr, (const int*)d_bbox);
     }
     return check_launch("frontier_kernel");
 }
