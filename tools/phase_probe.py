@@ -43,6 +43,11 @@ for k, nm in names.items():
     print(["fog_of_war", "explored_select", "frontier"][k], " ".join(f"{a}={acc[k, i] / n:.0f}us" for i, a in enumerate(nm)))
 print(f"border walks, all envs and scans: {walk[0] * 0.01 / n / E:.0f} us per env-step inside follow_border, "
       f"{walk[1] / n / E:.0f} emitted points, {walk[2] / n / E:.1f} contours per env-step")
+wc = np.zeros(16, np.int64); _lib.lib().vlfm_debug_parallel_walk_clocks(ctypes.c_void_p(wc.ctypes.data))
+dw = np.diff(wc[:8]) * 0.01
+print("parallel follower, last call of workgroup 0 (frontier kernel): " + " ".join(f"{nm}={v:.0f}us" for nm, v in zip(
+    ["count+scan", "ranks", "successors", "(scan/short walk)", "init", "ranking", "emit"], dw)),
+    f"| tables ok={wc[12]} states={wc[13]} border pixels={wc[14]}")
 print("frontier counts (frontiers, overflow, contours, chain points) env 0:", sim.obstacles.counts[0].tolist())
 st = np.zeros((E, 8), np.int32)
 ob = sim.obstacles

@@ -1302,6 +1302,9 @@ extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, in
 extern "C" int vlfm_debug_phase_clocks(long long* h_out /* [3][16] */) {
     return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(vlfm::g_phase_clock), sizeof(long long) * 48) == hipSuccess ? VLFM_OK : VLFM_ERR_HIP;
 }
+extern "C" int vlfm_debug_parallel_walk_clocks(long long* h_out16) {
+    return hipMemcpyFromSymbol(h_out16, HIP_SYMBOL(vlfm::g_walk_clk), sizeof(long long) * 16) == hipSuccess ? VLFM_OK : VLFM_ERR_HIP;
+}
 extern "C" int vlfm_debug_walk_stats(long long* h_out /* ticks, points, calls; reset afterwards */) {
     long long z = 0;
     if (hipMemcpyFromSymbol(&h_out[0], HIP_SYMBOL(vlfm::g_walk_ticks), 8) != hipSuccess) return VLFM_ERR_HIP;
