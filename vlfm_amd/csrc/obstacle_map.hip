@@ -368,7 +368,22 @@ struct FogScratch {         // per environment slices of global scratch
     int* status;            // [n_envs][4]: overflow flag, n obstacle contours, n lines, selected dist*1000
     int* bbox;              // [n_envs][4]: explored rows/cols touched so far (ymin, ymax, xmin, xmax)
     int cap_pts, cap_contours;
+    unsigned* walk[6];      // parallel border follower (border_parallel.h): six [n_envs][walk_words] planes the later kernels own
+    int* walk_pixbase;      // [n_envs][cap_pts]
+    int walk_words;
 };
+
+__device__ inline WalkTables fog_walk_tables(const FogScratch& sc, int env, int wrows, int wwords) {
+    WalkTables T;
+    const size_t o = (size_t)env * sc.walk_words;
+    T.bmask = sc.walk[0] + o; T.wprefix = reinterpret_cast<int*>(sc.walk[1] + o);
+    T.next = reinterpret_cast<int*>(sc.walk[2] + o); T.sinfo = sc.walk[3] + o;
+    T.jd0 = sc.walk[4] + o; T.jd1 = sc.walk[5] + o;
+    T.pixbase = sc.walk_pixbase + (size_t)env * sc.cap_pts;
+    T.cap_bp = sc.cap_pts; T.cap_states = sc.walk_words < 65535 ? sc.walk_words : 65535;
+    T.wrows = wrows; T.wwords = wwords;
+    return T;
+}
 
 // navigable = ~dilate(obstacles, k x k) (obstacle_map.py:105-109); explored &= navigable (obstacle_map.py:127 -- applied
 // ahead of this step's reveal, which only ever adds navigable cells, so the order is immaterial)
@@ -480,13 +495,15 @@ __global__ __launch_bounds__(1024) void fog_of_war_kernel(const FogParams* __res
         p_tr[i] = 0u; p_ng[i] = 0u;
     }
     __syncthreads();
-    if (wave == 0) {
+    __shared__ int sh_wg[WG_SH_INTS];
+    {
         ContourSink sink;
         sink.pts = pts; sink.start = cstart; sink.len = clen; sink.cap_pts = sc.cap_pts; sink.cap_contours = sc.cap_contours;
         sink.n_pts = 0; sink.n_contours = 0; sink.overflow = 0;
         Bits b{p_img + pw + 1, pw, wn, wn, 1};
-        scan_external(b, p_tr + pw + 1, p_ng + pw + 1, 0, wn - 1, 2, sink);
-        if (lane == 0) { sh_i[0] = sink.n_contours; sh_i[1] = sink.n_pts; sh_i[2] = sink.overflow; }
+        WalkTables T = fog_walk_tables(sc, P.env, wn, words);
+        wg_scan_external(b, p_tr + pw + 1, p_ng + pw + 1, 2, sink, T, sh_wg);   // the whole workgroup (border_parallel.h)
+        if (tid == 0) { sh_i[0] = sink.n_contours; sh_i[1] = sink.n_pts; sh_i[2] = sink.overflow; }
     }
     __threadfence_block();
     __syncthreads();
@@ -558,12 +575,15 @@ __global__ __launch_bounds__(1024) void fog_of_war_kernel(const FogParams* __res
         p_tr[i] = 0u; p_ng[i] = 0u;
     }
     __syncthreads();
-    if (wave == 0) {
-        ContourSink sink;
-        sink.pts = pts; sink.start = cstart; sink.len = clen; sink.cap_pts = sc.cap_pts; sink.cap_contours = sc.cap_contours;
-        sink.n_pts = 0; sink.n_contours = 0; sink.overflow = 0;
+    ContourSink sink;
+    sink.pts = pts; sink.start = cstart; sink.len = clen; sink.cap_pts = sc.cap_pts; sink.cap_contours = sc.cap_contours;
+    sink.n_pts = 0; sink.n_contours = 0; sink.overflow = 0;
+    {
         Bits b{p_img + pw + 1, pw, wn, wn, 1};
-        scan_external(b, p_tr + pw + 1, p_ng + pw + 1, 0, wn - 1, 2, sink);
+        WalkTables T = fog_walk_tables(sc, P.env, wn, words);
+        wg_scan_external(b, p_tr + pw + 1, p_ng + pw + 1, 2, sink, T, sh_wg);
+    }
+    if (wave == 0) {
         int best = -1;
         double best_d2 = 0;
         if (!sink.overflow) {
@@ -1254,7 +1274,9 @@ extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, in
     int rc = check_launch("navigable_kernel");
     if (rc != VLFM_OK || !explore) return rc;
     {
-        FogScratch fs{pts, starts, lens, lines, status, d_bbox, cap_pts, cap_contours};
+        FogScratch fs{pts, starts, lens, lines, status, d_bbox, cap_pts, cap_contours,
+                      {planes[0], planes[1], planes[2], planes[3], planes[4], planes[5]}, (int*)(base + L.off_pixbase),
+                      map_size * stride};
         const int wn = 2 * fog_radius + 5, words = (wn + 31) / 32;
         const size_t lds = (size_t)6 * wn * words * 4 + (size_t)3 * (wn + 2) * (words + 2) * 4 + 64;
         if (lds > 160 * 1024) return fail(VLFM_ERR_CAPACITY, "obstacle_map_update_batched: fog window too large for LDS");
