@@ -366,6 +366,15 @@ int vlfm_find_contours_external(const uint32_t* d_img, int planes, int rows, int
                                 uint32_t* d_scratch /* [2][planes][rows][stride] */, int32_t* d_pts, int cap_pts,
                                 int32_t* d_starts, int32_t* d_lens, int cap_contours, int32_t* d_counts, void* stream);
 
+/* The same result from ONE 1024-thread workgroup per plane (csrc/border_parallel.h: successor tables + list ranking on a padded
+ * LDS copy) -- the form the obstacle-map kernels use on their windows.  The plane must fit the LDS window
+ * (3 * (rows + 2) * (ceil(cols/32) + 2) * 4 <= 144 KB and rows * ceil(cols/32) <= 65535), else VLFM_ERR_CAPACITY.
+ * d_scratch: vlfm_find_contours_wg_scratch_bytes(...) bytes. */
+size_t vlfm_find_contours_wg_scratch_bytes(int planes, int rows, int cols, int cap_pts);
+int vlfm_find_contours_external_wg(const uint32_t* d_img, int planes, int rows, int cols, int method, void* d_scratch,
+                                   size_t scratch_bytes, int32_t* d_pts, int cap_pts, int32_t* d_starts, int32_t* d_lens,
+                                   int cap_contours, int32_t* d_counts, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * ObstacleMap.update_map, explore half (obstacle_map.py:105-169) for n environments.
  * ------------------------------------------------------------------------------------------- */

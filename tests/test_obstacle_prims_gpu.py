@@ -90,6 +90,93 @@ def test_find_contours_external_bit_exact(gpu_device, density, method):
             assert np.array_equal(g, w.reshape(-1, 2))
 
 
+def _gpu_contours_wg(img: np.ndarray, method: int, device, cap_p: int = 1 << 14):
+    """The workgroup-parallel border follower (csrc/border_parallel.h) through vlfm_find_contours_external_wg."""
+    planes, rows, cols = img.shape
+    bits = _pack(torch.from_numpy(img).to(device))
+    cap_c = 4096
+    nbytes = _lib.lib().vlfm_find_contours_wg_scratch_bytes(planes, rows, cols, cap_p)
+    assert nbytes > 0
+    scratch = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+    pts = torch.zeros((planes, cap_p, 2), dtype=torch.int32, device=device)
+    starts = torch.zeros((planes, cap_c), dtype=torch.int32, device=device)
+    lens = torch.zeros((planes, cap_c), dtype=torch.int32, device=device)
+    counts = torch.zeros((planes, 3), dtype=torch.int32, device=device)
+    _lib.check(_lib.lib().vlfm_find_contours_external_wg(bits.data_ptr(), planes, rows, cols, method, scratch.data_ptr(), nbytes,
+                                                        pts.data_ptr(), cap_p, starts.data_ptr(), lens.data_ptr(), cap_c,
+                                                        counts.data_ptr(), _stream()))
+    pts, starts, lens, counts = pts.cpu().numpy(), starts.cpu().numpy(), lens.cpu().numpy(), counts.cpu().numpy()
+    out = []
+    for p in range(planes):
+        assert counts[p, 2] == 0
+        cs = [pts[p, starts[p, k]:starts[p, k] + lens[p, k]] for k in range(counts[p, 0])]
+        out.append(cs[::-1])
+    return out
+
+
+def _structured_planes():
+    """Bitmaps that stress the state machine of the border follower: long ragged outlines with holes (the explored-area
+    shape), one-pixel spurs and diagonals (states that are entered and left through the same neighbour), checkerboards
+    (every pixel a border pixel with up to 4 diagonal neighbours), nested components, thick solids (interior successors)."""
+    from scipy import ndimage
+
+    rng = np.random.default_rng(11)
+    H, W = 240, 330
+    planes = []
+    blobs = ndimage.binary_dilation(rng.uniform(size=(H, W)) < 0.004, iterations=7)
+    holes = ndimage.binary_dilation(rng.uniform(size=(H, W)) < 0.002, iterations=3)
+    planes.append(blobs & ~holes)
+    cave = ndimage.binary_opening(rng.uniform(size=(H, W)) < 0.62, iterations=1)      # one sprawling component with many holes
+    planes.append(cave)
+    chk = (np.add.outer(np.arange(H), np.arange(W)) % 2 == 0)
+    chk[:, 110:] = False
+    chk[120:, :] = False
+    chk[60:120, 200:300] = True                                                         # a solid block beside the checkerboard
+    chk[80:100, 230:260] = False
+    chk[88:92, 240:250] = True
+    planes.append(chk)
+    lines = np.zeros((H, W), bool)
+    for k in range(0, 200, 7):
+        lines[k, 5:300 - k] = True                                                      # one-pixel horizontal spurs
+        lines[np.arange(5, 200), np.minimum(np.arange(5, 200) + k, W - 1)] = True       # diagonals crossing them
+    lines[10:230, 310] = True
+    planes.append(lines)
+    solid = np.zeros((H, W), bool)
+    solid[3:237, 3:327] = True                                                          # one big solid: long straight outline
+    solid[100:140, 100:230] = False
+    solid[110:130, 120:200] = True
+    planes.append(solid)
+    return np.stack(planes).astype(np.uint8)
+
+
+@pytest.mark.parametrize("method", [1, 2])
+def test_parallel_border_follower_equals_findcontours(gpu_device, method):
+    """Workgroup-parallel Suzuki-Abe (successor tables + list ranking) against cv2.findContours(RETR_EXTERNAL) restated in
+    oracle/cvport.c AND against the one-lane walk, on random noise of four densities and on structured bitmaps."""
+    from oracle import cv
+
+    for density in (0.02, 0.3, 0.55, 0.8):
+        rng = np.random.default_rng(int(density * 100) + method)
+        img = (rng.uniform(size=(3, 60, 90)) < density).astype(np.uint8)
+        got = _gpu_contours_wg(img, method, gpu_device)
+        serial = _gpu_contours(img, method, gpu_device)
+        for p in range(3):
+            want, _ = cv.findContours(img[p], cv.RETR_EXTERNAL, method)
+            assert len(got[p]) == len(want) == len(serial[p]), (density, p, len(got[p]), len(want))
+            for g, w, q in zip(got[p], want, serial[p]):
+                assert np.array_equal(g, w.reshape(-1, 2)) and np.array_equal(g, q)
+    img = _structured_planes()
+    got = _gpu_contours_wg(img, method, gpu_device, cap_p=1 << 15)
+    longest = 0
+    for p in range(img.shape[0]):
+        want, _ = cv.findContours(img[p], cv.RETR_EXTERNAL, method)
+        assert len(got[p]) == len(want), (p, len(got[p]), len(want))
+        for g, w in zip(got[p], want):
+            assert np.array_equal(g, w.reshape(-1, 2))
+            longest = max(longest, len(g))
+    assert longest > (500 if method == 1 else 100)   # the ranking path ran (borders closing within 16 steps are walked by one lane)
+
+
 def test_find_contours_map_sized(gpu_device):
     from oracle import cv
     from scipy import ndimage

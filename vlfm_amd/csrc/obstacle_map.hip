@@ -122,6 +122,51 @@ __global__ __launch_bounds__(64) void find_contours_kernel(const unsigned* __res
 }
 
 
+// The same scan by a whole workgroup (border_parallel.h) on a padded LDS copy of the plane: what fog_of_war / explored_select /
+// frontier do on their windows, exposed for images that fit (3 planes of (rows + 2) x (stride + 2) words in 144 KB) so that the
+// parallel follower can be checked against cv2.findContours on arbitrary bitmaps (tests/test_obstacle_prims_gpu.py).
+struct WgContourWork { unsigned* planes6; int* pixbase; int plane_words, cap_states; };
+__global__ __launch_bounds__(1024) void find_contours_wg_kernel(const unsigned* __restrict__ img, int rows, int cols, int stride,
+                                                                int method, WgContourWork wk, int2* __restrict__ pts, int cap_pts,
+                                                                int* __restrict__ starts, int* __restrict__ lens,
+                                                                int cap_contours, int* __restrict__ counts /* [planes][3] */) {
+    extern __shared__ __attribute__((aligned(16))) unsigned lds_win[];
+    __shared__ int sh_wg[WG_SH_INTS];
+    const size_t plane = blockIdx.x;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int pw = stride + 2, wn = (rows + 2) * pw;
+    unsigned* L_img = lds_win;
+    unsigned* L_tr = lds_win + wn;
+    unsigned* L_ng = lds_win + 2 * wn;
+    const unsigned* src = img + plane * rows * stride;
+    for (int i = tid; i < wn; i += nth) {
+        const int ly = i / pw - 1, lw = i % pw - 1;
+        const bool real = (unsigned)ly < (unsigned)rows && (unsigned)lw < (unsigned)stride;
+        unsigned w = real ? src[(size_t)ly * stride + lw] : 0u;
+        if (real && lw == stride - 1 && (cols & 31)) w &= (1u << (cols & 31)) - 1u;
+        L_img[i] = w; L_tr[i] = 0u; L_ng[i] = 0u;
+    }
+    __syncthreads();
+    ContourSink sink;
+    sink.pts = pts + plane * cap_pts; sink.start = starts + plane * cap_contours; sink.len = lens + plane * cap_contours;
+    sink.cap_pts = cap_pts; sink.cap_contours = cap_contours; sink.n_pts = 0; sink.n_contours = 0; sink.overflow = 0;
+    Bits b{L_img + pw + 1, pw, rows, stride * 32, 1};
+    WalkTables T;
+    unsigned* base = wk.planes6 + plane * 6 * (size_t)wk.plane_words;
+    T.bmask = base; T.wprefix = reinterpret_cast<int*>(base + wk.plane_words);
+    T.next = reinterpret_cast<int*>(base + 2 * (size_t)wk.plane_words); T.sinfo = base + 3 * (size_t)wk.plane_words;
+    T.jd0 = base + 4 * (size_t)wk.plane_words; T.jd1 = base + 5 * (size_t)wk.plane_words;
+    T.pixbase = wk.pixbase + plane * cap_pts;
+    T.cap_bp = cap_pts; T.cap_states = wk.cap_states;
+    T.wrows = rows; T.wwords = stride;
+    wg_scan_external(b, L_tr + pw + 1, L_ng + pw + 1, method, sink, T, sh_wg);
+    if (tid == 0) {
+        counts[plane * 3 + 0] = sink.n_contours;
+        counts[plane * 3 + 1] = sink.n_pts;
+        counts[plane * 3 + 2] = sink.overflow;
+    }
+}
+
 // Optional phase timing (compile with -DVLFM_PHASE_TIMING; tools/phase_probe.py): workgroup 0's thread 0 stamps the
 // constant-rate 100 MHz counter at phase boundaries.  Zero cost when the macro is not defined.
 #ifdef VLFM_PHASE_TIMING
@@ -1205,6 +1250,42 @@ extern "C" int vlfm_find_contours_external(const uint32_t* d_img, int planes, in
                        cols, stride, method, reinterpret_cast<int2*>(d_pts), cap_pts, d_starts, d_lens, cap_contours,
                        d_counts);
     return check_launch("find_contours_kernel");
+}
+
+extern "C" size_t vlfm_find_contours_wg_scratch_bytes(int planes, int rows, int cols, int cap_pts) {
+    if (planes <= 0 || rows <= 0 || cols <= 0 || cap_pts <= 0) return 0;
+    const size_t stride = (cols + 31) / 32;
+    size_t plane_words = (size_t)rows * stride;
+    if (plane_words < (size_t)2 * cap_pts) plane_words = (size_t)2 * cap_pts;   // room for the states (~5 per border pixel at most 8)
+    if (plane_words > 65535) plane_words = 65535;
+    if (plane_words < (size_t)rows * stride) return 0;                           // image too large for 16-bit state ids
+    return (size_t)planes * (6 * plane_words + (size_t)cap_pts) * 4;
+}
+
+extern "C" int vlfm_find_contours_external_wg(const uint32_t* d_img, int planes, int rows, int cols, int method,
+                                              void* d_scratch, size_t scratch_bytes, int32_t* d_pts, int cap_pts,
+                                              int32_t* d_starts, int32_t* d_lens, int cap_contours, int32_t* d_counts,
+                                              void* stream) {
+    if (!d_img || !d_scratch || !d_pts || !d_starts || !d_lens || !d_counts || planes <= 0 || rows <= 0 || cols <= 0 ||
+        (method != 1 && method != 2) || cols > 2048)
+        return fail(VLFM_ERR_INVALID, "find_contours_external_wg: bad argument (method 1|2, cols <= 2048)");
+    const int stride = (cols + 31) / 32;
+    const size_t lds = (size_t)3 * (rows + 2) * (stride + 2) * 4;
+    const size_t need = vlfm_find_contours_wg_scratch_bytes(planes, rows, cols, cap_pts);
+    if (lds > 144 * 1024 || need == 0) return fail(VLFM_ERR_CAPACITY, "find_contours_external_wg: the image does not fit the LDS window");
+    if (scratch_bytes < need) return fail(VLFM_ERR_CAPACITY, "find_contours_external_wg: scratch too small");
+    static LdsOptIn opt;
+    if (!opt.ensure(reinterpret_cast<const void*>(find_contours_wg_kernel), 144 * 1024))
+        return fail(VLFM_ERR_HIP, "find_contours_external_wg: cannot opt in to 144 KB of LDS");
+    size_t plane_words = (size_t)rows * stride;
+    if (plane_words < (size_t)2 * cap_pts) plane_words = (size_t)2 * cap_pts;
+    if (plane_words > 65535) plane_words = 65535;
+    WgContourWork wk{(unsigned*)d_scratch, (int*)((unsigned*)d_scratch + (size_t)planes * 6 * plane_words), (int)plane_words,
+                     (int)plane_words};
+    VLFM_TIMED("find_contours_wg_kernel", stream);
+    VLFM_KLAUNCH(find_contours_wg_kernel, dim3(planes), dim3(1024), lds, (hipStream_t)stream, d_img, rows, cols, stride, method, wk,
+                 reinterpret_cast<int2*>(d_pts), cap_pts, d_starts, d_lens, cap_contours, d_counts);
+    return check_launch("find_contours_wg_kernel");
 }
 
 // ---------------------------------------------------------------------------------------------------------------
