@@ -14,7 +14,7 @@
 //   3. points, the CHAIN_APPROX_SIMPLE filter (a state emits iff its outgoing direction differs from the one it was entered
 //      with, which is s_back ^ 4: local) and the +/- labels are written by all lanes at once.
 // Identical output to follow_border (same points, same order, same labels): the golden fixtures and property tests of
-// tests/ do not distinguish the two.  Borders that close within a few dozen steps are still walked by one lane (cheaper than
+// tests/ do not distinguish the two.  Borders that close within WG_SERIAL_STEPS steps are still walked by one lane (cheaper than
 // a ranking), and any situation the tables cannot express (capacity, a successor that is not a border pixel) falls back to it.
 #pragma once
 #include "bitmap.h"
@@ -66,6 +66,9 @@ struct WalkTables {          // per-environment global scratch (L2-resident: a f
 };
 
 constexpr int WG_SH_INTS = 48;   // shared scratch the functions below need (ints)
+// Borders that close within this many steps are walked by one lane (specks, single pixels); measured at 256 envs: 16 beats 64
+// (fog of war 0.62 vs 0.71 ms) although a ranking costs ~60 us whatever the border's length.
+constexpr int WG_SERIAL_STEPS = 16;
 
 // exclusive prefix sums of two ints over the workgroup (<= 16 wavefronts); sh: 32 ints
 __device__ inline void wg_scan2(int a, int b, int* sh, int& a_ex, int& b_ex, int& a_tot, int& b_tot) {
@@ -257,7 +260,7 @@ __device__ inline int wg_follow_border(const Bits& img, const WalkTables& T, uns
     const unsigned* base = img.w;
     const int pw = img.stride;
     if (tid == 0) {
-        int n = follow_border_short(img, traced, neg, x0, y0, method, out, cap, 16);
+        int n = follow_border_short(img, traced, neg, x0, y0, method, out, cap, WG_SERIAL_STEPS);
         sh[33] = n;
         if (n < 0) {
             const unsigned nb = nbr8_padded(base, pw, x0, y0);
