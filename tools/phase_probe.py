@@ -25,7 +25,10 @@ from vlfm_amd.harness import BatchedEpisodes
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 sim = BatchedEpisodes(E, device=torch.device("cuda:0"), use_blip2=False, overlap=False)
 sim.fast_forward(int(sys.argv[2]) if len(sys.argv) > 2 else 150)
+BLOCK = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+_lib.lib().vlfm_debug_phase_block(BLOCK)
 acc = np.zeros((3, 16)); n = 0
+spans = np.zeros((3, 1024))
 walk = np.zeros(3)
 w0 = np.zeros(3, np.int64); _lib.lib().vlfm_debug_walk_stats(ctypes.c_void_p(w0.ctypes.data))  # reset
 for _ in range(20):
@@ -35,12 +38,17 @@ for _ in range(20):
     d = np.diff(buf, axis=1) * 0.01   # 100 MHz ticks -> us
     d[(d < 0) | (d > 1e5)] = 0
     acc[:, :15] += d; n += 1
+    f1 = np.zeros((3, 1024), np.int64); l1 = np.zeros((3, 1024), np.int64)
+    _lib.lib().vlfm_debug_wg_spans(ctypes.c_void_p(f1.ctypes.data), ctypes.c_void_p(l1.ctypes.data)); spans += (l1 - f1) * 0.01
     w = np.zeros(3, np.int64); _lib.lib().vlfm_debug_walk_stats(ctypes.c_void_p(w.ctypes.data)); walk += w
 names = {0: ["cone raster", "window+masks", "obst contours", "shadow pts", "cut lines", "visible contours+pick", "fill", "dilate+OR"],
          1: ["window copy", "scan+walk", "offset+pick", "publish"],
          2: ["dilate5 full planes", "small-unexplored filter", "window copy", "scan+walk", "offset", "bad flags", "pieces", "midpoints"]}
 for k, nm in names.items():
     print(["fog_of_war", "explored_select", "frontier"][k], " ".join(f"{a}={acc[k, i] / n:.0f}us" for i, a in enumerate(nm)))
+for k, nm in enumerate(["fog_of_war", "explored_select", "frontier"]):
+    sp = spans[k, :E] / n
+    print(f"{nm}: first-to-last stamp per workgroup: block {BLOCK} {sp[BLOCK]:.0f} us, mean {sp.mean():.0f} us, slowest block {int(sp.argmax())} {sp.max():.0f} us")
 print(f"border walks, all envs and scans: {walk[0] * 0.01 / n / E:.0f} us per env-step inside follow_border, "
       f"{walk[1] / n / E:.0f} emitted points, {walk[2] / n / E:.1f} contours per env-step")
 wc = np.zeros(16, np.int64); _lib.lib().vlfm_debug_parallel_walk_clocks(ctypes.c_void_p(wc.ctypes.data))

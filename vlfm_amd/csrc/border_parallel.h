@@ -22,10 +22,11 @@
 namespace vlfm {
 
 #ifdef VLFM_PHASE_TIMING
-__device__ long long g_walk_clk[16];   // workgroup 0's stamps inside the parallel follower (the last call wins)
+__device__ long long g_walk_clk[16];   // one workgroup's stamps inside the parallel follower (the last call wins)
+__device__ int g_walk_block;
 #define WALK_STAMP(k)                                                                              \
     do {                                                                                           \
-        if (blockIdx.x == 0 && threadIdx.x == 0) g_walk_clk[k] = wall_clock64();                   \
+        if ((int)blockIdx.x == g_walk_block && threadIdx.x == 0) g_walk_clk[k] = wall_clock64();     \
     } while (0)
 #else
 #define WALK_STAMP(k) do {} while (0)
@@ -60,6 +61,9 @@ struct WalkTables {          // per-environment global scratch (L2-resident: a f
     unsigned* sinfo;         // [cap_states]      x | y << 11 | s_back << 22 | s_out << 25
     unsigned* jd0;           // [cap_states]      pointer-jumping buffers: dist << 16 | jump
     unsigned* jd1;
+    unsigned* ljd0 = nullptr;   // optional LDS copies of the two buffers for images with at most lds_states states (a round then
+    unsigned* ljd1 = nullptr;   // costs an LDS round trip instead of an L2 one: the fog-of-war windows)
+    int lds_states = 0;
     int cap_bp, cap_states;  // cap_states <= 65535
     int wrows, wwords;
     int n_states = 0, ok = 0;   // results of wg_build_walk_tables (uniform)
@@ -201,7 +205,7 @@ __device__ inline void wg_build_walk_tables(const Bits& img, unsigned* lt, unsig
     __syncthreads();
     WALK_STAMP(3);
 #ifdef VLFM_PHASE_TIMING
-    if (blockIdx.x == 0 && threadIdx.x == 0) { g_walk_clk[12] = T.ok; g_walk_clk[13] = T.n_states; g_walk_clk[14] = nb_tot; }
+    if ((int)blockIdx.x == g_walk_block && threadIdx.x == 0) { g_walk_clk[12] = T.ok; g_walk_clk[13] = T.n_states; g_walk_clk[14] = nb_tot; }
 #endif
 }
 
@@ -282,8 +286,8 @@ __device__ inline int wg_follow_border(const Bits& img, const WalkTables& T, uns
     __syncthreads();
     WALK_STAMP(4);
     // ---- list ranking: after the last round jump == id0 exactly for the states on state0's cycle, dist = steps to reach it
-    unsigned* A = T.jd0;
-    unsigned* B = T.jd1;
+    unsigned* A = N <= T.lds_states ? T.ljd0 : T.jd0;
+    unsigned* B = N <= T.lds_states ? T.ljd1 : T.jd1;
     for (int i = tid; i < N; i += nth) A[i] = i == id0 ? (unsigned)id0 : ((1u << 16) | (unsigned)T.next[i]);
     wg_sync_global();
     WALK_STAMP(5);

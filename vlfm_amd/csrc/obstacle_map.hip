@@ -171,15 +171,22 @@ __global__ __launch_bounds__(1024) void find_contours_wg_kernel(const unsigned* 
 // constant-rate 100 MHz counter at phase boundaries.  Zero cost when the macro is not defined.
 #ifdef VLFM_PHASE_TIMING
 __device__ long long g_phase_clock[3][16];
+__device__ int g_phase_block;              // the workgroup that stamps (vlfm_debug_phase_block)
+__device__ long long g_wg_first[3][1024];  // every workgroup's first and last stamp: which environment is the slow one?
+__device__ long long g_wg_last[3][1024];
 #define VLFM_PHASE(kernel_id, k)                                                                  \
     do {                                                                                          \
         __syncthreads();                                                                          \
-        if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_clock[kernel_id][k] = wall_clock64();    \
+        if (threadIdx.x == 0) {                                                                   \
+            const long long t_ = wall_clock64();                                                  \
+            if ((int)blockIdx.x == g_phase_block) g_phase_clock[kernel_id][k] = t_;               \
+            if (blockIdx.x < 1024) { if ((k) == 0) g_wg_first[kernel_id][blockIdx.x] = t_; g_wg_last[kernel_id][blockIdx.x] = t_; } \
+        }                                                                                         \
     } while (0)
 // the same without the barrier, for a stamp inside single-wavefront code
 #define VLFM_STAMP(kernel_id, k)                                                                  \
     do {                                                                                          \
-        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_phase_clock[kernel_id][k] = wall_clock64(); \
+        if ((int)blockIdx.x == g_phase_block && (threadIdx.x & 63) == 0) g_phase_clock[kernel_id][k] = wall_clock64(); \
     } while (0)
 #else
 #define VLFM_PHASE(kernel_id, k) do {} while (0)
@@ -416,6 +423,7 @@ struct FogScratch {         // per environment slices of global scratch
     unsigned* walk[6];      // parallel border follower (border_parallel.h): six [n_envs][walk_words] planes the later kernels own
     int* walk_pixbase;      // [n_envs][cap_pts]
     int walk_words;
+    int lds_states;         // states whose list ranking fits the kernel's LDS (2 words each)
 };
 
 __device__ inline WalkTables fog_walk_tables(const FogScratch& sc, int env, int wrows, int wwords) {
@@ -427,6 +435,7 @@ __device__ inline WalkTables fog_walk_tables(const FogScratch& sc, int env, int 
     T.pixbase = sc.walk_pixbase + (size_t)env * sc.cap_pts;
     T.cap_bp = sc.cap_pts; T.cap_states = sc.walk_words < 65535 ? sc.walk_words : 65535;
     T.wrows = wrows; T.wwords = wwords;
+    T.lds_states = sc.lds_states;
     return T;
 }
 
@@ -489,7 +498,8 @@ __global__ __launch_bounds__(1024) void fog_of_war_kernel(const FogParams* __res
     unsigned* p_img = fill + plane_words;
     unsigned* p_tr = p_img + pad_words;
     unsigned* p_ng = p_tr + pad_words;
-    int* sh_i = reinterpret_cast<int*>(p_ng + pad_words);  // small shared ints
+    int* sh_i = reinterpret_cast<int*>(p_ng + pad_words);  // small shared ints (16)
+    unsigned* l_jd = reinterpret_cast<unsigned*>(sh_i + 16);   // 2 x sc.lds_states words: list-ranking buffers of the border follower
     const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wave = tid >> 6;
     const size_t eoff = (size_t)P.env * S * mp.stride;
     const unsigned last_mask = (wn & 31) ? ((1u << (wn & 31)) - 1u) : 0xFFFFFFFFu;
@@ -547,6 +557,7 @@ __global__ __launch_bounds__(1024) void fog_of_war_kernel(const FogParams* __res
         sink.n_pts = 0; sink.n_contours = 0; sink.overflow = 0;
         Bits b{p_img + pw + 1, pw, wn, wn, 1};
         WalkTables T = fog_walk_tables(sc, P.env, wn, words);
+        T.ljd0 = l_jd; T.ljd1 = l_jd + sc.lds_states;
         wg_scan_external(b, p_tr + pw + 1, p_ng + pw + 1, 2, sink, T, sh_wg);   // the whole workgroup (border_parallel.h)
         if (tid == 0) { sh_i[0] = sink.n_contours; sh_i[1] = sink.n_pts; sh_i[2] = sink.overflow; }
     }
@@ -626,6 +637,7 @@ __global__ __launch_bounds__(1024) void fog_of_war_kernel(const FogParams* __res
     {
         Bits b{p_img + pw + 1, pw, wn, wn, 1};
         WalkTables T = fog_walk_tables(sc, P.env, wn, words);
+        T.ljd0 = l_jd; T.ljd1 = l_jd + sc.lds_states;
         wg_scan_external(b, p_tr + pw + 1, p_ng + pw + 1, 2, sink, T, sh_wg);
     }
     if (wave == 0) {
@@ -1357,10 +1369,15 @@ extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, in
     {
         FogScratch fs{pts, starts, lens, lines, status, d_bbox, cap_pts, cap_contours,
                       {planes[0], planes[1], planes[2], planes[3], planes[4], planes[5]}, (int*)(base + L.off_pixbase),
-                      map_size * stride};
+                      map_size * stride, 0};
         const int wn = 2 * fog_radius + 5, words = (wn + 31) / 32;
-        const size_t lds = (size_t)6 * wn * words * 4 + (size_t)3 * (wn + 2) * (words + 2) * 4 + 64;
+        size_t lds = (size_t)6 * wn * words * 4 + (size_t)3 * (wn + 2) * (words + 2) * 4 + 64;
         if (lds > 160 * 1024) return fail(VLFM_ERR_CAPACITY, "obstacle_map_update_batched: fog window too large for LDS");
+        // what is left of 152 KB holds the border follower's list-ranking buffers (two words per state; a window of 205 x 205
+        // cells has a few thousand states): a ranking round is then an LDS round trip instead of an L2 one
+        fs.lds_states = (int)((152 * 1024 - lds) / 8);
+        if (fs.lds_states > 16384) fs.lds_states = 16384;
+        lds += (size_t)fs.lds_states * 8;
         if (lds > 64 * 1024)  // beyond the default dynamic-LDS limit (max_depth * pixels_per_meter > ~110 cells)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fog_of_war_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1404,6 +1421,14 @@ extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, in
 #ifdef VLFM_PHASE_TIMING
 extern "C" int vlfm_debug_phase_clocks(long long* h_out /* [3][16] */) {
     return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(vlfm::g_phase_clock), sizeof(long long) * 48) == hipSuccess ? VLFM_OK : VLFM_ERR_HIP;
+}
+extern "C" int vlfm_debug_phase_block(int block) {
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(vlfm::g_walk_block), &block, sizeof(int));
+    return hipMemcpyToSymbol(HIP_SYMBOL(vlfm::g_phase_block), &block, sizeof(int)) == hipSuccess ? VLFM_OK : VLFM_ERR_HIP;
+}
+extern "C" int vlfm_debug_wg_spans(long long* h_first /* [3][1024] */, long long* h_last) {
+    if (hipMemcpyFromSymbol(h_first, HIP_SYMBOL(vlfm::g_wg_first), sizeof(long long) * 3 * 1024) != hipSuccess) return VLFM_ERR_HIP;
+    return hipMemcpyFromSymbol(h_last, HIP_SYMBOL(vlfm::g_wg_last), sizeof(long long) * 3 * 1024) == hipSuccess ? VLFM_OK : VLFM_ERR_HIP;
 }
 extern "C" int vlfm_debug_parallel_walk_clocks(long long* h_out16) {
     return hipMemcpyFromSymbol(h_out16, HIP_SYMBOL(vlfm::g_walk_clk), sizeof(long long) * 16) == hipSuccess ? VLFM_OK : VLFM_ERR_HIP;
