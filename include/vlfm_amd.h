@@ -328,6 +328,13 @@ int vlfm_ms_deform_attn(const float* d_value, const int32_t* d_spatial_shapes, c
                         const float* d_sampling_loc, const float* d_attn_weight, int batch, int n_query, int n_heads,
                         int head_dim, int n_levels, int n_points, int total_len, float* d_out, void* stream);
 
+/* Device: depthwise 3x3 convolution, padding 1, stride 1 or 2, NCHW f32: y = conv(x, w[C][1][3][3]) + bias[C] (NULL = none),
+ * followed by the exact (erf) GELU when gelu != 0.  The depthwise convolutions of MobileSAM's TinyViT encoder behind
+ * vlfm/vlm/sam.py:54 (MBConv conv2, local_conv, patch merging), with their folded BatchNorm as the bias.  width and the
+ * output width must be multiples of 4. */
+int vlfm_dwconv3x3_f32(const float* d_x, const float* d_w, const float* d_bias, float* d_y, int n, int channels, int height,
+                       int width, int stride, int gelu, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * ObjectPointCloudMap._extract_object_cloud (vlfm/mapping/object_point_cloud_map.py:150-170,186-212)
  * ------------------------------------------------------------------------------------------- */

@@ -260,3 +260,27 @@ def test_mobile_sam_loads_a_checkpoint_and_matches_the_oracle(gpu_device, tmp_pa
     assert got.shape == want.shape == (480, 640)
     assert (got != want).mean() <= 2e-3, (got != want).mean()    # fp32 on both sides; only logits within ~1e-4 of 0 may flip
     assert 0.02 < want.mean() < 0.98
+
+
+@pytest.mark.parametrize("case", [(2, 16, 32, 32, 1), (2, 16, 32, 32, 2), (1, 8, 64, 128, 1), (3, 5, 24, 40, 2), (1, 4, 12, 1024, 1)])
+def test_depthwise_conv3x3_kernel(gpu_device, case):
+    """vlfm_dwconv3x3_f32 (TinyViT's depthwise convolutions) against F.conv2d evaluated in float64: borders, both strides,
+    with and without bias and the fused exact GELU."""
+    import torch.nn.functional as F
+
+    from vlfm_amd.vlm import ops
+
+    n, c, h, w, stride = case
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(n, c, h, w, generator=g)
+    wt = torch.randn(c, 1, 3, 3, generator=g) * 0.3
+    b = torch.randn(c, generator=g)
+    for bias in (b, None):
+        for gelu in (False, True):
+            want = F.conv2d(x.double(), wt.double(), None if bias is None else bias.double(), stride, 1, 1, c)
+            if gelu:
+                want = F.gelu(want)
+            got = ops.depthwise_conv3x3(x.to(gpu_device), wt.to(gpu_device), None if bias is None else bias.to(gpu_device),
+                                        stride, gelu).cpu()
+            assert got.shape == want.shape
+            assert torch.allclose(got.double(), want, atol=2e-6, rtol=2e-6), float((got.double() - want).abs().max())

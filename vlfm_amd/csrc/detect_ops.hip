@@ -280,6 +280,67 @@ __global__ __launch_bounds__(256) void ms_deform_attn_kernel(const float* __rest
     }
     out[gid] = acc;
 }
+
+// ------------------------------------------------------------------------------------------------ depthwise 3x3 convolution
+// MobileSAM's TinyViT (behind vlfm/vlm/sam.py:54, SamPredictor.set_image [ext mobile_sam]) is full of depthwise 3x3 convolutions
+// in f32 -- MBConv's conv2 on a [B, 256, 256, 256] activation (2.1 GB at 32 frames), the local_conv of every attention block,
+// the patch-merging convs -- and MIOpen serves them with its naive fallback (2.2 TFLOP/s: 4.4 ms for the big one, 13 ms of the
+// 128-env full step, tools/conv_probe.py).  The op is memory-bound (18 flops per 8 bytes): one thread per 4 consecutive outputs,
+// 16-byte loads and stores, the three input rows of a quad come from L1 when the neighbouring row lanes fetched them, bias (the
+// folded BatchNorm) and the exact GELU that follows conv2 applied in registers.  NCHW, padding 1, stride 1 or 2.
+template <int STRIDE, bool GELU>
+__global__ __launch_bounds__(256) void dwconv3x3_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ y, int C, int H,
+                                                            int W, int HO, int WO, int rows_per_block) {
+    const int Q = WO >> 2;                       // output quads per row
+    const int tq = threadIdx.x % Q, ty = threadIdx.x / Q, RL = blockDim.x / Q;
+    if (ty >= RL) return;
+    const size_t plane = blockIdx.y;             // n * C + c
+    const int c = (int)(plane % C);
+    const float* xp = x + plane * H * W;
+    float* yp = y + plane * HO * WO;
+    float k[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) k[i] = w[c * 9 + i];
+    const float b = bias ? bias[c] : 0.0f;
+    const int y_end = min(HO, (int)(blockIdx.x + 1) * rows_per_block);
+    for (int yo = blockIdx.x * rows_per_block + ty; yo < y_end; yo += RL) {
+        float4 acc = make_float4(b, b, b, b);
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++) {
+            const int yi = yo * STRIDE + dy - 1;
+            if ((unsigned)yi >= (unsigned)H) continue;
+            const float* row = xp + (size_t)yi * W;
+            const float k0 = k[3 * dy], k1 = k[3 * dy + 1], k2 = k[3 * dy + 2];
+            if (STRIDE == 1) {
+                const int x0 = 4 * tq;
+                const float4 v = *reinterpret_cast<const float4*>(row + x0);
+                const float l = x0 > 0 ? row[x0 - 1] : 0.0f, r = x0 + 4 < W ? row[x0 + 4] : 0.0f;
+                acc.x += k0 * l + k1 * v.x + k2 * v.y;
+                acc.y += k0 * v.x + k1 * v.y + k2 * v.z;
+                acc.z += k0 * v.y + k1 * v.z + k2 * v.w;
+                acc.w += k0 * v.z + k1 * v.w + k2 * r;
+            } else {
+                const int x0 = 8 * tq;
+                const float4 v = *reinterpret_cast<const float4*>(row + x0);
+                const float4 u = *reinterpret_cast<const float4*>(row + x0 + 4);
+                const float l = x0 > 0 ? row[x0 - 1] : 0.0f;
+                acc.x += k0 * l + k1 * v.x + k2 * v.y;
+                acc.y += k0 * v.y + k1 * v.z + k2 * v.w;
+                acc.z += k0 * v.w + k1 * u.x + k2 * u.y;
+                acc.w += k0 * u.y + k1 * u.z + k2 * u.w;
+            }
+        }
+        if (GELU) {
+            acc.x = 0.5f * acc.x * (1.0f + erff(acc.x * 0.70710678118654752440f));
+            acc.y = 0.5f * acc.y * (1.0f + erff(acc.y * 0.70710678118654752440f));
+            acc.z = 0.5f * acc.z * (1.0f + erff(acc.z * 0.70710678118654752440f));
+            acc.w = 0.5f * acc.w * (1.0f + erff(acc.w * 0.70710678118654752440f));
+        }
+        *reinterpret_cast<float4*>(yp + (size_t)yo * WO + 4 * tq) = acc;
+    }
+}
+
 }  // namespace vlfm
 
 extern "C" int vlfm_ms_deform_attn(const float* d_value, const int32_t* d_spatial_shapes, const int32_t* d_level_start,
@@ -296,4 +357,29 @@ extern "C" int vlfm_ms_deform_attn(const float* d_value, const int32_t* d_spatia
                  d_spatial_shapes, d_level_start, d_sampling_loc, d_attn_weight, batch, n_query, n_heads, head_dim, n_levels,
                  n_points, total_len, d_out);
     return check_launch("ms_deform_attn_kernel");
+}
+
+extern "C" int vlfm_dwconv3x3_f32(const float* d_x, const float* d_w, const float* d_bias, float* d_y, int n, int channels,
+                                  int height, int width, int stride, int gelu, void* stream) {
+    if (n == 0) return VLFM_OK;
+    const int ho = (height + 2 - 3) / (stride > 0 ? stride : 1) + 1, wo = (width + 2 - 3) / (stride > 0 ? stride : 1) + 1;
+    if (!d_x || !d_w || !d_y || n < 0 || channels <= 0 || height <= 0 || width <= 0 || (stride != 1 && stride != 2) ||
+        (width & 3) || (wo & 3) || wo > 1024 || (stride == 2 && width != 2 * wo))
+        return fail(VLFM_ERR_INVALID, "dwconv3x3_f32: stride 1 or 2, width and output width multiples of 4 (<= 1024 outputs per row)");
+    const int q = wo / 4, rl = 256 / q > 0 ? 256 / q : 1;
+    const int threads = q * rl;
+    int rows_per_block = rl * 8;
+    if (rows_per_block > ho) rows_per_block = (ho + rl - 1) / rl * rl;
+    const dim3 grid((ho + rows_per_block - 1) / rows_per_block, (unsigned)n * channels), block(threads);
+    if (grid.y > 65535u * 16u) return fail(VLFM_ERR_CAPACITY, "dwconv3x3_f32: too many planes");
+    VLFM_TIMED("dwconv3x3_f32_kernel", stream);
+    hipStream_t s = (hipStream_t)stream;
+    if (stride == 1) {
+        if (gelu) VLFM_KLAUNCH((vlfm::dwconv3x3_f32_kernel<1, true>), grid, block, 0, s, d_x, d_w, d_bias, d_y, channels, height, width, ho, wo, rows_per_block);
+        else VLFM_KLAUNCH((vlfm::dwconv3x3_f32_kernel<1, false>), grid, block, 0, s, d_x, d_w, d_bias, d_y, channels, height, width, ho, wo, rows_per_block);
+    } else {
+        if (gelu) VLFM_KLAUNCH((vlfm::dwconv3x3_f32_kernel<2, true>), grid, block, 0, s, d_x, d_w, d_bias, d_y, channels, height, width, ho, wo, rows_per_block);
+        else VLFM_KLAUNCH((vlfm::dwconv3x3_f32_kernel<2, false>), grid, block, 0, s, d_x, d_w, d_bias, d_y, channels, height, width, ho, wo, rows_per_block);
+    }
+    return check_launch("dwconv3x3_f32_kernel");
 }

@@ -127,6 +127,19 @@ def layernorm_bias(x: torch.Tensor, channel_bias, weight: torch.Tensor, bias: to
     return y
 
 
+def depthwise_conv3x3(x: torch.Tensor, weight: torch.Tensor, bias, stride: int = 1, gelu: bool = False) -> torch.Tensor:
+    """Depthwise 3x3 convolution (padding 1, stride 1 or 2) of an NCHW f32 tensor, + bias, + exact GELU: the HIP kernel behind
+    TinyViT's depthwise convolutions (csrc/detect_ops.hip).  weight [C,1,3,3]."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+    n, c, h, w = x.shape
+    assert weight.shape == (c, 1, 3, 3) and weight.dtype == torch.float32 and weight.is_contiguous()
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    y = torch.empty((n, c, ho, wo), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().vlfm_dwconv3x3_f32(x.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                             y.data_ptr(), n, c, h, w, int(stride), int(gelu), _stream()), "dwconv3x3_f32")
+    return y
+
+
 def linear_gelu(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
     """gelu(x @ weight.T + bias), exact (erf) form, f16 in / f16 out with f32 accumulation: the hand-written MFMA GEMM of
     csrc/gemm_f16.hip with the activation in its epilogue (hipBLASLt only fuses the tanh approximation, so the library path

@@ -186,6 +186,7 @@ class YOLOv7:
                 self.model = YoloV7E6EClassNet(width=width)
             self.model.eval()
             self.weights = "random-init (E6E-class stand-in)"
+            det_ops.fold_batchnorm_(self.model)   # as yolov7's fuse() does before tracing / deployment
             g = conv_gflops(self.model, torch.zeros((1, 3) + self.in_hw, device=self.device))
             self.description = (f"random-init E6E-class stand-in, width {width}: {g:.1f} conv GFLOPs per {self.in_hw[1]}x"
                                 f"{self.in_hw[0]} frame (published YOLOv7-E6E: {E6E_PUBLISHED['gflops_at_1280x1280']} GFLOPs at "
