@@ -335,6 +335,11 @@ int vlfm_ms_deform_attn(const float* d_value, const int32_t* d_spatial_shapes, c
 int vlfm_dwconv3x3_f32(const float* d_x, const float* d_w, const float* d_bias, float* d_y, int n, int channels, int height,
                        int width, int stride, int gelu, void* stream);
 
+/* Device, in place: y[n][c][:] = act(y[n][c][:] + bias[c]) on an NCHW tensor of hw elements per plane; dtype 0 = f32, 1 = f16
+ * (bias has the tensor's type); act 0 = none, 1 = exact (erf) GELU, 2 = SiLU.  The bias + activation behind every convolution
+ * of the detector / MobileSAM encoders once their BatchNorm is folded into the weights (yolov7.py:70-99, sam.py:54). */
+int vlfm_bias_act_nchw(void* d_y, const void* d_bias, int n, int channels, long long hw, int dtype, int act, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * ObjectPointCloudMap._extract_object_cloud (vlfm/mapping/object_point_cloud_map.py:150-170,186-212)
  * ------------------------------------------------------------------------------------------- */

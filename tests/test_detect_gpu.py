@@ -284,3 +284,25 @@ def test_depthwise_conv3x3_kernel(gpu_device, case):
                                         stride, gelu).cpu()
             assert got.shape == want.shape
             assert torch.allclose(got.double(), want, atol=2e-6, rtol=2e-6), float((got.double() - want).abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("act", [None, "gelu", "silu"])
+def test_bias_act_kernel(gpu_device, dtype, act):
+    """vlfm_bias_act_nchw (the folded BatchNorm's bias + the activation in one in-place pass) against the framework ops in
+    float64: aligned planes, planes whose size is not a multiple of the vector width, a single-pixel plane."""
+    import torch.nn.functional as F
+
+    from vlfm_amd.vlm import ops
+
+    g = torch.Generator().manual_seed(3)
+    for shape in [(2, 5, 16, 24), (3, 7, 5, 7), (1, 3, 1, 1), (1, 2, 33, 130)]:
+        x = (torch.randn(shape, generator=g) * 2).to(dtype)
+        b = torch.randn(shape[1], generator=g).to(dtype)
+        want = x.double() + b.double().view(1, -1, 1, 1)
+        want = F.gelu(want) if act == "gelu" else F.silu(want) if act == "silu" else want
+        y = x.to(gpu_device).clone()
+        out = ops.bias_act(y, b.to(gpu_device), act)
+        assert out.data_ptr() == y.data_ptr()          # in place
+        tol = 2e-6 if dtype == torch.float32 else 2e-3
+        assert torch.allclose(out.cpu().double(), want, atol=tol, rtol=tol), (shape, float((out.cpu().double() - want).abs().max()))

@@ -151,6 +151,7 @@ def lib() -> ctypes.CDLL:
         L.vlfm_bits_dilate.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
         L.vlfm_find_contours_external.argtypes = [vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, vp, vp]
         L.vlfm_dwconv3x3_f32.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
+        L.vlfm_bias_act_nchw.argtypes = [vp, vp, ci, ci, ctypes.c_longlong, ci, ci, vp]
         L.vlfm_find_contours_wg_scratch_bytes.argtypes = [ci, ci, ci, ci]
         L.vlfm_find_contours_wg_scratch_bytes.restype = ctypes.c_size_t
         L.vlfm_find_contours_external_wg.argtypes = [vp, ci, ci, ci, ci, vp, ctypes.c_size_t, vp, ci, vp, vp, ci, vp, vp]

@@ -184,23 +184,38 @@ def patch_hf_deformable_attention(model) -> int:
 
 def fold_batchnorm_(model) -> int:
     """Inference-time folding of every eval-mode BatchNorm2d that directly follows a Conv2d inside an ``nn.Sequential`` (the
-    conv+bn(+act) triples of the YOLOv7-class network, TinyViT's ``Conv2d_BN``): the convolution gets the scaled weights and
-    a bias, the BatchNorm becomes ``Identity`` -- what yolov7's ``fuse()`` / TinyViT's ``Conv2d_BN.fuse()`` do before
-    deployment.  Same function up to float rounding; removes one full pass over every activation (9.9 + 5.8 ms of the
-    128-env full step, tools/full_step_probe.py).  Call AFTER the checkpoint is loaded.  Returns the number folded."""
+    conv + bn + SiLU triples of the YOLOv7-class network, TinyViT's ``Conv2d_BN``): the convolution gets the scaled weights,
+    the BatchNorm becomes an ``ops.BiasAct`` holding the folded bias -- and the SiLU / GELU module behind it, if there is one --
+    i.e. what yolov7's ``fuse()`` / TinyViT's ``Conv2d_BN.fuse()`` do before deployment, with bias + activation as ONE in-place
+    pass over the activation instead of the framework's BatchNorm pass + activation pass (MIOpen convolutions take no bias).
+    Same function up to float rounding.  Call AFTER the checkpoint is loaded.  Returns the number folded."""
     import torch.nn as nn
     from torch.nn.utils.fusion import fuse_conv_bn_eval
+
+    from .ops import BiasAct
 
     n = 0
     for m in list(model.modules()):
         if not isinstance(m, nn.Sequential):
             continue
         names = list(m._modules.keys())
-        for a, b in zip(names, names[1:]):
+        for pos, (a, b) in enumerate(zip(names, names[1:])):
             conv, bn = m._modules[a], m._modules[b]
             if isinstance(conv, nn.Conv2d) and isinstance(bn, nn.BatchNorm2d) and not bn.training:
-                m._modules[a] = fuse_conv_bn_eval(conv, bn)
-                m._modules[b] = nn.Identity()
+                fused = fuse_conv_bn_eval(conv, bn)
+                bias = fused.bias.detach().clone()
+                fused.bias = None
+                act = None
+                if pos + 2 < len(names):
+                    nxt = m._modules[names[pos + 2]]
+                    if isinstance(nxt, nn.SiLU):
+                        act = "silu"
+                    elif isinstance(nxt, nn.GELU) and getattr(nxt, "approximate", "none") == "none":
+                        act = "gelu"
+                    if act is not None:
+                        m._modules[names[pos + 2]] = nn.Identity()
+                m._modules[a] = fused
+                m._modules[b] = BiasAct(bias, act)
                 n += 1
     return n
 

@@ -127,6 +127,44 @@ def layernorm_bias(x: torch.Tensor, channel_bias, weight: torch.Tensor, bias: to
     return y
 
 
+_ACT_CODE = {None: 0, "none": 0, "gelu": 1, "silu": 2}
+
+
+def bias_act_(y: torch.Tensor, bias: torch.Tensor, act=None) -> torch.Tensor:
+    """In place on a contiguous NCHW f32 / f16 tensor: y = act(y + bias[c]); act in (None, "gelu", "silu").  One pass instead
+    of the framework's two (csrc/detect_ops.hip)."""
+    assert y.is_cuda and y.dim() == 4 and y.is_contiguous() and y.dtype in (torch.float32, torch.float16)
+    assert bias.dtype == y.dtype and bias.numel() == y.shape[1] and bias.is_contiguous()
+    n, c, h, w = y.shape
+    _lib.check(_lib.lib().vlfm_bias_act_nchw(y.data_ptr(), bias.data_ptr(), n, c, h * w, 0 if y.dtype == torch.float32 else 1,
+                                             _ACT_CODE[act], _stream()), "bias_act_nchw")
+    return y
+
+
+class BiasAct(torch.nn.Module):
+    """``act(x + bias[c])`` as a module: takes the place of a folded BatchNorm2d (+ the activation module behind it)."""
+
+    def __init__(self, bias: torch.Tensor, act=None):
+        super().__init__()
+        self.bias = torch.nn.Parameter(bias.detach().clone(), requires_grad=False)
+        self.act = act
+
+    def forward(self, x):
+        return bias_act(x, self.bias, self.act)
+
+
+def bias_act(x: torch.Tensor, bias: torch.Tensor, act=None) -> torch.Tensor:
+    """act(x + bias[c]): the HIP kernel, in place, for a fresh contiguous NCHW tensor on the GPU; the framework ops otherwise."""
+    if x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.float16) and x.is_contiguous() and not x.requires_grad:
+        return bias_act_(x, bias if bias.dtype == x.dtype else bias.to(x.dtype), act)
+    y = x + bias.to(x.dtype).view(1, -1, 1, 1)
+    if act == "gelu":
+        return torch.nn.functional.gelu(y)
+    if act == "silu":
+        return torch.nn.functional.silu(y)
+    return y
+
+
 def depthwise_conv3x3(x: torch.Tensor, weight: torch.Tensor, bias, stride: int = 1, gelu: bool = False) -> torch.Tensor:
     """Depthwise 3x3 convolution (padding 1, stride 1 or 2) of an NCHW f32 tensor, + bias, + exact GELU: the HIP kernel behind
     TinyViT's depthwise convolutions (csrc/detect_ops.hip).  weight [C,1,3,3]."""

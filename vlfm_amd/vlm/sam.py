@@ -32,17 +32,28 @@ class _ConvBN(nn.Sequential):
         self.add_module("bn", nn.BatchNorm2d(b))
 
 
+def _folded(cb: "_ConvBN") -> bool:
+    return isinstance(cb.bn, ops.BiasAct)
+
+
+def _conv_act(cb: "_ConvBN", x: torch.Tensor, gelu: bool) -> torch.Tensor:
+    """``gelu(cb(x))`` / ``cb(x)``; with the BatchNorm folded (det_ops.fold_batchnorm_) the bias and the GELU are one pass."""
+    if _folded(cb):
+        return ops.bias_act(cb.c(x), cb.bn.bias, "gelu" if gelu else None)
+    y = cb(x)
+    return F.gelu(y) if gelu else y
+
+
 def _dwconv(cb: "_ConvBN", x: torch.Tensor, gelu: bool) -> torch.Tensor:
     """A depthwise 3x3 ``_ConvBN`` (+ GELU): the HIP kernel once the BatchNorm is folded and the tensor lives on the GPU in f32
     (MIOpen falls back to its naive convolution for these: 13 ms of the 128-env full step), the framework path otherwise."""
     c = cb.c
-    if (x.is_cuda and x.dtype == torch.float32 and isinstance(cb.bn, nn.Identity) and c.groups == c.in_channels == c.out_channels
+    if (_folded(cb) and x.is_cuda and x.dtype == torch.float32 and c.groups == c.in_channels == c.out_channels
             and c.kernel_size == (3, 3) and c.padding == (1, 1) and c.stride[0] == c.stride[1] and c.stride[0] in (1, 2)
             and x.shape[3] % 4 == 0 and ((x.shape[3] - 1) // c.stride[0] + 1) % 4 == 0
             and (c.stride[0] == 1 or x.shape[3] % 2 == 0)):
-        return ops.depthwise_conv3x3(x.contiguous(), c.weight, c.bias, c.stride[0], gelu)
-    y = cb(x)
-    return F.gelu(y) if gelu else y
+        return ops.depthwise_conv3x3(x.contiguous(), c.weight, cb.bn.bias, c.stride[0], gelu)
+    return _conv_act(cb, x, gelu)
 
 
 class _PatchEmbed(nn.Module):
@@ -61,7 +72,7 @@ class _MBConv(nn.Module):
         self.conv1, self.conv2, self.conv3 = _ConvBN(dim, h), _ConvBN(h, h, 3, 1, 1, h), _ConvBN(h, dim)
 
     def forward(self, x):
-        return F.gelu(x + self.conv3(_dwconv(self.conv2, F.gelu(self.conv1(x)), True)))
+        return F.gelu(x + self.conv3(_dwconv(self.conv2, _conv_act(self.conv1, x, True), True)))
 
 
 class _PatchMerging(nn.Module):
@@ -71,7 +82,7 @@ class _PatchMerging(nn.Module):
         self.conv1, self.conv2, self.conv3 = _ConvBN(dim, out), _ConvBN(out, out, 3, stride, 1, out), _ConvBN(out, out)
 
     def forward(self, x):
-        return self.conv3(_dwconv(self.conv2, F.gelu(self.conv1(x)), True))
+        return self.conv3(_dwconv(self.conv2, _conv_act(self.conv1, x, True), True))
 
 
 class _WindowAttention(nn.Module):
