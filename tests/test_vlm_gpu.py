@@ -188,6 +188,51 @@ def test_vit_deferred_bias_path_equals_plain_path(gpu_device):
     assert (fast - want).abs().mean() <= 1.2 * (plain - want).abs().mean() + 1e-4  # not less accurate than the plain path
 
 
+def test_vit_block_with_the_fc1_gelu_kernel(gpu_device):
+    """The ViT fast path with fc1 + GELU through vlfm_gemm_f16_nt (forced on: the product switches to it at 32 images) against
+    the same path with the library GEMM + GELU pass, and against fp32 on the CPU; a hidden width the kernel cannot tile
+    (176) must silently stay on the library."""
+    from vlfm_amd.vlm.blip2itm import Blip2ITCConfig, Blip2ITCModel
+
+    g = torch.Generator().manual_seed(2)
+    for hidden, uses_kernel in ((192, True), (176, False)):
+        cfg = Blip2ITCConfig(image_size=56, patch_size=14, v_hidden=hidden, v_layers=3, v_heads=2, v_mlp=2 * hidden, q_hidden=64,
+                             q_layers=2, q_heads=4, q_mlp=128, vocab_size=100, max_position_embeddings=40,
+                             num_query_tokens=4, proj_dim=16)
+        ref = Blip2ITCModel(cfg).init_random(4).eval()
+        with torch.no_grad():
+            for n, p in ref.named_parameters():
+                if p.dim() > 1:
+                    p.mul_(4.0)
+                elif "layer_norm" not in n and "LayerNorm" not in n and "layernorm" not in n:
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+        gpu = Blip2ITCModel(cfg).eval()
+        gpu.load_state_dict(ref.state_dict())
+        gpu.to(gpu_device).set_precision(torch.float16)
+        pix = torch.randn(6, 3, 56, 56, generator=g)
+        calls = []
+        from vlfm_amd.vlm import ops
+        real = ops.linear_gelu
+        ops.linear_gelu = lambda *a: (calls.append(1), real(*a))[1]
+        try:
+            with torch.inference_mode():
+                want = ref.vision_tokens(pix)
+                gpu.deferred_bias = True
+                for blk in gpu.blocks:
+                    blk.hip_mlp_min_rows = 1
+                ours = gpu.vision_tokens(pix.to(gpu_device).half()).float().cpu()
+                n_calls = len(calls)
+                for blk in gpu.blocks:
+                    blk.hip_mlp_min_rows = 0
+                lib = gpu.vision_tokens(pix.to(gpu_device).half()).float().cpu()
+        finally:
+            ops.linear_gelu = real
+        assert n_calls == (cfg.v_layers if uses_kernel else 0) and len(calls) == n_calls
+        assert (ours - want).abs().max() <= 3e-2 and (lib - want).abs().max() <= 3e-2
+        assert (ours - lib).abs().max() <= 2e-2
+        assert (ours - want).abs().mean() <= 1.2 * (lib - want).abs().mean() + 1e-4
+
+
 @pytest.mark.parametrize("D", [88, 96])
 def test_vit_attention_kernel_vs_fp32_reference(gpu_device, D):
     """vlfm_vit_attention_f16 (257 tokens, 16 heads of 88 -- native, or zero-padded to 96) against

@@ -142,7 +142,8 @@ class _VitBlock(nn.Module):
             a = F.scaled_dot_product_attention(q[0], q[1], q[2]).transpose(1, 2).reshape(b * n, d)
             x2.addmm_(a, self.projection.weight.t())
         h = ops.layernorm_bias(x, c_mid, self.layer_norm2.weight, self.layer_norm2.bias, self.layer_norm2.eps)
-        if self.hip_mlp_min_rows and b * n >= self.hip_mlp_min_rows and self.fc1.weight.dtype == torch.float16:
+        if (self.hip_mlp_min_rows and b * n >= self.hip_mlp_min_rows and self.fc1.weight.dtype == torch.float16
+                and d % 64 == 0 and self.fc1.out_features % 8 == 0):   # the kernel's tile constraints (K % 64, N % 8)
             act = ops.linear_gelu(h.view(b * n, d), self.fc1.weight, self.fc1.bias)   # GELU in the GEMM epilogue
         else:
             act = F.gelu(F.linear(h, self.fc1.weight, self.fc1.bias)).view(b * n, -1)
