@@ -90,11 +90,10 @@ def test_find_contours_external_bit_exact(gpu_device, density, method):
             assert np.array_equal(g, w.reshape(-1, 2))
 
 
-def _gpu_contours_wg(img: np.ndarray, method: int, device, cap_p: int = 1 << 14):
+def _gpu_contours_wg(img: np.ndarray, method: int, device, cap_p: int = 1 << 14, cap_c: int = 4096):
     """The workgroup-parallel border follower (csrc/border_parallel.h) through vlfm_find_contours_external_wg."""
     planes, rows, cols = img.shape
     bits = _pack(torch.from_numpy(img).to(device))
-    cap_c = 4096
     nbytes = _lib.lib().vlfm_find_contours_wg_scratch_bytes(planes, rows, cols, cap_p)
     assert nbytes > 0
     scratch = torch.zeros(nbytes, dtype=torch.uint8, device=device)
@@ -175,6 +174,22 @@ def test_parallel_border_follower_equals_findcontours(gpu_device, method):
             assert np.array_equal(g, w.reshape(-1, 2))
             longest = max(longest, len(g))
     assert longest > (500 if method == 1 else 100)   # the ranking path ran (borders closing within 16 steps are walked by one lane)
+
+
+def test_parallel_border_follower_falls_back_when_the_tables_do_not_fit(gpu_device):
+    """More border pixels than the follower's tables hold (19 680 in 6 560 three-pixel dashes against a capacity of 16 384) but
+    fewer chain points than the output holds: every border is walked by one lane instead, same result."""
+    from oracle import cv
+
+    img = np.zeros((1, 240, 330), np.uint8)
+    for y in range(0, 160, 2):
+        for x0 in range(0, 328, 4):
+            img[0, y, x0:x0 + 3] = 1
+    got = _gpu_contours_wg(img, 2, gpu_device, cap_p=1 << 14, cap_c=8192)[0]
+    want, _ = cv.findContours(img[0], cv.RETR_EXTERNAL, cv.CHAIN_APPROX_SIMPLE)
+    assert len(got) == len(want) == 80 * 82
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w.reshape(-1, 2))
 
 
 def test_find_contours_map_sized(gpu_device):
