@@ -162,3 +162,77 @@ def test_text_branch_cache_returns_the_same_features():
         model(pixel_values=pix, input_ids=other, attention_mask=(other != 0).long())
     assert len(calls) == 3                             # second identical caption: no BERT forward
     assert torch.equal(a.logits, b.logits) and torch.equal(a.pred_boxes, b.pred_boxes)
+
+
+def test_fold_batchnorm_is_the_same_function():
+    """det_ops.fold_batchnorm_ (conv + eval-mode BatchNorm [+ SiLU / GELU module] -> conv + ops.BiasAct) on the two patterns it
+    serves: the YOLOv7-class conv + bn + SiLU triple and TinyViT's Conv2d_BN, with non-trivial running statistics; the BiasAct
+    module's framework path (CPU) must reproduce bias + activation."""
+    import torch.nn as nn
+
+    from vlfm_amd.vlm import ops
+    from vlfm_amd.vlm.sam import _ConvBN, _MBConv
+
+    g = torch.Generator().manual_seed(0)
+
+    def randomise(m):
+        for mod in m.modules():
+            if isinstance(mod, nn.BatchNorm2d):
+                mod.running_mean.copy_(torch.randn(mod.num_features, generator=g) * 0.2)
+                mod.running_var.copy_(torch.rand(mod.num_features, generator=g) + 0.5)
+                mod.weight.data.copy_(torch.rand(mod.num_features, generator=g) + 0.5)
+                mod.bias.data.copy_(torch.randn(mod.num_features, generator=g) * 0.2)
+
+    tri = nn.Sequential(nn.Conv2d(5, 7, 3, 1, 1, bias=False), nn.BatchNorm2d(7), nn.SiLU(inplace=True)).eval()
+    mb = _MBConv(8).eval()
+    cb = _ConvBN(4, 6, 3, 2, 1).eval()
+    for net, x in ((tri, torch.randn(2, 5, 9, 11, generator=g)), (mb, torch.randn(2, 8, 12, 12, generator=g)),
+                   (cb, torch.randn(1, 4, 10, 10, generator=g))):
+        randomise(net)
+        with torch.inference_mode():
+            want = net(x.clone())
+            n = det_ops.fold_batchnorm_(net)
+            got = net(x.clone())
+        assert n >= 1 and not any(isinstance(m, nn.BatchNorm2d) for m in net.modules())
+        assert torch.allclose(got, want, atol=2e-5, rtol=1e-5), float((got - want).abs().max())
+    assert isinstance(tri[1], ops.BiasAct) and tri[1].act == "silu" and isinstance(tri[2], nn.Identity) and tri[0].bias is None
+    assert isinstance(cb.bn, ops.BiasAct) and cb.bn.act is None
+    assert det_ops.fold_batchnorm_(tri) == 0          # idempotent
+
+
+def test_grounding_dino_postprocessing_equals_the_per_query_loop():
+    """GroundingDINO._detections (array operations + one decode per distinct token set) against the upstream per-query loop
+    (groundingdino.util.inference.predict [ext] + grounding_dino.py:70-72) on random probabilities: few, many and no queries
+    above the box threshold."""
+    from vlfm_amd.vlm.grounding_dino import GroundingDINO, WordTokenizer, preprocess_caption
+
+    class Stub(GroundingDINO):
+        def __init__(self):
+            wt = WordTokenizer(30522, 256)
+            self.tokenizer, self.decode = wt, wt.decode
+            self.box_threshold, self.text_threshold = 0.35, 0.25
+
+    g = Stub()
+    raw = "chair . bed . potted plant . toilet . tv . couch ."
+    ids = g.tokenizer(preprocess_caption(raw))
+
+    def loop(probs, boxes):
+        probs, boxes = torch.from_numpy(probs), torch.from_numpy(boxes)
+        keep = probs.max(dim=1)[0] > g.box_threshold
+        logit, box = probs[keep], boxes[keep]
+        phrases = []
+        for row in logit:
+            pos = row[: len(ids)] > g.text_threshold
+            pos[0] = False
+            pos[len(ids) - 1:] = False
+            phrases.append(g.decode([ids[k] for k in torch.nonzero(pos).flatten().tolist()]).replace(".", "").strip())
+        det = ObjectDetections(box, logit.max(dim=1)[0] if len(logit) else torch.zeros(0), phrases, image_source=None)
+        det.filter_by_class(raw[: -len(" .")].split(" . "))
+        return det
+
+    for seed, power, nq in ((0, 3, 300), (1, 1, 120), (2, 8, 300), (3, 60, 200)):
+        rng = np.random.default_rng(seed)
+        probs = rng.uniform(size=(nq, 256)).astype(np.float32) ** power
+        boxes = rng.uniform(size=(nq, 4)).astype(np.float32)
+        a, b = loop(probs, boxes), g._detections(probs, boxes, ids, raw)
+        assert a.phrases == b.phrases and torch.equal(a.boxes, b.boxes) and torch.equal(a.logits, b.logits)
