@@ -26,7 +26,6 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "../../include/vlfm_amd.h"
 #include "profile.h"
@@ -78,7 +77,7 @@ __device__ inline int vt_col(int key) {
 // Attention of the 32 query columns in ``qf`` against key tiles kt0 .. kt0+KT-1.  Returns the UNNORMALISED O^T
 // accumulators (3 tiles of 32 head channels), the column maximum of the raw scores and the column sum of
 // exp2((s - max) * c), all per lane for query column lane&31 (combined over both lane halves).
-template <int KT, int KS = AT_KS>
+template <int KT>
 __device__ inline void attend(const _Float16* __restrict__ Kl, const _Float16* __restrict__ Vl, const half8_t (&qf)[AT_D / 16],
                               int kt0, float c, f32x16_t (&o)[AT_D / 32], float& m_out, float& l_out) {
     const int lane = threadIdx.x & 63, col = lane & 31, grp = lane >> 5;
@@ -93,18 +92,18 @@ __device__ inline void attend(const _Float16* __restrict__ Kl, const _Float16* _
     // kk + 1 are fetched from LDS while step kk is in the matrix pipe.
     constexpr int G = KT >= 3 ? 3 : KT;
     static_assert(KT % G == 0, "key tiles come in whole groups");
-    const _Float16* kbase = Kl + (size_t)(32 * kt0 + col) * KS + 8 * grp;
+    const _Float16* kbase = Kl + (size_t)(32 * kt0 + col) * AT_KS + 8 * grp;
 #pragma unroll
     for (int g0 = 0; g0 < KT; g0 += G) {
         half8_t a_cur[G], a_nxt[G];
 #pragma unroll
-        for (int t = 0; t < G; t++) a_cur[t] = *reinterpret_cast<const half8_t*>(kbase + (size_t)(32 * (g0 + t)) * KS);
+        for (int t = 0; t < G; t++) a_cur[t] = *reinterpret_cast<const half8_t*>(kbase + (size_t)(32 * (g0 + t)) * AT_KS);
 #pragma unroll
         for (int kk = 0; kk < AT_D / 16; kk++) {
             if (kk + 1 < AT_D / 16) {
 #pragma unroll
                 for (int t = 0; t < G; t++)
-                    a_nxt[t] = *reinterpret_cast<const half8_t*>(kbase + (size_t)(32 * (g0 + t)) * KS + 16 * (kk + 1));
+                    a_nxt[t] = *reinterpret_cast<const half8_t*>(kbase + (size_t)(32 * (g0 + t)) * AT_KS + 16 * (kk + 1));
             }
 #pragma unroll
             for (int t = 0; t < G; t++)
@@ -333,176 +332,6 @@ __global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _
     AT_PHASE(11);
 }
 
-
-constexpr int PK_KS = 88;
-constexpr size_t PK_LDS_K = (size_t)AT_KROWS * PK_KS * 2 + 64;
-constexpr size_t PK_LDS_BYTES = 2 * PK_LDS_K + AT_LDS_V + AT_LDS_PART + AT_LDS_QCLS;
-using lds_bytes_ptr = __attribute__((address_space(3))) unsigned char*;
-using gbl_bytes_ptr = const __attribute__((address_space(1))) unsigned char*;
-
-__device__ inline void pk_request_k(const _Float16* base, size_t row_halfs, lds_bytes_ptr kbuf, int H, int wave, int lane) {
-    constexpr int kChunks = AT_S * 11;
-    constexpr int kInstr = (kChunks + 63) / 64;
-    for (int j = wave; j < kInstr; j += AT_WAVES) {
-        const int c = j * 64 + lane;
-        if (c < kChunks) {
-            const int tok = c / 11, piece = c - tok * 11;
-            const _Float16* src = base + (size_t)tok * row_halfs + (size_t)H * 88 + 8 * piece;
-            __builtin_amdgcn_global_load_lds((gbl_bytes_ptr)src, kbuf + __builtin_amdgcn_readfirstlane(j * 1024), 16, 0, 0);
-        }
-    }
-}
-
-__device__ __attribute__((noinline)) void pk_main(const _Float16* Kl, const _Float16* Vl, const half8_t (&qmain)[AT_D / 16], float c,
-                                                   _Float16* dst) {
-    const int grp = (threadIdx.x & 63) >> 5;
-    f32x16_t o[AT_D / 32];
-    float m, l;
-    attend<AT_KT, PK_KS>(Kl, Vl, qmain, 0, c, o, m, l);
-    const float inv = 1.0f / l;
-#pragma unroll
-    for (int dt = 0; dt < AT_D / 32; dt++) {
-#pragma unroll
-        for (int q4 = 0; q4 < 4; q4++) {
-            const half4_t v = half4_t{(_Float16)(o[dt][4 * q4] * inv), (_Float16)(o[dt][4 * q4 + 1] * inv),
-                                      (_Float16)(o[dt][4 * q4 + 2] * inv), (_Float16)(o[dt][4 * q4 + 3] * inv)};
-            if (32 * dt + 8 * q4 + 4 * grp < 88) *reinterpret_cast<half4_t*>(dst + 32 * dt + 8 * q4) = v;
-        }
-    }
-}
-
-
-__global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_pk_kernel(const _Float16* __restrict__ qkv,
-                                                                            _Float16* __restrict__ out, int B, int H,
-                                                                            float scale) {
-    constexpr int DH = 88;
-    extern __shared__ __attribute__((aligned(16))) unsigned char at_lds[];
-    _Float16* Vl = reinterpret_cast<_Float16*>(at_lds + 2 * PK_LDS_K);
-    float* part = reinterpret_cast<float*>(at_lds + 2 * PK_LDS_K + AT_LDS_V);
-    _Float16* qcls = reinterpret_cast<_Float16*>(at_lds + 2 * PK_LDS_K + AT_LDS_V + AT_LDS_PART);
-    const int tid = threadIdx.x, nth = blockDim.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), col = lane & 31, grp = lane >> 5;
-    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
-    const size_t row_halfs = (size_t)3 * H * DH;
-    const float c = scale * 1.4426950408889634f;
-    for (int i = tid; i < (int)((2 * PK_LDS_K + AT_LDS_V) / 4); i += nth) reinterpret_cast<unsigned*>(at_lds)[i] = 0u;
-    __syncthreads();
-    auto item = [&](int it, int& b, int& h) { const int slot = local + it * per_xcd; b = xcd + 8 * (slot / H); h = slot % H; return b < B; };
-    int b, h;
-    if (!item(0, b, h)) return;
-    pk_request_k(qkv + (size_t)b * AT_S * row_halfs + (size_t)h * DH, row_halfs, (lds_bytes_ptr)at_lds, H, wave, lane);
-    constexpr int kPairs = (AT_S + 1) / 2, kItems = kPairs * 11, kIters = (kItems + 64 * AT_WAVES - 1) / (64 * AT_WAVES);
-    half8_t vreg[kIters][2], qmain[AT_D / 16], qrow;
-    const int tq = 1 + 32 * wave + col;
-    auto request_vq = [&](const _Float16* base) {
-#pragma unroll
-        for (int k = 0; k < kIters; k++) {
-            const int i = tid + k * 64 * AT_WAVES;
-            const int s0 = 2 * (i / 11), ch = i % 11;
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const int s = s0 + u;
-                if (i < kItems && s < AT_S) {
-                    vreg[k][u] = *reinterpret_cast<const half8_t*>(base + (size_t)s * row_halfs + (size_t)2 * H * DH + 8 * ch);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) vreg[k][u][j] = (_Float16)0.0f;
-                }
-            }
-        }
-#pragma unroll
-        for (int kk = 0; kk < AT_D / 16; kk++) {
-            if (2 * kk + grp < DH / 8) {
-                qmain[kk] = *reinterpret_cast<const half8_t*>(base + (size_t)tq * row_halfs + 8 * grp + 16 * kk);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; j++) qmain[kk][j] = (_Float16)0.0f;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) qrow[j] = (_Float16)0.0f;
-        if (tid < DH / 8) qrow = *reinterpret_cast<const half8_t*>(base + 8 * tid);
-    };
-    request_vq(qkv + (size_t)b * AT_S * row_halfs + (size_t)h * DH);
-    for (int it = 0;; it++) {
-        if (!item(it, b, h)) break;
-        _Float16* Kl = reinterpret_cast<_Float16*>(at_lds + (size_t)(it & 1) * PK_LDS_K);
-        if (tid < AT_D / 8) *reinterpret_cast<half8_t*>(qcls + 8 * tid) = qrow;
-#pragma unroll
-        for (int k = 0; k < kIters; k++) {
-            const int i = tid + k * 64 * AT_WAVES;
-            const int s0 = 2 * (i / 11), ch = i % 11;
-            if (i < kItems) {
-                const int vc = vt_col(s0);
-                using half2_t = __attribute__((ext_vector_type(2))) _Float16;
-#pragma unroll
-                for (int j = 0; j < 8; j++)
-                    *reinterpret_cast<half2_t*>(Vl + (size_t)(8 * ch + j) * AT_VS + vc) = half2_t{vreg[k][0][j], vreg[k][1][j]};
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        __syncthreads();
-        asm volatile("" ::: "memory");
-        {
-            int nb, nh;
-            if (item(it + 1, nb, nh))
-                pk_request_k(qkv + (size_t)nb * AT_S * row_halfs + (size_t)nh * DH, row_halfs, (lds_bytes_ptr)(at_lds + (size_t)((it + 1) & 1) * PK_LDS_K), H, wave, lane);
-        }
-        auto cls_part = [&]() {
-            half8_t qf[AT_D / 16];
-#pragma unroll
-            for (int kk = 0; kk < AT_D / 16; kk++) {
-                half8_t z;
-#pragma unroll
-                for (int j = 0; j < 8; j++) z[j] = (_Float16)0.0f;
-                qf[kk] = col == 0 ? *reinterpret_cast<const half8_t*>(qcls + 8 * grp + 16 * kk) : z;
-            }
-            f32x16_t o[AT_D / 32];
-            float m, l;
-            if (wave < AT_WAVES - 1) attend<1, PK_KS>(Kl, Vl, qf, wave, c, o, m, l);
-            else attend<2, PK_KS>(Kl, Vl, qf, AT_WAVES - 1, c, o, m, l);
-            float* mine = part + (size_t)wave * (AT_D + 2);
-            if (col == 0) {
-#pragma unroll
-                for (int dt = 0; dt < AT_D / 32; dt++) {
-#pragma unroll
-                    for (int r = 0; r < 16; r++) mine[32 * dt + (r & 3) + 8 * (r >> 2) + 4 * grp] = o[dt][r];
-                }
-                if (grp == 0) { mine[AT_D] = m; mine[AT_D + 1] = l; }
-            }
-        };
-        const bool cls_first = wave >= AT_WAVES / 2;
-        if (cls_first) cls_part();
-        pk_main(Kl, Vl, qmain, c, out + ((size_t)(b * AT_S + tq) * H + h) * DH + 4 * grp);
-        {
-            int nb, nh;
-            if (!item(it + 1, nb, nh)) { nb = b; nh = h; }
-            request_vq(qkv + (size_t)nb * AT_S * row_halfs + (size_t)nh * DH);
-        }
-        if (!cls_first) cls_part();
-        __syncthreads();
-        if (wave == 0) {
-            float mx = -__builtin_huge_valf();
-#pragma unroll
-            for (int w = 0; w < AT_WAVES; w++) mx = fmaxf(mx, part[(size_t)w * (AT_D + 2) + AT_D]);
-            float wgt[AT_WAVES], lsum = 0.0f;
-#pragma unroll
-            for (int w = 0; w < AT_WAVES; w++) {
-                wgt[w] = exp2f((part[(size_t)w * (AT_D + 2) + AT_D] - mx) * c);
-                lsum += wgt[w] * part[(size_t)w * (AT_D + 2) + AT_D + 1];
-            }
-            const float inv = 1.0f / lsum;
-            _Float16* dst = out + ((size_t)(b * AT_S) * H + h) * DH;
-            for (int d = lane; d < DH; d += 64) {
-                float v = 0.0f;
-#pragma unroll
-                for (int w = 0; w < AT_WAVES; w++) v += wgt[w] * part[(size_t)w * (AT_D + 2) + d];
-                dst[d] = (_Float16)(v * inv);
-            }
-        }
-    }
-}
-
 }  // namespace vlfm
 
 using namespace vlfm;
@@ -518,20 +347,6 @@ extern "C" int vlfm_vit_attention_f16(const void* d_qkv, void* d_out, int batch,
     if (!(head_dim == 88 ? opt_in88.ensure(reinterpret_cast<const void*>(vit_attention_kernel<88>), AT_LDS_BYTES)
                          : opt_in96.ensure(reinterpret_cast<const void*>(vit_attention_kernel<96>), AT_LDS_BYTES)))
         return fail(VLFM_ERR_HIP, "vit_attention_f16: cannot opt in to 117 KB of LDS");
-    if (head_dim == 88 && !getenv("VLFM_ATTN_CLASSIC")) {   // persistent form: K by global_load_lds one item ahead (see the kernel)
-        static LdsOptIn opt_pk;
-        if (!opt_pk.ensure(reinterpret_cast<const void*>(vit_attention_pk_kernel), PK_LDS_BYTES))
-            return fail(VLFM_ERR_HIP, "vit_attention_f16: cannot opt in to 158 KB of LDS");
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        const int items = 8 * ((batch + 7) / 8) * heads;
-        int wgs = (cus / 8) * 8;
-        if (wgs > items) wgs = items;
-        VLFM_TIMED("vit_attention_kernel", stream);
-        VLFM_KLAUNCH(vit_attention_pk_kernel, dim3(wgs), dim3(64 * AT_WAVES), PK_LDS_BYTES, (hipStream_t)stream,
-                     (const _Float16*)d_qkv, (_Float16*)d_out, batch, heads, scale);
-        return check_launch("vit_attention_pk_kernel");
-    }
     const int stagger = 1;  // measured neutral to +3 %; kept: it costs nothing
     VLFM_TIMED("vit_attention_kernel", stream);
     const dim3 grid(8 * ((batch + 7) / 8) * heads), block(64 * AT_WAVES);
