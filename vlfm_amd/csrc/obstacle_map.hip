@@ -1158,47 +1158,72 @@ __global__ __launch_bounds__(1024) void frontier_kernel(const FogParams* __restr
         const bool bad_in_lds = (unsigned)npts_all <= sc.lds_bytes;
         double* seg = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(lds_win) + (bad_in_lds ? seg_off : 0));
         const size_t seg_cap = (sc.lds_bytes - (bad_in_lds ? seg_off : 0)) / sizeof(double);
-        for (int f = 0; f < np; f++) {
-            const int* pc = pieces + 6 * f;
-            const int base = pc[0], n = pc[1], s1 = pc[2], l1 = pc[3], s2 = pc[4], l2 = pc[5];
-            const int m = l1 + l2;
-            auto q = [&](int j) { const int k = j < l1 ? s1 + j : s2 + (j - l1); int idx = k + 1; if (idx >= n) idx -= n; if (idx >= n) idx %= n; return pts[base + idx]; };
-            auto seglen = [&](int k) {
-                const int2 a = q(k), b = q(k + 1);
-                const double ddx = (double)(a.x - b.x), ddy = (double)(a.y - b.y);
-                return sqrt(__dadd_rn(__dmul_rn(ddx, ddx), __dmul_rn(ddy, ddy)));
-            };
-            const bool staged = m >= 2 && (size_t)(m - 1) <= seg_cap;
-            if (staged)
-                for (int k = tid; k + 1 < m; k += nth) seg[k] = seglen(k);
-            __syncthreads();
-            if (tid == 0) {
-                double ox_ = 0, oy_ = 0;
-                if (m < 2) {
-                    if (m == 1) { const int2 p = q(0); ox_ = p.x; oy_ = p.y; }
-                } else {
-                    double total = 0;
-                    for (int k = 0; k + 1 < m; k++) total = __dadd_rn(total, staged ? seg[k] : seglen(k));
-                    const double half = total / 2;
-                    double cum = 0, upto = 0, sl = 0;
-                    int idx = 0;
-                    bool found = false;
-                    for (int k = 0; k + 1 < m; k++) {
-                        const double l = staged ? seg[k] : seglen(k);
-                        const double c2 = __dadd_rn(cum, l);
-                        if (c2 > half) { idx = k; upto = k > 0 ? cum : 0; sl = l; found = true; break; }
-                        cum = c2;
-                    }
-                    if (!found) { idx = 0; upto = 0; sl = staged ? seg[0] : seglen(0); }
-                    const double prop = __ddiv_rn(__dsub_rn(half, upto), sl);
-                    const int2 a = q(idx), b = q(idx + 1);
-                    ox_ = __dadd_rn((double)a.x, __dmul_rn(prop, (double)(b.x - a.x)));
-                    oy_ = __dadd_rn((double)a.y, __dmul_rn(prop, (double)(b.y - a.y)));
-                }
-                if (f < sc.cap_frontiers) { out_xy[2 * f] = ox_; out_xy[2 * f + 1] = oy_; }
-            }
-            __syncthreads();
+        // chain point j of piece f / length of its segment k (f64, the reference's expression)
+        auto q = [&](const int* pc, int j) {
+            const int base = pc[0], n = pc[1], s1 = pc[2], l1 = pc[3], s2 = pc[4];
+            const int k = j < l1 ? s1 + j : s2 + (j - l1);
+            int idx = k + 1;
+            if (idx >= n) idx -= n;
+            if (idx >= n) idx %= n;
+            return pts[base + idx];
+        };
+        auto seglen = [&](const int* pc, int k) {
+            const int2 a = q(pc, k), b = q(pc, k + 1);
+            const double ddx = (double)(a.x - b.x), ddy = (double)(a.y - b.y);
+            return sqrt(__dadd_rn(__dmul_rn(ddx, ddx), __dmul_rn(ddy, ddy)));
+        };
+        // all segment lengths of all pieces at once (piece f owns seg[off[f] .. off[f] + m_f - 1)), then one lane PER PIECE adds
+        // them up -- 16 pieces at a time instead of one (17 pieces took 70 us, two barriers each)
+        __shared__ int sh_off[257];
+        const int npc = np < 256 ? np : 256;
+        if (tid == 0) {
+            int o = 0;
+            for (int f = 0; f < npc; f++) { sh_off[f] = o; const int m = pieces[6 * f + 3] + pieces[6 * f + 5]; o += m >= 2 ? m - 1 : 0; }
+            sh_off[npc] = o;
         }
+        __syncthreads();
+        const int total = sh_off[npc];
+        const bool staged = (size_t)total <= seg_cap && np <= 256;
+        if (staged) {
+            for (int e = tid; e < total; e += nth) {
+                int lo = 0, hi = npc - 1;            // last piece whose offset is <= e and that owns segments
+                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (sh_off[mid] <= e) lo = mid; else hi = mid - 1; }
+                while (sh_off[lo + 1] == sh_off[lo]) lo++;   // (pieces without segments share their successor's offset)
+                seg[e] = seglen(pieces + 6 * lo, e - sh_off[lo]);
+            }
+        }
+        __syncthreads();
+        const int nwaves = (nth + 63) >> 6;
+        for (int f = staged ? wave : 0; f < np; f += staged ? nwaves : 1) {
+            if (staged ? lane != 0 : tid != 0) continue;
+            const int* pc = pieces + 6 * f;
+            const int m = pc[3] + pc[5];
+            const double* sg = seg + (staged ? sh_off[f] : 0);
+            double ox_ = 0, oy_ = 0;
+            if (m < 2) {
+                if (m == 1) { const int2 p2 = q(pc, 0); ox_ = p2.x; oy_ = p2.y; }
+            } else {
+                double totlen = 0;
+                for (int k = 0; k + 1 < m; k++) totlen = __dadd_rn(totlen, staged ? sg[k] : seglen(pc, k));
+                const double half = totlen / 2;
+                double cum = 0, upto = 0, sl = 0;
+                int idx = 0;
+                bool found = false;
+                for (int k = 0; k + 1 < m; k++) {
+                    const double l = staged ? sg[k] : seglen(pc, k);
+                    const double c2 = __dadd_rn(cum, l);
+                    if (c2 > half) { idx = k; upto = k > 0 ? cum : 0; sl = l; found = true; break; }
+                    cum = c2;
+                }
+                if (!found) { idx = 0; upto = 0; sl = staged ? sg[0] : seglen(pc, 0); }
+                const double prop = __ddiv_rn(__dsub_rn(half, upto), sl);
+                const int2 a = q(pc, idx), b = q(pc, idx + 1);
+                ox_ = __dadd_rn((double)a.x, __dmul_rn(prop, (double)(b.x - a.x)));
+                oy_ = __dadd_rn((double)a.y, __dmul_rn(prop, (double)(b.y - a.y)));
+            }
+            if (f < sc.cap_frontiers) { out_xy[2 * f] = ox_; out_xy[2 * f + 1] = oy_; }
+        }
+        __syncthreads();
     }
     VLFM_PHASE(2, 8);
     if (tid == 0) {
