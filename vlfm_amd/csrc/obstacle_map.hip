@@ -640,17 +640,29 @@ __global__ __launch_bounds__(1024) void fog_of_war_kernel(const FogParams* __res
         T.ljd0 = l_jd; T.ljd1 = l_jd + sc.lds_states;
         wg_scan_external(b, p_tr + pw + 1, p_ng + pw + 1, 2, sink, T, sh_wg);
     }
+    // distance of the agent to every contour: one wavefront per contour, 16 at a time (the line list is free: it holds the
+    // distances); then wavefront 0 picks.  OpenCV lists contours in reverse discovery order and the reference's loop keeps the
+    // FIRST strict minimum: in discovery order that is the LAST contour with the minimal distance.
+    double* d2s = reinterpret_cast<double*>(lines);
+    const int n_vis = sink.overflow ? 0 : (sink.n_contours < sc.cap_pts ? sink.n_contours : sc.cap_pts);
+    for (int c = wave; c < n_vis; c += nth >> 6) {
+        double d2; int inside;
+        wave_point_polygon(pts + cstart[c], clen[c], acx, acy, &d2, &inside);
+        if (lane == 0) d2s[c] = d2;
+    }
+    __threadfence_block();
+    __syncthreads();
     if (wave == 0) {
         int best = -1;
         double best_d2 = 0;
-        if (!sink.overflow) {
-            // OpenCV lists contours in reverse discovery order and the loop keeps the FIRST strict minimum:
-            // walking discovery order with <= selects the same contour
-            for (int c = 0; c < sink.n_contours; c++) {
-                double d2; int inside;
-                wave_point_polygon(pts + cstart[c], clen[c], acx, acy, &d2, &inside);
-                if (best < 0 || d2 <= best_d2) { best = c; best_d2 = d2; }
-            }
+        for (int c = lane; c < n_vis; c += 64) {
+            const double d2 = d2s[c];
+            if (best < 0 || d2 <= best_d2) { best = c; best_d2 = d2; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const int ob = __shfl_xor(best, off, 64);
+            const double od = __shfl_xor(best_d2, off, 64);
+            if (ob >= 0 && (best < 0 || od < best_d2 || (od == best_d2 && ob > best))) { best = ob; best_d2 = od; }
         }
         if (lane == 0) { sh_i[5] = best; sh_i[6] = sink.overflow; sh_i[7] = (best >= 0 && sqrt(best_d2) > 3.0) ? 1 : 0; }
     }
