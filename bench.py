@@ -494,6 +494,7 @@ def main():
                        "episode_steps_timed": [first_timed_step, first_timed_step + args.steps - 1],
                        "blip2": "ViT-g/14 39 blocks + Q-Former 12 layers, random-init" if not args.no_blip2 else None,
                        "attention_path": (sim.blip2.attention_path if sim.blip2 is not None else None),
+                       "fc1_gelu_path": (sim.blip2.mlp_path(E) if sim.blip2 is not None else None),
                        "value_map_update": "split (3 launches)" if sim.values.split_update else "single launch",
                        "parallelism": f"env-sharded x{world} (contiguous blocks), metric all-reduce only"},
             "roofline": roofline,

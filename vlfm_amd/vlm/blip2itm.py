@@ -552,6 +552,15 @@ class BLIP2ITM:
         flags = {bool(blk.hip_attention) for blk in self.model.blocks}
         return "hip" if flags == {True} else "library" if flags == {False} else "mixed"
 
+    def mlp_path(self, n_images: int) -> str:
+        """Which fc1 + GELU the ViT blocks run with at this batch size: "hip" (vlfm_gemm_f16_nt, GELU in the epilogue) or "library"
+        (hipBLASLt GEMM + a GELU pass)."""
+        blk = self.model.blocks[0]
+        rows = n_images * ((self.cfg.image_size // self.cfg.patch_size) ** 2 + 1)
+        ok = (blk.hip_mlp_min_rows and rows >= blk.hip_mlp_min_rows and blk.fc1.weight.dtype == torch.float16
+              and blk.fc1.in_features % 64 == 0 and blk.fc1.out_features % 8 == 0)
+        return "hip" if ok else "library"
+
     def _load_pretrained(self, model_dir: str) -> None:
         from safetensors.torch import load_file
 
