@@ -114,7 +114,12 @@ typedef struct {
  * therefore records the cell id (row * S + col) of every obstacle bit it is the FIRST to set; for island frames
  * vlfm_fill_small_holes_batched clears exactly those bits and vlfm_depth_scatter_holes_batched re-places the valid
  * texels outside the filled area.  d_count must be zero on entry (allocate zeroed; vlfm_fill_small_holes_batched
- * resets it).  Observations of one call must belong to distinct environment slots when a journal is used. */
+ * resets it -- a caller whose vlfm_depth_ingest_batched was NOT followed by vlfm_fill_small_holes_batched, e.g. after an
+ * error in between, zeroes d_count itself before the next ingest, or a later island frame would undo that step's bits).
+ * In this mode a texel that falls off the map is only NOTED by the ingest (status word 1, bit 1): whether the reference
+ * would have scattered it is decided by fill_small_holes, which promotes the note to VLFM_ERR_INDEX in status word 0
+ * unless the frame has islands (their surviving texels are placed, and judged, again by the hole scatter).
+ * Observations of one call must belong to distinct environment slots when a journal is used. */
 typedef struct {
     uint32_t* d_cells;    /* [n][capacity] */
     int32_t* d_count;     /* [n] */
@@ -127,7 +132,8 @@ int vlfm_depth_ingest_batched(const float* d_depth, int n, int height, int width
                               uint32_t* d_colmax_keys /* [n][W] or NULL */,
                               uint32_t* d_obstacle /* [n_envs][S][ceil(S/32)] bit-packed or NULL */, int map_size, int pixels_per_meter,
                               int32_t* d_status /* [n][2] sticky: [0] VLFM_ERR_INDEX if a point fell off the map,
-                                                   [1] 1 if the image holds a zero (invalid) depth texel */,
+                                                   [1] bit 0: the image holds a zero (invalid) depth texel; bit 1: the
+                                                   speculative pass (journal mode) hit a cell off the map */,
                               uint32_t* d_hole_bits /* OUT [n][H][ceil(W/32)] bit plane of (depth == 0), or NULL */,
                               const uint32_t* d_filled_bits /* IN  [n][H][ceil(W/32)] texels fill_small_holes set to
                                                                1.0 (vlfm_fill_small_holes_batched), or NULL */,
@@ -140,7 +146,7 @@ int vlfm_depth_ingest_batched(const float* d_depth, int n, int height, int width
  * order; each border whose cv2.contourArea is < area_thresh is drawn filled (cv2.drawContours(.., 1, -1)) into
  * d_filled_bits.  One workgroup per image; images whose status word [1] is 0 (no zero texel) cost one early exit and
  * get an all-zero d_filled_bits only if they had holes before (see d_dirty).
- *   d_status   [n][2] the ingest status (word 1 = image has zeros)
+ *   d_status   [n][2] the ingest status (word 1: bit 0 = image has zeros, bit 1 = speculative off-map hit; consumed here)
  *   d_scratch  vlfm_hole_scratch_bytes(n, H, W, cap_pts, cap_contours) bytes
  *   d_counts   [n][4] int32: (contours traced, contours filled, overflow flags: bit 0 contour scratch, bit 1 journal,
  *              bit 0 image had zero texels | bit 1 island frame = valid texels inside a filled contour)
@@ -175,7 +181,10 @@ int vlfm_depth_scatter_holes_batched(const vlfm_ingest_params* d_params, int n, 
  *   d_pose     [n]           vlfm_vm_pose
  *   d_values   [n][C]        f64 values (BLIP-2 cosines)
  *   d_conf     [n_envs][S][S]      f32 confidence maps   (BaseMap._map)
- *   d_value    [n_envs][S][S][C]   f32 value maps        (ValueMap._value_map)
+ *   d_value    [n_envs][S][S][C]   f64 value maps        (ValueMap._value_map).  f64 because the reference's array IS f64
+ *              after the first weighted fuse (`values` is an f64 ndarray; value_map.py:423 re-binds `_value_map` to the
+ *              f64 result) and stays f64; in the modes where it stays f32 (use_max_confidence :406, fusion "replace"
+ *              :381-384) the stored doubles are f32-representable.  Either way the array equals the reference's bit for bit.
  *   d_explored_bits [n_envs][S][ceil(S/32)] bit-packed ObstacleMap.explored_area when the value map was built with
  *              obstacle_map=... (value_map.py:369-375), or NULL = Habitat default (windowed update, exact).
  *              With it, the full-map zeroing is done by vlfm_value_map_mask_unexplored_batched (call it first).
@@ -186,7 +195,7 @@ size_t vlfm_value_map_scratch_bytes(int n, int template_size);
 int vlfm_value_map_update_batched(uint32_t* d_colmax_keys, int width, const double* d_tan,
                                   const float* d_template, const uint32_t* d_template_bits, int template_size,
                                   const vlfm_vm_pose* d_pose, const double* d_values, int n,
-                                  float* d_conf, float* d_value, int map_size, int channels, int pixels_per_meter,
+                                  float* d_conf, double* d_value, int map_size, int channels, int pixels_per_meter,
                                   double min_depth, double max_depth,
                                   int use_max_confidence, int fusion_type,
                                   const uint32_t* d_explored_bits, void* d_scratch, void* stream);
@@ -205,7 +214,7 @@ int vlfm_value_map_update_batched(uint32_t* d_colmax_keys, int width, const doub
 int vlfm_value_map_update_fused_batched(uint32_t* d_colmax_keys, int width, const double* d_tan,
                                         const float* d_template, const uint32_t* d_template_bits, int template_size,
                                         const vlfm_vm_pose* d_pose, const double* d_values, int n,
-                                        float* d_conf, float* d_value, int map_size, int channels, int pixels_per_meter,
+                                        float* d_conf, double* d_value, int map_size, int channels, int pixels_per_meter,
                                         double min_depth, double max_depth, int use_max_confidence, int fusion_type,
                                         const uint32_t* d_explored_bits, uint32_t* d_written_bits, int32_t* d_counters,
                                         const float* d_conf_quadrant, void* stream);
@@ -217,19 +226,22 @@ int vlfm_value_map_update_fused_batched(uint32_t* d_colmax_keys, int width, cons
  * sizes the launch.  Streaming, HBM-bound. */
 typedef struct { int32_t env, row_lo, row_hi, reserved; } vlfm_mask_job;
 int vlfm_value_map_mask_unexplored_batched(const vlfm_mask_job* d_jobs, int n, int max_rows,
-                                           const uint32_t* d_explored_bits, float* d_conf, float* d_value,
+                                           const uint32_t* d_explored_bits, float* d_conf, double* d_value,
                                            int map_size, int channels, void* stream);
 
 /* ValueMap.sort_waypoints scoring (value_map.py:146-187 + img_utils.py:213-266): per waypoint and channel the
  * median of the positive cells inside the radius disc, -1 if none.
  *   d_cells  [m][3] int32: (env, row, col) of each waypoint (host computes them by truncation, value_map.py:164-167)
  *   d_disc   [(2r+1)] int32 half-widths per disc row (cv2.circle raster, produced by vlfm_disc_rows_host)
- *   d_out    [m][C] f32 medians;  d_order [m] int32 = stable descending order within each env (C==1 only)
+ *   value_is_f32  non-zero when the reference's `_value_map` is still an f32 array in this map's mode (use_max_confidence
+ *            or fusion "replace", or no update yet): np.median then averages the two middle elements of an even count in
+ *            f32; zero = f64 arithmetic (the default weighted mode)
+ *   d_out    [m][C] f64 medians (np.median's result in the array's dtype, widened), -1 where the disc holds no positive cell
  */
 int vlfm_disc_rows_host(int radius, int32_t* h_halfwidth /* [2r+1] */);
-int vlfm_value_map_sort_waypoints_batched(const float* d_value, int map_size, int channels,
+int vlfm_value_map_sort_waypoints_batched(const double* d_value, int map_size, int channels,
                                           const int32_t* d_cells, int m, int radius, const int32_t* d_disc,
-                                          float* d_out, void* stream);
+                                          int value_is_f32, double* d_out, void* stream);
 
 
 /* ---------------------------------------------------------------------------------------------
@@ -416,13 +428,23 @@ size_t vlfm_obstacle_scratch_bytes(int n_envs, int map_size, int cap_pts, int ca
  *   d_bbox      [n_envs][4] int32 persistent (ymin, ymax, xmin, xmax) of everything ever revealed; reset value
  *               (S, -1, S, -1)
  *   d_frontiers [n_envs][cap_frontiers][2] f64 pixel coordinates (x, y) == ObstacleMap._frontiers_px
- *   d_counts    [n_envs][4] int32: (n frontiers, overflow flag, n contours, n chain points) */
+ *   d_counts    [n_envs][4] int32: (n frontiers, overflow flag, n contours, n chain points)
+ *   d_windows   [n][8] int32 or NULL.  Per observation two inclusive cell windows (y0, y1, x0, x1; empty when y1 < y0):
+ *               [0..3] where `navigable` has to be recomputed = the union of the reach windows (camera cell +- the largest
+ *               distance a scattered texel can have, + 1) of every frame ingested into this slot since its last call with
+ *               update_obstacles, grown by kernel_size / 2; [4..7] where `navigable` may have changed since this slot's
+ *               last call with explore (the union of those grown windows): the frontier stage's derived planes are
+ *               refreshed there and inside the revealed area's bounding box d_bbox (`explored` itself is masked inside
+ *               d_bbox: no explored bit exists outside it).  The caller
+ *               passes the whole map (0, S-1, 0, S-1) after a reset of the slot's planes, for a frame whose reach window
+ *               leaves the map (NumPy's negative-index wrap, obstacle_map.py:101, lands on the far side) and for the first
+ *               call on fresh scratch.  NULL = the reference's full-map passes (always valid). */
 int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, int n, const uint32_t* d_obstacle,
                                      uint32_t* d_navigable, uint32_t* d_explored, int32_t* d_bbox, int n_envs,
                                      int map_size, int kernel_size, int fog_radius, double area_thresh_px,
                                      void* d_scratch, size_t scratch_bytes, int cap_pts, int cap_contours,
                                      double* d_frontiers, int cap_frontiers, int32_t* d_counts, int update_obstacles,
-                                     int explore, void* stream);
+                                     int explore, const int32_t* d_windows, void* stream);
 
 /* Debug/diagnostic: copies the per-environment status words of the last pipeline run to the host. */
 int vlfm_obstacle_status(const void* d_scratch, int n_envs, int map_size, int cap_pts, int cap_contours,

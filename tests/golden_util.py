@@ -154,12 +154,12 @@ def replay_islands(make_map):
     assert np.array_equal(np.asarray(om.explored_area).astype(bool), unpack_plane(g["explored_bits"]))
 
 
-def replay_episode500(make_om, make_vm, exact: bool, tol: float = 1e-4, steps: int = 500, on_step=None):
+def replay_episode500(make_om, make_vm, steps: int = 500, on_step=None):
     """The full-length episode of tests/golden/world500.py against what THE REFERENCE'S ObstacleMap + ValueMap produced
-    (tests/golden/ep500.npz).  Every step: frontier pixels and world coordinates bit-exact, sort_waypoints values (exact
-    for the oracle, within ``tol`` for the HIP path, same order up to values closer than the tolerance).  Steps 100 /
-    250 / 500: obstacle / navigable / explored planes bit-exact, confidence / value maps exact (digests) or within
-    ``tol`` with identical support."""
+    (tests/golden/ep500.npz), exact for the oracle and for the HIP path alike.  Every step: frontier pixels and world
+    coordinates, sort_waypoints values AND permutation (value_map.py:183) bit-exact.  Steps 100 / 250 / 500: obstacle /
+    navigable / explored planes bit-exact, SHA-256 of the f32 confidence map and of the f64 value map equal to the
+    digests of the reference's arrays."""
     import sys
 
     if GOLDEN_DIR not in sys.path:
@@ -173,8 +173,6 @@ def replay_episode500(make_om, make_vm, exact: bool, tol: float = 1e-4, steps: i
     om = make_om(**mg.OBSTACLE_KW)
     vm = make_vm(1, use_max_confidence=False)
     offs = np.concatenate([[0], np.cumsum(g["frontier_counts"])])
-    qstep = 0.5 / 65535.0   # the snapshots are quantised to u16: |q(ref) - ref| <= qstep
-    worst = 0.0
     for i, depth, tf, values in w5.episode(g["actions"][:steps]):
         digest = np.frombuffer(hashlib.sha256(depth.tobytes()).digest()[:8], np.uint64)[0]
         assert digest == g["depth_digest"][i], "regenerated depth frame differs from the fixture's input"
@@ -192,14 +190,8 @@ def replay_episode500(make_om, make_vm, exact: bool, tol: float = 1e-4, steps: i
             ref_val = g["sorted_values"][offs[i]:offs[i + 1]]
             ref_wp = want_xy[g["sorted_idx"][offs[i]:offs[i + 1]]]
             s_wp, s_val = np.asarray(s_wp), np.asarray(s_val, np.float64)
-            if exact:
-                assert np.array_equal(s_val, ref_val) and np.array_equal(s_wp, ref_wp), f"step {i}"
-            else:
-                assert np.abs(s_val - ref_val).max() <= tol, f"sort_waypoints values at step {i}"
-                worst = max(worst, float(np.abs(s_val - ref_val).max()))
-                for r in np.flatnonzero((s_wp != ref_wp).any(axis=1)):   # same order up to near-ties
-                    j = int(np.flatnonzero((ref_wp == s_wp[r]).all(axis=1))[0])
-                    assert abs(ref_val[j] - ref_val[r]) <= 2 * tol, f"sort order differs at step {i}"
+            assert np.array_equal(s_val, ref_val), (f"sort_waypoints values at step {i}", np.abs(s_val - ref_val).max())
+            assert np.array_equal(s_wp, ref_wp), f"sort_waypoints permutation at step {i}"
         if on_step is not None:
             on_step(i, om, vm)
         step = i + 1
@@ -207,23 +199,19 @@ def replay_episode500(make_om, make_vm, exact: bool, tol: float = 1e-4, steps: i
             for name, plane in (("obstacle", om._map), ("navigable", om._navigable_map), ("explored", om.explored_area)):
                 assert np.array_equal(np.asarray(plane).astype(bool), unpack_plane(g[f"s{step}_{name}"])), \
                     f"{name} plane at step {step}"
-            conf = np.asarray(vm._map, np.float32)
-            val = np.asarray(vm._value_map, np.float64).reshape(1000, 1000)
-            if exact:
-                assert sha(conf) == str(g[f"s{step}_conf_sha"]) and sha(val) == str(g[f"s{step}_value_sha"]), step
-            else:
-                support = unpack_plane(g[f"s{step}_support"])
-                assert np.array_equal(conf > 0, support), f"confidence support at step {step}"
-                assert not np.any(val[~support])
-                ec = np.abs(conf[support] - g[f"s{step}_conf_q"] / 65535.0).max()
-                ev = np.abs(val[support] - g[f"s{step}_value_q"] / 65535.0).max()
-                assert ec <= tol - qstep and ev <= tol - qstep, (step, ec, ev)
-                worst = max(worst, float(ec), float(ev))
-    return worst
+            conf, val = np.asarray(vm._map), np.asarray(vm._value_map)
+            assert conf.dtype == np.float32 and str(val.dtype) == str(g["value_dtype"])
+            support = unpack_plane(g[f"s{step}_support"])
+            assert np.array_equal(conf > 0, support), f"confidence support at step {step}"
+            val = val.reshape(1000, 1000)
+            ec = np.abs(conf[support] - g[f"s{step}_conf_q"] / 65535.0).max()   # u16-quantised copies: a readable
+            ev = np.abs(val[support] - g[f"s{step}_value_q"] / 65535.0).max()   # distance should the digests differ
+            assert sha(conf) == str(g[f"s{step}_conf_sha"]), (step, "confidence map digest", ec)
+            assert sha(val) == str(g[f"s{step}_value_sha"]), (step, "value map digest", ev)
 
 
-def replay_two_cameras(make_map, exact: bool, tol: float = 1e-4):
-    """One value map fed by two cameras with different (fov, max_depth) per step (make_golden.two_camera_script)."""
+def replay_two_cameras(make_map):
+    """One value map fed by two cameras with different (fov, max_depth) per step (make_golden.two_camera_script); exact."""
     import sys
 
     if GOLDEN_DIR not in sys.path:
@@ -239,10 +227,5 @@ def replay_two_cameras(make_map, exact: bool, tol: float = 1e-4):
             k += 1
             vm.update_map(values, depth, tf, lo, hi, fov)
     conf = dense(g["conf_idx"], g["conf_val"], (1000, 1000), np.float32)
-    if exact:
-        assert np.array_equal(vm._map, conf)
-        assert sha(np.asarray(vm._value_map, np.float64)) == str(g["value_sha"])
-    else:
-        val = dense(g["conf_idx"], g["value_val"], (1000, 1000, 1), np.float64)
-        assert np.array_equal(np.asarray(vm._map) > 0, conf > 0)
-        assert np.abs(vm._map - conf).max() <= tol and np.abs(vm._value_map - val).max() <= tol
+    assert np.array_equal(vm._map, conf)
+    assert sha(np.asarray(vm._value_map, np.float64)) == str(g["value_sha"])

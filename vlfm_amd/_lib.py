@@ -126,7 +126,7 @@ def lib() -> ctypes.CDLL:
         L.vlfm_value_map_update_fused_batched.argtypes = [vp, ci, vp, vp, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci, cd, cd,
                                                           ci, ci, vp, vp, vp, vp, vp]
         L.vlfm_value_map_mask_unexplored_batched.argtypes = [vp, ci, ci, vp, vp, vp, ci, ci, vp]
-        L.vlfm_value_map_sort_waypoints_batched.argtypes = [vp, ci, ci, vp, ci, ci, vp, vp, vp]
+        L.vlfm_value_map_sort_waypoints_batched.argtypes = [vp, ci, ci, vp, ci, ci, vp, ci, vp, vp]
         L.vlfm_resample_coeffs_host.argtypes = [ci, ci, vp, vp, ci, ctypes.POINTER(ci)]
         L.vlfm_resample_coeffs_filter_host.argtypes = [ci, ci, ci, vp, vp, ci, ctypes.POINTER(ci)]
         L.vlfm_preprocess_sam_batched.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, vp, vp, ci, vp, vp, vp]
@@ -159,7 +159,7 @@ def lib() -> ctypes.CDLL:
         L.vlfm_obstacle_scratch_bytes.argtypes = [ci, ci, ci, ci]
         L.vlfm_obstacle_scratch_bytes.restype = ctypes.c_size_t
         L.vlfm_obstacle_map_update_batched.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, cd, vp, ctypes.c_size_t,
-                                                       ci, ci, vp, ci, vp, ci, ci, vp]
+                                                       ci, ci, vp, ci, vp, ci, ci, vp, vp]
         L.vlfm_obstacle_status.argtypes = [vp, ci, ci, ci, ci, vp]
         _lib = L
     return _lib

@@ -24,7 +24,9 @@ namespace vlfm {
 
 struct HoleArgs {
     const unsigned* holes;   // [n][H][hw]
-    int* status;             // [n][2]; word 1 = image has zeros (consumed: reset to 0 here)
+    int* status;             // [n][2]; word 1: bit 0 = image has zeros, bit 1 = the speculative scatter pass hit a cell off the
+                             //         map (consumed: reset to 0 here; bit 1 is promoted to word 0 = VLFM_ERR_INDEX unless the
+                             //         frame has islands, whose surviving texels hole_scatter_kernel places -- and judges -- again)
     unsigned* traced;        // [n][H][hw] scratch
     unsigned* neg;           // [n][H][hw]
     unsigned* fs;            // [n][H][hw] polygon fill: solid
@@ -53,7 +55,8 @@ __global__ __launch_bounds__(256) void fill_small_holes_kernel(HoleArgs a) {
     const int plane_words = a.H * a.hw;
     unsigned* filled = a.filled + poff;
     int* counts = a.counts + (size_t)obs * 4;
-    if (a.status[2 * obs + 1] == 0) {
+    const int st = a.status[2 * obs + 1];
+    if ((st & 1) == 0) {
         if (counts[3]) {  // the plane still holds a previous frame's fill
             for (int i = tid; i < plane_words; i += nth) filled[i] = 0u;
         }
@@ -61,6 +64,10 @@ __global__ __launch_bounds__(256) void fill_small_holes_kernel(HoleArgs a) {
         if (tid == 0) {
             counts[0] = 0; counts[1] = 0; counts[2] = 0; counts[3] = 0;
             if (a.journal_count) a.journal_count[obs] = 0;  // nothing to take back: the speculative pass stands
+            if (st & 2) {   // ... including its off-map hit: no hole, hence no island, the reference scatters that texel too
+                a.status[2 * obs] = VLFM_ERR_INDEX;
+                a.status[2 * obs + 1] = 0;
+            }
         }
         return;
     }
@@ -174,6 +181,9 @@ __global__ __launch_bounds__(256) void fill_small_holes_kernel(HoleArgs a) {
         counts[0] = n_contours; counts[1] = n_filled; counts[2] = overflow | (joverflow ? 2 : 0);
         counts[3] = 1 | (island ? 2 : 0);
         a.status[2 * obs + 1] = 0;  // consumed
+        // an off-map hit of the speculative pass stands unless this is an island frame (then every surviving valid texel is
+        // placed a second time by hole_scatter_kernel, which reports an off-map cell itself)
+        if ((st & 2) && !island) a.status[2 * obs] = VLFM_ERR_INDEX;
         if (a.journal_count) a.journal_count[obs] = 0;
     }
 }

@@ -14,6 +14,7 @@
 // see depth_ingest_kernel).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/vlfm_amd.h"
 #include "profile.h"
@@ -42,7 +43,8 @@ struct IngestArgs {
     const vlfm_ingest_params* prm;  // [n]
     unsigned* colmax_keys;          // [n][W] (zero-initialised keys) or null
     unsigned* obstacle;             // [n_envs][S][stride] bit-packed, or null
-    int* status;                    // [n][2]: (index error, saw zero depth)
+    int* status;                    // [n][2]: word 0 = index error (sticky); word 1 = bit 0 image has zero texels,
+                                    //         bit 1 the SPECULATIVE pass hit a cell off the map (both consumed by fill_small_holes)
     unsigned* hole_bits;            // [n][H][hw] OUT: bit plane of (depth == 0), or null
     const unsigned* filled_bits;    // [n][H][hw] IN: fill_small_holes' result (texel -> 1.0), or null
     int hw;                         // words per image row in hole/filled planes = ceil(W/32)
@@ -60,6 +62,7 @@ struct HeightBand {  // f32 shadow of the height test, widened by a safety margi
     float t8, t9, t10, t11, inv_fx, inv_fy, lo, hi;
     float zmin, zmax;    // range of scaled depth: d in [0, 1] -> z in [offset, scale + offset]
     float gx_lo, gx_hi;  // range over the image columns of  -t9 * (u - W/2) / fx
+    float depth_scale, depth_offset, depth_max;   // f32 copies of the parameter block's scalars (obstacle_map.py:92-93)
 };
 __device__ inline HeightBand make_band(const vlfm_ingest_params& p, int W, int H) {
     HeightBand b;
@@ -76,6 +79,7 @@ __device__ inline HeightBand make_band(const vlfm_ingest_params& p, int W, int H
     b.zmax = fmaxf(p.depth_offset, p.depth_offset + p.depth_scale);
     const float g0 = -b.t9 * (float)(0 - W / 2) * b.inv_fx, g1 = -b.t9 * (float)(W - 1 - W / 2) * b.inv_fx;
     b.gx_lo = fminf(g0, g1); b.gx_hi = fmaxf(g0, g1);
+    b.depth_scale = p.depth_scale; b.depth_offset = p.depth_offset; b.depth_max = p.depth_max;
     return b;
 }
 
@@ -93,30 +97,37 @@ __device__ inline bool row_may_hit(const HeightBand& b, int v, int H) {
     return !(z_hi + slack < b.lo || z_lo - slack > b.hi);  // NaN -> true
 }
 
-template <bool HOLE_PASS = false>
-__device__ inline void scatter_point(const IngestArgs& a, const vlfm_ingest_params& p, const HeightBand& band,
-                                     unsigned* grid, int obs, int u, int v, float d, bool filled) {
-    // fill_small_holes (img_utils.py:361-390) turned this texel into 1.0 -> z == max_depth -> masked out (:93)
-    if (filled) return;
-    if (!HOLE_PASS && d == 0.0f) {
-        // a hole in the depth image.  scatter bit 1: hole_area_thresh == -1 semantics (obstacle_map.py:87-89), every
-        // zero becomes 1.0 and therefore falls outside max_depth.  scatter bit 2: whether this zero survives
-        // fill_small_holes is not known yet -- hole_scatter_kernel places the survivors from the hole bit plane (an
-        // unfilled, large hole is used as it is: depth 0 -> z = min_depth, exactly like the reference).
-        if (p.scatter & 6) return;
-    }
+// ---- placement of one texel, in two halves -------------------------------------------------------------------------
+// candidate(): the cheap, branch-free f32 half every texel of a row that can reach the height band goes through.
+//   z = d * (max - min) + min in f32 (obstacle_map.py:92), masked by z < max_depth (:93), then a CONSERVATIVE f32 shadow of
+//   the height test: the exact f64 evaluation in place_exact() is what decides, but ~90 % of the texels (floor, ceiling) are
+//   far outside [min_height, max_height].  The f32 estimate of Z is within 1e-6 * (|row 3 of tf| . |point|) of the f64 value;
+//   the band is widened by 1e-4 of that magnitude, and NaNs pass (to the exact path).
+// place_exact(): unproject -> transform -> height band -> rint cell -> set the bit, every operation an explicitly rounded
+//   IEEE f64 operation in the reference's order.  Run DENSELY (one candidate per lane, see depth_ingest_kernel).
+__device__ inline bool candidate(const HeightBand& band, int W, int H, int u, int v, float d) {
+    const float z = __fadd_rn(__fmul_rn(d, band.depth_scale), band.depth_offset);  // obstacle_map.py:92 (f32)
+    const float xf = (float)(u - W / 2) * z * band.inv_fx, yf = (float)(v - H / 2) * z * band.inv_fy;
+    const float zf = band.t8 * z - band.t9 * xf - band.t10 * yf + band.t11;
+    return (z < band.depth_max) && !(zf < band.lo || zf > band.hi);                // :93, then the widened band
+}
+
+// The parameter block of an observation as wave-uniform values: read where it is needed (not carried through the streaming
+// loop) and forced into scalar registers -- the compiler does not prove the loads uniform by itself and would hold the 38
+// dwords in VECTOR registers across the whole drain loop, next to the f64 temporaries of two divisions.
+__device__ inline vlfm_ingest_params uniform_params(const vlfm_ingest_params* __restrict__ pp) {
+    vlfm_ingest_params p;
+    const int* src = reinterpret_cast<const int*>(pp);
+    int* dst = reinterpret_cast<int*>(&p);
+#pragma unroll
+    for (int u = 0; u < (int)(sizeof(vlfm_ingest_params) / 4); u++) dst[u] = __builtin_amdgcn_readfirstlane(src[u]);
+    return p;
+}
+
+template <bool HOLE_PASS>
+__device__ inline void place_exact(const IngestArgs& a, const vlfm_ingest_params& p, unsigned* grid, int obs, int u, int v,
+                                   float d) {
     const float z = __fadd_rn(__fmul_rn(d, p.depth_scale), p.depth_offset);  // obstacle_map.py:92 (f32)
-    if (!(z < p.depth_max)) return;                                          // :93
-    // Conservative f32 pre-test of the height band: the exact f64 evaluation below is what decides, but ~90 % of the
-    // texels (floor, ceiling) are far outside [min_height, max_height] and two f64 divisions + nine f64 products per
-    // texel would make this kernel compute-bound instead of HBM-bound.  The f32 estimate of Z is within
-    // 1e-6 * (|row 3 of tf| . |point|) of the f64 value; the band is widened by 1e-4 of that magnitude, and NaNs fall through
-    // to the exact path.
-    {
-        const float xf = (float)(u - a.W / 2) * z * band.inv_fx, yf = (float)(v - a.H / 2) * z * band.inv_fy;
-        const float zf = band.t8 * z - band.t9 * xf - band.t10 * yf + band.t11;
-        if (zf < band.lo || zf > band.hi) return;
-    }
     // get_point_cloud (geometry_utils.py:230-234): int64 * f32 -> f64, then / fx
     const double zd = (double)z;
     const double xc = __ddiv_rn(__dmul_rn((double)(u - a.W / 2), zd), p.fx);
@@ -136,20 +147,26 @@ __device__ inline void scatter_point(const IngestArgs& a, const vlfm_ingest_para
     long long row = (long long)rowf, col = (long long)colf;
     // NumPy fancy-index semantics (obstacle_map.py:101): [-S, -1] wraps, anything else outside raises IndexError
     if (row >= a.S || row < -a.S || col >= a.S || col < -a.S) {
-        a.status[2 * obs] = VLFM_ERR_INDEX;
+        // The speculative pass (fill_small_holes not evaluated yet) cannot know whether the reference would have seen this
+        // texel at all: an "island" texel inside a small hole becomes 1.0 and is dropped (img_utils.py:385-388) without
+        // ever reaching the scatter.  It only NOTES the hit (status word 1, bit 1); fill_small_holes_kernel promotes the
+        // note to the IndexError for frames without islands, and for island frames hole_scatter_kernel's second placement
+        // of the surviving texels raises it itself.
+        if (!HOLE_PASS && a.journal) atomicOr(&a.status[2 * obs + 1], 2);
+        else a.status[2 * obs] = VLFM_ERR_INDEX;
         return;
     }
     if (row < 0) row += a.S;
     if (col < 0) col += a.S;
-    // Obstacle bits are only ever SET between resets, so a plain (possibly stale) read that already shows the bit lets
-    // us skip the device-scope atomic: in steady state almost every in-band point re-observes a known obstacle cell.
+    // A plain (possibly stale) read that already shows the bit lets us skip the device-scope atomic: in steady state almost
+    // every in-band point re-observes a known obstacle cell.  (Bits are only cleared by reset() and by the island undo of
+    // fill_small_holes_kernel, which runs strictly after this kernel.)
     unsigned* word = &grid[(size_t)row * a.stride + (col >> 5)];
     const unsigned bit = 1u << (col & 31);
     if (!(*word & bit)) {
         const unsigned old = atomicOr(word, bit);
-        // Speculative single pass (fill_small_holes not evaluated yet): remember every bit this pass is the first to set.
-        // If the image turns out to hold valid texels INSIDE a filled hole contour ("islands": the reference rewrites
-        // them to 1.0 -> dropped, img_utils.py:385-388), fill_small_holes_kernel takes exactly these bits back and
+        // Speculative single pass: remember every bit this pass is the first to set.  If the image turns out to hold valid
+        // texels INSIDE a filled hole contour ("islands"), fill_small_holes_kernel takes exactly these bits back and
         // hole_scatter_kernel re-places the texels that survive.
         if (!HOLE_PASS && a.journal && !(old & bit)) {
             const int k = atomicAdd(&a.journal_count[obs], 1);
@@ -159,57 +176,104 @@ __device__ inline void scatter_point(const IngestArgs& a, const vlfm_ingest_para
 }
 
 // Work decomposition: a workgroup owns CG float4 column groups (CG*4 image columns, CG*16 contiguous bytes per row) and
-// a band of rows; lane (cx, ry) walks rows ry, ry+RL, ... of the band with UNROLL 16-byte loads in flight.  With one
-// band per image (the large-batch case) every column maximum is produced by exactly one workgroup -- no atomic
-// contention; small batches split the rows into bands to fill the chip and merge through atomicMax on the keys.
+// a band of rows; lane (cx, ry) walks rows ry, ry+RL, ... of the band with UNROLL 16-byte loads in flight, and the loads of
+// the NEXT iteration are issued before the current one is processed.  With one band per image (the large-batch case) every
+// column maximum is produced by exactly one workgroup -- no atomic contention; small batches split the rows into bands to
+// fill the chip and merge through atomicMax on the keys.
+//
+// Obstacle placement by IN-WORKGROUP COMPACTION (round 3).  Only ~8 % of the texels survive candidate(), and they sit in a
+// few image rows; calling the f64 placement from the streaming loop (rounds 1-2) kept both paths live in most wavefronts
+// and chained one dependent plane read per texel and lane: 142 us at 256 images, 0.28 of the HBM peak.  Now the streaming
+// loop only evaluates candidate() (a dozen f32 operations, no branch) into a 16-bit mask per lane and iteration; the
+// survivors are appended to a queue in LDS (wave prefix sum + one LDS atomic per wavefront; 8 bytes per entry: packed
+// (u, v) and the raw depth) and the WHOLE workgroup drains the queue with one candidate per lane: the f64 arithmetic runs
+// on full wavefronts and every plane read of a round is in flight at once.  Nothing goes through HBM (the first
+// design sketched -- a global candidate list and a second launch -- would have added ~100 MB of list traffic per 256
+// images).  The queue holds QCAP entries; an iteration with more candidates than that (a wall at band height filling the
+// tile) simply takes several append/drain rounds -- the loop is workgroup-uniform through __syncthreads_or.
 constexpr int CG = 32;   // float4 column groups per workgroup
 constexpr int RL = 16;   // row lanes per workgroup  -> 512 threads, a wavefront covers 2 rows x 512 B
+constexpr int INGEST_UNROLL = 4;
+constexpr int QCAP = 2048;   // candidate queue entries per workgroup (16 KB of LDS)
+constexpr int kIngestDefaultVariant = 0;   // 0 pf4 | 1 np4 | 2 np6 | 3 pf6 | 4 no register cap (see the stamped kernels)
 
-template <bool SCATTER>
-__global__ __launch_bounds__(CG * RL) void depth_ingest_kernel(IngestArgs a) {
+template <bool SCATTER, bool PREFETCH>
+__device__ __forceinline__ void depth_ingest_body(const IngestArgs& a) {
     __shared__ float4 part[RL][CG];
+    __shared__ uint2 queue[SCATTER ? QCAP : 1];
+    __shared__ unsigned q_tail;
+    __shared__ int sh_vlo, sh_vhi;
+    constexpr int UNROLL = INGEST_UNROLL;
     const int obs = blockIdx.z;
-    const int cx = threadIdx.x % CG, ry = threadIdx.x / CG;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int cx = tid % CG, ry = tid / CG;
     const int col4 = blockIdx.x * CG + cx;
     // Row bands are INTERLEAVED: band b owns the 16-row groups b, b + bands, b + 2 bands, ...  The texels that reach the
     // expensive f64 placement sit in a few adjacent image rows; contiguous bands would hand all of them to a fraction of
-    // the workgroups (wave divergence makes that path the critical one: a wavefront pays for it if any lane needs it).
+    // the workgroups.
     const int bands = gridDim.y, band_id = blockIdx.y;
     const int n_groups = (a.H + RL - 1) / RL;
-    const int r_end = a.H;
     const bool live = col4 < a.W4;
-    const vlfm_ingest_params p = a.prm[obs];
-    const HeightBand band = make_band(p, a.W, a.H);
+    const int p_scatter = a.prm[obs].scatter, p_env = a.prm[obs].env;
+    const HeightBand band = make_band(a.prm[obs], a.W, a.H);
     const float* img = a.depth + (size_t)obs * a.H * a.W;
     unsigned* grid = nullptr;
-    if (SCATTER) grid = a.obstacle + (size_t)p.env * a.S * a.stride;
+    if (SCATTER) grid = a.obstacle + (size_t)p_env * a.S * a.stride;
     unsigned* holes = a.hole_bits ? a.hole_bits + (size_t)obs * a.H * a.hw : nullptr;
     const unsigned* filled = a.filled_bits ? a.filled_bits + (size_t)obs * a.H * a.hw : nullptr;
     const float ninf = -__builtin_huge_valf();
     float4 m = make_float4(ninf, ninf, ninf, ninf);
     bool saw_zero = false;
     const bool scatter_only = a.colmax_keys == nullptr && holes == nullptr;  // the pass after fill_small_holes
-    constexpr int UNROLL = 4;
-    // every lane of the workgroup runs the same trip count (predicated), so the cross-lane packing of hole bits below is
-    // always executed convergently
-    for (int g0 = band_id; g0 < n_groups; g0 += UNROLL * bands) {
-        float4 d[UNROLL];
-        bool rowok[UNROLL], rowhit[UNROLL];
+    const bool do_scatter = SCATTER && (p_scatter & 1);
+    // hull [v_lo, v_hi] of the image rows that can reach the height band at all (row_may_hit is exact per row; the hull
+    // only lets a whole iteration skip the workgroup barrier of the placement rounds)
+    int v_lo = a.H, v_hi = -1;
+    if (SCATTER) {
+        if (tid == 0) { q_tail = 0u; sh_vlo = a.H; sh_vhi = -1; }
+        __syncthreads();
+        int lo = a.H, hi = -1;
+        if (do_scatter)
+            for (int v = tid; v < a.H; v += CG * RL)
+                if (row_may_hit(band, v, a.H)) { lo = min(lo, v); hi = max(hi, v); }
+        if (hi >= 0) { atomicMin(&sh_vlo, lo); atomicMax(&sh_vhi, hi); }
+        __syncthreads();
+        v_lo = sh_vlo; v_hi = sh_vhi;
+    }
+    unsigned drained = 0u;   // absolute queue index of the first entry not drained yet (identical in every thread)
+
+    // one iteration's loads: rows (g0 + k * bands) * RL + ry, k < UNROLL.  Rows that cannot reach the height band are not
+    // even loaded by a scatter-only pass; a combined pass loads them (column maximum, hole bits) but never tests them.
+    float4 nxt[UNROLL];
+    unsigned nxt_ok = 0u, nxt_hit = 0u;
+    auto issue = [&](int g0) {
+        nxt_ok = 0u; nxt_hit = 0u;
 #pragma unroll
         for (int k = 0; k < UNROLL; k++) {
             const int r = (g0 + k * bands) * RL + ry;
-            bool want = live && r < r_end;
-            // rows that cannot reach the height band: not even loaded by a scatter-only pass, loaded (column maximum,
-            // hole bits) but not offered to the placement path by a combined pass
-            rowhit[k] = SCATTER && want && row_may_hit(band, r, a.H);
-            if (SCATTER && scatter_only) want = rowhit[k];
-            rowok[k] = want;
-            d[k] = want ? reinterpret_cast<const float4*>(img + (size_t)r * a.W)[col4] : make_float4(ninf, ninf, ninf, ninf);
+            bool want = live && r < a.H;
+            const bool hit = SCATTER && want && r >= v_lo && r <= v_hi && row_may_hit(band, r, a.H);
+            if (SCATTER && scatter_only) want = hit;
+            nxt[k] = want ? reinterpret_cast<const float4*>(img + (size_t)r * a.W)[col4] : make_float4(ninf, ninf, ninf, ninf);
+            nxt_ok |= (want ? 1u : 0u) << k;
+            nxt_hit |= (hit ? 1u : 0u) << k;
         }
+    };
+    if (PREFETCH && band_id < n_groups) issue(band_id);
+    // every lane of the workgroup runs the same trip count (predicated), so the cross-lane packing of hole bits and the
+    // workgroup barriers of the placement rounds are always executed convergently
+    for (int g0 = band_id; g0 < n_groups; g0 += UNROLL * bands) {
+        if (!PREFETCH) issue(g0);
+        float4 d[UNROLL];
+#pragma unroll
+        for (int k = 0; k < UNROLL; k++) d[k] = nxt[k];
+        const unsigned okmask = nxt_ok, hitmask = nxt_hit;
+        if (PREFETCH && g0 + UNROLL * bands < n_groups) issue(g0 + UNROLL * bands);
+        unsigned cand = 0u;   // bit 4k + c: texel c of this lane's float4 of row group k needs the exact placement
 #pragma unroll
         for (int k = 0; k < UNROLL; k++) {
             const int r = (g0 + k * bands) * RL + ry;
-            const bool ok = rowok[k];
+            const bool ok = (okmask >> k) & 1u;
             m.x = fmaxf(m.x, d[k].x); m.y = fmaxf(m.y, d[k].y); m.z = fmaxf(m.z, d[k].z); m.w = fmaxf(m.w, d[k].w);
             if (holes) {
                 // (depth == 0) bit plane: 4 texels per lane, 8 neighbouring lanes (same row) per 32-bit word.  Four
@@ -220,25 +284,106 @@ __global__ __launch_bounds__(CG * RL) void depth_ingest_kernel(IngestArgs a) {
                 if (ok && (cx & 7) == 0) {
                     unsigned word = 0u;
                     if (b0 | b1 | b2 | b3) {
-                        const int sh = (threadIdx.x & 63) & ~7;
+                        const int sh = lane & ~7;
                         word = spread8((unsigned)(b0 >> sh) & 0xFFu) | (spread8((unsigned)(b1 >> sh) & 0xFFu) << 1) |
                                (spread8((unsigned)(b2 >> sh) & 0xFFu) << 2) | (spread8((unsigned)(b3 >> sh) & 0xFFu) << 3);
                     }
                     holes[(size_t)r * a.hw + (col4 >> 3)] = word;
                 }
             }
-            if (SCATTER && (p.scatter & 1) && rowhit[k]) {
-                unsigned fnib = 0u;
-                if (filled) fnib = (filled[(size_t)r * a.hw + (col4 >> 3)] >> ((col4 & 7) * 4)) & 0xFu;
+            if (do_scatter && ((hitmask >> k) & 1u)) {
+                // fill_small_holes (img_utils.py:361-390) turned a `filled` texel into 1.0 -> z == max_depth -> masked (:93).
+                // A zero texel is a hole in the depth image.  scatter bit 1: hole_area_thresh == -1 semantics
+                // (obstacle_map.py:87-89), every zero becomes 1.0 and therefore falls outside max_depth.  scatter bit 2:
+                // whether this zero survives fill_small_holes is not known yet -- hole_scatter_kernel places the survivors
+                // from the hole bit plane (an unfilled, large hole is used as it is: depth 0 -> z = min_depth).
+                unsigned skip = 0u;
+                if (filled) skip = (filled[(size_t)r * a.hw + (col4 >> 3)] >> ((col4 & 7) * 4)) & 0xFu;
+                if (p_scatter & 6)
+                    skip |= (d[k].x == 0.0f ? 1u : 0u) | (d[k].y == 0.0f ? 2u : 0u) | (d[k].z == 0.0f ? 4u : 0u) |
+                            (d[k].w == 0.0f ? 8u : 0u);
                 const int u = col4 * 4;
-                scatter_point(a, p, band, grid, obs, u + 0, r, d[k].x, fnib & 1u);
-                scatter_point(a, p, band, grid, obs, u + 1, r, d[k].y, fnib & 2u);
-                scatter_point(a, p, band, grid, obs, u + 2, r, d[k].z, fnib & 4u);
-                scatter_point(a, p, band, grid, obs, u + 3, r, d[k].w, fnib & 8u);
+                unsigned c4 = (candidate(band, a.W, a.H, u + 0, r, d[k].x) ? 1u : 0u) |
+                              (candidate(band, a.W, a.H, u + 1, r, d[k].y) ? 2u : 0u) |
+                              (candidate(band, a.W, a.H, u + 2, r, d[k].z) ? 4u : 0u) |
+                              (candidate(band, a.W, a.H, u + 3, r, d[k].w) ? 8u : 0u);
+                cand |= (c4 & ~skip) << (4 * k);
             }
         }
+        if (!SCATTER || !do_scatter) continue;
+        {   // can any row of this iteration reach the band?  (workgroup-uniform: depends on g0 only)
+            bool may = false;
+#pragma unroll
+            for (int k = 0; k < UNROLL; k++) {
+                const int r0 = (g0 + k * bands) * RL;
+                may |= r0 <= v_hi && r0 + RL - 1 >= v_lo && r0 < a.H;
+            }
+            if (!may) continue;
+        }
+        // ---- placement rounds: append the lanes' candidates to the LDS queue, drain it with one candidate per lane.
+        // The first round takes the texels from the registers they were loaded into; a further round (more than QCAP
+        // candidates in one iteration: rare) re-reads its leftovers from the image (L2), so that the 16 loaded values are
+        // dead during the f64 drain instead of occupying registers next to it.
+        auto append = [&](const float4 (&dd)[UNROLL]) {
+            const int cnt = __builtin_popcount(cand);
+            int incl = cnt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += t;
+            }
+            const int total = __shfl(incl, 63, 64);
+            unsigned base = 0u;
+            if (lane == 0 && total) base = atomicAdd(&q_tail, (unsigned)total);
+            base = (unsigned)__shfl((int)base, 0, 64);
+            unsigned slot = base + (unsigned)(incl - cnt) - drained;   // queue slot of this lane's first candidate
+            const unsigned pos0 = ((unsigned)(col4 * 4)) | ((unsigned)ry << 16);
+#pragma unroll
+            for (int k = 0; k < UNROLL; k++) {
+                const unsigned rbits = (unsigned)((g0 + k * bands) * RL) << 16;
+                const float dv[4] = {dd[k].x, dd[k].y, dd[k].z, dd[k].w};
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const unsigned bit = 1u << (4 * k + c);
+                    if (cand & bit) {
+                        if (slot < (unsigned)QCAP) {
+                            queue[slot] = make_uint2(pos0 + rbits + (unsigned)c, __float_as_uint(dv[c]));
+                            cand &= ~bit;
+                        }
+                        slot++;
+                    }
+                }
+            }
+        };
+        auto drain = [&]() {
+            __syncthreads();
+            const unsigned tail = q_tail;
+            const unsigned n_q = min(tail - drained, (unsigned)QCAP);
+            if (tid < n_q) {
+                const vlfm_ingest_params p = uniform_params(a.prm + obs);
+                for (unsigned i = tid; i < n_q; i += CG * RL) {
+                    const uint2 e = queue[i];
+                    place_exact<false>(a, p, grid, obs, (int)(e.x & 0xFFFFu), (int)(e.x >> 16), __uint_as_float(e.y));
+                }
+            }
+            drained = tail;
+        };
+        if (!__syncthreads_or(cand != 0u)) continue;   // (also: the previous iteration's drain has finished with the queue)
+        append(d);
+        drain();
+        while (__syncthreads_or(cand != 0u)) {
+            float4 again[UNROLL];
+#pragma unroll
+            for (int k = 0; k < UNROLL; k++) {
+                const int r = (g0 + k * bands) * RL + ry;
+                again[k] = ((cand >> (4 * k)) & 0xFu) ? reinterpret_cast<const float4*>(img + (size_t)r * a.W)[col4]
+                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            append(again);
+            drain();
+        }
     }
-    if (saw_zero) a.status[2 * obs + 1] = 1;
+    if (saw_zero) atomicOr(&a.status[2 * obs + 1], 1);
     if (a.colmax_keys == nullptr) return;
     part[ry][cx] = m;
     __syncthreads();
@@ -255,6 +400,21 @@ __global__ __launch_bounds__(CG * RL) void depth_ingest_kernel(IngestArgs a) {
         atomicMax(out + 3, f32_key(m.w));
     }
 }
+
+// The streaming pass without obstacles (ValueMapBatch.column_max) and the combined pass in its variants: software
+// prefetch of the next iteration's rows on / off, and the register budget (waves per SIMD) the compiler is held to --
+// 512-thread workgroups occupy 2 waves per SIMD each, so 4 = two workgroups per CU, 6 = three.  tools/ingest_probe.py times
+// them; vlfm_depth_ingest_batched picks VLFM_INGEST_VARIANT (default: kIngestDefaultVariant).
+template <bool SCATTER>
+__global__ __launch_bounds__(CG * RL) void depth_ingest_kernel(IngestArgs a) { depth_ingest_body<SCATTER, false>(a); }
+__global__ __launch_bounds__(CG * RL) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void depth_ingest_scatter_pf4_kernel(IngestArgs a) { depth_ingest_body<true, true>(a); }
+__global__ __launch_bounds__(CG * RL) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void depth_ingest_scatter_np4_kernel(IngestArgs a) { depth_ingest_body<true, false>(a); }
+__global__ __launch_bounds__(CG * RL) __attribute__((amdgpu_waves_per_eu(6, 6)))
+void depth_ingest_scatter_np6_kernel(IngestArgs a) { depth_ingest_body<true, false>(a); }
+__global__ __launch_bounds__(CG * RL) __attribute__((amdgpu_waves_per_eu(6, 6)))
+void depth_ingest_scatter_pf6_kernel(IngestArgs a) { depth_ingest_body<true, true>(a); }
 
 // The zero texels that fill_small_holes left alone (holes of area >= hole_area_thresh), placed from the bit planes: the
 // depth images are not read again.  One thread per 32-texel word of (hole & ~filled); frames without a zero texel
@@ -283,13 +443,13 @@ __global__ __launch_bounds__(256) void hole_scatter_kernel(IngestArgs a, const i
     while (w) {
         const int b = __builtin_ctz(w);
         w &= w - 1u;
-        if (u0 + b < a.W) scatter_point<true>(a, p, band, grid, obs, u0 + b, v, 0.0f, false);
+        if (u0 + b < a.W && candidate(band, a.W, a.H, u0 + b, v, 0.0f)) place_exact<true>(a, p, grid, obs, u0 + b, v, 0.0f);
     }
     const float* row = a.depth ? a.depth + ((size_t)obs * a.H + v) * a.W + u0 : nullptr;
     while (redo) {
         const int b = __builtin_ctz(redo);
         redo &= redo - 1u;
-        scatter_point<true>(a, p, band, grid, obs, u0 + b, v, row[b], false);
+        if (candidate(band, a.W, a.H, u0 + b, v, row[b])) place_exact<true>(a, p, grid, obs, u0 + b, v, row[b]);
     }
 }
 
@@ -326,6 +486,7 @@ extern "C" int vlfm_depth_ingest_batched(const float* d_depth, int n, int height
     if (!d_depth || !d_params || !d_status || n < 0 || height <= 0 || width <= 0)
         return fail(VLFM_ERR_INVALID, "depth_ingest_batched: bad argument");
     if (width % 4 != 0) return fail(VLFM_ERR_INVALID, "depth_ingest_batched: width must be a multiple of 4");
+    if (width > 65535 || height > 65535) return fail(VLFM_ERR_INVALID, "depth_ingest_batched: image sides must fit 16 bits");
     if (!d_colmax_keys && !d_obstacle && !d_hole_bits) return VLFM_OK;
     hipStream_t s = (hipStream_t)stream;
     IngestArgs a;
@@ -352,7 +513,17 @@ extern "C" int vlfm_depth_ingest_batched(const float* d_depth, int n, int height
         // profile name: the streaming pass (column maxima [+ hole bits]) is "depth_ingest_kernel"; a pass that ALSO or
         // ONLY scatters obstacle points is reported separately
         VLFM_TIMED(d_colmax_keys ? "depth_ingest_scatter_kernel" : "depth_scatter_kernel", s);
-        VLFM_KLAUNCH(depth_ingest_kernel<true>, dim3(gx, gy, n), dim3(CG * RL), 0, s, a);
+        static const int variant = [] {
+            const char* e = getenv("VLFM_INGEST_VARIANT");
+            return e ? atoi(e) : kIngestDefaultVariant;
+        }();
+        switch (variant) {
+            case 1: VLFM_KLAUNCH(depth_ingest_scatter_np4_kernel, dim3(gx, gy, n), dim3(CG * RL), 0, s, a); break;
+            case 2: VLFM_KLAUNCH(depth_ingest_scatter_np6_kernel, dim3(gx, gy, n), dim3(CG * RL), 0, s, a); break;
+            case 3: VLFM_KLAUNCH(depth_ingest_scatter_pf6_kernel, dim3(gx, gy, n), dim3(CG * RL), 0, s, a); break;
+            case 4: VLFM_KLAUNCH(depth_ingest_kernel<true>, dim3(gx, gy, n), dim3(CG * RL), 0, s, a); break;  // compiler's choice
+            default: VLFM_KLAUNCH(depth_ingest_scatter_pf4_kernel, dim3(gx, gy, n), dim3(CG * RL), 0, s, a); break;
+        }
     } else {
         VLFM_TIMED("depth_ingest_kernel", s);
         VLFM_KLAUNCH(depth_ingest_kernel<false>, dim3(gx, gy, n), dim3(CG * RL), 0, s, a);

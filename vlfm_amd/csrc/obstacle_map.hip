@@ -14,7 +14,9 @@
 //                        and their arc-length midpoints                                         obstacle_map.py:155-169 + B3
 //
 // Dense work (dilations, masks, rasterisation, packing) is data-parallel over words/pixels; the order-dependent part
-// (border chains) is a single-lane walk driven by a wave-parallel scan (bitmap.h).  No MFMA; bit and integer work.
+// (Suzuki-Abe border chains) is followed by the WHOLE workgroup: successor tables + list ranking by pointer jumping
+// (border_parallel.h), with the one-lane walk of bitmap.h kept for short borders and as the fallback.  No MFMA; bit and
+// integer work.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -440,17 +442,53 @@ __device__ inline WalkTables fog_walk_tables(const FogScratch& sc, int env, int 
 }
 
 // navigable = ~dilate(obstacles, k x k) (obstacle_map.py:105-109); explored &= navigable (obstacle_map.py:127 -- applied
-// ahead of this step's reveal, which only ever adds navigable cells, so the order is immaterial)
+// ahead of this step's reveal, which only ever adds navigable cells, so the order is immaterial).
+//
+// DIRTY WINDOWS (round 3).  The reference recomputes both over the whole S x S map every step; but obstacle bits only change
+// within the camera's reach of the frames ingested since the last recompute, so `navigable` only changes inside that
+// window grown by the dilation radius; and `explored &= navigable` only has to visit the bounding box of everything ever
+// revealed (no explored bit exists outside it; the box is persistent device state maintained by fog_of_war_kernel).  The
+// box, not a window of `navigable` changes: explored_select's filled contour (obstacle_map.py:145) may set explored bits
+// on non-navigable cells anywhere inside the explored area, which the NEXT step's masking takes away again.
+// The caller accumulates two windows per environment (ObstacleMapBatch: full map after reset(), after a frame whose reach
+// leaves the map -- negative indices wrap, obstacle_map.py:101 -- or with a non-rigid camera transform) and hands them over
+// per observation:
+//   win[0..3]  rows / columns (inclusive y0, y1, x0, x1) where `navigable` has to be recomputed (empty: y1 < y0)
+//   win[4..7]  where `navigable` may have changed since the last explore step: the frontier stage's derived planes are
+//              refreshed there (frontier_prepare_kernel)
+// One thread per 32-cell word; a workgroup (256 words = 8 rows at S = 1000) whose rows miss both windows exits on two scalar
+// compares.  win == null: the full-plane pass of rounds 1-2 (101 us at 256 environments against the window's ~6 us).
+struct DirtyWin { int y0, y1, x0, x1; };
+__device__ inline DirtyWin load_win(const int* __restrict__ w, int S) {
+    if (!w) return DirtyWin{0, S - 1, 0, S - 1};
+    return DirtyWin{w[0], w[1], w[2], w[3]};
+}
+__device__ inline bool rows_hit(const DirtyWin& d, int ya, int yb) { return d.y1 >= d.y0 && yb >= d.y0 && ya <= d.y1; }
+__device__ inline bool word_hit(const DirtyWin& d, int y, int wi) {
+    return d.y1 >= d.y0 && y >= d.y0 && y <= d.y1 && wi >= (d.x0 >> 5) && wi <= (d.x1 >> 5);
+}
+
 __global__ __launch_bounds__(256) void navigable_kernel(const FogParams* __restrict__ prm, MapPlanes mp, int radius,
-                                                        int update_obstacles, int explore) {
+                                                        int update_obstacles, int explore, const int* __restrict__ windows,
+                                                        const int* __restrict__ bbox) {
     const int e = prm[blockIdx.z].env;
     const int S = mp.S, stride = mp.stride;
     const size_t off = (size_t)e * S * stride;
+    const int* w = windows ? windows + 8 * blockIdx.z : nullptr;
+    const DirtyWin w_nav = load_win(w, S), w_mask = load_win(w ? bbox + (size_t)e * 4 : nullptr, S);
+    const bool do_mask = explore && prm[blockIdx.z].n_poly > 0;   // only the explore branch masks (:127)
+    {   // rows of this workgroup against the windows (uniform)
+        const int ya = (blockIdx.x * blockDim.x) / stride, yb = min(S - 1, (blockIdx.x * blockDim.x + blockDim.x - 1) / stride);
+        if (!((update_obstacles && rows_hit(w_nav, ya, yb)) || (do_mask && rows_hit(w_mask, ya, yb)))) return;
+    }
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= S * stride) return;
     const int y = idx / stride, wi = idx - y * stride;
+    const bool recompute = update_obstacles && word_hit(w_nav, y, wi);
+    const bool mask = do_mask && word_hit(w_mask, y, wi);
+    if (!recompute && !mask) return;
     unsigned nav;
-    if (update_obstacles) {
+    if (recompute) {
         const unsigned* src = mp.obstacle + off;
         unsigned acc = 0;
         for (int dy = -radius; dy <= radius; dy++)
@@ -461,7 +499,10 @@ __global__ __launch_bounds__(256) void navigable_kernel(const FogParams* __restr
     } else {
         nav = mp.navigable[off + idx];
     }
-    if (explore && prm[blockIdx.z].n_poly > 0) mp.explored[off + idx] &= nav;  // only the explore branch masks (:127)
+    if (mask) {
+        const unsigned ex = mp.explored[off + idx];
+        if (ex & ~nav) mp.explored[off + idx] = ex & nav;
+    }
 }
 
 __device__ inline unsigned load_window_word(const unsigned* plane, int S, int stride, int ox, int oy, int ly, int lw) {
@@ -866,6 +907,7 @@ struct FrontierScratch {
     const int* sel_status;  // [n_envs][4] of explored_select_kernel: word 0 = contour scratch overflow
     unsigned* walk_jd; int* walk_pixbase;  // parallel border follower, as in SelectScratch
     int walk_states;
+    int* derived_dirty;     // [n_envs]: explored_d holds this step's pocket fills -> frontier_prepare_kernel rebuilds the plane
 };
 
 __device__ inline unsigned ring_all_set(const unsigned* plane, int S, int stride, int tid, int nth) {
@@ -886,17 +928,35 @@ __device__ inline int reflect101(int i, int n) {
 
 // obstacle_map.py:159-163 + the first lines of detect_frontier_waypoints: explored_d = dilate(explored, 5x5) & navigable,
 // unexplored = navigable & ~explored_d, for every listed environment, one thread per 32-cell word.
+// Both planes are pure functions of (explored, navigable) with a 5 x 5 footprint, and they persist per environment: they
+// only have to be refreshed where an input may have changed since the last explore step -- inside the bounding box of
+// everything ever revealed (every change of `explored`: reveal, masking, component selection) grown by the footprint, and
+// inside the caller's window of `navigable` changes (win[4..7], see navigable_kernel).  Exception: last step's
+// filter_out_small_unexplored marked a pocket explored IN `explored_d` (frontier_kernel, the rare non-shortcut path; flagged
+// in `derived_dirty`): then the whole plane is rebuilt.
 __global__ __launch_bounds__(256) void frontier_prepare_kernel(const FogParams* __restrict__ prm, MapPlanes mp,
                                                                unsigned* __restrict__ explored_d,
-                                                               unsigned* __restrict__ unexplored) {
+                                                               unsigned* __restrict__ unexplored,
+                                                               const int* __restrict__ windows, const int* __restrict__ bbox,
+                                                               const int* __restrict__ derived_dirty) {
     const FogParams& P = prm[blockIdx.z];
     if (P.n_poly <= 0) return;
     const int S = mp.S, stride = mp.stride;
+    const bool full = !windows || derived_dirty[P.env] != 0;
+    const DirtyWin w_nav = load_win(full ? nullptr : windows + 8 * blockIdx.z + 4, S);
+    DirtyWin w_box{0, -1, 0, -1};
+    if (!full) {
+        const int* bb = bbox + (size_t)P.env * 4;
+        if (bb[1] >= bb[0]) w_box = DirtyWin{max(bb[0] - 3, 0), min(bb[1] + 3, S - 1), max(bb[2] - 3, 0), min(bb[3] + 3, S - 1)};
+        const int ya = (blockIdx.x * blockDim.x) / stride, yb = min(S - 1, (blockIdx.x * blockDim.x + blockDim.x - 1) / stride);
+        if (!rows_hit(w_nav, ya, yb) && !rows_hit(w_box, ya, yb)) return;
+    }
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= S * stride) return;
+    const int y = idx / stride, wi = idx - y * stride;
+    if (!full && !word_hit(w_nav, y, wi) && !word_hit(w_box, y, wi)) return;
     const size_t eoff = (size_t)P.env * S * stride;
     const unsigned* expl = mp.explored + eoff;
-    const int y = idx / stride, wi = idx - y * stride;
     unsigned acc = 0;
     for (int dy = -2; dy <= 2; dy++)
         acc |= hdilate(row_word(expl, stride, S, y + dy, wi - 1), row_word(expl, stride, S, y + dy, wi),
@@ -942,6 +1002,7 @@ __global__ __launch_bounds__(1024) void frontier_kernel(const FogParams* __restr
     if (!ring_ok) atomicAnd(&sh_i[0], 0);
     __syncthreads();
     const bool shortcut = sh_i[0] && ((double)(S - 1) * (double)(S - 1) >= sc.area_thresh);
+    if (tid == 0) sc.derived_dirty[P.env] = shortcut ? 0 : 1;   // the other branch may write pocket fills into explored_d
     if (!shortcut) {
         for (int i = tid; i < S * stride; i += nth) { traced[i] = 0u; neg[i] = 0u; }
         __threadfence();
@@ -1377,7 +1438,8 @@ extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, in
                                                 int n_envs, int map_size, int kernel_size, int fog_radius,
                                                 double area_thresh_px, void* d_scratch, size_t scratch_bytes,
                                                 int cap_pts, int cap_contours, double* d_frontiers, int cap_frontiers,
-                                                int32_t* d_counts, int update_obstacles, int explore, void* stream) {
+                                                int32_t* d_counts, int update_obstacles, int explore,
+                                                const int32_t* d_windows, void* stream) {
     if (n == 0) return VLFM_OK;
     if (!d_prm || !d_obstacle || !d_navigable || !d_explored || !d_bbox || !d_scratch || !d_frontiers || !d_counts ||
         n < 0 || map_size <= 0 || map_size > 2048 || kernel_size < 1 || !(kernel_size & 1) || kernel_size > 63 ||
@@ -1399,7 +1461,7 @@ extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, in
     if (update_obstacles || explore) {
         VLFM_TIMED("navigable_kernel", s);
         VLFM_KLAUNCH(navigable_kernel, dim3((map_size * stride + 255) / 256, 1, n), dim3(256), 0, s, d_prm, mp,
-                           kernel_size / 2, update_obstacles, explore);
+                           kernel_size / 2, update_obstacles, explore, d_windows, (const int*)d_bbox);
     }
     int rc = check_launch("navigable_kernel");
     if (rc != VLFM_OK || !explore) return rc;
@@ -1412,12 +1474,13 @@ extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, in
         if (lds > 160 * 1024) return fail(VLFM_ERR_CAPACITY, "obstacle_map_update_batched: fog window too large for LDS");
         // what is left of 152 KB holds the border follower's list-ranking buffers (two words per state; a window of 205 x 205
         // cells has a few thousand states): a ranking round is then an LDS round trip instead of an L2 one
-        fs.lds_states = (int)((152 * 1024 - lds) / 8);
-        if (fs.lds_states > 16384) fs.lds_states = 16384;
+        // (0 when the planes alone pass 152 KB: the follower then ranks in its global buffers, border_parallel.h)
+        const size_t budget = (size_t)152 * 1024;
+        fs.lds_states = lds < budget ? (int)((budget - lds) / 8 < 16384 ? (budget - lds) / 8 : 16384) : 0;
         lds += (size_t)fs.lds_states * 8;
-        if (lds > 64 * 1024)  // beyond the default dynamic-LDS limit (max_depth * pixels_per_meter > ~110 cells)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fog_of_war_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        static LdsOptIn opt_fog;   // beyond the default dynamic-LDS limit of 64 KB: opt in once per device, to the maximum
+        if (lds > 64 * 1024 && !opt_fog.ensure(reinterpret_cast<const void*>(fog_of_war_kernel), 160 * 1024))
+            return fail(VLFM_ERR_HIP, "obstacle_map_update_batched: cannot opt in to 160 KB of LDS for the fog-of-war kernel");
         VLFM_TIMED("fog_of_war_kernel", s);
         VLFM_KLAUNCH(fog_of_war_kernel, dim3(n), dim3(1024), lds, s, d_prm, mp, fs);
     }
@@ -1443,11 +1506,11 @@ extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, in
                            (unsigned char*)(base + L.off_bad), (int*)(base + L.off_pieces), d_frontiers, d_counts,
                            cap_pts, cap_contours, cap_frontiers, area_thresh_px, kWalkLdsBytes, status,
                            status + (size_t)n_envs * 4, (unsigned*)lines, (int*)(base + L.off_pixbase),
-                           2 * cap_pts > 65535 ? 65535 : 2 * cap_pts};
+                           2 * cap_pts > 65535 ? 65535 : 2 * cap_pts, status + (size_t)n_envs * 8};
         {
             VLFM_TIMED("frontier_prepare_kernel", s);
             VLFM_KLAUNCH(frontier_prepare_kernel, dim3((map_size * stride + 255) / 256, 1, n), dim3(256), 0, s, d_prm, mp,
-                         planes[4], planes[5]);
+                         planes[4], planes[5], d_windows, (const int*)d_bbox, (const int*)(status + (size_t)n_envs * 8));
         }
         VLFM_TIMED("frontier_kernel", s);
         VLFM_KLAUNCH(frontier_kernel, dim3(n), dim3(1024), kWalkLdsBytes, s, d_prm, mp, fr, (const int*)d_bbox);

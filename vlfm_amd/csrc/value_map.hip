@@ -2,7 +2,10 @@
 //
 // Data layout in HBM (per GPU, n_envs environment slots resident for the whole episode):
 //   conf  [n_envs][S][S]     f32   BaseMap._map of the ValueMap          (base_map.py:23)
-//   value [n_envs][S][S][C]  f32   ValueMap._value_map, channel-last     (value_map.py:66)
+//   value [n_envs][S][S][C]  f64   ValueMap._value_map, channel-last     (value_map.py:66).  f64 because the reference's
+//                                    array IS f64 after the first weighted fuse (`values` is an f64 ndarray, :423); in the
+//                                    modes that keep it f32 (max-confidence :406, replace :381-384) the stored doubles are
+//                                    f32-representable, so the map is the reference's to the last bit in every mode
 // Per step and observation:  colmax [W] f32 (from depth ingest), pose (64 B), values [C] f64.
 //
 // Kernels (all HBM/LDS integer+float work, no MFMA):
@@ -79,7 +82,7 @@ struct UpdateArgs {
                               // (template > 0) & ~(beyond the depth profile)
     const double* values;     // [n][C]
     float* conf;              // [n_envs][S][S]
-    float* value;             // [n_envs][S][S][C]
+    double* value;            // [n_envs][S][S][C]
     const unsigned* explored; // [n_envs][S][ceil(S/32)] bit-packed ObstacleMap.explored_area, or null
     int W, T, S, C;
     int vis_stride;           // words per observation in `visible` (T * words rounded up to a multiple of 4)
@@ -188,11 +191,11 @@ __device__ inline bool vis_test(const unsigned* vis, int words, int T, int y, in
 
 // The fusion arithmetic of one cell (value_map.py:377-429).  Returns false when the cell is left untouched.
 template <int C>
-__device__ inline bool fuse_cell(const UpdateArgs& a, float nw, float old, const float* oldv, const double* vals,
-                                 float& conf_out, float* value_out) {
+__device__ inline bool fuse_cell(const UpdateArgs& a, float nw, float old, const double* oldv, const double* vals,
+                                 float& conf_out, double* value_out) {
     if (a.fusion == VLFM_FUSE_REPLACE) {  // (:377-385)
         conf_out = nw;
-        for (int c = 0; c < C; c++) value_out[c] = (float)vals[c];
+        for (int c = 0; c < C; c++) value_out[c] = (double)(float)vals[c];   // assignment into the f32 array (:381-384)
         return true;
     }
     if (a.fusion == VLFM_FUSE_EQUAL_WEIGHTING) {  // (:386-391)
@@ -203,14 +206,15 @@ __device__ inline bool fuse_cell(const UpdateArgs& a, float nw, float old, const
     if (a.use_max_conf) {                       // (:401-408)
         if (!(nw > old)) return false;
         conf_out = nw;
-        for (int c = 0; c < C; c++) value_out[c] = (float)vals[c];
+        for (int c = 0; c < C; c++) value_out[c] = (double)(float)vals[c];   // masked assignment, array stays f32 (:406)
         return true;
     }
-    // weighted average (:414-424): weights in f32, value blend in f64 (values is an f64 ndarray), conf in f32
+    // weighted average (:414-424): weights in f32; the value blend is f64 * f64(w) + f64 * f64(w) and the RESULT STAYS f64
+    // (`_value_map` is re-bound to the f64 product, :423) -- kept in f64 here too, so no rounding the reference does not do
     const float den = __fadd_rn(old, nw);
     const float w_old = __fdiv_rn(old, den), w_new = __fdiv_rn(nw, den);
     for (int c = 0; c < C; c++)
-        value_out[c] = (float)__dadd_rn(__dmul_rn((double)oldv[c], (double)w_old), __dmul_rn(vals[c], (double)w_new));
+        value_out[c] = __dadd_rn(__dmul_rn(oldv[c], (double)w_old), __dmul_rn(vals[c], (double)w_new));
     conf_out = __fadd_rn(__fmul_rn(old, w_old), __fmul_rn(nw, w_new));
     return true;
 }
@@ -225,7 +229,7 @@ __device__ inline void fuse_tile(const UpdateArgs& a, const vlfm_vm_pose& pose, 
     const int words = (T + 31) >> 5;
     const int C = C_STATIC > 0 ? C_STATIC : a.C;
     float* conf = a.conf + (size_t)pose.env * S * S;
-    float* value = a.value + (size_t)pose.env * S * S * C;
+    double* value = a.value + (size_t)pose.env * S * S * C;
     const int ex_stride = (S + 31) >> 5;
     const unsigned* explored = a.explored ? a.explored + (size_t)pose.env * S * ex_stride : nullptr;
     const double* vals = a.values + (size_t)pose.reserved * C;
@@ -268,7 +272,7 @@ __device__ inline void fuse_tile(const UpdateArgs& a, const vlfm_vm_pose& pose, 
         float nw[ROWS_PER_WAVE], old[ROWS_PER_WAVE];
         size_t cell[ROWS_PER_WAVE];
         bool act[ROWS_PER_WAVE];
-        float oldv1[ROWS_PER_WAVE];
+        double oldv1[ROWS_PER_WAVE];
 #pragma unroll
         for (int k = 0; k < ROWS_PER_WAVE; k++) {
             // BilinearTab_f weights are products of k/32 in float (exact); accumulate in double like remapBilinear<double>
@@ -290,7 +294,8 @@ __device__ inline void fuse_tile(const UpdateArgs& a, const vlfm_vm_pose& pose, 
         for (int k = 0; k < ROWS_PER_WAVE; k++) {
             bool stored = false;
             if (act[k] && C_STATIC == 1) {
-                float c_out, v_out;
+                float c_out;
+                double v_out;
                 if (fuse_cell<1>(a, nw[k], old[k], &oldv1[k], vals, c_out, &v_out)) {
                     conf[cell[k]] = c_out;
                     value[cell[k]] = v_out;
@@ -316,8 +321,8 @@ __device__ inline void fuse_tile(const UpdateArgs& a, const vlfm_vm_pose& pose, 
                 float c_out = 0.0f;
                 bool wrote = false;
                 for (int c = 0; c < C; c++) {
-                    const float ov = value[cell[k] * C + c];
-                    float nv;
+                    const double ov = value[cell[k] * C + c];
+                    double nv;
                     wrote = fuse_cell<1>(a, nw[k], old[k], &ov, vals + c, c_out, &nv);
                     if (!wrote) break;
                     value[cell[k] * C + c] = nv;
@@ -403,7 +408,7 @@ __device__ inline void fuse_tile_lds(const UpdateArgs& a, const vlfm_vm_pose& po
     const int words = (T + 31) >> 5;
     const int C = C_STATIC > 0 ? C_STATIC : a.C;
     float* conf = a.conf + (size_t)pose.env * S * S;
-    float* value = a.value + (size_t)pose.env * S * S * C;
+    double* value = a.value + (size_t)pose.env * S * S * C;
     const int ex_stride = (S + 31) >> 5;
     const unsigned* explored = a.explored ? a.explored + (size_t)pose.env * S * ex_stride : nullptr;
     const double* vals = a.values + (size_t)pose.reserved * C;
@@ -474,7 +479,8 @@ __device__ inline void fuse_tile_lds(const UpdateArgs& a, const vlfm_vm_pose& po
             if (__ballot(any_on) == 0ull) continue;
         }
         // ---- phase B: issue the map reads of every active pixel
-        float old[R], oldv1[R];
+        float old[R];
+        double oldv1[R];
         int cell[R];
         unsigned act = 0u;
 #pragma unroll
@@ -496,7 +502,8 @@ __device__ inline void fuse_tile_lds(const UpdateArgs& a, const vlfm_vm_pose& po
             const bool on = (act >> k) & 1u;
             bool stored = false;
             if (on && C_STATIC == 1) {
-                float c_out, v_out;
+                float c_out;
+                double v_out;
                 if (fuse_cell<1>(a, nw[k], old[k], &oldv1[k], vals, c_out, &v_out)) {
                     conf[cell[k]] = c_out;
                     value[cell[k]] = v_out;
@@ -521,8 +528,8 @@ __device__ inline void fuse_tile_lds(const UpdateArgs& a, const vlfm_vm_pose& po
                 float c_out = 0.0f;
                 bool wrote = false;
                 for (int c = 0; c < C; c++) {
-                    const float ov = value[(size_t)cell[k] * C + c];
-                    float nv;
+                    const double ov = value[(size_t)cell[k] * C + c];
+                    double nv;
                     wrote = fuse_cell<1>(a, nw[k], old[k], &ov, vals + c, c_out, &nv);
                     if (!wrote) break;
                     value[(size_t)cell[k] * C + c] = nv;
@@ -827,7 +834,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void value_map_update_fused_kernel(U
         const unsigned* explored = a.explored + (size_t)pose.env * S * ex_stride;
         float* conf = a.conf + (size_t)pose.env * S * S;
         const int C = C_STATIC > 0 ? C_STATIC : a.C;
-        float* value = a.value + (size_t)pose.env * S * S * C;
+        double* value = a.value + (size_t)pose.env * S * S * C;
         for (int i = my_word; i < plane_words; i += G * nth) {
             const unsigned wr = i == my_word ? wr0 : written[i];
             if (!wr) continue;
@@ -840,7 +847,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void value_map_update_fused_kernel(U
                 dead &= dead - 1u;
                 const size_t cell = (size_t)row * S + c0 + b;
                 conf[cell] = 0.0f;
-                for (int c = 0; c < C; c++) value[cell * C + c] = 0.0f;
+                // `_value_map[explored_area == 0] *= 0` (:375): a product, so a negative value leaves -0.0
+                for (int c = 0; c < C; c++) value[cell * C + c] = __dmul_rn(value[cell * C + c], 0.0);
             }
         }
     }
@@ -881,14 +889,14 @@ __device__ inline bool clear_unexplored4(float4& v, unsigned nib) {
 
 __global__ __launch_bounds__(256) void mask_unexplored_kernel(const MaskJob* __restrict__ jobs, int S, int C,
                                                               const unsigned* __restrict__ explored,
-                                                              float* __restrict__ conf, float* __restrict__ value) {
+                                                              float* __restrict__ conf, double* __restrict__ value) {
     const MaskJob job = jobs[blockIdx.y];
     const int ex_stride = (S + 31) >> 5;
     const int groups = S >> 2;  // S % 4 == 0 (checked by the host)
     const size_t cells = (size_t)S * S;
     const unsigned* ex = explored + (size_t)job.env * S * ex_stride;
     float* cf = conf + (size_t)job.env * cells;
-    float* vl = value + (size_t)job.env * cells * C;
+    double* vl = value + (size_t)job.env * cells * C;
     const long long total = (long long)(job.row_hi - job.row_lo) * groups;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int row = job.row_lo + (int)(i / groups), g = (int)(i % groups);
@@ -897,16 +905,13 @@ __global__ __launch_bounds__(256) void mask_unexplored_kernel(const MaskJob* __r
         const size_t quad = ((size_t)row * S >> 2) + g;
         float4 c4 = reinterpret_cast<float4*>(cf)[quad];
         if (clear_unexplored4(c4, nib)) reinterpret_cast<float4*>(cf)[quad] = c4;
-        if (C == 1) {
-            float4 v4 = reinterpret_cast<float4*>(vl)[quad];
-            if (clear_unexplored4(v4, nib)) reinterpret_cast<float4*>(vl)[quad] = v4;
-        } else {
-            for (int k = 0; k < 4; k++) {
-                if ((nib >> k) & 1u) continue;
-                for (int c = 0; c < C; c++) {
-                    float* vp = vl + (quad * 4 + k) * C + c;
-                    if (*vp != 0.0f) *vp = 0.0f;
-                }
+        // `_value_map[explored_area == 0] *= 0` (:375): a product -- a negative value leaves -0.0, like the reference
+        for (int k = 0; k < 4; k++) {
+            if ((nib >> k) & 1u) continue;
+            for (int c = 0; c < C; c++) {
+                double* vp = vl + (quad * 4 + k) * C + c;
+                const double v = *vp;
+                if (v != 0.0) *vp = __dmul_rn(v, 0.0);
             }
         }
     }
@@ -914,15 +919,18 @@ __global__ __launch_bounds__(256) void mask_unexplored_kernel(const MaskJob* __r
 
 // ------------------------------------------------------------------------------------------------ sort_waypoints
 // One workgroup (256 threads) per (waypoint, channel).  Gathers the positive cells of the disc into LDS, then finds
-// the median by rank counting (n <= (2r+1)^2, r = 10 -> 441; O(n^2) compares spread over the workgroup).
-__global__ __launch_bounds__(256) void sort_waypoints_kernel(const float* __restrict__ value, int S, int C,
+// the median by rank counting (n <= (2r+1)^2, r = 10 -> 441; O(n^2) compares spread over the workgroup).  The map is f64
+// (see the layout note at the top); `value_is_f32` says that the reference's array is still f32 in this mode, in which case
+// np.median averages the two middle elements of an even count in f32.
+__global__ __launch_bounds__(256) void sort_waypoints_kernel(const double* __restrict__ value, int S, int C,
                                                              const int* __restrict__ cells, int radius,
-                                                             const int* __restrict__ disc_hw, float* __restrict__ out) {
+                                                             const int* __restrict__ disc_hw, int value_is_f32,
+                                                             double* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // dynamic LDS only (keeps the base 16-B aligned): [0] counter, [1..2] picked middles, [4..] gathered values
+    // dynamic LDS only (keeps the base 16-B aligned): [0] counter, [2..3] picked middles, [4..] gathered values (doubles)
     int& n_pos = *reinterpret_cast<int*>(smem);
-    float* picked = reinterpret_cast<float*>(smem) + 1;
-    float* vals = reinterpret_cast<float*>(smem) + 4;
+    double* picked = reinterpret_cast<double*>(smem) + 2;
+    double* vals = reinterpret_cast<double*>(smem) + 4;
     const int wp = blockIdx.x, ch = blockIdx.y;
     const int env = cells[3 * wp], row = cells[3 * wp + 1], col = cells[3 * wp + 2];
     const int side = 2 * radius + 1;
@@ -931,30 +939,30 @@ __global__ __launch_bounds__(256) void sort_waypoints_kernel(const float* __rest
     const int ch_h = r1 - r0, ch_w = c1 - c0;  // crop extents; the disc stays centred at (radius, radius) OF THE CROP
     if (threadIdx.x == 0) n_pos = 0;
     __syncthreads();
-    const float* vm = value + (size_t)env * S * S * C;
+    const double* vm = value + (size_t)env * S * S * C;
     for (int i = threadIdx.x; i < side * side; i += blockDim.x) {
         const int dy = i / side, dx = i - dy * side;
         if (dy >= ch_h || dx >= ch_w) continue;
         const int hw = disc_hw[dy];
         const int off = dx - radius;
         if (off < -hw || off > hw) continue;
-        const float v = vm[((size_t)(r0 + dy) * S + (c0 + dx)) * C + ch];
-        if (v > 0.0f) vals[atomicAdd(&n_pos, 1)] = v;
+        const double v = vm[((size_t)(r0 + dy) * S + (c0 + dx)) * C + ch];
+        if (v > 0.0) vals[atomicAdd(&n_pos, 1)] = v;
     }
     __syncthreads();
     const int n = n_pos;
     if (n == 0) {
-        if (threadIdx.x == 0) out[wp * C + ch] = -1.0f;
+        if (threadIdx.x == 0) out[wp * C + ch] = -1.0;
         return;
     }
     // rank of element i = #(v_j < v_i) + #(v_j == v_i, j < i): a permutation of 0..n-1 (gather order is arbitrary,
     // which is fine: equal values are interchangeable for a median)
     const int k_hi = n / 2, k_lo = (n - 1) / 2;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const float vi = vals[i];
+        const double vi = vals[i];
         int rank = 0;
         for (int j = 0; j < n; j++) {
-            const float vj = vals[j];
+            const double vj = vals[j];
             rank += (vj < vi) || (vj == vi && j < i);
         }
         if (rank == k_hi) picked[0] = vi;
@@ -962,8 +970,13 @@ __global__ __launch_bounds__(256) void sort_waypoints_kernel(const float* __rest
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        // np.median: middle element, or the mean of the two middle elements for even n (f32 add, exact halving)
-        out[wp * C + ch] = (n & 1) ? picked[0] : __fmul_rn(__fadd_rn(picked[1], picked[0]), 0.5f);
+        // np.median: middle element, or the mean of the two middle elements for even n -- np.mean in the ARRAY's dtype:
+        // f64 add + exact halving for the f64 map, f32 add for a map the reference still holds in f32
+        double m = picked[0];
+        if (!(n & 1))
+            m = value_is_f32 ? (double)__fmul_rn(__fadd_rn((float)picked[1], (float)picked[0]), 0.5f)
+                             : __dmul_rn(__dadd_rn(picked[1], picked[0]), 0.5);
+        out[wp * C + ch] = m;
     }
 }
 
@@ -997,7 +1010,7 @@ extern "C" size_t vlfm_value_map_scratch_bytes(int n, int template_size) {
 extern "C" int vlfm_value_map_update_batched(uint32_t* d_colmax_keys, int width, const double* d_tan,
                                              const float* d_template, const uint32_t* d_template_bits,
                                              int template_size, const vlfm_vm_pose* d_pose,
-                                             const double* d_values, int n, float* d_conf, float* d_value,
+                                             const double* d_values, int n, float* d_conf, double* d_value,
                                              int map_size, int channels, int pixels_per_meter, double min_depth,
                                              double max_depth, int use_max_confidence, int fusion_type,
                                              const uint32_t* d_explored_bits, void* d_scratch, void* stream) {
@@ -1047,7 +1060,7 @@ extern "C" int vlfm_debug_vm_phase_clocks(long long* h_out /* [16] */) {
 extern "C" int vlfm_value_map_update_fused_batched(uint32_t* d_colmax_keys, int width, const double* d_tan,
                                                    const float* d_template, const uint32_t* d_template_bits,
                                                    int template_size, const vlfm_vm_pose* d_pose,
-                                                   const double* d_values, int n, float* d_conf, float* d_value,
+                                                   const double* d_values, int n, float* d_conf, double* d_value,
                                                    int map_size, int channels, int pixels_per_meter, double min_depth,
                                                    double max_depth, int use_max_confidence, int fusion_type,
                                                    const uint32_t* d_explored_bits, uint32_t* d_written_bits,
@@ -1106,7 +1119,7 @@ extern "C" int vlfm_value_map_update_fused_batched(uint32_t* d_colmax_keys, int 
 }
 
 extern "C" int vlfm_value_map_mask_unexplored_batched(const vlfm_mask_job* d_jobs, int n, int max_rows,
-                                                      const uint32_t* d_explored_bits, float* d_conf, float* d_value,
+                                                      const uint32_t* d_explored_bits, float* d_conf, double* d_value,
                                                       int map_size, int channels, void* stream) {
     if (n == 0 || max_rows == 0) return VLFM_OK;
     if (!d_jobs || !d_explored_bits || !d_conf || !d_value || n < 0 || max_rows < 0 || map_size <= 0 || channels <= 0)
@@ -1124,17 +1137,17 @@ extern "C" int vlfm_value_map_mask_unexplored_batched(const vlfm_mask_job* d_job
     return check_launch("mask_unexplored_kernel");
 }
 
-extern "C" int vlfm_value_map_sort_waypoints_batched(const float* d_value, int map_size, int channels,
+extern "C" int vlfm_value_map_sort_waypoints_batched(const double* d_value, int map_size, int channels,
                                                      const int32_t* d_cells, int m, int radius, const int32_t* d_disc,
-                                                     float* d_out, void* stream) {
+                                                     int value_is_f32, double* d_out, void* stream) {
     if (m == 0) return VLFM_OK;
     if (!d_value || !d_cells || !d_disc || !d_out || m < 0 || radius < 0 || channels <= 0)
         return fail(VLFM_ERR_INVALID, "sort_waypoints_batched: bad argument");
     const int side = 2 * radius + 1;
-    const size_t lds = ((size_t)side * side + 4) * sizeof(float);
+    const size_t lds = ((size_t)side * side + 4) * sizeof(double);
     if (lds > 150 * 1024) return fail(VLFM_ERR_CAPACITY, "sort_waypoints_batched: radius too large");
     VLFM_TIMED("sort_waypoints_kernel", stream);
     VLFM_KLAUNCH(sort_waypoints_kernel, dim3(m, channels), dim3(256), lds, (hipStream_t)stream, d_value,
-                       map_size, channels, d_cells, radius, d_disc, d_out);
+                       map_size, channels, d_cells, radius, d_disc, value_is_f32, d_out);
     return check_launch("sort_waypoints_kernel");
 }

@@ -59,6 +59,18 @@ class ObstacleMapBatch:
         self._ring_fog = UploadRing(self.device, n_envs * ctypes.sizeof(_lib.FogParams), slots=8)
         self.frontiers_ready = False
         self._explored_u8 = None
+        self._journal_dirty = False   # the scatter journal holds entries no fill_small_holes launch has consumed
+        # Dirty windows (csrc/obstacle_map.hip: navigable_kernel / frontier_prepare_kernel), per slot, inclusive
+        # (y0, y1, x0, x1), empty when y1 < y0.  `_dirty_obst`: cells whose obstacle bit may have changed since `navigable`
+        # was last recomputed (union of the reach windows of the frames ingested); `_dirty_nav`: cells whose `navigable` bit
+        # may have changed since the last explore step.  A fresh slot starts with the whole map (first pass = the
+        # reference's full-map pass).  VLFM_FULL_PLANES=1 hands over NULL windows: the full-plane kernels, for A/B runs.
+        self._dirty_obst = np.tile(np.array([0, size - 1, 0, size - 1], np.int32), (n_envs, 1))
+        self._dirty_nav = self._dirty_obst.copy()
+        self._ring_win = UploadRing(self.device, n_envs * 32, slots=8)
+        import os
+
+        self.full_planes = os.environ.get("VLFM_FULL_PLANES", "0") == "1"
         # read-back path of the step: fixed-size staging + pinned host buffers, so a step never allocates and never
         # hands the runtime a pageable destination (which it would have to pin on the fly)
         self._d_fr_stage = torch.zeros((n_envs, self.READ_FRONTIERS, 2), dtype=torch.float64, device=self.device)
@@ -77,6 +89,57 @@ class ObstacleMapBatch:
         self.counts[idx] = 0
         self.frontiers_ready = False
         self._explored_u8 = None
+        self._dirty_obst[idx] = (0, self.size - 1, 0, self.size - 1)   # zeroed planes: everything is to be recomputed
+        self._dirty_nav[idx] = (0, self.size - 1, 0, self.size - 1)
+
+    @staticmethod
+    def _union(into: np.ndarray, idx: np.ndarray, win: np.ndarray) -> None:
+        """into[idx] |= win for inclusive (y0, y1, x0, x1) windows (empty: y1 < y0); idx holds distinct slots."""
+        cur = into[idx]
+        empty_cur, empty_new = cur[:, 1] < cur[:, 0], win[:, 1] < win[:, 0]
+        out = np.stack([np.minimum(cur[:, 0], win[:, 0]), np.maximum(cur[:, 1], win[:, 1]),
+                        np.minimum(cur[:, 2], win[:, 2]), np.maximum(cur[:, 3], win[:, 3])], axis=1)
+        out[empty_cur] = win[empty_cur]
+        out[empty_new] = cur[empty_new]
+        into[idx] = out
+
+    def _note_ingest(self, env: np.ndarray, tf: np.ndarray, reach_px: float) -> None:
+        """Every obstacle bit a frame can touch lies within ``reach_px`` cells of its camera cell (texel distance from the
+        camera <= max_depth * sqrt(1 + (W/2fx)^2 + (H/2fy)^2), rigid transform, one cell of rounding).  A window that
+        leaves the map is replaced by the whole map: out-of-range rows / columns wrap like NumPy's negative indices
+        (obstacle_map.py:101), and so is a camera transform whose rotation block is not orthonormal."""
+        S = self.size
+        R = tf[:, :3, :3]
+        rigid = np.abs(np.einsum("nij,nkj->nik", R, R) - np.eye(3)).reshape(len(tf), -1).max(axis=1) < 1e-9
+        cell = np.rint(tf[:, :2, 3] * self.pixels_per_meter) + S // 2        # (x -> row, y -> S - col), base_map.py:44-46
+        row, col = cell[:, 0], S - cell[:, 1]
+        r = int(np.ceil(reach_px)) + 2
+        win = np.stack([row - r, row + r, col - r, col + r], axis=1)
+        inside = rigid & np.isfinite(win).all(axis=1) & (win[:, 0] >= 0) & (win[:, 1] <= S - 1) & (win[:, 2] >= 0) & \
+            (win[:, 3] <= S - 1)
+        win = np.where(inside[:, None], win, np.array([0, S - 1, 0, S - 1], np.float64)[None]).astype(np.int32)
+        self._union(self._dirty_obst, env, win)
+
+    def _take_windows(self, env: np.ndarray, update_obstacles: bool, explore: bool) -> np.ndarray:
+        """[n, 8] int32 for vlfm_obstacle_map_update_batched and the bookkeeping that goes with handing them over."""
+        S, n = self.size, len(env)
+        out = np.empty((n, 8), np.int32)
+        out[:, 0:4] = (0, -1, 0, -1)
+        out[:, 4:8] = (0, -1, 0, -1)
+        if update_obstacles:
+            g = self.kernel_size // 2
+            w = self._dirty_obst[env].copy()
+            live = w[:, 1] >= w[:, 0]
+            w[:, 0] = np.maximum(w[:, 0] - g, 0); w[:, 1] = np.minimum(w[:, 1] + g, S - 1)
+            w[:, 2] = np.maximum(w[:, 2] - g, 0); w[:, 3] = np.minimum(w[:, 3] + g, S - 1)
+            w[~live] = (0, -1, 0, -1)
+            out[:, 0:4] = w
+            self._union(self._dirty_nav, env, w)
+            self._dirty_obst[env] = (0, -1, 0, -1)
+        if explore:
+            out[:, 4:8] = self._dirty_nav[env]
+            self._dirty_nav[env] = (0, -1, 0, -1)
+        return out
 
     def _unpack(self, bits):
         import torch
@@ -112,6 +175,9 @@ class ObstacleMapBatch:
         prm["env"] = np.arange(n) if env_ids is None else np.asarray(env_ids)
         assert int(prm["env"].max()) < self.n_envs and int(prm["env"].min()) >= 0, "environment slot out of range"
         prm["scatter"] = (1 if update_obstacles else 0) | (2 if self._hole_area_thresh == -1 else 0)
+        if update_obstacles:
+            reach_px = max_depth * float(np.sqrt(1.0 + (W / 2 / fx) ** 2 + (H / 2 / fy) ** 2)) * self.pixels_per_meter
+            self._note_ingest(np.asarray(prm["env"], np.int64), tf, reach_px)
         keys = None
         if want_colmax:
             if self.colmax_keys is None or self.colmax_keys.shape != (max(n, self.n_envs), W):
@@ -148,6 +214,11 @@ class ObstacleMapBatch:
                 cap = int(min(self.size * self.size, (2 * int(np.ceil(reach)) + 3) ** 2))
                 holes, filled, scratch, counts, journal = self._hole_buffers(n, H, W, cap)
                 jref = ctypes.byref(journal)
+                if self._journal_dirty:
+                    # an earlier step launched the speculative pass but never reached fill_small_holes (which consumes the
+                    # journal and resets its counters): entries of that step must not be undone by a later island frame
+                    self._journal_count.zero_()
+                self._journal_dirty = True
                 _lib.check(L.vlfm_depth_ingest_batched(depth.data_ptr(), n, H, W, d_prm.data_ptr(),
                                                        keys.data_ptr() if keys is not None else None,
                                                        self.obstacle_bits.data_ptr(), self.size,
@@ -159,6 +230,7 @@ class ObstacleMapBatch:
                                                            filled.data_ptr(), counts.data_ptr(), d_prm.data_ptr(),
                                                            self.obstacle_bits.data_ptr(), self.size, jref,
                                                            _stream_ptr()), "fill_small_holes")
+                self._journal_dirty = False   # consumed: fill_small_holes_kernel leaves every counter at zero
                 _lib.check(L.vlfm_depth_scatter_holes_batched(d_prm.data_ptr(), n, H, W, holes.data_ptr(),
                                                               filled.data_ptr(), counts.data_ptr(),
                                                               self.obstacle_bits.data_ptr(), self.size,
@@ -217,15 +289,18 @@ class ObstacleMapBatch:
         n = len(prm)
         if env_ids is not None:  # the explore pipeline owns a slot's planes for the whole launch
             assert len(set(int(e) for e in env_ids)) == n, "one observation per environment slot and call"
+        env = np.arange(n) if env_ids is None else np.asarray(env_ids, np.int64)
+        windows = self._take_windows(env, update_obstacles, explore)
         with torch.cuda.device(self.device):
             d_prm = self._ring_fog.upload(prm)
+            d_win = None if self.full_planes else self._ring_win.upload(windows)
             _lib.check(_lib.lib().vlfm_obstacle_map_update_batched(
                 d_prm.data_ptr(), n, self.obstacle_bits.data_ptr(), self.navigable_bits.data_ptr(),
                 self.explored_bits.data_ptr(), self.bbox.data_ptr(), self.n_envs, self.size, self.kernel_size,
                 int(max_depth * self.pixels_per_meter), float(self._area_thresh_in_pixels), self.scratch.data_ptr(),
                 self.scratch.numel(), self.CAP_PTS, self.CAP_CONTOURS, self.frontiers_px_dev.data_ptr(),
-                self.CAP_FRONTIERS, self.counts.data_ptr(), int(update_obstacles), int(explore), _stream_ptr()),
-                "obstacle_map_update")
+                self.CAP_FRONTIERS, self.counts.data_ptr(), int(update_obstacles), int(explore),
+                d_win.data_ptr() if d_win is not None else None, _stream_ptr()), "obstacle_map_update")
         self.frontiers_ready = bool(explore)
         self._explored_u8 = None
 

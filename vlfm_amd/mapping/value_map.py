@@ -210,7 +210,11 @@ class ValueMapBatch:
             self.fusion_type = os.environ["MAP_FUSION_TYPE"]
         assert self.fusion_type in _lib.FUSION_TYPES, f"Unknown fusion type {self.fusion_type}"
         self.conf = torch.zeros((n_envs, size, size), dtype=torch.float32, device=self.device)
-        self.value = torch.zeros((n_envs, size, size, value_channels), dtype=torch.float32, device=self.device)
+        # f64: the reference's `_value_map` IS f64 after the first weighted fuse (value_map.py:423: `values` is an f64
+        # ndarray and the attribute is re-bound to the f64 result); where the reference keeps it f32 (max-confidence :406,
+        # "replace" :381-384) the kernel stores f32-representable doubles.  Either way: bit-equal to the reference.
+        self.value = torch.zeros((n_envs, size, size, value_channels), dtype=torch.float64, device=self.device)
+        self.n_updates = np.zeros(n_envs, np.int64)   # update_map calls per slot since construction (dtype rule below)
         # bit-packed ObstacleMap.explored_area of the same slots ([n_envs,S,ceil(S/32)] int32) when the value map is
         # synchronised with an obstacle map (value_map.py:369-375); None = Habitat default
         self.explored_bits = explored_bits
@@ -226,8 +230,21 @@ class ValueMapBatch:
         # three-launch form (mask_unexplored + visible_mask + fuse) it replaced -- kept for A/B measurements
         self.split_update = os.environ.get("VLFM_VM_SPLIT", "0") == "1"
         self._written = None   # [n_envs,S,ceil(S/32)] cells that ever received a confidence (explored-synchronised mode)
+        self._written_stale = False  # an update ran without the explored plane since `_written` was last complete
         self._counters = None
         self._wp_out = self._wp_host = self._wp_cells = None
+
+    @property
+    def value_is_f32(self) -> bool:
+        """True when the reference's `_value_map` array never leaves f32 in this map's mode: masked assignment of
+        `values` (use_max_confidence, value_map.py:406) or the "replace" ablation (:381-384, which returns before the
+        weighted path).  Otherwise the first weighted fuse promotes it to f64 for good (:423)."""
+        return self.fusion_type == "replace" or self.use_max_confidence
+
+    def value_dtype(self, slot: int):
+        """dtype of the reference's `_value_map` for this slot right now (f32 until the first weighted fuse; reset() keeps
+        the dtype, value_map.py:96-98)."""
+        return np.float32 if (self.value_is_f32 or self.n_updates[slot] == 0) else np.float64
 
     # ------------------------------------------------------------------------------------------ helpers
     def reset(self, env_ids: Optional[Sequence[int]] = None) -> None:
@@ -315,6 +332,7 @@ class ValueMapBatch:
             # multi-camera loop, reality_policies.py:113-141, is sequential) must go through separate calls
             assert len(np.unique(pose["env"])) == len(pose), "one observation per environment slot and call"
             assert int(pose["env"].max()) < self.n_envs and int(pose["env"].min()) >= 0, "environment slot out of range"
+            self.n_updates[pose["env"]] += 1
         except Exception:
             if colmax is not None:
                 colmax.zero_()
@@ -334,17 +352,24 @@ class ValueMapBatch:
                 ex = self.explored_bits
                 assert ex.dtype == torch.int32 and ex.is_contiguous() and ex.shape[-2] == self.size
                 explored_ptr = ex.data_ptr()
+            # rows this step's windows may write (the split path's full-map sweep is limited to them)
+            np.minimum.at(self._row_lo, pose["env"], np.clip(pose["row0"], 0, self.size))
+            np.maximum.at(self._row_hi, pose["env"], np.clip(pose["row0"] + T, 0, self.size))
             if not self.split_update:
                 written_ptr = None
-                if explored_ptr is not None:
-                    if self._written is None:
-                        # conf may already hold values (an obstacle map attached mid-episode): start from conf != 0
-                        self._written = torch.zeros((self.n_envs, self.size, (self.size + 31) // 32), dtype=torch.int32,
-                                                    device=self.device)
-                        if bool((self.conf != 0).any()):
-                            _lib.check(L.vlfm_bits_pack((self.conf != 0).to(torch.uint8).contiguous().data_ptr(),
-                                                        self._written.data_ptr(), self.n_envs, self.size, self.size,
-                                                        _stream_ptr()), "bits_pack")
+                if explored_ptr is None:
+                    self._written_stale = True   # cells fused from here on are not recorded in the plane
+                else:
+                    if self._written is None or self._written_stale:
+                        # conf may already hold values (an obstacle map attached mid-episode, or detached for a while and
+                        # attached again): (re)start from conf != 0
+                        if self._written is None:
+                            self._written = torch.zeros((self.n_envs, self.size, (self.size + 31) // 32),
+                                                        dtype=torch.int32, device=self.device)
+                        _lib.check(L.vlfm_bits_pack((self.conf != 0).to(torch.uint8).contiguous().data_ptr(),
+                                                    self._written.data_ptr(), self.n_envs, self.size, self.size,
+                                                    _stream_ptr()), "bits_pack")
+                        self._written_stale = False
                     written_ptr = self._written.data_ptr()
                 if self._counters is None or self._counters.numel() < n:
                     self._counters = torch.zeros(max(n, self.n_envs), dtype=torch.int32, device=self.device)
@@ -377,21 +402,17 @@ class ValueMapBatch:
                                                        _lib.FUSION_TYPES[self.fusion_type], explored_ptr,
                                                        self._vis_scratch(n, T).data_ptr(), _stream_ptr()),
                        "value_map_update")
-        # rows this step's windows may have written
-        lo = np.clip(pose["row0"], 0, self.size)
-        hi = np.clip(pose["row0"] + T, 0, self.size)
-        np.minimum.at(self._row_lo, pose["env"], lo)
-        np.maximum.at(self._row_hi, pose["env"], hi)
 
     # ------------------------------------------------------------------------------------------ frontier scoring
     def waypoint_values(self, waypoints_xy: np.ndarray, env_of_waypoint: Sequence[int], radius: float) -> np.ndarray:
-        """Disc medians for m waypoints -> [m, C] f32 (value_map.py:161-176, img_utils.py:213-266)."""
+        """Disc medians for m waypoints -> [m, C] f64 (value_map.py:161-176, img_utils.py:213-266): np.median's result in
+        the dtype of the reference's array (f64 in the weighted mode, f32 -- widened exactly -- otherwise)."""
         import torch
 
         wp = np.asarray(waypoints_xy, np.float64).reshape(-1, 2)
         m = wp.shape[0]
         if m == 0:
-            return np.zeros((0, self.channels), np.float32)
+            return np.zeros((0, self.channels), np.float64)
         radius_px = int(radius * self.pixels_per_meter)
         # int() truncates toward zero (value_map.py:165-166) == ndarray.astype(int64) for finite values
         px = (-wp[:, 0] * self.pixels_per_meter).astype(np.int64) + self.size // 2
@@ -403,15 +424,16 @@ class ValueMapBatch:
         d_disc = _TEMPLATES.disc(self.device, radius_px)
         if self._wp_out is None or self._wp_out.shape[0] < m:
             cap = max(64, 1 << (m - 1).bit_length())
-            self._wp_out = torch.empty((cap, self.channels), dtype=torch.float32, device=self.device)
-            self._wp_host = torch.empty((cap, self.channels), dtype=torch.float32).pin_memory()
+            self._wp_out = torch.empty((cap, self.channels), dtype=torch.float64, device=self.device)
+            self._wp_host = torch.empty((cap, self.channels), dtype=torch.float64).pin_memory()
             self._wp_cells = UploadRing(self.device, cap * 12, slots=4)
         with torch.cuda.device(self.device):
             d_cells = self._wp_cells.upload(cells)
             _lib.check(_lib.lib().vlfm_value_map_sort_waypoints_batched(self.value.data_ptr(), self.size,
                                                                        self.channels, d_cells.data_ptr(), m,
                                                                        radius_px, d_disc.data_ptr(),
-                                                                       self._wp_out.data_ptr(), _stream_ptr()),
+                                                                       int(self.value_is_f32), self._wp_out.data_ptr(),
+                                                                       _stream_ptr()),
                        "sort_waypoints")
             self._wp_host[:m].copy_(self._wp_out[:m], non_blocking=True)
             torch.cuda.current_stream().synchronize()
@@ -486,7 +508,9 @@ class ValueMap(BaseMap):
 
     @property
     def _value_map(self) -> np.ndarray:
-        return self._batch.value[self._slot].cpu().numpy()
+        # the reference's array is f32 until the first weighted fuse and f64 from then on (value_map.py:423); in the modes
+        # that assign `values` into it (max-confidence, "replace") it stays f32.  The stored doubles are exact either way.
+        return self._batch.value[self._slot].cpu().numpy().astype(self._batch.value_dtype(self._slot), copy=False)
 
     def reset(self) -> None:
         super().reset()

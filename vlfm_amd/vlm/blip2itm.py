@@ -74,7 +74,9 @@ class _VitBlock(nn.Module):
 
         self._packed = None
         self.hip_attention = True  # vlfm_vit_attention_f16 at the ViT-g shape (257 tokens, 88-wide heads)
-        self.strict_hip_attention = False  # True: a failing HIP launch raises (bench.py) instead of falling back
+        # a failing vlfm_vit_attention_f16 launch RAISES: the product has one attention backend at this geometry.  Opt out
+        # explicitly (BLIP2ITM(..., strict_hip_attention=False)) to let a block switch to the library kernel with a warning
+        self.strict_hip_attention = True
         # fc1 + exact GELU in one hand-written MFMA kernel once the GEMM has this many rows (below, the library's smaller
         # tiles win: tools/gemm_f16_probe.py); 0 = always the library GEMM + a separate GELU pass
         self.hip_mlp_min_rows = 32 * 257
@@ -502,7 +504,8 @@ class BLIP2ITM:
 
     def __init__(self, name: str = "blip2_image_text_matching", model_type: str = "pretrain", device=None,
                  model_dir: Optional[str] = None, config: Optional[Blip2ITCConfig] = None,
-                 vision_dtype: torch.dtype = torch.float16, seed: int = 0, allow_random_init: bool = False) -> None:
+                 vision_dtype: torch.dtype = torch.float16, seed: int = 0, allow_random_init: bool = False,
+                 strict_hip_attention: bool = True) -> None:
         from ..mapping.base_map import require_gpu
         from .. import _lib
 
@@ -530,6 +533,7 @@ class BLIP2ITM:
         self.model.eval().to(self.device).set_precision(vision_dtype)
         for blk in self.model.blocks:
             blk.pack_heads()
+            blk.strict_hip_attention = bool(strict_hip_attention)
         self._text_cache: Dict[str, torch.Tensor] = {}
         self._proj_t = None
         self.two_stream_min = None    # e.g. 64: run batches of at least that many images as two halves on two streams
@@ -664,11 +668,7 @@ class BLIP2ITMClient:
 
     def cosine(self, image: np.ndarray, txt: str) -> float:
         if self._emulate_jpeg:
-            import io
+            from .transport import jpeg_roundtrip
 
-            from PIL import Image
-
-            buf = io.BytesIO()
-            Image.fromarray(image).save(buf, format="JPEG", quality=90)  # server_wrapper.py:57-61
-            image = np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGB"))
+            image = jpeg_roundtrip(image)  # server_wrapper.py:57-68
         return self._model.cosine(image, txt)

@@ -171,17 +171,24 @@ class GroundingDINO:
 
 
 class GroundingDINOClient:
-    """grounding_dino.py:77-85; ``port`` accepted and ignored (the model lives in this process)."""
+    """grounding_dino.py:77-85; ``port`` accepted and ignored (the model lives in this process).  ``emulate_jpeg=True``
+    reproduces the reference's quality-90 JPEG transport (server_wrapper.py:57-68) for A/B checks."""
 
     _shared: Dict[str, GroundingDINO] = {}
 
-    def __init__(self, port: int = 12181, device=None, **model_kwargs) -> None:
+    def __init__(self, port: int = 12181, device=None, emulate_jpeg: bool = False, **model_kwargs) -> None:
         key = str(device)
         if key not in GroundingDINOClient._shared:
             GroundingDINOClient._shared[key] = GroundingDINO(device=device, **model_kwargs)
         self._model = GroundingDINOClient._shared[key]
+        self._emulate_jpeg = emulate_jpeg
         self.url = f"inprocess://gdino (port {port} ignored)"
 
     def predict(self, image_numpy: np.ndarray, caption: Optional[str] = "") -> ObjectDetections:
-        det = self._model.predict(image_numpy, caption=caption)
+        seen = image_numpy
+        if self._emulate_jpeg:
+            from .transport import jpeg_roundtrip
+
+            seen = jpeg_roundtrip(image_numpy)
+        det = self._model.predict(seen, caption=caption)
         return ObjectDetections.from_json(det.to_json(), image_source=image_numpy)

@@ -332,17 +332,24 @@ class MobileSAM:
 
 
 class MobileSAMClient:
-    """sam.py:60-69; ``port`` accepted and ignored (in-process)."""
+    """sam.py:60-69; ``port`` accepted and ignored (in-process).  ``emulate_jpeg=True`` reproduces the reference's
+    quality-90 JPEG transport of the frame (server_wrapper.py:57-68) for A/B checks; the mask travels losslessly there too."""
 
     _shared: Dict[str, MobileSAM] = {}
 
-    def __init__(self, port: int = 12183, device=None, **model_kwargs) -> None:
+    def __init__(self, port: int = 12183, device=None, emulate_jpeg: bool = False, **model_kwargs) -> None:
         key = str(device)
         if key not in MobileSAMClient._shared:
             MobileSAMClient._shared[key] = MobileSAM(device=device, **model_kwargs)
         self._model = MobileSAMClient._shared[key]
+        self._emulate_jpeg = emulate_jpeg
         self.url = f"inprocess://mobile_sam (port {port} ignored)"
 
     def segment_bbox(self, image: np.ndarray, bbox: List[int]) -> np.ndarray:
         # the reference ships the mask as the bytes of a bool array reshaped to image.shape[:2] (sam.py:67)
-        return self._model.segment_bbox(image, bbox).reshape(image.shape[:2])
+        seen = image
+        if self._emulate_jpeg:
+            from .transport import jpeg_roundtrip
+
+            seen = jpeg_roundtrip(image)
+        return self._model.segment_bbox(seen, bbox).reshape(image.shape[:2])

@@ -232,17 +232,25 @@ class YOLOv7:
 
 
 class YOLOv7Client:
-    """yolov7.py:113-121: ``predict(image_numpy) -> ObjectDetections``; ``port`` is accepted and ignored (in-process)."""
+    """yolov7.py:113-121: ``predict(image_numpy) -> ObjectDetections``; ``port`` is accepted and ignored (in-process).
+    ``emulate_jpeg=True`` reproduces the reference's quality-90 JPEG transport (server_wrapper.py:57-68) for A/B checks."""
 
     _shared: Dict[str, YOLOv7] = {}
 
-    def __init__(self, port: int = 12184, device=None, **model_kwargs) -> None:
+    def __init__(self, port: int = 12184, device=None, emulate_jpeg: bool = False, **model_kwargs) -> None:
         key = str(device)
         if key not in YOLOv7Client._shared:
             YOLOv7Client._shared[key] = YOLOv7(device=device, **model_kwargs)
         self._model = YOLOv7Client._shared[key]
+        self._emulate_jpeg = emulate_jpeg
         self.url = f"inprocess://yolov7 (port {port} ignored)"
 
     def predict(self, image_numpy: np.ndarray) -> ObjectDetections:
-        # the reference round-trips through JSON (yolov7.py:117-119): float32 tensors rebuilt from Python lists
-        return ObjectDetections.from_json(self._model.predict(image_numpy).to_json(), image_source=image_numpy)
+        seen = image_numpy
+        if self._emulate_jpeg:
+            from .transport import jpeg_roundtrip
+
+            seen = jpeg_roundtrip(image_numpy)
+        # the reference round-trips through JSON (yolov7.py:117-119): float32 tensors rebuilt from Python lists; the
+        # detections are attached to the caller's frame, not to the transported copy
+        return ObjectDetections.from_json(self._model.predict(seen).to_json(), image_source=image_numpy)
