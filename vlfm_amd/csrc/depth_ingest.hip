@@ -112,18 +112,6 @@ __device__ inline bool candidate(const HeightBand& band, int W, int H, int u, in
     return (z < band.depth_max) && !(zf < band.lo || zf > band.hi);                // :93, then the widened band
 }
 
-// The parameter block of an observation as wave-uniform values: read where it is needed (not carried through the streaming
-// loop) and forced into scalar registers -- the compiler does not prove the loads uniform by itself and would hold the 38
-// dwords in VECTOR registers across the whole drain loop, next to the f64 temporaries of two divisions.
-__device__ inline vlfm_ingest_params uniform_params(const vlfm_ingest_params* __restrict__ pp) {
-    vlfm_ingest_params p;
-    const int* src = reinterpret_cast<const int*>(pp);
-    int* dst = reinterpret_cast<int*>(&p);
-#pragma unroll
-    for (int u = 0; u < (int)(sizeof(vlfm_ingest_params) / 4); u++) dst[u] = __builtin_amdgcn_readfirstlane(src[u]);
-    return p;
-}
-
 template <bool HOLE_PASS>
 __device__ inline void place_exact(const IngestArgs& a, const vlfm_ingest_params& p, unsigned* grid, int obs, int u, int v,
                                    float d) {
@@ -176,33 +164,33 @@ __device__ inline void place_exact(const IngestArgs& a, const vlfm_ingest_params
 }
 
 // Work decomposition: a workgroup owns CG float4 column groups (CG*4 image columns, CG*16 contiguous bytes per row) and
-// a band of rows; lane (cx, ry) walks rows ry, ry+RL, ... of the band with UNROLL 16-byte loads in flight, and the loads of
-// the NEXT iteration are issued before the current one is processed.  With one band per image (the large-batch case) every
-// column maximum is produced by exactly one workgroup -- no atomic contention; small batches split the rows into bands to
-// fill the chip and merge through atomicMax on the keys.
+// a band of rows; lane (cx, ry) walks rows ry, ry+RL, ... of the band with UNROLL 16-byte loads in flight (optionally with
+// the loads of the NEXT iteration issued before the current one is processed).  With one band per image (the large-batch
+// case) every column maximum is produced by exactly one workgroup -- no atomic contention; small batches split the rows
+// into bands to fill the chip and merge through atomicMax on the keys.
 //
-// Obstacle placement by IN-WORKGROUP COMPACTION (round 3).  Only ~8 % of the texels survive candidate(), and they sit in a
+// Obstacle placement by WAVE-LOCAL COMPACTION (round 3).  Only ~8 % of the texels survive candidate(), and they sit in a
 // few image rows; calling the f64 placement from the streaming loop (rounds 1-2) kept both paths live in most wavefronts
 // and chained one dependent plane read per texel and lane: 142 us at 256 images, 0.28 of the HBM peak.  Now the streaming
-// loop only evaluates candidate() (a dozen f32 operations, no branch) into a 16-bit mask per lane and iteration; the
-// survivors are appended to a queue in LDS (wave prefix sum + one LDS atomic per wavefront; 8 bytes per entry: packed
-// (u, v) and the raw depth) and the WHOLE workgroup drains the queue with one candidate per lane: the f64 arithmetic runs
-// on full wavefronts and every plane read of a round is in flight at once.  Nothing goes through HBM (the first
-// design sketched -- a global candidate list and a second launch -- would have added ~100 MB of list traffic per 256
-// images).  The queue holds QCAP entries; an iteration with more candidates than that (a wall at band height filling the
-// tile) simply takes several append/drain rounds -- the loop is workgroup-uniform through __syncthreads_or.
+// loop only evaluates candidate() (a dozen f32 operations, no branch); the survivors of a row group are appended to the
+// WAVEFRONT's own ring in LDS (four ballots + mbcnt give every lane its slots; 8 bytes per entry: packed (u, v) and the raw
+// depth), and whenever the ring holds 64 entries the wavefront places 64 of them, one per lane: the f64 arithmetic runs on
+// full wavefronts and the 64 plane reads of a pass are in flight together.  Everything is wave-synchronous -- no workgroup
+// barrier, no atomics on the queue, the other wavefronts keep streaming -- and nothing goes through HBM (a global
+// candidate list + a second launch would add ~100 MB of list traffic per 256 images).  The remainder (< 64 entries) is
+// placed once, when the wavefront has finished its rows.  First form tried: one queue per workgroup filled through an LDS
+// atomic and drained by all 512 lanes between two barriers per round -- 185-213 us, SLOWER than the divergent form: the
+// barriers stop the streaming of all eight wavefronts for every round, and with 128 registers only two workgroups fit a CU.
 constexpr int CG = 32;   // float4 column groups per workgroup
 constexpr int RL = 16;   // row lanes per workgroup  -> 512 threads, a wavefront covers 2 rows x 512 B
 constexpr int INGEST_UNROLL = 4;
-constexpr int QCAP = 2048;   // candidate queue entries per workgroup (16 KB of LDS)
+constexpr int WQ = 512;      // ring entries per wavefront (power of two >= 63 + 256: a row group adds at most 256)
 constexpr int kIngestDefaultVariant = 0;   // 0 pf4 | 1 np4 | 2 np6 | 3 pf6 | 4 no register cap (see the stamped kernels)
 
 template <bool SCATTER, bool PREFETCH>
 __device__ __forceinline__ void depth_ingest_body(const IngestArgs& a) {
     __shared__ float4 part[RL][CG];
-    __shared__ uint2 queue[SCATTER ? QCAP : 1];
-    __shared__ unsigned q_tail;
-    __shared__ int sh_vlo, sh_vhi;
+    __shared__ uint2 ring[SCATTER ? CG * RL / 64 : 1][SCATTER ? WQ : 1];
     constexpr int UNROLL = INGEST_UNROLL;
     const int obs = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -214,33 +202,20 @@ __device__ __forceinline__ void depth_ingest_body(const IngestArgs& a) {
     const int bands = gridDim.y, band_id = blockIdx.y;
     const int n_groups = (a.H + RL - 1) / RL;
     const bool live = col4 < a.W4;
-    const int p_scatter = a.prm[obs].scatter, p_env = a.prm[obs].env;
-    const HeightBand band = make_band(a.prm[obs], a.W, a.H);
+    const vlfm_ingest_params p = a.prm[obs];   // uniform address, before any store of this kernel: scalar loads
+    const HeightBand band = make_band(p, a.W, a.H);
     const float* img = a.depth + (size_t)obs * a.H * a.W;
     unsigned* grid = nullptr;
-    if (SCATTER) grid = a.obstacle + (size_t)p_env * a.S * a.stride;
+    if (SCATTER) grid = a.obstacle + (size_t)p.env * a.S * a.stride;
     unsigned* holes = a.hole_bits ? a.hole_bits + (size_t)obs * a.H * a.hw : nullptr;
     const unsigned* filled = a.filled_bits ? a.filled_bits + (size_t)obs * a.H * a.hw : nullptr;
     const float ninf = -__builtin_huge_valf();
     float4 m = make_float4(ninf, ninf, ninf, ninf);
     bool saw_zero = false;
     const bool scatter_only = a.colmax_keys == nullptr && holes == nullptr;  // the pass after fill_small_holes
-    const bool do_scatter = SCATTER && (p_scatter & 1);
-    // hull [v_lo, v_hi] of the image rows that can reach the height band at all (row_may_hit is exact per row; the hull
-    // only lets a whole iteration skip the workgroup barrier of the placement rounds)
-    int v_lo = a.H, v_hi = -1;
-    if (SCATTER) {
-        if (tid == 0) { q_tail = 0u; sh_vlo = a.H; sh_vhi = -1; }
-        __syncthreads();
-        int lo = a.H, hi = -1;
-        if (do_scatter)
-            for (int v = tid; v < a.H; v += CG * RL)
-                if (row_may_hit(band, v, a.H)) { lo = min(lo, v); hi = max(hi, v); }
-        if (hi >= 0) { atomicMin(&sh_vlo, lo); atomicMax(&sh_vhi, hi); }
-        __syncthreads();
-        v_lo = sh_vlo; v_hi = sh_vhi;
-    }
-    unsigned drained = 0u;   // absolute queue index of the first entry not drained yet (identical in every thread)
+    const bool do_scatter = SCATTER && (p.scatter & 1);
+    uint2* q = ring[SCATTER ? (tid >> 6) : 0];
+    unsigned q_head = 0u, q_cnt = 0u;   // wave-uniform: first pending entry, number of pending entries
 
     // one iteration's loads: rows (g0 + k * bands) * RL + ry, k < UNROLL.  Rows that cannot reach the height band are not
     // even loaded by a scatter-only pass; a combined pass loads them (column maximum, hole bits) but never tests them.
@@ -252,7 +227,7 @@ __device__ __forceinline__ void depth_ingest_body(const IngestArgs& a) {
         for (int k = 0; k < UNROLL; k++) {
             const int r = (g0 + k * bands) * RL + ry;
             bool want = live && r < a.H;
-            const bool hit = SCATTER && want && r >= v_lo && r <= v_hi && row_may_hit(band, r, a.H);
+            const bool hit = SCATTER && do_scatter && want && row_may_hit(band, r, a.H);
             if (SCATTER && scatter_only) want = hit;
             nxt[k] = want ? reinterpret_cast<const float4*>(img + (size_t)r * a.W)[col4] : make_float4(ninf, ninf, ninf, ninf);
             nxt_ok |= (want ? 1u : 0u) << k;
@@ -260,8 +235,8 @@ __device__ __forceinline__ void depth_ingest_body(const IngestArgs& a) {
         }
     };
     if (PREFETCH && band_id < n_groups) issue(band_id);
-    // every lane of the workgroup runs the same trip count (predicated), so the cross-lane packing of hole bits and the
-    // workgroup barriers of the placement rounds are always executed convergently
+    // every lane of the workgroup runs the same trip count (predicated), so the cross-lane packing of hole bits and of the
+    // candidate ring is always executed convergently
     for (int g0 = band_id; g0 < n_groups; g0 += UNROLL * bands) {
         if (!PREFETCH) issue(g0);
         float4 d[UNROLL];
@@ -269,7 +244,6 @@ __device__ __forceinline__ void depth_ingest_body(const IngestArgs& a) {
         for (int k = 0; k < UNROLL; k++) d[k] = nxt[k];
         const unsigned okmask = nxt_ok, hitmask = nxt_hit;
         if (PREFETCH && g0 + UNROLL * bands < n_groups) issue(g0 + UNROLL * bands);
-        unsigned cand = 0u;   // bit 4k + c: texel c of this lane's float4 of row group k needs the exact placement
 #pragma unroll
         for (int k = 0; k < UNROLL; k++) {
             const int r = (g0 + k * bands) * RL + ry;
@@ -291,7 +265,11 @@ __device__ __forceinline__ void depth_ingest_body(const IngestArgs& a) {
                     holes[(size_t)r * a.hw + (col4 >> 3)] = word;
                 }
             }
-            if (do_scatter && ((hitmask >> k) & 1u)) {
+            if (!SCATTER || !do_scatter) continue;
+            const bool hit = (hitmask >> k) & 1u;
+            if (__ballot(hit) == 0ull) continue;   // neither of this wavefront's two rows can reach the height band
+            unsigned c4 = 0u;
+            if (hit) {
                 // fill_small_holes (img_utils.py:361-390) turned a `filled` texel into 1.0 -> z == max_depth -> masked (:93).
                 // A zero texel is a hole in the depth image.  scatter bit 1: hole_area_thresh == -1 semantics
                 // (obstacle_map.py:87-89), every zero becomes 1.0 and therefore falls outside max_depth.  scatter bit 2:
@@ -299,88 +277,47 @@ __device__ __forceinline__ void depth_ingest_body(const IngestArgs& a) {
                 // from the hole bit plane (an unfilled, large hole is used as it is: depth 0 -> z = min_depth).
                 unsigned skip = 0u;
                 if (filled) skip = (filled[(size_t)r * a.hw + (col4 >> 3)] >> ((col4 & 7) * 4)) & 0xFu;
-                if (p_scatter & 6)
+                if (p.scatter & 6)
                     skip |= (d[k].x == 0.0f ? 1u : 0u) | (d[k].y == 0.0f ? 2u : 0u) | (d[k].z == 0.0f ? 4u : 0u) |
                             (d[k].w == 0.0f ? 8u : 0u);
                 const int u = col4 * 4;
-                unsigned c4 = (candidate(band, a.W, a.H, u + 0, r, d[k].x) ? 1u : 0u) |
-                              (candidate(band, a.W, a.H, u + 1, r, d[k].y) ? 2u : 0u) |
-                              (candidate(band, a.W, a.H, u + 2, r, d[k].z) ? 4u : 0u) |
-                              (candidate(band, a.W, a.H, u + 3, r, d[k].w) ? 8u : 0u);
-                cand |= (c4 & ~skip) << (4 * k);
+                c4 = ((candidate(band, a.W, a.H, u + 0, r, d[k].x) ? 1u : 0u) |
+                      (candidate(band, a.W, a.H, u + 1, r, d[k].y) ? 2u : 0u) |
+                      (candidate(band, a.W, a.H, u + 2, r, d[k].z) ? 4u : 0u) |
+                      (candidate(band, a.W, a.H, u + 3, r, d[k].w) ? 8u : 0u)) & ~skip;
+            }
+            // ---- append this row group's survivors to the wavefront's ring: texel c of lane L goes behind all texels
+            // c' < c of every lane and the texels c of the lanes below L
+            const unsigned long long B0 = __ballot(c4 & 1u), B1 = __ballot(c4 & 2u), B2 = __ballot(c4 & 4u), B3 = __ballot(c4 & 8u);
+            const unsigned n0 = __popcll(B0), n1 = __popcll(B1), n2 = __popcll(B2), n3 = __popcll(B3);
+            const unsigned total = n0 + n1 + n2 + n3;
+            if (total == 0u) continue;
+            {
+                const unsigned tail = q_head + q_cnt;
+                const unsigned pos = ((unsigned)(col4 * 4)) | ((unsigned)r << 16);
+                const unsigned below0 = __builtin_amdgcn_mbcnt_hi((unsigned)(B0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)B0, 0u));
+                const unsigned below1 = __builtin_amdgcn_mbcnt_hi((unsigned)(B1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)B1, 0u));
+                const unsigned below2 = __builtin_amdgcn_mbcnt_hi((unsigned)(B2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)B2, 0u));
+                const unsigned below3 = __builtin_amdgcn_mbcnt_hi((unsigned)(B3 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)B3, 0u));
+                if (c4 & 1u) q[(tail + below0) & (WQ - 1)] = make_uint2(pos + 0u, __float_as_uint(d[k].x));
+                if (c4 & 2u) q[(tail + n0 + below1) & (WQ - 1)] = make_uint2(pos + 1u, __float_as_uint(d[k].y));
+                if (c4 & 4u) q[(tail + n0 + n1 + below2) & (WQ - 1)] = make_uint2(pos + 2u, __float_as_uint(d[k].z));
+                if (c4 & 8u) q[(tail + n0 + n1 + n2 + below3) & (WQ - 1)] = make_uint2(pos + 3u, __float_as_uint(d[k].w));
+                q_cnt += total;
+            }
+            // ---- full passes: 64 pending entries -> one per lane
+            while (q_cnt >= 64u) {
+                const uint2 e = q[(q_head + (unsigned)lane) & (WQ - 1)];
+                place_exact<false>(a, p, grid, obs, (int)(e.x & 0xFFFFu), (int)(e.x >> 16), __uint_as_float(e.y));
+                q_head += 64u;
+                q_cnt -= 64u;
             }
         }
-        if (!SCATTER || !do_scatter) continue;
-        {   // can any row of this iteration reach the band?  (workgroup-uniform: depends on g0 only)
-            bool may = false;
-#pragma unroll
-            for (int k = 0; k < UNROLL; k++) {
-                const int r0 = (g0 + k * bands) * RL;
-                may |= r0 <= v_hi && r0 + RL - 1 >= v_lo && r0 < a.H;
-            }
-            if (!may) continue;
-        }
-        // ---- placement rounds: append the lanes' candidates to the LDS queue, drain it with one candidate per lane.
-        // The first round takes the texels from the registers they were loaded into; a further round (more than QCAP
-        // candidates in one iteration: rare) re-reads its leftovers from the image (L2), so that the 16 loaded values are
-        // dead during the f64 drain instead of occupying registers next to it.
-        auto append = [&](const float4 (&dd)[UNROLL]) {
-            const int cnt = __builtin_popcount(cand);
-            int incl = cnt;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int t = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += t;
-            }
-            const int total = __shfl(incl, 63, 64);
-            unsigned base = 0u;
-            if (lane == 0 && total) base = atomicAdd(&q_tail, (unsigned)total);
-            base = (unsigned)__shfl((int)base, 0, 64);
-            unsigned slot = base + (unsigned)(incl - cnt) - drained;   // queue slot of this lane's first candidate
-            const unsigned pos0 = ((unsigned)(col4 * 4)) | ((unsigned)ry << 16);
-#pragma unroll
-            for (int k = 0; k < UNROLL; k++) {
-                const unsigned rbits = (unsigned)((g0 + k * bands) * RL) << 16;
-                const float dv[4] = {dd[k].x, dd[k].y, dd[k].z, dd[k].w};
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const unsigned bit = 1u << (4 * k + c);
-                    if (cand & bit) {
-                        if (slot < (unsigned)QCAP) {
-                            queue[slot] = make_uint2(pos0 + rbits + (unsigned)c, __float_as_uint(dv[c]));
-                            cand &= ~bit;
-                        }
-                        slot++;
-                    }
-                }
-            }
-        };
-        auto drain = [&]() {
-            __syncthreads();
-            const unsigned tail = q_tail;
-            const unsigned n_q = min(tail - drained, (unsigned)QCAP);
-            if (tid < n_q) {
-                const vlfm_ingest_params p = uniform_params(a.prm + obs);
-                for (unsigned i = tid; i < n_q; i += CG * RL) {
-                    const uint2 e = queue[i];
-                    place_exact<false>(a, p, grid, obs, (int)(e.x & 0xFFFFu), (int)(e.x >> 16), __uint_as_float(e.y));
-                }
-            }
-            drained = tail;
-        };
-        if (!__syncthreads_or(cand != 0u)) continue;   // (also: the previous iteration's drain has finished with the queue)
-        append(d);
-        drain();
-        while (__syncthreads_or(cand != 0u)) {
-            float4 again[UNROLL];
-#pragma unroll
-            for (int k = 0; k < UNROLL; k++) {
-                const int r = (g0 + k * bands) * RL + ry;
-                again[k] = ((cand >> (4 * k)) & 0xFu) ? reinterpret_cast<const float4*>(img + (size_t)r * a.W)[col4]
-                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            append(again);
-            drain();
+    }
+    if (SCATTER && do_scatter && q_cnt) {   // the wavefront's remainder (< 64 entries)
+        if ((unsigned)lane < q_cnt) {
+            const uint2 e = q[(q_head + (unsigned)lane) & (WQ - 1)];
+            place_exact<false>(a, p, grid, obs, (int)(e.x & 0xFFFFu), (int)(e.x >> 16), __uint_as_float(e.y));
         }
     }
     if (saw_zero) atomicOr(&a.status[2 * obs + 1], 1);

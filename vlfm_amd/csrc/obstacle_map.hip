@@ -1478,9 +1478,9 @@ extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, in
         const size_t budget = (size_t)152 * 1024;
         fs.lds_states = lds < budget ? (int)((budget - lds) / 8 < 16384 ? (budget - lds) / 8 : 16384) : 0;
         lds += (size_t)fs.lds_states * 8;
-        static LdsOptIn opt_fog;   // beyond the default dynamic-LDS limit of 64 KB: opt in once per device, to the maximum
-        if (lds > 64 * 1024 && !opt_fog.ensure(reinterpret_cast<const void*>(fog_of_war_kernel), 160 * 1024))
-            return fail(VLFM_ERR_HIP, "obstacle_map_update_batched: cannot opt in to 160 KB of LDS for the fog-of-war kernel");
+        static LdsOptIn opt_fog;   // beyond the default dynamic-LDS limit of 64 KB: opt in (once per device and size)
+        if (lds > 64 * 1024 && !opt_fog.ensure(reinterpret_cast<const void*>(fog_of_war_kernel), lds))
+            return fail(VLFM_ERR_HIP, "obstacle_map_update_batched: cannot opt in to the fog-of-war kernel's LDS window");
         VLFM_TIMED("fog_of_war_kernel", s);
         VLFM_KLAUNCH(fog_of_war_kernel, dim3(n), dim3(1024), lds, s, d_prm, mp, fs);
     }

@@ -20,15 +20,19 @@ inline int check_launch(const char* what) {
     return VLFM_OK;
 }
 // More than 64 KB of dynamic LDS needs an explicit opt-in per kernel AND per device.  One instance per call site
-// (function-local static); remembers which devices of this process have been done.
+// (function-local static); remembers how many bytes each device of this process has been opted in to, and asks again only
+// for more.  (The limit is 160 KB minus the kernel's static LDS: ask for what the launch uses, not for the maximum.)
 struct LdsOptIn {
-    unsigned long long done = 0;
+    size_t have[64] = {};
     bool ensure(const void* kernel, size_t bytes) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) return false;
-        if (dev < 64 && ((done >> dev) & 1ull)) return true;
-        if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
-        if (dev < 64) done |= 1ull << dev;
+        if (dev >= 0 && dev < 64 && have[dev] >= bytes) return true;
+        if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        if (dev >= 0 && dev < 64) have[dev] = bytes;
         return true;
     }
 };

@@ -1,0 +1,392 @@
+"""The YOLOv7-E6E network the reference deploys (reference: /root/reference/vlfm/vlm/yolov7.py:33-47 --
+``attempt_load("data/yolov7-e6e.pt")`` then ``TracedModel``; the graph itself lives in the un-vendored WongKinYiu/yolov7
+repository [ext], ``cfg/deploy/yolov7-e6e.yaml`` + ``models/common.py`` / ``models/yolo.py``).
+
+Restated from the published architecture so that
+
+* the module list has the checkpoint's OWN indices: ``state_dict()`` keys are ``model.{i}.conv.weight``, ``model.{i}.bn.*``,
+  ``model.{i}.cv1.conv.weight`` (DownC / SPPCSPC), ``model.261.m.{j}.weight`` ..., i.e. a state dict taken from
+  ``yolov7-e6e.pt`` loads with ``strict=True`` (`load_yolov7_state_dict`, strict both ways, fused or unfused Conv+BN);
+* the published figures of the YOLOv7-E6E row hold: 151.7 M parameters, 843.2 GFLOPs at 1280 x 1280 (tests/test_yolov7_cpu.py
+  pins both within 0.5 %), 4 detection levels at strides 8 / 16 / 32 / 64 with 3 anchors each -> 17 850 candidates at the
+  reference's 448 x 640 input (yolov7.py:71-76).
+
+Layout of the 262 modules (index: module), as in the yaml:
+  0 ReOrg | 1 Conv(3*4 -> 80, 3x3) | five stages, each = DownC + E-ELAN (two ELAN branches of 2 x 1x1 + 6 x 3x3 + concat + 1x1,
+  summed by a Shortcut): 2-23 (160), 24-45 (320), 46-67 (640), 68-89 (960), 90-111 (1280) | 112 SPPCSPC(640) | top-down:
+  113-137 (P5, 480), 138-162 (P4, 320), 163-187 (P3, 160), each = 1x1 + upsample + 1x1 lateral + concat + E-ELAN-W |
+  bottom-up: 188-210 (P4, 320), 211-233 (P5, 480), 234-256 (P6, 640), each = DownC + concat + E-ELAN-W | 257-260 3x3 output
+  convs (320 / 640 / 960 / 1280) | 261 Detect.
+
+``yolov7-e6e.pt`` itself is a pickle of the yolov7 repository's classes (``models.yolo.Model``, ``models.common.Conv`` ...).
+`read_yolov7_checkpoint` opens it WITHOUT that repository: a restricted unpickler maps every class of the repository's
+``models.*`` / ``utils.*`` namespaces onto an inert ``nn.Module`` shell (pickle restores ``_modules`` / ``_parameters`` /
+``_buffers`` through ``__dict__``, no constructor runs), and the state dict is read off the shells.  Nothing but tensors,
+containers and those shells is allowed through.
+"""
+from __future__ import annotations
+
+import io
+import math
+import pickle
+from typing import Dict, List, Sequence, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+ANCHORS = [[19, 27, 44, 40, 38, 94], [96, 68, 86, 152, 180, 137], [140, 301, 303, 264, 238, 542],
+           [436, 615, 739, 380, 925, 792]]          # cfg/deploy/yolov7-e6e.yaml [ext]
+STRIDES = [8, 16, 32, 64]
+PUBLISHED = {"params_M": 151.7, "gflops_at_1280x1280": 843.2}   # yolov7 README, YOLOv7-E6E row [ext]
+
+
+# ------------------------------------------------------------------------------------------------ modules (models/common.py)
+class Conv(nn.Module):
+    """Conv2d(bias=False) + BatchNorm2d + SiLU, 'same' padding (models/common.py Conv [ext])."""
+
+    def __init__(self, c1: int, c2: int, k: int = 1, s: int = 1):
+        super().__init__()
+        self.conv = nn.Conv2d(c1, c2, k, s, k // 2, bias=False)
+        self.bn = nn.BatchNorm2d(c2, eps=1e-3, momentum=0.03)   # yolov7 sets these in Model.__init__ (initialize_weights)
+        self.act = nn.SiLU(inplace=True)
+
+    def forward(self, x):
+        return self.act(self.bn(self.conv(x)))
+
+
+class ReOrg(nn.Module):
+    def forward(self, x):  # space to depth: (b, c, h, w) -> (b, 4c, h/2, w/2)
+        return torch.cat([x[..., ::2, ::2], x[..., 1::2, ::2], x[..., ::2, 1::2], x[..., 1::2, 1::2]], 1)
+
+
+class DownC(nn.Module):
+    """cat(3x3 stride-k conv of a 1x1 conv, 1x1 conv of a k x k max-pool) (models/common.py DownC [ext])."""
+
+    def __init__(self, c1: int, c2: int, k: int = 2):
+        super().__init__()
+        self.cv1 = Conv(c1, c1, 1, 1)
+        self.cv2 = Conv(c1, c2 // 2, 3, k)
+        self.cv3 = Conv(c1, c2 // 2, 1, 1)
+        self.mp = nn.MaxPool2d(kernel_size=k, stride=k)
+
+    def forward(self, x):
+        return torch.cat((self.cv2(self.cv1(x)), self.cv3(self.mp(x))), dim=1)
+
+
+class SPPCSPC(nn.Module):
+    """CSP spatial pyramid pooling (models/common.py SPPCSPC, e = 0.5, k = (5, 9, 13) [ext])."""
+
+    def __init__(self, c1: int, c2: int, k: Sequence[int] = (5, 9, 13)):
+        super().__init__()
+        c_ = c2
+        self.cv1, self.cv2 = Conv(c1, c_, 1, 1), Conv(c1, c_, 1, 1)
+        self.cv3, self.cv4 = Conv(c_, c_, 3, 1), Conv(c_, c_, 1, 1)
+        self.m = nn.ModuleList([nn.MaxPool2d(kernel_size=x, stride=1, padding=x // 2) for x in k])
+        self.cv5, self.cv6 = Conv(4 * c_, c_, 1, 1), Conv(c_, c_, 3, 1)
+        self.cv7 = Conv(2 * c_, c2, 1, 1)
+
+    def forward(self, x):
+        x1 = self.cv4(self.cv3(self.cv1(x)))
+        y1 = self.cv6(self.cv5(torch.cat([x1] + [m(x1) for m in self.m], 1)))
+        return self.cv7(torch.cat((y1, self.cv2(x)), dim=1))
+
+
+class Concat(nn.Module):
+    def forward(self, xs):
+        return torch.cat(xs, 1)
+
+
+class Shortcut(nn.Module):
+    def forward(self, xs):
+        return xs[0] + xs[1]
+
+
+class Detect(nn.Module):
+    """Inference form of models/yolo.py Detect [ext]: per level a 1x1 conv to na * (5 + nc) channels, sigmoid, grid decode
+    ``xy = (2 s - 0.5 + grid) * stride``, ``wh = (2 s)^2 * anchor``; output [B, sum(na * h * w), 5 + nc] in input pixels."""
+
+    def __init__(self, nc: int, anchors: Sequence[Sequence[int]], ch: Sequence[int]):
+        super().__init__()
+        self.nc, self.no, self.nl, self.na = nc, nc + 5, len(anchors), len(anchors[0]) // 2
+        a = torch.tensor(anchors, dtype=torch.float32).view(self.nl, -1, 2)
+        # the checkpoint stores `anchors` in units of the level's stride and `anchor_grid` in pixels (models/yolo.py)
+        self.register_buffer("anchors", a / torch.tensor(STRIDES[: self.nl], dtype=torch.float32).view(-1, 1, 1))
+        self.register_buffer("anchor_grid", a.clone().view(self.nl, 1, -1, 1, 1, 2))
+        self.m = nn.ModuleList(nn.Conv2d(x, self.no * self.na, 1) for x in ch)
+        self.stride = STRIDES[: self.nl]
+
+    def forward(self, xs):
+        z = []
+        for i, x in enumerate(xs):
+            y = self.m[i](x)
+            b, _, ny, nx = y.shape
+            y = y.view(b, self.na, self.no, ny, nx).permute(0, 1, 3, 4, 2).sigmoid()
+            gy, gx = torch.meshgrid(torch.arange(ny, device=y.device), torch.arange(nx, device=y.device), indexing="ij")
+            grid = torch.stack((gx, gy), -1).view(1, 1, ny, nx, 2).to(y.dtype)
+            xy = (y[..., 0:2] * 2.0 - 0.5 + grid) * self.stride[i]
+            wh = (y[..., 2:4] * 2) ** 2 * self.anchor_grid[i].to(y.dtype)
+            z.append(torch.cat((xy, wh, y[..., 4:]), -1).view(b, -1, self.no))
+        return torch.cat(z, 1)
+
+
+# ------------------------------------------------------------------------------------------------ the layer table
+Spec = Tuple[Union[int, List[int]], str, tuple]   # (from, module, args) with yolov7's relative / absolute `from` convention
+
+
+def _elan(specs: List[Spec], c_in_from: int, hidden: int, mid: int, out: int, taps: List[int]) -> None:
+    """One ELAN branch: two 1x1 convs on the block input, six chained 3x3 convs, concat of `taps`, 1x1 to `out`."""
+    specs.append((c_in_from, "Conv", (hidden, 1, 1)))
+    specs.append((c_in_from - 1, "Conv", (hidden, 1, 1)))
+    for _ in range(6):
+        specs.append((-1, "Conv", (mid, 3, 1)))
+    specs.append((taps, "Concat", ()))
+    specs.append((-1, "Conv", (out, 1, 1)))
+
+
+def _e_elan(specs: List[Spec], hidden: int, mid: int, out: int, taps: List[int]) -> None:
+    """E-ELAN: two ELAN branches on the same input (the second reaches back over the first: from -11 / -12), summed."""
+    _elan(specs, -1, hidden, mid, out, taps)
+    _elan(specs, -11, hidden, mid, out, taps)
+    specs.append(([-1, -11], "Shortcut", ()))
+
+
+def layer_table(nc: int = 80) -> List[Spec]:
+    s: List[Spec] = [(-1, "ReOrg", ()), (-1, "Conv", (80, 3, 1))]
+    back = [-1, -3, -5, -7, -8]                       # backbone ELAN: every other 3x3 + the two 1x1
+    for c, out in ((64, 160), (128, 320), (256, 640), (384, 960), (512, 1280)):
+        s.append((-1, "DownC", (out,)))
+        _e_elan(s, c, c, out, back)
+    assert len(s) == 112
+    s.append((-1, "SPPCSPC", (640,)))                  # 112
+    head = [-1, -2, -3, -4, -5, -6, -7, -8]            # head ELAN-W: all six 3x3 + the two 1x1
+    for c, route in ((480, 89), (320, 67), (160, 45)):  # top-down: P5, P4, P3
+        s.append((-1, "Conv", (c, 1, 1)))
+        s.append((-1, "Upsample", ()))
+        s.append((route, "Conv", (c, 1, 1)))
+        s.append(([-1, -2], "Concat", ()))
+        _e_elan(s, int(c * 0.8), c * 2 // 5, c, head)
+    assert len(s) == 188
+    for c, route in ((320, 162), (480, 137), (640, 112)):   # bottom-up: P4, P5, P6
+        s.append((-1, "DownC", (c,)))
+        s.append(([-1, route], "Concat", ()))
+        _e_elan(s, int(c * 0.8), c * 2 // 5, c, head)
+    assert len(s) == 257
+    for route, c in ((187, 320), (210, 640), (233, 960), (256, 1280)):
+        s.append((route, "Conv", (c, 3, 1)))
+    s.append(([257, 258, 259, 260], "Detect", (nc,)))
+    assert len(s) == 262
+    return s
+
+
+class YoloV7E6E(nn.Module):
+    """models/yolo.py Model for cfg/deploy/yolov7-e6e.yaml [ext]: `self.model` is the indexed module list; forward follows
+    the `from` column.  Output of the Detect layer: [B, N, 5 + nc] (yolov7's inference tensor, `pred[0]` of the reference,
+    yolov7.py:79)."""
+
+    def __init__(self, nc: int = 80, ch: int = 3):
+        super().__init__()
+        self.nc = nc
+        table = layer_table(nc)
+        chans: List[int] = []
+        mods: List[nn.Module] = []
+        self.froms: List[Union[int, List[int]]] = []
+        for i, (f, kind, args) in enumerate(table):
+            def src(j):
+                return ch if (j == -1 and i == 0) else chans[j if j >= 0 else i + j]
+            if kind == "ReOrg":
+                m, c2 = ReOrg(), src(f) * 4
+            elif kind == "Conv":
+                m, c2 = Conv(src(f), *args), args[0]
+            elif kind == "DownC":
+                m, c2 = DownC(src(f), args[0]), args[0]
+            elif kind == "SPPCSPC":
+                m, c2 = SPPCSPC(src(f), args[0]), args[0]
+            elif kind == "Upsample":
+                m, c2 = nn.Upsample(None, 2, "nearest"), src(f)
+            elif kind == "Concat":
+                m, c2 = Concat(), sum(src(j) for j in f)
+            elif kind == "Shortcut":
+                m, c2 = Shortcut(), src(f[0])
+                assert src(f[0]) == src(f[1])
+            elif kind == "Detect":
+                m, c2 = Detect(args[0], ANCHORS, [src(j) for j in f]), 0
+            else:  # pragma: no cover
+                raise ValueError(kind)
+            mods.append(m)
+            chans.append(c2)
+            self.froms.append(f)
+        self.model = nn.ModuleList(mods)
+        # which outputs are read again later (yolov7's `save` list): everything else is dropped as soon as it is consumed
+        self.keep = set()
+        for i, f in enumerate(self.froms):
+            for j in ([f] if isinstance(f, int) else f):
+                if j != -1:
+                    self.keep.add(j if j >= 0 else i + j)
+
+    def init_random(self, seed: int = 0) -> "YoloV7E6E":
+        """Kaiming-uniform convolutions (PyTorch's default), BatchNorm at identity, and yolov7's Detect._initialize_biases [ext]
+        (objectness prior of ~8 objects per 640-px image, class prior 0.6 / nc): without it a random-init head passes half of
+        the 17 850 candidates through conf > 0.25, which no trained detector does and which would make the NMS the dominant
+        cost of a benchmark run."""
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        with torch.no_grad():
+            for m in self.modules():
+                if isinstance(m, nn.Conv2d):
+                    fan_in = m.in_channels * m.kernel_size[0] * m.kernel_size[1]
+                    bound = math.sqrt(3.0 / fan_in)     # variance-preserving through SiLU-ish activations, 262 layers deep
+                    m.weight.copy_((torch.rand(m.weight.shape, generator=g) * 2 - 1).mul_(bound).to(m.weight.device))
+            det = self.model[-1]
+            for conv, stride in zip(det.m, det.stride):
+                b = conv.bias.view(det.na, -1)
+                b.zero_()
+                b[:, 4] = math.log(8 / (640 / stride) ** 2)
+                b[:, 5:] = math.log(0.6 / (self.nc - 0.99))
+        return self
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        outs: Dict[int, torch.Tensor] = {}
+        for i, (m, f) in enumerate(zip(self.model, self.froms)):
+            if isinstance(f, int):
+                inp = x if f == -1 else outs[f if f >= 0 else i + f]
+            else:
+                inp = [x if j == -1 else outs[j if j >= 0 else i + j] for j in f]
+            x = m(inp)
+            if i in self.keep:
+                outs[i] = x
+        return x
+
+
+def count_parameters(model: nn.Module) -> int:
+    return sum(p.numel() for p in model.parameters())
+
+
+def gflops(model: nn.Module, height: int, width: int) -> float:
+    """2 x MACs of every convolution for one image of height x width (what yolov7's model_info / thop reports), from the
+    layer shapes alone (meta tensors: nothing is allocated or computed)."""
+    total = [0.0]
+    hooks = []
+
+    def hook(m, inp, out):
+        total[0] += 2.0 * out.numel() * m.kernel_size[0] * m.kernel_size[1] * (m.in_channels // m.groups)
+
+    for m in model.modules():
+        if isinstance(m, nn.Conv2d):
+            hooks.append(m.register_forward_hook(hook))
+    dev = next(model.parameters()).device
+    with torch.inference_mode():
+        model(torch.zeros((1, 3, height, width), device=dev))
+    for h in hooks:
+        h.remove()
+    return total[0] / 1e9
+
+
+# ------------------------------------------------------------------------------------------------ weights
+def expected_state_dict_keys(model: YoloV7E6E, fused: bool = False) -> List[str]:
+    keys = list(model.state_dict().keys())
+    if fused:  # yolov7's Model.fuse(): bn folded into conv, which gains a bias
+        keys = [k for k in keys if ".bn." not in k]
+        keys += [k[: -len("weight")] + "bias" for k in keys if k.endswith(".conv.weight")]
+    return keys
+
+
+def load_yolov7_state_dict(model: YoloV7E6E, sd: Dict[str, torch.Tensor]) -> str:
+    """Load a state dict taken from ``yolov7-e6e.pt`` (``ckpt['model'].state_dict()``, before or after ``fuse()``), strict
+    both ways: every tensor of the file must be consumed and every parameter / buffer of the graph must be fed, with equal
+    shapes.  Returns "unfused" or "fused".  A fused file is loaded by un-fusing trivially: BatchNorm becomes the identity
+    (weight 1, bias = the conv bias, mean 0, var 1 - eps) so that the graph -- and the BatchNorm folding done afterwards --
+    sees one form."""
+    sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}
+    own = model.state_dict()
+    fused = not any(".bn." in k for k in sd)
+    ignorable = {k for k in sd if k.endswith("num_batches_tracked")} | {k for k in sd if k.endswith(".ia.implicit") or
+                                                                        k.endswith(".im.implicit")}
+    if any(k.endswith(".implicit") for k in sd):
+        raise ValueError("this state dict has IDetect's implicit layers: it is a *_training.pt model, not the deploy model "
+                         "yolov7-e6e.pt the reference loads (vlfm/vlm/yolov7.py:35)")
+    feed: Dict[str, torch.Tensor] = {}
+    used = set()
+    for k, t in own.items():
+        if k.endswith("num_batches_tracked"):
+            if k in sd:
+                feed[k] = sd[k]
+                used.add(k)
+            continue
+        if fused and ".bn." in k:
+            conv_bias = sd.get(k.split(".bn.")[0] + ".conv.bias")
+            if conv_bias is None:
+                raise KeyError(f"fused state dict lacks {k.split('.bn.')[0]}.conv.bias")
+            used.add(k.split(".bn.")[0] + ".conv.bias")
+            leaf = k.rsplit(".", 1)[1]
+            if leaf == "weight":
+                feed[k] = torch.ones_like(t)
+            elif leaf == "bias":
+                feed[k] = conv_bias.to(t.dtype)
+            elif leaf == "running_mean":
+                feed[k] = torch.zeros_like(t)
+            else:  # running_var: the fold computes w / sqrt(var + eps)
+                feed[k] = torch.full_like(t, 1.0 - 1e-3)
+            continue
+        if k not in sd:
+            raise KeyError(f"state dict lacks {k} (is this yolov7-e6e?  {len(sd)} tensors given, {len(own)} expected)")
+        if tuple(sd[k].shape) != tuple(t.shape):
+            raise ValueError(f"{k}: shape {tuple(sd[k].shape)} in the file, {tuple(t.shape)} in the yolov7-e6e graph")
+        feed[k] = sd[k]
+        used.add(k)
+    extra = sorted(set(sd) - used - ignorable)
+    if extra:
+        raise KeyError(f"{len(extra)} tensors of the file have no place in the yolov7-e6e graph, e.g. {extra[:4]}")
+    model.load_state_dict(feed, strict=False)
+    return "fused" if fused else "unfused"
+
+
+class _Shell(nn.Module):
+    """What a class of the yolov7 repository becomes when its pickle is opened without the repository."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("a checkpoint shell cannot be executed; take its state_dict()")
+
+
+class _CheckpointUnpickler(pickle.Unpickler):
+    _ALLOWED_PREFIXES = ("torch.", "collections", "numpy", "_codecs", "builtins")
+    _ALLOWED_BUILTINS = {"set", "frozenset", "dict", "list", "tuple", "int", "float", "bool", "str", "bytes", "slice",
+                         "complex", "getattr", "object"}
+
+    def find_class(self, module: str, name: str):
+        root = module.split(".")[0]
+        if root in ("models", "utils"):   # the yolov7 repository's own namespaces
+            return type(name, (_Shell,), {"__module__": module})
+        if module == "builtins":
+            if name not in self._ALLOWED_BUILTINS or name == "getattr":
+                raise pickle.UnpicklingError(f"refusing builtins.{name} in a checkpoint")
+            return super().find_class(module, name)
+        if module == "torch" or module.startswith(self._ALLOWED_PREFIXES) or root in ("torch", "numpy", "collections"):
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"refusing {module}.{name} in a checkpoint")
+
+
+class _PickleModule:
+    """`pickle_module` for torch.load: the standard module with the restricted Unpickler."""
+
+    __name__ = "vlfm_amd_checkpoint_pickle"
+    Unpickler = _CheckpointUnpickler
+    load = staticmethod(lambda f, **kw: _CheckpointUnpickler(f, **kw).load())
+    loads = staticmethod(lambda b, **kw: _CheckpointUnpickler(io.BytesIO(b), **kw).load())
+    dump, dumps, HIGHEST_PROTOCOL, PickleError, UnpicklingError = (pickle.dump, pickle.dumps, pickle.HIGHEST_PROTOCOL,
+                                                                   pickle.PickleError, pickle.UnpicklingError)
+
+
+def read_yolov7_checkpoint(path: str) -> Dict[str, torch.Tensor]:
+    """State dict (f32) of the model inside a yolov7 ``.pt`` (what ``attempt_load`` reads: ``ckpt['ema' if ckpt.get('ema')
+    else 'model']``, models/experimental.py [ext]) -- or of a file that already IS a state dict."""
+    ckpt = torch.load(path, map_location="cpu", pickle_module=_PickleModule, weights_only=False)
+    if isinstance(ckpt, dict) and ("model" in ckpt or "ema" in ckpt):
+        obj = ckpt["ema"] if ckpt.get("ema") is not None else ckpt["model"]
+    else:
+        obj = ckpt
+    if isinstance(obj, nn.Module):
+        sd = obj.state_dict()
+    elif isinstance(obj, dict) and all(torch.is_tensor(v) for v in obj.values()):
+        sd = obj
+    else:
+        raise ValueError(f"{path!r}: neither a yolov7 checkpoint nor a state dict ({type(obj).__name__})")
+    return {k: v.float() if v.is_floating_point() else v for k, v in sd.items()}
