@@ -69,11 +69,8 @@ def test_resize_area_oracle_known_answers():
 
 def test_stand_in_networks_contracts():
     from vlfm_amd.vlm.sam import TinyViT
-    from vlfm_amd.vlm.yolov7 import YoloV7E6EClassNet
 
-    with torch.inference_mode():
-        y = YoloV7E6EClassNet(width=8).eval()(torch.rand(1, 3, 128, 192))
-        assert y.shape == (1, (16 * 24 + 8 * 12 + 4 * 6 + 2 * 3) * 3, 85)
+    with torch.inference_mode():   # (the detector's graph has its own file: tests/test_yolov7_cpu.py)
         e = TinyViT().eval()(torch.rand(1, 3, 128, 128))[0]
         assert e.shape == (1, 256, 8, 8)
     from vlfm_amd.vlm.grounding_dino import WordTokenizer, preprocess_caption

@@ -78,9 +78,9 @@ def test_yolov7_pipeline(gpu_device):
     from vlfm_amd.vlm.coco_classes import COCO_CLASSES
     from vlfm_amd.vlm.yolov7 import YOLOv7, YOLOv7Client
 
-    model = YOLOv7(device=gpu_device, width=16, allow_random_init=True)
+    model = YOLOv7(device=gpu_device, width_multiple=0.2, allow_random_init=True)   # the E6E topology in miniature
     with torch.no_grad():   # make the random net emit confident boxes
-        for d in model.model.detect:
+        for d in model.model.model[-1].m:
             d.bias.fill_(0.0)
             d.bias.view(3, 85)[:, 4] = 1.5
     rng = np.random.default_rng(6)
@@ -105,7 +105,7 @@ def test_yolov7_pipeline(gpu_device):
                                     nms_fn=lambda bx, s, t, m: torch.from_numpy(ref_nms(bx.numpy(), s.numpy(), t))[:m])
     for x, y in zip(a, b):
         assert torch.equal(x.cpu(), y)
-    c = YOLOv7Client(port=12184, device=gpu_device, width=16, allow_random_init=True)
+    c = YOLOv7Client(port=12184, device=gpu_device, width_multiple=0.2, allow_random_init=True)
     assert isinstance(c.predict(imgs[0]).to_json()["phrases"], list)
 
 
@@ -181,38 +181,59 @@ def test_ms_deform_attn_matches_hf_pytorch_path(gpu_device):
     assert torch.allclose(got, want, atol=1e-5, rtol=1e-5), float((got - want).abs().max())
 
 
-def test_yolov7_torchscript_weights_path_and_no_silent_fallback(gpu_device, tmp_path):
-    """The weights route of YOLOv7 (yolov7.py:35-38 in the reference): a TorchScript export of the detector whose output is
-    the inference tensor [B, N, 85].  Exercised with a traced stand-in: loaded through ``weights=`` it must give the same
-    detections as the eager module; a missing path, a non-TorchScript file or no weights at all must raise."""
-    from vlfm_amd.vlm.yolov7 import YOLOv7, YoloV7E6EClassNet
+def test_yolov7_weight_routes_and_no_silent_fallback(gpu_device, tmp_path):
+    """The weights routes of YOLOv7 (yolov7.py:35-38 in the reference hands `yolov7-e6e.pt` to attempt_load): a TorchScript
+    export whose output is the inference tensor [B, N, 85] (exercised with a traced miniature: same detections as the eager
+    module), a checkpoint / state dict of the FULL yolov7-e6e graph (synthetic tensors under the checkpoint's own keys: loaded
+    strictly, then the same detections as the network they came from); a missing path, a file that is neither, a state dict
+    of another network, or no weights at all must raise."""
+    from vlfm_amd.vlm.yolov7 import YOLOv7
+    from vlfm_amd.vlm.yolov7_e6e import YoloV7E6E
+
+    def confident(net):
+        with torch.no_grad():   # make the random net emit confident boxes
+            for m in net.model[-1].m:
+                m.bias.fill_(0.0)
+                m.bias.view(3, 85)[:, 4] = 1.5
+        return net
 
     torch.manual_seed(3)
     with torch.device(gpu_device):
-        net = YoloV7E6EClassNet(width=16).eval()
-    with torch.no_grad():   # make the random net emit confident boxes
-        for m in net.detect:
-            m.bias.fill_(0.0)
-            m.bias.view(3, 85)[:, 4] = 1.5
+        net = confident(YoloV7E6E(width_multiple=0.2).init_random(3).eval())
     example = torch.rand(1, 3, 448, 640, device=gpu_device)
-    path = str(tmp_path / "stand_in.torchscript.pt")
+    path = str(tmp_path / "mini.torchscript.pt")
     torch.jit.trace(net, example).save(path)
     loaded = YOLOv7(weights=path, device=gpu_device, half_precision=False)
     assert loaded.weights == f"torchscript:{path}"
-    eager = YOLOv7(device=gpu_device, width=16, allow_random_init=True, half_precision=False)
+    eager = YOLOv7(device=gpu_device, width_multiple=0.2, allow_random_init=True, half_precision=False)
     eager.model = net
     rng = np.random.default_rng(0)
     img = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
     a, b = loaded.predict(img), eager.predict(img)
     assert a.num_detections == b.num_detections and a.num_detections > 0
     assert torch.allclose(a.boxes, b.boxes, atol=1e-5) and a.phrases == b.phrases
-    assert "conv GFLOPs" in eager.description and eager.stand_in_gflops > 0
+    assert "conv GFLOPs" in eager.description and "M parameters" in eager.description and eager.gflops > 0
+    # ---- the full graph through the checkpoint route
+    with torch.device(gpu_device):
+        full = confident(YoloV7E6E().init_random(5).eval())
+    ck = str(tmp_path / "yolov7-e6e.pt")
+    torch.save({"model": {k: v.half() if v.is_floating_point() else v for k, v in full.state_dict().items()}, "ema": None}, ck)
+    from_ck = YOLOv7(weights=ck, device=gpu_device)
+    assert from_ck.weights.startswith("yolov7-e6e checkpoint (unfused)") and "151.8 M parameters" in from_ck.description
+    ref = YOLOv7(device=gpu_device, allow_random_init=True)
+    ref.model = full.half().fuse_()
+    a, b = from_ck.predict(img), ref.predict(img)
+    assert a.num_detections == b.num_detections and a.phrases == b.phrases and torch.allclose(a.boxes, b.boxes, atol=2e-3)
     with pytest.raises(FileNotFoundError):
         YOLOv7(weights=str(tmp_path / "nope.pt"), device=gpu_device)
     bogus = tmp_path / "pickled.pt"
-    torch.save({"model": "not torchscript"}, str(bogus))
-    with pytest.raises(ValueError, match="TorchScript"):
+    torch.save({"model": "neither"}, str(bogus))
+    with pytest.raises(ValueError, match="neither a TorchScript module"):
         YOLOv7(weights=str(bogus), device=gpu_device)
+    other = tmp_path / "other_net.pt"
+    torch.save(net.state_dict(), str(other))       # a state dict, but of a different network (the miniature's shapes)
+    with pytest.raises(ValueError, match="shape"):
+        YOLOv7(weights=str(other), device=gpu_device)
     with pytest.raises(ValueError, match="allow_random_init"):
         YOLOv7(device=gpu_device)
 
@@ -302,7 +323,10 @@ def test_bias_act_kernel(gpu_device, dtype, act):
         want = x.double() + b.double().view(1, -1, 1, 1)
         want = F.gelu(want) if act == "gelu" else F.silu(want) if act == "silu" else want
         y = x.to(gpu_device).clone()
-        out = ops.bias_act(y, b.to(gpu_device), act)
-        assert out.data_ptr() == y.data_ptr()          # in place
+        pure = ops.bias_act(y, b.to(gpu_device), act)             # default: the input is left alone (framework ops)
+        assert pure.data_ptr() != y.data_ptr() and torch.equal(y.cpu(), x)
+        out = ops.bias_act(y, b.to(gpu_device), act, inplace=True)
+        assert out.data_ptr() == y.data_ptr()          # in place: the HIP kernel
         tol = 2e-6 if dtype == torch.float32 else 2e-3
         assert torch.allclose(out.cpu().double(), want, atol=tol, rtol=tol), (shape, float((out.cpu().double() - want).abs().max()))
+        assert torch.allclose(pure.cpu().double(), want, atol=tol, rtol=tol)

@@ -215,7 +215,7 @@ def fold_batchnorm_(model) -> int:
                     if act is not None:
                         m._modules[names[pos + 2]] = nn.Identity()
                 m._modules[a] = fused
-                m._modules[b] = BiasAct(bias, act)
+                m._modules[b] = BiasAct(bias, act, inplace=True)   # the fused conv's output has this one consumer
                 n += 1
     return n
 

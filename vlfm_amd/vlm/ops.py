@@ -141,21 +141,30 @@ def bias_act_(y: torch.Tensor, bias: torch.Tensor, act=None) -> torch.Tensor:
     return y
 
 
-class BiasAct(torch.nn.Module):
-    """``act(x + bias[c])`` as a module: takes the place of a folded BatchNorm2d (+ the activation module behind it)."""
+_BIAS_ACT_MAX_PLANES = 65535 * 16   # vlfm_bias_act_nchw's grid: n * C planes per launch
 
-    def __init__(self, bias: torch.Tensor, act=None):
+
+class BiasAct(torch.nn.Module):
+    """``act(x + bias[c])`` as a module: takes the place of a folded BatchNorm2d (+ the activation module behind it).
+    ``inplace=True`` overwrites its input (one pass of the HIP kernel): right exactly where ``det_ops.fold_batchnorm_``
+    installs it -- behind a convolution whose output has no other consumer.  The default leaves the input alone."""
+
+    def __init__(self, bias: torch.Tensor, act=None, inplace: bool = False):
         super().__init__()
         self.bias = torch.nn.Parameter(bias.detach().clone(), requires_grad=False)
         self.act = act
+        self.inplace = inplace
 
     def forward(self, x):
-        return bias_act(x, self.bias, self.act)
+        return bias_act(x, self.bias, self.act, inplace=self.inplace)
 
 
-def bias_act(x: torch.Tensor, bias: torch.Tensor, act=None) -> torch.Tensor:
-    """act(x + bias[c]): the HIP kernel, in place, for a fresh contiguous NCHW tensor on the GPU; the framework ops otherwise."""
-    if x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.float16) and x.is_contiguous() and not x.requires_grad:
+def bias_act(x: torch.Tensor, bias: torch.Tensor, act=None, inplace: bool = False) -> torch.Tensor:
+    """act(x + bias[c]).  ``inplace=True``: the HIP kernel, OVERWRITING ``x`` (a contiguous NCHW f32 / f16 tensor on the GPU
+    without grad, within the kernel's plane limit); otherwise -- and for anything the kernel does not take -- the framework
+    ops, which leave ``x`` untouched."""
+    if (inplace and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.float16) and x.is_contiguous()
+            and not x.requires_grad and x.shape[0] * x.shape[1] <= _BIAS_ACT_MAX_PLANES):
         return bias_act_(x, bias if bias.dtype == x.dtype else bias.to(x.dtype), act)
     y = x + bias.to(x.dtype).view(1, -1, 1, 1)
     if act == "gelu":

@@ -39,7 +39,7 @@ def _folded(cb: "_ConvBN") -> bool:
 def _conv_act(cb: "_ConvBN", x: torch.Tensor, gelu: bool) -> torch.Tensor:
     """``gelu(cb(x))`` / ``cb(x)``; with the BatchNorm folded (det_ops.fold_batchnorm_) the bias and the GELU are one pass."""
     if _folded(cb):
-        return ops.bias_act(cb.c(x), cb.bn.bias, "gelu" if gelu else None)
+        return ops.bias_act(cb.c(x), cb.bn.bias, "gelu" if gelu else None, inplace=True)   # the conv output is ours alone
     y = cb(x)
     return F.gelu(y) if gelu else y
 

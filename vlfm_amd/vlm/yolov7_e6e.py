@@ -53,6 +53,20 @@ class Conv(nn.Module):
     def forward(self, x):
         return self.act(self.bn(self.conv(x)))
 
+    def fuse_(self) -> None:
+        """yolov7's Model.fuse() [ext] for this triple: BatchNorm folded into the convolution's weights; the folded bias and
+        the SiLU become ONE in-place pass (ops.BiasAct -> vlfm_bias_act_nchw; MIOpen convolutions take no bias)."""
+        from torch.nn.utils.fusion import fuse_conv_bn_eval
+
+        from .ops import BiasAct
+
+        if not isinstance(self.bn, nn.BatchNorm2d):
+            return
+        fused = fuse_conv_bn_eval(self.conv.eval(), self.bn.eval())
+        bias = fused.bias.detach().clone()
+        fused.bias = None
+        self.conv, self.bn, self.act = fused, BiasAct(bias, "silu", inplace=True), nn.Identity()
+
 
 class ReOrg(nn.Module):
     def forward(self, x):  # space to depth: (b, c, h, w) -> (b, 4c, h/2, w/2)
@@ -183,10 +197,17 @@ class YoloV7E6E(nn.Module):
     the `from` column.  Output of the Detect layer: [B, N, 5 + nc] (yolov7's inference tensor, `pred[0]` of the reference,
     yolov7.py:79)."""
 
-    def __init__(self, nc: int = 80, ch: int = 3):
+    def __init__(self, nc: int = 80, ch: int = 3, width_multiple: float = 1.0):
+        """``width_multiple`` is the yaml's channel multiplier (parse_model's ``make_divisible(c2 * gw, 8)`` [ext]); yolov7-e6e
+        is 1.0 -- smaller values give same-topology miniatures for tests."""
         super().__init__()
         self.nc = nc
-        table = layer_table(nc)
+
+        def w(c: int) -> int:
+            return c if width_multiple == 1.0 else max(8, int(math.ceil(c * width_multiple / 8) * 8))
+
+        table = [(f, kind, ((w(args[0]),) + tuple(args[1:])) if kind in ("Conv", "DownC", "SPPCSPC") else args)
+                 for f, kind, args in layer_table(nc)]
         chans: List[int] = []
         mods: List[nn.Module] = []
         self.froms: List[Union[int, List[int]]] = []
@@ -222,6 +243,12 @@ class YoloV7E6E(nn.Module):
             for j in ([f] if isinstance(f, int) else f):
                 if j != -1:
                     self.keep.add(j if j >= 0 else i + j)
+
+    def fuse_(self) -> "YoloV7E6E":
+        for m in self.modules():
+            if isinstance(m, Conv):
+                m.fuse_()
+        return self
 
     def init_random(self, seed: int = 0) -> "YoloV7E6E":
         """Kaiming-uniform convolutions (PyTorch's default), BatchNorm at identity, and yolov7's Detect._initialize_biases [ext]
@@ -355,7 +382,7 @@ class _CheckpointUnpickler(pickle.Unpickler):
         root = module.split(".")[0]
         if root in ("models", "utils"):   # the yolov7 repository's own namespaces
             return type(name, (_Shell,), {"__module__": module})
-        if module == "builtins":
+        if module in ("builtins", "__builtin__"):   # (protocol-2 pickles, which torch.save writes, spell it the old way)
             if name not in self._ALLOWED_BUILTINS or name == "getattr":
                 raise pickle.UnpicklingError(f"refusing builtins.{name} in a checkpoint")
             return super().find_class(module, name)
