@@ -216,14 +216,15 @@ def test_yolov7_weight_routes_and_no_silent_fallback(gpu_device, tmp_path):
     # ---- the full graph through the checkpoint route
     with torch.device(gpu_device):
         full = confident(YoloV7E6E().init_random(5).eval())
+    full.half().float()     # f16-representable weights: the file stores halves (like the real one), the comparison stays exact
     ck = str(tmp_path / "yolov7-e6e.pt")
     torch.save({"model": {k: v.half() if v.is_floating_point() else v for k, v in full.state_dict().items()}, "ema": None}, ck)
     from_ck = YOLOv7(weights=ck, device=gpu_device)
     assert from_ck.weights.startswith("yolov7-e6e checkpoint (unfused)") and "151.8 M parameters" in from_ck.description
     ref = YOLOv7(device=gpu_device, allow_random_init=True)
-    ref.model = full.half().fuse_()
+    ref.model = full.fuse_().half()      # what YOLOv7.__init__ does with a loaded graph: fold in f32, then halve
     a, b = from_ck.predict(img), ref.predict(img)
-    assert a.num_detections == b.num_detections and a.phrases == b.phrases and torch.allclose(a.boxes, b.boxes, atol=2e-3)
+    assert a.num_detections == b.num_detections > 0 and a.phrases == b.phrases and torch.equal(a.boxes, b.boxes)
     with pytest.raises(FileNotFoundError):
         YOLOv7(weights=str(tmp_path / "nope.pt"), device=gpu_device)
     bogus = tmp_path / "pickled.pt"

@@ -34,6 +34,13 @@ def one(variant: int, E: int = 256, H: int = 480, W: int = 640, steps: int = 30)
         ob.colmax_keys.zero_()
     torch.cuda.synchronize()
     ms, n = _lib.profile_read("depth_ingest_scatter_kernel")
+    for t in range(10):   # the same frames through the streaming-only form (column maxima, no obstacle plane): the floor
+        ob.ingest(frames[t % 4], rr.tf_table[150 + t % 4], MIN_DEPTH, MAX_DEPTH, fx, fy, want_colmax=True, update_obstacles=False)
+        ob.colmax_keys.zero_()
+    torch.cuda.synchronize()
+    ms0, n0 = _lib.profile_read("depth_ingest_kernel")
+    print(f"streaming only (column maxima): {ms0 * 1e3:8.1f} us over {n0} launches = {E * H * W * 4 / (ms0 * 1e-3) / 1e12:.2f} TB/s",
+          flush=True)
     bits = ob.obstacle_bits.cpu().numpy()
     print(f"variant {variant}: {ms * 1e3:8.1f} us over {n} launches ({E} x {H}x{W}: "
           f"{E * H * W * 4 / (ms * 1e-3) / 1e12:.2f} TB/s of depth), obstacle bits {int(np.unpackbits(bits.view(np.uint8)).sum())}, "

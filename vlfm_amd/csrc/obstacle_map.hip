@@ -1406,7 +1406,7 @@ constexpr unsigned kWalkLdsBytes = 144 * 1024;
 
 struct ScratchLayout {
     size_t plane_words, total;
-    size_t off_planes[6], off_pts, off_lines, off_starts, off_lens, off_bad, off_pieces, off_status, off_pixbase;
+    size_t off_planes[8], off_pts, off_lines, off_starts, off_lens, off_bad, off_pieces, off_status, off_pixbase;
 };
 ScratchLayout layout(int n_envs, int S, int cap_pts, int cap_contours) {
     ScratchLayout L;
@@ -1414,7 +1414,10 @@ ScratchLayout layout(int n_envs, int S, int cap_pts, int cap_contours) {
     L.plane_words = (size_t)n_envs * S * stride;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) / 256 * 256; return r; };
-    for (int k = 0; k < 6; k++) L.off_planes[k] = take(L.plane_words * 4);
+    // planes 0-5: scratch shared by the stages of one step (label planes, fill planes, the fog kernel's follower tables);
+    // planes 6-7: the frontier stage's derived planes explored_d / unexplored, which PERSIST between steps (they are only
+    // refreshed inside the dirty windows, frontier_prepare_kernel) and therefore belong to nobody else
+    for (int k = 0; k < 8; k++) L.off_planes[k] = take(L.plane_words * 4);
     L.off_pts = take((size_t)n_envs * cap_pts * sizeof(int2));
     L.off_lines = take((size_t)n_envs * cap_pts * sizeof(int4));
     L.off_starts = take((size_t)n_envs * cap_contours * 4);
@@ -1451,8 +1454,8 @@ extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, in
     const int stride = (map_size + 31) / 32;
     unsigned char* base = (unsigned char*)d_scratch;
     MapPlanes mp{d_obstacle, d_navigable, d_explored, map_size, stride};
-    unsigned* planes[6];
-    for (int k = 0; k < 6; k++) planes[k] = (unsigned*)(base + L.off_planes[k]);
+    unsigned* planes[8];
+    for (int k = 0; k < 8; k++) planes[k] = (unsigned*)(base + L.off_planes[k]);
     int2* pts = (int2*)(base + L.off_pts);
     int4* lines = (int4*)(base + L.off_lines);
     int* starts = (int*)(base + L.off_starts);
@@ -1502,7 +1505,7 @@ extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, in
     rc = check_launch("explored_select_kernel");
     if (rc != VLFM_OK) return rc;
     {
-        FrontierScratch fr{planes[4], planes[5], planes[0], planes[1], planes[2], planes[3], pts, starts, lens,
+        FrontierScratch fr{planes[6], planes[7], planes[0], planes[1], planes[2], planes[3], pts, starts, lens,
                            (unsigned char*)(base + L.off_bad), (int*)(base + L.off_pieces), d_frontiers, d_counts,
                            cap_pts, cap_contours, cap_frontiers, area_thresh_px, kWalkLdsBytes, status,
                            status + (size_t)n_envs * 4, (unsigned*)lines, (int*)(base + L.off_pixbase),
@@ -1510,7 +1513,7 @@ extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, in
         {
             VLFM_TIMED("frontier_prepare_kernel", s);
             VLFM_KLAUNCH(frontier_prepare_kernel, dim3((map_size * stride + 255) / 256, 1, n), dim3(256), 0, s, d_prm, mp,
-                         planes[4], planes[5], d_windows, (const int*)d_bbox, (const int*)(status + (size_t)n_envs * 8));
+                         planes[6], planes[7], d_windows, (const int*)d_bbox, (const int*)(status + (size_t)n_envs * 8));
         }
         VLFM_TIMED("frontier_kernel", s);
         VLFM_KLAUNCH(frontier_kernel, dim3(n), dim3(1024), kWalkLdsBytes, s, d_prm, mp, fr, (const int*)d_bbox);
