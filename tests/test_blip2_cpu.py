@@ -127,3 +127,117 @@ def test_head_padding_is_exact():
         assert m.blocks[0]._packed is not None and m.blocks[0]._packed[3] == 96
         got = m.vision_tokens(x)
     assert torch.allclose(got, want, atol=1e-6, rtol=0)
+
+
+# ------------------------------------------------------------------------------------------------ the reference's artefacts
+def _lavis_spec(cfg: Blip2ITCConfig, with_vit_in_file: bool):
+    """Names -> shapes of LAVIS' artefacts for this geometry, from LAVIS' own module definitions [ext] (Blip2Qformer in
+    lavis/models/blip2_models/blip2_qformer.py + Qformer.py, VisionTransformer in lavis/models/eva_vit.py):
+    ``blip2_pretrained.pth['model']`` and ``eva_vit_g.pth`` (the full 40-block EVA tower with its classifier norm)."""
+    H, I, Hq, Iq = cfg.v_hidden, cfg.v_mlp, cfg.q_hidden, cfg.q_mlp
+    n_tok = (cfg.image_size // cfg.patch_size) ** 2 + 1
+    vit = {"cls_token": (1, 1, H), "pos_embed": (1, n_tok, H), "patch_embed.proj.weight": (H, 3, cfg.patch_size, cfg.patch_size),
+           "patch_embed.proj.bias": (H,), "norm.weight": (H,), "norm.bias": (H,)}
+    for i in range(cfg.v_layers + 1):          # LAVIS builds depth - 1 blocks and loads non-strictly: the file has one more
+        o = f"blocks.{i}."
+        vit.update({o + "norm1.weight": (H,), o + "norm1.bias": (H,), o + "attn.q_bias": (H,), o + "attn.v_bias": (H,),
+                    o + "attn.qkv.weight": (3 * H, H), o + "attn.proj.weight": (H, H), o + "attn.proj.bias": (H,),
+                    o + "norm2.weight": (H,), o + "norm2.bias": (H,), o + "mlp.fc1.weight": (I, H), o + "mlp.fc1.bias": (I,),
+                    o + "mlp.fc2.weight": (H, I), o + "mlp.fc2.bias": (H,)})
+    q = {"query_tokens": (1, cfg.num_query_tokens, Hq), "ln_vision.weight": (H,), "ln_vision.bias": (H,),
+         "Qformer.bert.embeddings.position_ids": (1, cfg.max_position_embeddings),
+         "Qformer.bert.embeddings.word_embeddings.weight": (cfg.vocab_size, Hq),
+         "Qformer.bert.embeddings.position_embeddings.weight": (cfg.max_position_embeddings, Hq),
+         "Qformer.bert.embeddings.LayerNorm.weight": (Hq,), "Qformer.bert.embeddings.LayerNorm.bias": (Hq,),
+         "vision_proj.weight": (cfg.proj_dim, Hq), "vision_proj.bias": (cfg.proj_dim,), "text_proj.weight": (cfg.proj_dim, Hq),
+         "text_proj.bias": (cfg.proj_dim,), "itm_head.weight": (2, Hq), "itm_head.bias": (2,), "temp": (),
+         "Qformer.cls.predictions.bias": (cfg.vocab_size,), "Qformer.cls.predictions.transform.dense.weight": (Hq, Hq),
+         "Qformer.cls.predictions.transform.dense.bias": (Hq,), "Qformer.cls.predictions.transform.LayerNorm.weight": (Hq,),
+         "Qformer.cls.predictions.transform.LayerNorm.bias": (Hq,), "Qformer.cls.predictions.decoder.weight": (cfg.vocab_size, Hq),
+         "Qformer.cls.predictions.decoder.bias": (cfg.vocab_size,)}
+    for i in range(cfg.q_layers):
+        o = f"Qformer.bert.encoder.layer.{i}."
+        atts = [("attention", Hq)] + ([("crossattention", H)] if i % cfg.cross_attention_frequency == 0 else [])
+        for att, kv in atts:
+            q.update({o + f"{att}.self.query.weight": (Hq, Hq), o + f"{att}.self.query.bias": (Hq,),
+                      o + f"{att}.self.key.weight": (Hq, kv), o + f"{att}.self.key.bias": (Hq,),
+                      o + f"{att}.self.value.weight": (Hq, kv), o + f"{att}.self.value.bias": (Hq,),
+                      o + f"{att}.output.dense.weight": (Hq, Hq), o + f"{att}.output.dense.bias": (Hq,),
+                      o + f"{att}.output.LayerNorm.weight": (Hq,), o + f"{att}.output.LayerNorm.bias": (Hq,)})
+        for a, b in (("intermediate", "output"), ("intermediate_query", "output_query")):
+            q.update({o + f"{a}.dense.weight": (Iq, Hq), o + f"{a}.dense.bias": (Iq,), o + f"{b}.dense.weight": (Hq, Iq),
+                      o + f"{b}.dense.bias": (Hq,), o + f"{b}.LayerNorm.weight": (Hq,), o + f"{b}.LayerNorm.bias": (Hq,)})
+    if with_vit_in_file:
+        q.update({"visual_encoder." + k: v for k, v in vit.items() if not k.startswith(("norm.", f"blocks.{cfg.v_layers}."))})
+        return q, None
+    return q, vit
+
+
+@pytest.mark.parametrize("vit_in_file", [False, True])
+def test_lavis_artefacts_load_strictly_and_give_the_hf_ports_scores(vit_in_file):
+    """blip2itm.py:29-34 loads LAVIS' blip2_pretrained.pth (+ eva_vit_g.pth).  Synthetic files with LAVIS' names and shapes:
+    every tensor placed or on the explicit not-used list, every parameter fed; and the SAME tensors fed to transformers'
+    Blip2ForImageTextRetrieval under ITS names give the same ITC score -- the two loaders agree on where each tensor goes
+    (incl. EVA's [q_bias, 0, v_bias])."""
+    cfg = Blip2ITCConfig.tiny()
+    g = torch.Generator().manual_seed(11)
+    q_spec, vit_spec = _lavis_spec(cfg, vit_in_file)
+
+    def rnd(spec):
+        out = {}
+        for k, shape in spec.items():
+            t = torch.randn(shape, generator=g) * 0.08
+            out[k] = t + 1.0 if (("norm" in k.lower() or "ln_vision" in k) and k.endswith("weight")) else t
+        return out
+
+    sd = rnd(q_spec)
+    vit = rnd(vit_spec) if vit_spec is not None else None
+    ours = Blip2ITCModel(cfg).eval()
+    ours.load_lavis_state_dict({"module." + k: v for k, v in sd.items()}, vit)
+    # the same tensors under transformers' names
+    V = (lambda k: vit[k]) if vit is not None else (lambda k: sd["visual_encoder." + k])
+    hf = _hf_model(cfg)
+    t = {"vision_model.embeddings.class_embedding": V("cls_token"), "vision_model.embeddings.position_embedding": V("pos_embed"),
+         "vision_model.embeddings.patch_embedding.weight": V("patch_embed.proj.weight"),
+         "vision_model.embeddings.patch_embedding.bias": V("patch_embed.proj.bias"),
+         "vision_model.post_layernorm.weight": sd["ln_vision.weight"], "vision_model.post_layernorm.bias": sd["ln_vision.bias"],
+         "query_tokens": sd["query_tokens"], "embeddings.word_embeddings.weight": sd["Qformer.bert.embeddings.word_embeddings.weight"],
+         "embeddings.position_embeddings.weight": sd["Qformer.bert.embeddings.position_embeddings.weight"],
+         "qformer.layernorm.weight": sd["Qformer.bert.embeddings.LayerNorm.weight"],
+         "qformer.layernorm.bias": sd["Qformer.bert.embeddings.LayerNorm.bias"],
+         "vision_projection.weight": sd["vision_proj.weight"], "vision_projection.bias": sd["vision_proj.bias"],
+         "text_projection.weight": sd["text_proj.weight"], "text_projection.bias": sd["text_proj.bias"]}
+    for i in range(cfg.v_layers):
+        o, d = f"blocks.{i}.", f"vision_model.encoder.layers.{i}."
+        for a, b in (("norm1", "layer_norm1"), ("norm2", "layer_norm2"), ("attn.proj", "self_attn.projection"),
+                     ("mlp.fc1", "mlp.fc1"), ("mlp.fc2", "mlp.fc2")):
+            t[d + b + ".weight"], t[d + b + ".bias"] = V(o + a + ".weight"), V(o + a + ".bias")
+        t[d + "self_attn.qkv.weight"] = V(o + "attn.qkv.weight")
+        t[d + "self_attn.qkv.bias"] = torch.cat([V(o + "attn.q_bias"), torch.zeros(cfg.v_hidden), V(o + "attn.v_bias")])
+    for k, v in sd.items():
+        if k.startswith("Qformer.bert.encoder."):
+            t["qformer." + k[len("Qformer.bert."):].replace(".self.", ".attention.")] = v
+    missing = [k for k in hf.state_dict() if k not in t and not k.startswith(("itm_head", "temp"))]
+    res = hf.load_state_dict(t, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys[:5]
+    assert all(k.startswith(("itm_head", "temp")) or "position_ids" in k for k in res.missing_keys), res.missing_keys[:5]
+    pix = torch.randn(2, 3, cfg.image_size, cfg.image_size, generator=g)
+    ids = torch.randint(0, cfg.vocab_size, (1, 7), generator=g)
+    with torch.inference_mode():
+        want = hf(pixel_values=pix, input_ids=ids.expand(2, -1), attention_mask=torch.ones(2, 7, dtype=torch.long),
+                  use_image_text_matching_head=False).logits_per_image
+        got = ours.itc_reference_head(ours.query_features(ours.vision_tokens(pix)), ours.text_feature(ids))
+    assert torch.allclose(got, want[:, 0] if want.dim() == 2 else want.flatten()[:2], atol=2e-5, rtol=0), (got, want)
+    # strictness
+    extra = dict(sd); extra["Qformer.bert.encoder.layer.0.crossattention.self.gate"] = torch.zeros(1)
+    with pytest.raises(KeyError, match="no place"):
+        Blip2ITCModel(cfg).load_lavis_state_dict(extra, vit)
+    lacking = dict(sd); lacking.pop("vision_proj.bias")
+    with pytest.raises(KeyError, match="vision_proj.bias"):
+        Blip2ITCModel(cfg).load_lavis_state_dict(lacking, vit)
+    if not vit_in_file:
+        with pytest.raises(KeyError, match="eva_vit_g"):
+            Blip2ITCModel(cfg).load_lavis_state_dict(sd, None)           # the frozen tower is not in blip2_pretrained.pth
+        both = dict(sd); both["visual_encoder.cls_token"] = vit["cls_token"]
+        with pytest.raises(KeyError, match="twice"):
+            Blip2ITCModel(cfg).load_lavis_state_dict(both, vit)

@@ -247,14 +247,68 @@ def test_detectors_and_segmenter_refuse_unusable_weights(gpu_device, tmp_path):
         GroundingDINO(device=gpu_device)
     pth = tmp_path / "groundingdino_swint_ogc.pth"
     torch.save({"model": {}}, str(pth))
-    with pytest.raises(ValueError, match="convert_grounding_dino_to_hf"):
-        GroundingDINO(config_path="GroundingDINO_SwinT_OGC.py", weights_path=str(pth), device=gpu_device)
+    with pytest.raises(KeyError, match="does not have"):         # an empty / foreign state dict is not silently accepted
+        GroundingDINO(weights_path=str(pth), device=gpu_device)
+    with pytest.raises(FileNotFoundError):
+        GroundingDINO(config_path=str(tmp_path / "GroundingDINO_SwinT_OGC.py"), weights_path=str(pth), device=gpu_device)
     with pytest.raises(FileNotFoundError):
         GroundingDINO(weights_path=str(tmp_path / "missing.pth"), device=gpu_device)
     with pytest.raises(ValueError, match="allow_random_init"):
         MobileSAM(device=gpu_device)
     with pytest.raises(FileNotFoundError):
         MobileSAM(sam_checkpoint=str(tmp_path / "mobile_sam.pt"), device=gpu_device)
+
+
+def test_grounding_dino_loads_the_references_own_checkpoint_format(gpu_device, tmp_path):
+    """grounding_dino.py:18-19,33: ``weights_path`` = a groundingdino ``.pth`` ({"model": state dict under the ORIGINAL names,
+    q | k | v fused}).  A synthetic file in that layout (a miniature network's weights re-packed) goes through the constructor;
+    the detections equal those of the network the tensors came from.  Real weights need the BERT vocabulary on disk."""
+    from transformers import GroundingDinoConfig, GroundingDinoForObjectDetection
+
+    from vlfm_amd.vlm import gdino_weights as gw
+    from vlfm_amd.vlm.grounding_dino import GroundingDINO
+
+    tiny = GroundingDinoConfig(num_queries=30, d_model=32, encoder_layers=2, decoder_layers=2, encoder_ffn_dim=64,
+                               decoder_ffn_dim=64, encoder_attention_heads=2, decoder_attention_heads=2,
+                               backbone_config={"model_type": "swin", "embed_dim": 16, "depths": [1, 1, 1, 1],
+                                                "num_heads": [1, 2, 2, 2], "window_size": 4,
+                                                "out_features": ["stage2", "stage3", "stage4"]},
+                               text_config={"model_type": "bert", "hidden_size": 32, "num_hidden_layers": 1,
+                                            "num_attention_heads": 2, "intermediate_size": 64, "vocab_size": 30522,
+                                            "max_position_embeddings": 64})
+    torch.manual_seed(4)
+    src = GroundingDinoForObjectDetection(tiny).eval()
+    hf, spec = src.state_dict(), gw.original_state_dict_spec(tiny)
+    orig = {}
+    for k, t in hf.items():
+        s = gw.source_of(k)
+        if s is None:
+            continue
+        if s[1] is None:
+            orig[s[0]] = t.clone()
+        else:
+            n = spec[s[0]][0] // 3
+            orig.setdefault(s[0], torch.zeros(spec[s[0]]))[s[1] * n:(s[1] + 1) * n] = t
+    for k, shape in spec.items():
+        orig.setdefault(k, torch.zeros(shape, dtype=torch.long if k.endswith(("position_ids", "position_index")) else torch.float32))
+    pth = str(tmp_path / "groundingdino_swint_ogc.pth")
+    torch.save({"model": {"module." + k: v for k, v in orig.items()}}, pth)
+    vocab = tmp_path / "vocab.txt"
+    words = ["[PAD]"] + [f"[unused{i}]" for i in range(99)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"] + \
+            [f"w{i}" for i in range(908)] + ["."] + ["chair", "bed", "plant", "potted", "tv", "couch", "toilet"]
+    vocab.write_text("\n".join(words) + "\n")
+    with pytest.raises(ValueError, match="vocabulary"):
+        GroundingDINO(weights_path=pth, hf_config=tiny, device=gpu_device)       # no vocabulary on disk, no stand-in
+    gd = GroundingDINO(weights_path=pth, hf_config=tiny, device=gpu_device, tokenizer_dir=str(tmp_path),
+                       box_threshold=0.0, text_threshold=0.0)
+    assert gd.weights.startswith("groundingdino checkpoint:")
+    ref = GroundingDINO(hf_config=tiny, device=gpu_device, box_threshold=0.0, text_threshold=0.0)
+    ref.model.load_state_dict(hf)
+    ref.tokenizer, ref.decode = gd.tokenizer, gd.decode
+    rng = np.random.default_rng(8)
+    img = rng.integers(0, 256, (96, 128, 3), dtype=np.uint8)
+    a, b = gd.predict(img, caption="chair . bed ."), ref.predict(img, caption="chair . bed .")
+    assert a.phrases == b.phrases and torch.equal(a.boxes, b.boxes) and torch.equal(a.logits, b.logits)
 
 
 def test_mobile_sam_loads_a_checkpoint_and_matches_the_oracle(gpu_device, tmp_path):

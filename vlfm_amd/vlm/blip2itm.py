@@ -377,6 +377,93 @@ class Blip2ITCModel(nn.Module):
             put(n + ".weight", n + ".weight")
             put(n + ".bias", n + ".bias")
 
+    def load_lavis_state_dict(self, sd: Dict[str, torch.Tensor], vit_sd: Optional[Dict[str, torch.Tensor]] = None) -> None:
+        """Load what the REFERENCE loads (blip2itm.py:29-34: LAVIS ``load_model_and_preprocess("blip2_image_text_matching",
+        "pretrain")`` [ext]): ``sd`` = the ``model`` entry of ``blip2_pretrained.pth`` (Blip2Qformer: ``query_tokens``,
+        ``ln_vision.*``, ``Qformer.bert.*``, ``vision_proj.*``, ``text_proj.*``, + ``itm_head`` / ``temp`` / the LM head
+        ``Qformer.cls.*``, which the ITC score does not use), ``vit_sd`` = ``eva_vit_g.pth`` (the frozen EVA ViT-g LAVIS reads
+        from its own file: bare names ``cls_token``, ``pos_embed``, ``patch_embed.proj.*``, ``blocks.{i}.*``; the 40th block
+        and the classifier's norm / head are dropped there too, lavis/models/eva_vit.py [ext]) -- or the tower under
+        ``visual_encoder.*`` inside ``sd`` when the file carries it.  Strict both ways: every parameter of this graph is fed,
+        every tensor given is placed or on the explicit not-used list, shapes equal.  EVA's attention has ``q_bias`` /
+        ``v_bias`` and no key bias: the qkv bias is [q_bias, 0, v_bias]."""
+        c = self.cfg
+        sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
+        vit = {("visual_encoder." + k): v for k, v in (vit_sd or {}).items()}
+        overlap = set(vit) & set(sd)
+        if overlap:
+            raise KeyError(f"the vision tower is given twice (e.g. {sorted(overlap)[:2]})")
+        src = {**sd, **vit}
+        own = dict(self.named_parameters())
+        used, fed = set(), set()
+
+        def take(key: str) -> torch.Tensor:
+            if key not in src:
+                raise KeyError(f"LAVIS state dict lacks {key}" + ("" if vit_sd is not None or not key.startswith("visual_encoder.")
+                                                                 else " (blip2_pretrained.pth does not carry the frozen ViT: "
+                                                                      "pass eva_vit_g.pth as the vision checkpoint)"))
+            used.add(key)
+            return src[key]
+
+        def put(name: str, value: torch.Tensor) -> None:
+            if tuple(value.shape) != tuple(own[name].shape) and value.numel() != own[name].numel():
+                raise ValueError(f"{name}: {tuple(own[name].shape)} in the graph, {tuple(value.shape)} in the file")
+            with torch.no_grad():
+                own[name].copy_(value.to(own[name].dtype).reshape(own[name].shape))
+            fed.add(name)
+
+        put("class_embedding", take("visual_encoder.cls_token"))
+        put("position_embedding", take("visual_encoder.pos_embed"))
+        put("patch_embedding.weight", take("visual_encoder.patch_embed.proj.weight"))
+        put("patch_embedding.bias", take("visual_encoder.patch_embed.proj.bias"))
+        for i in range(c.v_layers):
+            o, d = f"visual_encoder.blocks.{i}.", f"blocks.{i}."
+            for a, b in (("norm1", "layer_norm1"), ("norm2", "layer_norm2"), ("attn.proj", "projection"),
+                         ("mlp.fc1", "fc1"), ("mlp.fc2", "fc2")):
+                put(d + b + ".weight", take(o + a + ".weight"))
+                put(d + b + ".bias", take(o + a + ".bias"))
+            put(d + "qkv.weight", take(o + "attn.qkv.weight"))
+            qb, vb = take(o + "attn.q_bias"), take(o + "attn.v_bias")
+            put(d + "qkv.bias", torch.cat([qb, torch.zeros_like(vb), vb]))
+        put("post_layernorm.weight", take("ln_vision.weight"))
+        put("post_layernorm.bias", take("ln_vision.bias"))
+        put("query_tokens", take("query_tokens"))
+        put("word_embeddings.weight", take("Qformer.bert.embeddings.word_embeddings.weight"))
+        put("position_embeddings.weight", take("Qformer.bert.embeddings.position_embeddings.weight"))
+        put("q_layernorm.weight", take("Qformer.bert.embeddings.LayerNorm.weight"))
+        put("q_layernorm.bias", take("Qformer.bert.embeddings.LayerNorm.bias"))
+        for i, layer in enumerate(self.q_layers):
+            o, d = f"Qformer.bert.encoder.layer.{i}.", f"q_layers.{i}."
+            for att in ["attention"] + (["crossattention"] if layer.crossattention is not None else []):
+                for theirs, mine in (("self.query", "query"), ("self.key", "key"), ("self.value", "value"),
+                                     ("output.dense", "dense"), ("output.LayerNorm", "LayerNorm")):
+                    put(f"{d}{att}.{mine}.weight", take(f"{o}{att}.{theirs}.weight"))
+                    put(f"{d}{att}.{mine}.bias", take(f"{o}{att}.{theirs}.bias"))
+            for t_i, t_o, mine in (("intermediate", "output", "ffn_text"), ("intermediate_query", "output_query", "ffn_query")):
+                put(f"{d}{mine}.up.weight", take(f"{o}{t_i}.dense.weight"))
+                put(f"{d}{mine}.up.bias", take(f"{o}{t_i}.dense.bias"))
+                put(f"{d}{mine}.down.weight", take(f"{o}{t_o}.dense.weight"))
+                put(f"{d}{mine}.down.bias", take(f"{o}{t_o}.dense.bias"))
+                put(f"{d}{mine}.LayerNorm.weight", take(f"{o}{t_o}.LayerNorm.weight"))
+                put(f"{d}{mine}.LayerNorm.bias", take(f"{o}{t_o}.LayerNorm.bias"))
+        put("vision_projection.weight", take("vision_proj.weight"))
+        put("vision_projection.bias", take("vision_proj.bias"))
+        put("text_projection.weight", take("text_proj.weight"))
+        put("text_projection.bias", take("text_proj.bias"))
+        unfed = sorted(set(own) - fed)
+        if unfed:
+            raise KeyError(f"{len(unfed)} parameters of the graph were not fed, e.g. {unfed[:4]}")
+
+        def unused_ok(k: str) -> bool:   # present in the files, not part of the ITC score (or of LAVIS' own 39-block tower)
+            return (k.startswith(("Qformer.cls.", "itm_head.")) or k in ("temp", "Qformer.bert.embeddings.position_ids")
+                    or k.startswith(f"visual_encoder.blocks.{c.v_layers}.")
+                    or k.startswith(("visual_encoder.norm.", "visual_encoder.fc_norm.", "visual_encoder.head.")))
+
+        left = sorted(k for k in src if k not in used and not unused_ok(k))
+        if left:
+            raise KeyError(f"{len(left)} tensors of the file have no place in the ITC graph, e.g. {left[:4]}")
+        self.weights_changed()
+
     # ---- branches --------------------------------------------------------------------------------------------
     def vision_tokens(self, pixel_values: torch.Tensor) -> torch.Tensor:
         """[B,3,224,224] (or im2col patches [B,256,588] straight from the preprocess kernel) -> LayerNorm'd ViT tokens
@@ -505,7 +592,8 @@ class BLIP2ITM:
     def __init__(self, name: str = "blip2_image_text_matching", model_type: str = "pretrain", device=None,
                  model_dir: Optional[str] = None, config: Optional[Blip2ITCConfig] = None,
                  vision_dtype: torch.dtype = torch.float16, seed: int = 0, allow_random_init: bool = False,
-                 strict_hip_attention: bool = True) -> None:
+                 strict_hip_attention: bool = True, checkpoint: Optional[str] = None, vit_checkpoint: Optional[str] = None,
+                 tokenizer_dir: Optional[str] = None) -> None:
         from ..mapping.base_map import require_gpu
         from .. import _lib
 
@@ -514,14 +602,29 @@ class BLIP2ITM:
         self.cfg = config or Blip2ITCConfig()
         self.tokenizer = None
         model_dir = model_dir or os.environ.get("BLIP2ITM_MODEL_DIR")
-        if model_dir:
+        checkpoint = checkpoint or os.environ.get("BLIP2_LAVIS_CHECKPOINT")
+        vit_checkpoint = vit_checkpoint or os.environ.get("EVA_VIT_G_CHECKPOINT")
+        if checkpoint and not model_dir:
+            # the reference's own artefacts (blip2itm.py:29-34 -> LAVIS [ext]): blip2_pretrained.pth (+ eva_vit_g.pth)
+            for f in (checkpoint, vit_checkpoint):
+                if f and not os.path.isfile(f):
+                    raise FileNotFoundError(f"BLIP-2 checkpoint {f!r} not found")
+            self.model = Blip2ITCModel(self.cfg)
+            ck = torch.load(checkpoint, map_location="cpu", weights_only=True)
+            vit = torch.load(vit_checkpoint, map_location="cpu", weights_only=True) if vit_checkpoint else None
+            self.model.load_lavis_state_dict(ck["model"] if isinstance(ck, dict) and "model" in ck else ck,
+                                             vit["model"] if isinstance(vit, dict) and "model" in vit else vit)
+            self.tokenizer = self._lavis_tokenizer(tokenizer_dir)
+            self.weights = f"lavis:{checkpoint}" + (f" + {vit_checkpoint}" if vit_checkpoint else "")
+        elif model_dir:
             self.model = Blip2ITCModel(self.cfg)
             self._load_pretrained(model_dir)
             self.weights = f"pretrained:{model_dir}"
         elif not (allow_random_init or config is not None):
             # the reference downloads its weights through LAVIS (blip2itm.py:29-34); a scorer that silently runs on random
             # weights would steer the value map with noise
-            raise ValueError("BLIP2ITM needs model_dir / BLIP2ITM_MODEL_DIR (a Salesforce/blip2-itm-vit-g checkpoint directory); "
+            raise ValueError("BLIP2ITM needs `checkpoint` (+ `vit_checkpoint`): LAVIS' blip2_pretrained.pth and eva_vit_g.pth, what "
+                             "the reference loads -- or model_dir / BLIP2ITM_MODEL_DIR (a Salesforce/blip2-itm-vit-g directory); "
                              "pass allow_random_init=True for a randomly initialised network (benchmarks / geometry tests only)")
         else:
             with torch.device(self.device):  # allocate and initialise the 1.2 B parameters directly in HBM
@@ -538,6 +641,25 @@ class BLIP2ITM:
         self._proj_t = None
         self.two_stream_min = None    # e.g. 64: run batches of at least that many images as two halves on two streams
         self._side_stream = None
+
+    def _lavis_tokenizer(self, tokenizer_dir: Optional[str]):
+        """LAVIS' Blip2Base.init_tokenizer [ext]: bert-base-uncased + the added ``[DEC]`` token (id 30522); truncation to
+        ``max_txt_len``.  The vocabulary has to be on disk (``tokenizer_dir`` / ``BLIP2_TOKENIZER``, or the local transformers
+        cache): real weights never run on the hash stand-in."""
+        from transformers import BertTokenizer
+
+        path = tokenizer_dir or os.environ.get("BLIP2_TOKENIZER")
+        try:
+            if path:
+                vocab = path if os.path.isfile(path) else os.path.join(path, "vocab.txt")
+                tok = BertTokenizer(vocab_file=vocab, do_lower_case=True)
+            else:
+                tok = BertTokenizer.from_pretrained("bert-base-uncased", local_files_only=True)
+        except Exception as exc:  # noqa: BLE001
+            raise ValueError("BLIP-2 weights need the bert-base-uncased vocabulary: pass tokenizer_dir (or set BLIP2_TOKENIZER) "
+                             "to a directory with its vocab.txt") from exc
+        tok.add_special_tokens({"bos_token": "[DEC]"})
+        return lambda t: tok(t, truncation=True, max_length=self.cfg.max_txt_len)["input_ids"]
 
     @property
     def strict_hip_attention(self) -> bool:

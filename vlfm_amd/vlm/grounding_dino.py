@@ -58,17 +58,41 @@ def preprocess_caption(caption: str) -> str:
     return result if result.endswith(".") else result + "."
 
 
+def _bert_tokenizer(tokenizer_dir: Optional[str]):
+    """The groundingdino package builds ``bert-base-uncased``'s tokenizer from the hub [ext]; offline it has to be on disk:
+    ``tokenizer_dir`` / ``GROUNDING_DINO_TOKENIZER`` (a directory holding ``vocab.txt``, or the file), else the local
+    transformers cache.  There is no stand-in vocabulary for real weights."""
+    from transformers import BertTokenizer
+
+    path = tokenizer_dir or os.environ.get("GROUNDING_DINO_TOKENIZER")
+    if path:
+        vocab = path if os.path.isfile(path) else os.path.join(path, "vocab.txt")
+        if not os.path.isfile(vocab):
+            raise FileNotFoundError(f"no vocab.txt under {path!r}")
+        return BertTokenizer(vocab_file=vocab, do_lower_case=True)
+    try:
+        return BertTokenizer.from_pretrained("bert-base-uncased", local_files_only=True)
+    except Exception as exc:  # noqa: BLE001
+        raise ValueError("GroundingDINO weights need the bert-base-uncased vocabulary: pass tokenizer_dir (or set "
+                         "GROUNDING_DINO_TOKENIZER) to a directory with its vocab.txt") from exc
+
+
 class GroundingDINO:
     """grounding_dino.py:22-74.  The reference hands ``config_path`` / ``weights_path`` (GroundingDINO_SwinT_OGC.py,
     groundingdino_swint_ogc.pth) to the un-vendored groundingdino package.  Here the network is transformers'
-    ``GroundingDinoForObjectDetection``: ``model_dir`` (or ``GROUNDING_DINO_MODEL_DIR``; ``weights_path`` may also name
-    such a directory) is a checkpoint in transformers' format -- e.g. ``IDEA-Research/grounding-dino-tiny``, which IS
-    groundingdino_swint_ogc converted by transformers' convert_grounding_dino_to_hf.py.  An original ``.pth`` is refused
-    with that instruction instead of being ignored, and random weights need ``allow_random_init=True``."""
+    ``GroundingDinoForObjectDetection`` and BOTH forms of the weights load:
+
+    * the reference's own files: ``weights_path`` = the ``.pth``, ``config_path`` = the ``.py`` hyper-parameter file (parsed,
+      never executed; omitted = the Swin-T OGC geometry).  The state dict goes through ``gdino_weights``' key map, strictly
+      (every tensor of the file placed, every parameter of the graph fed, shapes equal);
+    * ``model_dir`` (or ``GROUNDING_DINO_MODEL_DIR``; ``weights_path`` may also name such a directory): a checkpoint in
+      transformers' format, e.g. ``IDEA-Research/grounding-dino-tiny`` = the converted groundingdino_swint_ogc.
+
+    A path that is given must load; random weights need ``allow_random_init=True``."""
 
     def __init__(self, config_path: Optional[str] = None, weights_path: Optional[str] = None, caption: str = CLASSES,
                  box_threshold: float = 0.35, text_threshold: float = 0.25, device=None, model_dir: Optional[str] = None,
-                 hf_config=None, seed: int = 0, allow_random_init: bool = False) -> None:
+                 hf_config=None, seed: int = 0, allow_random_init: bool = False, tokenizer_dir: Optional[str] = None) -> None:
         from transformers import GroundingDinoConfig, GroundingDinoForObjectDetection
 
         from ..mapping.base_map import require_gpu
@@ -76,19 +100,32 @@ class GroundingDINO:
         self.device = require_gpu(device)
         self.caption, self.box_threshold, self.text_threshold = caption, box_threshold, text_threshold
         model_dir = model_dir or os.environ.get("GROUNDING_DINO_MODEL_DIR")
+        original = None
         if not model_dir and weights_path:
             if os.path.isdir(weights_path):
                 model_dir = weights_path
             elif not os.path.exists(weights_path):
                 raise FileNotFoundError(f"GroundingDINO weights {weights_path!r} not found")
             else:
-                raise ValueError(
-                    f"{weights_path!r} is a checkpoint of the groundingdino package; this class runs transformers' "
-                    "GroundingDinoForObjectDetection.  Convert it once with transformers' convert_grounding_dino_to_hf.py "
-                    "(or download IDEA-Research/grounding-dino-tiny, the converted groundingdino_swint_ogc) and pass the "
-                    "directory as model_dir / GROUNDING_DINO_MODEL_DIR" + (f" (config_path {config_path!r} is not needed)"
-                                                                          if config_path else ""))
-        if model_dir:
+                original = weights_path
+        if original:
+            from . import gdino_weights
+
+            if config_path and not os.path.isfile(config_path):
+                raise FileNotFoundError(f"GroundingDINO config {config_path!r} not found")
+            cfg = hf_config or (gdino_weights.config_from_groundingdino_py(config_path) if config_path
+                                else GroundingDinoConfig())
+            ckpt = torch.load(original, map_location="cpu", weights_only=True)
+            sd = ckpt["model"] if isinstance(ckpt, dict) and "model" in ckpt else ckpt
+            self.model = GroundingDinoForObjectDetection(cfg)
+            feed = gdino_weights.convert_groundingdino_state_dict(sd, self.model.state_dict())
+            res = self.model.load_state_dict(feed, strict=False)
+            assert not res.unexpected_keys and set(res.missing_keys) <= set(gdino_weights._NOT_FED), res
+            tok = _bert_tokenizer(tokenizer_dir)
+            self.tokenizer = lambda t: tok(t)["input_ids"]
+            self.decode = tok.decode
+            self.weights = f"groundingdino checkpoint:{original}"
+        elif model_dir:
             from transformers import AutoTokenizer
 
             self.model = GroundingDinoForObjectDetection.from_pretrained(model_dir)
@@ -104,8 +141,9 @@ class GroundingDINO:
             self.tokenizer, self.decode = wt, wt.decode
             self.weights = "random-init"
         else:
-            raise ValueError("GroundingDINO needs model_dir / GROUNDING_DINO_MODEL_DIR (a transformers-format checkpoint); "
-                             "pass allow_random_init=True for a randomly initialised network (benchmarks only)")
+            raise ValueError("GroundingDINO needs weights_path (groundingdino_swint_ogc.pth) or model_dir / "
+                             "GROUNDING_DINO_MODEL_DIR (a transformers-format checkpoint); pass allow_random_init=True for a "
+                             "randomly initialised network (benchmarks only)")
         self.description = f"GroundingDINO (HF Swin-T + BERT-base geometry, 172 M parameters) {self.weights}"
         self.model.eval().to(self.device)
         # transformers validates the spatial shapes of EVERY deformable-attention call with a device read-back (`.item()`):

@@ -261,7 +261,7 @@ class YoloV7E6E(nn.Module):
                 if isinstance(m, nn.Conv2d):
                     fan_in = m.in_channels * m.kernel_size[0] * m.kernel_size[1]
                     bound = math.sqrt(3.0 / fan_in)     # variance-preserving through SiLU-ish activations, 262 layers deep
-                    m.weight.copy_((torch.rand(m.weight.shape, generator=g) * 2 - 1).mul_(bound).to(m.weight.device))
+                    m.weight.copy_((torch.rand(m.weight.shape, generator=g, device="cpu") * 2 - 1).mul_(bound).to(m.weight.device))
             det = self.model[-1]
             for conv, stride in zip(det.m, det.stride):
                 b = conv.bias.view(det.na, -1)
