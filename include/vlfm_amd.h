@@ -140,6 +140,11 @@ int vlfm_depth_ingest_batched(const float* d_depth, int n, int height, int width
                               const vlfm_scatter_journal* journal /* host pointer or NULL (see above) */,
                               void* stream);
 
+/* Diagnostic: the depth scatter divides by the focal lengths with a hoisted reciprocal and one FMA correction step (same bits
+ * as the IEEE division, a quarter of its instructions).  Counts into d_mismatches[0] (caller zeroes it) the numerators for
+ * which that quotient differs from __ddiv_rn(numerator, divisor): must stay 0. */
+int vlfm_selftest_div_exact(const double* d_numerators, int n, double divisor, int32_t* d_mismatches, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * fill_small_holes (vlfm/utils/img_utils.py:361-390) for n depth images, on the bit plane (depth == 0) produced by
  * vlfm_depth_ingest_batched: cv2.findContours(RETR_TREE, CHAIN_APPROX_SIMPLE) = every outer AND hole border, in OpenCV's

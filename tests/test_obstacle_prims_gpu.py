@@ -203,3 +203,25 @@ def test_find_contours_map_sized(gpu_device):
     assert len(got) == len(want) and len(want) > 20
     for g, w in zip(got, want):
         assert np.array_equal(g, w.reshape(-1, 2))
+
+
+def test_hoisted_reciprocal_division_equals_the_ieee_division(gpu_device):
+    """csrc/depth_ingest.hip: (u - W/2) z / fx with y = RN(1/fx) hoisted, q0 = RN(a y), r = fma(-fx, q0, a), q = fma(r, y, q0)
+    -- Markstein's division step -- must give the bits of the IEEE division for the numerators the scatter produces
+    (integer pixel offset x an f32 depth widened to f64) and for arbitrary doubles, for several focal lengths."""
+    from vlfm_amd import _lib
+
+    rng = np.random.default_rng(12)
+    n = 1 << 22
+    z = rng.uniform(0.05, 12.0, n).astype(np.float32).astype(np.float64)
+    u = rng.integers(-2048, 2048, n).astype(np.float64)
+    sets = [u * z, rng.standard_normal(n) * 1e3, np.ldexp(rng.uniform(1, 2, n), rng.integers(-40, 40, n)),
+            np.concatenate([[0.0, -0.0, 1.0, -1.0], np.nextafter(388.19, 1e9) * np.arange(1, n - 3)])]
+    L = _lib.lib()
+    for fx in (388.1926244788403, 320.0, 776.3852489576806, 1.0 / 3.0, 554.2562584220407, 0.1):
+        for a in sets:
+            d_a = torch.from_numpy(np.ascontiguousarray(a)).to(gpu_device)
+            bad = torch.zeros(1, dtype=torch.int32, device=gpu_device)
+            _lib.check(L.vlfm_selftest_div_exact(d_a.data_ptr(), d_a.numel(), float(fx), bad.data_ptr(),
+                                                 torch.cuda.current_stream().cuda_stream), "selftest_div_exact")
+            assert int(bad.item()) == 0, (fx, int(bad.item()))

@@ -111,15 +111,38 @@ __device__ inline bool candidate(const HeightBand& band, int W, int H, int u, in
     const float zf = band.t8 * z - band.t9 * xf - band.t10 * yf + band.t11;
     return (z < band.depth_max) && !(zf < band.lo || zf > band.hi);                // :93, then the widened band
 }
+// The same test with the per-column and per-row factors of  Z = z (t8 - t9 (u - W/2)/fx - t10 (v - H/2)/fy) + t11  taken
+// out of the texel loop (gx = -t9 (u - W/2)/fx is a lane constant, gy = t8 - t10 (v - H/2)/fy a row constant): two exactly
+// rounded operations for z (the `z < max_depth` mask must be the reference's), one add, one FMA, three compares.  The
+// re-association moves the f32 estimate by a few ulp -- the band's margin is 1e-4 of the operands' magnitude.
+__device__ inline bool candidate_fast(const HeightBand& band, float gx, float gy, float d) {
+    const float z = __fadd_rn(__fmul_rn(d, band.depth_scale), band.depth_offset);  // obstacle_map.py:92 (f32)
+    const float zf = __builtin_fmaf(z, gx + gy, band.t11);
+    return (z < band.depth_max) && !(zf < band.lo || zf > band.hi);
+}
+
+// a / b in f64, correctly rounded, with the reciprocal y = RN(1 / b) hoisted out (b is the focal length: the same for every
+// texel of the launch).  q0 = RN(a y) is a faithful quotient, r = a - b q0 is exact in one FMA, and RN(q0 + r y) is then the
+// correctly rounded a / b (Markstein's division step: the final FMA of the hardware's own v_div_scale / v_rcp / v_div_fmas /
+// v_div_fixup expansion, without the per-call refinement of the reciprocal and without the scaling that only matters near
+// overflow / underflow -- |a| <= image width x max depth, b a focal length in pixels).  Same bits as __ddiv_rn(a, b) in 3
+// operations instead of ~12 (tests/test_obstacle_prims_gpu.py checks 2^24 random quotients against the division).
+struct ExactRecip { double b, y; };
+__device__ inline ExactRecip exact_recip(double b) { return ExactRecip{b, __ddiv_rn(1.0, b)}; }
+__device__ inline double div_exact(double a, const ExactRecip& r) {
+    const double q0 = __dmul_rn(a, r.y);
+    const double rem = __fma_rn(-r.b, q0, a);
+    return __fma_rn(rem, r.y, q0);
+}
 
 template <bool HOLE_PASS>
-__device__ inline void place_exact(const IngestArgs& a, const vlfm_ingest_params& p, unsigned* grid, int obs, int u, int v,
-                                   float d) {
+__device__ inline void place_exact(const IngestArgs& a, const vlfm_ingest_params& p, const ExactRecip& rfx,
+                                   const ExactRecip& rfy, unsigned* grid, int obs, int u, int v, float d) {
     const float z = __fadd_rn(__fmul_rn(d, p.depth_scale), p.depth_offset);  // obstacle_map.py:92 (f32)
     // get_point_cloud (geometry_utils.py:230-234): int64 * f32 -> f64, then / fx
     const double zd = (double)z;
-    const double xc = __ddiv_rn(__dmul_rn((double)(u - a.W / 2), zd), p.fx);
-    const double yc = __ddiv_rn(__dmul_rn((double)(v - a.H / 2), zd), p.fy);
+    const double xc = div_exact(__dmul_rn((double)(u - a.W / 2), zd), rfx);
+    const double yc = div_exact(__dmul_rn((double)(v - a.H / 2), zd), rfy);
     const double c0 = zd, c1 = -xc, c2 = -yc;
     // transform_points (geometry_utils.py:207-213): tf @ [c;1], left to right, then divide by w
     const double* t = p.tf;
@@ -132,9 +155,11 @@ __device__ inline void place_exact(const IngestArgs& a, const vlfm_ingest_params
     const double half = (double)(a.S / 2);
     const double colf = (double)a.S - __dadd_rn(rint(__dmul_rn(Y, a.ppm)), half);
     const double rowf = __dadd_rn(rint(__dmul_rn(X, a.ppm)), half);
-    long long row = (long long)rowf, col = (long long)colf;
-    // NumPy fancy-index semantics (obstacle_map.py:101): [-S, -1] wraps, anything else outside raises IndexError
-    if (row >= a.S || row < -a.S || col >= a.S || col < -a.S) {
+    // NumPy fancy-index semantics (obstacle_map.py:101): [-S, -1] wraps, anything else outside raises IndexError.  The test
+    // runs on the (integer-valued) doubles; only values inside [-S, S) are converted (one instruction instead of the
+    // multi-instruction f64 -> i64 sequence).
+    const double Sd = (double)a.S;
+    if (!(rowf < Sd && rowf >= -Sd && colf < Sd && colf >= -Sd)) {
         // The speculative pass (fill_small_holes not evaluated yet) cannot know whether the reference would have seen this
         // texel at all: an "island" texel inside a small hole becomes 1.0 and is dropped (img_utils.py:385-388) without
         // ever reaching the scatter.  It only NOTES the hit (status word 1, bit 1); fill_small_holes_kernel promotes the
@@ -144,6 +169,7 @@ __device__ inline void place_exact(const IngestArgs& a, const vlfm_ingest_params
         else a.status[2 * obs] = VLFM_ERR_INDEX;
         return;
     }
+    int row = (int)rowf, col = (int)colf;
     if (row < 0) row += a.S;
     if (col < 0) col += a.S;
     // A plain (possibly stale) read that already shows the bit lets us skip the device-scope atomic: in steady state almost
@@ -191,6 +217,7 @@ template <bool SCATTER, bool PREFETCH>
 __device__ __forceinline__ void depth_ingest_body(const IngestArgs& a) {
     __shared__ float4 part[RL][CG];
     __shared__ uint2 ring[SCATTER ? CG * RL / 64 : 1][SCATTER ? WQ : 1];
+    __shared__ unsigned long long row_hits[SCATTER ? 1024 : 1];   // bit v: image row v can reach the height band (H <= 65535)
     constexpr int UNROLL = INGEST_UNROLL;
     const int obs = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -216,6 +243,20 @@ __device__ __forceinline__ void depth_ingest_body(const IngestArgs& a) {
     const bool do_scatter = SCATTER && (p.scatter & 1);
     uint2* q = ring[SCATTER ? (tid >> 6) : 0];
     unsigned q_head = 0u, q_cnt = 0u;   // wave-uniform: first pending entry, number of pending entries
+    ExactRecip rfx{1.0, 1.0}, rfy{1.0, 1.0};
+    float gx[4] = {0.f, 0.f, 0.f, 0.f};
+    if (SCATTER && do_scatter) {
+        // row_may_hit once per row and workgroup (it was ~25 instructions per lane and row group inside the streaming loop)
+        for (int v0 = 0; v0 < a.H; v0 += CG * RL) {
+            const int v = v0 + tid;
+            const unsigned long long hitmask = __ballot(v < a.H && row_may_hit(band, v, a.H));
+            if (lane == 0) row_hits[(v0 + tid) >> 6] = hitmask;
+        }
+        rfx = exact_recip(p.fx); rfy = exact_recip(p.fy);
+#pragma unroll
+        for (int c = 0; c < 4; c++) gx[c] = -band.t9 * (float)(col4 * 4 + c - a.W / 2) * band.inv_fx;
+        __syncthreads();
+    }
 
     // one iteration's loads: rows (g0 + k * bands) * RL + ry, k < UNROLL.  Rows that cannot reach the height band are not
     // even loaded by a scatter-only pass; a combined pass loads them (column maximum, hole bits) but never tests them.
@@ -227,7 +268,7 @@ __device__ __forceinline__ void depth_ingest_body(const IngestArgs& a) {
         for (int k = 0; k < UNROLL; k++) {
             const int r = (g0 + k * bands) * RL + ry;
             bool want = live && r < a.H;
-            const bool hit = SCATTER && do_scatter && want && row_may_hit(band, r, a.H);
+            const bool hit = SCATTER && do_scatter && want && ((row_hits[r >> 6] >> (r & 63)) & 1ull);
             if (SCATTER && scatter_only) want = hit;
             nxt[k] = want ? reinterpret_cast<const float4*>(img + (size_t)r * a.W)[col4] : make_float4(ninf, ninf, ninf, ninf);
             nxt_ok |= (want ? 1u : 0u) << k;
@@ -280,11 +321,9 @@ __device__ __forceinline__ void depth_ingest_body(const IngestArgs& a) {
                 if (p.scatter & 6)
                     skip |= (d[k].x == 0.0f ? 1u : 0u) | (d[k].y == 0.0f ? 2u : 0u) | (d[k].z == 0.0f ? 4u : 0u) |
                             (d[k].w == 0.0f ? 8u : 0u);
-                const int u = col4 * 4;
-                c4 = ((candidate(band, a.W, a.H, u + 0, r, d[k].x) ? 1u : 0u) |
-                      (candidate(band, a.W, a.H, u + 1, r, d[k].y) ? 2u : 0u) |
-                      (candidate(band, a.W, a.H, u + 2, r, d[k].z) ? 4u : 0u) |
-                      (candidate(band, a.W, a.H, u + 3, r, d[k].w) ? 8u : 0u)) & ~skip;
+                const float gy = band.t8 - band.t10 * (float)(r - a.H / 2) * band.inv_fy;
+                c4 = ((candidate_fast(band, gx[0], gy, d[k].x) ? 1u : 0u) | (candidate_fast(band, gx[1], gy, d[k].y) ? 2u : 0u) |
+                      (candidate_fast(band, gx[2], gy, d[k].z) ? 4u : 0u) | (candidate_fast(band, gx[3], gy, d[k].w) ? 8u : 0u)) & ~skip;
             }
             // ---- append this row group's survivors to the wavefront's ring: texel c of lane L goes behind all texels
             // c' < c of every lane and the texels c of the lanes below L
@@ -308,7 +347,7 @@ __device__ __forceinline__ void depth_ingest_body(const IngestArgs& a) {
             // ---- full passes: 64 pending entries -> one per lane
             while (q_cnt >= 64u) {
                 const uint2 e = q[(q_head + (unsigned)lane) & (WQ - 1)];
-                place_exact<false>(a, p, grid, obs, (int)(e.x & 0xFFFFu), (int)(e.x >> 16), __uint_as_float(e.y));
+                place_exact<false>(a, p, rfx, rfy, grid, obs, (int)(e.x & 0xFFFFu), (int)(e.x >> 16), __uint_as_float(e.y));
                 q_head += 64u;
                 q_cnt -= 64u;
             }
@@ -317,7 +356,7 @@ __device__ __forceinline__ void depth_ingest_body(const IngestArgs& a) {
     if (SCATTER && do_scatter && q_cnt) {   // the wavefront's remainder (< 64 entries)
         if ((unsigned)lane < q_cnt) {
             const uint2 e = q[(q_head + (unsigned)lane) & (WQ - 1)];
-            place_exact<false>(a, p, grid, obs, (int)(e.x & 0xFFFFu), (int)(e.x >> 16), __uint_as_float(e.y));
+            place_exact<false>(a, p, rfx, rfy, grid, obs, (int)(e.x & 0xFFFFu), (int)(e.x >> 16), __uint_as_float(e.y));
         }
     }
     if (saw_zero) atomicOr(&a.status[2 * obs + 1], 1);
@@ -377,22 +416,40 @@ __global__ __launch_bounds__(256) void hole_scatter_kernel(IngestArgs a, const i
     }
     if (!(w | redo)) return;
     unsigned* grid = a.obstacle + (size_t)p.env * a.S * a.stride;
+    const ExactRecip rfx = exact_recip(p.fx), rfy = exact_recip(p.fy);
     while (w) {
         const int b = __builtin_ctz(w);
         w &= w - 1u;
-        if (u0 + b < a.W && candidate(band, a.W, a.H, u0 + b, v, 0.0f)) place_exact<true>(a, p, grid, obs, u0 + b, v, 0.0f);
+        if (u0 + b < a.W && candidate(band, a.W, a.H, u0 + b, v, 0.0f)) place_exact<true>(a, p, rfx, rfy, grid, obs, u0 + b, v, 0.0f);
     }
     const float* row = a.depth ? a.depth + ((size_t)obs * a.H + v) * a.W + u0 : nullptr;
     while (redo) {
         const int b = __builtin_ctz(redo);
         redo &= redo - 1u;
-        if (candidate(band, a.W, a.H, u0 + b, v, row[b])) place_exact<true>(a, p, grid, obs, u0 + b, v, row[b]);
+        if (candidate(band, a.W, a.H, u0 + b, v, row[b])) place_exact<true>(a, p, rfx, rfy, grid, obs, u0 + b, v, row[b]);
+    }
+}
+
+// self-test of div_exact against the IEEE division (tests/test_obstacle_prims_gpu.py)
+__global__ __launch_bounds__(256) void div_exact_check_kernel(const double* __restrict__ a, int n, double b, int* mismatches) {
+    const ExactRecip r = exact_recip(b);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double want = __ddiv_rn(a[i], b), got = div_exact(a[i], r);
+        if (__double_as_longlong(want) != __double_as_longlong(got)) atomicAdd(mismatches, 1);
     }
 }
 
 }  // namespace vlfm
 
 using namespace vlfm;
+
+extern "C" int vlfm_selftest_div_exact(const double* d_numerators, int n, double divisor, int32_t* d_mismatches, void* stream) {
+    if (!d_numerators || !d_mismatches || n < 0) return fail(VLFM_ERR_INVALID, "selftest_div_exact: bad argument");
+    if (n == 0) return VLFM_OK;
+    hipLaunchKernelGGL(div_exact_check_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, d_numerators, n, divisor,
+                       d_mismatches);
+    return check_launch("div_exact_check_kernel");
+}
 
 extern "C" int vlfm_depth_scatter_holes_batched(const vlfm_ingest_params* d_params, int n, int height, int width,
                                                 const uint32_t* d_hole_bits, const uint32_t* d_filled_bits,

@@ -655,6 +655,8 @@ class BLIP2ITM:
                 tok = BertTokenizer(vocab_file=vocab, do_lower_case=True)
             else:
                 tok = BertTokenizer.from_pretrained("bert-base-uncased", local_files_only=True)
+                if len(tok) < 30522:   # transformers can hand back an EMPTY tokenizer when nothing is cached
+                    raise FileNotFoundError("no cached bert-base-uncased vocabulary")
         except Exception as exc:  # noqa: BLE001
             raise ValueError("BLIP-2 weights need the bert-base-uncased vocabulary: pass tokenizer_dir (or set BLIP2_TOKENIZER) "
                              "to a directory with its vocab.txt") from exc

@@ -70,11 +70,15 @@ def _bert_tokenizer(tokenizer_dir: Optional[str]):
         if not os.path.isfile(vocab):
             raise FileNotFoundError(f"no vocab.txt under {path!r}")
         return BertTokenizer(vocab_file=vocab, do_lower_case=True)
+    msg = ("GroundingDINO weights need the bert-base-uncased vocabulary: pass tokenizer_dir (or set GROUNDING_DINO_TOKENIZER) "
+           "to a directory with its vocab.txt")
     try:
-        return BertTokenizer.from_pretrained("bert-base-uncased", local_files_only=True)
+        tok = BertTokenizer.from_pretrained("bert-base-uncased", local_files_only=True)
     except Exception as exc:  # noqa: BLE001
-        raise ValueError("GroundingDINO weights need the bert-base-uncased vocabulary: pass tokenizer_dir (or set "
-                         "GROUNDING_DINO_TOKENIZER) to a directory with its vocab.txt") from exc
+        raise ValueError(msg) from exc
+    if len(tok) < 30522:   # transformers can hand back an EMPTY tokenizer (special tokens only) when nothing is cached
+        raise ValueError(msg)
+    return tok
 
 
 class GroundingDINO:
