@@ -65,6 +65,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-steps", type=int, default=2, help="BLIP-2 fp32 forwards timed on the host")
     ap.add_argument("--no-overlap", action="store_true", help="run the obstacle pipeline on the BLIP-2 stream")
     ap.add_argument("--host-profile", action="store_true", help="cProfile the timed region (stderr), for tuning")
+    ap.add_argument("--host-busy-cores", type=float, default=None,
+                    help="--dry-run: host cores one rank keeps busy (default: the figure measured by the last committed "
+                         "1-GPU run, profiles/host_busy.json); the dry run asserts ranks x this <= the cgroup CPU quota")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher + process group + barriers + metric all-reduce around a stub step: no GPU work "
                          "(backend gloo when no GPU is visible) -- the multi-rank plumbing test of tests/")
@@ -343,8 +346,9 @@ def map_roofline(kms, E, H, W, sync, stored_cells, pmc):
         table[name] = rec
 
     depth_bytes = 4 * H * W
-    # one pass reads every texel once for both maps (the reference reads the image twice: SURVEY 8d prices 4*H*W per map)
-    entry("depth_ingest_scatter_kernel", E * 2 * depth_bytes, E * (depth_bytes + 4 * W),
+    # one pass reads every texel ONCE for both maps: priced at the bytes it reads (SURVEY 8d prices 4*H*W per map because
+    # the reference reads the image twice; that "reference-equivalent" 8*H*W figure is not reported as a fraction any more)
+    entry("depth_ingest_scatter_kernel", E * depth_bytes, E * (depth_bytes + 4 * W),
           "4*H*W texel reads + W column-max keys; obstacle-bit atomics not counted")
     entry("depth_ingest_kernel", E * depth_bytes, E * (depth_bytes + 4 * W), "4*H*W texel reads + W keys")
     entry("depth_scatter_kernel", E * depth_bytes, E * depth_bytes // 2, "only rows that can reach the height band are read")
@@ -380,8 +384,23 @@ def dry_run(args) -> None:
     D.barrier(device)
     elapsed = time.perf_counter() - t0
     elapsed_max, (env_steps, id_sum) = D.reduce_metrics(elapsed, [float(len(ids) * args.steps), float(sum(ids))], device)
+    # host headroom: every rank drives its GPU from one Python thread; N ranks on one node must fit the CPU quota or the
+    # cgroup throttles all of them (it did at 16 CPUs: tools/stall_probe.py).  The per-rank figure is measured, not assumed:
+    # the 1-GPU run writes it into its JSON line (`host.busy_cores_per_rank`) and into profiles/host_busy.json.
+    busy = args.host_busy_cores
+    if busy is None:
+        try:
+            busy = float(json.load(open(os.path.join(ROOT, "profiles", "host_busy.json")))["busy_cores_per_rank"])
+        except (OSError, ValueError, KeyError):
+            busy = None
+    quota = usable_cores()
+    if busy is not None:
+        assert world * busy <= quota, (f"{world} ranks x {busy:.2f} busy host cores each = {world * busy:.1f} > the CPU quota of "
+                                       f"{quota} cores: the ranks would throttle one another")
     if rank == 0:
         print(json.dumps({"metric": "env-steps/s (DRY RUN: stub step, no GPU work)", "dry_run": True,
+                          "host": {"busy_cores_per_rank": busy, "ranks": world, "cgroup_quota_cores": quota,
+                                   "fits": None if busy is None else bool(world * busy <= quota)},
                           "value": round(env_steps / elapsed_max, 2), "unit": "env-steps/s", "n_gpus": world,
                           "ranks": world, "backend": "nccl (RCCL)" if use_gpu else "gloo", "steps": args.steps,
                           "warmup": args.warmup, "global_envs": args.envs * world, "env_id_checksum": id_sum,
@@ -435,6 +454,7 @@ def main():
         prof = cProfile.Profile()
     barrier()
     t0 = time.perf_counter()
+    cpu0 = time.process_time()   # CPU seconds of ALL threads of this rank (Python thread + HIP runtime helpers)
     if prof is not None:
         prof.enable()
     for _ in range(args.steps):
@@ -443,13 +463,15 @@ def main():
         prof.disable()
     barrier()
     elapsed = time.perf_counter() - t0
+    host_cpu = time.process_time() - cpu0
     sim.check()  # a capacity overflow or an off-map obstacle point inside the timed region fails the benchmark
     if prof is not None and rank == 0:
         import pstats
 
         pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(35)
 
-    elapsed_max, (env_steps,) = D.reduce_metrics(elapsed, [float(args.envs * args.steps)], device)
+    elapsed_max, (env_steps, host_cpu_sum, host_busy_sum) = D.reduce_metrics(
+        elapsed, [float(args.envs * args.steps), host_cpu, host_cpu / elapsed], device)
 
     torch.cuda.synchronize(device)
     kms = read_kernel_ms()
@@ -466,7 +488,8 @@ def main():
                     "achieved": head["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["frac"],
                     "traffic": head.get("traffic"), "traffic_frac": head.get("traffic_frac"),
                     "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of tools/pmc_traffic.sh; null = not "
-                                      "collected for this kernel / configuration)",
+                                      "collected for this kernel / configuration); produced by commit "
+                                      + str(load_pmc().get("_commit", "unknown")),
                     "algorithmic_bytes_per_launch": head["algorithmic_bytes_per_launch"],
                     "necessary_bytes_per_launch": head["necessary_bytes_per_launch"],
                     "necessary_frac": head["necessary_frac"], "stored_cells_per_observation": round(stored, 1),
@@ -498,7 +521,21 @@ def main():
                        "value_map_update": "split (3 launches)" if sim.values.split_update else "single launch",
                        "parallelism": f"env-sharded x{world} (contiguous blocks), metric all-reduce only"},
             "roofline": roofline,
+            # 8-GPU readiness without the node: how much host CPU one rank needs, against what the container may use
+            "host": {"cpu_s_per_step_per_rank": round(host_cpu_sum / world / args.steps, 5),
+                     "busy_cores_per_rank": round(host_busy_sum / world, 3), "busy_cores_all_ranks": round(host_busy_sum, 3),
+                     "cgroup_quota_cores": usable_cores(),
+                     "ranks_that_fit_the_quota": int(usable_cores() / max(host_busy_sum / world, 1e-9)),
+                     "note": "process_time of all threads of a rank over the timed region / wall time; `python bench.py "
+                             "--gpus 8 --dry-run` asserts 8 x busy_cores_per_rank <= the quota"},
         }
+        if world == 1 and not args.no_blip2 and args.envs == 256:
+            try:   # the figure the dry run checks against (committed with the profiles of the round)
+                json.dump({"busy_cores_per_rank": round(host_busy_sum / world, 3), "envs_per_gpu": E,
+                           "cpu_s_per_step": round(host_cpu_sum / world / args.steps, 5)},
+                          open(os.path.join(ROOT, "gpurun_out", "host_busy.json"), "w"))
+            except OSError:
+                pass
         if world == 1 and not args.no_small:
             out["small_batch"] = side_legs(args, sim, device, common)
         if world == 1 and not args.no_cpu_baseline:

@@ -219,9 +219,9 @@ def test_hoisted_reciprocal_division_equals_the_ieee_division(gpu_device):
             np.concatenate([[0.0, -0.0, 1.0, -1.0], np.nextafter(388.19, 1e9) * np.arange(1, n - 3)])]
     L = _lib.lib()
     for fx in (388.1926244788403, 320.0, 776.3852489576806, 1.0 / 3.0, 554.2562584220407, 0.1):
-        for a in sets:
+        for k, a in enumerate(sets):
             d_a = torch.from_numpy(np.ascontiguousarray(a)).to(gpu_device)
             bad = torch.zeros(1, dtype=torch.int32, device=gpu_device)
             _lib.check(L.vlfm_selftest_div_exact(d_a.data_ptr(), d_a.numel(), float(fx), bad.data_ptr(),
                                                  torch.cuda.current_stream().cuda_stream), "selftest_div_exact")
-            assert int(bad.item()) == 0, (fx, int(bad.item()))
+            assert int(bad.item()) == 0, (fx, k, int(bad.item()))

@@ -48,6 +48,13 @@ def main(E, W, H, sync=False):
                "bytes_per_launch_upper": round(2 * fetch_b + write_b)}
         out[f"{label}@E={E},{W}x{H}" + (",sync" if sync else "")] = rec
         print(label, rec)
+    try:   # which tree produced these counters (bench.py quotes it next to `roofline.traffic`)
+        import subprocess
+
+        head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:  # noqa: BLE001 -- the GPU box has no .git: the caller passes VLFM_COMMIT
+        head = os.environ.get("VLFM_COMMIT", "unknown")
+    out["_commit"] = head
     json.dump(out, open(out_path, "w"), indent=1, sort_keys=True)
 
 

@@ -132,7 +132,7 @@ __device__ inline ExactRecip exact_recip(double b) { return ExactRecip{b, __ddiv
 __device__ inline double div_exact(double a, const ExactRecip& r) {
     const double q0 = __dmul_rn(a, r.y);
     const double rem = __fma_rn(-r.b, q0, a);
-    return __fma_rn(rem, r.y, q0);
+    return rem == 0.0 ? q0 : __fma_rn(rem, r.y, q0);   // (exact quotient: keep q0 -- the FMA would turn a -0.0 into +0.0)
 }
 
 template <bool HOLE_PASS>
