@@ -56,6 +56,11 @@ struct IngestArgs {
     int ry;                         // rows advanced per iteration (= blockDim.x / cols_per_block)
     int rows_per_block;
     double ppm;
+    // two-pass form: the streaming pass writes its candidates to a global list, depth_place_kernel places them
+    uint2* cand;                    // [n][cand_cap] entries (packed (u, v), raw depth) or null = place inside the streaming pass
+    unsigned* cand_count;           // [n] entries written (zero on entry; depth_place_kernel hands it back zeroed)
+    unsigned* cand_done;            // [n] workgroups of depth_place_kernel that have finished (zero on entry and on exit)
+    unsigned cand_cap;              // H * W: every texel may be a candidate
 };
 
 struct HeightBand {  // f32 shadow of the height test, widened by a safety margin
@@ -213,7 +218,7 @@ constexpr int INGEST_UNROLL = 4;
 constexpr int WQ = 512;      // ring entries per wavefront (power of two >= 63 + 256: a row group adds at most 256)
 constexpr int kIngestDefaultVariant = 0;   // 0 pf4 | 1 np4 | 2 np6 | 3 pf6 | 4 no register cap (see the stamped kernels)
 
-template <bool SCATTER, bool PREFETCH>
+template <bool SCATTER, bool PREFETCH, bool LIST = false>
 __device__ __forceinline__ void depth_ingest_body(const IngestArgs& a) {
     __shared__ float4 part[RL][CG];
     __shared__ uint2 ring[SCATTER ? CG * RL / 64 : 1][SCATTER ? WQ : 1];
@@ -344,19 +349,33 @@ __device__ __forceinline__ void depth_ingest_body(const IngestArgs& a) {
                 if (c4 & 8u) q[(tail + n0 + n1 + n2 + below3) & (WQ - 1)] = make_uint2(pos + 3u, __float_as_uint(d[k].w));
                 q_cnt += total;
             }
-            // ---- full passes: 64 pending entries -> one per lane
+            // ---- full passes: 64 pending entries -> one per lane: placed here, or (two-pass form) moved to the observation's
+            // global candidate list as one coalesced 512-byte store behind ONE returning atomic per 64 entries
             while (q_cnt >= 64u) {
                 const uint2 e = q[(q_head + (unsigned)lane) & (WQ - 1)];
-                place_exact<false>(a, p, rfx, rfy, grid, obs, (int)(e.x & 0xFFFFu), (int)(e.x >> 16), __uint_as_float(e.y));
+                if (LIST) {
+                    unsigned base = 0u;
+                    if (lane == 0) base = atomicAdd(&a.cand_count[obs], 64u);
+                    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                    a.cand[(size_t)obs * a.cand_cap + base + (unsigned)lane] = e;
+                } else {
+                    place_exact<false>(a, p, rfx, rfy, grid, obs, (int)(e.x & 0xFFFFu), (int)(e.x >> 16), __uint_as_float(e.y));
+                }
                 q_head += 64u;
                 q_cnt -= 64u;
             }
         }
     }
     if (SCATTER && do_scatter && q_cnt) {   // the wavefront's remainder (< 64 entries)
+        unsigned base = 0u;
+        if (LIST) {
+            if (lane == 0) base = atomicAdd(&a.cand_count[obs], q_cnt);
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        }
         if ((unsigned)lane < q_cnt) {
             const uint2 e = q[(q_head + (unsigned)lane) & (WQ - 1)];
-            place_exact<false>(a, p, rfx, rfy, grid, obs, (int)(e.x & 0xFFFFu), (int)(e.x >> 16), __uint_as_float(e.y));
+            if (LIST) a.cand[(size_t)obs * a.cand_cap + base + (unsigned)lane] = e;
+            else place_exact<false>(a, p, rfx, rfy, grid, obs, (int)(e.x & 0xFFFFu), (int)(e.x >> 16), __uint_as_float(e.y));
         }
     }
     if (saw_zero) atomicOr(&a.status[2 * obs + 1], 1);
@@ -391,6 +410,35 @@ __global__ __launch_bounds__(CG * RL) __attribute__((amdgpu_waves_per_eu(6, 6)))
 void depth_ingest_scatter_np6_kernel(IngestArgs a) { depth_ingest_body<true, false>(a); }
 __global__ __launch_bounds__(CG * RL) __attribute__((amdgpu_waves_per_eu(6, 6)))
 void depth_ingest_scatter_pf6_kernel(IngestArgs a) { depth_ingest_body<true, true>(a); }
+// two-pass form, pass 1: stream + pre-test + compaction into the global candidate list (no f64, no plane access)
+__global__ __launch_bounds__(CG * RL) void depth_ingest_list_np_kernel(IngestArgs a) { depth_ingest_body<true, false, true>(a); }
+__global__ __launch_bounds__(CG * RL) void depth_ingest_list_pf_kernel(IngestArgs a) { depth_ingest_body<true, true, true>(a); }
+
+// two-pass form, pass 2: the exact placement of every listed candidate, one per lane -- dense f64 work on full wavefronts
+// over the whole chip, all plane reads of a sweep in flight.  grid = (G, n).  The last workgroup of an observation hands
+// the list counter back zeroed for the next depth pass.
+__global__ __launch_bounds__(256) void depth_place_kernel(IngestArgs a) {
+    const int obs = blockIdx.y, tid = threadIdx.x;
+    const vlfm_ingest_params p = a.prm[obs];
+    const unsigned n_c = a.cand_count[obs];
+    if (n_c) {
+        const ExactRecip rfx = exact_recip(p.fx), rfy = exact_recip(p.fy);
+        unsigned* grid = a.obstacle + (size_t)p.env * a.S * a.stride;
+        const uint2* list = a.cand + (size_t)obs * a.cand_cap;
+        for (unsigned i = blockIdx.x * blockDim.x + tid; i < n_c; i += gridDim.x * blockDim.x) {
+            const uint2 e = list[i];
+            place_exact<false>(a, p, rfx, rfy, grid, obs, (int)(e.x & 0xFFFFu), (int)(e.x >> 16), __uint_as_float(e.y));
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        if (atomicAdd(&a.cand_done[obs], 1u) == gridDim.x - 1u) {
+            a.cand_count[obs] = 0u;
+            a.cand_done[obs] = 0u;
+        }
+    }
+}
 
 // The zero texels that fill_small_holes left alone (holes of area >= hole_area_thresh), placed from the bit planes: the
 // depth images are not read again.  One thread per 32-texel word of (hole & ~filled); frames without a zero texel
@@ -443,6 +491,11 @@ __global__ __launch_bounds__(256) void div_exact_check_kernel(const double* __re
 
 using namespace vlfm;
 
+extern "C" size_t vlfm_depth_candidates_bytes(int n, int height, int width) {
+    if (n <= 0 || height <= 0 || width <= 0) return 0;
+    return (((size_t)2 * n * 4 + 255) / 256) * 256 + (size_t)n * height * width * sizeof(uint2);
+}
+
 extern "C" int vlfm_selftest_div_exact(const double* d_numerators, int n, double divisor, int32_t* d_mismatches, void* stream) {
     if (!d_numerators || !d_mismatches || n < 0) return fail(VLFM_ERR_INVALID, "selftest_div_exact: bad argument");
     if (n == 0) return VLFM_OK;
@@ -475,10 +528,12 @@ extern "C" int vlfm_depth_ingest_batched(const float* d_depth, int n, int height
                                          const vlfm_ingest_params* d_params, uint32_t* d_colmax_keys, uint32_t* d_obstacle,
                                          int map_size, int pixels_per_meter, int32_t* d_status, uint32_t* d_hole_bits,
                                          const uint32_t* d_filled_bits, const vlfm_scatter_journal* journal,
-                                         void* stream) {
+                                         void* d_candidates, size_t candidates_bytes, void* stream) {
     if (n == 0) return VLFM_OK;
     if (!d_depth || !d_params || !d_status || n < 0 || height <= 0 || width <= 0)
         return fail(VLFM_ERR_INVALID, "depth_ingest_batched: bad argument");
+    if (d_candidates && candidates_bytes < vlfm_depth_candidates_bytes(n, height, width))
+        return fail(VLFM_ERR_CAPACITY, "depth_ingest_batched: candidate scratch too small");
     if (width % 4 != 0) return fail(VLFM_ERR_INVALID, "depth_ingest_batched: width must be a multiple of 4");
     if (width > 65535 || height > 65535) return fail(VLFM_ERR_INVALID, "depth_ingest_batched: image sides must fit 16 bits");
     if (!d_colmax_keys && !d_obstacle && !d_hole_bits) return VLFM_OK;
@@ -494,6 +549,13 @@ extern "C" int vlfm_depth_ingest_batched(const float* d_depth, int n, int height
     a.H = height; a.W = width; a.W4 = width / 4; a.S = map_size; a.stride = (map_size + 31) / 32;
     a.ppm = (double)pixels_per_meter;
     a.cols_per_block = CG; a.ry = RL;
+    a.cand = nullptr; a.cand_count = nullptr; a.cand_done = nullptr; a.cand_cap = 0u;
+    if (d_candidates && d_obstacle) {   // layout: [n] counters | [n] done flags | pad to 256 B | [n][H*W] entries
+        a.cand_count = reinterpret_cast<unsigned*>(d_candidates);
+        a.cand_done = a.cand_count + n;
+        a.cand = reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(d_candidates) + (((size_t)2 * n * 4 + 255) / 256) * 256);
+        a.cand_cap = (unsigned)height * (unsigned)width;
+    }
     const int gx = (a.W4 + CG - 1) / CG;
     // row bands: aim for ~2048 workgroups (8 per CU) so that enough 16-byte loads are in flight to cover HBM latency,
     // but never fewer than RL rows per band
@@ -511,6 +573,22 @@ extern "C" int vlfm_depth_ingest_batched(const float* d_depth, int n, int height
             const char* e = getenv("VLFM_INGEST_VARIANT");
             return e ? atoi(e) : kIngestDefaultVariant;
         }();
+        if (a.cand) {
+            // two passes: the streaming pass only lists its candidates; the placement is a kernel of its own
+            if (variant == 1 || variant == 2 || variant == 4)
+                VLFM_KLAUNCH(depth_ingest_list_np_kernel, dim3(gx, gy, n), dim3(CG * RL), 0, s, a);
+            else
+                VLFM_KLAUNCH(depth_ingest_list_pf_kernel, dim3(gx, gy, n), dim3(CG * RL), 0, s, a);
+            int rc1 = check_launch("depth_ingest_list_kernel");
+            if (rc1 != VLFM_OK) return rc1;
+            int G = (4096 + n - 1) / n;
+            const int g_max = (int)((a.cand_cap + 255u) / 256u);
+            if (G > g_max) G = g_max;
+            if (G < 1) G = 1;
+            VLFM_TIMED("depth_place_kernel", s);
+            VLFM_KLAUNCH(depth_place_kernel, dim3(G, n), dim3(256), 0, s, a);
+            return check_launch("depth_place_kernel");
+        }
         switch (variant) {
             case 1: VLFM_KLAUNCH(depth_ingest_scatter_np4_kernel, dim3(gx, gy, n), dim3(CG * RL), 0, s, a); break;
             case 2: VLFM_KLAUNCH(depth_ingest_scatter_np6_kernel, dim3(gx, gy, n), dim3(CG * RL), 0, s, a); break;
