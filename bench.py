@@ -354,10 +354,16 @@ def map_roofline(kms, E, H, W, sync, stored_cells, pmc):
     entry("depth_scatter_kernel", E * depth_bytes, E * depth_bytes // 2, "only rows that can reach the height band are read")
     window = 4 * T * T + 8 * T * T + 8 * T * T                      # template + conf RMW + value RMW (C = 1)
     full = S * S + 8 * S * S + 8 * S * S + 4 * T * T                # explored + full-map conf/value RMW + template
-    need = stored_cells * (16 + 4) + 4 * W + ((2 * S * ((S + 31) // 32) * 4) if sync else 0)
+    need = stored_cells * (8 + 16 + 4) + 4 * W + ((2 * S * ((S + 31) // 32) * 4) if sync else 0)
     entry("value_map_update_fused_kernel", E * (full if sync else window), E * need,
-          "cells stored x (8 B conf RMW + 8 B value RMW + 4 B template tap) + W keys"
+          "cells stored x (8 B conf RMW + 16 B value RMW (f64, like the reference's promoted array) + 4 B template tap) + W keys"
           + (" + explored and written bit planes" if sync else ""))
+    if "value_map_update_fused_kernel" in table:
+        # SURVEY 8d prices the value map at 4 B per cell; the reference's array -- and since round 3 the device's -- is f64
+        f64_bytes = E * ((full + 8 * S * S) if sync else (window + 8 * T * T))
+        rec = table["value_map_update_fused_kernel"]
+        rec["algorithmic_bytes_per_launch_f64_value"] = int(f64_bytes)
+        rec["frac_f64_value"] = round(f64_bytes / (kms["value_map_update_fused_kernel"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     entry("value_map_fuse_kernel", E * window, E * (stored_cells * 20 + 5632), "cells stored x 20 B + visibility plane")
     entry("mask_unexplored_kernel", E * (S * S + 8 * S * S + 8 * S * S), E * S * 125, "explored bit plane only when nothing is cleared")
     return table
@@ -504,7 +510,7 @@ def main():
             "value": round(env_steps / elapsed_max, 2), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 maps / f16 ViT-g + f32 Q-Former", "data": "synthetic",
+            "dtype": "f32 confidence + f64 value maps (the reference's own dtypes) / f16 ViT-g + f32 Q-Former", "data": "synthetic",
             "ranks": world, "backend": "nccl (RCCL)" if dist.is_initialized() else "single process, no process group",
             "config": {"workload": ("configs[1] step (BLIP-2 ITC cosine + ValueMap fusion"
                                     + (" + ObstacleMap update" if have_obstacle else "")

@@ -138,15 +138,7 @@ int vlfm_depth_ingest_batched(const float* d_depth, int n, int height, int width
                               const uint32_t* d_filled_bits /* IN  [n][H][ceil(W/32)] texels fill_small_holes set to
                                                                1.0 (vlfm_fill_small_holes_batched), or NULL */,
                               const vlfm_scatter_journal* journal /* host pointer or NULL (see above) */,
-                              void* d_candidates /* NULL, or vlfm_depth_candidates_bytes(n, H, W) bytes, ZERO on first use */,
-                              size_t candidates_bytes, void* stream);
-/* d_candidates selects how the obstacle placement is organised.  NULL: inside the streaming pass (every wavefront compacts
- * the texels that pass the f32 pre-test into its own LDS ring and places 64 at a time; no extra HBM traffic).  Non-NULL: TWO
- * launches -- the streaming pass only lists its candidates (8 B each: packed (u, v) + raw depth, moved from the LDS rings to
- * the observation's list 64 at a time) and stays HBM-bound; depth_place_kernel then places them, one per lane, as dense f64
- * work.  The buffer holds [n] counters, [n] completion flags and n x H x W entries (every texel may be a candidate); the
- * library hands counters and flags back zeroed after every call, so a zero-initialised buffer needs no upkeep. */
-size_t vlfm_depth_candidates_bytes(int n, int height, int width);
+                              void* stream);
 
 /* Diagnostic: the depth scatter divides by the focal lengths with a hoisted reciprocal and one FMA correction step (same bits
  * as the IEEE division, a quarter of its instructions).  Counts into d_mismatches[0] (caller zeroes it) the numerators for

@@ -42,10 +42,6 @@ def one(variant: int, E: int = 256, H: int = 480, W: int = 640, steps: int = 30)
     print(f"streaming only (column maxima): {ms0 * 1e3:8.1f} us over {n0} launches = {E * H * W * 4 / (ms0 * 1e-3) / 1e12:.2f} TB/s",
           flush=True)
     bits = ob.obstacle_bits.cpu().numpy()
-    ms2, n2 = _lib.profile_read("depth_place_kernel")
-    if n2:
-        print(f"two-pass: streaming + listing {ms * 1e3:8.1f} us ({E * H * W * 4 / (ms * 1e-3) / 1e12:.2f} TB/s), placement "
-              f"{ms2 * 1e3:8.1f} us, sum {(ms + ms2) * 1e3:8.1f} us", flush=True)
     print(f"variant {variant}: {ms * 1e3:8.1f} us over {n} launches ({E} x {H}x{W}: "
           f"{E * H * W * 4 / (ms * 1e-3) / 1e12:.2f} TB/s of depth), obstacle bits {int(np.unpackbits(bits.view(np.uint8)).sum())}, "
           f"checksum {int(bits.astype(np.int64).sum()) & 0xFFFFFFFF:08x}", flush=True)
@@ -58,10 +54,6 @@ if __name__ == "__main__":
         for v in range(5):
             env = dict(os.environ, VLFM_INGEST_VARIANT=str(v))
             subprocess.run([sys.executable, os.path.abspath(__file__), str(v)], env=env, check=False)
-        for v in (0, 1):   # the two-pass form (global candidate list + depth_place_kernel)
-            env = dict(os.environ, VLFM_INGEST_VARIANT=str(v), VLFM_INGEST_TWO_PASS="1")
-            subprocess.run([sys.executable, os.path.abspath(__file__), str(v)], env=env, check=False)
-            subprocess.run([sys.executable, os.path.abspath(__file__), str(v), "16", "720", "1280"], env=env, check=False)
         for v in (0, 1):   # config-5 geometry: 16 x 1280x720
             env = dict(os.environ, VLFM_INGEST_VARIANT=str(v))
             subprocess.run([sys.executable, os.path.abspath(__file__), str(v), "16", "720", "1280"], env=env, check=False)

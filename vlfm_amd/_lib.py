@@ -110,9 +110,7 @@ def lib() -> ctypes.CDLL:
         L.vlfm_tan_table_host.argtypes = [cd, ci, vp]
         L.vlfm_disc_rows_host.argtypes = [ci, vp]
         L.vlfm_cone_template_build.argtypes = [vp, vp, ci, ci, vp, vp, vp]
-        L.vlfm_depth_ingest_batched.argtypes = [vp, ci, ci, ci, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
-        L.vlfm_depth_candidates_bytes.argtypes = [ci, ci, ci]
-        L.vlfm_depth_candidates_bytes.restype = ctypes.c_size_t
+        L.vlfm_depth_ingest_batched.argtypes = [vp, ci, ci, ci, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp]
         L.vlfm_selftest_div_exact.argtypes = [vp, ci, cd, vp, vp]
         L.vlfm_hole_scratch_bytes.argtypes = [ci, ci, ci, ci, ci]
         L.vlfm_hole_scratch_bytes.restype = ctypes.c_size_t

@@ -56,11 +56,6 @@ struct IngestArgs {
     int ry;                         // rows advanced per iteration (= blockDim.x / cols_per_block)
     int rows_per_block;
     double ppm;
-    // two-pass form: the streaming pass writes its candidates to a global list, depth_place_kernel places them
-    uint2* cand;                    // [n][cand_cap] entries (packed (u, v), raw depth) or null = place inside the streaming pass
-    unsigned* cand_count;           // [n] entries written (zero on entry; depth_place_kernel hands it back zeroed)
-    unsigned* cand_done;            // [n] workgroups of depth_place_kernel that have finished (zero on entry and on exit)
-    unsigned cand_cap;              // H * W: every texel may be a candidate
 };
 
 struct HeightBand {  // f32 shadow of the height test, widened by a safety margin
@@ -180,7 +175,7 @@ __device__ inline void place_exact(const IngestArgs& a, const vlfm_ingest_params
     // A plain (possibly stale) read that already shows the bit lets us skip the device-scope atomic: in steady state almost
     // every in-band point re-observes a known obstacle cell.  (Bits are only cleared by reset() and by the island undo of
     // fill_small_holes_kernel, which runs strictly after this kernel.)
-    unsigned* word = &grid[(size_t)row * a.stride + (col >> 5)];
+    unsigned* word = &grid[row * a.stride + (col >> 5)];   // S <= 2048 (checked by the host): the index fits 32 bits
     const unsigned bit = 1u << (col & 31);
     if (!(*word & bit)) {
         const unsigned old = atomicOr(word, bit);
@@ -218,7 +213,7 @@ constexpr int INGEST_UNROLL = 4;
 constexpr int WQ = 512;      // ring entries per wavefront (power of two >= 63 + 256: a row group adds at most 256)
 constexpr int kIngestDefaultVariant = 0;   // 0 pf4 | 1 np4 | 2 np6 | 3 pf6 | 4 no register cap (see the stamped kernels)
 
-template <bool SCATTER, bool PREFETCH, bool LIST = false>
+template <bool SCATTER, bool PREFETCH>
 __device__ __forceinline__ void depth_ingest_body(const IngestArgs& a) {
     __shared__ float4 part[RL][CG];
     __shared__ uint2 ring[SCATTER ? CG * RL / 64 : 1][SCATTER ? WQ : 1];
@@ -266,9 +261,8 @@ __device__ __forceinline__ void depth_ingest_body(const IngestArgs& a) {
     // one iteration's loads: rows (g0 + k * bands) * RL + ry, k < UNROLL.  Rows that cannot reach the height band are not
     // even loaded by a scatter-only pass; a combined pass loads them (column maximum, hole bits) but never tests them.
     float4 nxt[UNROLL];
-    unsigned nxt_ok = 0u, nxt_hit = 0u;
+    bool nxt_ok[UNROLL], nxt_hit[UNROLL];   // lane predicates: they live in scalar register pairs, not in packed vector masks
     auto issue = [&](int g0) {
-        nxt_ok = 0u; nxt_hit = 0u;
 #pragma unroll
         for (int k = 0; k < UNROLL; k++) {
             const int r = (g0 + k * bands) * RL + ry;
@@ -276,8 +270,8 @@ __device__ __forceinline__ void depth_ingest_body(const IngestArgs& a) {
             const bool hit = SCATTER && do_scatter && want && ((row_hits[r >> 6] >> (r & 63)) & 1ull);
             if (SCATTER && scatter_only) want = hit;
             nxt[k] = want ? reinterpret_cast<const float4*>(img + (size_t)r * a.W)[col4] : make_float4(ninf, ninf, ninf, ninf);
-            nxt_ok |= (want ? 1u : 0u) << k;
-            nxt_hit |= (hit ? 1u : 0u) << k;
+            nxt_ok[k] = want;
+            nxt_hit[k] = hit;
         }
     };
     if (PREFETCH && band_id < n_groups) issue(band_id);
@@ -286,33 +280,40 @@ __device__ __forceinline__ void depth_ingest_body(const IngestArgs& a) {
     for (int g0 = band_id; g0 < n_groups; g0 += UNROLL * bands) {
         if (!PREFETCH) issue(g0);
         float4 d[UNROLL];
+        bool okb[UNROLL], hitb[UNROLL];
 #pragma unroll
-        for (int k = 0; k < UNROLL; k++) d[k] = nxt[k];
-        const unsigned okmask = nxt_ok, hitmask = nxt_hit;
+        for (int k = 0; k < UNROLL; k++) { d[k] = nxt[k]; okb[k] = nxt_ok[k]; hitb[k] = nxt_hit[k]; }
         if (PREFETCH && g0 + UNROLL * bands < n_groups) issue(g0 + UNROLL * bands);
 #pragma unroll
         for (int k = 0; k < UNROLL; k++) {
             const int r = (g0 + k * bands) * RL + ry;
-            const bool ok = (okmask >> k) & 1u;
+            const bool ok = okb[k];
             m.x = fmaxf(m.x, d[k].x); m.y = fmaxf(m.y, d[k].y); m.z = fmaxf(m.z, d[k].z); m.w = fmaxf(m.w, d[k].w);
+            unsigned zero4 = 0u;   // this lane's (depth == 0) texels
             if (holes) {
-                // (depth == 0) bit plane: 4 texels per lane, 8 neighbouring lanes (same row) per 32-bit word.  Four
-                // wave ballots (scalar unit) + a bit spread in the group's leader lane; no cross-lane data movement.
-                const unsigned long long b0 = __ballot(ok && d[k].x == 0.0f), b1 = __ballot(ok && d[k].y == 0.0f);
-                const unsigned long long b2 = __ballot(ok && d[k].z == 0.0f), b3 = __ballot(ok && d[k].w == 0.0f);
-                saw_zero |= (b0 | b1 | b2 | b3) != 0ull;
-                if (ok && (cx & 7) == 0) {
-                    unsigned word = 0u;
+                // (depth == 0) bit plane: 4 texels per lane, 8 neighbouring lanes (same row) per 32-bit word.  A frame behind
+                // depth_camera_filtering has no zero at all: three min + one compare + one ballot say so for the whole
+                // wavefront, and the plane word is simply 0.  Otherwise four wave ballots (scalar unit) + a bit spread in the
+                // group's leader lane; no cross-lane data movement.
+                const float mn = fminf(fminf(d[k].x, d[k].y), fminf(d[k].z, d[k].w));
+                unsigned word = 0u;
+                if (__ballot(ok && !(mn > 0.0f)) != 0ull) {
+                    zero4 = (d[k].x == 0.0f ? 1u : 0u) | (d[k].y == 0.0f ? 2u : 0u) | (d[k].z == 0.0f ? 4u : 0u) |
+                            (d[k].w == 0.0f ? 8u : 0u);
+                    if (!ok) zero4 = 0u;
+                    const unsigned long long b0 = __ballot(zero4 & 1u), b1 = __ballot(zero4 & 2u);
+                    const unsigned long long b2 = __ballot(zero4 & 4u), b3 = __ballot(zero4 & 8u);
+                    saw_zero |= (b0 | b1 | b2 | b3) != 0ull;
                     if (b0 | b1 | b2 | b3) {
                         const int sh = lane & ~7;
                         word = spread8((unsigned)(b0 >> sh) & 0xFFu) | (spread8((unsigned)(b1 >> sh) & 0xFFu) << 1) |
                                (spread8((unsigned)(b2 >> sh) & 0xFFu) << 2) | (spread8((unsigned)(b3 >> sh) & 0xFFu) << 3);
                     }
-                    holes[(size_t)r * a.hw + (col4 >> 3)] = word;
                 }
+                if (ok && (cx & 7) == 0) holes[(size_t)r * a.hw + (col4 >> 3)] = word;
             }
             if (!SCATTER || !do_scatter) continue;
-            const bool hit = (hitmask >> k) & 1u;
+            const bool hit = hitb[k];
             if (__ballot(hit) == 0ull) continue;   // neither of this wavefront's two rows can reach the height band
             unsigned c4 = 0u;
             if (hit) {
@@ -324,21 +325,31 @@ __device__ __forceinline__ void depth_ingest_body(const IngestArgs& a) {
                 unsigned skip = 0u;
                 if (filled) skip = (filled[(size_t)r * a.hw + (col4 >> 3)] >> ((col4 & 7) * 4)) & 0xFu;
                 if (p.scatter & 6)
-                    skip |= (d[k].x == 0.0f ? 1u : 0u) | (d[k].y == 0.0f ? 2u : 0u) | (d[k].z == 0.0f ? 4u : 0u) |
-                            (d[k].w == 0.0f ? 8u : 0u);
+                    skip |= holes ? zero4 : ((d[k].x == 0.0f ? 1u : 0u) | (d[k].y == 0.0f ? 2u : 0u) |
+                                             (d[k].z == 0.0f ? 4u : 0u) | (d[k].w == 0.0f ? 8u : 0u));
                 const float gy = band.t8 - band.t10 * (float)(r - a.H / 2) * band.inv_fy;
                 c4 = ((candidate_fast(band, gx[0], gy, d[k].x) ? 1u : 0u) | (candidate_fast(band, gx[1], gy, d[k].y) ? 2u : 0u) |
                       (candidate_fast(band, gx[2], gy, d[k].z) ? 4u : 0u) | (candidate_fast(band, gx[3], gy, d[k].w) ? 8u : 0u)) & ~skip;
             }
             // ---- append this row group's survivors to the wavefront's ring: texel c of lane L goes behind all texels
             // c' < c of every lane and the texels c of the lanes below L
-            const unsigned long long B0 = __ballot(c4 & 1u), B1 = __ballot(c4 & 2u), B2 = __ballot(c4 & 4u), B3 = __ballot(c4 & 8u);
-            const unsigned n0 = __popcll(B0), n1 = __popcll(B1), n2 = __popcll(B2), n3 = __popcll(B3);
-            const unsigned total = n0 + n1 + n2 + n3;
-            if (total == 0u) continue;
-            {
-                const unsigned tail = q_head + q_cnt;
-                const unsigned pos = ((unsigned)(col4 * 4)) | ((unsigned)r << 16);
+            const unsigned long long Bany = __ballot(c4 != 0u);
+            if (Bany == 0ull) continue;
+            const unsigned tail = q_head + q_cnt;
+            const unsigned pos = ((unsigned)(col4 * 4)) | ((unsigned)r << 16);
+            if (__ballot(c4 == 0xFu) == Bany) {
+                // the common shape of an in-band row: every lane that has a survivor has all four -- one ballot places them
+                const unsigned first = tail + 4u * __builtin_amdgcn_mbcnt_hi((unsigned)(Bany >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)Bany, 0u));
+                if (c4) {
+                    q[(first + 0u) & (WQ - 1)] = make_uint2(pos + 0u, __float_as_uint(d[k].x));
+                    q[(first + 1u) & (WQ - 1)] = make_uint2(pos + 1u, __float_as_uint(d[k].y));
+                    q[(first + 2u) & (WQ - 1)] = make_uint2(pos + 2u, __float_as_uint(d[k].z));
+                    q[(first + 3u) & (WQ - 1)] = make_uint2(pos + 3u, __float_as_uint(d[k].w));
+                }
+                q_cnt += 4u * (unsigned)__popcll(Bany);
+            } else {
+                const unsigned long long B0 = __ballot(c4 & 1u), B1 = __ballot(c4 & 2u), B2 = __ballot(c4 & 4u), B3 = __ballot(c4 & 8u);
+                const unsigned n0 = __popcll(B0), n1 = __popcll(B1), n2 = __popcll(B2), n3 = __popcll(B3);
                 const unsigned below0 = __builtin_amdgcn_mbcnt_hi((unsigned)(B0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)B0, 0u));
                 const unsigned below1 = __builtin_amdgcn_mbcnt_hi((unsigned)(B1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)B1, 0u));
                 const unsigned below2 = __builtin_amdgcn_mbcnt_hi((unsigned)(B2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)B2, 0u));
@@ -347,35 +358,21 @@ __device__ __forceinline__ void depth_ingest_body(const IngestArgs& a) {
                 if (c4 & 2u) q[(tail + n0 + below1) & (WQ - 1)] = make_uint2(pos + 1u, __float_as_uint(d[k].y));
                 if (c4 & 4u) q[(tail + n0 + n1 + below2) & (WQ - 1)] = make_uint2(pos + 2u, __float_as_uint(d[k].z));
                 if (c4 & 8u) q[(tail + n0 + n1 + n2 + below3) & (WQ - 1)] = make_uint2(pos + 3u, __float_as_uint(d[k].w));
-                q_cnt += total;
+                q_cnt += n0 + n1 + n2 + n3;
             }
-            // ---- full passes: 64 pending entries -> one per lane: placed here, or (two-pass form) moved to the observation's
-            // global candidate list as one coalesced 512-byte store behind ONE returning atomic per 64 entries
+            // ---- full passes: 64 pending entries -> one per lane
             while (q_cnt >= 64u) {
                 const uint2 e = q[(q_head + (unsigned)lane) & (WQ - 1)];
-                if (LIST) {
-                    unsigned base = 0u;
-                    if (lane == 0) base = atomicAdd(&a.cand_count[obs], 64u);
-                    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-                    a.cand[(size_t)obs * a.cand_cap + base + (unsigned)lane] = e;
-                } else {
-                    place_exact<false>(a, p, rfx, rfy, grid, obs, (int)(e.x & 0xFFFFu), (int)(e.x >> 16), __uint_as_float(e.y));
-                }
+                place_exact<false>(a, p, rfx, rfy, grid, obs, (int)(e.x & 0xFFFFu), (int)(e.x >> 16), __uint_as_float(e.y));
                 q_head += 64u;
                 q_cnt -= 64u;
             }
         }
     }
     if (SCATTER && do_scatter && q_cnt) {   // the wavefront's remainder (< 64 entries)
-        unsigned base = 0u;
-        if (LIST) {
-            if (lane == 0) base = atomicAdd(&a.cand_count[obs], q_cnt);
-            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-        }
         if ((unsigned)lane < q_cnt) {
             const uint2 e = q[(q_head + (unsigned)lane) & (WQ - 1)];
-            if (LIST) a.cand[(size_t)obs * a.cand_cap + base + (unsigned)lane] = e;
-            else place_exact<false>(a, p, rfx, rfy, grid, obs, (int)(e.x & 0xFFFFu), (int)(e.x >> 16), __uint_as_float(e.y));
+            place_exact<false>(a, p, rfx, rfy, grid, obs, (int)(e.x & 0xFFFFu), (int)(e.x >> 16), __uint_as_float(e.y));
         }
     }
     if (saw_zero) atomicOr(&a.status[2 * obs + 1], 1);
@@ -410,35 +407,6 @@ __global__ __launch_bounds__(CG * RL) __attribute__((amdgpu_waves_per_eu(6, 6)))
 void depth_ingest_scatter_np6_kernel(IngestArgs a) { depth_ingest_body<true, false>(a); }
 __global__ __launch_bounds__(CG * RL) __attribute__((amdgpu_waves_per_eu(6, 6)))
 void depth_ingest_scatter_pf6_kernel(IngestArgs a) { depth_ingest_body<true, true>(a); }
-// two-pass form, pass 1: stream + pre-test + compaction into the global candidate list (no f64, no plane access)
-__global__ __launch_bounds__(CG * RL) void depth_ingest_list_np_kernel(IngestArgs a) { depth_ingest_body<true, false, true>(a); }
-__global__ __launch_bounds__(CG * RL) void depth_ingest_list_pf_kernel(IngestArgs a) { depth_ingest_body<true, true, true>(a); }
-
-// two-pass form, pass 2: the exact placement of every listed candidate, one per lane -- dense f64 work on full wavefronts
-// over the whole chip, all plane reads of a sweep in flight.  grid = (G, n).  The last workgroup of an observation hands
-// the list counter back zeroed for the next depth pass.
-__global__ __launch_bounds__(256) void depth_place_kernel(IngestArgs a) {
-    const int obs = blockIdx.y, tid = threadIdx.x;
-    const vlfm_ingest_params p = a.prm[obs];
-    const unsigned n_c = a.cand_count[obs];
-    if (n_c) {
-        const ExactRecip rfx = exact_recip(p.fx), rfy = exact_recip(p.fy);
-        unsigned* grid = a.obstacle + (size_t)p.env * a.S * a.stride;
-        const uint2* list = a.cand + (size_t)obs * a.cand_cap;
-        for (unsigned i = blockIdx.x * blockDim.x + tid; i < n_c; i += gridDim.x * blockDim.x) {
-            const uint2 e = list[i];
-            place_exact<false>(a, p, rfx, rfy, grid, obs, (int)(e.x & 0xFFFFu), (int)(e.x >> 16), __uint_as_float(e.y));
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        __threadfence();
-        if (atomicAdd(&a.cand_done[obs], 1u) == gridDim.x - 1u) {
-            a.cand_count[obs] = 0u;
-            a.cand_done[obs] = 0u;
-        }
-    }
-}
 
 // The zero texels that fill_small_holes left alone (holes of area >= hole_area_thresh), placed from the bit planes: the
 // depth images are not read again.  One thread per 32-texel word of (hole & ~filled); frames without a zero texel
@@ -491,11 +459,6 @@ __global__ __launch_bounds__(256) void div_exact_check_kernel(const double* __re
 
 using namespace vlfm;
 
-extern "C" size_t vlfm_depth_candidates_bytes(int n, int height, int width) {
-    if (n <= 0 || height <= 0 || width <= 0) return 0;
-    return (((size_t)2 * n * 4 + 255) / 256) * 256 + (size_t)n * height * width * sizeof(uint2);
-}
-
 extern "C" int vlfm_selftest_div_exact(const double* d_numerators, int n, double divisor, int32_t* d_mismatches, void* stream) {
     if (!d_numerators || !d_mismatches || n < 0) return fail(VLFM_ERR_INVALID, "selftest_div_exact: bad argument");
     if (n == 0) return VLFM_OK;
@@ -528,12 +491,10 @@ extern "C" int vlfm_depth_ingest_batched(const float* d_depth, int n, int height
                                          const vlfm_ingest_params* d_params, uint32_t* d_colmax_keys, uint32_t* d_obstacle,
                                          int map_size, int pixels_per_meter, int32_t* d_status, uint32_t* d_hole_bits,
                                          const uint32_t* d_filled_bits, const vlfm_scatter_journal* journal,
-                                         void* d_candidates, size_t candidates_bytes, void* stream) {
+                                         void* stream) {
     if (n == 0) return VLFM_OK;
     if (!d_depth || !d_params || !d_status || n < 0 || height <= 0 || width <= 0)
         return fail(VLFM_ERR_INVALID, "depth_ingest_batched: bad argument");
-    if (d_candidates && candidates_bytes < vlfm_depth_candidates_bytes(n, height, width))
-        return fail(VLFM_ERR_CAPACITY, "depth_ingest_batched: candidate scratch too small");
     if (width % 4 != 0) return fail(VLFM_ERR_INVALID, "depth_ingest_batched: width must be a multiple of 4");
     if (width > 65535 || height > 65535) return fail(VLFM_ERR_INVALID, "depth_ingest_batched: image sides must fit 16 bits");
     if (!d_colmax_keys && !d_obstacle && !d_hole_bits) return VLFM_OK;
@@ -549,13 +510,6 @@ extern "C" int vlfm_depth_ingest_batched(const float* d_depth, int n, int height
     a.H = height; a.W = width; a.W4 = width / 4; a.S = map_size; a.stride = (map_size + 31) / 32;
     a.ppm = (double)pixels_per_meter;
     a.cols_per_block = CG; a.ry = RL;
-    a.cand = nullptr; a.cand_count = nullptr; a.cand_done = nullptr; a.cand_cap = 0u;
-    if (d_candidates && d_obstacle) {   // layout: [n] counters | [n] done flags | pad to 256 B | [n][H*W] entries
-        a.cand_count = reinterpret_cast<unsigned*>(d_candidates);
-        a.cand_done = a.cand_count + n;
-        a.cand = reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(d_candidates) + (((size_t)2 * n * 4 + 255) / 256) * 256);
-        a.cand_cap = (unsigned)height * (unsigned)width;
-    }
     const int gx = (a.W4 + CG - 1) / CG;
     // row bands: aim for ~2048 workgroups (8 per CU) so that enough 16-byte loads are in flight to cover HBM latency,
     // but never fewer than RL rows per band
@@ -573,22 +527,6 @@ extern "C" int vlfm_depth_ingest_batched(const float* d_depth, int n, int height
             const char* e = getenv("VLFM_INGEST_VARIANT");
             return e ? atoi(e) : kIngestDefaultVariant;
         }();
-        if (a.cand) {
-            // two passes: the streaming pass only lists its candidates; the placement is a kernel of its own
-            if (variant == 1 || variant == 2 || variant == 4)
-                VLFM_KLAUNCH(depth_ingest_list_np_kernel, dim3(gx, gy, n), dim3(CG * RL), 0, s, a);
-            else
-                VLFM_KLAUNCH(depth_ingest_list_pf_kernel, dim3(gx, gy, n), dim3(CG * RL), 0, s, a);
-            int rc1 = check_launch("depth_ingest_list_kernel");
-            if (rc1 != VLFM_OK) return rc1;
-            int G = (4096 + n - 1) / n;
-            const int g_max = (int)((a.cand_cap + 255u) / 256u);
-            if (G > g_max) G = g_max;
-            if (G < 1) G = 1;
-            VLFM_TIMED("depth_place_kernel", s);
-            VLFM_KLAUNCH(depth_place_kernel, dim3(G, n), dim3(256), 0, s, a);
-            return check_launch("depth_place_kernel");
-        }
         switch (variant) {
             case 1: VLFM_KLAUNCH(depth_ingest_scatter_np4_kernel, dim3(gx, gy, n), dim3(CG * RL), 0, s, a); break;
             case 2: VLFM_KLAUNCH(depth_ingest_scatter_np6_kernel, dim3(gx, gy, n), dim3(CG * RL), 0, s, a); break;

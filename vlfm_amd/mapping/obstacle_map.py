@@ -71,8 +71,6 @@ class ObstacleMapBatch:
         import os
 
         self.full_planes = os.environ.get("VLFM_FULL_PLANES", "0") == "1"
-        self.two_pass_ingest = os.environ.get("VLFM_INGEST_TWO_PASS", "0") == "1"
-        self._cand = None
         # read-back path of the step: fixed-size staging + pinned host buffers, so a step never allocates and never
         # hands the runtime a pageable destination (which it would have to pin on the fly)
         self._d_fr_stage = torch.zeros((n_envs, self.READ_FRONTIERS, 2), dtype=torch.float64, device=self.device)
@@ -192,14 +190,6 @@ class ObstacleMapBatch:
             # the speculative pass journals the bits it sets per observation; two observations of one slot in the same
             # launch would hide each other's first-time bits (the reference's multi-camera loop is sequential anyway)
             assert len(np.unique(prm["env"])) == n, "one observation per environment slot and call"
-        cand_ptr, cand_bytes = None, 0
-        if self.two_pass_ingest and update_obstacles:
-            # two-pass depth scatter (csrc/depth_ingest.hip): the streaming pass lists its candidates, depth_place_kernel
-            # places them.  Worst case every texel is a candidate: n x H x W x 8 B (630 MB at 256 x 640x480)
-            need = L.vlfm_depth_candidates_bytes(max(n, self.n_envs), H, W)
-            if self._cand is None or self._cand.numel() < need:
-                self._cand = torch.zeros(need, dtype=torch.uint8, device=self.device)
-            cand_ptr, cand_bytes = self._cand.data_ptr(), self._cand.numel()
         with torch.cuda.device(self.device):
             d_prm = self._ring_ingest.upload(prm)
             if not fill:
@@ -209,8 +199,7 @@ class ObstacleMapBatch:
                                                        keys.data_ptr() if keys is not None else None,
                                                        self.obstacle_bits.data_ptr() if update_obstacles else None,
                                                        self.size, self.pixels_per_meter, self.status.data_ptr(),
-                                                       None, None, None, cand_ptr if update_obstacles else None, cand_bytes,
-                                                       _stream_ptr()), "depth_ingest")
+                                                       None, None, None, _stream_ptr()), "depth_ingest")
             else:
                 # fill_small_holes (img_utils.py:361-390) sits between reading the depth and scattering it, but it only
                 # decides the fate of texels inside zero regions: the single streaming pass SPECULATIVELY places every
@@ -234,8 +223,7 @@ class ObstacleMapBatch:
                                                        keys.data_ptr() if keys is not None else None,
                                                        self.obstacle_bits.data_ptr(), self.size,
                                                        self.pixels_per_meter, self.status.data_ptr(),
-                                                       holes.data_ptr(), None, jref, cand_ptr, cand_bytes, _stream_ptr()),
-                           "depth_ingest")
+                                                       holes.data_ptr(), None, jref, _stream_ptr()), "depth_ingest")
                 _lib.check(L.vlfm_fill_small_holes_batched(holes.data_ptr(), self.status.data_ptr(), n, H, W,
                                                            float(self._hole_area_thresh), scratch.data_ptr(),
                                                            scratch.numel(), self.HOLE_CAP_PTS, self.HOLE_CAP_CONTOURS,

@@ -298,7 +298,7 @@ class ValueMapBatch:
             d_prm = self._rings(n).upload(prm)
             _lib.check(_lib.lib().vlfm_depth_ingest_batched(depth.data_ptr(), n, H, W, d_prm.data_ptr(),
                                                            colmax.data_ptr(), None, self.size, self.pixels_per_meter,
-                                                           status.data_ptr(), None, None, None, None, 0, _stream_ptr()),
+                                                           status.data_ptr(), None, None, None, _stream_ptr()),
                        "depth_ingest")
         return colmax[:n]
 
