@@ -1,0 +1,23 @@
+#!/bin/bash
+# Round-3 evidence session: full GPU tests, default bench, rocprofv3 kernel stats (headline + config 5), PMC traffic of the
+# map kernels, SQ counters of the depth pass.  Everything lands under gpurun_out/s_r3/; the summaries are copied to profiles/.
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
+export TMPDIR=/tmp
+O=gpurun_out/s_r3; mkdir -p $O
+timeout 1500 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log; tail -4 $O/pytest_gpu.log
+timeout 1500 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"; tail -c 400 $O/bench_default.json
+cd /tmp
+timeout 400 rocprofv3 --kernel-trace --stats -d $R/$O/prof_default -o p -- python $R/bench.py --no-small --no-cpu-baseline --steps 10 > $R/$O/prof_default.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/$O/prof_cfg5 -o p -- python $R/bench.py --no-blip2 --envs 16 --height 720 --width 1280 --sync-explored --no-small --no-cpu-baseline > $R/$O/prof_cfg5.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/$O/prof_maps -o p -- python $R/bench.py --no-blip2 --no-small --no-cpu-baseline --steps 20 > $R/$O/prof_maps.log 2>&1
+cd $R
+python tools/rocprof_summary.py $O/prof_default/p_results.db $O/r03_bench_e256_kernel_stats.csv > $O/summary_default.log 2>&1
+python tools/rocprof_summary.py $O/prof_cfg5/p_results.db $O/r03_cfg5_maps_kernel_stats.csv > $O/summary_cfg5.log 2>&1
+python tools/rocprof_summary.py $O/prof_maps/p_results.db $O/r03_maps_e256_kernel_stats.csv > $O/summary_maps.log 2>&1
+VLFM_COMMIT=${VLFM_COMMIT:-unknown} bash tools/pmc_traffic.sh 256 640 480 > $O/pmc_e256.log 2>&1
+VLFM_COMMIT=${VLFM_COMMIT:-unknown} bash tools/pmc_traffic.sh 16 1280 720 sync > $O/pmc_cfg5.log 2>&1
+cp profiles/pmc_traffic.json $O/pmc_traffic.json
+bash tools/pmc_sq.sh ingest depth_ingest -- python $R/tools/ingest_probe.py 4 > /dev/null 2>&1; cp gpurun_out/pmc_sq_ingest.txt $O/r03_ingest_sq_pmc.txt
+cp gpurun_out/host_busy.json $O/host_busy.json 2>/dev/null
+find gpurun_out -name "*.db" -size +20M -delete
+ls $O

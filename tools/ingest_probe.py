@@ -1,7 +1,7 @@
-"""Times the variants of the combined depth pass (csrc/depth_ingest.hip: VLFM_INGEST_VARIANT) on the headline geometry and
-checks that they set the same obstacle bits.  One process per variant (the variant is read once per process).
-    python tools/ingest_probe.py            -> runs every variant in a subprocess, prints a table
-    python tools/ingest_probe.py <variant>  -> one variant: prints 'variant us checksum'"""
+"""Times the combined depth pass (csrc/depth_ingest.hip: column maxima + obstacle scatter) and the streaming-only pass (column
+maxima alone: the floor) on mid-episode frames of the rooms world, and prints a checksum of the obstacle planes.
+    python tools/ingest_probe.py                     -> 256 x 480x640, 16 x 720x1280, 8 x 480x640 (one process each)
+    python tools/ingest_probe.py <tag> [E H W]       -> one geometry"""
 import os
 import subprocess
 import sys
@@ -51,9 +51,5 @@ if __name__ == "__main__":
     if len(sys.argv) > 1:
         one(int(sys.argv[1]), *(int(a) for a in sys.argv[2:]))
     else:
-        for v in range(5):
-            env = dict(os.environ, VLFM_INGEST_VARIANT=str(v))
-            subprocess.run([sys.executable, os.path.abspath(__file__), str(v)], env=env, check=False)
-        for v in (0, 1):   # config-5 geometry: 16 x 1280x720
-            env = dict(os.environ, VLFM_INGEST_VARIANT=str(v))
-            subprocess.run([sys.executable, os.path.abspath(__file__), str(v), "16", "720", "1280"], env=env, check=False)
+        for shape in (["256", "480", "640"], ["16", "720", "1280"], ["8", "480", "640"]):
+            subprocess.run([sys.executable, os.path.abspath(__file__), "0"] + shape, check=False)

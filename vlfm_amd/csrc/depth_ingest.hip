@@ -190,8 +190,7 @@ __device__ inline void place_exact(const IngestArgs& a, const vlfm_ingest_params
 }
 
 // Work decomposition: a workgroup owns CG float4 column groups (CG*4 image columns, CG*16 contiguous bytes per row) and
-// a band of rows; lane (cx, ry) walks rows ry, ry+RL, ... of the band with UNROLL 16-byte loads in flight (optionally with
-// the loads of the NEXT iteration issued before the current one is processed).  With one band per image (the large-batch
+// a band of rows; lane (cx, ry) walks rows ry, ry+RL, ... of the band with UNROLL 16-byte loads in flight.  With one band per image (the large-batch
 // case) every column maximum is produced by exactly one workgroup -- no atomic contention; small batches split the rows
 // into bands to fill the chip and merge through atomicMax on the keys.
 //
@@ -211,9 +210,8 @@ constexpr int CG = 32;   // float4 column groups per workgroup
 constexpr int RL = 16;   // row lanes per workgroup  -> 512 threads, a wavefront covers 2 rows x 512 B
 constexpr int INGEST_UNROLL = 4;
 constexpr int WQ = 512;      // ring entries per wavefront (power of two >= 63 + 256: a row group adds at most 256)
-constexpr int kIngestDefaultVariant = 0;   // 0 pf4 | 1 np4 | 2 np6 | 3 pf6 | 4 no register cap (see the stamped kernels)
 
-template <bool SCATTER, bool PREFETCH>
+template <bool SCATTER>
 __device__ __forceinline__ void depth_ingest_body(const IngestArgs& a) {
     __shared__ float4 part[RL][CG];
     __shared__ uint2 ring[SCATTER ? CG * RL / 64 : 1][SCATTER ? WQ : 1];
@@ -274,16 +272,14 @@ __device__ __forceinline__ void depth_ingest_body(const IngestArgs& a) {
             nxt_hit[k] = hit;
         }
     };
-    if (PREFETCH && band_id < n_groups) issue(band_id);
     // every lane of the workgroup runs the same trip count (predicated), so the cross-lane packing of hole bits and of the
     // candidate ring is always executed convergently
     for (int g0 = band_id; g0 < n_groups; g0 += UNROLL * bands) {
-        if (!PREFETCH) issue(g0);
+        issue(g0);
         float4 d[UNROLL];
         bool okb[UNROLL], hitb[UNROLL];
 #pragma unroll
         for (int k = 0; k < UNROLL; k++) { d[k] = nxt[k]; okb[k] = nxt_ok[k]; hitb[k] = nxt_hit[k]; }
-        if (PREFETCH && g0 + UNROLL * bands < n_groups) issue(g0 + UNROLL * bands);
 #pragma unroll
         for (int k = 0; k < UNROLL; k++) {
             const int r = (g0 + k * bands) * RL + ry;
@@ -393,20 +389,11 @@ __device__ __forceinline__ void depth_ingest_body(const IngestArgs& a) {
     }
 }
 
-// The streaming pass without obstacles (ValueMapBatch.column_max) and the combined pass in its variants: software
-// prefetch of the next iteration's rows on / off, and the register budget (waves per SIMD) the compiler is held to --
-// 512-thread workgroups occupy 2 waves per SIMD each, so 4 = two workgroups per CU, 6 = three.  tools/ingest_probe.py times
-// them; vlfm_depth_ingest_batched picks VLFM_INGEST_VARIANT (default: kIngestDefaultVariant).
+// Register budget / prefetch variants measured at 256 x 640x480 (tools/ingest_probe.py, round 3): the compiler's own
+// allocation without software prefetch (79 VGPRs, 3 workgroups per CU) 95 us; prefetch of the next iteration's rows held to
+// 4 waves per SIMD 96 us, to 6 waves per SIMD (spills) 130 us; no prefetch held to 4 waves 107 us.  One form is kept.
 template <bool SCATTER>
-__global__ __launch_bounds__(CG * RL) void depth_ingest_kernel(IngestArgs a) { depth_ingest_body<SCATTER, false>(a); }
-__global__ __launch_bounds__(CG * RL) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void depth_ingest_scatter_pf4_kernel(IngestArgs a) { depth_ingest_body<true, true>(a); }
-__global__ __launch_bounds__(CG * RL) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void depth_ingest_scatter_np4_kernel(IngestArgs a) { depth_ingest_body<true, false>(a); }
-__global__ __launch_bounds__(CG * RL) __attribute__((amdgpu_waves_per_eu(6, 6)))
-void depth_ingest_scatter_np6_kernel(IngestArgs a) { depth_ingest_body<true, false>(a); }
-__global__ __launch_bounds__(CG * RL) __attribute__((amdgpu_waves_per_eu(6, 6)))
-void depth_ingest_scatter_pf6_kernel(IngestArgs a) { depth_ingest_body<true, true>(a); }
+__global__ __launch_bounds__(CG * RL) void depth_ingest_kernel(IngestArgs a) { depth_ingest_body<SCATTER>(a); }
 
 // The zero texels that fill_small_holes left alone (holes of area >= hole_area_thresh), placed from the bit planes: the
 // depth images are not read again.  One thread per 32-texel word of (hole & ~filled); frames without a zero texel
@@ -523,17 +510,7 @@ extern "C" int vlfm_depth_ingest_batched(const float* d_depth, int n, int height
         // profile name: the streaming pass (column maxima [+ hole bits]) is "depth_ingest_kernel"; a pass that ALSO or
         // ONLY scatters obstacle points is reported separately
         VLFM_TIMED(d_colmax_keys ? "depth_ingest_scatter_kernel" : "depth_scatter_kernel", s);
-        static const int variant = [] {
-            const char* e = getenv("VLFM_INGEST_VARIANT");
-            return e ? atoi(e) : kIngestDefaultVariant;
-        }();
-        switch (variant) {
-            case 1: VLFM_KLAUNCH(depth_ingest_scatter_np4_kernel, dim3(gx, gy, n), dim3(CG * RL), 0, s, a); break;
-            case 2: VLFM_KLAUNCH(depth_ingest_scatter_np6_kernel, dim3(gx, gy, n), dim3(CG * RL), 0, s, a); break;
-            case 3: VLFM_KLAUNCH(depth_ingest_scatter_pf6_kernel, dim3(gx, gy, n), dim3(CG * RL), 0, s, a); break;
-            case 4: VLFM_KLAUNCH(depth_ingest_kernel<true>, dim3(gx, gy, n), dim3(CG * RL), 0, s, a); break;  // compiler's choice
-            default: VLFM_KLAUNCH(depth_ingest_scatter_pf4_kernel, dim3(gx, gy, n), dim3(CG * RL), 0, s, a); break;
-        }
+        VLFM_KLAUNCH(depth_ingest_kernel<true>, dim3(gx, gy, n), dim3(CG * RL), 0, s, a);
     } else {
         VLFM_TIMED("depth_ingest_kernel", s);
         VLFM_KLAUNCH(depth_ingest_kernel<false>, dim3(gx, gy, n), dim3(CG * RL), 0, s, a);
