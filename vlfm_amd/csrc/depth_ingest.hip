@@ -136,9 +136,6 @@ __device__ inline double div_exact(double a, const ExactRecip& r) {
 }
 
 template <bool HOLE_PASS>
-__device__ inline void commit_cell(const IngestArgs& a, unsigned* grid, int obs, bool inside, int row, int col);
-
-template <bool HOLE_PASS>
 __device__ inline void place_exact(const IngestArgs& a, const vlfm_ingest_params& p, const ExactRecip& rfx,
                                    const ExactRecip& rfy, unsigned* grid, int obs, int u, int v, float d) {
     const float z = __fadd_rn(__fmul_rn(d, p.depth_scale), p.depth_offset);  // obstacle_map.py:92 (f32)
@@ -158,18 +155,11 @@ __device__ inline void place_exact(const IngestArgs& a, const vlfm_ingest_params
     const double half = (double)(a.S / 2);
     const double colf = (double)a.S - __dadd_rn(rint(__dmul_rn(Y, a.ppm)), half);
     const double rowf = __dadd_rn(rint(__dmul_rn(X, a.ppm)), half);
-    // The index test runs on the (integer-valued) doubles; only values inside [-S, S) are converted (one instruction instead
-    // of the multi-instruction f64 -> i64 sequence).
+    // NumPy fancy-index semantics (obstacle_map.py:101): [-S, -1] wraps, anything else outside raises IndexError.  The test
+    // runs on the (integer-valued) doubles; only values inside [-S, S) are converted (one instruction instead of the
+    // multi-instruction f64 -> i64 sequence).
     const double Sd = (double)a.S;
-    const bool inside = rowf < Sd && rowf >= -Sd && colf < Sd && colf >= -Sd;
-    commit_cell<HOLE_PASS>(a, grid, obs, inside, inside ? (int)rowf : 0, inside ? (int)colf : 0);
-}
-
-// Set the obstacle bit of cell (row, col) with NumPy's fancy-index semantics (obstacle_map.py:101): [-S, -1] wraps, anything
-// else outside raises IndexError (`inside` = false).
-template <bool HOLE_PASS>
-__device__ inline void commit_cell(const IngestArgs& a, unsigned* grid, int obs, bool inside, int row, int col) {
-    if (!inside) {
+    if (!(rowf < Sd && rowf >= -Sd && colf < Sd && colf >= -Sd)) {
         // The speculative pass (fill_small_holes not evaluated yet) cannot know whether the reference would have seen this
         // texel at all: an "island" texel inside a small hole becomes 1.0 and is dropped (img_utils.py:385-388) without
         // ever reaching the scatter.  It only NOTES the hit (status word 1, bit 1); fill_small_holes_kernel promotes the
@@ -179,6 +169,7 @@ __device__ inline void commit_cell(const IngestArgs& a, unsigned* grid, int obs,
         else a.status[2 * obs] = VLFM_ERR_INDEX;
         return;
     }
+    int row = (int)rowf, col = (int)colf;
     if (row < 0) row += a.S;
     if (col < 0) col += a.S;
     // A plain (possibly stale) read that already shows the bit lets us skip the device-scope atomic: in steady state almost
@@ -196,57 +187,6 @@ __device__ inline void commit_cell(const IngestArgs& a, unsigned* grid, int obs,
             if (k < a.journal_cap) a.journal[(size_t)obs * a.journal_cap + k] = (unsigned)(row * a.S + col);
         }
     }
-}
-
-// ---- f32 tier of the placement (round 3): a FILTERED exact computation.
-// The reference's decision for a texel is (a) is Z inside [min_height, max_height], (b) which integers are rint(X ppm) and
-// rint(Y ppm).  Both are evaluated here in f32 together with a rigorous bound on the distance between the f32 value and the
-// value the reference's f64 chain produces: with M = tn (|z| + |x_cam| + |y_cam|) + t3n (tn / t3n = the largest |rotation| /
-// |translation| entry of the transform) every one of the <= 8 f32 roundings on the way to X, Y or Z moves the result by at
-// most 2^-24 M, the f64 chain's own error is ten orders smaller, so |f32 - reference| <= 16 * 2^-24 * M =: B (twice the sum).
-// The texel is SURE when Z is farther than B (+ the f32 rounding of the band edges) from both band edges and both cell
-// coordinates are farther than B ppm + 2^-22 |w| from the nearest rounding boundary (half-integers, incl. exact ties): then
-// the f32 decision IS the reference's and the cell is committed from the f32 values.  Everything else (~0.1 % of the
-// candidates) is DOUBTFUL and goes to the exact f64 path.  15 f32 operations decide what 47 f64 operations decided before.
-struct ShadowTf {
-    float t[12];
-    float tn, t3n, lo_in, hi_in, lo_out, hi_out;   // band edges moved inwards / outwards by their own f32 rounding
-    float inv_fx, inv_fy, ppm, scale, offset;
-};
-__device__ inline ShadowTf make_shadow(const vlfm_ingest_params& p, double ppm) {
-    ShadowTf s;
-    float tn = 0.f, t3n = 0.f;
-#pragma unroll
-    for (int i = 0; i < 12; i++) {
-        s.t[i] = (float)p.tf[i];
-        if ((i & 3) == 3) t3n = fmaxf(t3n, fabsf(s.t[i])); else tn = fmaxf(tn, fabsf(s.t[i]));
-    }
-    // (float)tf rounds every entry by <= 2^-24 relative: covered by the factor 16 (8 roundings counted, 8 spare)
-    s.tn = tn; s.t3n = t3n;
-    const float lo = (float)p.min_height, hi = (float)p.max_height;
-    const float el = 1.2e-7f * fabsf(lo) + 1e-30f, eh = 1.2e-7f * fabsf(hi) + 1e-30f;   // |(float)h - h| <= 2^-24 |h|
-    s.lo_in = lo + el; s.hi_in = hi - eh; s.lo_out = lo - el; s.hi_out = hi + eh;
-    s.inv_fx = (float)(1.0 / p.fx); s.inv_fy = (float)(1.0 / p.fy); s.ppm = (float)ppm;
-    s.scale = p.depth_scale; s.offset = p.depth_offset;
-    return s;
-}
-// 0 = surely outside the band (nothing to do), 1 = sure cell (ri, ci) = (rint(X ppm), rint(Y ppm)), 2 = doubtful
-__device__ inline int shadow_cell(const ShadowTf& s, int W, int H, int u, int v, float d, int& ri, int& ci) {
-    const float z = __fadd_rn(__fmul_rn(d, s.scale), s.offset);
-    const float xf = (float)(u - W / 2) * z * s.inv_fx, yf = (float)(v - H / 2) * z * s.inv_fy;
-    const float M = __builtin_fmaf(s.tn, fabsf(z) + fabsf(xf) + fabsf(yf), s.t3n);
-    const float B = 9.6e-7f * M;                                   // 16 * 2^-24 = 9.54e-7
-    const float Z = __builtin_fmaf(s.t[8], z, __builtin_fmaf(-s.t[9], xf, __builtin_fmaf(-s.t[10], yf, s.t[11])));
-    if (Z < s.lo_out - B || Z > s.hi_out + B) return 0;
-    if (!(Z >= s.lo_in + B && Z <= s.hi_in - B)) return 2;         // (NaN lands here)
-    const float X = __builtin_fmaf(s.t[0], z, __builtin_fmaf(-s.t[1], xf, __builtin_fmaf(-s.t[2], yf, s.t[3])));
-    const float Y = __builtin_fmaf(s.t[4], z, __builtin_fmaf(-s.t[5], xf, __builtin_fmaf(-s.t[6], yf, s.t[7])));
-    const float wx = X * s.ppm, wy = Y * s.ppm;
-    const float rx = rintf(wx), ry = rintf(wy);
-    const float slack = B * s.ppm + 2.4e-7f * fmaxf(fabsf(wx), fabsf(wy));   // + the products' own rounding (2^-22 |w|)
-    if (!(fabsf(wx - rx) < 0.5f - slack && fabsf(wy - ry) < 0.5f - slack) || !(fabsf(wx) < 1e6f && fabsf(wy) < 1e6f)) return 2;
-    ri = (int)rx; ci = (int)ry;
-    return 1;
 }
 
 // Work decomposition: a workgroup owns CG float4 column groups (CG*4 image columns, CG*16 contiguous bytes per row) and
@@ -270,16 +210,12 @@ constexpr int CG = 32;   // float4 column groups per workgroup
 constexpr int RL = 16;   // row lanes per workgroup  -> 512 threads, a wavefront covers 2 rows x 512 B
 constexpr int INGEST_UNROLL = 4;
 constexpr int WQ = 512;      // ring entries per wavefront (power of two >= 63 + 256: a row group adds at most 256)
-constexpr int DCAP = 256;    // doubtful candidates per workgroup kept for the exact f64 pass at the end (2 KB of LDS)
-constexpr int ROW_WORDS = 128;   // row-hit table: 8192 image rows (taller images evaluate row_may_hit per lane)
 
 template <bool SCATTER>
 __device__ __forceinline__ void depth_ingest_body(const IngestArgs& a) {
     __shared__ float4 part[RL][CG];
     __shared__ uint2 ring[SCATTER ? CG * RL / 64 : 1][SCATTER ? WQ : 1];
-    __shared__ unsigned long long row_hits[SCATTER ? ROW_WORDS : 1];   // bit v: image row v can reach the height band
-    __shared__ uint2 doubt[SCATTER ? DCAP : 1];                   // candidates the f32 tier could not decide
-    __shared__ unsigned doubt_n;
+    __shared__ unsigned long long row_hits[SCATTER ? 1024 : 1];   // bit v: image row v can reach the height band (H <= 65535)
     constexpr int UNROLL = INGEST_UNROLL;
     const int obs = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -309,38 +245,16 @@ __device__ __forceinline__ void depth_ingest_body(const IngestArgs& a) {
     float gx[4] = {0.f, 0.f, 0.f, 0.f};
     if (SCATTER && do_scatter) {
         // row_may_hit once per row and workgroup (it was ~25 instructions per lane and row group inside the streaming loop)
-        for (int v0 = 0; v0 < a.H && v0 < ROW_WORDS * 64; v0 += CG * RL) {
+        for (int v0 = 0; v0 < a.H; v0 += CG * RL) {
             const int v = v0 + tid;
             const unsigned long long hitmask = __ballot(v < a.H && row_may_hit(band, v, a.H));
-            if (lane == 0 && v < ROW_WORDS * 64) row_hits[v >> 6] = hitmask;
+            if (lane == 0) row_hits[(v0 + tid) >> 6] = hitmask;
         }
         rfx = exact_recip(p.fx); rfy = exact_recip(p.fy);
 #pragma unroll
         for (int c = 0; c < 4; c++) gx[c] = -band.t9 * (float)(col4 * 4 + c - a.W / 2) * band.inv_fx;
-        if (tid == 0) doubt_n = 0u;
         __syncthreads();
     }
-    ShadowTf sh = make_shadow(p, a.ppm);
-    {   // wave-uniform values: keep them in scalar registers
-        int* w = reinterpret_cast<int*>(&sh);
-#pragma unroll
-        for (int i = 0; i < (int)(sizeof(ShadowTf) / 4); i++) w[i] = __builtin_amdgcn_readfirstlane(w[i]);
-    }
-    // one ring entry: the f32 tier decides (see shadow_cell); what it cannot decide waits for the exact pass at the end
-    auto place_entry = [&](const uint2 e) {
-        const int u = (int)(e.x & 0xFFFFu), v = (int)(e.x >> 16);
-        int ri = 0, ci = 0;
-        const int cls = shadow_cell(sh, a.W, a.H, u, v, __uint_as_float(e.y), ri, ci);
-        if (cls == 1) {
-            const int row = ri + a.S / 2, col = a.S - (ci + a.S / 2);           // base_map.py:44-46
-            const bool inside = row < a.S && row >= -a.S && col < a.S && col >= -a.S;
-            commit_cell<false>(a, grid, obs, inside, row, col);
-        } else if (cls == 2) {
-            const unsigned slot = atomicAdd(&doubt_n, 1u);
-            if (slot < (unsigned)DCAP) doubt[slot] = e;
-            else place_exact<false>(a, p, rfx, rfy, grid, obs, u, v, __uint_as_float(e.y));   // (list full: decide now)
-        }
-    };
 
     // one iteration's loads: rows (g0 + k * bands) * RL + ry, k < UNROLL.  Rows that cannot reach the height band are not
     // even loaded by a scatter-only pass; a combined pass loads them (column maximum, hole bits) but never tests them.
@@ -351,8 +265,7 @@ __device__ __forceinline__ void depth_ingest_body(const IngestArgs& a) {
         for (int k = 0; k < UNROLL; k++) {
             const int r = (g0 + k * bands) * RL + ry;
             bool want = live && r < a.H;
-            const bool hit = SCATTER && do_scatter && want &&
-                             (r < ROW_WORDS * 64 ? (bool)((row_hits[r >> 6] >> (r & 63)) & 1ull) : row_may_hit(band, r, a.H));
+            const bool hit = SCATTER && do_scatter && want && ((row_hits[r >> 6] >> (r & 63)) & 1ull);
             if (SCATTER && scatter_only) want = hit;
             nxt[k] = want ? reinterpret_cast<const float4*>(img + (size_t)r * a.W)[col4] : make_float4(ninf, ninf, ninf, ninf);
             nxt_ok[k] = want;
@@ -445,19 +358,16 @@ __device__ __forceinline__ void depth_ingest_body(const IngestArgs& a) {
             }
             // ---- full passes: 64 pending entries -> one per lane
             while (q_cnt >= 64u) {
-                place_entry(q[(q_head + (unsigned)lane) & (WQ - 1)]);
+                const uint2 e = q[(q_head + (unsigned)lane) & (WQ - 1)];
+                place_exact<false>(a, p, rfx, rfy, grid, obs, (int)(e.x & 0xFFFFu), (int)(e.x >> 16), __uint_as_float(e.y));
                 q_head += 64u;
                 q_cnt -= 64u;
             }
         }
     }
-    if (SCATTER && do_scatter) {
-        if ((unsigned)lane < q_cnt) place_entry(q[(q_head + (unsigned)lane) & (WQ - 1)]);   // the wavefront's remainder (< 64)
-        __syncthreads();
-        // the exact pass over what the f32 tier left undecided (a handful of entries per workgroup)
-        const unsigned nd = min(doubt_n, (unsigned)DCAP);
-        for (unsigned i = tid; i < nd; i += CG * RL) {
-            const uint2 e = doubt[i];
+    if (SCATTER && do_scatter && q_cnt) {   // the wavefront's remainder (< 64 entries)
+        if ((unsigned)lane < q_cnt) {
+            const uint2 e = q[(q_head + (unsigned)lane) & (WQ - 1)];
             place_exact<false>(a, p, rfx, rfy, grid, obs, (int)(e.x & 0xFFFFu), (int)(e.x >> 16), __uint_as_float(e.y));
         }
     }
@@ -479,13 +389,23 @@ __device__ __forceinline__ void depth_ingest_body(const IngestArgs& a) {
     }
 }
 
+// Also measured and removed (round 3, tools/ingest_probe.py, 256 x 640x480, all bit-identical planes):
+//  * an f32 tier in front of the exact placement -- X, Y, Z in f32 with a rigorous bound B = 16 * 2^-24 * M on their distance
+//    from the reference's f64 values; a texel whose Z is farther than B from both band edges and whose cell coordinates are
+//    farther than B ppm from a rounding boundary is committed from the f32 values, the other ~0.1 % go to an exact pass at the
+//    end of the workgroup.  15 f32 operations instead of 47 f64 ones per candidate, and SLOWER: 114-121 us against 95 us.  By
+//    then the kernel is no longer bound by its arithmetic (SQ counters: VALU busy 54 % of the time, waves parked on
+//    s_waitcnt 67 % of their cycles); the tier's 20 uniform floats cost registers (99 instead of 79: two workgroups per CU
+//    instead of three) and that occupancy is what the streaming half lives on;
+//  * a global candidate list + a second placement launch (the two-pass form): 341 + 129 us -- one returning atomic per 64
+//    entries on ONE counter per image serialises at ~260 ns each, and 4096 workgroups reading the same few hundred plane words
+//    at once are slower than the same reads spread over the streaming pass;
+//  * one queue per workgroup drained by all 512 lanes between two barriers: 185-213 us (every round stops all eight wavefronts).
 // Register budget / prefetch variants measured at 256 x 640x480 (tools/ingest_probe.py, round 3): the compiler's own
 // allocation without software prefetch (79 VGPRs, 3 workgroups per CU) 95 us; prefetch of the next iteration's rows held to
 // 4 waves per SIMD 96 us, to 6 waves per SIMD (spills) 130 us; no prefetch held to 4 waves 107 us.  One form is kept.
 template <bool SCATTER>
 __global__ __launch_bounds__(CG * RL) void depth_ingest_kernel(IngestArgs a) { depth_ingest_body<SCATTER>(a); }
-__global__ __launch_bounds__(CG * RL) __attribute__((amdgpu_waves_per_eu(6, 6)))
-void depth_ingest_scatter_w6_kernel(IngestArgs a) { depth_ingest_body<true>(a); }   // A/B: 80 registers, 3 workgroups per CU
 
 // The zero texels that fill_small_holes left alone (holes of area >= hole_area_thresh), placed from the bit planes: the
 // depth images are not read again.  One thread per 32-texel word of (hole & ~filled); frames without a zero texel
@@ -602,9 +522,7 @@ extern "C" int vlfm_depth_ingest_batched(const float* d_depth, int n, int height
         // profile name: the streaming pass (column maxima [+ hole bits]) is "depth_ingest_kernel"; a pass that ALSO or
         // ONLY scatters obstacle points is reported separately
         VLFM_TIMED(d_colmax_keys ? "depth_ingest_scatter_kernel" : "depth_scatter_kernel", s);
-        static const bool w6 = getenv("VLFM_INGEST_W6") && atoi(getenv("VLFM_INGEST_W6")) != 0;
-        if (w6) VLFM_KLAUNCH(depth_ingest_scatter_w6_kernel, dim3(gx, gy, n), dim3(CG * RL), 0, s, a);
-        else VLFM_KLAUNCH(depth_ingest_kernel<true>, dim3(gx, gy, n), dim3(CG * RL), 0, s, a);
+        VLFM_KLAUNCH(depth_ingest_kernel<true>, dim3(gx, gy, n), dim3(CG * RL), 0, s, a);
     } else {
         VLFM_TIMED("depth_ingest_kernel", s);
         VLFM_KLAUNCH(depth_ingest_kernel<false>, dim3(gx, gy, n), dim3(CG * RL), 0, s, a);
