@@ -434,22 +434,26 @@ size_t vlfm_obstacle_scratch_bytes(int n_envs, int map_size, int cap_pts, int ca
  *               (S, -1, S, -1)
  *   d_frontiers [n_envs][cap_frontiers][2] f64 pixel coordinates (x, y) == ObstacleMap._frontiers_px
  *   d_counts    [n_envs][4] int32: (n frontiers, overflow flag, n contours, n chain points)
- *   d_windows   [n][8] int32 or NULL.  Per observation two inclusive cell windows (y0, y1, x0, x1; empty when y1 < y0):
+ *   d_windows   [n][12] int32 or NULL.  Per observation three inclusive cell windows (y0, y1, x0, x1; empty when y1 < y0):
  *               [0..3] where `navigable` has to be recomputed = the union of the reach windows (camera cell +- the largest
  *               distance a scattered texel can have, + 1) of every frame ingested into this slot since its last call with
- *               update_obstacles, grown by kernel_size / 2; [4..7] where `navigable` may have changed since this slot's
- *               last call with explore (the union of those grown windows): the frontier stage's derived planes are
- *               refreshed there and inside the revealed area's bounding box d_bbox (`explored` itself is masked inside
- *               d_bbox: no explored bit exists outside it).  The caller
+ *               update_obstacles, grown by kernel_size / 2; [4..7] where `explored` has to be masked = the caller's mirror
+ *               of d_bbox BEFORE this call (no explored bit exists outside it); [8..11] where the frontier stage's derived
+ *               planes are refreshed = the windows [0..3] of every call since this slot's last call with explore, united
+ *               with d_bbox AFTER this call's reveal (agent cell +- (fog_radius + 2), clipped) grown by 3.  The caller
  *               passes the whole map (0, S-1, 0, S-1) after a reset of the slot's planes, for a frame whose reach window
  *               leaves the map (NumPy's negative-index wrap, obstacle_map.py:101, lands on the far side) and for the first
- *               call on fresh scratch.  NULL = the reference's full-map passes (always valid). */
+ *               call on fresh scratch.  NULL = the reference's full-map passes (always valid).
+ *   window_blocks_navigable / window_blocks_prepare: launch sizes (256-word workgroups per observation) for the two windowed
+ *               kernels = ceil(max over the batch of rows x 32-cell words of the window(s) / 256); the kernels stride, so
+ *               any positive value is correct and 0 means "size for the full plane". */
 int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, int n, const uint32_t* d_obstacle,
                                      uint32_t* d_navigable, uint32_t* d_explored, int32_t* d_bbox, int n_envs,
                                      int map_size, int kernel_size, int fog_radius, double area_thresh_px,
                                      void* d_scratch, size_t scratch_bytes, int cap_pts, int cap_contours,
                                      double* d_frontiers, int cap_frontiers, int32_t* d_counts, int update_obstacles,
-                                     int explore, const int32_t* d_windows, void* stream);
+                                     int explore, const int32_t* d_windows, int window_blocks_navigable,
+                                     int window_blocks_prepare, void* stream);
 
 /* Debug/diagnostic: copies the per-environment status words of the last pipeline run to the host. */
 int vlfm_obstacle_status(const void* d_scratch, int n_envs, int map_size, int cap_pts, int cap_contours,

@@ -157,24 +157,34 @@ def test_obstacle_map_dirty_window_bookkeeping():
     slot hands over the whole map; a frame's reach window bounds every cell its scatter can touch (checked against the
     reference's own unprojection, geometry_utils.py:205-236 + base_map.py:44-46); a window that leaves the map, or a
     non-rigid transform, widens to the whole map (NumPy's negative-index wrap lands on the far side); windows accumulate
-    over explore=False calls and are consumed by the call that uses them."""
+    over explore=False calls and are consumed by the call that uses them; the explored-mask window is the mirror of the
+    revealed area's bounding box BEFORE the call, the refresh window contains it AFTER the call grown by 3; the launch sizes
+    cover the largest window of the batch."""
     from oracle.ref_geometry import apply_tf as transform_points, unproject as get_point_cloud
     from vlfm_amd.mapping.obstacle_map import ObstacleMapBatch
     from vlfm_amd.synthetic import MAX_DEPTH, MIN_DEPTH, camera_intrinsics, pose_to_tf
 
-    S, E = 1000, 4
+    S, E, R = 1000, 4, 100
     ob = ObstacleMapBatch.__new__(ObstacleMapBatch)   # host bookkeeping only: no device
     ob.size, ob.pixels_per_meter, ob.kernel_size, ob.n_envs = S, 20, 7, E
-    full = np.array([0, S - 1, 0, S - 1], np.int32)
+    full, empty = np.array([0, S - 1, 0, S - 1], np.int32), np.array([0, -1, 0, -1], np.int32)
     ob._dirty_obst = np.tile(full, (E, 1))
     ob._dirty_nav = ob._dirty_obst.copy()
+    ob._bbox_host = np.tile(empty, (E, 1))
     env = np.arange(E)
-    w = ob._take_windows(env, True, True)
-    assert (w[:, :4] == full).all() and (w[:, 4:] == full).all()                 # first step = the full-map pass
+    agent = np.array([[500, 500], [420, 610], [900, 510], [500, 500]])          # (x = col, y = row)
+    w, nb_nav, nb_prep = ob._take_windows(env, True, True, agent, R)
+    assert (w[:, 0:4] == full).all() and (w[:, 8:12] == full).all()              # first step = the full-map pass
+    assert (w[:, 5] < w[:, 4]).all()                                             # nothing revealed yet: nothing to mask
+    assert nb_nav == nb_prep == -(-S * 32 // 256)
     assert (ob._dirty_obst[:, 1] < ob._dirty_obst[:, 0]).all() and (ob._dirty_nav[:, 1] < ob._dirty_nav[:, 0]).all()
-    # nothing ingested, nothing to do
-    w = ob._take_windows(env, True, True)
-    assert (w[:, 1] < w[:, 0]).all() and (w[:, 5] < w[:, 4]).all()
+    assert (ob._bbox_host[0] == (398, 602, 398, 602)).all() and (ob._bbox_host[2] == (408, 612, 798, 999)).all()
+    # nothing ingested: only the explore half has work -- mask inside the old box, refresh inside the new box + 3
+    w, nb_nav, nb_prep = ob._take_windows(env, True, True, agent + 5, R)
+    assert (w[:, 1] < w[:, 0]).all()
+    assert (w[0, 4:8] == (398, 602, 398, 602)).all() and (w[0, 8:12] == (395, 610, 395, 610)).all()
+    area = lambda q: int(((q[:, 1] - q[:, 0] + 1) * ((q[:, 3] >> 5) - (q[:, 2] >> 5) + 1)).max())   # rows x 32-cell words
+    assert nb_nav == -(-area(w[:, 4:8]) // 256) == 7 and nb_prep == -(-area(w[:, 8:12]) // 256)
 
     H, W = 480, 640
     fx, fy, _ = camera_intrinsics(W)
@@ -198,14 +208,18 @@ def test_obstacle_map_dirty_window_bookkeeping():
         assert (y1 - y0) <= 2 * (int(np.ceil(reach)) + 2) and 0 <= y0 and y1 <= S - 1
     # explore=False (a body camera): navigable is recomputed in the grown window, which stays pending for the reveal
     before = ob._dirty_obst[:2].copy()
-    w = ob._take_windows(env[:2], True, False)
-    assert (w[:, 0] == before[:, 0] - 3).all() and (w[:, 1] == before[:, 1] + 3).all() and (w[:, 5] < w[:, 4]).all()
+    w, nb_nav, _ = ob._take_windows(env[:2], True, False)
+    assert (w[:, 0] == before[:, 0] - 3).all() and (w[:, 1] == before[:, 1] + 3).all()
+    assert (w[:, 5] < w[:, 4]).all() and (w[:, 9] < w[:, 8]).all()
     assert (ob._dirty_nav[:2] == w[:, :4]).all()
+    rows, words = w[:, 1] - w[:, 0] + 1, (w[:, 3] >> 5) - (w[:, 2] >> 5) + 1
+    assert nb_nav == -(-int((rows * words).max()) // 256)
     ob._note_ingest(env[:1], np.stack([pose_to_tf(5.0, -2.0, 0.0)]), reach)     # a second camera of slot 0
-    w2 = ob._take_windows(env[:1], True, False)
-    w3 = ob._take_windows(env[:2], False, True)                                 # the reveal without depth
-    assert (w3[:, 1] < w3[:, 0]).all()
-    assert w3[0, 4] == min(w[0, 0], w2[0, 0]) and w3[0, 5] == max(w[0, 1], w2[0, 1])      # union of both cameras' windows
-    assert w3[0, 6] == min(w[0, 2], w2[0, 2]) and w3[0, 7] == max(w[0, 3], w2[0, 3])
-    assert (w3[1, 4:] == w[1, :4]).all()
+    w2, _, _ = ob._take_windows(env[:1], True, False)
+    box_before = ob._bbox_host[:2].copy()
+    w3, _, _ = ob._take_windows(env[:2], False, True, agent[:2], R)             # the reveal without depth
+    assert (w3[:, 1] < w3[:, 0]).all() and (w3[:, 4:8] == box_before).all()
+    assert w3[0, 8] <= min(w[0, 0], w2[0, 0]) and w3[0, 9] >= max(w[0, 1], w2[0, 1])     # both cameras' windows ...
+    assert w3[0, 10] <= min(w[0, 2], w2[0, 2]) and w3[0, 11] >= max(w[0, 3], w2[0, 3])
+    assert w3[0, 8] <= ob._bbox_host[0, 0] - 3 and w3[0, 9] >= ob._bbox_host[0, 1] + 3  # ... and the revealed box grown by 3
     assert (ob._dirty_nav[:2, 1] < ob._dirty_nav[:2, 0]).all()

@@ -11,7 +11,7 @@ import torch  # noqa: E402
 from vlfm_amd.vlm.yolov7 import YOLOv7  # noqa: E402
 
 
-def timed(fn, n=5):
+def timed(fn, n=8):
     for _ in range(2):
         fn()
     torch.cuda.synchronize()

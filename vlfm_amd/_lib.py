@@ -160,7 +160,7 @@ def lib() -> ctypes.CDLL:
         L.vlfm_obstacle_scratch_bytes.argtypes = [ci, ci, ci, ci]
         L.vlfm_obstacle_scratch_bytes.restype = ctypes.c_size_t
         L.vlfm_obstacle_map_update_batched.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, cd, vp, ctypes.c_size_t,
-                                                       ci, ci, vp, ci, vp, ci, ci, vp, vp]
+                                                       ci, ci, vp, ci, vp, ci, ci, vp, ci, ci, vp]
         L.vlfm_obstacle_status.argtypes = [vp, ci, ci, ci, ci, vp]
         _lib = L
     return _lib

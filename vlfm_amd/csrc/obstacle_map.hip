@@ -450,58 +450,66 @@ __device__ inline WalkTables fog_walk_tables(const FogScratch& sc, int env, int 
 // revealed (no explored bit exists outside it; the box is persistent device state maintained by fog_of_war_kernel).  The
 // box, not a window of `navigable` changes: explored_select's filled contour (obstacle_map.py:145) may set explored bits
 // on non-navigable cells anywhere inside the explored area, which the NEXT step's masking takes away again.
-// The caller accumulates two windows per environment (ObstacleMapBatch: full map after reset(), after a frame whose reach
-// leaves the map -- negative indices wrap, obstacle_map.py:101 -- or with a non-rigid camera transform) and hands them over
-// per observation:
-//   win[0..3]  rows / columns (inclusive y0, y1, x0, x1) where `navigable` has to be recomputed (empty: y1 < y0)
-//   win[4..7]  where `navigable` may have changed since the last explore step: the frontier stage's derived planes are
-//              refreshed there (frontier_prepare_kernel)
-// One thread per 32-cell word; a workgroup (256 words = 8 rows at S = 1000) whose rows miss both windows exits on two scalar
-// compares.  win == null: the full-plane pass of rounds 1-2 (101 us at 256 environments against the window's ~6 us).
+// The caller accumulates the windows per environment (ObstacleMapBatch: full map after reset(), after a frame whose reach
+// leaves the map -- negative indices wrap, obstacle_map.py:101 -- or with a non-rigid camera transform) and hands three of
+// them over per observation, inclusive (y0, y1, x0, x1), empty when y1 < y0:
+//   win[0..3]   where `navigable` has to be recomputed
+//   win[4..7]   where `explored` has to be masked: the caller's mirror of the revealed area's bounding box BEFORE this step
+//   win[8..11]  where the frontier stage's derived planes have to be refreshed (frontier_prepare_kernel): the windows of
+//               `navigable` changes since the last explore step, united with the bounding box AFTER this step grown by 3
+// and sizes the launch for the largest window of the batch: the kernels walk (row, word) items of their window in a
+// grid-stride loop, so that a step costs the window's ~3 000 words per environment instead of the plane's 32 000 (round 2:
+// 101 us at 256 environments; early-exit workgroups over the full plane: 53 us; window-sized grid: see profiles/).
+// win == null: the full-plane pass.
 struct DirtyWin { int y0, y1, x0, x1; };
 __device__ inline DirtyWin load_win(const int* __restrict__ w, int S) {
     if (!w) return DirtyWin{0, S - 1, 0, S - 1};
     return DirtyWin{w[0], w[1], w[2], w[3]};
 }
-__device__ inline bool rows_hit(const DirtyWin& d, int ya, int yb) { return d.y1 >= d.y0 && yb >= d.y0 && ya <= d.y1; }
+__device__ inline bool win_empty(const DirtyWin& d) { return d.y1 < d.y0 || d.x1 < d.x0; }
+__device__ inline DirtyWin win_union(const DirtyWin& a, const DirtyWin& b) {
+    if (win_empty(a)) return b;
+    if (win_empty(b)) return a;
+    return DirtyWin{min(a.y0, b.y0), max(a.y1, b.y1), min(a.x0, b.x0), max(a.x1, b.x1)};
+}
 __device__ inline bool word_hit(const DirtyWin& d, int y, int wi) {
-    return d.y1 >= d.y0 && y >= d.y0 && y <= d.y1 && wi >= (d.x0 >> 5) && wi <= (d.x1 >> 5);
+    return !win_empty(d) && y >= d.y0 && y <= d.y1 && wi >= (d.x0 >> 5) && wi <= (d.x1 >> 5);
 }
 
 __global__ __launch_bounds__(256) void navigable_kernel(const FogParams* __restrict__ prm, MapPlanes mp, int radius,
-                                                        int update_obstacles, int explore, const int* __restrict__ windows,
-                                                        const int* __restrict__ bbox) {
+                                                        int update_obstacles, int explore, const int* __restrict__ windows) {
     const int e = prm[blockIdx.z].env;
     const int S = mp.S, stride = mp.stride;
     const size_t off = (size_t)e * S * stride;
-    const int* w = windows ? windows + 8 * blockIdx.z : nullptr;
-    const DirtyWin w_nav = load_win(w, S), w_mask = load_win(w ? bbox + (size_t)e * 4 : nullptr, S);
+    const int* w = windows ? windows + 12 * blockIdx.z : nullptr;
     const bool do_mask = explore && prm[blockIdx.z].n_poly > 0;   // only the explore branch masks (:127)
-    {   // rows of this workgroup against the windows (uniform)
-        const int ya = (blockIdx.x * blockDim.x) / stride, yb = min(S - 1, (blockIdx.x * blockDim.x + blockDim.x - 1) / stride);
-        if (!((update_obstacles && rows_hit(w_nav, ya, yb)) || (do_mask && rows_hit(w_mask, ya, yb)))) return;
-    }
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= S * stride) return;
-    const int y = idx / stride, wi = idx - y * stride;
-    const bool recompute = update_obstacles && word_hit(w_nav, y, wi);
-    const bool mask = do_mask && word_hit(w_mask, y, wi);
-    if (!recompute && !mask) return;
-    unsigned nav;
-    if (recompute) {
-        const unsigned* src = mp.obstacle + off;
-        unsigned acc = 0;
-        for (int dy = -radius; dy <= radius; dy++)
-            acc |= hdilate(row_word(src, stride, S, y + dy, wi - 1), row_word(src, stride, S, y + dy, wi),
-                           row_word(src, stride, S, y + dy, wi + 1), radius);
-        nav = ~acc & tail_mask(S, wi);
-        mp.navigable[off + idx] = nav;
-    } else {
-        nav = mp.navigable[off + idx];
-    }
-    if (mask) {
-        const unsigned ex = mp.explored[off + idx];
-        if (ex & ~nav) mp.explored[off + idx] = ex & nav;
+    DirtyWin w_nav = load_win(w, S), w_mask = load_win(w ? w + 4 : nullptr, S);
+    if (!update_obstacles) w_nav = DirtyWin{0, -1, 0, -1};
+    if (!do_mask) w_mask = DirtyWin{0, -1, 0, -1};
+    const DirtyWin U = win_union(w_nav, w_mask);
+    if (win_empty(U)) return;
+    const int wx0 = U.x0 >> 5, ww = (U.x1 >> 5) - wx0 + 1, n_items = (U.y1 - U.y0 + 1) * ww;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += gridDim.x * blockDim.x) {
+        const int y = U.y0 + i / ww, wi = wx0 + i % ww;
+        const bool recompute = word_hit(w_nav, y, wi), mask = word_hit(w_mask, y, wi);
+        if (!recompute && !mask) continue;
+        const int idx = y * stride + wi;
+        unsigned nav;
+        if (recompute) {
+            const unsigned* src = mp.obstacle + off;
+            unsigned acc = 0;
+            for (int dy = -radius; dy <= radius; dy++)
+                acc |= hdilate(row_word(src, stride, S, y + dy, wi - 1), row_word(src, stride, S, y + dy, wi),
+                               row_word(src, stride, S, y + dy, wi + 1), radius);
+            nav = ~acc & tail_mask(S, wi);
+            mp.navigable[off + idx] = nav;
+        } else {
+            nav = mp.navigable[off + idx];
+        }
+        if (mask) {
+            const unsigned ex = mp.explored[off + idx];
+            if (ex & ~nav) mp.explored[off + idx] = ex & nav;
+        }
     }
 }
 
@@ -929,42 +937,35 @@ __device__ inline int reflect101(int i, int n) {
 // obstacle_map.py:159-163 + the first lines of detect_frontier_waypoints: explored_d = dilate(explored, 5x5) & navigable,
 // unexplored = navigable & ~explored_d, for every listed environment, one thread per 32-cell word.
 // Both planes are pure functions of (explored, navigable) with a 5 x 5 footprint, and they persist per environment: they
-// only have to be refreshed where an input may have changed since the last explore step -- inside the bounding box of
-// everything ever revealed (every change of `explored`: reveal, masking, component selection) grown by the footprint, and
-// inside the caller's window of `navigable` changes (win[4..7], see navigable_kernel).  Exception: last step's
-// filter_out_small_unexplored marked a pocket explored IN `explored_d` (frontier_kernel, the rare non-shortcut path; flagged
-// in `derived_dirty`): then the whole plane is rebuilt.
+// only have to be refreshed where an input may have changed since the last explore step -- win[8..11] (see navigable_kernel).
+// Exception: last step's filter_out_small_unexplored marked a pocket explored IN `explored_d` (frontier_kernel, the rare
+// non-shortcut path; flagged in `derived_dirty`): then the whole plane is rebuilt (by the same window-sized grid, striding).
 __global__ __launch_bounds__(256) void frontier_prepare_kernel(const FogParams* __restrict__ prm, MapPlanes mp,
                                                                unsigned* __restrict__ explored_d,
                                                                unsigned* __restrict__ unexplored,
-                                                               const int* __restrict__ windows, const int* __restrict__ bbox,
+                                                               const int* __restrict__ windows,
                                                                const int* __restrict__ derived_dirty) {
     const FogParams& P = prm[blockIdx.z];
     if (P.n_poly <= 0) return;
     const int S = mp.S, stride = mp.stride;
     const bool full = !windows || derived_dirty[P.env] != 0;
-    const DirtyWin w_nav = load_win(full ? nullptr : windows + 8 * blockIdx.z + 4, S);
-    DirtyWin w_box{0, -1, 0, -1};
-    if (!full) {
-        const int* bb = bbox + (size_t)P.env * 4;
-        if (bb[1] >= bb[0]) w_box = DirtyWin{max(bb[0] - 3, 0), min(bb[1] + 3, S - 1), max(bb[2] - 3, 0), min(bb[3] + 3, S - 1)};
-        const int ya = (blockIdx.x * blockDim.x) / stride, yb = min(S - 1, (blockIdx.x * blockDim.x + blockDim.x - 1) / stride);
-        if (!rows_hit(w_nav, ya, yb) && !rows_hit(w_box, ya, yb)) return;
-    }
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= S * stride) return;
-    const int y = idx / stride, wi = idx - y * stride;
-    if (!full && !word_hit(w_nav, y, wi) && !word_hit(w_box, y, wi)) return;
+    const DirtyWin U = load_win(full ? nullptr : windows + 12 * blockIdx.z + 8, S);
+    if (win_empty(U)) return;
+    const int wx0 = U.x0 >> 5, ww = (U.x1 >> 5) - wx0 + 1, n_items = (U.y1 - U.y0 + 1) * ww;
     const size_t eoff = (size_t)P.env * S * stride;
     const unsigned* expl = mp.explored + eoff;
-    unsigned acc = 0;
-    for (int dy = -2; dy <= 2; dy++)
-        acc |= hdilate(row_word(expl, stride, S, y + dy, wi - 1), row_word(expl, stride, S, y + dy, wi),
-                       row_word(expl, stride, S, y + dy, wi + 1), 2);
-    const unsigned nv = mp.navigable[eoff + idx];
-    acc &= nv & tail_mask(S, wi);
-    explored_d[eoff + idx] = acc;
-    unexplored[eoff + idx] = nv & ~acc;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += gridDim.x * blockDim.x) {
+        const int y = U.y0 + i / ww, wi = wx0 + i % ww;
+        const int idx = y * stride + wi;
+        unsigned acc = 0;
+        for (int dy = -2; dy <= 2; dy++)
+            acc |= hdilate(row_word(expl, stride, S, y + dy, wi - 1), row_word(expl, stride, S, y + dy, wi),
+                           row_word(expl, stride, S, y + dy, wi + 1), 2);
+        const unsigned nv = mp.navigable[eoff + idx];
+        acc &= nv & tail_mask(S, wi);
+        explored_d[eoff + idx] = acc;
+        unexplored[eoff + idx] = nv & ~acc;
+    }
 }
 
 __global__ __launch_bounds__(1024) void frontier_kernel(const FogParams* __restrict__ prm, MapPlanes mp, FrontierScratch sc,
@@ -1442,7 +1443,8 @@ extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, in
                                                 double area_thresh_px, void* d_scratch, size_t scratch_bytes,
                                                 int cap_pts, int cap_contours, double* d_frontiers, int cap_frontiers,
                                                 int32_t* d_counts, int update_obstacles, int explore,
-                                                const int32_t* d_windows, void* stream) {
+                                                const int32_t* d_windows, int window_blocks_navigable,
+                                                int window_blocks_prepare, void* stream) {
     if (n == 0) return VLFM_OK;
     if (!d_prm || !d_obstacle || !d_navigable || !d_explored || !d_bbox || !d_scratch || !d_frontiers || !d_counts ||
         n < 0 || map_size <= 0 || map_size > 2048 || kernel_size < 1 || !(kernel_size & 1) || kernel_size > 63 ||
@@ -1463,8 +1465,11 @@ extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, in
     int* status = (int*)(base + L.off_status);
     if (update_obstacles || explore) {
         VLFM_TIMED("navigable_kernel", s);
-        VLFM_KLAUNCH(navigable_kernel, dim3((map_size * stride + 255) / 256, 1, n), dim3(256), 0, s, d_prm, mp,
-                           kernel_size / 2, update_obstacles, explore, d_windows, (const int*)d_bbox);
+        const int full_blocks = (map_size * stride + 255) / 256;
+        const int nb = (d_windows && window_blocks_navigable > 0 && window_blocks_navigable < full_blocks)
+                           ? window_blocks_navigable : full_blocks;
+        VLFM_KLAUNCH(navigable_kernel, dim3(nb, 1, n), dim3(256), 0, s, d_prm, mp, kernel_size / 2, update_obstacles, explore,
+                     d_windows);
     }
     int rc = check_launch("navigable_kernel");
     if (rc != VLFM_OK || !explore) return rc;
@@ -1512,8 +1517,11 @@ extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, in
                            2 * cap_pts > 65535 ? 65535 : 2 * cap_pts, status + (size_t)n_envs * 8};
         {
             VLFM_TIMED("frontier_prepare_kernel", s);
-            VLFM_KLAUNCH(frontier_prepare_kernel, dim3((map_size * stride + 255) / 256, 1, n), dim3(256), 0, s, d_prm, mp,
-                         planes[6], planes[7], d_windows, (const int*)d_bbox, (const int*)(status + (size_t)n_envs * 8));
+            const int full_blocks = (map_size * stride + 255) / 256;
+            const int nb = (d_windows && window_blocks_prepare > 0 && window_blocks_prepare < full_blocks)
+                               ? window_blocks_prepare : full_blocks;
+            VLFM_KLAUNCH(frontier_prepare_kernel, dim3(nb, 1, n), dim3(256), 0, s, d_prm, mp, planes[6], planes[7], d_windows,
+                         (const int*)(status + (size_t)n_envs * 8));
         }
         VLFM_TIMED("frontier_kernel", s);
         VLFM_KLAUNCH(frontier_kernel, dim3(n), dim3(1024), kWalkLdsBytes, s, d_prm, mp, fr, (const int*)d_bbox);

@@ -67,7 +67,9 @@ class ObstacleMapBatch:
         # reference's full-map pass).  VLFM_FULL_PLANES=1 hands over NULL windows: the full-plane kernels, for A/B runs.
         self._dirty_obst = np.tile(np.array([0, size - 1, 0, size - 1], np.int32), (n_envs, 1))
         self._dirty_nav = self._dirty_obst.copy()
-        self._ring_win = UploadRing(self.device, n_envs * 32, slots=8)
+        # host mirror of the device's bounding box of everything ever revealed (fog_of_war_kernel: agent cell +- (R + 2))
+        self._bbox_host = np.tile(np.array([0, -1, 0, -1], np.int32), (n_envs, 1))
+        self._ring_win = UploadRing(self.device, n_envs * 48, slots=8)
         import os
 
         self.full_planes = os.environ.get("VLFM_FULL_PLANES", "0") == "1"
@@ -91,6 +93,7 @@ class ObstacleMapBatch:
         self._explored_u8 = None
         self._dirty_obst[idx] = (0, self.size - 1, 0, self.size - 1)   # zeroed planes: everything is to be recomputed
         self._dirty_nav[idx] = (0, self.size - 1, 0, self.size - 1)
+        self._bbox_host[idx] = (0, -1, 0, -1)
 
     @staticmethod
     def _union(into: np.ndarray, idx: np.ndarray, win: np.ndarray) -> None:
@@ -120,26 +123,52 @@ class ObstacleMapBatch:
         win = np.where(inside[:, None], win, np.array([0, S - 1, 0, S - 1], np.float64)[None]).astype(np.int32)
         self._union(self._dirty_obst, env, win)
 
-    def _take_windows(self, env: np.ndarray, update_obstacles: bool, explore: bool) -> np.ndarray:
-        """[n, 8] int32 for vlfm_obstacle_map_update_batched and the bookkeeping that goes with handing them over."""
+    def _take_windows(self, env: np.ndarray, update_obstacles: bool, explore: bool, agent_px=None, fog_radius: int = 0):
+        """([n, 12] int32 windows, workgroups for navigable_kernel, workgroups for frontier_prepare_kernel) for
+        vlfm_obstacle_map_update_batched, and the bookkeeping that goes with handing them over.  ``agent_px`` [n, 2] (x, y)
+        = the agent cells of an explore call: the reveal touches agent +- (fog_radius + 2)."""
         S, n = self.size, len(env)
-        out = np.empty((n, 8), np.int32)
-        out[:, 0:4] = (0, -1, 0, -1)
-        out[:, 4:8] = (0, -1, 0, -1)
+        empty = np.array([0, -1, 0, -1], np.int32)
+        out = np.tile(np.concatenate([empty, empty, empty]), (n, 1))
         if update_obstacles:
             g = self.kernel_size // 2
             w = self._dirty_obst[env].copy()
             live = w[:, 1] >= w[:, 0]
             w[:, 0] = np.maximum(w[:, 0] - g, 0); w[:, 1] = np.minimum(w[:, 1] + g, S - 1)
             w[:, 2] = np.maximum(w[:, 2] - g, 0); w[:, 3] = np.minimum(w[:, 3] + g, S - 1)
-            w[~live] = (0, -1, 0, -1)
+            w[~live] = empty
             out[:, 0:4] = w
             self._union(self._dirty_nav, env, w)
-            self._dirty_obst[env] = (0, -1, 0, -1)
+            self._dirty_obst[env] = empty
         if explore:
-            out[:, 4:8] = self._dirty_nav[env]
-            self._dirty_nav[env] = (0, -1, 0, -1)
-        return out
+            out[:, 4:8] = self._bbox_host[env]                     # explored bits live inside the box of the steps so far
+            r = int(fog_radius) + 2
+            ax, ay = np.asarray(agent_px[:, 0], np.int64), np.asarray(agent_px[:, 1], np.int64)
+            fog = np.stack([np.maximum(ay - r, 0), np.minimum(ay + r, S - 1), np.maximum(ax - r, 0),
+                            np.minimum(ax + r, S - 1)], axis=1).astype(np.int32)       # (window side 2 r + 1 = 2 R + 5)
+            self._union(self._bbox_host, env, fog)
+            box = self._bbox_host[env].copy()
+            live = box[:, 1] >= box[:, 0]
+            box[:, 0] = np.maximum(box[:, 0] - 3, 0); box[:, 1] = np.minimum(box[:, 1] + 3, S - 1)
+            box[:, 2] = np.maximum(box[:, 2] - 3, 0); box[:, 3] = np.minimum(box[:, 3] + 3, S - 1)
+            box[~live] = empty
+            refresh = self._dirty_nav[env].copy()
+            tmp = np.tile(empty, (n, 1))
+            tmp[:] = refresh
+            self._union(tmp, np.arange(n), box)
+            out[:, 8:12] = tmp
+            self._dirty_nav[env] = empty
+
+        def blocks(*wins) -> int:
+            """256-word workgroups for the largest bounding union of the given windows over the batch."""
+            u = np.tile(empty, (n, 1))
+            for w_ in wins:
+                self._union(u, np.arange(n), w_)
+            rows = np.maximum(u[:, 1] - u[:, 0] + 1, 0)
+            words = np.maximum((u[:, 3] >> 5) - (u[:, 2] >> 5) + 1, 0)
+            return int(max(1, -(-int((rows * words).max()) // 256)))
+
+        return out.astype(np.int32), blocks(out[:, 0:4], out[:, 4:8]), blocks(out[:, 8:12])
 
     def _unpack(self, bits):
         import torch
@@ -290,7 +319,9 @@ class ObstacleMapBatch:
         if env_ids is not None:  # the explore pipeline owns a slot's planes for the whole launch
             assert len(set(int(e) for e in env_ids)) == n, "one observation per environment slot and call"
         env = np.arange(n) if env_ids is None else np.asarray(env_ids, np.int64)
-        windows = self._take_windows(env, update_obstacles, explore)
+        agent = np.array([[q.ax, q.ay] for q in prm], np.int64) if explore else None
+        windows, nb_nav, nb_prep = self._take_windows(env, update_obstacles, explore, agent,
+                                                      int(max_depth * self.pixels_per_meter))
         with torch.cuda.device(self.device):
             d_prm = self._ring_fog.upload(prm)
             d_win = None if self.full_planes else self._ring_win.upload(windows)
@@ -300,7 +331,7 @@ class ObstacleMapBatch:
                 int(max_depth * self.pixels_per_meter), float(self._area_thresh_in_pixels), self.scratch.data_ptr(),
                 self.scratch.numel(), self.CAP_PTS, self.CAP_CONTOURS, self.frontiers_px_dev.data_ptr(),
                 self.CAP_FRONTIERS, self.counts.data_ptr(), int(update_obstacles), int(explore),
-                d_win.data_ptr() if d_win is not None else None, _stream_ptr()), "obstacle_map_update")
+                d_win.data_ptr() if d_win is not None else None, nb_nav, nb_prep, _stream_ptr()), "obstacle_map_update")
         self.frontiers_ready = bool(explore)
         self._explored_u8 = None
 
