@@ -617,59 +617,77 @@ __global__ __launch_bounds__(1024) void fog_of_war_kernel(const FogParams* __res
     if (tid == 0) { status[1] = n_obst; }
     if (n_obst == 0) return;  // "no obstacles in the cone": fog returned unchanged -> nothing revealed this step
     VLFM_PHASE(0, 3);
-    // ---- 4. shadow-casting points: convex blobs contribute their two angular extremes, the others every vertex
+    // ---- 4. shadow-casting points: convex blobs contribute their two angular extremes, the others every vertex.
+    // One WAVEFRONT per blob (round 3; before: the whole workgroup per blob with three barriers each, and ONE lane evaluating
+    // the f64 atan2 of every vertex of a convex blob in a serial loop).  The cuts of step 5 only clear bits, so the order in
+    // which blobs append their points is immaterial; np.argmin / np.argmax keep the FIRST extreme, i.e. the smallest index
+    // among equal angles -- the wave reduction orders (angle, index) pairs accordingly.
     const int acx = P.ax - ox, acy = P.ay - oy;  // agent in window coordinates (contour points are window-local)
-    for (int c = 0; c < n_obst; c++) {
+    for (int c = wave; c < n_obst; c += nth >> 6) {
         const int n = clen[c];
         const int2* cp = pts + cstart[c];
-        if (tid == 0) sh_i[4] = 0;
-        __syncthreads();
         // cv::isContourConvex on the SIMPLE vertices
-        for (int i = tid; i < n; i += nth) {
+        int flags = 0;
+        for (int i = lane; i < n; i += 64) {
             const int2 p2 = cp[(i - 2 + 2 * n) % n], p1 = cp[(i - 1 + n) % n], p = cp[i];
             const int dx0 = p1.x - p2.x, dy0 = p1.y - p2.y, dx = p.x - p1.x, dy = p.y - p1.y;
             const int dxdy0 = dx * dy0, dydx0 = dy * dx0;
-            atomicOr(&sh_i[4], dydx0 > dxdy0 ? 1 : (dydx0 < dxdy0 ? 2 : 3));
+            flags |= dydx0 > dxdy0 ? 1 : (dydx0 < dxdy0 ? 2 : 3);
         }
-        __syncthreads();
-        const bool convex = n > 0 && sh_i[4] != 3;
-        const int base = sh_i[3];
+        for (int off = 32; off > 0; off >>= 1) flags |= __shfl_xor(flags, off, 64);
+        const bool convex = n > 0 && flags != 3;
         if (convex) {
-            if (tid == 0) {
-                // get_two_farthest_points: rotate (pt - source) by the upstream matrix, atan2, first argmin / argmax
-                int imin = 0, imax = 0;
-                double amin = 0, amax = 0;
-                for (int i = 0; i < n; i++) {
-                    const double px = (double)(cp[i].x - acx), py = (double)(cp[i].y - acy);
-                    const double rx = __dadd_rn(__dmul_rn(px, P.rot_c), __dmul_rn(py, P.rot_s));
-                    const double ry = __dadd_rn(__dmul_rn(px, -P.rot_s), __dmul_rn(py, P.rot_c));
-                    const double a = atan2(ry, rx);
-                    if (i == 0 || a < amin) { if (i == 0 || a < amin) { amin = a; imin = i; } }
-                    if (i == 0 || a > amax) { amax = a; imax = i; }
-                }
+            // get_two_farthest_points: rotate (pt - source) by the upstream matrix, atan2, first argmin / argmax
+            double amin = 0, amax = 0;
+            int imin = 0x7FFFFFFF, imax = 0x7FFFFFFF;
+            for (int i = lane; i < n; i += 64) {
+                const double px = (double)(cp[i].x - acx), py = (double)(cp[i].y - acy);
+                const double rx = __dadd_rn(__dmul_rn(px, P.rot_c), __dmul_rn(py, P.rot_s));
+                const double ry = __dadd_rn(__dmul_rn(px, -P.rot_s), __dmul_rn(py, P.rot_c));
+                const double a = atan2(ry, rx);
+                if (imin == 0x7FFFFFFF || a < amin) { amin = a; imin = i; }
+                if (imax == 0x7FFFFFFF || a > amax) { amax = a; imax = i; }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                const double oa = __shfl_xor(amin, off, 64), ob = __shfl_xor(amax, off, 64);
+                const int oi = __shfl_xor(imin, off, 64), oj = __shfl_xor(imax, off, 64);
+                if (oi != 0x7FFFFFFF && (imin == 0x7FFFFFFF || oa < amin || (oa == amin && oi < imin))) { amin = oa; imin = oi; }
+                if (oj != 0x7FFFFFFF && (imax == 0x7FFFFFFF || ob > amax || (ob == amax && oj < imax))) { amax = ob; imax = oj; }
+            }
+            if (lane == 0) {
+                const int base = atomicAdd(&sh_i[3], 2);
                 lines[base] = make_int4(cp[imin].x, cp[imin].y, 0, 0);
                 lines[base + 1] = make_int4(cp[imax].x, cp[imax].y, 0, 0);
-                sh_i[3] = base + 2;
             }
         } else {
-            for (int i = tid; i < n; i += nth) lines[base + i] = make_int4(cp[i].x, cp[i].y, 0, 0);
-            if (tid == 0) sh_i[3] = base + n;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&sh_i[3], n);
+            base = __shfl(base, 0, 64);
+            for (int i = lane; i < n; i += 64) lines[base + i] = make_int4(cp[i].x, cp[i].y, 0, 0);
         }
-        __syncthreads();
     }
+    __threadfence_block();
+    __syncthreads();
     const int n_lines = sh_i[3];
     if (tid == 0) status[2] = n_lines;
     VLFM_PHASE(0, 4);
-    // ---- 5. cut the visible mask with 2-px lines from every point away from the agent (cv2.polylines, color 0)
-    // one (part, line) task per lane, PART-MAJOR so that a wavefront runs one code path (edge / interior / end disc): the
-    // critical path becomes one edge + one interior + one disc instead of a whole line
-    for (int t = tid; t < n_lines * THICK_LINE_PARTS; t += nth) {
-        const int part = t / n_lines, i = t - part * n_lines;
+    // ---- 5. cut the visible mask with 2-px lines from every point away from the agent (cv2.polylines, color 0).  End
+    // points first (one f64 atan2 / cos / sin per LINE, not per task), then one (part, line) task per lane, PART-MAJOR so that
+    // a wavefront runs one code path (edge / interior / end disc): the critical path becomes one edge + one interior + one
+    // disc instead of a whole line
+    for (int i = tid; i < n_lines; i += nth) {
         const int px = lines[i].x + ox, py = lines[i].y + oy;  // image coordinates
         const double ang = atan2((double)(py - P.ay), (double)(px - P.ax));
         const double ex = __dadd_rn((double)px, __dmul_rn(P.line_len, cos(ang)));
         const double ey = __dadd_rn((double)py, __dmul_rn(P.line_len, sin(ang)));
-        thick_line2_clear(vis, W, px, py, (int)ex, (int)ey, part);  // .astype(np.int32): truncation
+        lines[i].z = (int)ex; lines[i].w = (int)ey;            // .astype(np.int32): truncation
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int t = tid; t < n_lines * THICK_LINE_PARTS; t += nth) {
+        const int part = t / n_lines, i = t - part * n_lines;
+        const int4 ln = lines[i];
+        thick_line2_clear(vis, W, ln.x + ox, ln.y + oy, ln.z, ln.w, part);
     }
     __syncthreads();
     VLFM_PHASE(0, 5);
