@@ -64,6 +64,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2, help="BLIP-2 fp32 forwards timed on the host")
     ap.add_argument("--no-overlap", action="store_true", help="run the obstacle pipeline on the BLIP-2 stream")
+    ap.add_argument("--kernel-event-every", type=int, default=5,
+                    help="HIP events around every n-th launch of each map kernel in the timed region (roofline.achieved)")
     ap.add_argument("--host-profile", action="store_true", help="cProfile the timed region (stderr), for tuning")
     ap.add_argument("--host-busy-cores", type=float, default=None,
                     help="--dry-run: host cores one rank keeps busy (default: the figure measured by the last committed "
@@ -291,6 +293,9 @@ MAP_KERNELS = ("depth_ingest_kernel", "depth_scatter_kernel", "depth_ingest_scat
                "frontier_prepare_kernel", "frontier_kernel")
 
 
+LAUNCHES_TIMED = {}
+
+
 def read_kernel_ms():
     from vlfm_amd import _lib
 
@@ -299,6 +304,7 @@ def read_kernel_ms():
         ms, n = _lib.profile_read(k)
         if n:
             out[k] = ms
+            LAUNCHES_TIMED[k] = n
     return out
 
 
@@ -415,6 +421,21 @@ def dry_run(args) -> None:
 
 
 # ------------------------------------------------------------------------------------------------ main
+def thread_cpu_seconds():
+    """{tid: (comm, user+system CPU seconds)} of this process's threads (/proc/self/task): who is busy on the host."""
+    out = {}
+    tick = os.sysconf("SC_CLK_TCK")
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            raw = open(f"/proc/self/task/{tid}/stat").read()
+        except OSError:
+            continue
+        comm = raw[raw.index("(") + 1:raw.rindex(")")]
+        f = raw[raw.rindex(")") + 2:].split()
+        out[int(tid)] = (comm, (int(f[11]) + int(f[12])) / tick)
+    return out
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -424,16 +445,18 @@ def main():
     import torch
     import torch.distributed as dist
 
+    from vlfm_amd import _lib
     from vlfm_amd import distributed as D
 
     rank, local_rank, world = D.world()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU"
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
+    # before the first stream exists: the runtime fixes a queue's wait policy when it creates the queue
+    _lib.host_wait_blocking(device)
     D.init("nccl", device)  # backend "nccl" is RCCL on ROCm; only the metric all-reduces use it
     torch.set_num_threads(1)  # the GPU leg has no CPU tensor math; idle OpenMP spinners would only eat the CPU quota
 
-    from vlfm_amd import _lib
     from vlfm_amd.harness import BatchedEpisodes
 
     have_obstacle = not args.no_obstacle
@@ -452,7 +475,10 @@ def main():
     for _ in range(args.warmup):
         sim.step()
     first_timed_step = sim.t
-    _lib.lib().vlfm_profile_enable(1)  # dispatch-timestamp events around every kernel launch of libvlfm_amd
+    # dispatch-timestamp events on every `--kernel-event-every`-th launch of each libvlfm_amd kernel: a timed dispatch keeps
+    # the runtime's completion thread (and the thread waiting for the stream) awake for the whole step - measured with
+    # tools/host_busy_probe.py: every launch timed = 164.5 ms/step and 2.0 busy host cores, none = 160.8 ms and 1.0
+    _lib.lib().vlfm_profile_enable(args.kernel_event_every)
     prof = None
     if args.host_profile:
         import cProfile
@@ -461,6 +487,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     cpu0 = time.process_time()   # CPU seconds of ALL threads of this rank (Python thread + HIP runtime helpers)
+    threads0 = thread_cpu_seconds()
     if prof is not None:
         prof.enable()
     for _ in range(args.steps):
@@ -470,6 +497,9 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     host_cpu = time.process_time() - cpu0
+    threads1 = thread_cpu_seconds()
+    by_thread = sorted(((round((threads1[t][1] - threads0.get(t, (None, 0.0))[1]) / elapsed, 3), threads1[t][0])
+                        for t in threads1), reverse=True)[:4]
     sim.check()  # a capacity overflow or an off-map obstacle point inside the timed region fails the benchmark
     if prof is not None and rank == 0:
         import pstats
@@ -481,6 +511,7 @@ def main():
 
     torch.cuda.synchronize(device)
     kms = read_kernel_ms()
+    timed_launches = LAUNCHES_TIMED.get("value_map_update_fused_kernel", LAUNCHES_TIMED.get("value_map_fuse_kernel", 0))
     _lib.lib().vlfm_profile_enable(0)
     if rank == 0:
         H, W, E = args.height, args.width, args.envs
@@ -500,6 +531,9 @@ def main():
                     "necessary_bytes_per_launch": head["necessary_bytes_per_launch"],
                     "necessary_frac": head["necessary_frac"], "stored_cells_per_observation": round(stored, 1),
                     "launch_ms": head["launch_ms"],
+                    "launch_ms_source": f"HIP events on the dispatch (hipExtLaunchKernelGGL), every {args.kernel_event_every}"
+                                        f". launch of each kernel in the timed region: "
+                                        f"{timed_launches} launches timed",
                     "bound_evidence": ("`frac` prices the reference's whole 201x201 window (SURVEY 8d); the launch only has to "
                                        "move `necessary_bytes_per_launch` (the visible cone is a fraction of the window), so the "
                                        "honest HBM fraction is `necessary_frac` / `traffic_frac`; below 0.3 the kernel is "
@@ -530,6 +564,7 @@ def main():
             # 8-GPU readiness without the node: how much host CPU one rank needs, against what the container may use
             "host": {"cpu_s_per_step_per_rank": round(host_cpu_sum / world / args.steps, 5),
                      "busy_cores_per_rank": round(host_busy_sum / world, 3), "busy_cores_all_ranks": round(host_busy_sum, 3),
+                     "busiest_threads_rank0": [{"comm": c, "busy_cores": b} for b, c in by_thread],
                      "cgroup_quota_cores": usable_cores(),
                      "ranks_that_fit_the_quota": int(usable_cores() / max(host_busy_sum / world, 1e-9)),
                      "note": "process_time of all threads of a rank over the timed region / wall time; `python bench.py "

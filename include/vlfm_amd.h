@@ -39,10 +39,18 @@ enum { VLFM_FUSE_DEFAULT = 0, VLFM_FUSE_REPLACE = 1, VLFM_FUSE_EQUAL_WEIGHTING =
 const char* vlfm_last_error(void);
 int vlfm_abi_version(void);
 
-/* Optional per-kernel timing: when enabled every kernel launch of this library is bracketed by hipEvents on its
- * launch stream.  kernel_name is the device function's name (e.g. "depth_ingest_kernel"). */
+/* Optional per-kernel timing: on = 1 brackets every kernel launch of this library with hipEvents on its launch stream,
+ * on = n > 1 every n-th launch of each kernel (sampling: a timed dispatch costs host time and keeps the runtime's
+ * completion thread awake), 0 switches it off.  kernel_name is the device function's name (e.g. "depth_ingest_kernel"). */
 int vlfm_profile_enable(int on);
 int vlfm_profile_read(const char* kernel_name, double* mean_ms, int* launches);
+
+/* How the CURRENT device's host waits (hipStreamSynchronize / hipEventSynchronize, also PyTorch's) behave: blocking != 0
+ * selects hipDeviceScheduleBlockingSync (the waiting thread sleeps on the completion interrupt), 0 restores the
+ * runtime's default (hipDeviceScheduleAuto: a busy wait that holds one host core for as long as the GPU runs).  With one
+ * rank per GPU and ~100 ms of queued perception work per step the busy wait is what fills the node's CPU quota; the
+ * reference has no counterpart (its per-step waits are blocking socket reads, vlfm/vlm/server_wrapper.py:78-109). */
+int vlfm_host_wait_mode(int blocking);
 
 /* ---------------------------------------------------------------------------------------------
  * Per-observation pose parameters of one value-map update (64 bytes, uploaded to HBM by the caller).

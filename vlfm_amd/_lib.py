@@ -104,6 +104,7 @@ def lib() -> ctypes.CDLL:
         L.vlfm_last_error.restype = ctypes.c_char_p
         L.vlfm_abi_version.restype = ci
         L.vlfm_profile_enable.argtypes = [ci]
+        L.vlfm_host_wait_mode.argtypes = [ci]
         L.vlfm_profile_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(cd), ctypes.POINTER(ci)]
         L.vlfm_value_map_pose_params.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp, ctypes.POINTER(ci)]
         L.vlfm_cone_template_host.argtypes = [cd, cd, ci, cd, vp, ci, vp, ci, ctypes.POINTER(ci)]
@@ -175,6 +176,16 @@ def profile_read(kernel: str):
 
 def last_error() -> str:
     return lib().vlfm_last_error().decode()
+
+
+def host_wait_blocking(device=None, blocking: bool = True) -> None:
+    """Make host waits on `device` (default: the current one) sleep on the completion interrupt instead of spinning
+    (vlfm_host_wait_mode).  Call it before the device's first stream / allocation: the runtime fixes a queue's wait
+    policy when it creates the queue (measured: set after the model was built, the waiting thread still spun)."""
+    import torch
+
+    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+        check(lib().vlfm_host_wait_mode(int(bool(blocking))), "host_wait_mode")
 
 
 def check(rc: int, what: str = "") -> int:

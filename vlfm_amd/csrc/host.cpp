@@ -223,9 +223,9 @@ extern "C" int vlfm_disc_rows_host(int radius, int32_t* h_halfwidth) {
 
 namespace vlfm {
 namespace {
-struct KernelLog { std::vector<std::pair<hipEvent_t, hipEvent_t>> spans; };
+struct KernelLog { std::vector<std::pair<hipEvent_t, hipEvent_t>> spans; long launches = 0; };
 std::mutex g_prof_mu;
-bool g_prof_on = false;
+int g_prof_every = 0;   // 0 = off, n = bracket every n-th launch of each kernel
 std::map<std::string, KernelLog> g_prof;
 const size_t kMaxSpans = 8192;
 }  // namespace
@@ -236,7 +236,11 @@ ProfileScope* current_profile_scope() { return g_scope; }
 ProfileScope::ProfileScope(const char* name, hipStream_t stream) : name_(name), stream_(stream) {
     prev_ = g_scope;
     g_scope = this;
-    if (!g_prof_on) return;
+    if (!g_prof_every) return;
+    if (g_prof_every > 1) {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (g_prof[name_].launches++ % g_prof_every != 0) return;
+    }
     if (hipEventCreate(&start_) != hipSuccess || hipEventCreate(&stop_) != hipSuccess) return;
     active_ = true;
 }
@@ -251,12 +255,22 @@ ProfileScope::~ProfileScope() {
 }
 }  // namespace vlfm
 
+extern "C" int vlfm_host_wait_mode(int blocking) {
+    hipError_t e = hipSetDeviceFlags(blocking ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        vlfm::set_last_error((std::string("hipSetDeviceFlags: ") + hipGetErrorString(e)).c_str());
+        return VLFM_ERR_HIP;
+    }
+    return VLFM_OK;
+}
+
 extern "C" int vlfm_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(vlfm::g_prof_mu);
     for (auto& kv : vlfm::g_prof)
         for (auto& sp : kv.second.spans) { (void)hipEventDestroy(sp.first); (void)hipEventDestroy(sp.second); }
     vlfm::g_prof.clear();
-    vlfm::g_prof_on = on != 0;
+    vlfm::g_prof_every = on > 0 ? on : 0;
     return VLFM_OK;
 }
 

@@ -92,6 +92,7 @@ class BatchedEpisodes:
                  graph_blip2: Optional[bool] = None, host_inputs: bool = False, select_frontiers: bool = False,
                  pointnav=None, world: str = "rooms") -> None:
         self.device = require_gpu(device)
+        _lib.host_wait_blocking(self.device)   # a rank waiting for its GPU must not hold a host core (bench.py `host`)
         self.E, self.H, self.W, self.S = n_envs, height, width, map_size
         self.fx, self.fy, self.fov = camera_intrinsics(width)
         self.episode_len = episode_len

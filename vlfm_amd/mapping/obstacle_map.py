@@ -18,7 +18,7 @@ import numpy as np
 
 from .. import _lib
 from .base_map import BaseMap, require_gpu
-from .value_map import INGEST_DTYPE, UploadRing, _stream_ptr
+from .value_map import INGEST_DTYPE, UploadRing, _stream_ptr, wait_stream
 
 
 def _wrap_heading(theta):
@@ -348,7 +348,7 @@ class ObstacleMapBatch:
             self._d_fr_stage.copy_(self.frontiers_px_dev[:, :self.READ_FRONTIERS])
             self._h_counts.copy_(self.counts, non_blocking=True)
             self._h_fr.copy_(self._d_fr_stage, non_blocking=True)
-            torch.cuda.current_stream().synchronize()
+            wait_stream()
         counts = self._h_counts.numpy()
         if (counts[:, 1] != 0).any():
             raise RuntimeError("obstacle-map scratch capacity exceeded (CAP_PTS/CAP_CONTOURS/CAP_FRONTIERS)")
@@ -375,7 +375,7 @@ class ObstacleMapBatch:
 
         with torch.cuda.device(self.device):
             self._h_status.copy_(self.status, non_blocking=True)
-            torch.cuda.current_stream().synchronize()
+            wait_stream()
         st = self._h_status.numpy().copy()
         self.status.zero_()
         if (st[:, 0] != 0).any():

@@ -29,6 +29,25 @@ def _stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+_WAIT_EVENTS: Dict[int, Any] = {}
+
+
+def wait_stream() -> None:
+    """Wait for the current stream on a reusable event.  Whether the wait spins or sleeps is the DEVICE's schedule flag
+    (hipDeviceScheduleBlockingSync, set by _lib.host_wait_blocking / vlfm_host_wait_mode): measured on MI355X
+    (tools/host_wait_probe.py) hipEventBlockingSync on the event alone still holds a core for the whole wait, the device
+    flag brings the waiting thread to 0.00 cores.  The per-step read-backs sit behind ~100 ms of queued perception
+    work, so a spinning rank costs a full host core (`host` block of bench.py)."""
+    import torch
+
+    dev = torch.cuda.current_device()
+    ev = _WAIT_EVENTS.get(dev)
+    if ev is None:
+        ev = _WAIT_EVENTS[dev] = torch.cuda.Event(blocking=True)
+    ev.record()
+    ev.synchronize()
+
+
 def _bytes_to_device(buf, device):
     """Upload a ctypes array / bytes object as a uint8 tensor (8-byte aligned by the caching allocator)."""
     import torch
@@ -55,6 +74,7 @@ class UploadRing:
         self.host_np = [h.numpy() for h in self.host]
         self.dev = [torch.empty(nbytes, dtype=torch.uint8, device=device) for _ in range(slots)]
         self.done = [None] * slots
+        self.events = [None] * slots   # one interrupt-driven event per slot, reused
         self.k = 0
 
     def upload(self, buf):
@@ -72,9 +92,10 @@ class UploadRing:
             self.done[i].synchronize()
         self.host_np[i][:n] = src
         self.dev[i][:n].copy_(self.host[i][:n], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        self.done[i] = ev
+        if self.events[i] is None:
+            self.events[i] = torch.cuda.Event(blocking=True)
+        self.events[i].record()
+        self.done[i] = self.events[i]
         return self.dev[i]
 
 
@@ -436,7 +457,7 @@ class ValueMapBatch:
                                                                        _stream_ptr()),
                        "sort_waypoints")
             self._wp_host[:m].copy_(self._wp_out[:m], non_blocking=True)
-            torch.cuda.current_stream().synchronize()
+            wait_stream()
         return self._wp_host[:m].numpy().copy()
 
 
