@@ -43,7 +43,6 @@ def run(mode):
     host = torch.empty(1 << 20, dtype=torch.float16).pin_memory()
     host_dev = None
     if "zerocopy" in opts:
-        from torch.utils.cpp_extension import load_inline  # noqa: F401  (not needed: from_blob-free route below)
         ptr = ctypes.c_void_p()
         rc = hip.hipHostGetDevicePointer(ctypes.byref(ptr), ctypes.c_void_p(host.data_ptr()), 0)
         print(f"  hipHostGetDevicePointer -> {rc}, same address: {ptr.value == host.data_ptr()}")
@@ -87,5 +86,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1:
         run(sys.argv[1])
     else:
-        for mode in ("flags+evblock+d2hs", "flags+evblock+zerocopy", "flags+streamsync+d2hs"):
+        for mode in ("event", "evblock", "flags", "flags+evblock", "flags+streamsync", "flags+devsync",
+                     "flags+evblock+side", "flags+evblock+d2h", "flags+evblock+d2hs", "flags+evblock+zerocopy",
+                     "flags+evblock+two", "flags_late+evblock"):
             subprocess.run([sys.executable, __file__, mode], timeout=60)
