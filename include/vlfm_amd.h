@@ -323,6 +323,20 @@ int vlfm_gemm_f16_nt(const void* d_x, const void* d_w, const void* d_bias, void*
  * Detector-side kernels (vlfm/vlm/yolov7.py:50-110, vlfm/vlm/grounding_dino.py:38-74)
  * ------------------------------------------------------------------------------------------- */
 
+/* One convolution of the yolov7-e6e graph the reference runs in fp16 (vlfm/vlm/yolov7.py:35-48,89), BatchNorm folded:
+ * out = act(conv(x, w) + bias) as an implicit GEMM on the matrix cores (csrc/conv_nhwc.hip), NHWC f16, f32 accumulation.
+ *   d_x    [batch][height][width] pixels, x_pix_stride elements apart; the first `cin` channels of a pixel are read
+ *   d_w    [cout][ksize][ksize][cin] (the channels_last memory of the [cout][cin][k][k] filter); d_bias [cout] or NULL
+ *   d_out  [batch][Ho][Wo] pixels, out_pix_stride elements apart; `cout` channels are written (Ho = (height + 2 pad -
+ *          ksize) / stride + 1, pad = ksize / 2) -- so a layer can write straight into a concatenation buffer
+ *   d_zero at least 16 zero bytes in device memory (what rows in the zero padding fetch)
+ *   act    0 = none, 1 = SiLU
+ * ksize 1 or 3, stride 1 or 2, cin % 64 == 0, cout % 8 == 0, both pixel strides % 8 == 0, tensors < 2^31 elements;
+ * anything else returns VLFM_ERR_INVALID (the caller keeps such a layer on the framework's convolution). */
+int vlfm_conv_nhwc_f16(const void* d_x, const void* d_w, const void* d_bias, void* d_out, const void* d_zero, int batch,
+                       int height, int width, int cin, int cout, int ksize, int stride, int x_pix_stride,
+                       int out_pix_stride, int act, void* stream);
+
 /* Host: cv::computeResizeAreaTab for one axis (cv2.resize INTER_AREA, shrinking or identity).  Returns the tap count
  * used (<= ktaps_capacity) or a negative status.  h_first/h_count [dsize], h_w [dsize][ktaps_capacity]. */
 int vlfm_resize_area_tab_host(int ssize, int dsize, int32_t* h_first, int32_t* h_count, float* h_w, int ktaps_capacity);

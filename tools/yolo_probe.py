@@ -24,10 +24,22 @@ def timed(fn, n=8):
 
 def main(batch):
     dev = torch.device("cuda:0")
-    det = YOLOv7(device=dev, allow_random_init=True)
-    print(det.description, flush=True)
+    hip = YOLOv7(device=dev, allow_random_init=True)
+    print(hip.description, flush=True)
     x = torch.rand(batch, 3, 448, 640, device=dev, dtype=torch.float16)
+    xcl = x.contiguous(memory_format=torch.channels_last)
+    det = YOLOv7(device=dev, allow_random_init=True, hip_conv=False)
     with torch.inference_mode():
+        torch.backends.cudnn.benchmark = "hip-only" not in sys.argv   # the layers left on the framework: MIOpen's find mode
+        t = timed(lambda: hip.model(xcl))
+        print(f"NHWC, conv_nhwc.hip ({hip.hip_convs} layers)     : {t:8.2f} ms / {batch} frames = "
+              f"{hip.gflops * batch / t:.0f} TFLOP/s", flush=True)
+        if "hip-only" in sys.argv:
+            return
+        a, b = hip.model(xcl)[0].float(), det.model(x)[0].float()
+        print(f"  max |difference| of the raw predictions against the NCHW framework path: {float((a - b).abs().max()):.4g} "
+              f"(values up to {float(b.abs().max()):.4g})", flush=True)
+        torch.backends.cudnn.benchmark = False
         print(f"NCHW, BiasAct kernel in place        : {timed(lambda: det.model(x)):8.2f} ms / {batch} frames", flush=True)
         if len(sys.argv) > 2 and sys.argv[2] == "nchw-only":
             return

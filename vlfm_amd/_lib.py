@@ -13,7 +13,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VLFM_LIB_PATH") or os.path.join(_HERE, "libvlfm_amd.so")  # override: diagnostic builds
-SOURCES = ["value_map.hip", "depth_ingest.hip", "depth_holes.hip", "obstacle_map.hip", "vlm_ops.hip", "vit_attention.hip", "detect_ops.hip", "object_cloud.hip", "gemm_f16.hip", "host.cpp"]
+SOURCES = ["value_map.hip", "depth_ingest.hip", "depth_holes.hip", "obstacle_map.hip", "vlm_ops.hip", "vit_attention.hip", "detect_ops.hip", "object_cloud.hip", "gemm_f16.hip", "conv_nhwc.hip", "host.cpp"]
 
 VLFM_OK = 0
 VLFM_ERR_INVALID = -1
@@ -121,6 +121,7 @@ def lib() -> ctypes.CDLL:
         L.vlfm_layernorm_bias_f16.argtypes = [vp, vp, vp, vp, vp, ci, ci, ctypes.c_float, vp]
         L.vlfm_vit_attention_f16.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.c_float, vp]
         L.vlfm_gemm_f16_nt.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
+        L.vlfm_conv_nhwc_f16.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
         L.vlfm_value_map_scratch_bytes.argtypes = [ci, ci]
         L.vlfm_value_map_scratch_bytes.restype = ctypes.c_size_t
         L.vlfm_value_map_update_batched.argtypes = [vp, ci, vp, vp, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci, cd, cd, ci,

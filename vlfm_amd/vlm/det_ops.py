@@ -182,6 +182,82 @@ def patch_hf_deformable_attention(model) -> int:
     return n
 
 
+_ZERO_PAGES: Dict[str, torch.Tensor] = {}
+
+
+def conv_nhwc_supported(cin: int, cout: int, ksize, stride, padding=None, groups: int = 1, dilation=(1, 1)) -> bool:
+    """The layer shapes csrc/conv_nhwc.hip takes (vlfm_conv_nhwc_f16) once ``pack_conv_weight`` has padded the channel counts to
+    multiples of 8: square 1x1 / 3x3 filters with 'same' padding, stride 1 or 2, no groups, no dilation."""
+    k = ksize if isinstance(ksize, int) else (ksize[0] if ksize[0] == ksize[1] else -1)
+    s = stride if isinstance(stride, int) else (stride[0] if stride[0] == stride[1] else -1)
+    pad_ok = padding is None or padding in (k // 2, (k // 2, k // 2))
+    return k in (1, 3) and s in (1, 2) and pad_ok and groups == 1 and tuple(dilation) == (1, 1) and cin > 0 and cout > 0
+
+
+def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor] = None):
+    """[Cout, Cin, k, k] (+ bias) -> the operands of ``conv_nhwc``: f16 filter rows [Cout_p, Kpad] holding each filter's
+    [k][k][Cin_p] weights (the channels_last order) followed by zeros up to Kpad = round_up(k * k * Cin_p, 64), and the f16 bias
+    [Cout_p]; Cin_p / Cout_p = the channel counts rounded up to multiples of 8 with zero weights (the 12-channel stem reads a
+    16-channel input, the 255-channel Detect heads write 256 channels of which the caller keeps 255)."""
+    cout, cin, k, k2 = weight.shape
+    assert k == k2
+    cin_p, cout_p = (cin + 7) // 8 * 8, (cout + 7) // 8 * 8
+    w = torch.zeros((cout_p, k, k, cin_p), dtype=torch.float16, device=weight.device)
+    w[:cout, :, :, :cin] = weight.detach().permute(0, 2, 3, 1).to(torch.float16)
+    ktot = k * k * cin_p
+    kpad = (ktot + 63) // 64 * 64
+    rows = torch.zeros((cout_p, kpad), dtype=torch.float16, device=weight.device)
+    rows[:, :ktot] = w.reshape(cout_p, ktot)
+    b = None
+    if bias is not None:
+        b = torch.zeros(cout_p, dtype=torch.float16, device=weight.device)
+        b[:cout] = bias.detach().to(torch.float16)
+    return rows, b
+
+
+def conv_nhwc(x: torch.Tensor, w_rows: torch.Tensor, bias: Optional[torch.Tensor], ksize: int, stride: int = 1,
+              act: Optional[str] = "silu", out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(conv2d(x, w, padding=ksize // 2, stride) + bias) on the matrix cores (csrc/conv_nhwc.hip): one convolution of the
+    yolov7-e6e graph (vlfm/vlm/yolov7.py:89) as an implicit GEMM, bias + SiLU in the epilogue.
+      x       [B, Cin, H, W] f16 whose MEMORY is NHWC: a channels_last tensor or a channel slice of one (anything else is
+              converted, which costs a pass); Cin % 8 == 0 (``pack_conv_weight`` pads the filter; pad the input alike)
+      w_rows, bias   from ``pack_conv_weight``
+      out     optional [B, Cout_p, Ho, Wo] f16 view with NHWC memory (e.g. a channel slice of a concatenation buffer)
+    Returns a channels_last [B, Cout_p, Ho, Wo] tensor (or ``out``)."""
+    assert x.is_cuda and x.dtype == torch.float16 and x.dim() == 4 and w_rows.dtype == torch.float16 and w_rows.is_contiguous()
+    B, cin, H, W = x.shape
+    cout, k = w_rows.shape[0], int(ksize)
+    assert cin % 8 == 0 and cout % 8 == 0 and w_rows.shape[1] == (k * k * cin + 63) // 64 * 64, (tuple(w_rows.shape), cin, k)
+    assert bias is None or (bias.dtype == torch.float16 and bias.is_contiguous() and bias.numel() == cout)
+
+    def nhwc_pixel_stride(t: torch.Tensor) -> int:
+        b, c, h, w = t.shape
+        ps = t.stride(3) if w > 1 else (t.stride(2) if h > 1 else (t.stride(0) if b > 1 else c))
+        ok = ((c == 1 or t.stride(1) == 1) and (w == 1 or t.stride(3) == ps) and (h == 1 or t.stride(2) == w * ps)
+              and (b == 1 or t.stride(0) == h * w * ps) and ps >= c and ps % 8 == 0 and t.data_ptr() % 16 == 0)
+        return ps if ok else -1
+
+    xp = nhwc_pixel_stride(x)
+    if xp < 0:
+        x = x.contiguous(memory_format=torch.channels_last)
+        xp = nhwc_pixel_stride(x)
+        assert xp > 0
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    if out is None:
+        out = torch.empty((B, cout, Ho, Wo), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
+    op = nhwc_pixel_stride(out)
+    assert out.shape == (B, cout, Ho, Wo) and out.dtype == torch.float16 and op > 0, "out must be an NHWC-memory f16 view"
+    key = str(x.device)
+    if key not in _ZERO_PAGES:
+        _ZERO_PAGES[key] = torch.zeros(64, dtype=torch.float16, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().vlfm_conv_nhwc_f16(x.data_ptr(), w_rows.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                                 out.data_ptr(), _ZERO_PAGES[key].data_ptr(), B, H, W, cin, cout, k, int(stride),
+                                                 xp, op, {None: 0, "silu": 1}[act], _stream()), "conv_nhwc_f16")
+    return out
+
+
 def fold_batchnorm_(model) -> int:
     """Inference-time folding of every eval-mode BatchNorm2d that directly follows a Conv2d inside an ``nn.Sequential`` (the
     conv + bn + SiLU triples of the YOLOv7-class network, TinyViT's ``Conv2d_BN``): the convolution gets the scaled weights,

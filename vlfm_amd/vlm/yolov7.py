@@ -35,7 +35,7 @@ class YOLOv7:
     builds a same-topology miniature for tests; the deployed network is 1.0."""
 
     def __init__(self, weights: Optional[str] = None, image_size: int = 640, half_precision: bool = True, device=None,
-                 allow_random_init: bool = False, width_multiple: float = 1.0) -> None:
+                 allow_random_init: bool = False, width_multiple: float = 1.0, hip_conv: bool = True) -> None:
         from ..mapping.base_map import require_gpu
 
         self.device = require_gpu(device)
@@ -66,6 +66,11 @@ class YOLOv7:
                                 f"{E6E_PUBLISHED['gflops_at_1280x1280'] * self.in_hw[0] * self.in_hw[1] / 1280.0 ** 2:.1f} here)")
         if self.half_precision:
             self.model.half()
+        # fp16 on the GPU: NHWC execution with the 1x1 / 3x3 layers as implicit GEMMs on the matrix cores (csrc/conv_nhwc.hip)
+        self.hip_convs = 0
+        if isinstance(self.model, YoloV7E6E) and self.half_precision and hip_conv:
+            self.hip_convs = self.model.use_hip_conv_()
+            self.description += f"; {self.hip_convs} convolutions on conv_nhwc.hip"
 
     def _load(self, path: str):
         try:
@@ -89,6 +94,8 @@ class YOLOv7:
         B, H, W, _ = images_u8.shape
         img = det_ops.resize_area(images_u8, self.in_hw[0], self.in_hw[1],
                                   torch.float16 if self.half_precision else torch.float32)
+        if self.hip_convs:
+            img = img.contiguous(memory_format=torch.channels_last)
         pred = self.model(img)
         pred = pred[0] if isinstance(pred, (tuple, list)) else pred
         dets = det_ops.non_max_suppression(pred.float(), conf_thres, iou_thres, classes=classes, agnostic=agnostic_nms)

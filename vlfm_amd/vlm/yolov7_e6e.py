@@ -50,8 +50,32 @@ class Conv(nn.Module):
         self.bn = nn.BatchNorm2d(c2, eps=1e-3, momentum=0.03)   # yolov7 sets these in Model.__init__ (initialize_weights)
         self.act = nn.SiLU(inplace=True)
 
+    hip_conv = False   # set by use_hip_conv_()
+
     def forward(self, x):
+        if self.hip_conv and x.is_cuda and x.dtype == torch.float16:
+            from .det_ops import conv_nhwc
+
+            c = self.conv
+            if x.shape[1] != self.cin_p:     # the 12-channel stem: zero channels up to the filter's padded width
+                x = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, self.cin_p - x.shape[1]))
+            y = conv_nhwc(x, self.w_rows, self.b_rows, c.kernel_size[0], c.stride[0], "silu")
+            return y if y.shape[1] == c.out_channels else y[:, :c.out_channels]
         return self.act(self.bn(self.conv(x)))
+
+    def use_hip_conv_(self) -> bool:
+        """After fuse_() and .half(): evaluate this layer as an implicit GEMM on the matrix cores with bias + SiLU in the epilogue
+        (det_ops.conv_nhwc -> csrc/conv_nhwc.hip).  Every Conv of the e6e graph qualifies (1x1 / 3x3, stride 1 / 2)."""
+        from .det_ops import conv_nhwc_supported, pack_conv_weight
+        from .ops import BiasAct
+
+        c = self.conv
+        if (isinstance(self.bn, BiasAct) and self.bn.act == "silu" and c.weight.is_cuda and c.weight.dtype == torch.float16
+                and conv_nhwc_supported(c.in_channels, c.out_channels, c.kernel_size, c.stride, c.padding, c.groups, c.dilation)):
+            self.w_rows, self.b_rows = pack_conv_weight(c.weight, self.bn.bias)
+            self.cin_p = (c.in_channels + 7) // 8 * 8
+            self.hip_conv = True
+        return self.hip_conv
 
     def fuse_(self) -> None:
         """yolov7's Model.fuse() [ext] for this triple: BatchNorm folded into the convolution's weights; the folded bias and
@@ -128,11 +152,25 @@ class Detect(nn.Module):
         self.register_buffer("anchor_grid", a.clone().view(self.nl, 1, -1, 1, 1, 2))
         self.m = nn.ModuleList(nn.Conv2d(x, self.no * self.na, 1) for x in ch)
         self.stride = STRIDES[: self.nl]
+        self.hip_rows = None
+
+    def use_hip_conv_(self) -> int:
+        """The three / four 1x1 head convolutions (255 outputs, written as 256) on csrc/conv_nhwc.hip; f16 weights on the GPU."""
+        from .det_ops import pack_conv_weight
+
+        if all(m.weight.is_cuda and m.weight.dtype == torch.float16 for m in self.m):
+            self.hip_rows = [pack_conv_weight(m.weight, m.bias) for m in self.m]
+        return len(self.hip_rows or ())
 
     def forward(self, xs):
         z = []
         for i, x in enumerate(xs):
-            y = self.m[i](x)
+            if self.hip_rows is not None and x.is_cuda and x.dtype == torch.float16:
+                from .det_ops import conv_nhwc
+
+                y = conv_nhwc(x, self.hip_rows[i][0], self.hip_rows[i][1], 1, 1, None)[:, :self.no * self.na]
+            else:
+                y = self.m[i](x)
             b, _, ny, nx = y.shape
             y = y.view(b, self.na, self.no, ny, nx).permute(0, 1, 3, 4, 2).sigmoid()
             gy, gx = torch.meshgrid(torch.arange(ny, device=y.device), torch.arange(nx, device=y.device), indexing="ij")
@@ -249,6 +287,13 @@ class YoloV7E6E(nn.Module):
             if isinstance(m, Conv):
                 m.fuse_()
         return self
+
+    def use_hip_conv_(self) -> int:
+        """NHWC execution: every convolution on csrc/conv_nhwc.hip, the rest of the graph (pooling, concatenation, upsampling,
+        the box decode) on the framework's channels_last kernels.  Call after fuse_() and .half() on the GPU; returns the
+        number of layers taken."""
+        self.to(memory_format=torch.channels_last)
+        return sum(int(m.use_hip_conv_()) for m in self.modules() if isinstance(m, (Conv, Detect)))
 
     def init_random(self, seed: int = 0) -> "YoloV7E6E":
         """Kaiming-uniform convolutions (PyTorch's default), BatchNorm at identity, and yolov7's Detect._initialize_biases [ext]
