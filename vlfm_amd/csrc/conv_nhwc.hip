@@ -14,8 +14,8 @@
 // tap falls into the zero padding (or beyond M) fetch from a 16-byte zero page instead -- no im2col buffer, no padded copy.
 // LDS layout, the XOR slot permutation that makes the MFMA fragment reads conflict-free, the operand roles (A-operand = filter rows,
 // so a lane ends up with 4 consecutive output channels of one pixel) and the transposing epilogue are those of gemm_f16.hip.
-// Tile: 256 pixels x BN channels, BN in {64, 128, 256} chosen per layer (8 wavefronts as 8x1, 4x2, 4x2); two LDS buffers; the
-// lock-step schedule.  Pixel strides of input and output are arguments: a layer can read a channel slice of a concatenation buffer
+// Tile: BM pixels x BN channels from seven shapes between 256 x 256 and 64 x 64, chosen per layer by a cost estimate (pick_cfg);
+// 8 wavefronts; two LDS buffers; the lock-step schedule.  Pixel strides of input and output are arguments: a layer can read a channel slice of a concatenation buffer
 // and write into one.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -34,7 +34,6 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 using lds_ptr = __attribute__((address_space(3))) unsigned char*;
 using gbl_ptr = const __attribute__((address_space(1))) unsigned char*;
 
-constexpr int BM = 256;            // pixels per tile
 constexpr int GK = 64;             // channels per K-tile
 constexpr int ROWB = GK * 2;       // bytes per staged row
 
@@ -58,12 +57,13 @@ __device__ inline float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + 
 // GEN = true : Cin % 8 == 0; k runs over (tap, channel) continuously, every 16-byte slot (8 channels) decodes its own tap, and K is
 //              padded to a multiple of 64 with zero weights (the filter rows are Kpad = round_up(taps * Cin, 64) elements apart; slots
 //              past the last tap fetch the zero page) -- the 80 / 160 / 480-channel layers and the 12(16)-channel stem.
-template <int BN, int WM, int WN, int ACT, bool GEN>
+template <int BM, int BN, int WM, int WN, int ACT, bool GEN>
 __global__ __launch_bounds__(512) void conv_nhwc_kernel(ConvArgs a) {
     constexpr int FA = WN / 16, FB = WM / 16;       // fragments per wavefront: filter rows, pixel rows
     constexpr int WAVES_M = BM / WM;
     constexpr int WOPER = BN * ROWB, BUF = WOPER + BM * ROWB;
     constexpr int WCH = BN / 64;                    // 8-row chunks of the filter tile each wavefront stages
+    constexpr int XCH = BM / 64;                    // ... and of the pixel tile
     constexpr int EPI_ROW = WN * 2 + 16;            // epilogue staging row stride (conflict-free 8-byte writes, 16-byte reads)
     static_assert((BM / WM) * (BN / WN) == 8, "8 wavefronts");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -86,18 +86,18 @@ __global__ __launch_bounds__(512) void conv_nhwc_kernel(ConvArgs a) {
 
     // ---- the four pixel rows and WCH filter rows this lane stages in every K-tile
     const int sub = lane >> 3, p = lane & 7;
-    int x_off[4], x_iy[4], x_ix[4];
-    int slot2[2];                       // the logical 16-byte slot this lane fetches in its even / odd rows (chunk parity)
+    int x_off[XCH], x_iy[XCH], x_ix[XCH];
+    int slot2[2];                       // the logical 16-byte slot this lane fetches in rows of an even / odd chunk
     slot2[0] = p ^ (sub >> 1);
     slot2[1] = p ^ (4 + (sub >> 1));
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int r = (wave * 4 + j) * 8 + sub, m = m0 + r;     // (r >> 1) & 7 == (j & 1) * 4 + (sub >> 1)
+    for (int j = 0; j < XCH; j++) {
+        const int r = (wave * XCH + j) * 8 + sub, m = m0 + r;     // (r >> 1) & 7 == (chunk & 1) * 4 + (sub >> 1)
         if (m < a.M) {
             const int hw = a.Ho * a.Wo, b = m / hw, rem = m - b * hw, oy = rem / a.Wo, ox = rem - oy * a.Wo;
             x_iy[j] = oy * a.stride - a.pad;
             x_ix[j] = ox * a.stride - a.pad;
-            x_off[j] = ((b * a.H + x_iy[j]) * a.W + x_ix[j]) * a.x_pix + (GEN ? 0 : slot2[j & 1] * 8);
+            x_off[j] = ((b * a.H + x_iy[j]) * a.W + x_ix[j]) * a.x_pix + (GEN ? 0 : slot2[(wave * XCH + j) & 1] * 8);
         } else {
             x_iy[j] = -(1 << 20); x_ix[j] = 0; x_off[j] = 0;
         }
@@ -128,11 +128,11 @@ __global__ __launch_bounds__(512) void conv_nhwc_kernel(ConvArgs a) {
             tap_off[0] = tap_off[1] = (ty[0] * a.W + tx[0]) * a.x_pix + c0;
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int h = j & 1;
+        for (int j = 0; j < XCH; j++) {
+            const int h = (wave * XCH + j) & 1;
             const bool ok = tap_ok[h] && (unsigned)(x_iy[j] + ty[h]) < (unsigned)a.H && (unsigned)(x_ix[j] + tx[h]) < (unsigned)a.W;
             const _Float16* gx = ok ? a.x + (x_off[j] + tap_off[h]) : a.zero;
-            const int dst = __builtin_amdgcn_readfirstlane(buf + WOPER + (wave * 4 + j) * 1024);
+            const int dst = __builtin_amdgcn_readfirstlane(buf + WOPER + (wave * XCH + j) * 1024);
             __builtin_amdgcn_global_load_lds((gbl_ptr)gx, lds + dst, 16, 0, 0);
         }
 #pragma unroll
@@ -232,17 +232,19 @@ __global__ __launch_bounds__(512) void conv_nhwc_kernel(ConvArgs a) {
     }
 }
 
-template <int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN>
 constexpr int lds_bytes() {
     constexpr int ops = 2 * (BN + BM) * ROWB, epi = 8 * WM * (WN * 2 + 16);
     return ops > epi ? ops : epi;
 }
 
-template <int BN, int WM, int WN, bool GEN>
-static int launch(const ConvArgs& a, int act, hipStream_t stream) {
-    constexpr int LDS = lds_bytes<BN, WM, WN>();
-    void (*const k_silu)(ConvArgs) = conv_nhwc_kernel<BN, WM, WN, ACT_SILU, GEN>;
-    void (*const k_none)(ConvArgs) = conv_nhwc_kernel<BN, WM, WN, ACT_NONE, GEN>;
+template <int BM, int BN, int WM, int WN, bool GEN>
+static int launch(ConvArgs a, int act, hipStream_t stream) {
+    constexpr int LDS = lds_bytes<BM, BN, WM, WN>();
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (a.Cout + BN - 1) / BN;
+    void (*const k_silu)(ConvArgs) = conv_nhwc_kernel<BM, BN, WM, WN, ACT_SILU, GEN>;
+    void (*const k_none)(ConvArgs) = conv_nhwc_kernel<BM, BN, WM, WN, ACT_NONE, GEN>;
     static LdsOptIn opt[2];
     if (!opt[act].ensure(reinterpret_cast<const void*>(act == ACT_SILU ? k_silu : k_none), LDS))
         return fail(VLFM_ERR_HIP, "conv_nhwc_f16: cannot opt in to the LDS size");
@@ -253,11 +255,40 @@ static int launch(const ConvArgs& a, int act, hipStream_t stream) {
     return check_launch("conv_nhwc_kernel");
 }
 
+// The tile shapes (pixels x channels; 8 wavefronts each): the big ones have the best ratio of MFMA work to LDS traffic, the small ones
+// fill the chip when a layer has few pixels (7x10 and 14x20 feature maps) and waste less on narrow layers.
+struct TileCfg { int bm, bn; double rate; };      // rate: relative throughput of a CU running this shape (tools/conv_nhwc_probe.py sweep:
+                                                  // with these the pick is within 1.3 % of the best shape summed over the probe layers)
+static const TileCfg kCfg[] = {{256, 256, 0.85}, {256, 128, 1.00}, {256, 64, 0.95}, {128, 128, 1.05},
+                               {128, 64, 0.85},  {64, 128, 0.82},  {64, 64, 0.62}};
+constexpr int kNumCfg = 7;
+
 template <bool GEN>
-static int launch_bn(const ConvArgs& a, int bn, int act, hipStream_t stream) {
-    if (bn == 256) return launch<256, 64, 128, GEN>(a, act, stream);
-    if (bn == 128) return launch<128, 64, 64, GEN>(a, act, stream);
-    return launch<64, 32, 64, GEN>(a, act, stream);
+static int launch_cfg(const ConvArgs& a, int cfg, int act, hipStream_t stream) {
+    switch (cfg) {
+        case 0: return launch<256, 256, 64, 128, GEN>(a, act, stream);
+        case 1: return launch<256, 128, 64, 64, GEN>(a, act, stream);
+        case 2: return launch<256, 64, 32, 64, GEN>(a, act, stream);
+        case 3: return launch<128, 128, 32, 64, GEN>(a, act, stream);
+        case 4: return launch<128, 64, 32, 32, GEN>(a, act, stream);
+        case 5: return launch<64, 128, 16, 64, GEN>(a, act, stream);
+        default: return launch<64, 64, 16, 32, GEN>(a, act, stream);
+    }
+}
+
+// Estimated time of a layer under a tile shape, in units of (256 x 256 x 64) MFMA tiles at the big shape's rate: the busiest CU works
+// through ceil(tiles / 256) tiles (workgroups are dealt round-robin), each costing its padded volume over the shape's rate.
+static int pick_cfg(int M, int cout, int ktiles) {
+    int best = 0;
+    double best_t = 1e300;
+    for (int c = 0; c < kNumCfg; c++) {
+        const long long tiles = (long long)((M + kCfg[c].bm - 1) / kCfg[c].bm) * ((cout + kCfg[c].bn - 1) / kCfg[c].bn);
+        const double per_cu = (double)((tiles + 255) / 256);
+        // + 1.5 K-tiles of fixed cost per tile: prologue (first loads in flight) and the epilogue's store
+        const double t = per_cu * (kCfg[c].bm / 256.0) * (kCfg[c].bn / 256.0) * (ktiles + 1.5) / kCfg[c].rate;
+        if (t < best_t) { best_t = t; best = c; }
+    }
+    return best;
 }
 
 }  // namespace conv
@@ -295,15 +326,9 @@ extern "C" int vlfm_conv_nhwc_f16(const void* d_x, const void* d_w, const void* 
         return fail(VLFM_ERR_INVALID, "conv_nhwc_f16: tensors of 2^31 elements or more are not supported (split the batch)");
     a.M = batch * a.Ho * a.Wo;
     a.ktiles_per_tap = cin / conv::GK;
-    // channel tile: the one that wastes the fewest padded channels, the wider one on a tie (fewer passes over the activation)
-    int bn = 64, best = 1 << 30;
-    for (int cand : {256, 128, 64}) {
-        const int waste = (cout + cand - 1) / cand * cand - cout;
-        if (waste < best) { best = waste; bn = cand; }
-    }
-    if (const char* e = getenv("VLFM_CONV_BN")) { const int v = atoi(e); if (v == 64 || v == 128 || v == 256) bn = v; }
-    a.tiles_m = (a.M + conv::BM - 1) / conv::BM;
-    a.tiles_n = (cout + bn - 1) / bn;
-    return (cin % conv::GK) == 0 ? conv::launch_bn<false>(a, bn, act, (hipStream_t)stream)
-                                 : conv::launch_bn<true>(a, bn, act, (hipStream_t)stream);
+    const int ktiles = (a.taps * cin + conv::GK - 1) / conv::GK;
+    int cfg = conv::pick_cfg(a.M, cout, ktiles);
+    if (const char* e = getenv("VLFM_CONV_CFG")) { const int v = atoi(e); if (v >= 0 && v < conv::kNumCfg) cfg = v; }   // tuning aid
+    return (cin % conv::GK) == 0 ? conv::launch_cfg<false>(a, cfg, act, (hipStream_t)stream)
+                                 : conv::launch_cfg<true>(a, cfg, act, (hipStream_t)stream);
 }

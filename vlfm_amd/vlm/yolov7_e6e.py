@@ -52,16 +52,29 @@ class Conv(nn.Module):
 
     hip_conv = False   # set by use_hip_conv_()
 
-    def forward(self, x):
-        if self.hip_conv and x.is_cuda and x.dtype == torch.float16:
+    def forward(self, x, out=None):
+        """``out``: an NHWC-memory view [B, c2, Ho, Wo] to write into (a channel slice of a concatenation buffer); only on the
+        HIP path (callers check ``takes_out(x)`` first)."""
+        if self.takes_hip(x):
             from .det_ops import conv_nhwc
 
             c = self.conv
             if x.shape[1] != self.cin_p:     # the 12-channel stem: zero channels up to the filter's padded width
                 x = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, self.cin_p - x.shape[1]))
-            y = conv_nhwc(x, self.w_rows, self.b_rows, c.kernel_size[0], c.stride[0], "silu")
+            y = conv_nhwc(x, self.w_rows, self.b_rows, c.kernel_size[0], c.stride[0], "silu", out=out)
             return y if y.shape[1] == c.out_channels else y[:, :c.out_channels]
+        assert out is None
         return self.act(self.bn(self.conv(x)))
+
+    def takes_hip(self, x) -> bool:
+        return self.hip_conv and x.is_cuda and x.dtype == torch.float16
+
+    def takes_out(self, x) -> bool:
+        return self.takes_hip(x) and self.conv.out_channels % 8 == 0
+
+    def out_hw(self, h: int, w: int):
+        k, s = self.conv.kernel_size[0], self.conv.stride[0]
+        return (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
 
     def use_hip_conv_(self) -> bool:
         """After fuse_() and .half(): evaluate this layer as an implicit GEMM on the matrix cores with bias + SiLU in the epilogue
@@ -108,7 +121,15 @@ class DownC(nn.Module):
         self.mp = nn.MaxPool2d(kernel_size=k, stride=k)
 
     def forward(self, x):
-        return torch.cat((self.cv2(self.cv1(x)), self.cv3(self.mp(x))), dim=1)
+        t, p = self.cv1(x), self.mp(x)
+        if self.cv2.takes_out(t) and self.cv3.takes_out(p) and self.cv2.out_hw(*t.shape[2:]) == tuple(p.shape[2:]):
+            ca, cb = self.cv2.conv.out_channels, self.cv3.conv.out_channels     # both halves straight into the concatenation
+            buf = torch.empty((x.shape[0], ca + cb, p.shape[2], p.shape[3]), dtype=x.dtype, device=x.device,
+                              memory_format=torch.channels_last)
+            self.cv2(t, out=buf[:, :ca])
+            self.cv3(p, out=buf[:, ca:])
+            return buf
+        return torch.cat((self.cv2(t), self.cv3(p)), dim=1)
 
 
 class SPPCSPC(nn.Module):
@@ -124,7 +145,18 @@ class SPPCSPC(nn.Module):
         self.cv7 = Conv(2 * c_, c2, 1, 1)
 
     def forward(self, x):
-        x1 = self.cv4(self.cv3(self.cv1(x)))
+        t = self.cv3(self.cv1(x))
+        if self.cv4.takes_out(t) and self.cv6.takes_out(t) and self.cv2.takes_out(x):
+            c_, (B, _, h, w) = self.cv4.conv.out_channels, x.shape
+            pyr = torch.empty((B, 4 * c_, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            x1 = self.cv4(t, out=pyr[:, :c_])
+            for i, m in enumerate(self.m):
+                pyr[:, (i + 1) * c_:(i + 2) * c_].copy_(m(x1))
+            two = torch.empty((B, 2 * c_, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            self.cv6(self.cv5(pyr), out=two[:, :c_])
+            self.cv2(x, out=two[:, c_:])
+            return self.cv7(two)
+        x1 = self.cv4(t)
         y1 = self.cv6(self.cv5(torch.cat([x1] + [m(x1) for m in self.m], 1)))
         return self.cv7(torch.cat((y1, self.cv2(x)), dim=1))
 
@@ -275,6 +307,8 @@ class YoloV7E6E(nn.Module):
             chans.append(c2)
             self.froms.append(f)
         self.model = nn.ModuleList(mods)
+        self._out_channels = list(chans)
+        self.cat_plan, self.out_slot = {}, {}
         # which outputs are read again later (yolov7's `save` list): everything else is dropped as soon as it is consumed
         self.keep = set()
         for i, f in enumerate(self.froms):
@@ -293,7 +327,9 @@ class YoloV7E6E(nn.Module):
         the box decode) on the framework's channels_last kernels.  Call after fuse_() and .half() on the GPU; returns the
         number of layers taken."""
         self.to(memory_format=torch.channels_last)
-        return sum(int(m.use_hip_conv_()) for m in self.modules() if isinstance(m, (Conv, Detect)))
+        n = sum(int(m.use_hip_conv_()) for m in self.modules() if isinstance(m, (Conv, Detect)))
+        self._plan_concats()
+        return n
 
     def init_random(self, seed: int = 0) -> "YoloV7E6E":
         """Kaiming-uniform convolutions (PyTorch's default), BatchNorm at identity, and yolov7's Detect._initialize_biases [ext]
@@ -315,14 +351,54 @@ class YoloV7E6E(nn.Module):
                 b[:, 5:] = math.log(0.6 / (self.nc - 0.99))
         return self
 
+    def _plan_concats(self) -> None:
+        """For the NHWC path: which top-level convolutions can write straight into the buffer of the Concat that reads them (the
+        ELAN blocks concatenate five convolution outputs each; torch.cat would copy every one of them once more).  A producer
+        feeds at most one buffer in place; whatever else a Concat reads (an Upsample, a block output, a producer already placed
+        elsewhere) is copied into its slice at the Concat."""
+        self.out_slot: Dict[int, Tuple[int, int, int]] = {}      # producer index -> (concat index, channel offset, total channels)
+        self.cat_plan: Dict[int, List[Tuple[int, int, int, bool]]] = {}   # concat index -> [(source, offset, channels, in place)]
+        chans = self._out_channels
+        for i, (m, f) in enumerate(zip(self.model, self.froms)):
+            if not isinstance(m, Concat):
+                continue
+            srcs = [i - 1 if j == -1 else (j if j >= 0 else i + j) for j in f]
+            total, off, plan = sum(chans[j] for j in srcs), 0, []
+            for j in srcs:
+                prod = self.model[j]
+                placed = (isinstance(prod, Conv) and prod.hip_conv and prod.conv.out_channels % 8 == 0 and off % 8 == 0
+                          and total % 8 == 0 and j not in self.out_slot)
+                if placed:
+                    self.out_slot[j] = (i, off, total)
+                plan.append((j, off, chans[j], placed))
+                off += chans[j]
+            if any(p[3] for p in plan):
+                self.cat_plan[i] = plan
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         outs: Dict[int, torch.Tensor] = {}
+        bufs: Dict[int, torch.Tensor] = {}       # concatenation buffers of this forward (NHWC path)
+        planned = bool(self.cat_plan) and x.is_cuda and x.dtype == torch.float16
         for i, (m, f) in enumerate(zip(self.model, self.froms)):
             if isinstance(f, int):
                 inp = x if f == -1 else outs[f if f >= 0 else i + f]
             else:
                 inp = [x if j == -1 else outs[j if j >= 0 else i + j] for j in f]
-            x = m(inp)
+            if planned and i in self.out_slot:
+                ci, off, total = self.out_slot[i]
+                if ci not in bufs:
+                    ho, wo = m.out_hw(inp.shape[2], inp.shape[3])
+                    bufs[ci] = torch.empty((inp.shape[0], total, ho, wo), dtype=inp.dtype, device=inp.device,
+                                           memory_format=torch.channels_last)
+                x = m(inp, out=bufs[ci][:, off:off + m.conv.out_channels])
+            elif planned and i in self.cat_plan:
+                buf = bufs.pop(i)
+                for (j, off, c, placed), t in zip(self.cat_plan[i], inp):
+                    if not placed:
+                        buf[:, off:off + c].copy_(t)
+                x = buf
+            else:
+                x = m(inp)
             if i in self.keep:
                 outs[i] = x
         return x
