@@ -19,5 +19,13 @@ VLFM_COMMIT=${VLFM_COMMIT:-unknown} bash tools/pmc_traffic.sh 16 1280 720 sync >
 cp profiles/pmc_traffic.json $O/pmc_traffic.json
 bash tools/pmc_sq.sh ingest depth_ingest -- python $R/tools/ingest_probe.py 4 > /dev/null 2>&1; cp gpurun_out/pmc_sq_ingest.txt $O/r03_ingest_sq_pmc.txt
 cp gpurun_out/host_busy.json $O/host_busy.json 2>/dev/null
+# yolov7-e6e on conv_nhwc.hip: per-layer-shape table, tile-shape sweep, rocprofv3 kernel stats of the forward alone
+(timeout 200 python tools/yolo_layer_probe.py 64 2>&1 | grep -v amdgpu.ids) > $O/r03_yolo_e6e_layers_b64.txt 2>&1
+(timeout 200 python tools/yolo_layer_probe.py 128 2>&1 | grep -v amdgpu.ids) > $O/r03_yolo_e6e_layers_b128.txt 2>&1
+(timeout 200 python tools/conv_nhwc_probe.py 64 sweep 2>&1 | grep -v amdgpu.ids) > $O/r03_conv_nhwc_tile_sweep_b64.txt 2>&1
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/$O/prof_yolo -o p -- python $R/tools/yolo_probe.py 64 hip-only > $R/$O/prof_yolo.log 2>&1
+cd $R
+python tools/rocprof_summary.py $O/prof_yolo/p_results.db $O/r03_yolo_e6e_b64_kernel_stats.csv > $O/summary_yolo.log 2>&1
 find gpurun_out -name "*.db" -size +20M -delete
 ls $O

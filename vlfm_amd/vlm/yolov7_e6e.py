@@ -272,6 +272,7 @@ class YoloV7E6E(nn.Module):
         is 1.0 -- smaller values give same-topology miniatures for tests."""
         super().__init__()
         self.nc = nc
+        self.ch_in, self.width_multiple = ch, width_multiple
 
         def w(c: int) -> int:
             return c if width_multiple == 1.0 else max(8, int(math.ceil(c * width_multiple / 8) * 8))
@@ -417,6 +418,9 @@ def gflops(model: nn.Module, height: int, width: int) -> float:
     def hook(m, inp, out):
         total[0] += 2.0 * out.numel() * m.kernel_size[0] * m.kernel_size[1] * (m.in_channels // m.groups)
 
+    if isinstance(model, YoloV7E6E):      # a parameter-free twin on the meta device: same layer shapes, no memory, no kernels
+        with torch.device("meta"):
+            model = YoloV7E6E(model.nc, model.ch_in, model.width_multiple).eval()
     for m in model.modules():
         if isinstance(m, nn.Conv2d):
             hooks.append(m.register_forward_hook(hook))
