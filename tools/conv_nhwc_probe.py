@@ -26,6 +26,9 @@ def timed(fn, n=10):
     return (time.perf_counter() - t0) / n
 
 
+NCFG = 7
+
+
 def sweep(batch):
     """Every tile shape (VLFM_CONV_CFG 0..6) and the library's own pick on every probe shape."""
     dev = torch.device("cuda:0")
@@ -38,15 +41,15 @@ def sweep(batch):
         rows, bias = det_ops.pack_conv_weight(w, torch.randn(cout, device=dev))
         flop = 2.0 * batch * H * W * cout * cin * k * k
         ts = []
-        for cfg in list(range(7)) + [None]:
+        for cfg in list(range(NCFG)) + [None]:
             if cfg is None:
                 os.environ.pop("VLFM_CONV_CFG", None)
             else:
                 os.environ["VLFM_CONV_CFG"] = str(cfg)
             ts.append(timed(lambda: det_ops.conv_nhwc(x, rows, bias, k, s, "silu"), n=6))
-        best = min(range(7), key=lambda i: ts[i])
-        print(f"{cin:5d}->{cout:5d} k{k} s{s} {H:4d}x{W:<4d}: " + " ".join(f"{t * 1e6:7.1f}" for t in ts[:7])
-              + f" | {ts[7] * 1e6:7.1f}  best cfg {best} = {flop / ts[best] / 1e12:5.0f} TFLOP/s, auto {flop / ts[7] / 1e12:5.0f}",
+        best = min(range(NCFG), key=lambda i: ts[i])
+        print(f"{cin:5d}->{cout:5d} k{k} s{s} {H:4d}x{W:<4d}: " + " ".join(f"{t * 1e6:7.1f}" for t in ts[:NCFG])
+              + f" | {ts[NCFG] * 1e6:7.1f}  best cfg {best} = {flop / ts[best] / 1e12:5.0f} TFLOP/s, auto {flop / ts[NCFG] / 1e12:5.0f}",
               flush=True)
 
 
