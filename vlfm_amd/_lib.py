@@ -121,6 +121,7 @@ def lib() -> ctypes.CDLL:
         L.vlfm_layernorm_bias_f16.argtypes = [vp, vp, vp, vp, vp, ci, ci, ctypes.c_float, vp]
         L.vlfm_vit_attention_f16.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.c_float, vp]
         L.vlfm_gemm_f16_nt.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
+        L.vlfm_conv_nhwc_tile.argtypes = [ci, ci, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(ci)]
         L.vlfm_conv_nhwc_f16.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
         L.vlfm_value_map_scratch_bytes.argtypes = [ci, ci]
         L.vlfm_value_map_scratch_bytes.restype = ctypes.c_size_t

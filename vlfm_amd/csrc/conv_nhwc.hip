@@ -297,6 +297,17 @@ static int pick_cfg(int M, int cout, int ktiles) {
 
 using namespace vlfm;
 
+// The tile shape vlfm_conv_nhwc_f16 uses for a layer of `pixels` output pixels, `cout` channels and K = ksize^2 * cin (host logic only:
+// no device needed; tests/test_host_logic.py pins the properties the estimate must have).
+extern "C" int vlfm_conv_nhwc_tile(int pixels, int cin, int cout, int ksize, int* tile_pixels, int* tile_channels) {
+    if (pixels <= 0 || cin <= 0 || cout <= 0 || (ksize != 1 && ksize != 3) || !tile_pixels || !tile_channels)
+        return fail(VLFM_ERR_INVALID, "conv_nhwc_tile: bad argument");
+    const int c = conv::pick_cfg(pixels, cout, (ksize * ksize * cin + conv::GK - 1) / conv::GK);
+    *tile_pixels = conv::kCfg[c].bm;
+    *tile_channels = conv::kCfg[c].bn;
+    return VLFM_OK;
+}
+
 // out = act(conv(x, w) + bias) for a 1x1 (pad 0) or 3x3 (pad 1) filter, stride 1 or 2, NHWC f16 with f32 accumulation.
 //   d_x   [batch][height][width] pixels, x_pix_stride elements apart, the first `cin` channels of each are read
 //   d_w   [cout][Kpad]: a filter's [ksize][ksize][cin] weights followed by zeros up to Kpad = round_up(ksize * ksize * cin, 64)
