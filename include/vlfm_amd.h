@@ -323,6 +323,21 @@ int vlfm_gemm_f16_nt(const void* d_x, const void* d_w, const void* d_bias, void*
  * Detector-side kernels (vlfm/vlm/yolov7.py:50-110, vlfm/vlm/grounding_dino.py:38-74)
  * ------------------------------------------------------------------------------------------- */
 
+/* The memory-bound glue of TinyViT's windowed-attention blocks (MobileSAM's image encoder behind vlfm/vlm/sam.py:54; TinyViTBlock of
+ * mobile_sam/modeling/tiny_vit_sam.py [ext]) on NHWC f32 rows (csrc/sam_ops.hip):
+ *   vlfm_layernorm_rows_f32     LayerNorm over `channels` of [batch][height][width] rows; window > 0 writes the rows of the
+ *                               zero-padded image in window order [batch * nWy * nWx][window^2][channels] (pad + window partition +
+ *                               attn.norm in one pass; padded positions receive beta = LayerNorm(0))
+ *   vlfm_window_reverse_add_f32 d_x[b][y][x][:] += d_windows[row of (b, y, x) in window order][:]  (reverse + crop + residual add)
+ *   vlfm_dwconv3x3_nhwc_f32     the block's depthwise 3x3 `local_conv` (stride 1, padding 1) + folded-BatchNorm bias; d_w9c [9][channels]
+ * channels % 4 == 0 everywhere. */
+int vlfm_layernorm_rows_f32(const float* d_x, const float* d_gamma, const float* d_beta, float* d_out, int batch, int height,
+                            int width, int channels, int window, float eps, void* stream);
+int vlfm_window_reverse_add_f32(float* d_x, const float* d_windows, int batch, int height, int width, int channels, int window,
+                                void* stream);
+int vlfm_dwconv3x3_nhwc_f32(const float* d_x, const float* d_w9c, const float* d_bias, float* d_out, int batch, int height, int width,
+                            int channels, void* stream);
+
 /* One convolution of the yolov7-e6e graph the reference runs in fp16 (vlfm/vlm/yolov7.py:35-48,89), BatchNorm folded:
  * out = act(conv(x, w) + bias) as an implicit GEMM on the matrix cores (csrc/conv_nhwc.hip), NHWC f16, f32 accumulation.
  *   d_x    [batch][height][width] pixels, x_pix_stride elements apart; the first `cin` channels of a pixel are read

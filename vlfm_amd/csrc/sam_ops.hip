@@ -1,0 +1,195 @@
+// sam_ops.hip -- the memory-bound glue of TinyViT's windowed-attention blocks (the image encoder of MobileSAM behind
+// vlfm/vlm/sam.py:54 `predictor.set_image`; mobile_sam/modeling/tiny_vit_sam.py TinyViTBlock [ext]) in f32 on NHWC rows.
+//
+// Profile of the framework path at 32 frames (tools/sam_probe.py + tools/rocprof_tail.py): LayerNorm 9 % of the
+// encoder at 0.7 TB/s (one short row per block), residual / bias adds 10 %, window-partition / reverse / NCHW<->NHWC copies 9 %.  A
+// block is: pad -> partition into windows -> LayerNorm -> attention -> reverse -> residual add -> depthwise 3x3 -> LayerNorm -> MLP ->
+// residual add.  With the activation kept as [B, H, W, C] rows between the blocks of a stage the glue collapses into three kernels:
+//   * layernorm_rows_f32_kernel: LayerNorm of a C-float row per wavefront, written either in place order (the MLP's norm) or straight
+//     into the window order [B * nWy * nWx, ws * ws, C] (the attention's norm: pad + partition + norm in one pass; padded positions
+//     get LayerNorm(0) = beta, which is what the reference computes for its zero padding);
+//   * window_reverse_add_f32_kernel: x[b, y, x, :] += a[window(b, y, x), position, :] (reverse + crop + residual add in one pass);
+//   * dwconv3x3_nhwc_f32_kernel: the block's depthwise 3x3 `local_conv` with its folded-BatchNorm bias on NHWC rows (16-byte
+//     accesses along the channels, weights as [9][C]), so that the tensor never goes back to NCHW inside a stage.
+// All three are HBM-bound by construction: 16 bytes per lane, consecutive lanes on consecutive addresses.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vlfm_amd.h"
+#include "profile.h"
+#include "status.h"
+
+namespace vlfm {
+namespace sam {
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// One wavefront per OUTPUT row.  window == 0: out row r = in row r.  window > 0: out rows are in window order over the padded
+// image (Hp = ceil(H / ws) * ws): r = ((b * nWy + wy) * nWx + wx) * ws * ws + iy * ws + ix  <-  (b, wy * ws + iy, wx * ws + ix).
+template <int MAXV>   // float4 per lane: C <= 256 * MAXV
+__global__ __launch_bounds__(256) void layernorm_rows_f32_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float* __restrict__ out, int B,
+                                                                 int H, int W, int C, int ws, float eps, long long out_rows) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= out_rows) return;
+    const int C4 = C >> 2;
+    long long in_row = r;
+    bool real = true;
+    if (ws > 0) {
+        const int nwx = (W + ws - 1) / ws, nwy = (H + ws - 1) / ws, ww = ws * ws;
+        const long long win = r / ww;
+        const int pos = (int)(r - win * ww), iy = pos / ws, ix = pos - iy * ws;
+        const int wx = (int)(win % nwx), wy = (int)((win / nwx) % nwy), b = (int)(win / ((long long)nwx * nwy));
+        const int y = wy * ws + iy, xx = wx * ws + ix;
+        real = y < H && xx < W;
+        in_row = ((long long)b * H + y) * W + xx;
+    }
+    float4* orow = reinterpret_cast<float4*>(out + r * C);
+    if (!real) {   // LayerNorm of the reference's zero padding: (0 - 0) / sqrt(0 + eps) * gamma + beta
+        for (int i = lane; i < C4; i += 64) orow[i] = reinterpret_cast<const float4*>(beta)[i];
+        return;
+    }
+    const float4* irow = reinterpret_cast<const float4*>(x + in_row * C);
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; k++) {
+        const int i = lane + 64 * k;
+        v[k] = i < C4 ? irow[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; k++) {
+        if (lane + 64 * k < C4) {
+            const float a = v[k].x - mean, b2 = v[k].y - mean, c = v[k].z - mean, d = v[k].w - mean;
+            q += (a * a + b2 * b2) + (c * c + d * d);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int k = 0; k < MAXV; k++) {
+        const int i = lane + 64 * k;
+        if (i < C4) {
+            const float4 g = reinterpret_cast<const float4*>(gamma)[i], bb = reinterpret_cast<const float4*>(beta)[i];
+            float4 o;
+            o.x = (v[k].x - mean) * rstd * g.x + bb.x;
+            o.y = (v[k].y - mean) * rstd * g.y + bb.y;
+            o.z = (v[k].z - mean) * rstd * g.z + bb.z;
+            o.w = (v[k].w - mean) * rstd * g.w + bb.w;
+            orow[i] = o;
+        }
+    }
+}
+
+// x[b, y, xx, :] += a[window row of (b, y, xx), :]   (one thread per float4)
+__global__ __launch_bounds__(256) void window_reverse_add_f32_kernel(float* __restrict__ x, const float* __restrict__ a, int B, int H,
+                                                                     int W, int C, int ws, long long n4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int C4 = C >> 2;
+    const long long row = i / C4;
+    const int c4 = (int)(i - row * C4);
+    const int xx = (int)(row % W), y = (int)((row / W) % H), b = (int)(row / ((long long)W * H));
+    const int nwx = (W + ws - 1) / ws, nwy = (H + ws - 1) / ws;
+    const int wy = y / ws, iy = y - wy * ws, wx = xx / ws, ix = xx - wx * ws;
+    const long long arow = (((long long)b * nwy + wy) * nwx + wx) * (ws * ws) + iy * ws + ix;
+    float4 v = reinterpret_cast<float4*>(x)[i];
+    const float4 t = reinterpret_cast<const float4*>(a)[arow * C4 + c4];
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    reinterpret_cast<float4*>(x)[i] = v;
+}
+
+// out[b, y, xx, c] = bias[c] + sum_{dy, dx} w9c[(dy * 3 + dx)][c] * x[b, y + dy - 1, xx + dx - 1, c]   (stride 1, zero padding 1)
+__global__ __launch_bounds__(256) void dwconv3x3_nhwc_f32_kernel(const float* __restrict__ x, const float* __restrict__ w9c,
+                                                                 const float* __restrict__ bias, float* __restrict__ out, int B, int H,
+                                                                 int W, int C, long long n4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int C4 = C >> 2;
+    const long long row = i / C4;
+    const int c4 = (int)(i - row * C4);
+    const int xx = (int)(row % W), y = (int)((row / W) % H);
+    float4 acc = bias ? reinterpret_cast<const float4*>(bias)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int dy = 0; dy < 3; dy++) {
+        const int yi = y + dy - 1;
+        if ((unsigned)yi >= (unsigned)H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++) {
+            const int xi = xx + dx - 1;
+            if ((unsigned)xi >= (unsigned)W) continue;
+            const float4 v = reinterpret_cast<const float4*>(x)[(row + (long long)(dy - 1) * W + (dx - 1)) * C4 + c4];
+            const float4 k = reinterpret_cast<const float4*>(w9c)[(dy * 3 + dx) * C4 + c4];
+            acc.x += k.x * v.x; acc.y += k.y * v.y; acc.z += k.z * v.z; acc.w += k.w * v.w;
+        }
+    }
+    reinterpret_cast<float4*>(out)[i] = acc;
+}
+
+}  // namespace sam
+}  // namespace vlfm
+
+using namespace vlfm;
+
+// LayerNorm over the last dimension of [batch, height, width, channels] f32 rows (channels % 4 == 0, <= 1024).  window == 0: d_out has
+// the same row order.  window > 0: d_out is [batch * ceil(H / window) * ceil(W / window), window * window, channels] -- the rows of
+// the zero-padded image in window order (TinyViTBlock's pad + window partition + attn.norm); padded positions receive beta.
+extern "C" int vlfm_layernorm_rows_f32(const float* d_x, const float* d_gamma, const float* d_beta, float* d_out, int batch, int height,
+                                       int width, int channels, int window, float eps, void* stream) {
+    if (batch == 0) return VLFM_OK;
+    if (!d_x || !d_gamma || !d_beta || !d_out || batch < 0 || height <= 0 || width <= 0 || channels <= 0 || (channels & 3) ||
+        channels > 1024 || window < 0)
+        return fail(VLFM_ERR_INVALID, "layernorm_rows_f32: channels must be a multiple of 4 and <= 1024");
+    long long rows = (long long)batch * height * width;
+    if (window > 0) {
+        const long long nwy = (height + window - 1) / window, nwx = (width + window - 1) / window;
+        rows = (long long)batch * nwy * nwx * window * window;
+    }
+    const long long blocks = (rows + 3) / 4;
+    if (blocks > 0x7fffffffLL) return fail(VLFM_ERR_CAPACITY, "layernorm_rows_f32: too many rows");
+    const dim3 grid((unsigned)blocks), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    VLFM_TIMED("layernorm_rows_f32_kernel", stream);
+    const int c4 = channels / 4;
+    if (c4 <= 64) VLFM_KLAUNCH((sam::layernorm_rows_f32_kernel<1>), grid, block, 0, s, d_x, d_gamma, d_beta, d_out, batch, height, width, channels, window, eps, rows);
+    else if (c4 <= 128) VLFM_KLAUNCH((sam::layernorm_rows_f32_kernel<2>), grid, block, 0, s, d_x, d_gamma, d_beta, d_out, batch, height, width, channels, window, eps, rows);
+    else VLFM_KLAUNCH((sam::layernorm_rows_f32_kernel<4>), grid, block, 0, s, d_x, d_gamma, d_beta, d_out, batch, height, width, channels, window, eps, rows);
+    return check_launch("layernorm_rows_f32_kernel");
+}
+
+// d_x[b, y, x, :] += d_windows[row of (b, y, x) in window order, :]: TinyViTBlock's window reverse + crop + residual add, in place.
+extern "C" int vlfm_window_reverse_add_f32(float* d_x, const float* d_windows, int batch, int height, int width, int channels, int window,
+                                           void* stream) {
+    if (batch == 0) return VLFM_OK;
+    if (!d_x || !d_windows || batch < 0 || height <= 0 || width <= 0 || channels <= 0 || (channels & 3) || window <= 0)
+        return fail(VLFM_ERR_INVALID, "window_reverse_add_f32: channels must be a multiple of 4, window > 0");
+    const long long n4 = (long long)batch * height * width * (channels / 4);
+    const long long blocks = (n4 + 255) / 256;
+    if (blocks > 0x7fffffffLL) return fail(VLFM_ERR_CAPACITY, "window_reverse_add_f32: tensor too large");
+    VLFM_TIMED("window_reverse_add_f32_kernel", stream);
+    VLFM_KLAUNCH(sam::window_reverse_add_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_x, d_windows, batch,
+                 height, width, channels, window, n4);
+    return check_launch("window_reverse_add_f32_kernel");
+}
+
+// Depthwise 3x3 convolution (stride 1, zero padding 1) + bias on NHWC f32 rows; d_w9c is [9][channels] (tap-major).
+extern "C" int vlfm_dwconv3x3_nhwc_f32(const float* d_x, const float* d_w9c, const float* d_bias, float* d_out, int batch, int height,
+                                       int width, int channels, void* stream) {
+    if (batch == 0) return VLFM_OK;
+    if (!d_x || !d_w9c || !d_out || batch < 0 || height <= 0 || width <= 0 || channels <= 0 || (channels & 3))
+        return fail(VLFM_ERR_INVALID, "dwconv3x3_nhwc_f32: channels must be a multiple of 4");
+    const long long n4 = (long long)batch * height * width * (channels / 4);
+    const long long blocks = (n4 + 255) / 256;
+    if (blocks > 0x7fffffffLL) return fail(VLFM_ERR_CAPACITY, "dwconv3x3_nhwc_f32: tensor too large");
+    VLFM_TIMED("dwconv3x3_nhwc_f32_kernel", stream);
+    VLFM_KLAUNCH(sam::dwconv3x3_nhwc_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_x, d_w9c, d_bias, d_out,
+                 batch, height, width, channels, n4);
+    return check_launch("dwconv3x3_nhwc_f32_kernel");
+}

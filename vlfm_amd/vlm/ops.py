@@ -187,6 +187,47 @@ def depthwise_conv3x3(x: torch.Tensor, weight: torch.Tensor, bias, stride: int =
     return y
 
 
+def layernorm_rows(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float, window: int = 0) -> torch.Tensor:
+    """LayerNorm over the channels of a contiguous f32 [B, H, W, C] tensor (csrc/sam_ops.hip).  ``window == 0``: same shape.
+    ``window > 0``: TinyViTBlock's pad + window partition + ``attn.norm`` in one pass -> [B * nWy * nWx, window^2, C], the rows
+    of the zero-padded image in window order (padded positions hold LayerNorm(0) = bias, as in the reference)."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+    B, H, W, C = x.shape
+    assert weight.dtype == torch.float32 and bias.dtype == torch.float32 and weight.numel() == C == bias.numel()
+    if window > 0:
+        nwy, nwx = (H + window - 1) // window, (W + window - 1) // window
+        out = torch.empty((B * nwy * nwx, window * window, C), dtype=torch.float32, device=x.device)
+    else:
+        out = torch.empty_like(x)
+    _lib.check(_lib.lib().vlfm_layernorm_rows_f32(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, W, C,
+                                                  int(window), float(eps), _stream()), "layernorm_rows_f32")
+    return out
+
+
+def window_reverse_add_(x: torch.Tensor, windows: torch.Tensor, window: int) -> torch.Tensor:
+    """In place: x[b, y, x] += windows[row of (b, y, x) in window order] -- TinyViTBlock's window reverse + crop + residual add
+    (csrc/sam_ops.hip).  x [B, H, W, C] f32 contiguous, windows [B * nWy * nWx, window^2, C]."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+    B, H, W, C = x.shape
+    nwy, nwx = (H + window - 1) // window, (W + window - 1) // window
+    assert windows.is_contiguous() and windows.dtype == torch.float32 and windows.numel() == B * nwy * nwx * window * window * C
+    _lib.check(_lib.lib().vlfm_window_reverse_add_f32(x.data_ptr(), windows.data_ptr(), B, H, W, C, int(window), _stream()),
+               "window_reverse_add_f32")
+    return x
+
+
+def depthwise_conv3x3_nhwc(x: torch.Tensor, w9c: torch.Tensor, bias) -> torch.Tensor:
+    """Depthwise 3x3 convolution (stride 1, padding 1) + bias of a contiguous f32 [B, H, W, C] tensor; ``w9c`` is the [C, 1, 3, 3]
+    weight as [9, C] (``weight.view(C, 9).t().contiguous()``)."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+    B, H, W, C = x.shape
+    assert w9c.shape == (9, C) and w9c.is_contiguous() and w9c.dtype == torch.float32
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().vlfm_dwconv3x3_nhwc_f32(x.data_ptr(), w9c.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                                  out.data_ptr(), B, H, W, C, _stream()), "dwconv3x3_nhwc_f32")
+    return out
+
+
 def linear_gelu(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
     """gelu(x @ weight.T + bias), exact (erf) form, f16 in / f16 out with f32 accumulation: the hand-written MFMA GEMM of
     csrc/gemm_f16.hip with the activation in its epilogue (hipBLASLt only fuses the tanh approximation, so the library path

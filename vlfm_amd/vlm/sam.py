@@ -102,9 +102,9 @@ class _WindowAttention(nn.Module):
         self.attention_biases = nn.Parameter(torch.zeros(heads, len(offs)))
         self.register_buffer("attention_bias_idxs", torch.tensor(idx).view(len(pts), len(pts)), persistent=False)
 
-    def forward(self, x):  # [B*, N, C]
+    def forward(self, x, normed: bool = False):  # [B*, N, C]; normed: ``x`` already went through self.norm
         b, n, c = x.shape
-        q, k, v = self.qkv(self.norm(x)).view(b, n, self.heads, 3 * self.kd).split(self.kd, dim=3)
+        q, k, v = self.qkv(x if normed else self.norm(x)).view(b, n, self.heads, 3 * self.kd).split(self.kd, dim=3)
         bias = self.attention_biases[:, self.attention_bias_idxs].unsqueeze(0).to(x.dtype)
         a = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), attn_mask=bias)
         return self.proj(a.transpose(1, 2).reshape(b, n, c))
@@ -144,6 +144,26 @@ class _TinyViTBlock(nn.Module):
         t = t + self.mlp(t)
         return t.permute(0, 3, 1, 2)
 
+    def rows_path(self, t: torch.Tensor) -> bool:
+        """The NHWC-rows path (csrc/sam_ops.hip) takes f32 GPU tensors once the local_conv's BatchNorm is folded."""
+        return t.is_cuda and t.dtype == torch.float32 and _folded(self.local_conv) and t.shape[-1] % 4 == 0
+
+    def forward_rows(self, t):  # [B, H, W, C] contiguous f32, OWNED by the caller's stage loop (updated in place)
+        """The same block on NHWC rows: pad + window partition + attn.norm is one kernel, window reverse + crop + residual add is
+        one (in place), the depthwise local_conv stays on NHWC rows, the MLP's norm is the row LayerNorm -- 12 passes over the
+        activation instead of ~20, none of them strided."""
+        b, h, w, c = t.shape
+        ws = self.window
+        a = self.attn(ops.layernorm_rows(t, self.attn.norm.weight, self.attn.norm.bias, self.attn.norm.eps, ws), normed=True)
+        ops.window_reverse_add_(t, a.contiguous(), ws)
+        lc = self.local_conv
+        if getattr(self, "_w9c", None) is None or self._w9c.device != t.device:
+            self._w9c = lc.c.weight.detach().reshape(c, 9).t().contiguous()
+        t = ops.depthwise_conv3x3_nhwc(t, self._w9c, lc.bn.bias)
+        m = self.mlp
+        hid = F.gelu(m.fc1(ops.layernorm_rows(t, m.norm.weight, m.norm.bias, m.norm.eps)))
+        return t.add_(m.fc2(hid))
+
 
 class _Stage(nn.Module):
     """``blocks`` + optional ``downsample``: layers.0 is the MBConv stage, layers.1-3 the windowed-attention stages."""
@@ -155,7 +175,16 @@ class _Stage(nn.Module):
             self.downsample = downsample
 
     def forward(self, x):
-        for blk in self.blocks:
+        blocks = list(self.blocks)
+        if blocks and all(isinstance(b, _TinyViTBlock) for b in blocks):
+            t = x.permute(0, 2, 3, 1)
+            if all(b.rows_path(t) for b in blocks):      # one NCHW -> NHWC copy per stage instead of four per block
+                t = t.contiguous()
+                for blk in blocks:
+                    t = blk.forward_rows(t)
+                x = t.permute(0, 3, 1, 2).contiguous()
+                return self.downsample(x) if hasattr(self, "downsample") else x
+        for blk in blocks:
             x = blk(x)
         return self.downsample(x) if hasattr(self, "downsample") else x
 
