@@ -27,5 +27,11 @@ cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/$O/prof_yolo -o p -- python $R/tools/yolo_probe.py 64 hip-only > $R/$O/prof_yolo.log 2>&1
 cd $R
 python tools/rocprof_summary.py $O/prof_yolo/p_results.db $O/r03_yolo_e6e_b64_kernel_stats.csv > $O/summary_yolo.log 2>&1
+# MobileSAM: steady-state kernel table of 32 frames, and the full step's parts at 128 environments
+cd /tmp
+timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/prof_sam -o p -- python $R/tools/sam_probe.py 32 > $R/$O/sam_probe.log 2>&1
+cd $R
+python tools/rocprof_tail.py /tmp/prof_sam/p_results.db 200 30 > $O/r03_mobile_sam_b32_steady_state.txt 2>&1
+(timeout 300 python tools/full_step_parts_probe.py 128 2>&1 | grep -v amdgpu.ids | tail -6) > $O/r03_full_step_parts_e128.txt 2>&1
 find gpurun_out -name "*.db" -size +20M -delete
 ls $O
