@@ -337,6 +337,11 @@ int vlfm_window_reverse_add_f32(float* d_x, const float* d_windows, int batch, i
                                 void* stream);
 int vlfm_dwconv3x3_nhwc_f32(const float* d_x, const float* d_w9c, const float* d_bias, float* d_out, int batch, int height, int width,
                             int channels, void* stream);
+/* TinyViT's window attention (head width 32; `Attention` of tiny_vit_sam.py [ext]): out = softmax(scale * q k^T + bias) v per
+ * (window, head).  d_qkv [windows * tokens][heads][q | k | v][32] f32 (the qkv Linear's output), d_bias_t [heads][tokens][tokens] =
+ * the additive bias TRANSPOSED (bias_t[h][j][i] = bias[h][i][j]), d_out [windows * tokens][heads * 32].  tokens <= 256. */
+int vlfm_window_attention_f32(const float* d_qkv, const float* d_bias_t, float* d_out, long long windows, int tokens, int heads,
+                              float scale, void* stream);
 
 /* One convolution of the yolov7-e6e graph the reference runs in fp16 (vlfm/vlm/yolov7.py:35-48,89), BatchNorm folded:
  * out = act(conv(x, w) + bias) as an implicit GEMM on the matrix cores (csrc/conv_nhwc.hip), NHWC f16, f32 accumulation.

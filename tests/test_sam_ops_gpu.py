@@ -94,3 +94,19 @@ def test_tinyvit_encoder_rows_path_matches_the_nchw_path_and_the_cpu(gpu_device)
     assert scale > 0.1
     assert float((rows - nchw).abs().max()) <= 2e-4 * scale
     assert float((rows - cpu).abs().max()) <= 2e-3 * scale
+
+
+@pytest.mark.parametrize("nw,n,heads", [(37, 49, 4), (11, 196, 5), (5, 49, 10), (3, 1, 2), (2, 256, 1), (4, 70, 3)])
+def test_window_attention(gpu_device, nw, n, heads):
+    """vlfm_window_attention_f32 against the library's scaled_dot_product_attention with the additive bias as attn_mask (what the
+    block called before), f32: |err| <= 2e-5 * max(1, |ref|) (online softmax over chunks of four keys vs the library's tiling)."""
+    from vlfm_amd.vlm import ops
+
+    g = torch.Generator().manual_seed(nw * 100 + n + heads)
+    qkv = (torch.randn(nw, n, heads * 96, generator=g) * 1.3).to(gpu_device)
+    bias = (torch.randn(heads, n, n, generator=g) * 2.0).to(gpu_device)          # NOT symmetric: the transposition matters
+    q, k, v = qkv.view(nw, n, heads, 96).split(32, dim=3)
+    ref = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), attn_mask=bias.unsqueeze(0))
+    ref = ref.transpose(1, 2).reshape(nw, n, heads * 32)
+    got = ops.window_attention(qkv, bias.transpose(1, 2).contiguous(), heads, 32 ** -0.5)
+    assert got.shape == ref.shape and close(got, ref)

@@ -228,6 +228,19 @@ def depthwise_conv3x3_nhwc(x: torch.Tensor, w9c: torch.Tensor, bias) -> torch.Te
     return out
 
 
+def window_attention(qkv: torch.Tensor, bias_t: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
+    """TinyViT's window attention (head width 32) in one kernel (csrc/sam_ops.hip): ``qkv`` [windows, tokens, heads * 96] f32 as the
+    qkv Linear emits it (per head q | k | v), ``bias_t`` [heads, tokens, tokens] the additive bias transposed over its last two
+    dimensions; returns softmax(scale * q k^T + bias) v as [windows, tokens, heads * 32]."""
+    assert qkv.is_cuda and qkv.dtype == torch.float32 and qkv.dim() == 3 and qkv.is_contiguous() and qkv.shape[2] == heads * 96
+    nw, n, _ = qkv.shape
+    assert bias_t.shape == (heads, n, n) and bias_t.is_contiguous() and bias_t.dtype == torch.float32 and n <= 256
+    out = torch.empty((nw, n, heads * 32), dtype=torch.float32, device=qkv.device)
+    _lib.check(_lib.lib().vlfm_window_attention_f32(qkv.data_ptr(), bias_t.data_ptr(), out.data_ptr(), nw, n, heads, float(scale),
+                                                    _stream()), "window_attention_f32")
+    return out
+
+
 def linear_gelu(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
     """gelu(x @ weight.T + bias), exact (erf) form, f16 in / f16 out with f32 accumulation: the hand-written MFMA GEMM of
     csrc/gemm_f16.hip with the activation in its epilogue (hipBLASLt only fuses the tanh approximation, so the library path

@@ -104,6 +104,14 @@ class _WindowAttention(nn.Module):
 
     def forward(self, x, normed: bool = False):  # [B*, N, C]; normed: ``x`` already went through self.norm
         b, n, c = x.shape
+        if x.is_cuda and x.dtype == torch.float32 and self.kd == 32 and n <= 256 and not torch.is_grad_enabled():
+            # one kernel per block: a window's K / V in LDS, bias added in the score loop (csrc/sam_ops.hip)
+            key = (str(x.device), self.attention_biases._version)
+            if getattr(self, "_bias_t", (None,))[0] != key:
+                bias = self.attention_biases[:, self.attention_bias_idxs].detach().to(torch.float32)
+                self._bias_t = (key, bias.transpose(1, 2).contiguous())
+            a = ops.window_attention(self.qkv(x if normed else self.norm(x)), self._bias_t[1], self.heads, self.kd ** -0.5)
+            return self.proj(a)
         q, k, v = self.qkv(x if normed else self.norm(x)).view(b, n, self.heads, 3 * self.kd).split(self.kd, dim=3)
         bias = self.attention_biases[:, self.attention_bias_idxs].unsqueeze(0).to(x.dtype)
         a = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), attn_mask=bias)
