@@ -135,44 +135,37 @@ __global__ __launch_bounds__(256) void dwconv3x3_nhwc_f32_kernel(const float* __
 
 // Window attention of TinyViT (head width 32, windows of N = ws^2 = 49 or 196 tokens, additive relative-position bias):
 //   out[t][h*32 ..] = softmax_j(scale * q_t . k_j + bias[h][i][j]) . v_j      over the N tokens j of token t's window (i = t mod N)
-// One workgroup per (window, head), one lane per query.  The window's K and V (N x 32 floats each, 12.5 / 50 KB) are staged once into
-// LDS with coalesced 16-byte loads and then read as BROADCASTS (every lane needs the same key row at the same time: conflict-free by
-// construction); q and the running output stay in registers; the softmax is the online form over chunks of four keys (one rescale
-// per chunk); explicit fmaf (the library is built with -ffp-contract=off for the bit-exact map kernels).  The library flash kernel the framework dispatches for this shape spends 0.5 - 0.8 ms per block on a few GFLOP
-// (tools/sam_attn_probe.py): its tiles are built for long sequences.  qkv rows are [heads][q | k | v][32] as TinyViT's qkv Linear
-// emits them; bias_t is the bias TRANSPOSED, [heads][j][i], so that consecutive lanes read consecutive addresses.
+// One workgroup per (window, head), one lane per query; q and the running output stay in registers; the softmax is the online form
+// over chunks of four keys (one rescale per chunk); explicit fmaf (the library is built with -ffp-contract=off for the bit-exact map
+// kernels).  Every lane needs the SAME key / value row at the same time, i.e. the row address is wave-uniform: the compiler fetches the
+// rows with scalar loads (s_load_dwordx16 through the scalar cache) into SGPRs, which the FMAs take as their scalar operand -- no
+// staging pass, no barrier, no LDS.  qkv rows are [heads][q | k | v][32] as TinyViT's qkv Linear emits them; bias_t is the bias
+// TRANSPOSED, [heads][j][i], so that consecutive lanes read consecutive addresses.
+// Measured per block at 32 frames (tools/sam_attn_probe.py; stage 1 / 2 / 3 = 11 552 x 4 x 49, 800 x 5 x 196, 3 200 x 10 x 49 windows x
+// heads x tokens): the library flash kernel the framework dispatches 0.76 / 0.80 / 0.50 ms (its tiles are built for long sequences; plus
+// q / k / v transposes); K / V staged in LDS and read as broadcasts 0.57 / 0.63 / 0.40 (64 ds_read_b128 per four keys and wavefront
+// keep the LDS ~85 % busy beside 300 VALU instructions); this form 0.49 / 0.58 / 0.37; the same with channel pairs in v_pk_fma_f32
+// 0.57 / 0.70 / 0.40 (the packed form cannot take the scalar operands directly).  What bounds it now is the f32 vector ALU.
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void window_attention_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ bias_t,
                                                                       float* __restrict__ out, int N, int heads, float scale_log2e) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float4* Ks = reinterpret_cast<float4*>(smem_raw);          // [N][8] float4
-    float4* Vs = Ks + (size_t)N * 8;
     const int h = blockIdx.x % heads;
     const long long win = blockIdx.x / heads;
     const int i = threadIdx.x;
     const size_t row = (size_t)heads * 96;                      // floats per token in qkv
     const float* base = qkv + (size_t)win * N * row + (size_t)h * 96;
-    for (int idx = i; idx < N * 8; idx += THREADS) {            // 8 consecutive lanes fetch one 128-byte key / value row
-        const int r = idx >> 3, c = idx & 7;
-        Ks[idx] = reinterpret_cast<const float4*>(base + (size_t)r * row + 32)[c];
-        Vs[idx] = reinterpret_cast<const float4*>(base + (size_t)r * row + 64)[c];
-    }
-    float4 q[8];
-    const bool live = i < N;
-    if (live) {
+    if (i >= N) return;
+    float q[32];
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
-            q[c] = reinterpret_cast<const float4*>(base + (size_t)i * row)[c];
-            q[c].x *= scale_log2e; q[c].y *= scale_log2e; q[c].z *= scale_log2e; q[c].w *= scale_log2e;
-        }
+    for (int c = 0; c < 8; c++) {
+        const float4 t = reinterpret_cast<const float4*>(base + (size_t)i * row)[c];
+        q[4 * c] = t.x * scale_log2e; q[4 * c + 1] = t.y * scale_log2e; q[4 * c + 2] = t.z * scale_log2e; q[4 * c + 3] = t.w * scale_log2e;
     }
-    __syncthreads();
-    if (!live) return;
     const float LOG2E = 1.4426950408889634f;
     const float* bcol = bias_t + ((size_t)h * N) * N + i;       // bias[h][i][j] at bcol[j * N]
-    float4 o[8];
+    float o[32];
 #pragma unroll
-    for (int c = 0; c < 8; c++) o[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < 32; c++) o[c] = 0.f;
     float m = -INFINITY, l = 0.f;
     for (int j0 = 0; j0 < N; j0 += 4) {
         float sc[4];
@@ -180,12 +173,10 @@ __global__ __launch_bounds__(THREADS) void window_attention_f32_kernel(const flo
         for (int u = 0; u < 4; u++) {
             const int j = j0 + u;
             if (j < N) {
+                const float* kj = base + (size_t)j * row + 32;       // wave-uniform address
                 float acc = bcol[(size_t)j * N] * LOG2E;
 #pragma unroll
-                for (int c = 0; c < 8; c++) {
-                    const float4 kv = Ks[j * 8 + c];
-                    acc = fmaf(q[c].x, kv.x, fmaf(q[c].y, kv.y, fmaf(q[c].z, kv.z, fmaf(q[c].w, kv.w, acc))));
-                }
+                for (int c = 0; c < 32; c++) acc = fmaf(q[c], kj[c], acc);
                 sc[u] = acc;
             } else {
                 sc[u] = -INFINITY;
@@ -196,26 +187,23 @@ __global__ __launch_bounds__(THREADS) void window_attention_f32_kernel(const flo
         m = mn;
         l *= alpha;
 #pragma unroll
-        for (int c = 0; c < 8; c++) { o[c].x *= alpha; o[c].y *= alpha; o[c].z *= alpha; o[c].w *= alpha; }
+        for (int c = 0; c < 32; c++) o[c] *= alpha;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int j = j0 + u;
             if (j < N) {
+                const float* vj = base + (size_t)j * row + 64;       // wave-uniform address
                 const float pj = exp2f(sc[u] - mn);
                 l += pj;
 #pragma unroll
-                for (int c = 0; c < 8; c++) {
-                    const float4 vv = Vs[j * 8 + c];
-                    o[c].x = fmaf(pj, vv.x, o[c].x); o[c].y = fmaf(pj, vv.y, o[c].y);
-                    o[c].z = fmaf(pj, vv.z, o[c].z); o[c].w = fmaf(pj, vv.w, o[c].w);
-                }
+                for (int c = 0; c < 32; c++) o[c] = fmaf(pj, vj[c], o[c]);
             }
         }
     }
     const float inv = 1.0f / l;
     float4* orow = reinterpret_cast<float4*>(out + ((size_t)win * N + i) * ((size_t)heads * 32) + (size_t)h * 32);
 #pragma unroll
-    for (int c = 0; c < 8; c++) orow[c] = make_float4(o[c].x * inv, o[c].y * inv, o[c].z * inv, o[c].w * inv);
+    for (int c = 0; c < 8; c++) orow[c] = make_float4(o[4 * c] * inv, o[4 * c + 1] * inv, o[4 * c + 2] * inv, o[4 * c + 3] * inv);
 }
 
 }  // namespace sam
@@ -231,14 +219,13 @@ extern "C" int vlfm_window_attention_f32(const float* d_qkv, const float* d_bias
     if (windows == 0) return VLFM_OK;
     if (!d_qkv || !d_bias_t || !d_out || windows < 0 || tokens <= 0 || tokens > 256 || heads <= 0 || windows * heads > 0x7fffffffLL)
         return fail(VLFM_ERR_INVALID, "window_attention_f32: 1 <= tokens <= 256, head width 32");
-    const size_t lds = (size_t)tokens * 32 * 4 * 2;
     const dim3 grid((unsigned)(windows * heads));
     const float sl = scale * 1.4426950408889634f;
     hipStream_t s = (hipStream_t)stream;
     VLFM_TIMED("window_attention_f32_kernel", stream);
-    if (tokens <= 64) VLFM_KLAUNCH((sam::window_attention_f32_kernel<64>), grid, dim3(64), lds, s, d_qkv, d_bias_t, d_out, tokens, heads, sl);
-    else if (tokens <= 128) VLFM_KLAUNCH((sam::window_attention_f32_kernel<128>), grid, dim3(128), lds, s, d_qkv, d_bias_t, d_out, tokens, heads, sl);
-    else VLFM_KLAUNCH((sam::window_attention_f32_kernel<256>), grid, dim3(256), lds, s, d_qkv, d_bias_t, d_out, tokens, heads, sl);
+    if (tokens <= 64) VLFM_KLAUNCH((sam::window_attention_f32_kernel<64>), grid, dim3(64), 0, s, d_qkv, d_bias_t, d_out, tokens, heads, sl);
+    else if (tokens <= 128) VLFM_KLAUNCH((sam::window_attention_f32_kernel<128>), grid, dim3(128), 0, s, d_qkv, d_bias_t, d_out, tokens, heads, sl);
+    else VLFM_KLAUNCH((sam::window_attention_f32_kernel<256>), grid, dim3(256), 0, s, d_qkv, d_bias_t, d_out, tokens, heads, sl);
     return check_launch("window_attention_f32_kernel");
 }
 

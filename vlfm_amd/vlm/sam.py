@@ -105,7 +105,7 @@ class _WindowAttention(nn.Module):
     def forward(self, x, normed: bool = False):  # [B*, N, C]; normed: ``x`` already went through self.norm
         b, n, c = x.shape
         if x.is_cuda and x.dtype == torch.float32 and self.kd == 32 and n <= 256 and not torch.is_grad_enabled():
-            # one kernel per block: a window's K / V in LDS, bias added in the score loop (csrc/sam_ops.hip)
+            # one kernel per block: a lane per query, the window's key / value rows through scalar loads (csrc/sam_ops.hip)
             key = (str(x.device), self.attention_biases._version)
             if getattr(self, "_bias_t", (None,))[0] != key:
                 bias = self.attention_biases[:, self.attention_bias_idxs].detach().to(torch.float32)
