@@ -160,3 +160,26 @@ def test_e6e_graph_on_hip_convolutions_matches_the_framework_path(gpu_device):
         # and in the mean the two f16 paths are equally close to f32
         m_lib, m_hip = float((lib - ref).abs().mean()), float((hip - ref).abs().mean())
         assert m_hip <= 1.5 * m_lib + 1e-4, (m_hip, m_lib)
+
+
+def test_predict_batch_slices_large_batches(gpu_device):
+    """YOLOv7.predict_batch sends batches beyond MAX_FRAMES_PER_FORWARD through the network in slices (the convolution kernel
+    addresses with 32-bit element offsets): same detections as one forward."""
+    from vlfm_amd.vlm.yolov7 import YOLOv7
+
+    det = YOLOv7(device=gpu_device, allow_random_init=True, width_multiple=0.25)
+    assert det.hip_convs == 244
+    with torch.no_grad():   # make the random net emit confident boxes
+        for m in det.model.model[-1].m:
+            m.bias.fill_(0.0)
+            m.bias.view(3, 85)[:, 4] = 1.5
+        det.model.model[-1].use_hip_conv_()          # re-pack the head's filter rows with the new bias
+    g = torch.Generator().manual_seed(9)
+    frames = torch.randint(0, 255, (5, 480, 640, 3), generator=g, dtype=torch.uint8).to(gpu_device)
+    whole = det.predict_batch(frames)
+    det.MAX_FRAMES_PER_FORWARD = 2
+    sliced = det.predict_batch(frames)
+    assert len(whole) == len(sliced) == 5 and sum(d.num_detections for d in whole) > 0
+    for a, b in zip(whole, sliced):
+        assert a.num_detections == b.num_detections and torch.equal(a.boxes, b.boxes) and torch.equal(a.logits, b.logits)
+        assert a.phrases == b.phrases

@@ -72,6 +72,8 @@ class YOLOv7:
             self.hip_convs = self.model.use_hip_conv_()
             self.description += f"; {self.hip_convs} convolutions on conv_nhwc.hip"
 
+    MAX_FRAMES_PER_FORWARD = 256
+
     def _load(self, path: str):
         try:
             return torch.jit.load(path, map_location=self.device).eval(), f"torchscript:{path}"
@@ -96,8 +98,13 @@ class YOLOv7:
                                   torch.float16 if self.half_precision else torch.float32)
         if self.hip_convs:
             img = img.contiguous(memory_format=torch.channels_last)
-        pred = self.model(img)
-        pred = pred[0] if isinstance(pred, (tuple, list)) else pred
+        # csrc/conv_nhwc.hip addresses with 32-bit element offsets: the widest activation (80 channels at half resolution) of 256
+        # frames is 1.47 G elements, so larger batches go through the network in slices
+        preds = []
+        for i in range(0, B, self.MAX_FRAMES_PER_FORWARD):
+            pred = self.model(img[i:i + self.MAX_FRAMES_PER_FORWARD])
+            preds.append(pred[0] if isinstance(pred, (tuple, list)) else pred)
+        pred = preds[0] if len(preds) == 1 else torch.cat(preds, 0)
         dets = det_ops.non_max_suppression(pred.float(), conf_thres, iou_thres, classes=classes, agnostic=agnostic_nms)
         # rescale / round / normalise all detections of the batch at once, one transfer to the host (yolov7.py:99-110 per image)
         sizes = [int(p.shape[0]) for p in dets]
