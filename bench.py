@@ -689,12 +689,29 @@ def side_legs(args, sim, device, common):
                                pointnav=WrappedPointNavResNetPolicy(None, device=device, n_envs=n_envs,
                                                                     discrete_actions=True), **common)
         full.fast_forward(min(args.preroll, 40))
+        conv_launches = int(getattr(detector, "hip_convs", 0))
+        if conv_launches:
+            _lib.lib().vlfm_profile_enable(7)    # every 7th convolution launch: walks through all 244 layers over the timed steps
         dt = timed(full, warm, n)
-        side[f"configs[2] full step{tag}, envs_per_gpu={n_envs}"] = {
+        rec = {
             "value": round(n_envs / dt, 2), "unit": "env-steps/s", "ms_per_step": round(dt * 1e3, 3),
             "controller": "PointNav ResNet-18-GN + LSTM, random-init, discrete head",
             "detector": getattr(detector, "description", detector.weights),
             "segmenter": "MobileSAM (TinyViT-5M) random-init, 1 box for every 4th env-step"}
+        if conv_launches:
+            ms, timed_n = _lib.profile_read("conv_nhwc_kernel")
+            _lib.lib().vlfm_profile_enable(0)
+            if timed_n:
+                flop = detector.gflops * 1e9 * n_envs                      # 2 x MACs of every convolution, all frames
+                achieved = flop / (ms * 1e-3 * conv_launches) / 1e12       # mean launch x launches per forward
+                rec["detector_roofline"] = {
+                    "bound": "mfma", "kernel": "conv_nhwc_kernel (csrc/conv_nhwc.hip), f16 in / f32 accumulate",
+                    "achieved": round(achieved, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4),
+                    "launches_per_forward": conv_launches, "launches_timed": timed_n, "mean_launch_ms": round(ms, 5),
+                    "gflop_per_frame": round(detector.gflops, 1),
+                    "note": "HIP events on every 7th launch; the layer mix is what it is: 64-channel 3x3 layers are LDS-bound "
+                            "(~0.6 PFLOP/s), the 80 / 160-channel 1x1 layers at 224x320 / 112x160 HBM-bound (DESIGN.md 6d)"}
+        side[f"configs[2] full step{tag}, envs_per_gpu={n_envs}"] = rec
         del full
 
     def leg_full():
