@@ -6,6 +6,7 @@ export TMPDIR=/tmp
 O=gpurun_out/s_r3; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log; tail -4 $O/pytest_gpu.log
 timeout 1500 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"; tail -c 400 $O/bench_default.json
+cp gpurun_out/host_busy.json $O/host_busy.json 2>/dev/null   # the plain run's figure (the rocprofv3 runs below rewrite the file with their own overhead)
 cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats -d $R/$O/prof_default -o p -- python $R/bench.py --no-small --no-cpu-baseline --steps 10 > $R/$O/prof_default.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/$O/prof_cfg5 -o p -- python $R/bench.py --no-blip2 --envs 16 --height 720 --width 1280 --sync-explored --no-small --no-cpu-baseline > $R/$O/prof_cfg5.log 2>&1
@@ -18,7 +19,6 @@ VLFM_COMMIT=${VLFM_COMMIT:-unknown} bash tools/pmc_traffic.sh 256 640 480 > $O/p
 VLFM_COMMIT=${VLFM_COMMIT:-unknown} bash tools/pmc_traffic.sh 16 1280 720 sync > $O/pmc_cfg5.log 2>&1
 cp profiles/pmc_traffic.json $O/pmc_traffic.json
 bash tools/pmc_sq.sh ingest depth_ingest -- python $R/tools/ingest_probe.py 4 > /dev/null 2>&1; cp gpurun_out/pmc_sq_ingest.txt $O/r03_ingest_sq_pmc.txt
-cp gpurun_out/host_busy.json $O/host_busy.json 2>/dev/null
 # yolov7-e6e on conv_nhwc.hip: per-layer-shape table, tile-shape sweep, rocprofv3 kernel stats of the forward alone
 (timeout 200 python tools/yolo_layer_probe.py 64 2>&1 | grep -v amdgpu.ids) > $O/r03_yolo_e6e_layers_b64.txt 2>&1
 (timeout 200 python tools/yolo_layer_probe.py 128 2>&1 | grep -v amdgpu.ids) > $O/r03_yolo_e6e_layers_b128.txt 2>&1
