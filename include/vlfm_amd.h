@@ -353,6 +353,9 @@ int vlfm_window_attention_f32(const float* d_qkv, const float* d_bias_t, float* 
  *   act    0 = none, 1 = SiLU
  * ksize 1 or 3, stride 1 or 2, cin % 64 == 0, cout % 8 == 0, both pixel strides % 8 == 0, tensors < 2^31 elements;
  * anything else returns VLFM_ERR_INVALID (the caller keeps such a layer on the framework's convolution). */
+/* 2x2 / stride-2 max pooling of a contiguous NHWC f16 tensor (DownC's pooling branch in the same graph): even height and width,
+ * channels % 8 == 0. */
+int vlfm_maxpool2x2_nhwc_f16(const void* d_x, void* d_out, int batch, int height, int width, int channels, void* stream);
 int vlfm_conv_nhwc_tile(int pixels, int cin, int cout, int ksize, int* tile_pixels, int* tile_channels);  /* host: the tile shape chosen */
 int vlfm_conv_nhwc_f16(const void* d_x, const void* d_w, const void* d_bias, void* d_out, const void* d_zero, int batch,
                        int height, int width, int cin, int cout, int ksize, int stride, int x_pix_stride,

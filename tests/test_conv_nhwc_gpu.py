@@ -183,3 +183,16 @@ def test_predict_batch_slices_large_batches(gpu_device):
     for a, b in zip(whole, sliced):
         assert a.num_detections == b.num_detections and torch.equal(a.boxes, b.boxes) and torch.equal(a.logits, b.logits)
         assert a.phrases == b.phrases
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 80, 224, 320), (3, 8, 2, 2), (1, 320, 14, 20)])
+def test_maxpool2x2_nhwc_is_the_framework_pooling(gpu_device, B, C, H, W):
+    from vlfm_amd.vlm import det_ops
+
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(B, C, H, W, generator=g).half().to(gpu_device).contiguous(memory_format=torch.channels_last)
+    got = det_ops.maxpool2x2_nhwc(x)
+    assert got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, torch.nn.functional.max_pool2d(x, 2, 2))                 # a maximum has no rounding
+    odd = torch.randn(1, 12, 5, 6).half().to(gpu_device)                             # not a shape the kernel takes: framework path
+    assert torch.equal(det_ops.maxpool2x2_nhwc(odd), torch.nn.functional.max_pool2d(odd, 2, 2))

@@ -125,6 +125,7 @@ def lib() -> ctypes.CDLL:
         L.vlfm_window_reverse_add_f32.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
         L.vlfm_dwconv3x3_nhwc_f32.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
         L.vlfm_window_attention_f32.argtypes = [vp, vp, vp, ctypes.c_longlong, ci, ci, ctypes.c_float, vp]
+        L.vlfm_maxpool2x2_nhwc_f16.argtypes = [vp, vp, ci, ci, ci, ci, vp]
         L.vlfm_conv_nhwc_tile.argtypes = [ci, ci, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(ci)]
         L.vlfm_conv_nhwc_f16.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
         L.vlfm_value_map_scratch_bytes.argtypes = [ci, ci]

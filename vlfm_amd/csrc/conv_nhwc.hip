@@ -292,10 +292,46 @@ static int pick_cfg(int M, int cout, int ktiles) {
     return best;
 }
 
+// 2x2 / stride-2 max pooling on NHWC f16 rows (DownC's `mp` in front of its 1x1 convolution): 16 bytes = 8 channels per lane,
+// consecutive lanes on consecutive channels.  The framework's NHWC pooling kernel moves ~1.5 TB/s on the 80-channel 224x320 map.
+__global__ __launch_bounds__(256) void maxpool2x2_nhwc_f16_kernel(const _Float16* __restrict__ x, _Float16* __restrict__ out, int H,
+                                                                 int W, int C8, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int c = (int)(i % C8);
+    const long long pix = i / C8;
+    const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho);
+    const long long b = pix / ((long long)Wo * Ho);
+    const half8* p = reinterpret_cast<const half8*>(x) + (((b * H + 2 * oy) * W + 2 * ox) * C8 + c);
+    const half8 v00 = p[0], v01 = p[C8], v10 = p[(long long)W * C8], v11 = p[(long long)W * C8 + C8];
+    half8 r;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const _Float16 a = v00[k] > v01[k] ? v00[k] : v01[k], bb = v10[k] > v11[k] ? v10[k] : v11[k];
+        r[k] = a > bb ? a : bb;
+    }
+    reinterpret_cast<half8*>(out)[i] = r;
+}
+
 }  // namespace conv
 }  // namespace vlfm
 
 using namespace vlfm;
+
+// out[b][oy][ox][:] = max over the 2x2 block of x (stride 2, no padding; height and width even): contiguous NHWC f16, channels % 8 == 0.
+extern "C" int vlfm_maxpool2x2_nhwc_f16(const void* d_x, void* d_out, int batch, int height, int width, int channels, void* stream) {
+    if (batch == 0) return VLFM_OK;
+    if (!d_x || !d_out || batch < 0 || height <= 0 || width <= 0 || (height & 1) || (width & 1) || channels <= 0 || (channels & 7))
+        return fail(VLFM_ERR_INVALID, "maxpool2x2_nhwc_f16: even height and width, channels % 8 == 0");
+    const long long n = (long long)batch * (height / 2) * (width / 2) * (channels / 8);
+    const long long blocks = (n + 255) / 256;
+    if (blocks > 0x7fffffffLL) return fail(VLFM_ERR_CAPACITY, "maxpool2x2_nhwc_f16: tensor too large");
+    VLFM_TIMED("maxpool2x2_nhwc_f16_kernel", stream);
+    VLFM_KLAUNCH(conv::maxpool2x2_nhwc_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)d_x,
+                 (_Float16*)d_out, height, width, channels / 8, n);
+    return check_launch("maxpool2x2_nhwc_f16_kernel");
+}
 
 // The tile shape vlfm_conv_nhwc_f16 uses for a layer of `pixels` output pixels, `cout` channels and K = ksize^2 * cin (host logic only:
 // no device needed; tests/test_host_logic.py pins the properties the estimate must have).

@@ -268,6 +268,19 @@ def conv_nhwc(x: torch.Tensor, w_rows: torch.Tensor, bias: Optional[torch.Tensor
     return out
 
 
+def maxpool2x2_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """``F.max_pool2d(x, 2, 2)`` of a channels_last f16 tensor with even sides and C % 8 == 0 (csrc/conv_nhwc.hip): DownC's
+    pooling branch at HBM rate; anything else goes to the framework."""
+    B, C, H, W = x.shape
+    if not (x.is_cuda and x.dtype == torch.float16 and C % 8 == 0 and H % 2 == 0 and W % 2 == 0
+            and x.is_contiguous(memory_format=torch.channels_last)):
+        return torch.nn.functional.max_pool2d(x, 2, 2)
+    out = torch.empty((B, C, H // 2, W // 2), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().vlfm_maxpool2x2_nhwc_f16(x.data_ptr(), out.data_ptr(), B, H, W, C, _stream()), "maxpool2x2_nhwc_f16")
+    return out
+
+
 def fold_batchnorm_(model) -> int:
     """Inference-time folding of every eval-mode BatchNorm2d that directly follows a Conv2d inside an ``nn.Sequential`` (the
     conv + bn + SiLU triples of the YOLOv7-class network, TinyViT's ``Conv2d_BN``): the convolution gets the scaled weights,

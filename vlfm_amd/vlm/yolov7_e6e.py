@@ -121,7 +121,13 @@ class DownC(nn.Module):
         self.mp = nn.MaxPool2d(kernel_size=k, stride=k)
 
     def forward(self, x):
-        t, p = self.cv1(x), self.mp(x)
+        t = self.cv1(x)
+        if self.cv3.takes_hip(x) and self.mp.kernel_size == 2 and self.mp.stride == 2:
+            from .det_ops import maxpool2x2_nhwc
+
+            p = maxpool2x2_nhwc(x)
+        else:
+            p = self.mp(x)
         if self.cv2.takes_out(t) and self.cv3.takes_out(p) and self.cv2.out_hw(*t.shape[2:]) == tuple(p.shape[2:]):
             ca, cb = self.cv2.conv.out_channels, self.cv3.conv.out_channels     # both halves straight into the concatenation
             buf = torch.empty((x.shape[0], ca + cb, p.shape[2], p.shape[3]), dtype=x.dtype, device=x.device,
