@@ -1,3 +1,6 @@
+"""The tile shapes of csrc/conv_nhwc.hip (a 1x1 convolution IS an NT GEMM) on the ViT-g GEMM shapes of the headline step, next to
+hipBLASLt: is the two-workgroups-per-CU 128x128 form that wins on the detector's layers a candidate for the ViT?  (Measured: no --
+785-857 TFLOP/s against 968-1184.)  Usage: python tools/conv_as_gemm_probe.py"""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
