@@ -490,6 +490,10 @@ size_t vlfm_obstacle_scratch_bytes(int n_envs, int map_size, int cap_pts, int ca
  *               passes the whole map (0, S-1, 0, S-1) after a reset of the slot's planes, for a frame whose reach window
  *               leaves the map (NumPy's negative-index wrap, obstacle_map.py:101, lands on the far side) and for the first
  *               call on fresh scratch.  NULL = the reference's full-map passes (always valid).
+ *               SKIPPED observations (d_prm[k].n_poly <= 0): the kernels neither mask nor refresh anything for them, so the
+ *               caller must KEEP that observation's pending windows [0..3] / [8..11] in its own bookkeeping and hand them
+ *               over again with the slot's next non-skipped call (ObstacleMapBatch._take_windows does); dropping them leaves
+ *               stale derived planes and stale frontiers.
  *   window_blocks_navigable / window_blocks_prepare: launch sizes (256-word workgroups per observation) for the two windowed
  *               kernels = ceil(max over the batch of rows x 32-cell words of the window(s) / 256); the kernels stride, so
  *               any positive value is correct and 0 means "size for the full plane". */

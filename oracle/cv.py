@@ -4,7 +4,12 @@ A tiny ``cv2``-shaped facade over ``oracle/cvport.c`` so that the oracle modules
 (`oracle/value_map.py`, `oracle/obstacle_map.py`, ...) can follow the reference
 source line by line (``cv2.ellipse`` -> ``cv.ellipse`` etc.).  OpenCV itself is not
 available in this environment (pinned opencv-python==4.5.5.64,
-/root/reference/pyproject.toml:28); parity with real OpenCV is UNPINNED.
+/root/reference/pyproject.toml:28); parity with real OpenCV is UNPINNED HERE.
+
+On a machine that HAS the pinned wheel, ``VLFM_REAL_CV2=1`` rebinds every facade function below to the real ``cv2``
+(``use_real()``), so the same oracle modules and the same tests run on OpenCV itself and any deviation of cvport.c shows up
+as a diff against the committed fixtures (tools/verify_with_real_vlfm.md).  ``STANDIN`` keeps the cvport versions reachable
+for the side-by-side comparison in tests/test_oracle_cv.py.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
 """
@@ -238,3 +243,61 @@ def boundingRect(array):
     if len(xs) == 0:
         return (0, 0, 0, 0)
     return (int(xs.min()), int(ys.min()), int(xs.max() - xs.min() + 1), int(ys.max() - ys.min() + 1))
+
+
+# ---------------------------------------------------------------------------------------------- real-library switch
+FACADE_NAMES = ("ellipse", "drawContours", "circle", "polylines", "getRotationMatrix2D", "warpAffine", "dilate", "blur",
+                "findContours", "contourArea", "pointPolygonTest", "isContourConvex", "bitwise_and", "erode", "boundingRect")
+STANDIN = {n: globals()[n] for n in FACADE_NAMES}      # the cvport.c versions, whatever the module-level names point at
+BACKEND = "stand-in: oracle/cvport.c (OpenCV 4.5.5 restated)"
+
+
+def real_cv2_requested() -> bool:
+    return os.environ.get("VLFM_REAL_CV2", "") not in ("", "0")
+
+
+def import_real_cv2():
+    """The real ``cv2`` package, or ImportError: a module named cv2 that carries ref_shim's stand-in mark does not count."""
+    import importlib
+    import sys
+
+    mod = sys.modules.get("cv2")
+    if mod is not None and getattr(mod, "__vlfm_standin__", False):
+        del sys.modules["cv2"]
+        mod = None
+    mod = mod or importlib.import_module("cv2")
+    if getattr(mod, "__vlfm_standin__", False):
+        raise ImportError("the module named cv2 is oracle/ref_shim.py's stand-in")
+    return mod
+
+
+def use_real(cv2_module=None) -> str:
+    """Rebind the facade to a real OpenCV: every oracle module that says ``cv.ellipse`` / ``cv.warpAffine`` ... now runs
+    OpenCV's own code.  Returns the backend description."""
+    global BACKEND
+    real = cv2_module or import_real_cv2()
+    g = globals()
+    for n in FACADE_NAMES:
+        g[n] = getattr(real, n)
+    for n in ("RETR_EXTERNAL", "RETR_LIST", "RETR_CCOMP", "RETR_TREE", "CHAIN_APPROX_NONE", "CHAIN_APPROX_SIMPLE"):
+        g[n] = getattr(real, n)
+    _find = real.findContours
+
+    def findContours(image, mode, method):   # OpenCV 3.x returned (image, contours, hierarchy); 4.x (contours, hierarchy)
+        out = _find(image, mode, method)
+        return (list(out[-2]), out[-1])
+
+    g["findContours"] = findContours
+    BACKEND = f"real: cv2 {getattr(real, '__version__', '?')} ({getattr(real, '__file__', '?')})"
+    return BACKEND
+
+
+def use_standin() -> None:
+    global BACKEND
+    globals().update(STANDIN)
+    globals().update(RETR_EXTERNAL=0, RETR_LIST=1, RETR_CCOMP=2, RETR_TREE=3, CHAIN_APPROX_NONE=1, CHAIN_APPROX_SIMPLE=2)
+    BACKEND = "stand-in: oracle/cvport.c (OpenCV 4.5.5 restated)"
+
+
+if real_cv2_requested():
+    use_real()   # ImportError here is the loud failure VLFM_REAL_CV2=1 asks for

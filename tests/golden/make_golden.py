@@ -9,6 +9,9 @@ the OpenCV / frontier_exploration rules stay restatements (PARITY UNPINNED for t
 
     python tests/golden/make_golden.py            # (re)write tests/golden/*.npz   (needs /root/reference)
     python tests/golden/make_golden.py --check    # regenerate in memory and compare with the committed files
+    python tests/golden/make_golden.py --check --real-cv2   # the same with the REAL opencv-python (and frontier_exploration, if
+                                                  # importable) under the reference instead of the stand-ins: per fixture the
+                                                  # largest difference and the first differing cell (tools/verify_with_real_vlfm.md)
 
 Inputs are the deterministic synthetic episodes of vlfm_amd/synthetic.py; each fixture stores the poses
 and values explicitly and a SHA-256 of every depth frame, so a consumer that regenerates the depth from the seed can
@@ -729,11 +732,36 @@ def same(a, b) -> bool:
     return a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
 
 
+def describe_difference(have, want) -> str:
+    """Largest difference and first differing cell of two arrays (for the --check report)."""
+    a, b = np.asarray(have), np.asarray(want)
+    if a.shape != b.shape:
+        return f"shape {a.shape} in the file, {b.shape} regenerated"
+    if a.dtype.kind in "US" or b.dtype.kind in "US" or a.dtype.kind == "b":
+        bad = np.flatnonzero((a != b).reshape(-1))
+        return f"{len(bad)} of {a.size} entries differ, first at flat index {int(bad[0])}: {a.reshape(-1)[bad[0]]!r} vs {b.reshape(-1)[bad[0]]!r}"
+    neq = ~((a == b) | (np.isnan(a.astype(np.float64)) & np.isnan(b.astype(np.float64))))
+    bad = np.flatnonzero(neq.reshape(-1))
+    d = np.abs(a.astype(np.float64) - b.astype(np.float64)).reshape(-1)
+    first = np.unravel_index(int(bad[0]), a.shape) if a.ndim else ()
+    return (f"{len(bad)} of {a.size} cells differ, max |diff| {np.nanmax(d[bad]):.3e}, first at {tuple(int(i) for i in first)}: "
+            f"{a.reshape(-1)[bad[0]]!r} in the file vs {b.reshape(-1)[bad[0]]!r} regenerated")
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--real-cv2", action="store_true",
+                    help="run the reference on the real cv2 (mandatory) / frontier_exploration (if importable) instead of the stand-ins")
     args = ap.parse_args()
+    if args.real_cv2:
+        if not args.check:
+            ap.error("--real-cv2 only makes sense with --check: the committed fixtures are the stand-in run everyone can reproduce")
+        os.environ["VLFM_REAL_CV2"] = "1"      # before oracle.cv is imported, and inherited by the ep500 worker process
+    from oracle import ref_shim
+
     cases = generate()
+    print("libraries under the reference:", ref_shim.backends())
     bad = 0
     for name, blob in cases.items():
         path = os.path.join(HERE, name + ".npz")
@@ -741,8 +769,11 @@ def main() -> int:
             here = 0
             with np.load(path, allow_pickle=False) as have:
                 for k, v in blob.items():
-                    if k not in have.files or not same(have[k], v):
-                        print(f"MISMATCH {name}.{k}")
+                    if k not in have.files:
+                        print(f"MISMATCH {name}.{k}: not in the committed file")
+                        here += 1
+                    elif not same(have[k], v):
+                        print(f"MISMATCH {name}.{k}: {describe_difference(have[k], v)}")
                         here += 1
             bad += here
             print(f"checked {name}: {'ok' if not here else 'DIFFERS'}")

@@ -199,3 +199,70 @@ def test_thick_polyline_covers_thin_line_and_is_wider():
     from scipy import ndimage
     lab, n = ndimage.label(img[8:18, 11:25])  # a window the band crosses completely
     assert n >= 2
+
+
+# ------------------------------------------------------------------------------------------ cvport.c beside the REAL cv2
+def _real_cv2_or_skip():
+    """The real wheel, if this machine has one (tools/verify_with_real_vlfm.md); with VLFM_REAL_CV2=1 its absence already
+    failed at ``from oracle import cv``."""
+    import pytest
+
+    try:
+        return cv.import_real_cv2()
+    except ImportError:
+        pytest.skip("no real cv2 on this machine (opencv-python==4.5.5.64 is the reference's pin)")
+
+
+def _blobs(rng, shape=(160, 200)):
+    img = np.zeros(shape, np.uint8)
+    for _ in range(int(rng.integers(2, 7))):
+        cy, cx = rng.integers(10, shape[0] - 10), rng.integers(10, shape[1] - 10)
+        ry, rx = rng.integers(2, 25), rng.integers(2, 25)
+        img[max(cy - ry, 0):cy + ry, max(cx - rx, 0):cx + rx] = 1
+    holes = rng.integers(0, 2, shape).astype(np.uint8)
+    return img & (holes | (rng.random(shape) < 0.97).astype(np.uint8))
+
+
+def test_cvport_equals_real_cv2_on_the_entry_points_of_the_path():
+    """Side by side on seeded random inputs, bit for bit: the sector mask and rotation of value_map.py:260,325-334, the filled
+    polygons of img_utils.py / obstacle_map.py:164, the dilation of obstacle_map.py:117, the contour calls of :128-169."""
+    real = _real_cv2_or_skip()
+    S = cv.STANDIN
+    rng = np.random.default_rng(20240926)
+    for it in range(40):
+        size = int(rng.choice([101, 201, 401]))
+        c = size // 2
+        fov = float(rng.uniform(40, 110))
+        for dtype in (np.uint8, np.float64):
+            a, b = np.zeros((size, size), dtype), np.zeros((size, size), dtype)
+            args = ((c, c), (c, c), 0, -fov / 2 + 90, fov / 2 + 90, 1, -1)
+            S["ellipse"](a, *args); real.ellipse(b, *args)
+            assert np.array_equal(a, b), ("ellipse", size, fov, dtype)
+        angle = float(rng.uniform(-360, 360))
+        M0, M1 = S["getRotationMatrix2D"]((c, c), angle, 1.0), real.getRotationMatrix2D((c, c), angle, 1.0)
+        assert np.array_equal(M0, M1), ("getRotationMatrix2D", angle)
+        src = rng.random((size, size)) * (rng.random((size, size)) < 0.5)
+        assert np.array_equal(S["warpAffine"](src, M0, (size, size)), real.warpAffine(src, M1, (size, size))), ("warpAffine", angle)
+        poly = rng.integers(-20, size + 20, (int(rng.integers(3, 40)), 2)).astype(np.int32)
+        a, b = np.zeros((size, size), np.uint8), np.zeros((size, size), np.uint8)
+        S["drawContours"](a, [poly], -1, 1, -1); real.drawContours(b, [poly], -1, 1, -1)
+        assert np.array_equal(a, b), ("drawContours", it)
+        img = _blobs(rng)
+        k = int(rng.choice([3, 7, 9]))
+        kern = np.ones((k, k), np.uint8)
+        assert np.array_equal(S["dilate"](img, kern, iterations=1), real.dilate(img, kern, iterations=1)), ("dilate", k)
+        for mode, method in ((0, 1), (0, 2), (1, 1), (1, 2)):   # RETR_EXTERNAL / RETR_LIST x CHAIN_APPROX_NONE / SIMPLE
+            c0, _ = S["findContours"](img.copy(), mode, method)
+            c1 = real.findContours(img.copy(), mode, method)[-2]
+            assert len(c0) == len(c1), ("findContours count", mode, method)
+            for p, q in zip(c0, c1):
+                assert np.array_equal(np.asarray(p), np.asarray(q)), ("findContours", mode, method)
+                assert S["contourArea"](p) == real.contourArea(q)
+                pt = (float(rng.integers(0, img.shape[1])), float(rng.integers(0, img.shape[0])))
+                assert S["pointPolygonTest"](p, pt, False) == real.pointPolygonTest(q, pt, False)
+                assert S["pointPolygonTest"](p, pt, True) == real.pointPolygonTest(q, pt, True)
+        cen = (int(rng.integers(0, size)), int(rng.integers(0, size)))
+        a, b = np.zeros((size, size), np.uint8), np.zeros((size, size), np.uint8)
+        r = int(rng.integers(1, 30))
+        S["circle"](a, cen, r, 1, -1); real.circle(b, cen, r, 1, -1)
+        assert np.array_equal(a, b), ("circle", cen, r)

@@ -191,3 +191,24 @@ def test_a_pickled_yolov7_checkpoint_opens_without_the_yolov7_repository(tmp_pat
     torch.save({"model": Evil()}, str(tmp_path / "evil.pt"))
     with pytest.raises(Exception, match="refusing"):
         e6e.read_yolov7_checkpoint(str(tmp_path / "evil.pt"))
+
+
+@pytest.mark.parametrize("target", ["torch.utils.collect_env.run", "torch.hub.load", "torch.load", "numpy.load",
+                                    "builtins.getattr", "builtins.eval", "torch.storage._load_from_bytes", "os.system"])
+def test_the_checkpoint_reader_refuses_callables_inside_torch_and_numpy(tmp_path, target):
+    """a prefix rule ("torch.*", "numpy*") lets REDUCE call torch.utils.collect_env.run(<shell command>).  The
+    allowlist is exact: each of these globals must be refused BEFORE anything is called (the marker file must not appear)."""
+    import importlib
+
+    mod, name = target.rsplit(".", 1)
+    fn = getattr(importlib.import_module(mod), name)
+    marker = tmp_path / "pwned"
+
+    class Evil:
+        def __reduce__(self):
+            return (fn, (f"touch {marker}",))
+
+    torch.save({"model": Evil()}, str(tmp_path / "evil.pt"))
+    with pytest.raises(Exception, match="refusing"):
+        e6e.read_yolov7_checkpoint(str(tmp_path / "evil.pt"))
+    assert not marker.exists()

@@ -24,7 +24,7 @@ names = ["keys->vertices", "flattened raster", "key hand-back", "resolve+visible
 for (E, H, W, sync, wgs) in [(256, 480, 640, False, 256), (256, 480, 640, False, 512), (128, 480, 640, False, 256), (128, 480, 640, False, 512),
                              (64, 480, 640, False, 256), (64, 480, 640, False, 512), (16, 720, 1280, True, 112), (16, 720, 1280, True, 48),
                              (8, 480, 640, False, 256), (8, 480, 640, False, 24), (1, 480, 640, False, 256), (1, 480, 640, False, 3)]:
-    os.environ["VLFM_VM_TARGET_WGS"] = str(wgs)
+    os.environ["VLFM_VM_TARGET_WGS"] = str(wgs)   # NOTE (round 4): the library now reads this once per process -- run one process per value
     sim = BatchedEpisodes(E, device=torch.device("cuda:0"), use_blip2=False, overlap=False, height=H, width=W, sync_explored=sync)
     sim.fast_forward(60)
     acc = np.zeros(7); n = 0; tile = np.zeros(3)

@@ -195,6 +195,24 @@ def host_wait_blocking(device=None, blocking: bool = True) -> None:
         check(lib().vlfm_host_wait_mode(int(bool(blocking))), "host_wait_mode")
 
 
+def try_host_wait_blocking(device=None) -> bool:
+    """`host_wait_blocking` for library code that does not own the process: the flag changes how EVERY wait on the device behaves
+    and some runtimes reject a change once the primary context is active, so a failure is a warning, never an exception, and
+    VLFM_HOST_WAIT=spin opts out.  Returns whether the flag was set."""
+    import os
+    import warnings
+
+    if os.environ.get("VLFM_HOST_WAIT", "blocking") == "spin":
+        return False
+    try:
+        host_wait_blocking(device)
+        return True
+    except Exception as exc:  # noqa: BLE001
+        warnings.warn(f"blocking host waits not enabled on {device}: {exc} (call vlfm_amd._lib.host_wait_blocking before the "
+                      f"device's first allocation; waits will spin on a host core)")
+        return False
+
+
 def check(rc: int, what: str = "") -> int:
     """Map a vlfm_status to the reference's Python exception conventions."""
     if rc >= 0:

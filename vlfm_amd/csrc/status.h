@@ -19,6 +19,21 @@ inline int check_launch(const char* what) {
     }
     return VLFM_OK;
 }
+// Compute units of the CURRENT device, asked once per device and process (launch-size decisions: "one workgroup per CU").
+inline int device_cu_count() {
+    static int cached[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+            (void)hipGetLastError();
+            n = 256;   // MI355X
+        }
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
 // More than 64 KB of dynamic LDS needs an explicit opt-in per kernel AND per device.  One instance per call site
 // (function-local static); remembers how many bytes each device of this process has been opted in to, and asks again only
 // for more.  (The limit is 160 KB minus the kernel's static LDS: ask for what the launch uses, not for the maximum.)

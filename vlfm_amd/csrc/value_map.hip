@@ -1101,11 +1101,9 @@ extern "C" int vlfm_value_map_update_fused_batched(uint32_t* d_colmax_keys, int 
     const int tiles = (T + ROWS_PER_TILE - 1) / ROWS_PER_TILE;
     // workgroups per observation: a 1024-thread workgroup fills a CU (register budget), so aim for one per CU over all
     // observations; more than ceil(tiles / 4) would leave workgroups without a tile
-    int target = 256;
-    if (const char* e = getenv("VLFM_VM_TARGET_WGS")) {  // diagnostic: tools/vm_phase_probe.py sweeps it
-        const int t = atoi(e);
-        if (t > 0) target = t;
-    }
+    // (the device's CU count, asked once; VLFM_VM_TARGET_WGS -- read once per process -- is tools/vm_phase_probe.py's sweep knob)
+    static const int target_override = [] { const char* e = getenv("VLFM_VM_TARGET_WGS"); return e ? atoi(e) : 0; }();
+    const int target = target_override > 0 ? target_override : device_cu_count();
     int G = (target + n - 1) / n;
     const int g_max = (tiles + FUSED_THREADS / 256 - 1) / (FUSED_THREADS / 256);
     if (G > g_max) G = g_max;

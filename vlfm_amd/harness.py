@@ -92,7 +92,9 @@ class BatchedEpisodes:
                  graph_blip2: Optional[bool] = None, host_inputs: bool = False, select_frontiers: bool = False,
                  pointnav=None, world: str = "rooms") -> None:
         self.device = require_gpu(device)
-        _lib.host_wait_blocking(self.device)   # a rank waiting for its GPU must not hold a host core (bench.py `host`)
+        # a rank waiting for its GPU must not hold a host core (bench.py `host`).  Effective only before the device's first
+        # stream exists (bench.py sets it first thing); here it is best effort: a warning on failure, VLFM_HOST_WAIT=spin opts out
+        _lib.try_host_wait_blocking(self.device)
         self.E, self.H, self.W, self.S = n_envs, height, width, map_size
         self.fx, self.fy, self.fov = camera_intrinsics(width)
         self.episode_len = episode_len

@@ -123,10 +123,13 @@ class ObstacleMapBatch:
         win = np.where(inside[:, None], win, np.array([0, S - 1, 0, S - 1], np.float64)[None]).astype(np.int32)
         self._union(self._dirty_obst, env, win)
 
-    def _take_windows(self, env: np.ndarray, update_obstacles: bool, explore: bool, agent_px=None, fog_radius: int = 0):
+    def _take_windows(self, env: np.ndarray, update_obstacles: bool, explore: bool, agent_px=None, fog_radius: int = 0,
+                      skipped=None):
         """([n, 12] int32 windows, workgroups for navigable_kernel, workgroups for frontier_prepare_kernel) for
         vlfm_obstacle_map_update_batched, and the bookkeeping that goes with handing them over.  ``agent_px`` [n, 2] (x, y)
-        = the agent cells of an explore call: the reveal touches agent +- (fog_radius + 2)."""
+        = the agent cells of an explore call: the reveal touches agent +- (fog_radius + 2).  ``skipped`` [n] bool marks
+        observations whose fog params carry n_poly <= 0: the kernels do nothing for them, so their pending refresh windows stay
+        pending (include/vlfm_amd.h, d_windows)."""
         S, n = self.size, len(env)
         empty = np.array([0, -1, 0, -1], np.int32)
         out = np.tile(np.concatenate([empty, empty, empty]), (n, 1))
@@ -157,7 +160,8 @@ class ObstacleMapBatch:
             tmp[:] = refresh
             self._union(tmp, np.arange(n), box)
             out[:, 8:12] = tmp
-            self._dirty_nav[env] = empty
+            done = env if skipped is None else env[~np.asarray(skipped, bool)]
+            self._dirty_nav[done] = empty
 
         def blocks(*wins) -> int:
             """256-word workgroups for the largest bounding union of the given windows over the batch."""
@@ -321,7 +325,8 @@ class ObstacleMapBatch:
         env = np.arange(n) if env_ids is None else np.asarray(env_ids, np.int64)
         agent = np.array([[q.ax, q.ay] for q in prm], np.int64) if explore else None
         windows, nb_nav, nb_prep = self._take_windows(env, update_obstacles, explore, agent,
-                                                      int(max_depth * self.pixels_per_meter))
+                                                      int(max_depth * self.pixels_per_meter),
+                                                      skipped=np.array([q.n_poly <= 0 for q in prm], bool))
         with torch.cuda.device(self.device):
             d_prm = self._ring_fog.upload(prm)
             d_win = None if self.full_planes else self._ring_win.upload(windows)

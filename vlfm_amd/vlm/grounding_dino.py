@@ -124,7 +124,9 @@ class GroundingDINO:
             self.model = GroundingDinoForObjectDetection(cfg)
             feed = gdino_weights.convert_groundingdino_state_dict(sd, self.model.state_dict())
             res = self.model.load_state_dict(feed, strict=False)
-            assert not res.unexpected_keys and set(res.missing_keys) <= set(gdino_weights._NOT_FED), res
+            if res.unexpected_keys or not set(res.missing_keys) <= set(gdino_weights._NOT_FED):   # (not an assert: python -O)
+                raise KeyError(f"GroundingDINO checkpoint {original!r} does not fill the graph: unexpected "
+                               f"{list(res.unexpected_keys)[:4]}, missing {list(res.missing_keys)[:4]}")
             tok = _bert_tokenizer(tokenizer_dir)
             self.tokenizer = lambda t: tok(t)["input_ids"]
             self.decode = tok.decode

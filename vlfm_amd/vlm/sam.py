@@ -106,7 +106,7 @@ class _WindowAttention(nn.Module):
         b, n, c = x.shape
         if x.is_cuda and x.dtype == torch.float32 and self.kd == 32 and n <= 256 and not torch.is_grad_enabled():
             # one kernel per block: a lane per query, the window's key / value rows through scalar loads (csrc/sam_ops.hip)
-            key = (str(x.device), self.attention_biases._version)
+            key = (str(x.device), self.attention_biases._version, self.attention_biases.data_ptr())
             if getattr(self, "_bias_t", (None,))[0] != key:
                 bias = self.attention_biases[:, self.attention_bias_idxs].detach().to(torch.float32)
                 self._bias_t = (key, bias.transpose(1, 2).contiguous())
@@ -154,7 +154,8 @@ class _TinyViTBlock(nn.Module):
 
     def rows_path(self, t: torch.Tensor) -> bool:
         """The NHWC-rows path (csrc/sam_ops.hip) takes f32 GPU tensors once the local_conv's BatchNorm is folded."""
-        return t.is_cuda and t.dtype == torch.float32 and _folded(self.local_conv) and t.shape[-1] % 4 == 0
+        return (t.is_cuda and t.dtype == torch.float32 and _folded(self.local_conv) and t.shape[-1] % 4 == 0
+                and not torch.is_grad_enabled() and not t.requires_grad)    # the rows kernels are forward-only and in place
 
     def forward_rows(self, t):  # [B, H, W, C] contiguous f32, OWNED by the caller's stage loop (updated in place)
         """The same block on NHWC rows: pad + window partition + attn.norm is one kernel, window reverse + crop + residual add is
@@ -165,9 +166,10 @@ class _TinyViTBlock(nn.Module):
         a = self.attn(ops.layernorm_rows(t, self.attn.norm.weight, self.attn.norm.bias, self.attn.norm.eps, ws), normed=True)
         ops.window_reverse_add_(t, a.contiguous(), ws)
         lc = self.local_conv
-        if getattr(self, "_w9c", None) is None or self._w9c.device != t.device:
-            self._w9c = lc.c.weight.detach().reshape(c, 9).t().contiguous()
-        t = ops.depthwise_conv3x3_nhwc(t, self._w9c, lc.bn.bias)
+        key = (str(t.device), lc.c.weight._version, lc.c.weight.data_ptr())   # a weight reload must not meet a stale repack
+        if getattr(self, "_w9c", (None,))[0] != key:
+            self._w9c = (key, lc.c.weight.detach().reshape(c, 9).t().contiguous())
+        t = ops.depthwise_conv3x3_nhwc(t, self._w9c[1], lc.bn.bias)
         m = self.mlp
         hid = F.gelu(m.fc1(ops.layernorm_rows(t, m.norm.weight, m.norm.bias, m.norm.eps)))
         return t.add_(m.fc2(hid))
@@ -188,6 +190,8 @@ class _Stage(nn.Module):
             t = x.permute(0, 2, 3, 1)
             if all(b.rows_path(t) for b in blocks):      # one NCHW -> NHWC copy per stage instead of four per block
                 t = t.contiguous()
+                if t.data_ptr() == x.data_ptr():   # channels_last input: .contiguous() is a view, and the rows path writes in place
+                    t = t.clone()
                 for blk in blocks:
                     t = blk.forward_rows(t)
                 x = t.permute(0, 3, 1, 2).contiguous()

@@ -21,8 +21,9 @@ Layout of the 262 modules (index: module), as in the yaml:
 ``yolov7-e6e.pt`` itself is a pickle of the yolov7 repository's classes (``models.yolo.Model``, ``models.common.Conv`` ...).
 `read_yolov7_checkpoint` opens it WITHOUT that repository: a restricted unpickler maps every class of the repository's
 ``models.*`` / ``utils.*`` namespaces onto an inert ``nn.Module`` shell (pickle restores ``_modules`` / ``_parameters`` /
-``_buffers`` through ``__dict__``, no constructor runs), and the state dict is read off the shells.  Nothing but tensors,
-containers and those shells is allowed through.
+``_buffers`` through ``__dict__``, no constructor runs), and the state dict is read off the shells.  Everything else goes through
+an EXACT (module, name) allowlist -- tensor / storage rebuilders, dtypes, containers, numpy scalars, ``torch.nn.modules`` classes --
+because whatever ``find_class`` returns can be CALLED by the pickle (``torch.utils.*``, ``torch.hub``, ``numpy.load`` are refused).
 """
 from __future__ import annotations
 
@@ -456,8 +457,7 @@ def load_yolov7_state_dict(model: YoloV7E6E, sd: Dict[str, torch.Tensor]) -> str
     sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}
     own = model.state_dict()
     fused = not any(".bn." in k for k in sd)
-    ignorable = {k for k in sd if k.endswith("num_batches_tracked")} | {k for k in sd if k.endswith(".ia.implicit") or
-                                                                        k.endswith(".im.implicit")}
+    ignorable = {k for k in sd if k.endswith("num_batches_tracked")}
     if any(k.endswith(".implicit") for k in sd):
         raise ValueError("this state dict has IDetect's implicit layers: it is a *_training.pt model, not the deploy model "
                          "yolov7-e6e.pt the reference loads (vlfm/vlm/yolov7.py:35)")
@@ -505,20 +505,44 @@ class _Shell(nn.Module):
 
 
 class _CheckpointUnpickler(pickle.Unpickler):
-    _ALLOWED_PREFIXES = ("torch.", "collections", "numpy", "_codecs", "builtins")
-    _ALLOWED_BUILTINS = {"set", "frozenset", "dict", "list", "tuple", "int", "float", "bool", "str", "bytes", "slice",
-                         "complex", "getattr", "object"}
+    """An EXACT allowlist, because pickle's REDUCE opcode calls whatever ``find_class`` hands back: a prefix rule such as
+    "anything under torch.*" lets ``torch.utils.collect_env.run`` (a shell), ``torch.hub.load``, ``numpy.load`` ... through.
+    What a yolov7 ``.pt`` (or a state-dict file) needs is: the tensor / parameter / storage rebuilders, ``torch.Size``,
+    dtypes and devices, ``OrderedDict``, numpy scalars (``best_fitness``), the ``torch.nn.modules`` CLASSES (instantiated
+    through ``copyreg._reconstructor`` / NEWOBJ, whose constructors only allocate) and the repository's own classes, which
+    become inert shells."""
+
+    _EXACT = {
+        ("collections", "OrderedDict"), ("copyreg", "_reconstructor"), ("copy_reg", "_reconstructor"),
+        ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
+        ("torch._utils", "_rebuild_parameter_with_state"), ("torch._tensor", "_rebuild_from_type_v2"),
+        ("torch", "Size"), ("torch", "device"), ("torch", "Tensor"), ("torch.nn.parameter", "Parameter"),
+        ("torch.storage", "UntypedStorage"), ("torch.storage", "TypedStorage"), ("torch.storage", "_load_from_bytes"),
+        ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+        ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+        ("numpy", "dtype"), ("numpy", "ndarray"), ("_codecs", "encode"),
+    }
+    _EXACT.discard(("torch.storage", "_load_from_bytes"))   # (it is torch.load again: never)
+    _BUILTINS = {"set", "frozenset", "dict", "list", "tuple", "int", "float", "bool", "str", "bytes", "slice", "complex",
+                 "object"}
 
     def find_class(self, module: str, name: str):
         root = module.split(".")[0]
         if root in ("models", "utils"):   # the yolov7 repository's own namespaces
             return type(name, (_Shell,), {"__module__": module})
         if module in ("builtins", "__builtin__"):   # (protocol-2 pickles, which torch.save writes, spell it the old way)
-            if name not in self._ALLOWED_BUILTINS or name == "getattr":
-                raise pickle.UnpicklingError(f"refusing builtins.{name} in a checkpoint")
+            if name in self._BUILTINS:
+                return super().find_class(module, name)
+        elif (module, name) in self._EXACT:
             return super().find_class(module, name)
-        if module == "torch" or module.startswith(self._ALLOWED_PREFIXES) or root in ("torch", "numpy", "collections"):
-            return super().find_class(module, name)
+        elif module == "torch" and "." not in name:
+            obj = getattr(torch, name, None)
+            if isinstance(obj, torch.dtype) or (isinstance(obj, type) and name.endswith("Storage")):
+                return obj
+        elif module.startswith("torch.nn.modules.") and "." not in name:
+            obj = super().find_class(module, name)
+            if isinstance(obj, type) and issubclass(obj, nn.Module):
+                return obj
         raise pickle.UnpicklingError(f"refusing {module}.{name} in a checkpoint")
 
 
