@@ -319,6 +319,21 @@ int vlfm_vit_attention_f16(const void* d_qkv, void* d_out, int batch, int tokens
 int vlfm_gemm_f16_nt(const void* d_x, const void* d_w, const void* d_bias, void* d_c, int m, int n, int k, int epilogue,
                      void* stream);
 
+/* C[M][N] = act(X[M][K] . W[N][K]^T + bias[N]) + residual[M][N]: f32 operands, f32 accumulation, f32 result on the matrix cores
+ * (csrc/gemm_f32.hip) -- the Linear layers of GroundingDINO, which the reference runs in fp32 (vlfm/vlm/grounding_dino.py:38-74,
+ * groundingdino's build_model [ext]), and of MobileSAM's TinyViT (vlfm/vlm/sam.py:40-57).
+ *   activation  0 none, 1 ReLU, 2 exact (erf) GELU; d_bias / d_residual may be NULL (d_residual may alias d_c)
+ *   precision   0 = v_mfma_f32_32x32x2_f32: bit for bit a k-ordered f32 fma chain (157 TFLOP/s peak)
+ *               1 = every operand as hi + 2^-11 lo' in two f16 (representation error <= 2^-24 |a|, f32's own unit roundoff), three
+ *                   f16 MFMAs per product block, f32 accumulation: f32-grade results at 5.3x the matrix rate.  Needs d_w_hi / d_w_lo
+ *                   = vlfm_split_f32_to_f16_pair(d_w) (once per layer) and d_overflow, a device int that the kernel ORs with 1 when
+ *                   an |operand| >= 65504 (f16's range) was met: the result of that call is then invalid and the caller must
+ *                   repeat it with precision 0 (vlfm_amd/vlm/ops.py:LinearF32 does, at its next host synchronisation point)
+ *   K % 32 == 0; X, W, C, residual and the split planes 16-byte aligned; M and N tails are handled. */
+int vlfm_split_f32_to_f16_pair(const float* d_src, void* d_hi, void* d_lo, long long count, int* d_overflow, void* stream);
+int vlfm_gemm_f32_nt(const float* d_x, const float* d_w, const float* d_bias, const float* d_residual, float* d_c, int m, int n,
+                     int k, int activation, int precision, const void* d_w_hi, const void* d_w_lo, int* d_overflow, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Detector-side kernels (vlfm/vlm/yolov7.py:50-110, vlfm/vlm/grounding_dino.py:38-74)
  * ------------------------------------------------------------------------------------------- */

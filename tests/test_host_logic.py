@@ -78,48 +78,82 @@ def test_tan_table_and_disc_rows():
             assert xs[0] == r - hw[i] and xs[-1] == r + hw[i] and len(xs) == 2 * hw[i] + 1
 
 
-def test_harness_frontier_selection_and_goal_geometry_are_the_scalar_rules_vectorised():
-    """BatchedEpisodes._select / _navigate (host side of the full step) against the scalar rules of policy_step.py."""
+def test_harness_decide_and_navigate_are_the_scalar_rules_vectorised():
+    """BatchedEpisodes._decide / _navigate (host side of the full step) against the scalar rules of policy_step.py: the three
+    modes of base_objectnav_policy.py:126-135, frontier stickiness (itm_policy.py:76-152), goal hand-over and stop rule
+    (:243-283), and the controller state of environments that do not consult the controller."""
     import numpy as np
     import torch
 
     from vlfm_amd.harness import BatchedEpisodes
-    from vlfm_amd.policy_step import FrontierSelector, rho_theta
+    from vlfm_amd.policy_step import ACTION_STOP, ACTION_TURN_LEFT, FrontierSelector, rho_theta
 
     class H:  # just the attributes the two methods touch
         pass
 
+    class FakeObjectMap:
+        def __init__(self, goal):
+            self.goal, self.asked = goal, 0
+
+        def has_object(self, name):
+            return self.goal is not None
+
+        def get_best_object(self, name, xy):
+            self.asked += 1
+            return np.asarray(self.goal)
+
     h = H()
-    h.E = 3
-    h.selectors = [FrontierSelector() for _ in range(3)]
+    h.E, h.targets, h.device, h.stop_radius = 4, ["chair", "bed", "tv", "couch"], torch.device("cpu"), 0.9
+    h.selectors = [FrontierSelector() for _ in range(4)]
+    h.object_maps = [FakeObjectMap(None), FakeObjectMap(None), FakeObjectMap(None), FakeObjectMap([4.5, 4.0, 0.3])]
     wps = np.array([[1.0, 0.0], [2.0, 0.0], [5.0, 5.0], [6.0, 6.0], [7.0, 7.0]])
     env_of = np.array([0, 0, 2, 2, 2])
-    poses = np.array([[0.0, 0.0, 0.3], [1.0, 1.0, -1.0], [4.0, 4.0, 2.0]])
-    goals = BatchedEpisodes._select(h, wps, env_of, np.array([0.2, 0.3, 0.1, 0.5, 0.4]), poses)
+    poses = np.array([[0.0, 0.0, 0.3], [1.0, 1.0, -1.0], [4.0, 4.0, 2.0], [4.0, 4.0, 0.1]])
+    vals = np.array([0.2, 0.3, 0.1, 0.5, 0.4])
+    # during the 12 initialisation steps nobody gets a goal, but the object map is consulted like in the reference (:123)
+    modes, goals, halt = BatchedEpisodes._decide(h, wps, env_of, vals, poses, 5)
+    assert modes == ["initialize"] * 4 and np.isnan(goals).all() and not halt.any() and h.object_maps[3].asked == 1
+    assert np.array_equal(h.selectors[0].last_frontier, np.zeros(2))            # selectors untouched while initialising
+    modes, goals, halt = BatchedEpisodes._decide(h, wps, env_of, vals, poses, 12)
+    assert modes == ["explore", "explore", "explore", "navigate"]
     assert np.array_equal(goals[0], [2.0, 0.0]) and np.isnan(goals[1]).all() and np.array_equal(goals[2], [6.0, 6.0])
-    # second step: env 0's pursued frontier dropped by less than 0.01 below ... stays; env 2's is gone -> nearest within 0.5 m
-    goals2 = BatchedEpisodes._select(h, np.array([[1.0, 0.0], [2.0, 0.0], [6.2, 6.0], [9.0, 9.0]]),
-                                     np.array([0, 0, 2, 2]), np.array([0.9, 0.295, 0.495, 0.8]), poses)
+    assert np.array_equal(goals[3], [4.5, 4.0]) and halt.tolist() == [False, True, False, False]   # env 1: no frontier -> stop
+    # next step: env 0's pursued frontier dropped by less than 0.01 -> stays; env 2's is gone -> nearest within 0.5 m
+    modes2, goals2, halt2 = BatchedEpisodes._decide(h, np.array([[1.0, 0.0], [2.0, 0.0], [6.2, 6.0], [9.0, 9.0]]),
+                                                    np.array([0, 0, 2, 2]), np.array([0.9, 0.295, 0.495, 0.8]), poses, 13)
     assert np.array_equal(goals2[0], [2.0, 0.0]) and np.array_equal(goals2[2], [6.2, 6.0])
 
     captured = {}
 
     class Ctrl:
+        discrete = True
+        pointnav_test_recurrent_hidden_states = torch.arange(4.0).reshape(4, 1, 1).repeat(1, 2, 3)
+        pointnav_prev_actions = torch.arange(4).reshape(4, 1)
+
         def reset(self, ids):
             captured["reset"] = list(np.asarray(ids))
 
         def act_on_depth(self, depth, rt, masks):
             captured["rt"], captured["masks"] = rt.numpy(), masks.numpy()
-            return torch.zeros(3, 1, dtype=torch.long)
+            self.pointnav_test_recurrent_hidden_states = self.pointnav_test_recurrent_hidden_states + 100.0
+            self.pointnav_prev_actions = torch.full((4, 1), 1)
+            return torch.ones(4, 1, dtype=torch.long)
 
-    h.pointnav, h.prev_goals, h.t, h.episode_len = Ctrl(), np.zeros((3, 2)), 5, 500
-    h.prev_goals[0] = goals2[0]  # env 0 keeps its goal -> no reset; env 1 has no goal (stays in place); env 2 moved
-    BatchedEpisodes._navigate(h, torch.zeros(3, 4, 4), goals2, poses)
+    h.pointnav, h.prev_goals = Ctrl(), np.zeros((4, 2))
+    h.prev_goals[0] = goals2[0]  # env 0 keeps its goal -> no reset; env 1 has no goal; env 2 moved; env 3 navigates, within 0.9 m
+    acts = BatchedEpisodes._navigate(h, torch.zeros(4, 4, 4), modes2, goals2, halt2, poses)
     for e in (0, 2):
         rho, theta = rho_theta(poses[e, :2], poses[e, 2], goals2[e])
         assert abs(captured["rt"][e, 0] - rho) < 1e-6 and abs(captured["rt"][e, 1] - theta) < 1e-6
-    assert captured["rt"][1, 0] == 0.0                       # no frontier: the goal is the robot's own position
-    assert captured["reset"] == [1, 2] and captured["masks"].tolist() == [True, False, False]
+    assert captured["reset"] == [2, 3] and captured["masks"].tolist() == [True, True, False, False]
+    assert acts.tolist() == [1, ACTION_STOP, 1, ACTION_STOP]     # no frontier -> STOP; object goal 0.5 m away -> STOP
+    assert h.last_stops.tolist() == [False, True, False, True] and np.isnan(h.last_rho_theta[1]).all()
+    st = h.pointnav.pointnav_test_recurrent_hidden_states[:, 0, 0].tolist()
+    assert st == [100.0, 1.0, 102.0, 3.0]                        # stopped environments keep their controller state
+    assert h.pointnav.pointnav_prev_actions.reshape(-1).tolist() == [1, 1, 1, 3]
+    modes0 = ["initialize"] * 4
+    acts0 = BatchedEpisodes._navigate(h, torch.zeros(4, 4, 4), modes0, np.full((4, 2), np.nan), np.zeros(4, bool), poses)
+    assert acts0.tolist() == [ACTION_TURN_LEFT] * 4
 
 
 def test_episode_log_matches_the_reference_log_saver_fixture(tmp_path, monkeypatch, capsys):

@@ -13,7 +13,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VLFM_LIB_PATH") or os.path.join(_HERE, "libvlfm_amd.so")  # override: diagnostic builds
-SOURCES = ["value_map.hip", "depth_ingest.hip", "depth_holes.hip", "obstacle_map.hip", "vlm_ops.hip", "vit_attention.hip", "detect_ops.hip", "object_cloud.hip", "gemm_f16.hip", "conv_nhwc.hip", "sam_ops.hip", "host.cpp"]
+SOURCES = ["value_map.hip", "depth_ingest.hip", "depth_holes.hip", "obstacle_map.hip", "vlm_ops.hip", "vit_attention.hip", "detect_ops.hip", "object_cloud.hip", "gemm_f16.hip", "gemm_f32.hip", "conv_nhwc.hip", "sam_ops.hip", "host.cpp"]
 
 VLFM_OK = 0
 VLFM_ERR_INVALID = -1
@@ -121,6 +121,8 @@ def lib() -> ctypes.CDLL:
         L.vlfm_layernorm_bias_f16.argtypes = [vp, vp, vp, vp, vp, ci, ci, ctypes.c_float, vp]
         L.vlfm_vit_attention_f16.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.c_float, vp]
         L.vlfm_gemm_f16_nt.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
+        L.vlfm_gemm_f32_nt.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp]
+        L.vlfm_split_f32_to_f16_pair.argtypes = [vp, vp, vp, ctypes.c_longlong, vp, vp]
         L.vlfm_layernorm_rows_f32.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ctypes.c_float, vp]
         L.vlfm_window_reverse_add_f32.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
         L.vlfm_dwconv3x3_nhwc_f32.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]

@@ -9,6 +9,14 @@ per-step hot path of ITMPolicyV2 (vlfm/policy/itm_policy.py:251-261):
                         -> ValueMap.update_map          (itm_policy.py:204-206)            [one launch for all envs]
     _explore            -> ValueMap.sort_waypoints      (itm_policy.py:263-267)            [disc medians per frontier]
 
+and, with a detector / segmenter / ``object_maps=True`` (the configs[2] "full" step, base_objectnav_policy.py:106-150,285-356):
+
+    _update_object_map  -> detector.predict (YOLOv7 | GroundingDINO), class + confidence filters   (:221-241)
+                        -> MobileSAM.segment_bbox per surviving box                               (:311-321)
+                        -> ObjectPointCloudMap.update_map per mask, update_explored per step      (:337-350)
+    act                 -> initialise (12 x TURN_LEFT) | explore (best frontier) | navigate (object goal, stop rule)
+                        -> PointNav controller on the chosen goal                                  (:126-135,243-283)
+
 Episodes are independent, so multi-GPU scaling is pure sharding (contiguous blocks: env e -> rank e // envs_per_rank,
 vlfm_amd/distributed.py); the only collective is the metric all-reduce in bench.py.
 """
@@ -27,6 +35,83 @@ from .synthetic import BOXES, CAMERA_HEIGHT, HEADINGS, MAX_DEPTH, MIN_DEPTH, YAW
 
 PROMPT = "Seems like there is a target_object ahead."  # vlfm/policy/base_objectnav_policy.py:377
 TARGETS = ["chair", "bed", "potted plant", "toilet", "tv", "couch"]  # HM3D ObjectNav categories
+
+
+class ScriptedSightings:
+    """A deterministic detector HEAD and episode script for networks without pretrained weights: which (environment, step) pairs
+    carry a detection, of what, how confident, where in the image and how far away -- a pure function of (env_id, step), so that
+    the workload of the stages behind the detector (MobileSAM, ObjectPointCloudMap) is STATED instead of being decided by random
+    logits.  An environment lives through ObjectNav episodes shaped like the reference's: 12 initialisation turns, a SEARCH phase of
+    ``search_min + (hash mod search_span)`` steps in which only distractors show up (``distractor_rate`` of the steps: a wrong class
+    or a low-confidence target, which the filters of base_objectnav_policy.py:231-233 must drop before SAM), then the target IN VIEW
+    for ``nav_steps`` steps (``in_view_rate`` of them carry a confidence-0.9 detection: survives both the 0.8 YOLOv7 and the 0.4
+    GroundingDINO threshold) while the policy navigates to it; after the last of these the robot "arrives": the episode ends like
+    the reference's does on STOP, and the environment starts the next one in place (maps, object map, selector and controller
+    reset).  ``desync``: environment e starts ``hash(e)`` steps into its first episode, so a batch is spread over all phases.
+    The object is an ellipse painted into the depth frame (nearer surfaces win), so the object cloud is an object, not a wall."""
+
+    def __init__(self, in_view_rate: float = 0.8, distractor_rate: float = 0.0625, search_min: int = 60, search_span: int = 120,
+                 nav_steps: int = 30, height: int = 480, width: int = 640, desync: bool = True) -> None:
+        self.in_view_rate, self.distractor_rate = in_view_rate, distractor_rate
+        self.search_min, self.search_span, self.nav_steps = search_min, search_span, nav_steps
+        self.H, self.W, self.desync = height, width, desync
+
+    @staticmethod
+    def _mix(a: int, b: int, salt: int) -> int:
+        h = (a * 2654435761 + b * 40503 + salt * 97 + 0x9E3779B9) & 0xFFFFFFFF
+        h ^= h >> 16
+        h = (h * 0x85EBCA6B) & 0xFFFFFFFF
+        h ^= h >> 13
+        h = (h * 0xC2B2AE35) & 0xFFFFFFFF
+        return h ^ (h >> 16)
+
+    def episode_length(self, env_id: int, k: int) -> int:
+        return 12 + self.search_min + self._mix(env_id, k, 3) % max(self.search_span, 1) + self.nav_steps
+
+    def locate(self, env_id: int, step: int):
+        """(episode index, step inside the episode, episode length) of environment ``env_id`` at harness step ``step``."""
+        g = step + (self._mix(env_id, 0, 9) % self.episode_length(env_id, 0) if self.desync else 0)
+        k = 0
+        while g >= self.episode_length(env_id, k):
+            g -= self.episode_length(env_id, k)
+            k += 1
+        return k, g, self.episode_length(env_id, k)
+
+    def episode_ends(self, env_id: int, step: int) -> bool:
+        _, s_, n = self.locate(env_id, step)
+        return s_ == n - 1
+
+    def mean_detections_per_env_step(self) -> float:
+        return self.in_view_rate * self.nav_steps / (12 + self.search_min + (self.search_span - 1) / 2.0 + self.nav_steps)
+
+    def at(self, env_id: int, step: int, target: str):
+        """[(phrase, confidence, (cx, cy, ax, ay) pixels, normalised depth)] for one environment-step."""
+        _, s_, n = self.locate(env_id, step)
+        if s_ < 12:
+            return []
+        in_view = s_ >= n - self.nav_steps
+        u = self._mix(env_id, step, 1) / 2.0 ** 32
+        if u >= (self.in_view_rate if in_view else self.distractor_rate):
+            return []
+        g = self._mix(env_id, step, 2)
+        cx = int(self.W * (0.2 + 0.6 * ((g & 0xFF) / 255.0)))
+        cy = int(self.H * (0.45 + 0.15 * (((g >> 8) & 0xFF) / 255.0)))
+        ax, ay = 40 + ((g >> 16) & 0x1F), 50 + ((g >> 21) & 0x1F)
+        depth = 0.3 + 0.3 * (((g >> 26) & 0x3F) / 63.0)
+        if in_view:
+            return [(target, 0.9, (cx, cy, ax, ay), depth)]
+        wrong = "tv" if target != "tv" else "chair"
+        return [(wrong, 0.93, (cx, cy, ax, ay), depth)] if (g & 1) else [(target, 0.35, (cx, cy, ax, ay), depth)]
+
+
+def ellipse_masks(ellipses, height: int, width: int, device) -> torch.Tensor:
+    """[n,H,W] bool: (x - cx)^2 / max(ax, 1)^2 + (y - cy)^2 / max(ay, 1)^2 <= 1 in f64 for ``ellipses`` [n,4] = (cx, cy, ax, ay)."""
+    e = torch.as_tensor(np.asarray(ellipses, np.float64).reshape(-1, 4), device=device)
+    yy = torch.arange(height, device=device, dtype=torch.float64)[None, :, None]
+    xx = torch.arange(width, device=device, dtype=torch.float64)[None, None, :]
+    cx, cy = e[:, 0, None, None], e[:, 1, None, None]
+    ax, ay = e[:, 2, None, None].clamp(min=1.0), e[:, 3, None, None].clamp(min=1.0)
+    return (xx - cx) ** 2 / ax ** 2 + (yy - cy) ** 2 / ay ** 2 <= 1
 
 
 class RoomsRenderer:
@@ -54,10 +139,15 @@ class RoomsRenderer:
         self.boxes = torch.tensor(BOXES, **f64)                                                  # [B,4]
         self.window = None
         self.window_t0 = 0
+        self.painter = None      # optional (t, frames [E,H,W]) -> frames: scripted objects in front of the walls
 
     @torch.no_grad()
     def render(self, t: int) -> torch.Tensor:
         """[E,H,W] f32 normalised depth of episode step t."""
+        d = self._render_walls(t)
+        return self.painter(t, d) if self.painter is not None else d
+
+    def _render_walls(self, t: int) -> torch.Tensor:
         x, y = self.xy[t, :, 0][:, None, None], self.xy[t, :, 1][:, None, None]
         c, s = self.cs[t, :, 0][:, None, None], self.cs[t, :, 1][:, None, None]
         dx, dy = c - s * self.m, s + c * self.m                                                  # [E,W,1]
@@ -90,7 +180,10 @@ class BatchedEpisodes:
                  n_frontiers: int = 8, sync_explored: bool = False, obstacle: bool = True,
                  episode_len: int = 500, overlap: bool = True, detector=None, sam=None, sam_every: int = 4,
                  graph_blip2: Optional[bool] = None, host_inputs: bool = False, select_frontiers: bool = False,
-                 pointnav=None, world: str = "rooms") -> None:
+                 pointnav=None, world: str = "rooms", object_maps: bool = False,
+                 sightings: Optional["ScriptedSightings"] = None, scripted_masks: bool = False,
+                 coco_threshold: float = 0.8, non_coco_threshold: float = 0.4, pointnav_stop_radius: float = 0.9,
+                 object_map_erosion_size: float = 5) -> None:
         self.device = require_gpu(device)
         # a rank waiting for its GPU must not hold a host core (bench.py `host`).  Effective only before the device's first
         # stream exists (bench.py sets it first thing); here it is best effort: a warning on failure, VLFM_HOST_WAIT=spin opts out
@@ -159,6 +252,28 @@ class BatchedEpisodes:
         self.gdino_caption = " . ".join(TARGETS) + " ."
         self.last_detections = None
         self.last_masks = None
+        # the stage BEHIND the detector (base_objectnav_policy.py:311-350): one ObjectPointCloudMap per environment, each with
+        # its own NumPy stream (the reference draws from the global generator; E interleaved episodes need E streams)
+        self.object_maps = None
+        if object_maps:
+            from .mapping.object_point_cloud_map import ObjectPointCloudMap
+
+            self.object_maps = [ObjectPointCloudMap(object_map_erosion_size, device=self.device,
+                                                    rng=np.random.RandomState(1000 + i)) for i in self.env_ids]
+        self.sightings, self.scripted_masks = sightings, scripted_masks
+        self._sight_cache: Dict[int, List] = {}
+        self._sched_cache: Dict[int, tuple] = {}
+        if sightings is not None and self.rooms is not None:
+            self.rooms.painter = self._paint_sightings
+        self.det_threshold = non_coco_threshold if self.detector_is_prompted else coco_threshold   # :231-233
+        self.stop_radius = pointnav_stop_radius
+        self.last_modes: List[str] = []
+        self.last_episode_end = np.zeros(n_envs, bool)
+        self.last_stops = np.zeros(n_envs, bool)
+        self.last_resets = np.zeros(n_envs, bool)
+        self.last_rho_theta = np.full((n_envs, 2), np.nan)
+        self.object_stats = {"detections": 0, "masks": 0, "cloud_updates": 0, "env_steps": 0,
+                             "modes": {"initialize": 0, "explore": 0, "navigate": 0}}
         self.map_stream = torch.cuda.Stream(self.device) if overlap else None
         self.last_cosines: Optional[torch.Tensor] = None
         self.last_frontier_values: Optional[np.ndarray] = None
@@ -185,35 +300,203 @@ class BatchedEpisodes:
             from .policy_step import FrontierSelector
 
             self.selectors = [FrontierSelector() for _ in range(self.E)]
+        if self.object_maps is not None:
+            for om in self.object_maps:
+                om.reset()
+        self.prev_goals = np.zeros((self.E, 2))
+        if self.pointnav is not None:
+            self.pointnav.reset()
 
-    def _select(self, wps: np.ndarray, env_of: np.ndarray, vals: np.ndarray, poses: np.ndarray) -> np.ndarray:
-        """Per environment: sort_waypoints' descending order (value_map.py:183-186), then the selection rule."""
+    # ------------------------------------------------------------------------------------------ scripted detector head
+    def _sightings_at(self, t_ep: int) -> List:
+        """[(env slot, phrase, confidence, (cx, cy, ax, ay), depth)] of episode step ``t_ep`` (memoised: the painter asks when
+        the frame is rendered, the step asks again when it runs)."""
+        if t_ep not in self._sight_cache:
+            if len(self._sight_cache) > 4096:
+                self._sight_cache.clear()
+            self._sight_cache[t_ep] = [(e, *sg) for e, i in enumerate(self.env_ids)
+                                       for sg in self.sightings.at(i, t_ep, self.targets[e])]
+        return self._sight_cache[t_ep]
+
+    def _paint_sightings(self, t_ep: int, frames: torch.Tensor) -> torch.Tensor:
+        """The scripted objects of step ``t_ep`` into the rendered depth frames: an ellipse at the object's depth wherever it is
+        nearer than the wall / floor behind it (so both maps and the object cloud see one consistent scene)."""
+        sg = self._sightings_at(t_ep)
+        self._schedule(t_ep)
+        if not sg:
+            return frames
+        idx = torch.tensor([s_[0] for s_ in sg], device=frames.device)
+        m = ellipse_masks([s_[3] for s_ in sg], self.H, self.W, frames.device)
+        d = torch.tensor([s_[4] for s_ in sg], dtype=frames.dtype, device=frames.device)[:, None, None]
+        cur = frames[idx]
+        frames[idx] = torch.where(m, torch.minimum(cur, d), cur)   # (an environment has at most one sighting per step)
+        return frames
+
+    def _scripted_detections(self, t_ep: int):
+        """What the scripted head reports for every environment at this step, as the detector clients' ``ObjectDetections``
+        (normalised xyxy boxes, f32, like yolov7.py:99-110 / grounding_dino.py:60-66)."""
+        from .vlm.detections import ObjectDetections
+
+        per = [[] for _ in range(self.E)]
+        for (e, phrase, conf, (cx, cy, ax, ay), _) in self._sightings_at(t_ep):
+            per[e].append(([(cx - ax) / self.W, (cy - ay) / self.H, (cx + ax) / self.W, (cy + ay) / self.H], conf, phrase))
+        return [ObjectDetections(torch.tensor([r[0] for r in rows], dtype=torch.float32).reshape(-1, 4),
+                                 torch.tensor([r[1] for r in rows], dtype=torch.float32), [r[2] for r in rows],
+                                 image_source=None, fmt="xyxy") for rows in per]
+
+    # ------------------------------------------------------------------------------------------ object maps
+    def _update_object_maps(self, dets, rgb: torch.Tensor, depth: torch.Tensor, tf: np.ndarray) -> None:
+        """BaseObjectNavPolicy._update_object_map for every environment (base_objectnav_policy.py:285-352): class + confidence
+        filters, ONE MobileSAM call for all surviving boxes of the batch (the reference re-encodes the frame per box too),
+        ObjectPointCloudMap.update_map per mask (csrc/object_cloud.hip: erosion, back-projection, DBSCAN), update_explored
+        per environment and step."""
+        jobs = []
+        for e, det in enumerate(dets):
+            det.filter_by_class(self.targets[e].split("|"))
+            det.filter_by_conf(self.det_threshold)
+            # the reference multiplies the f32 row by an int64 ndarray: NumPy promotes to f64 first (:312)
+            jobs += [(e, det.boxes[i].detach().cpu().numpy().astype(np.float64) * np.array([self.W, self.H, self.W, self.H]))
+                     for i in range(len(det.logits))]
+        self.object_stats["detections"] += len(jobs)
+        self.last_masks = None
+        if jobs:
+            envs = [j[0] for j in jobs]
+            boxes = np.stack([j[1] for j in jobs])
+            masks = None
+            if self.sam is not None:
+                masks = self.sam.segment_bboxes(rgb[envs], torch.from_numpy(boxes).to(torch.float32)[:, None, :])[:, 0]
+            if masks is None or self.scripted_masks:
+                # without pretrained weights the segmenter's logits mean nothing: the mask handed on is the box's inscribed ellipse
+                # (the MobileSAM forward above still ran and is timed); also the stand-in when no segmenter is attached
+                masks = ellipse_masks(np.stack([(boxes[:, 0] + boxes[:, 2]) / 2, (boxes[:, 1] + boxes[:, 3]) / 2,
+                                                (boxes[:, 2] - boxes[:, 0]) / 2, (boxes[:, 3] - boxes[:, 1]) / 2], axis=1),
+                                      self.H, self.W, self.device)
+            self.last_masks = (envs, masks)
+            self.object_stats["masks"] += len(jobs)
+            for j, e in enumerate(envs):
+                om = self.object_maps[e]
+                before = len(om.clouds.get(self.targets[e], ()))
+                om.update_map(self.targets[e], depth[e], masks[j], tf[e], MIN_DEPTH, MAX_DEPTH, self.fx, self.fy)
+                self.object_stats["cloud_updates"] += int(len(om.clouds.get(self.targets[e], ())) != before)
+        for e, om in enumerate(self.object_maps):
+            if om.clouds:
+                om.update_explored(tf[e], MAX_DEPTH, self.fov)     # cone_fov = get_fov(fx, width) (:349)
+
+    # ------------------------------------------------------------------------------------------ act
+    def _episode_steps(self, t_ep: int) -> np.ndarray:
+        """Steps since each environment's last episode start (the policy's ``_num_steps``): the harness step for everybody
+        without a script, the script's per-environment episode clock with one."""
+        if self.sightings is None:
+            return np.full(self.E, t_ep, np.int64)
+        return self._schedule(t_ep)[0]
+
+    def _schedule(self, t_ep: int):
+        """(steps into the episode [E], episode ends with this step [E]) of the script at harness step ``t_ep``, memoised (the
+        painter computes it when a frame is pre-rendered, outside a timed region)."""
+        hit = self._sched_cache.get(t_ep)
+        if hit is None:
+            if len(self._sched_cache) > 4096:
+                self._sched_cache.clear()
+            loc = [self.sightings.locate(i, t_ep) for i in self.env_ids]
+            hit = self._sched_cache[t_ep] = (np.array([l[1] for l in loc], np.int64),
+                                            np.array([l[1] == l[2] - 1 for l in loc], bool))
+        return hit
+
+    def _end_episodes(self, t_ep: int) -> None:
+        """Environments whose scripted episode ends with this step (the robot "arrived": the reference's episode ends on STOP):
+        their maps, object map, selector and controller state are reset for the next episode, which starts in place."""
+        self.last_episode_end = np.zeros(self.E, bool)
+        if self.sightings is None:
+            return
+        done = np.flatnonzero(self._schedule(t_ep)[1]).tolist()
+        if not done:
+            return
+        from .policy_step import FrontierSelector
+
+        self.last_episode_end[done] = True
+        self.values.reset(done)
+        if self.obstacles is not None:
+            self.obstacles.reset(done)
+        for e in done:
+            if self.object_maps is not None:
+                self.object_maps[e].reset()
+            if self.selectors is not None:
+                self.selectors[e] = FrontierSelector()
+        self.prev_goals[done] = 0.0
+        if self.pointnav is not None:
+            self.pointnav.reset(done)
+        self.object_stats["episodes_ended"] = self.object_stats.get("episodes_ended", 0) + len(done)
+
+    def _decide(self, wps: np.ndarray, env_of: np.ndarray, vals, poses: np.ndarray, t_ep: int):
+        """BaseObjectNavPolicy.act's three modes for every environment (base_objectnav_policy.py:126-135): 12 initialisation
+        turns, then the object goal if the object map has the target, else the best frontier (itm_policy.py:64-152).  Returns
+        (modes, goals [E,2] (nan = none), stop_no_frontier [E])."""
         goals = np.full((self.E, 2), np.nan)
-        vals = np.asarray(vals, np.float64).reshape(-1)
+        modes, halt = [], np.zeros(self.E, bool)
+        vals = np.asarray(vals, np.float64).reshape(-1) if vals is not None else np.zeros(0)
         bounds = np.searchsorted(env_of, np.arange(self.E + 1))
+        ep_steps = self._episode_steps(t_ep)
         for e in range(self.E):
-            lo, hi = bounds[e], bounds[e + 1]
-            if hi > lo:
-                order = np.argsort(-vals[lo:hi])
+            target, robot_xy = self.targets[e], poses[e, :2]
+            obj = None
+            if self.object_maps is not None and self.object_maps[e].has_object(target):
+                obj = self.object_maps[e].get_best_object(target, robot_xy)        # every step, like the reference (:123)
+            if ep_steps[e] < 12:     # _done_initializing flips after the 12th call (habitat_policies.py:150-153)
+                modes.append("initialize")
+            elif obj is None:
+                modes.append("explore")
+                lo, hi = bounds[e], bounds[e + 1]
+                if hi <= lo:
+                    halt[e] = True          # "No frontiers found during exploration, stopping." itm_policy.py:64-67
+                    continue
+                order = np.argsort(-vals[lo:hi])       # sort_waypoints' descending order (value_map.py:183-186)
                 pts = wps[lo:hi]
-                goals[e], _ = self.selectors[e].choose(pts[order], [float(v) for v in vals[lo:hi][order]], pts,
-                                                       poses[e, :2])
-        return goals
+                goals[e], _ = self.selectors[e].choose(pts[order], [float(v) for v in vals[lo:hi][order]], pts, robot_xy)
+            else:
+                modes.append("navigate")
+                goals[e] = obj[:2]
+        return modes, goals, halt
 
-    def _navigate(self, depth: torch.Tensor, goals: np.ndarray, poses: np.ndarray) -> torch.Tensor:
-        """(rho, theta) of every environment's goal in its robot frame (geometry_utils.py:9-34), controller state reset
-        where the goal moved by more than 0.1 m (base_objectnav_policy.py:255-259), one batched forward."""
-        goals = np.where(np.isnan(goals), poses[:, :2], goals)
-        moved = np.linalg.norm(goals - self.prev_goals, axis=1) > 0.1
-        self.prev_goals = goals
-        d = goals - poses[:, :2]
+    def _navigate(self, depth: torch.Tensor, modes: List[str], goals: np.ndarray, halt: np.ndarray, poses: np.ndarray):
+        """BaseObjectNavPolicy._pointnav for every environment with a goal (base_objectnav_policy.py:243-283): a goal that moved
+        by more than 0.1 m resets the controller, (rho, theta) in the robot frame (geometry_utils.py:9-34), STOP within
+        ``pointnav_stop_radius`` of an OBJECT goal; ONE batched controller forward.  Environments that do not consult the
+        controller this step (initialising, stopping, no frontier) keep its recurrent state and previous action untouched, as in
+        the single-environment policy.  Returns the [E] action ids (TURN_LEFT while initialising, STOP where issued)."""
+        from .policy_step import ACTION_STOP, ACTION_TURN_LEFT
+
+        E = self.E
+        have = ~np.isnan(goals[:, 0])
+        moved = np.zeros(E, bool)
+        moved[have] = np.linalg.norm(goals[have] - self.prev_goals[have], axis=1) > 0.1
+        self.prev_goals[have] = goals[have]
+        d = np.where(have[:, None], goals - poses[:, :2], 0.0)
         c, s = np.cos(-poses[:, 2]), np.sin(-poses[:, 2])
         lx, ly = c * d[:, 0] - s * d[:, 1], s * d[:, 0] + c * d[:, 1]
-        rt = torch.from_numpy(np.stack([np.hypot(lx, ly), np.arctan2(ly, lx)], axis=1).astype(np.float32))
-        fresh = moved | (self.t % self.episode_len == 0)
-        if fresh.any():
-            self.pointnav.reset(np.flatnonzero(fresh))
-        return self.pointnav.act_on_depth(depth, rt, torch.from_numpy(~fresh))
+        rho, theta = np.hypot(lx, ly), np.arctan2(ly, lx)
+        navigate = np.array([m == "navigate" for m in modes], bool)
+        stop = halt | (have & navigate & (rho < self.stop_radius))
+        run = have & ~stop
+        self.last_stops, self.last_resets = stop, moved & have
+        self.last_rho_theta = np.where(have[:, None], np.stack([rho, theta], axis=1), np.nan)
+        if self.pointnav is None:
+            return None
+        pn = self.pointnav
+        if moved.any():
+            pn.reset(np.flatnonzero(moved))                     # (before the stop check, like the reference)
+        keep = torch.from_numpy(~run).to(self.device)
+        h0, a0 = pn.pointnav_test_recurrent_hidden_states.clone(), pn.pointnav_prev_actions.clone()
+        rt = torch.from_numpy(np.stack([rho, theta], axis=1).astype(np.float32))
+        acts = pn.act_on_depth(depth, rt, torch.from_numpy(~moved))
+        pn.pointnav_test_recurrent_hidden_states[keep] = h0[keep]
+        pn.pointnav_prev_actions[keep] = a0[keep]
+        if not pn.discrete:
+            return acts
+        override = np.full(E, -1, np.int64)
+        override[[m == "initialize" for m in modes]] = ACTION_TURN_LEFT
+        override[stop] = ACTION_STOP
+        ov = torch.from_numpy(override).to(self.device)
+        return torch.where(ov >= 0, ov, acts.reshape(E).to(torch.int64))
 
     def prepare(self, n_steps: int) -> None:
         """Render the depth frames of the next ``n_steps`` steps now (rooms world), so that a timed region that follows
@@ -231,13 +514,13 @@ class BatchedEpisodes:
         """Advance every episode by ``n_steps`` MAP-ONLY steps (stub cosines instead of the BLIP-2 forward, no detector /
         segmenter / controller): brings explored area, obstacle planes and contour lengths to a mid-episode state cheaply
         before a measurement, instead of timing the empty world of an episode's first steps."""
-        saved = (self.blip2, self.detector, self.sam, self.selectors, self.pointnav)
-        self.blip2 = self.detector = self.sam = self.selectors = self.pointnav = None
+        saved = (self.blip2, self.detector, self.sam, self.selectors, self.pointnav, self.object_maps)
+        self.blip2 = self.detector = self.sam = self.selectors = self.pointnav = self.object_maps = None
         try:
             for _ in range(n_steps):
                 self.step()
         finally:
-            self.blip2, self.detector, self.sam, self.selectors, self.pointnav = saved
+            self.blip2, self.detector, self.sam, self.selectors, self.pointnav, self.object_maps = saved
 
     def frontier_stats(self):
         """(mean, max) number of frontiers per environment at the last step (what the obstacle pipeline is working on)."""
@@ -312,11 +595,19 @@ class BatchedEpisodes:
         else:
             cos = torch.from_numpy(self.stub_rng.uniform(0.15, 0.45, size=self.E)).to(self.device)
         self.last_cosines = cos
+        t_ep = self.t % self.episode_len
+        dets = None
         if self.detector is not None:
             # YOLOv7 takes the frames alone; GroundingDINO is prompted (MP3D-style caption, habitat_policies.py:139-141)
-            self.last_detections = (self.detector.predict_batch(rgb, [self.gdino_caption]) if self.detector_is_prompted
-                                    else self.detector.predict_batch(rgb))
-        if self.sam is not None:
+            dets = (self.detector.predict_batch(rgb, [self.gdino_caption]) if self.detector_is_prompted
+                    else self.detector.predict_batch(rgb))
+        if self.sightings is not None and (self.detector is not None or self.object_maps is not None):
+            dets = self._scripted_detections(t_ep)     # the scripted HEAD: the network above ran (and is timed), its random logits are not used
+        self.last_detections = dets
+        if self.object_maps is not None and dets is not None:
+            self._update_object_maps(dets, rgb, depth, tf)
+        elif self.sam is not None:
+            # (legacy leg without object maps: MobileSAM on one fixed box for every ``sam_every``-th environment-step)
             sel = [e for e in range(self.E) if (self.t + e) % self.sam_every == 0]
             if sel:
                 box = torch.tensor([[[0.3 * self.W, 0.3 * self.H, 0.7 * self.W, 0.8 * self.H]]] * len(sel))
@@ -335,10 +626,15 @@ class BatchedEpisodes:
         main.wait_stream(side)
         self.values.update(cos.reshape(self.E, 1), None, tf, MIN_DEPTH, MAX_DEPTH, self.fov, colmax=colmax)
         # ---- frontier scoring (ITMPolicyV2._sort_frontiers_by_value, radius 0.5 m)
+        self.last_frontier_values = None
         if len(wps):
             self.last_frontier_values = self.values.waypoint_values(wps, env_of, 0.5)  # D2H sync: the policy needs it
-            if self.selectors is not None:
-                self.last_goals = self._select(wps, env_of, self.last_frontier_values, poses)
-                if self.pointnav is not None:
-                    self.last_actions = self._navigate(depth, self.last_goals, poses)
+        if self.selectors is not None:
+            modes, goals, halt = self._decide(wps, env_of, self.last_frontier_values, poses, t_ep)
+            self.last_modes, self.last_goals = modes, goals
+            self.last_actions = self._navigate(depth, modes, goals, halt, poses)
+            self.object_stats["env_steps"] += self.E
+            for m in modes:
+                self.object_stats["modes"][m] += 1
+        self._end_episodes(t_ep)
         self.t += 1

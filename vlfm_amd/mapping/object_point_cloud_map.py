@@ -38,12 +38,16 @@ def within_fov_cone(cone_origin, cone_angle, cone_fov, cone_range, points) -> np
     return points[mask]
 
 
-def too_offset(mask: np.ndarray) -> bool:
+def too_offset(mask) -> bool:
     """Does the detection hug the left or right image border (object_point_cloud_map.py:272-297)?  A mask whose column
     extent lies wholly in the outer third of the image AND reaches within 5 % of that border is "too offset": its
-    points get an out-of-range tag because the object is probably cut off by the image edge."""
+    points get an out-of-range tag because the object is probably cut off by the image edge.  ``mask``: (H,W) ndarray, or a
+    device tensor (the column occupancy is reduced on the device; W bytes cross to the host)."""
     width = mask.shape[1]
-    occupied = np.flatnonzero(np.asarray(mask).any(axis=0))       # cv2.boundingRect's x-extent
+    if hasattr(mask, "is_cuda"):
+        occupied = np.flatnonzero((mask != 0).any(dim=0).cpu().numpy())
+    else:
+        occupied = np.flatnonzero(np.asarray(mask).any(axis=0))       # cv2.boundingRect's x-extent
     left, right = (int(occupied[0]), int(occupied[-1]) + 1) if len(occupied) else (0, 0)
     band = width // 3
     if right <= band:
@@ -53,11 +57,11 @@ def too_offset(mask: np.ndarray) -> bool:
     return False
 
 
-def get_random_subarray(points, size: int):
+def get_random_subarray(points, size: int, rng=np.random):
     """At most ``size`` rows, chosen by NumPy's GLOBAL generator like the reference (:253-269), so a seeded session
     reproduces its clouds."""
     n = len(points)
-    return points if n <= size else points[np.random.choice(n, size, replace=False)]
+    return points if n <= size else points[rng.choice(n, size, replace=False)]
 
 
 class ObjectPointCloudMap:
@@ -68,16 +72,28 @@ class ObjectPointCloudMap:
     clouds: Dict[str, np.ndarray] = {}
     use_dbscan: bool = True
 
-    def __init__(self, erosion_size: float, device=None) -> None:
+    def __init__(self, erosion_size: float, device=None, rng=None) -> None:
+        """``rng``: where the two random draws come from.  Default = NumPy's GLOBAL generator, like the reference; the batched
+        harness gives every environment its own ``np.random.RandomState(seed)`` (same stream as ``np.random.seed(seed)``
+        followed by the global calls), so that E interleaved episodes each reproduce their single-environment run."""
         self._erosion_size = erosion_size
+        self._rng = rng if rng is not None else np.random
         self.last_target_coord: Union[np.ndarray, None] = None
         self.device = require_gpu(device)
         _lib.lib()
         self.clouds = {}
         self._bufs = None
+        self._near_only: Dict[str, tuple] = {}     # name -> (id(cloud array), rows): every tag of that array is 1.0
 
     def reset(self) -> None:
         self.clouds, self.last_target_coord = {}, None
+        self._near_only = {}
+
+    def _all_near(self, name: str) -> bool:
+        """True when the cloud stored under ``name`` is known to hold only trusted (tag 1.0) points -- bookkeeping of update_map /
+        update_explored, valid only for the very array it was recorded for (``clouds`` is a public dict)."""
+        cloud = self.clouds.get(name)
+        return cloud is not None and self._near_only.get(name) == (id(cloud), len(cloud))
 
     def has_object(self, target_class: str) -> bool:
         return len(self.clouds.get(target_class, ())) > 0
@@ -90,7 +106,7 @@ class ObjectPointCloudMap:
             return
         # exactly ONE draw from the global generator per non-empty observation, whichever branch is taken (the reference
         # evaluates np.random.rand() on both paths); the "near" path keeps its tags in f32 like the reference's astype
-        tag = np.random.rand()
+        tag = self._rng.rand()
         if too_offset(object_mask):
             tags = np.full(len(camera_frame), tag, dtype=camera_frame.dtype)
         else:
@@ -101,12 +117,20 @@ class ObjectPointCloudMap:
         if np.linalg.norm(self._get_closest_point(tagged, here)[:3] - here) < 1.0:
             return  # closer than 1 m: depth this near is not trusted (:63-67)
         known = self.clouds.get(object_name)
+        near_only = (known is None or self._all_near(object_name)) and bool(np.all(tags == 1))
         self.clouds[object_name] = tagged if known is None else np.concatenate((known, tagged), axis=0)
+        if near_only:
+            self._near_only[object_name] = (id(self.clouds[object_name]), len(self.clouds[object_name]))
+        else:
+            self._near_only.pop(object_name, None)
 
     def get_best_object(self, target_class: str, curr_position: np.ndarray) -> np.ndarray:
         """Goal point with hysteresis (:77-101): keep the previous goal when the new closest point moved < 0.1 m, or
         < 0.5 m while the robot is still more than 2 m away."""
-        candidate = self._get_closest_point(self.get_target_cloud(target_class), curr_position)[:2]
+        # (a cloud of trusted points only IS its target cloud: no copy, no mask -- the harness asks this for every environment
+        # and step, on clouds of 10^5 points)
+        cloud = self.clouds[target_class] if self._all_near(target_class) else self.get_target_cloud(target_class)
+        candidate = self._get_closest_point(cloud, curr_position)[:2]
         previous = self.last_target_coord
         if previous is not None:
             moved = np.linalg.norm(candidate - previous)
@@ -120,6 +144,8 @@ class ObjectPointCloudMap:
         tag other than 1 that shows up inside the view cone is removed from the cloud as a whole."""
         origin, heading = tf_camera_to_episodic[:3, 3], extract_yaw(tf_camera_to_episodic)
         for name, cloud in list(self.clouds.items()):
+            if self._all_near(name):
+                continue       # only tags other than 1 can be dropped (`- {1}` below): nothing to do, same result
             seen_tags = set(within_fov_cone(origin, heading, cone_fov, max_depth * 0.5, cloud)[..., -1].tolist()) - {1}
             for t in seen_tags:
                 cloud = cloud[cloud[..., -1] != t]
@@ -155,7 +181,7 @@ class ObjectPointCloudMap:
             n = int(count.item())
             cloud = cloud[:n]
             if n > 5000:  # get_random_subarray: NumPy's global RNG picks, the device gathers
-                idx = np.random.choice(n, 5000, replace=False)
+                idx = self._rng.choice(n, 5000, replace=False)
                 cloud = cloud[torch.from_numpy(idx).to(dev)].contiguous()
                 n = 5000
             if not self.use_dbscan or n == 0:

@@ -371,10 +371,10 @@ class ITMPolicyV2Step:
         discrete = self._pointnav.discrete
         if mode == "initialize":
             return ACTION_TURN_LEFT if discrete else np.zeros(2, np.float32)
+        if reset and np.isfinite(rho):
+            self._pointnav.reset()          # (inside the goal bookkeeping, i.e. BEFORE the stop check: :255-259 vs :277-279)
         if stop:
             return ACTION_STOP if discrete else np.zeros(2, np.float32)
-        if reset:
-            self._pointnav.reset()
         a = self._pointnav.act_on_depth(torch.from_numpy(np.ascontiguousarray(depth, np.float32))[None],
                                         torch.tensor([[rho, theta]], dtype=torch.float32),
                                         torch.tensor([not reset]))

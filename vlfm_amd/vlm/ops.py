@@ -268,3 +268,80 @@ def vit_attention(qkv: torch.Tensor, batch: int, tokens: int, heads: int, head_d
     _lib.check(_lib.lib().vlfm_vit_attention_f16(qkv.data_ptr(), out.data_ptr(), batch, tokens, heads, head_dim,
                                                  float(scale), _stream()), "vit_attention_f16")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ f32 Linear on the matrix cores
+_ACT32 = {None: 0, "none": 0, "relu": 1, "gelu": 2}
+GEMM_F32_PRECISION = {"exact": 0, "split": 1}
+_overflow_flags: Dict[str, torch.Tensor] = {}
+_split_cache: Dict[int, tuple] = {}
+
+
+def gemm_f32_overflow_flag(device) -> torch.Tensor:
+    """The sticky device int the split-precision GEMMs OR into when an operand leaves f16's range (one per device)."""
+    key = str(device)
+    if key not in _overflow_flags:
+        _overflow_flags[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _overflow_flags[key]
+
+
+def split_weight(weight: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(hi, lo') f16 planes of an f32 weight: hi = f16(w), lo' = f16((w - hi) 2^11).  Memoised per tensor OBJECT (a weak reference
+    proves it is still the same tensor: an address alone is reused by the allocator) and per ``_version`` (in-place updates)."""
+    import weakref
+
+    key = id(weight)
+    hit = _split_cache.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr():
+        return hit[3], hit[4]
+    if len(_split_cache) > 2048:
+        for k in [k for k, v in _split_cache.items() if v[0]() is None]:
+            del _split_cache[k]
+    w = weight.detach().contiguous()
+    hi = torch.empty(w.shape, dtype=torch.float16, device=w.device)
+    lo = torch.empty_like(hi)
+    _lib.check(_lib.lib().vlfm_split_f32_to_f16_pair(w.data_ptr(), hi.data_ptr(), lo.data_ptr(), w.numel(),
+                                                     gemm_f32_overflow_flag(w.device).data_ptr(), _stream()), "split_f32")
+    _split_cache[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), hi, lo)
+    return hi, lo
+
+
+def linear_f32_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """Shapes csrc/gemm_f32.hip takes: f32 on the GPU, K % 32 == 0, enough rows and columns to fill a 128 x 128 tile halfway."""
+    k = weight.shape[1]
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and k % 32 == 0 and x.shape[-1] == k
+            and weight.shape[0] >= 32 and x.numel() // k >= 64 and not torch.is_grad_enabled())
+
+
+def linear_f32(x: torch.Tensor, weight: torch.Tensor, bias=None, act=None, residual=None, precision: str = "exact",
+               out=None) -> torch.Tensor:
+    """act(x @ weight.T + bias) + residual for f32 tensors on the matrix cores (csrc/gemm_f32.hip); x [..., K], weight [N, K].
+    precision "exact": v_mfma_f32_32x32x2_f32 (a k-ordered f32 fma chain); "split": the f16 hi/lo form (f32-grade, 5.3x the rate;
+    check ``gemm_f32_overflow_flag`` at the next synchronisation point)."""
+    K = weight.shape[1]
+    N = weight.shape[0]
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, K)
+    if not x2.is_contiguous() or x2.data_ptr() % 16:
+        x2 = x2.contiguous()
+    w = weight if weight.is_contiguous() else weight.contiguous()
+    M = x2.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    res = None
+    if residual is not None:
+        res = residual.reshape(M, N)
+        if not res.is_contiguous() or res.data_ptr() % 16:
+            res = res.contiguous()
+    b = None
+    if bias is not None:
+        b = bias if bias.is_contiguous() else bias.contiguous()
+    prec = GEMM_F32_PRECISION[precision]
+    hi = lo = None
+    if prec == 1:
+        hi, lo = split_weight(w)
+    _lib.check(_lib.lib().vlfm_gemm_f32_nt(x2.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None,
+                                           res.data_ptr() if res is not None else None, out.data_ptr(), M, N, K, _ACT32[act], prec,
+                                           hi.data_ptr() if hi is not None else None, lo.data_ptr() if lo is not None else None,
+                                           gemm_f32_overflow_flag(x.device).data_ptr(), _stream()), "gemm_f32_nt")
+    return out.view(*lead, N)
