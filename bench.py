@@ -61,6 +61,7 @@ def parse_args(argv=None):
                     help="map-only steps every episode is advanced by before the warm-up (mid-episode map state)")
     ap.add_argument("--no-small", action="store_true", help="skip the side measurements (small batches, config 5, PCIe)")
     ap.add_argument("--no-full", action="store_true", help="skip the configs[2] full-step side runs")
+    ap.add_argument("--only-full", action="store_true", help="side runs: only the configs[2] full-step legs (tuning aid)")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--no-blip2", action="store_true", help="map kernels only (NOT the headline metric)")
@@ -828,10 +829,11 @@ def side_legs(args, sim, device, common):
         for n_envs in (8, 64):
             full_step(n_envs, det, " with GroundingDINO", 2, 30)
 
-    leg("small batches", leg_small)
-    leg("config 5", leg_cfg5)
-    leg("episode phases", leg_episode_phases)
-    leg("pcie_inclusive", leg_host)
+    if not args.only_full:
+        leg("small batches", leg_small)
+        leg("config 5", leg_cfg5)
+        leg("episode phases", leg_episode_phases)
+        leg("pcie_inclusive", leg_host)
     if not args.no_full:
         leg("configs[2] full step", leg_full)
         leg("configs[2] full step with GroundingDINO", leg_gdino)

@@ -357,6 +357,16 @@ int vlfm_dwconv3x3_nhwc_f32(const float* d_x, const float* d_w9c, const float* d
  * the additive bias TRANSPOSED (bias_t[h][j][i] = bias[h][i][j]), d_out [windows * tokens][heads * 32].  tokens <= 256. */
 int vlfm_window_attention_f32(const float* d_qkv, const float* d_bias_t, float* d_out, long long windows, int tokens, int heads,
                               float scale, void* stream);
+/* Swin variants (the GroundingDINO backbone, vlfm/vlm/grounding_dino.py:38-74; transformers' SwinLayer [ext]): windows of the zero-padded
+ * image ROLLED by -shift along both axes (0 <= shift < window); pad_zero: padded positions receive 0 (Swin pads AFTER the norm) instead of
+ * beta; d_mask_t [windows_per_image][tokens][tokens] = the shifted-window attention mask, added to window w's scores as
+ * d_mask_t[w % windows_per_image] (NULL = none). */
+int vlfm_layernorm_rows_shifted_f32(const float* d_x, const float* d_gamma, const float* d_beta, float* d_out, int batch, int height,
+                                    int width, int channels, int window, float eps, int shift, int pad_zero, void* stream);
+int vlfm_window_reverse_add_shifted_f32(float* d_x, const float* d_windows, int batch, int height, int width, int channels, int window,
+                                        int shift, void* stream);
+int vlfm_window_attention_masked_f32(const float* d_qkv, const float* d_bias_t, const float* d_mask_t, int windows_per_image, float* d_out,
+                                     long long windows, int tokens, int heads, float scale, void* stream);
 
 /* One convolution of the yolov7-e6e graph the reference runs in fp16 (vlfm/vlm/yolov7.py:35-48,89), BatchNorm folded:
  * out = act(conv(x, w) + bias) as an implicit GEMM on the matrix cores (csrc/conv_nhwc.hip), NHWC f16, f32 accumulation.
@@ -405,6 +415,13 @@ int vlfm_nms(const float* d_boxes_xyxy, const int32_t* d_order, int n, float iou
 int vlfm_ms_deform_attn(const float* d_value, const int32_t* d_spatial_shapes, const int32_t* d_level_start,
                         const float* d_sampling_loc, const float* d_attn_weight, int batch, int n_query, int n_heads,
                         int head_dim, int n_levels, int n_points, int total_len, float* d_out, void* stream);
+/* The same with the softmax and the sampling-location arithmetic of GroundingDinoMultiscaleDeformableAttention.forward [ext] inside the
+ * kernel: d_offsets_logits [B][Q][heads*L*P*2 + heads*L*P] = the raw output of the sampling_offsets | attention_weights Linears
+ * (offsets [h][l][p][2], then logits [h][l][p]), d_reference [B][Q][L][ref_coords], ref_coords 2 (points: + offset / (W_l, H_l)) or 4
+ * (boxes: + offset / P * size * 0.5).  8 heads of width 32. */
+int vlfm_ms_deform_attn_fused(const float* d_value, const int32_t* d_spatial_shapes, const int32_t* d_level_start,
+                              const float* d_offsets_logits, const float* d_reference, int batch, int n_query, int n_heads,
+                              int head_dim, int n_levels, int n_points, int ref_coords, int total_len, float* d_out, void* stream);
 
 /* Device: depthwise 3x3 convolution, padding 1, stride 1 or 2, NCHW f32: y = conv(x, w[C][1][3][3]) + bias[C] (NULL = none),
  * followed by the exact (erf) GELU when gelu != 0.  The depthwise convolutions of MobileSAM's TinyViT encoder behind

@@ -104,6 +104,8 @@ def test_harness_decide_and_navigate_are_the_scalar_rules_vectorised():
 
     h = H()
     h.E, h.targets, h.device, h.stop_radius = 4, ["chair", "bed", "tv", "couch"], torch.device("cpu"), 0.9
+    h.sightings = None                                     # no episode script: every environment is on the harness clock
+    h._episode_steps = lambda t_ep: BatchedEpisodes._episode_steps(h, t_ep)
     h.selectors = [FrontierSelector() for _ in range(4)]
     h.object_maps = [FakeObjectMap(None), FakeObjectMap(None), FakeObjectMap(None), FakeObjectMap([4.5, 4.0, 0.3])]
     wps = np.array([[1.0, 0.0], [2.0, 0.0], [5.0, 5.0], [6.0, 6.0], [7.0, 7.0]])

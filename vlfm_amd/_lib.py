@@ -127,6 +127,9 @@ def lib() -> ctypes.CDLL:
         L.vlfm_window_reverse_add_f32.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
         L.vlfm_dwconv3x3_nhwc_f32.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
         L.vlfm_window_attention_f32.argtypes = [vp, vp, vp, ctypes.c_longlong, ci, ci, ctypes.c_float, vp]
+        L.vlfm_layernorm_rows_shifted_f32.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ctypes.c_float, ci, ci, vp]
+        L.vlfm_window_reverse_add_shifted_f32.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, vp]
+        L.vlfm_window_attention_masked_f32.argtypes = [vp, vp, vp, ci, vp, ctypes.c_longlong, ci, ci, ctypes.c_float, vp]
         L.vlfm_maxpool2x2_nhwc_f16.argtypes = [vp, vp, ci, ci, ci, ci, vp]
         L.vlfm_conv_nhwc_tile.argtypes = [ci, ci, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(ci)]
         L.vlfm_conv_nhwc_f16.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
@@ -151,6 +154,7 @@ def lib() -> ctypes.CDLL:
         L.vlfm_nms_scratch_bytes.restype = ctypes.c_size_t
         L.vlfm_nms.argtypes = [vp, vp, ci, cf, vp, ctypes.c_size_t, vp, vp, ci, vp]
         L.vlfm_ms_deform_attn.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]
+        L.vlfm_ms_deform_attn_fused.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp]
         L.vlfm_object_cloud_scratch_bytes.argtypes = [ci, ci]
         L.vlfm_object_cloud_scratch_bytes.restype = ctypes.c_size_t
         L.vlfm_object_cloud_extract.argtypes = [vp, vp, ci, ci, ci, cd, cd, cd, cd, vp, vp, ci, vp, vp]

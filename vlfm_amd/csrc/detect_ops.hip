@@ -374,7 +374,89 @@ __global__ __launch_bounds__(256) void bias_act_nchw_kernel(T* __restrict__ y, c
         p[i] = (T)apply_act<ACT>((float)p[i] + b);
 }
 
+
+// The same sampling with everything in front of it fused in (round 4): the softmax over a head's L * P logits and the sampling
+// locations (GroundingDinoMultiscaleDeformableAttention.forward [ext]: reference point + offset / (W_l, H_l), or for 4-coordinate
+// reference boxes + offset / P * box size * 0.5) are evaluated in the kernel from the RAW output of the fused offsets|logits GEMM, so
+// the six elementwise passes over [B, Q, heads, L, P, 2] tensors (0.4 GB each at 64 frames) and the softmax launch disappear.  A
+// wavefront owns one query: lane = head * 8 + channel group, 4 channels (16 bytes) per lane -- the location arithmetic runs once per 8
+// lanes instead of once per channel, every gather is a dwordx4 and the 8 lanes of a head read one 128-byte segment, the result row
+// (heads * 32 floats = 1 KB) is written by one wavefront.  heads == 8, D == 32 (the shipped geometry; others use the plain kernel).
+//   ow   [B][Q][heads*L*P*2 + heads*L*P]: offsets [h][l][p][2], then logits [h][l][p]
+//   ref  [B][Q][L][C], C = 2 or 4
+__global__ __launch_bounds__(256) void ms_deform_attn_fused_kernel(const float* __restrict__ value, const int* __restrict__ shapes,
+                                                                   const int* __restrict__ level_start, const float* __restrict__ ow,
+                                                                   const float* __restrict__ ref, int B, int Q, int L, int P, int C,
+                                                                   int total, float* __restrict__ out) {
+    constexpr int HEADS = 8, D = 32;
+    const int lane = threadIdx.x & 63;
+    const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);     // (b, q)
+    if (item >= (long long)B * Q) return;
+    const int b = (int)(item / Q);
+    const int h = lane >> 3, c4 = lane & 7;
+    const int LP = L * P;
+    const float* row = ow + (size_t)item * (HEADS * LP * 3);
+    const float* off = row + (size_t)h * LP * 2;
+    const float* lg = row + (size_t)HEADS * LP * 2 + (size_t)h * LP;
+    const float* rq = ref + (size_t)item * L * C;
+    // softmax over the head's L * P logits
+    float mx = -INFINITY;
+    for (int i = 0; i < LP; i++) mx = fmaxf(mx, lg[i]);
+    float den = 0.f;
+    for (int i = 0; i < LP; i++) den += expf(lg[i] - mx);
+    const float inv = 1.0f / den;
+    const float* vb = value + (size_t)b * total * HEADS * D + (size_t)h * D + c4 * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int l = 0; l < L; l++) {
+        const int Hl = shapes[2 * l], Wl = shapes[2 * l + 1];
+        const float* vl = vb + (size_t)level_start[l] * HEADS * D;
+        const float rx = rq[l * C], ry = rq[l * C + 1];
+        float sx, sy;
+        if (C == 2) { sx = 1.0f / (float)Wl; sy = 1.0f / (float)Hl; }
+        else { sx = rq[l * C + 2]; sy = rq[l * C + 3]; }
+        for (int p = 0; p < P; p++) {
+            const float ox = off[(l * P + p) * 2], oy = off[(l * P + p) * 2 + 1];
+            float lx, ly;
+            if (C == 2) { lx = rx + ox / (float)Wl; ly = ry + oy / (float)Hl; }        // reference + offset / (W, H)
+            else { lx = rx + ox / (float)P * sx * 0.5f; ly = ry + oy / (float)P * sy * 0.5f; }
+            const float w = expf(lg[l * P + p] - mx) * inv;
+            const float x = lx * (float)Wl - 0.5f, y = ly * (float)Hl - 0.5f;
+            const float xf = floorf(x), yf = floorf(y);
+            const int x0 = (int)xf, y0 = (int)yf;
+            const float tx = x - xf, ty = y - yf;
+            const bool xin0 = (unsigned)x0 < (unsigned)Wl, xin1 = (unsigned)(x0 + 1) < (unsigned)Wl;
+            const bool yin0 = (unsigned)y0 < (unsigned)Hl, yin1 = (unsigned)(y0 + 1) < (unsigned)Hl;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            auto tap = [&](int yy, int xx, float k) {
+                const float4 v = *reinterpret_cast<const float4*>(vl + ((size_t)yy * Wl + xx) * HEADS * D);
+                s.x += v.x * k; s.y += v.y * k; s.z += v.z * k; s.w += v.w * k;
+            };
+            if (yin0 && xin0) tap(y0, x0, (1.f - tx) * (1.f - ty));
+            if (yin0 && xin1) tap(y0, x0 + 1, tx * (1.f - ty));
+            if (yin1 && xin0) tap(y0 + 1, x0, (1.f - tx) * ty);
+            if (yin1 && xin1) tap(y0 + 1, x0 + 1, tx * ty);
+            acc.x += s.x * w; acc.y += s.y * w; acc.z += s.z * w; acc.w += s.w * w;
+        }
+    }
+    *reinterpret_cast<float4*>(out + (size_t)item * HEADS * D + h * D + c4 * 4) = acc;
+}
+
 }  // namespace vlfm
+
+extern "C" int vlfm_ms_deform_attn_fused(const float* d_value, const int32_t* d_spatial_shapes, const int32_t* d_level_start,
+                                         const float* d_offsets_logits, const float* d_reference, int batch, int n_query, int n_heads,
+                                         int head_dim, int n_levels, int n_points, int ref_coords, int total_len, float* d_out,
+                                         void* stream) {
+    if (batch == 0 || n_query == 0) return VLFM_OK;
+    if (!d_value || !d_spatial_shapes || !d_level_start || !d_offsets_logits || !d_reference || !d_out || batch < 0 || n_query < 0 ||
+        n_heads != 8 || head_dim != 32 || n_levels <= 0 || n_points <= 0 || total_len <= 0 || (ref_coords != 2 && ref_coords != 4))
+        return fail(VLFM_ERR_INVALID, "ms_deform_attn_fused: 8 heads of width 32, reference points with 2 or 4 coordinates");
+    const long long items = (long long)batch * n_query;
+    VLFM_TIMED("ms_deform_attn_fused_kernel", stream);
+    VLFM_KLAUNCH(vlfm::ms_deform_attn_fused_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, d_value, d_spatial_shapes,
+                 d_level_start, d_offsets_logits, d_reference, batch, n_query, n_levels, n_points, ref_coords, total_len, d_out);
+    return check_launch("ms_deform_attn_fused_kernel");
+}
 
 extern "C" int vlfm_ms_deform_attn(const float* d_value, const int32_t* d_spatial_shapes, const int32_t* d_level_start,
                                    const float* d_sampling_loc, const float* d_attn_weight, int batch, int n_query,

@@ -135,55 +135,104 @@ __global__ __launch_bounds__(256) void dbscan_adjacency_kernel(const double* __r
     if (lane == 0) degree[i] = deg;
 }
 
-// One workgroup: connected components of the core graph by min-label propagation (label = smallest core index reached),
-// border attachment, cluster sizes, largest cluster, ordered output.  n <= 8192.
+// One workgroup: connected components of the core graph by BIT-PARALLEL breadth-first search (round 4; before: min-label propagation
+// that enumerated every neighbour of every core point once per sweep -- 5000 points of one dense object blob have ~1000 neighbours each,
+// and with the serial size / compaction loops of one lane a call took 20-35 ms, which made the object-map stage THE cost of the
+// batched full step).  The eps-adjacency is already a bit matrix; a search level is "OR the adjacency rows of the frontier": every
+// wavefront takes frontier nodes, its lanes OR the row's words (masked by the core set) into registers, and the wavefront's result
+// goes to LDS once per level -- n x n / 64 word operations per component in total, no neighbour enumeration.  Components are seeded
+// in ascending order of their smallest core index (the order in which the sequential scan of the reference's Open3D seeds them), so
+// label = that index, as before.  Border points have fewer than min_points neighbours: enumerating those is cheap.  Cluster sizes,
+// the first largest cluster and the ordered index list are parallel reductions / prefix sums.  n <= 8192.
+constexpr int DB_WORDS = 128;    // 8192 / 64
+
 __global__ __launch_bounds__(1024) void dbscan_cluster_kernel(const unsigned long long* __restrict__ adj, const int* __restrict__ degree,
                                                               int n, int cb_count, int min_points, int* __restrict__ label,
                                                               int* __restrict__ sizes /* [n] scratch */, int* __restrict__ keep,
                                                               int* __restrict__ num_keep) {
-    __shared__ int changed;
-    __shared__ int best_label, best_size, out_count;
-    const int tid = threadIdx.x, nth = blockDim.x;
-    // label[i] = i for core points, INT_MAX otherwise
-    for (int i = tid; i < n; i += nth) { label[i] = degree[i] >= min_points ? i : 0x7FFFFFFF; sizes[i] = 0; }
+    __shared__ unsigned long long core[DB_WORDS], unvis[DB_WORDS], comp[DB_WORDS], front[DB_WORDS], nxt[DB_WORDS];
+    __shared__ int sh_root, sh_more, best_label, best_size;
+    __shared__ int wprefix[DB_WORDS + 1];
+    __shared__ unsigned long long red_key[16];
+    const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nth >> 6;
+    // ---- core set as a bit set; every label starts as noise
+    for (int base = 0; base < cb_count * 64; base += nth) {
+        const int i = base + tid;
+        const bool is_core = i < n && degree[i] >= min_points;
+        const unsigned long long w = __ballot(is_core);
+        if (lane == 0 && (i >> 6) < cb_count) { core[i >> 6] = w; unvis[i >> 6] = w; }
+        if (i < n) { label[i] = 0x7FFFFFFF; sizes[i] = 0; }
+    }
     __syncthreads();
     for (;;) {
-        if (tid == 0) changed = 0;
+        // ---- next seed: the smallest core index not yet in a component
+        if (wave == 0) {
+            int first = 0x7FFFFFFF;
+            for (int wd = lane; wd < cb_count; wd += 64)
+                if (unvis[wd] && first == 0x7FFFFFFF) first = wd * 64 + __builtin_ctzll(unvis[wd]);
+            for (int off = 32; off > 0; off >>= 1) first = min(first, __shfl_xor(first, off, 64));
+            if (lane == 0) sh_root = first;
+        }
         __syncthreads();
-        for (int i = tid; i < n; i += nth) {
-            if (degree[i] < min_points) continue;
-            int best = label[i];
+        const int root = sh_root;
+        if (root == 0x7FFFFFFF) break;
+        for (int wd = tid; wd < cb_count; wd += nth) {
+            const unsigned long long b = wd == (root >> 6) ? (1ull << (root & 63)) : 0ull;
+            comp[wd] = b; front[wd] = b; nxt[wd] = 0ull;
+        }
+        __syncthreads();
+        // ---- breadth-first levels
+        for (;;) {
+            // lane l of a wavefront accumulates words l and l + 64 of the rows of the frontier nodes its wavefront takes
+            unsigned long long a0 = 0ull, a1 = 0ull;
+            for (int wd = wave; wd < cb_count; wd += nwaves) {
+                unsigned long long f = front[wd];          // wave-uniform
+                while (f) {
+                    const int i = wd * 64 + __builtin_ctzll(f);
+                    f &= f - 1;
+                    const unsigned long long* row = adj + (size_t)i * cb_count;
+                    if (lane < cb_count) a0 |= row[lane];
+                    if (lane + 64 < cb_count) a1 |= row[lane + 64];
+                }
+            }
+            if (lane < cb_count && a0) atomicOr(&nxt[lane], a0 & core[lane]);
+            if (lane + 64 < cb_count && a1) atomicOr(&nxt[lane + 64], a1 & core[lane + 64]);
+            if (tid == 0) sh_more = 0;
+            __syncthreads();
+            for (int wd = tid; wd < cb_count; wd += nth) {
+                const unsigned long long fresh = nxt[wd] & ~comp[wd];
+                comp[wd] |= fresh; front[wd] = fresh; nxt[wd] = 0ull;
+                if (fresh) sh_more = 1;
+            }
+            __syncthreads();
+            if (!sh_more) break;
+            __syncthreads();
+        }
+        // ---- the component's label, and out of the unvisited set
+        for (int i = tid; i < cb_count * 64; i += nth)
+            if (i < n && ((comp[i >> 6] >> (i & 63)) & 1ull)) label[i] = root;
+        for (int wd = tid; wd < cb_count; wd += nth) unvis[wd] &= ~comp[wd];
+        __syncthreads();
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- border points: the lowest-labelled neighbouring core cluster (clusters are seeded in order of their smallest core index, so
+    // "lowest root index" == "first cluster to reach the point"); noise keeps INT_MAX.  Read core labels only: border points do not feed
+    // each other (their own labels are written after the barrier)
+    for (int i = tid; i < n; i += nth) {
+        int best = 0x7FFFFFFF;
+        if (degree[i] < min_points) {
             const unsigned long long* row = adj + (size_t)i * cb_count;
             for (int cb = 0; cb < cb_count; cb++) {
-                unsigned long long w = row[cb];
+                unsigned long long w = row[cb] & core[cb];
                 while (w) {
                     const int j = cb * 64 + __builtin_ctzll(w);
                     w &= w - 1;
-                    if (degree[j] >= min_points) { const int lj = label[j]; if (lj < best) best = lj; }
+                    best = min(best, label[j]);
                 }
             }
-            if (best < label[i]) { label[i] = best; changed = 1; }  // monotone: racy reads only delay convergence
         }
-        __syncthreads();
-        const int again = changed;
-        __syncthreads();
-        if (!again) break;
-    }
-    // border points: the lowest-labelled neighbouring core cluster (clusters are seeded in order of their smallest core
-    // index, so "lowest root index" == "first cluster to reach the point"); noise keeps INT_MAX
-    for (int i = tid; i < n; i += nth) {
-        if (degree[i] >= min_points) continue;
-        int best = 0x7FFFFFFF;
-        const unsigned long long* row = adj + (size_t)i * cb_count;
-        for (int cb = 0; cb < cb_count; cb++) {
-            unsigned long long w = row[cb];
-            while (w) {
-                const int j = cb * 64 + __builtin_ctzll(w);
-                w &= w - 1;
-                if (degree[j] >= min_points && label[j] < best) best = label[j];
-            }
-        }
-        sizes[i] = best;  // staged so that border points do not feed each other
+        sizes[i] = best;   // staged
     }
     __syncthreads();
     for (int i = tid; i < n; i += nth) if (degree[i] < min_points) label[i] = sizes[i];
@@ -192,17 +241,42 @@ __global__ __launch_bounds__(1024) void dbscan_cluster_kernel(const unsigned lon
     __syncthreads();
     for (int i = tid; i < n; i += nth) if (label[i] != 0x7FFFFFFF) atomicAdd(&sizes[label[i]], 1);
     __syncthreads();
-    if (tid == 0) {  // np.argmax over clusters in label order (roots ascending == labels ascending): first maximum
-        int bl = -1, bs = 0;
-        for (int r = 0; r < n; r++) if (sizes[r] > bs) { bs = sizes[r]; bl = r; }
-        best_label = bl; best_size = bs; out_count = 0;
+    // ---- np.argmax over clusters in label order (roots ascending == labels ascending): the FIRST maximum = largest size, then the
+    // smallest root.  key = size << 32 | (0xFFFFFFFF - root): the maximum key wins
+    unsigned long long key = 0ull;
+    for (int r = tid; r < n; r += nth) {
+        const int sz = sizes[r];
+        if (sz > 0) { const unsigned long long k = ((unsigned long long)(unsigned)sz << 32) | (0xFFFFFFFFu - (unsigned)r); key = k > key ? k : key; }
+    }
+    for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(key, off, 64); key = o > key ? o : key; }
+    if (lane == 0) red_key[wave] = key;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long k = 0ull;
+        for (int w = 0; w < nwaves; w++) k = red_key[w] > k ? red_key[w] : k;
+        best_size = (int)(k >> 32);
+        best_label = k ? (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull)) : -1;
     }
     __syncthreads();
     if (best_label < 0) { if (tid == 0) *num_keep = 0; return; }
-    if (tid == 0) {  // ordered compaction (np.where order); n is a few thousand
+    // ---- ordered compaction (np.where order): membership bit set -> per-word prefix -> every member writes its own slot
+    const int bl = best_label;
+    for (int base = 0; base < cb_count * 64; base += nth) {
+        const int i = base + tid;
+        const unsigned long long w = __ballot(i < n && label[i] == bl);
+        if (lane == 0 && (i >> 6) < cb_count) comp[i >> 6] = w;
+    }
+    __syncthreads();
+    if (tid == 0) {
         int c = 0;
-        for (int i = 0; i < n; i++) if (label[i] == best_label) keep[c++] = i;
+        for (int wd = 0; wd < cb_count; wd++) { wprefix[wd] = c; c += __popcll(comp[wd]); }   // <= 128 LDS words
+        wprefix[cb_count] = c;
         *num_keep = c;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += nth) {
+        const unsigned long long w = comp[i >> 6];
+        if ((w >> (i & 63)) & 1ull) keep[wprefix[i >> 6] + __popcll(w & ((1ull << (i & 63)) - 1ull))] = i;
     }
 }
 

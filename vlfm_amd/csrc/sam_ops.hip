@@ -33,7 +33,8 @@ __device__ inline float wave_sum(float v) {
 template <int MAXV>   // float4 per lane: C <= 256 * MAXV
 __global__ __launch_bounds__(256) void layernorm_rows_f32_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, float* __restrict__ out, int B,
-                                                                 int H, int W, int C, int ws, float eps, long long out_rows) {
+                                                                 int H, int W, int C, int ws, float eps, long long out_rows,
+                                                                 int shift, int pad_zero) {
     const int lane = threadIdx.x & 63;
     const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= out_rows) return;
@@ -45,13 +46,19 @@ __global__ __launch_bounds__(256) void layernorm_rows_f32_kernel(const float* __
         const long long win = r / ww;
         const int pos = (int)(r - win * ww), iy = pos / ws, ix = pos - iy * ws;
         const int wx = (int)(win % nwx), wy = (int)((win / nwx) % nwy), b = (int)(win / ((long long)nwx * nwy));
-        const int y = wy * ws + iy, xx = wx * ws + ix;
+        int y = wy * ws + iy, xx = wx * ws + ix;
+        if (shift) {   // Swin's cyclic shift of the PADDED image (torch.roll by -shift): window cell (y, xx) <- padded cell (y + shift, xx + shift)
+            const int Hp = nwy * ws, Wp = nwx * ws;
+            y = y + shift; if (y >= Hp) y -= Hp;
+            xx = xx + shift; if (xx >= Wp) xx -= Wp;
+        }
         real = y < H && xx < W;
         in_row = ((long long)b * H + y) * W + xx;
     }
     float4* orow = reinterpret_cast<float4*>(out + r * C);
-    if (!real) {   // LayerNorm of the reference's zero padding: (0 - 0) / sqrt(0 + eps) * gamma + beta
-        for (int i = lane; i < C4; i += 64) orow[i] = reinterpret_cast<const float4*>(beta)[i];
+    if (!real) {   // TinyViT pads BEFORE the norm: LayerNorm(0) = beta.  Swin pads AFTER the norm (pad_zero): 0.
+        for (int i = lane; i < C4; i += 64)
+            orow[i] = pad_zero ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<const float4*>(beta)[i];
         return;
     }
     const float4* irow = reinterpret_cast<const float4*>(x + in_row * C);
@@ -90,7 +97,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_f32_kernel(const float* __
 
 // x[b, y, xx, :] += a[window row of (b, y, xx), :]   (one thread per float4)
 __global__ __launch_bounds__(256) void window_reverse_add_f32_kernel(float* __restrict__ x, const float* __restrict__ a, int B, int H,
-                                                                     int W, int C, int ws, long long n4) {
+                                                                     int W, int C, int ws, long long n4, int shift) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     const int C4 = C >> 2;
@@ -98,7 +105,12 @@ __global__ __launch_bounds__(256) void window_reverse_add_f32_kernel(float* __re
     const int c4 = (int)(i - row * C4);
     const int xx = (int)(row % W), y = (int)((row / W) % H), b = (int)(row / ((long long)W * H));
     const int nwx = (W + ws - 1) / ws, nwy = (H + ws - 1) / ws;
-    const int wy = y / ws, iy = y - wy * ws, wx = xx / ws, ix = xx - wx * ws;
+    int ys = y, xs = xx;
+    if (shift) {   // the windows hold the image rolled by -shift: padded cell (y, xx) sits at shifted cell (y - shift, xx - shift)
+        ys = y - shift; if (ys < 0) ys += nwy * ws;
+        xs = xx - shift; if (xs < 0) xs += nwx * ws;
+    }
+    const int wy = ys / ws, iy = ys - wy * ws, wx = xs / ws, ix = xs - wx * ws;
     const long long arow = (((long long)b * nwy + wy) * nwx + wx) * (ws * ws) + iy * ws + ix;
     float4 v = reinterpret_cast<float4*>(x)[i];
     const float4 t = reinterpret_cast<const float4*>(a)[arow * C4 + c4];
@@ -148,7 +160,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_nhwc_f32_kernel(const float* __
 // 0.57 / 0.70 / 0.40 (the packed form cannot take the scalar operands directly).  What bounds it now is the f32 vector ALU.
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void window_attention_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ bias_t,
-                                                                      float* __restrict__ out, int N, int heads, float scale_log2e) {
+                                                                      float* __restrict__ out, int N, int heads, float scale_log2e,
+                                                                      const float* __restrict__ mask_t, int wins_per_image) {
     const int h = blockIdx.x % heads;
     const long long win = blockIdx.x / heads;
     const int i = threadIdx.x;
@@ -163,6 +176,8 @@ __global__ __launch_bounds__(THREADS) void window_attention_f32_kernel(const flo
     }
     const float LOG2E = 1.4426950408889634f;
     const float* bcol = bias_t + ((size_t)h * N) * N + i;       // bias[h][i][j] at bcol[j * N]
+    // Swin's shifted windows: an additive mask per window POSITION in the image, [wins_per_image][j][i] (0 / -100), or null
+    const float* mcol = mask_t ? mask_t + ((size_t)(win % wins_per_image) * N) * N + i : nullptr;
     float o[32];
 #pragma unroll
     for (int c = 0; c < 32; c++) o[c] = 0.f;
@@ -174,7 +189,7 @@ __global__ __launch_bounds__(THREADS) void window_attention_f32_kernel(const flo
             const int j = j0 + u;
             if (j < N) {
                 const float* kj = base + (size_t)j * row + 32;       // wave-uniform address
-                float acc = bcol[(size_t)j * N] * LOG2E;
+                float acc = (mcol ? bcol[(size_t)j * N] + mcol[(size_t)j * N] : bcol[(size_t)j * N]) * LOG2E;
 #pragma unroll
                 for (int c = 0; c < 32; c++) acc = fmaf(q[c], kj[c], acc);
                 sc[u] = acc;
@@ -216,16 +231,25 @@ using namespace vlfm;
 // out = softmax(scale * q k^T + bias) v per (window, head); tokens <= 256.
 extern "C" int vlfm_window_attention_f32(const float* d_qkv, const float* d_bias_t, float* d_out, long long windows, int tokens, int heads,
                                          float scale, void* stream) {
+    return vlfm_window_attention_masked_f32(d_qkv, d_bias_t, nullptr, 1, d_out, windows, tokens, heads, scale, stream);
+}
+
+// The same with Swin's shifted-window mask (the detector backbone behind vlfm/vlm/grounding_dino.py:38-74): d_mask_t
+// [windows_per_image][tokens][tokens] is added to the bias of window w's scores as d_mask_t[w % windows_per_image] (transposed like
+// d_bias_t; the mask is symmetric); NULL = no mask.
+extern "C" int vlfm_window_attention_masked_f32(const float* d_qkv, const float* d_bias_t, const float* d_mask_t, int windows_per_image,
+                                                float* d_out, long long windows, int tokens, int heads, float scale, void* stream) {
     if (windows == 0) return VLFM_OK;
-    if (!d_qkv || !d_bias_t || !d_out || windows < 0 || tokens <= 0 || tokens > 256 || heads <= 0 || windows * heads > 0x7fffffffLL)
+    if (!d_qkv || !d_bias_t || !d_out || windows < 0 || tokens <= 0 || tokens > 256 || heads <= 0 || windows * heads > 0x7fffffffLL ||
+        windows_per_image <= 0)
         return fail(VLFM_ERR_INVALID, "window_attention_f32: 1 <= tokens <= 256, head width 32");
     const dim3 grid((unsigned)(windows * heads));
     const float sl = scale * 1.4426950408889634f;
     hipStream_t s = (hipStream_t)stream;
     VLFM_TIMED("window_attention_f32_kernel", stream);
-    if (tokens <= 64) VLFM_KLAUNCH((sam::window_attention_f32_kernel<64>), grid, dim3(64), 0, s, d_qkv, d_bias_t, d_out, tokens, heads, sl);
-    else if (tokens <= 128) VLFM_KLAUNCH((sam::window_attention_f32_kernel<128>), grid, dim3(128), 0, s, d_qkv, d_bias_t, d_out, tokens, heads, sl);
-    else VLFM_KLAUNCH((sam::window_attention_f32_kernel<256>), grid, dim3(256), 0, s, d_qkv, d_bias_t, d_out, tokens, heads, sl);
+    if (tokens <= 64) VLFM_KLAUNCH((sam::window_attention_f32_kernel<64>), grid, dim3(64), 0, s, d_qkv, d_bias_t, d_out, tokens, heads, sl, d_mask_t, windows_per_image);
+    else if (tokens <= 128) VLFM_KLAUNCH((sam::window_attention_f32_kernel<128>), grid, dim3(128), 0, s, d_qkv, d_bias_t, d_out, tokens, heads, sl, d_mask_t, windows_per_image);
+    else VLFM_KLAUNCH((sam::window_attention_f32_kernel<256>), grid, dim3(256), 0, s, d_qkv, d_bias_t, d_out, tokens, heads, sl, d_mask_t, windows_per_image);
     return check_launch("window_attention_f32_kernel");
 }
 
@@ -234,10 +258,18 @@ extern "C" int vlfm_window_attention_f32(const float* d_qkv, const float* d_bias
 // the zero-padded image in window order (TinyViTBlock's pad + window partition + attn.norm); padded positions receive beta.
 extern "C" int vlfm_layernorm_rows_f32(const float* d_x, const float* d_gamma, const float* d_beta, float* d_out, int batch, int height,
                                        int width, int channels, int window, float eps, void* stream) {
+    return vlfm_layernorm_rows_shifted_f32(d_x, d_gamma, d_beta, d_out, batch, height, width, channels, window, eps, 0, 0, stream);
+}
+
+// The same for Swin's (shifted) windows: the window rows are those of the zero-padded image ROLLED by -shift along both axes
+// (SwinLayer.cyclic_shift), 0 <= shift < window; pad_zero != 0: padded positions receive 0 (Swin pads after the norm) instead of beta.
+extern "C" int vlfm_layernorm_rows_shifted_f32(const float* d_x, const float* d_gamma, const float* d_beta, float* d_out, int batch,
+                                               int height, int width, int channels, int window, float eps, int shift, int pad_zero,
+                                               void* stream) {
     if (batch == 0) return VLFM_OK;
     if (!d_x || !d_gamma || !d_beta || !d_out || batch < 0 || height <= 0 || width <= 0 || channels <= 0 || (channels & 3) ||
-        channels > 1024 || window < 0)
-        return fail(VLFM_ERR_INVALID, "layernorm_rows_f32: channels must be a multiple of 4 and <= 1024");
+        channels > 1024 || window < 0 || shift < 0 || (shift > 0 && shift >= window))
+        return fail(VLFM_ERR_INVALID, "layernorm_rows_f32: channels must be a multiple of 4 and <= 1024, 0 <= shift < window");
     long long rows = (long long)batch * height * width;
     if (window > 0) {
         const long long nwy = (height + window - 1) / window, nwx = (width + window - 1) / window;
@@ -249,24 +281,31 @@ extern "C" int vlfm_layernorm_rows_f32(const float* d_x, const float* d_gamma, c
     hipStream_t s = (hipStream_t)stream;
     VLFM_TIMED("layernorm_rows_f32_kernel", stream);
     const int c4 = channels / 4;
-    if (c4 <= 64) VLFM_KLAUNCH((sam::layernorm_rows_f32_kernel<1>), grid, block, 0, s, d_x, d_gamma, d_beta, d_out, batch, height, width, channels, window, eps, rows);
-    else if (c4 <= 128) VLFM_KLAUNCH((sam::layernorm_rows_f32_kernel<2>), grid, block, 0, s, d_x, d_gamma, d_beta, d_out, batch, height, width, channels, window, eps, rows);
-    else VLFM_KLAUNCH((sam::layernorm_rows_f32_kernel<4>), grid, block, 0, s, d_x, d_gamma, d_beta, d_out, batch, height, width, channels, window, eps, rows);
+    if (c4 <= 64) VLFM_KLAUNCH((sam::layernorm_rows_f32_kernel<1>), grid, block, 0, s, d_x, d_gamma, d_beta, d_out, batch, height, width, channels, window, eps, rows, shift, pad_zero);
+    else if (c4 <= 128) VLFM_KLAUNCH((sam::layernorm_rows_f32_kernel<2>), grid, block, 0, s, d_x, d_gamma, d_beta, d_out, batch, height, width, channels, window, eps, rows, shift, pad_zero);
+    else VLFM_KLAUNCH((sam::layernorm_rows_f32_kernel<4>), grid, block, 0, s, d_x, d_gamma, d_beta, d_out, batch, height, width, channels, window, eps, rows, shift, pad_zero);
     return check_launch("layernorm_rows_f32_kernel");
 }
 
 // d_x[b, y, x, :] += d_windows[row of (b, y, x) in window order, :]: TinyViTBlock's window reverse + crop + residual add, in place.
 extern "C" int vlfm_window_reverse_add_f32(float* d_x, const float* d_windows, int batch, int height, int width, int channels, int window,
                                            void* stream) {
+    return vlfm_window_reverse_add_shifted_f32(d_x, d_windows, batch, height, width, channels, window, 0, stream);
+}
+
+// The same when the windows hold the image rolled by -shift (Swin): reverse + roll back + crop + residual add, in place.
+extern "C" int vlfm_window_reverse_add_shifted_f32(float* d_x, const float* d_windows, int batch, int height, int width, int channels,
+                                                   int window, int shift, void* stream) {
     if (batch == 0) return VLFM_OK;
-    if (!d_x || !d_windows || batch < 0 || height <= 0 || width <= 0 || channels <= 0 || (channels & 3) || window <= 0)
-        return fail(VLFM_ERR_INVALID, "window_reverse_add_f32: channels must be a multiple of 4, window > 0");
+    if (!d_x || !d_windows || batch < 0 || height <= 0 || width <= 0 || channels <= 0 || (channels & 3) || window <= 0 || shift < 0 ||
+        shift >= window)
+        return fail(VLFM_ERR_INVALID, "window_reverse_add_f32: channels must be a multiple of 4, window > 0, 0 <= shift < window");
     const long long n4 = (long long)batch * height * width * (channels / 4);
     const long long blocks = (n4 + 255) / 256;
     if (blocks > 0x7fffffffLL) return fail(VLFM_ERR_CAPACITY, "window_reverse_add_f32: tensor too large");
     VLFM_TIMED("window_reverse_add_f32_kernel", stream);
     VLFM_KLAUNCH(sam::window_reverse_add_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_x, d_windows, batch,
-                 height, width, channels, window, n4);
+                 height, width, channels, window, n4, shift);
     return check_launch("window_reverse_add_f32_kernel");
 }
 

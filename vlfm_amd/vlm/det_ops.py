@@ -171,6 +171,32 @@ def ms_deform_attn(value: torch.Tensor, spatial_shapes_list, level_start_index: 
     return out
 
 
+def ms_deform_attn_fused(value: torch.Tensor, spatial_shapes_list, level_start_index: torch.Tensor, offsets_logits: torch.Tensor,
+                         reference_points: torch.Tensor, n_levels: int, n_points: int) -> torch.Tensor:
+    """The sampling with its softmax and location arithmetic inside the kernel (csrc/detect_ops.hip): value [B,S,8,32],
+    offsets_logits [B,Q,8*L*P*3] (the raw output of the sampling_offsets | attention_weights Linears), reference_points [B,Q,L,2|4]
+    -> [B,Q,256]."""
+    B, S, heads, D = value.shape
+    Q = offsets_logits.shape[1]
+    C = reference_points.shape[-1]
+    dev = value.device
+    key = (str(dev), tuple((int(h), int(w)) for h, w in spatial_shapes_list))
+    shapes = _SHAPE_CACHE.get(key)
+    if shapes is None:
+        shapes = _SHAPE_CACHE[key] = torch.tensor([[int(h), int(w)] for h, w in spatial_shapes_list], dtype=torch.int32, device=dev)
+    ls = level_start_index if level_start_index.dtype == torch.int32 else level_start_index.to(torch.int32)
+    out = torch.empty((B, Q, heads * D), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().vlfm_ms_deform_attn_fused(value.contiguous().data_ptr(), shapes.data_ptr(), ls.contiguous().data_ptr(),
+                                                        offsets_logits.contiguous().data_ptr(), reference_points.contiguous().data_ptr(),
+                                                        B, Q, heads, D, n_levels, n_points, C, S, out.data_ptr(), _stream()),
+                   "ms_deform_attn_fused")
+    return out
+
+
+_SHAPE_CACHE: Dict[Tuple, torch.Tensor] = {}
+
+
 def patch_hf_deformable_attention(model) -> int:
     """Route every HF ``MultiScaleDeformableAttention`` module of ``model`` (GroundingDINO) through the HIP kernel when its
     inputs are f32 device tensors; anything else keeps the module's own PyTorch path.  Returns the number patched."""

@@ -1,0 +1,374 @@
+"""GroundingDINO's forward on MI355X kernels (reference: vlfm/vlm/grounding_dino.py:38-74 runs the network in fp32 through the
+un-vendored groundingdino package; here the graph is transformers' ``GroundingDinoForObjectDetection`` -- same parameters, loaded
+by vlm/gdino_weights.py -- and this module replaces the forward of its heavy sub-modules, leaving their parameters where the
+checkpoint loaders put them).
+
+Where a 64-frame forward went before (profiles/r04_gdino_b64_before.txt: 291 ms of kernels, 368 ms wall): f32 GEMMs 147 ms
+(hipBLASLt at 107-147 TFLOP/s: already 0.7-0.9 of the f32 matrix peak -- there is no TF32-like mode on gfx950), MsDeformAttn
+39 ms, ~2 150 launches of elementwise / LayerNorm / permute kernels 100 ms, and 77 ms in which the GPU waits for the host.
+
+What this module does about it:
+  * every eligible ``nn.Linear`` runs on csrc/gemm_f32.hip's SPLIT form (f32 in / f32 out / f32 accumulate, operands as two f16:
+    f32-grade results at 1.5-2x hipBLASLt's f32 rate), with bias / ReLU / exact GELU / residual in the epilogue where the graph
+    allows; an operand outside f16's range raises a sticky device flag and ``GroundingDINO.predict_batch`` repeats the batch on
+    the library's exact f32 GEMMs;
+  * Swin blocks on NHWC rows: LayerNorm + pad + cyclic shift + window partition in one kernel, one fused q|k|v GEMM in the
+    attention kernel's per-head layout, window attention with the relative-position bias and the shifted-window mask
+    (csrc/sam_ops.hip), output projection, window reverse + roll back + crop + residual add in one in-place kernel, LayerNorm
+    rows, fc1 + GELU, fc2 + residual: 8 launches per block instead of ~45, no permute / roll / pad / contiguous copies;
+  * encoder deformable layers: value / offsets+weights (one GEMM) / output projection + residual, row LayerNorms, fc1 + ReLU,
+    fc2 + residual; the padding mask fill is skipped when the batch has no padding (all frames share one size);
+  * fusion layers: the two 256 -> 1024 vision projections as one GEMM (the 1/16 query scale folded into the weights: a power of
+    two, exact), the layer-scale folded into the output projection + residual epilogue, row LayerNorm.
+``accelerate(model)`` installs everything and returns a summary; ``model.vlfm_gemm_precision`` switches the GEMM form."""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+class _State:
+    """Per-model switches read by the patched forwards."""
+
+    def __init__(self) -> None:
+        self.precision = "split"        # "split" | "library" (F.linear = hipBLASLt exact f32)
+        self.no_padding = True          # every frame of a batch has the same size: the encoder's padding mask is empty
+        self.fused_sampling = True      # deformable attention: softmax + sampling locations inside the sampling kernel
+
+
+def _linear(st: _State, x: torch.Tensor, lin_w: torch.Tensor, lin_b, act=None, residual=None, out=None) -> torch.Tensor:
+    """act(x W^T + b) + residual on the matrix cores when the shape allows and the model runs in a fused precision; else torch."""
+    if st.precision != "library" and ops.linear_f32_supported(x, lin_w):
+        return ops.linear_f32(x, lin_w, lin_b, act=act, residual=residual, precision=st.precision, out=out)
+    y = F.linear(x, lin_w, lin_b)
+    if act == "relu":
+        y = torch.relu_(y)
+    elif act == "gelu":
+        y = F.gelu(y)
+    if residual is not None:
+        y = y.add_(residual.reshape(y.shape))
+    if out is not None:
+        out.copy_(y.reshape(out.shape))
+        return out.view(y.shape)
+    return y
+
+
+def _ln(x: torch.Tensor, ln: nn.LayerNorm) -> torch.Tensor:
+    """LayerNorm over the last dimension through the row kernel (f32 GPU tensors, C % 4 == 0, C <= 1024); else torch."""
+    C = x.shape[-1]
+    if x.is_cuda and x.dtype == torch.float32 and C % 4 == 0 and C <= 1024 and x.is_contiguous() and not torch.is_grad_enabled():
+        return ops.layernorm_rows(x.view(-1, 1, 1, C), ln.weight, ln.bias, ln.eps).view(x.shape)
+    return ln(x)
+
+
+def patch_linears(model: nn.Module, st: _State) -> int:
+    n = 0
+    for mod in model.modules():
+        if isinstance(mod, nn.Linear) and not getattr(mod, "_vlfm_fast", False):
+            def forward(x, _m=mod):
+                return _linear(st, x, _m.weight, _m.bias)
+
+            mod.forward = forward
+            mod._vlfm_fast = True
+            n += 1
+    return n
+
+
+# ------------------------------------------------------------------------------------------------ Swin
+class _Cache:
+    """Derived tensors of a module (fused weights, transposed biases), rebuilt when a source parameter changes."""
+
+    def __init__(self) -> None:
+        self.key, self.val = None, None
+
+    def get(self, params, build):
+        key = tuple((p.data_ptr(), ops.tensor_version(p), str(p.device)) for p in params)
+        if key != self.key:
+            self.key, self.val = key, build()
+        return self.val
+
+
+def _swin_qkv(att) -> tuple:
+    """The q / k / v Linears as ONE [heads * 96, C] weight in the attention kernel's layout (per head: q | k | v, 32 rows each)."""
+    heads, hd = att.num_attention_heads, att.head_dim
+    ws = [l.weight.detach().view(heads, hd, -1) for l in (att.q_proj, att.k_proj, att.v_proj)]
+    w = torch.stack(ws, dim=1).reshape(heads * 3 * hd, -1).contiguous()
+    b = None
+    if att.q_proj.bias is not None:
+        b = torch.stack([l.bias.detach().view(heads, hd) for l in (att.q_proj, att.k_proj, att.v_proj)], dim=1).reshape(-1).contiguous()
+    return w, b
+
+
+def patch_swin_layers(backbone: nn.Module, st: _State) -> int:
+    n = 0
+    for layer in backbone.modules():
+        if type(layer).__name__ != "SwinLayer" or layer.attention.head_dim != 32:
+            continue
+        plain = layer.forward
+        qkv_cache, bias_cache, mask_cache = _Cache(), _Cache(), {}
+
+        def forward(hidden_states, input_dimensions, always_partition=False, _l=layer, _plain=plain, _qkv=qkv_cache,
+                    _bias=bias_cache, _masks=mask_cache, **kw):
+            x = hidden_states
+            C = x.shape[-1]
+            if not (x.is_cuda and x.dtype == torch.float32 and C % 4 == 0 and not torch.is_grad_enabled()
+                    and not kw.get("output_attentions")):
+                return _plain(hidden_states, input_dimensions, always_partition=always_partition, **kw)
+            if not always_partition:
+                _l.set_shift_and_window_size(input_dimensions)
+            H, W = input_dimensions
+            B = x.shape[0]
+            ws, shift = int(_l.window_size), int(_l.shift_size)
+            att = _l.attention
+            heads = att.num_attention_heads
+            x = x.reshape(B, H, W, C)
+            if not x.is_contiguous():
+                x = x.contiguous()
+            nwy, nwx = -(-H // ws), -(-W // ws)
+            wins = ops.layernorm_rows(x, _l.layernorm_before.weight, _l.layernorm_before.bias, _l.layernorm_before.eps,
+                                      window=ws, shift=shift, pad_zero=True)                       # [B nW, ws^2, C]
+            wq, bq = _qkv.get([att.q_proj.weight, att.k_proj.weight, att.v_proj.weight] +
+                              ([att.q_proj.bias, att.k_proj.bias, att.v_proj.bias] if att.q_proj.bias is not None else []),
+                              lambda: _swin_qkv(att))
+            qkv = _linear(st, wins, wq, bq)                                                       # [B nW, ws^2, heads * 96]
+            rpb = att.relative_position_bias
+            bias_t = _bias.get([rpb.relative_position_bias_table],
+                               lambda: rpb()[0].detach().float().transpose(1, 2).contiguous())    # [heads, j, i]
+            mask = None
+            if shift > 0:
+                mk = (nwy * ws, nwx * ws, ws, shift, str(x.device))
+                if mk not in _masks:
+                    _masks[mk] = _l.get_attn_mask(nwy * ws, nwx * ws, dtype=torch.float32, device=x.device).contiguous()
+                mask = _masks[mk]
+            a = ops.window_attention(qkv.view(B * nwy * nwx, ws * ws, heads * 96), bias_t, heads, att.scaling, mask_t=mask)
+            o = _linear(st, a, att.o_proj.weight, att.o_proj.bias)
+            ops.window_reverse_add_(x, o.reshape(B * nwy * nwx, ws * ws, C).contiguous(), ws, shift)   # x += attention (in place)
+            y = ops.layernorm_rows(x, _l.layernorm_after.weight, _l.layernorm_after.bias, _l.layernorm_after.eps)
+            hid = _linear(st, y.view(B * H * W, C), _l.mlp.fc1.weight, _l.mlp.fc1.bias, act="gelu")
+            x2 = x.view(B * H * W, C)
+            _linear(st, hid, _l.mlp.fc2.weight, _l.mlp.fc2.bias, residual=x2, out=x2)                  # x += mlp (in place)
+            return x.view(B, H * W, C), None
+
+        layer.forward = forward
+        n += 1
+    return n
+
+
+# ------------------------------------------------------------------------------------------------ deformable attention + encoder layer
+def patch_deformable(model: nn.Module, st: _State) -> int:
+    n = 0
+    for mod in model.modules():
+        if type(mod).__name__ != "GroundingDinoMultiscaleDeformableAttention":
+            continue
+        ow_cache = _Cache()
+
+        def forward(hidden_states, attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None,
+                    position_embeddings=None, reference_points=None, spatial_shapes=None, spatial_shapes_list=None,
+                    level_start_index=None, output_attentions=False, residual=None, _m=mod, _ow=ow_cache):
+            """GroundingDinoMultiscaleDeformableAttention.forward [ext] with: value projection, ONE GEMM for sampling offsets +
+            attention logits, the output projection taking the caller's residual in its epilogue."""
+            q = hidden_states if position_embeddings is None else hidden_states + position_embeddings
+            B, Q, _ = q.shape
+            S = encoder_hidden_states.shape[1]
+            value = _linear(st, encoder_hidden_states, _m.value_proj.weight, _m.value_proj.bias)
+            if attention_mask is not None and not st.no_padding:
+                value = value.masked_fill(~attention_mask[..., None], float(0))
+            value = value.view(B, S, _m.n_heads, _m.d_model // _m.n_heads)
+            n_off = _m.sampling_offsets.out_features
+            w, b = _ow.get([_m.sampling_offsets.weight, _m.sampling_offsets.bias, _m.attention_weights.weight, _m.attention_weights.bias],
+                           lambda: (torch.cat([_m.sampling_offsets.weight.detach(), _m.attention_weights.weight.detach()], 0).contiguous(),
+                                    torch.cat([_m.sampling_offsets.bias.detach(), _m.attention_weights.bias.detach()], 0).contiguous()))
+            ow = _linear(st, q, w, b)
+            if (st.fused_sampling and _m.n_heads == 8 and _m.d_model == 256 and value.is_cuda and value.dtype == torch.float32
+                    and reference_points.shape[-1] in (2, 4) and reference_points.dtype == torch.float32):
+                # softmax + sampling locations + bilinear sampling in one kernel (csrc/detect_ops.hip)
+                from . import det_ops
+
+                out = det_ops.ms_deform_attn_fused(value, spatial_shapes_list, level_start_index, ow.view(B, Q, -1), reference_points,
+                                                   _m.n_levels, _m.n_points)
+                return _linear(st, out, _m.output_proj.weight, _m.output_proj.bias, residual=residual), None
+            sampling_offsets = ow[..., :n_off].reshape(B, Q, _m.n_heads, _m.n_levels, _m.n_points, 2)
+            aw = ow[..., n_off:].reshape(B, Q, _m.n_heads, _m.n_levels * _m.n_points)
+            aw = F.softmax(aw, -1).view(B, Q, _m.n_heads, _m.n_levels, _m.n_points)
+            if reference_points.shape[-1] == 2:
+                norm = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
+                loc = reference_points[:, :, None, :, None, :] + sampling_offsets / norm[None, None, None, :, None, :]
+            elif reference_points.shape[-1] == 4:
+                loc = (reference_points[:, :, None, :, None, :2]
+                       + sampling_offsets / _m.n_points * reference_points[:, :, None, :, None, 2:] * 0.5)
+            else:
+                raise ValueError(f"Last dim of reference_points must be 2 or 4, but got {reference_points.shape[-1]}")
+            out = _m.attn(value, spatial_shapes, spatial_shapes_list, level_start_index, loc, aw, _m.im2col_step)
+            out = _linear(st, out, _m.output_proj.weight, _m.output_proj.bias, residual=residual)
+            return out, aw
+
+        mod.forward = forward
+        n += 1
+    for mod in model.modules():
+        if type(mod).__name__ != "GroundingDinoDeformableLayer":
+            continue
+
+        def layer_forward(hidden_states, attention_mask, position_embeddings=None, reference_points=None, spatial_shapes=None,
+                          spatial_shapes_list=None, level_start_index=None, output_attentions=False, _m=mod):
+            """GroundingDinoDeformableLayer.forward [ext] (eval mode: the dropouts are identities)."""
+            x, aw = _m.self_attn(hidden_states=hidden_states, attention_mask=attention_mask, encoder_hidden_states=hidden_states,
+                                 encoder_attention_mask=attention_mask, position_embeddings=position_embeddings,
+                                 reference_points=reference_points, spatial_shapes=spatial_shapes,
+                                 spatial_shapes_list=spatial_shapes_list, level_start_index=level_start_index,
+                                 output_attentions=output_attentions, residual=hidden_states)
+            x = _ln(x, _m.self_attn_layer_norm)
+            h = _linear(st, x, _m.fc1.weight, _m.fc1.bias, act="relu")     # config.activation_function == "relu" (checked at install)
+            x = _linear(st, h, _m.fc2.weight, _m.fc2.bias, residual=x)
+            return _ln(x, _m.final_layer_norm), aw
+
+        mod.forward = layer_forward
+        n += 1
+    return n
+
+
+# ------------------------------------------------------------------------------------------------ fusion layer
+def patch_fusion(model: nn.Module, st: _State) -> int:
+    n = 0
+    for mod in model.modules():
+        if type(mod).__name__ != "GroundingDinoFusionLayer":
+            continue
+        vcache, ocache = _Cache(), _Cache()
+
+        def forward(vision_features, text_features, attention_mask_vision=None, attention_mask_text=None, _m=mod, _vc=vcache,
+                    _oc=ocache):
+            """GroundingDinoFusionLayer.forward + GroundingDinoBiMultiHeadAttention.forward [ext], eval mode: same arithmetic with
+            the two vision projections as one GEMM (query scale = head_dim^-0.5 folded in: a power of two for the shipped
+            geometry) and the vision layer-scale folded into the output projection, which adds the residual in its epilogue."""
+            a = _m.attn
+            v = _ln(vision_features, _m.layer_norm_vision)
+            t = _m.layer_norm_text(text_features)
+            B, Lv, _ = v.shape
+            E, Hh, hd = a.embed_dim, a.num_heads, a.head_dim
+            wv, bv = _vc.get([a.vision_proj.weight, a.vision_proj.bias, a.values_vision_proj.weight, a.values_vision_proj.bias],
+                             lambda: (torch.cat([a.vision_proj.weight.detach() * a.scale, a.values_vision_proj.weight.detach()], 0).contiguous(),
+                                      torch.cat([a.vision_proj.bias.detach() * a.scale, a.values_vision_proj.bias.detach()], 0).contiguous()))
+            vq = _linear(st, v, wv, bv)                                                  # [B, Lv, 2E]: scaled queries | values
+            q = vq[..., :E].reshape(B, Lv, Hh, hd).transpose(1, 2).reshape(B * Hh, Lv, hd)
+            vv = vq[..., E:].reshape(B, Lv, Hh, hd).transpose(1, 2).reshape(B * Hh, Lv, hd)
+            k = a.text_proj(t).view(B, -1, Hh, hd).transpose(1, 2).reshape(B * Hh, -1, hd)
+            tv = a.values_text_proj(t).view(B, -1, Hh, hd).transpose(1, 2).reshape(B * Hh, -1, hd)
+            Lt = k.shape[1]
+            w = torch.bmm(q, k.transpose(1, 2))                                           # [B heads, Lv, Lt]
+            w = w - w.max()
+            w = torch.clamp(w, min=-50000, max=50000)
+            wt = w.transpose(1, 2)
+            wt = wt - torch.max(wt, dim=-1, keepdim=True)[0]
+            wt = torch.clamp(wt, min=-50000, max=50000)
+            if attention_mask_vision is not None and not st.no_padding:
+                wt = wt.masked_fill(attention_mask_vision[:, None, None, :].repeat(1, Hh, 1, 1).flatten(0, 1), float("-inf"))
+            wt = wt.softmax(dim=-1)
+            if attention_mask_text is not None:
+                w = w.masked_fill(attention_mask_text[:, None, None, :].repeat(1, Hh, 1, 1).flatten(0, 1), float("-inf"))
+            wv_ = w.softmax(dim=-1)
+            ov = torch.bmm(wv_, tv).view(B, Hh, Lv, hd).transpose(1, 2).reshape(B, Lv, E)
+            ot = torch.bmm(wt, vv).view(B, Hh, Lt, hd).transpose(1, 2).reshape(B, Lt, E)
+            wo, bo = _oc.get([a.out_vision_proj.weight, a.out_vision_proj.bias, _m.vision_param],
+                             lambda: ((a.out_vision_proj.weight.detach() * _m.vision_param.detach()[:, None]).contiguous(),
+                                      (a.out_vision_proj.bias.detach() * _m.vision_param.detach()).contiguous()))
+            v = _linear(st, ov, wo, bo, residual=v)                                       # v + gamma_v * out_vision_proj(.)
+            t = t + _m.text_param * a.out_text_proj(ot)
+            return (v, wv_), (t, wt)
+
+        mod.forward = forward
+        n += 1
+    return n
+
+
+def accelerate(model: nn.Module, precision: str = "split") -> Dict[str, int]:
+    """Install the fused forwards on a transformers GroundingDinoForObjectDetection in eval mode.  ``model.vlfm_fast`` holds the
+    switches (``precision``: "split" / "library"; ``no_padding``)."""
+    st = _State()
+    st.precision = precision
+    cfg = model.config
+    assert cfg.activation_function == "relu", "the fused encoder FFN assumes ReLU (GroundingDINO_SwinT_OGC)"
+    assert not model.training, "fused forwards are inference-only: call model.eval() first"
+    model.vlfm_fast = st
+    out = {"swin_layers": patch_swin_layers(model.model.backbone, st), "deformable": patch_deformable(model, st),
+           "fusion_layers": patch_fusion(model, st), "linears": patch_linears(model, st)}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ HIP-graph replay of the forward
+class HostConstantCache:
+    """transformers' GroundingDINO forward builds a few small device tensors from Python lists on every call
+    (``torch.tensor(SPECIAL_TOKENS, device=...)``, ``torch.as_tensor(spatial_shapes_list, device=...)``): host-to-device copies,
+    which a HIP-graph capture does not allow.  Inside this context ``torch.tensor`` / ``torch.as_tensor`` of a Python list / tuple /
+    number onto a GPU are memoised by (value, dtype, device): run the forward once eagerly inside the context (records the
+    constants), then capture inside it (every constant is a cache hit, nothing crosses PCIe).  The values are compile-time
+    constants of the model for a fixed input geometry; sharing one tensor per value is safe as long as nobody writes into it --
+    the forward does not."""
+
+    def __init__(self) -> None:
+        self.cache: Dict = {}
+        self._saved = None
+
+    def _wrap(self, fn):
+        def cached(data, *args, **kw):
+            dev = kw.get("device", None)
+            if isinstance(data, (list, tuple, int, float, bool)) and dev is not None and torch.device(dev).type == "cuda":
+                key = (fn.__name__, repr(data), str(kw.get("dtype", None)), str(torch.device(dev)), repr(args))
+                if key not in self.cache:
+                    self.cache[key] = fn(data, *args, **kw)
+                return self.cache[key]
+            return fn(data, *args, **kw)
+        return cached
+
+    def __enter__(self):
+        self._saved = (torch.tensor, torch.as_tensor)
+        torch.tensor, torch.as_tensor = self._wrap(self._saved[0]), self._wrap(self._saved[1])
+        return self
+
+    def __exit__(self, *exc):
+        torch.tensor, torch.as_tensor = self._saved
+        return False
+
+
+class GraphedForward:
+    """The whole detector forward of one input signature (batch, frame size, caption batch, GEMM precision) as ONE HIP graph: at 64
+    frames the eager forward issues ~1 200 launches even after the fusions above and the GPU waits for Python between them.  The
+    inputs are copied into the graph's static buffers, the outputs (logits, boxes) are the graph's static tensors: read them
+    before the next replay of the same signature."""
+
+    def __init__(self, model: nn.Module, max_graphs: int = 4) -> None:
+        self.model, self.max_graphs = model, max_graphs
+        self.graphs: Dict = {}
+        self.consts = HostConstantCache()
+
+    def __call__(self, key, pixel_values, input_ids, attention_mask, token_type_ids):
+        key = (key, tuple(pixel_values.shape), tuple(input_ids.shape), self.model.vlfm_fast.precision)
+        g = self.graphs.get(key)
+        if g is None:
+            if len(self.graphs) >= self.max_graphs:
+                self.graphs.pop(next(iter(self.graphs)))
+            static = [t.clone() for t in (pixel_values, input_ids, attention_mask, token_type_ids)]
+
+            def run():
+                out = self.model(pixel_values=static[0], input_ids=static[1], attention_mask=static[2], token_type_ids=static[3])
+                return out.logits, out.pred_boxes
+
+            with self.consts:
+                side = torch.cuda.Stream(device=pixel_values.device)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(2):      # fills every cache (split weights, fused weights, masks, host constants) before the capture
+                        run()
+                torch.cuda.current_stream().wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    outs = run()
+            g = self.graphs[key] = (graph, static, outs)
+        graph, static, outs = g
+        for dst, src in zip(static, (pixel_values, input_ids, attention_mask, token_type_ids)):
+            dst.copy_(src, non_blocking=True)
+        graph.replay()
+        return outs

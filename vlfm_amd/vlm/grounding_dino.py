@@ -96,7 +96,8 @@ class GroundingDINO:
 
     def __init__(self, config_path: Optional[str] = None, weights_path: Optional[str] = None, caption: str = CLASSES,
                  box_threshold: float = 0.35, text_threshold: float = 0.25, device=None, model_dir: Optional[str] = None,
-                 hf_config=None, seed: int = 0, allow_random_init: bool = False, tokenizer_dir: Optional[str] = None) -> None:
+                 hf_config=None, seed: int = 0, allow_random_init: bool = False, tokenizer_dir: Optional[str] = None,
+                 fast: Optional[bool] = None, gemm_precision: Optional[str] = None, graph: Optional[bool] = None) -> None:
         from transformers import GroundingDinoConfig, GroundingDinoForObjectDetection
 
         from ..mapping.base_map import require_gpu
@@ -159,6 +160,21 @@ class GroundingDINO:
         self.hip_deform_attn = det_ops.patch_hf_deformable_attention(self.model)  # HIP MsDeformAttn
         self.gemm_convs = det_ops.patch_convs_as_gemm(self.model)   # patch-embed / 1x1 convolutions as GEMMs
         det_ops.cache_text_branch(self.model)                       # the caption is constant over an episode
+        # fused forwards on csrc/gemm_f32.hip + csrc/sam_ops.hip (vlm/gdino_fast.py).  VLFM_GDINO_FAST=0 keeps transformers' own
+        # forward; gemm_precision "split" (default) = f32-grade GEMMs from f16 operand pairs with the exact library GEMMs as the
+        # automatic fallback when an operand leaves f16's range, "library" = hipBLASLt f32 throughout; graph = replay the forward of
+        # a recurring input signature from a HIP graph
+        from . import gdino_fast
+
+        self.fast = (os.environ.get("VLFM_GDINO_FAST", "1") != "0") if fast is None else bool(fast)
+        self.gemm_precision = gemm_precision or os.environ.get("VLFM_GDINO_GEMM", "split")
+        self.fast_summary = gdino_fast.accelerate(self.model, self.gemm_precision) if self.fast else None
+        self.use_graph = self.fast and ((os.environ.get("VLFM_GDINO_GRAPH", "1") != "0") if graph is None else bool(graph))
+        self._graphed = gdino_fast.GraphedForward(self.model) if self.use_graph else None
+        self.overflow_fallbacks = 0
+        if self.fast:
+            self.description += (f"; fused MI355X forward (vlm/gdino_fast.py), f32 GEMMs: {self.gemm_precision}"
+                                 + (", HIP-graph replay" if self.use_graph else ""))
 
     @torch.inference_mode()
     def predict_batch(self, images_u8: torch.Tensor, captions: Sequence[str]) -> List[ObjectDetections]:
@@ -175,11 +191,37 @@ class GroundingDINO:
             mask[b, : len(i)] = 1
         pix = det_ops.to_tensor_normalize(images_u8)
         self.model.vlfm_text_key = tuple(caps)   # the BERT branch is memoised per caption batch (det_ops.cache_text_branch)
-        out = self.model(pixel_values=pix, input_ids=input_ids.to(self.device), attention_mask=mask.to(self.device),
-                         token_type_ids=torch.zeros_like(input_ids).to(self.device))
-        probs = out.logits.sigmoid().float().cpu().numpy()     # [B, nq, max_text_len]
-        boxes = out.pred_boxes.float().cpu().numpy()            # [B, nq, 4] normalised cxcywh
+        logits, pred_boxes = self._forward(pix, input_ids.to(self.device), mask.to(self.device), tuple(caps))
+        probs = logits.sigmoid().float().cpu().numpy()      # [B, nq, max_text_len]
+        boxes = pred_boxes.float().cpu().numpy()            # [B, nq, 4] normalised cxcywh
+        if self.fast and self.model.vlfm_fast.precision == "split":
+            from . import ops
+
+            flag = ops.gemm_f32_overflow_flag(self.device)
+            if int(flag.item()):     # (the copies above already synchronised) an operand left f16's range: the split results are void
+                flag.zero_()
+                self.overflow_fallbacks += 1
+                self.model.vlfm_fast.precision = "library"
+                try:
+                    logits, pred_boxes = self._forward(pix, input_ids.to(self.device), mask.to(self.device), tuple(caps))
+                    probs, boxes = logits.sigmoid().float().cpu().numpy(), pred_boxes.float().cpu().numpy()
+                finally:
+                    self.model.vlfm_fast.precision = "split"
         return [self._detections(probs[b], boxes[b], ids[b], raw[b]) for b in range(B)]
+
+    def _forward(self, pix: torch.Tensor, input_ids: torch.Tensor, mask: torch.Tensor, key):
+        tt = torch.zeros_like(input_ids)
+        if self._graphed is not None:
+            try:
+                return self._graphed(key, pix, input_ids, mask, tt)
+            except Exception as exc:  # noqa: BLE001 -- a capture that the runtime refuses must not take the detector down
+                import warnings
+
+                warnings.warn(f"GroundingDINO: HIP-graph capture failed ({type(exc).__name__}: {exc}); running eagerly from now on")
+                self._graphed, self.use_graph = None, False
+                torch.cuda.synchronize(self.device)
+        out = self.model(pixel_values=pix, input_ids=input_ids, attention_mask=mask, token_type_ids=tt)
+        return out.logits, out.pred_boxes
 
     def _detections(self, probs: np.ndarray, boxes: np.ndarray, ids: Sequence[int], raw_caption: str) -> ObjectDetections:
         """groundingdino.util.inference.predict's post-processing [ext] + grounding_dino.py:70-72 for one image: queries whose best

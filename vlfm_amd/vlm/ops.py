@@ -187,10 +187,12 @@ def depthwise_conv3x3(x: torch.Tensor, weight: torch.Tensor, bias, stride: int =
     return y
 
 
-def layernorm_rows(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float, window: int = 0) -> torch.Tensor:
+def layernorm_rows(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float, window: int = 0, shift: int = 0,
+                   pad_zero: bool = False) -> torch.Tensor:
     """LayerNorm over the channels of a contiguous f32 [B, H, W, C] tensor (csrc/sam_ops.hip).  ``window == 0``: same shape.
     ``window > 0``: TinyViTBlock's pad + window partition + ``attn.norm`` in one pass -> [B * nWy * nWx, window^2, C], the rows
-    of the zero-padded image in window order (padded positions hold LayerNorm(0) = bias, as in the reference)."""
+    of the zero-padded image in window order (padded positions hold LayerNorm(0) = bias, as in the reference).  ``shift`` /
+    ``pad_zero``: Swin's form -- norm, zero padding AFTER the norm, roll by -shift, partition (SwinLayer.forward [ext])."""
     assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
     B, H, W, C = x.shape
     assert weight.dtype == torch.float32 and bias.dtype == torch.float32 and weight.numel() == C == bias.numel()
@@ -199,20 +201,21 @@ def layernorm_rows(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, ep
         out = torch.empty((B * nwy * nwx, window * window, C), dtype=torch.float32, device=x.device)
     else:
         out = torch.empty_like(x)
-    _lib.check(_lib.lib().vlfm_layernorm_rows_f32(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, W, C,
-                                                  int(window), float(eps), _stream()), "layernorm_rows_f32")
+    _lib.check(_lib.lib().vlfm_layernorm_rows_shifted_f32(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, W, C,
+                                                          int(window), float(eps), int(shift), int(pad_zero), _stream()),
+               "layernorm_rows_f32")
     return out
 
 
-def window_reverse_add_(x: torch.Tensor, windows: torch.Tensor, window: int) -> torch.Tensor:
+def window_reverse_add_(x: torch.Tensor, windows: torch.Tensor, window: int, shift: int = 0) -> torch.Tensor:
     """In place: x[b, y, x] += windows[row of (b, y, x) in window order] -- TinyViTBlock's window reverse + crop + residual add
     (csrc/sam_ops.hip).  x [B, H, W, C] f32 contiguous, windows [B * nWy * nWx, window^2, C]."""
     assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
     B, H, W, C = x.shape
     nwy, nwx = (H + window - 1) // window, (W + window - 1) // window
     assert windows.is_contiguous() and windows.dtype == torch.float32 and windows.numel() == B * nwy * nwx * window * window * C
-    _lib.check(_lib.lib().vlfm_window_reverse_add_f32(x.data_ptr(), windows.data_ptr(), B, H, W, C, int(window), _stream()),
-               "window_reverse_add_f32")
+    _lib.check(_lib.lib().vlfm_window_reverse_add_shifted_f32(x.data_ptr(), windows.data_ptr(), B, H, W, C, int(window), int(shift),
+                                                              _stream()), "window_reverse_add_f32")
     return x
 
 
@@ -228,7 +231,7 @@ def depthwise_conv3x3_nhwc(x: torch.Tensor, w9c: torch.Tensor, bias) -> torch.Te
     return out
 
 
-def window_attention(qkv: torch.Tensor, bias_t: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
+def window_attention(qkv: torch.Tensor, bias_t: torch.Tensor, heads: int, scale: float, mask_t=None) -> torch.Tensor:
     """TinyViT's window attention (head width 32) in one kernel (csrc/sam_ops.hip): ``qkv`` [windows, tokens, heads * 96] f32 as the
     qkv Linear emits it (per head q | k | v), ``bias_t`` [heads, tokens, tokens] the additive bias transposed over its last two
     dimensions; returns softmax(scale * q k^T + bias) v as [windows, tokens, heads * 32]."""
@@ -236,8 +239,15 @@ def window_attention(qkv: torch.Tensor, bias_t: torch.Tensor, heads: int, scale:
     nw, n, _ = qkv.shape
     assert bias_t.shape == (heads, n, n) and bias_t.is_contiguous() and bias_t.dtype == torch.float32 and n <= 256
     out = torch.empty((nw, n, heads * 32), dtype=torch.float32, device=qkv.device)
-    _lib.check(_lib.lib().vlfm_window_attention_f32(qkv.data_ptr(), bias_t.data_ptr(), out.data_ptr(), nw, n, heads, float(scale),
-                                                    _stream()), "window_attention_f32")
+    per_image = 1
+    if mask_t is not None:   # Swin's shifted-window mask [windows per image, tokens, tokens] (symmetric)
+        assert mask_t.dim() == 3 and mask_t.shape[1:] == (n, n) and mask_t.is_contiguous() and mask_t.dtype == torch.float32
+        per_image = mask_t.shape[0]
+        assert nw % per_image == 0
+    _lib.check(_lib.lib().vlfm_window_attention_masked_f32(qkv.data_ptr(), bias_t.data_ptr(),
+                                                           mask_t.data_ptr() if mask_t is not None else None, per_image,
+                                                           out.data_ptr(), nw, n, heads, float(scale), _stream()),
+               "window_attention_f32")
     return out
 
 
@@ -285,6 +295,15 @@ def gemm_f32_overflow_flag(device) -> torch.Tensor:
     return _overflow_flags[key]
 
 
+def tensor_version(t: torch.Tensor) -> int:
+    """``t._version``, or 0 for a tensor created under ``torch.inference_mode()`` (those do not track in-place updates -- and cannot
+    be updated in place outside inference mode either)."""
+    try:
+        return t._version
+    except RuntimeError:
+        return 0
+
+
 def split_weight(weight: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """(hi, lo') f16 planes of an f32 weight: hi = f16(w), lo' = f16((w - hi) 2^11).  Memoised per tensor OBJECT (a weak reference
     proves it is still the same tensor: an address alone is reused by the allocator) and per ``_version`` (in-place updates)."""
@@ -292,7 +311,7 @@ def split_weight(weight: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
 
     key = id(weight)
     hit = _split_cache.get(key)
-    if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr():
+    if hit is not None and hit[0]() is weight and hit[1] == tensor_version(weight) and hit[2] == weight.data_ptr():
         return hit[3], hit[4]
     if len(_split_cache) > 2048:
         for k in [k for k, v in _split_cache.items() if v[0]() is None]:
@@ -302,7 +321,7 @@ def split_weight(weight: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     lo = torch.empty_like(hi)
     _lib.check(_lib.lib().vlfm_split_f32_to_f16_pair(w.data_ptr(), hi.data_ptr(), lo.data_ptr(), w.numel(),
                                                      gemm_f32_overflow_flag(w.device).data_ptr(), _stream()), "split_f32")
-    _split_cache[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), hi, lo)
+    _split_cache[key] = (weakref.ref(weight), tensor_version(weight), weight.data_ptr(), hi, lo)
     return hi, lo
 
 

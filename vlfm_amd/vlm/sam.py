@@ -106,7 +106,7 @@ class _WindowAttention(nn.Module):
         b, n, c = x.shape
         if x.is_cuda and x.dtype == torch.float32 and self.kd == 32 and n <= 256 and not torch.is_grad_enabled():
             # one kernel per block: a lane per query, the window's key / value rows through scalar loads (csrc/sam_ops.hip)
-            key = (str(x.device), self.attention_biases._version, self.attention_biases.data_ptr())
+            key = (str(x.device), ops.tensor_version(self.attention_biases), self.attention_biases.data_ptr())
             if getattr(self, "_bias_t", (None,))[0] != key:
                 bias = self.attention_biases[:, self.attention_bias_idxs].detach().to(torch.float32)
                 self._bias_t = (key, bias.transpose(1, 2).contiguous())
@@ -166,7 +166,7 @@ class _TinyViTBlock(nn.Module):
         a = self.attn(ops.layernorm_rows(t, self.attn.norm.weight, self.attn.norm.bias, self.attn.norm.eps, ws), normed=True)
         ops.window_reverse_add_(t, a.contiguous(), ws)
         lc = self.local_conv
-        key = (str(t.device), lc.c.weight._version, lc.c.weight.data_ptr())   # a weight reload must not meet a stale repack
+        key = (str(t.device), ops.tensor_version(lc.c.weight), lc.c.weight.data_ptr())   # a weight reload must not meet a stale repack
         if getattr(self, "_w9c", (None,))[0] != key:
             self._w9c = (key, lc.c.weight.detach().reshape(c, 9).t().contiguous())
         t = ops.depthwise_conv3x3_nhwc(t, self._w9c[1], lc.bn.bias)
