@@ -765,6 +765,7 @@ def side_legs(args, sim, device, common):
                                pointnav=WrappedPointNavResNetPolicy(None, device=device, n_envs=n_envs,
                                                                     discrete_actions=True), **common)
         full.fast_forward(min(args.preroll, 40))
+        full.warm_up_segmenter()       # (every batch size the segmenter can meet, before the clock starts)
         for k_ in list(full.object_stats):
             full.object_stats[k_] = {m: 0 for m in full.object_stats[k_]} if isinstance(full.object_stats[k_], dict) else 0
         conv_launches = int(getattr(detector, "hip_convs", 0))

@@ -198,7 +198,8 @@ def test_fold_batchnorm_is_the_same_function():
 
 
 def test_grounding_dino_postprocessing_equals_the_per_query_loop():
-    """GroundingDINO._detections (array operations + one decode per distinct token set) against the upstream per-query loop
+    """GroundingDINO._postprocess_device + _detections (reductions where the logits are, token sets as bit patterns, one decode per
+    distinct token set) against the upstream per-query loop
     (groundingdino.util.inference.predict [ext] + grounding_dino.py:70-72) on random probabilities: few, many and no queries
     above the box threshold."""
     from vlfm_amd.vlm.grounding_dino import GroundingDINO, WordTokenizer, preprocess_caption
@@ -208,6 +209,7 @@ def test_grounding_dino_postprocessing_equals_the_per_query_loop():
             wt = WordTokenizer(30522, 256)
             self.tokenizer, self.decode = wt, wt.decode
             self.box_threshold, self.text_threshold = 0.35, 0.25
+            self.device, self._phrase_cache = torch.device("cpu"), {}
 
     g = Stub()
     raw = "chair . bed . potted plant . toilet . tv . couch ."
@@ -229,7 +231,10 @@ def test_grounding_dino_postprocessing_equals_the_per_query_loop():
 
     for seed, power, nq in ((0, 3, 300), (1, 1, 120), (2, 8, 300), (3, 60, 200)):
         rng = np.random.default_rng(seed)
-        probs = rng.uniform(size=(nq, 256)).astype(np.float32) ** power
+        want = np.clip(rng.uniform(size=(nq, 256)) ** power, 1e-6, 1 - 1e-6)
+        logits = torch.from_numpy(np.log(want / (1 - want)).astype(np.float32))
+        probs = logits.sigmoid().float().numpy()          # what the device path thresholds: sigmoid of the f32 logits
         boxes = rng.uniform(size=(nq, 4)).astype(np.float32)
-        a, b = loop(probs, boxes), g._detections(probs, boxes, ids, raw)
+        best, bx, bits = g._postprocess_device(logits[None], torch.from_numpy(boxes)[None], [ids])
+        a, b = loop(probs, boxes), g._detections(best[0], bx[0], bits[0], ids, raw)
         assert a.phrases == b.phrases and torch.equal(a.boxes, b.boxes) and torch.equal(a.logits, b.logits)

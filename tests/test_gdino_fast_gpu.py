@@ -61,19 +61,31 @@ def test_fused_forward_equals_the_hf_forward_at_full_geometry(gpu_device):
         res = {}
         for prec in ("library", "split"):
             fused.model.vlfm_fast.precision = prec
-            ops.gemm_f32_overflow_flag(gpu_device).zero_()
+            ops.gemm_f32_overflow_flag(gpu_device, "gdino").zero_()
             out = fused.model(**kw)
             torch.cuda.synchronize()
-            assert int(ops.gemm_f32_overflow_flag(gpu_device).item()) == 0
+            assert int(ops.gemm_f32_overflow_flag(gpu_device, "gdino").item()) == 0
             res[prec] = (out.logits.clone(), out.pred_boxes.clone())
-            db = float((out.pred_boxes - want.pred_boxes).abs().max())
+            # everything in front of the two-stage query selection: strict
+            for name in ("encoder_last_hidden_state_vision", "encoder_last_hidden_state_text", "enc_outputs_class",
+                         "enc_outputs_coord_logits"):
+                a, b = getattr(out, name), getattr(want, name)
+                ok = torch.isfinite(b)
+                assert bool((torch.isfinite(a) == ok).all()), (prec, name)
+                err, scale = float((a[ok] - b[ok]).abs().max()), float(b[ok].abs().max())
+                assert err <= 1e-3 * max(scale, 1.0), (prec, name, err, scale)
+            # behind it: the decoder starts from the 900 best of 6380 proposals; with random weights the scores at the cut are a
+            # few 1e-6 apart, so an f32-roundoff-level difference can swap a proposal in or out, and THAT query then differs
+            # completely.  Queries fed the same proposal must agree to the usual bar; nearly all must be such queries.
             fin = torch.isfinite(want.logits)
             assert bool((torch.isfinite(out.logits) == fin).all())
-            dp = float((out.logits[fin].sigmoid() - want.logits[fin].sigmoid()).abs().max())
-            assert db <= 2e-3 and dp <= 2e-3, (prec, db, dp)
-        # the split form against the library form of the SAME fused graph: f32-grade
-        d = float((res["split"][1] - res["library"][1]).abs().max())
-        assert d <= 5e-4, d
+            dq = (out.pred_boxes - want.pred_boxes).abs().amax(dim=2)                                     # [B, nq]
+            dpq = torch.where(fin, (out.logits.sigmoid() - want.logits.sigmoid()).abs(), torch.zeros_like(want.logits)).amax(dim=2)
+            same = (dq <= 2e-3) & (dpq <= 2e-3)
+            assert float(same.float().mean()) >= 0.97, (prec, float(same.float().mean()), float(dq.max()), float(dpq.max()))
+        # the split form against the library form of the SAME fused graph: f32-grade (same-proposal queries)
+        d = (res["split"][1] - res["library"][1]).abs().amax(dim=2)
+        assert float((d <= 5e-4).float().mean()) >= 0.97, float(d.max())
     # the product path: predict_batch (HIP-graph replay) == the same forward run eagerly, twice in a row
     fused.model.vlfm_fast.precision = "split"
     fused.box_threshold = fused.text_threshold = 0.0
@@ -145,3 +157,40 @@ def test_fused_deformable_attention_equals_the_module(gpu_device, coords, querie
                 got = m2.forward(residual=resid, **kw)[0]
                 err = float((got - want).abs().max())
                 assert err <= 2e-4 * float(want.abs().max()), (prec, fused, err)
+
+
+def test_reassociated_fusion_layer_equals_the_module(gpu_device):
+    """GroundingDinoFusionLayer [ext] against its re-associated form (text pushed through the vision-side weights) at the encoder's real
+    sizes: 6380 vision tokens, a 15-token caption with padding in one batch entry."""
+    import copy
+
+    from transformers import GroundingDinoConfig
+    from transformers.models.grounding_dino.modeling_grounding_dino import GroundingDinoFusionLayer
+
+    from vlfm_amd.vlm import gdino_fast
+
+    torch.manual_seed(21)
+    layer = GroundingDinoFusionLayer(GroundingDinoConfig()).eval().to(gpu_device)
+    with torch.no_grad():
+        layer.vision_param.fill_(0.3)
+        layer.text_param.fill_(0.2)
+        for p in layer.attn.parameters():
+            p.normal_(0, 0.05)
+    fused = copy.deepcopy(layer)
+    st = gdino_fast._State()
+    assert gdino_fast.patch_fusion(torch.nn.ModuleList([fused]), st) == 1
+    B, Lv, Lt = 3, 6380, 15
+    v = torch.randn(B, Lv, 256, device=gpu_device)
+    t = torch.randn(B, Lt, 256, device=gpu_device)
+    mt = torch.zeros(B, Lt, dtype=torch.bool, device=gpu_device)
+    mt[1, 11:] = True
+    mv = torch.zeros(B, Lv, dtype=torch.bool, device=gpu_device)
+    with torch.inference_mode():
+        (v0, pv0), (t0, pt0) = layer(v, t, attention_mask_vision=mv, attention_mask_text=mt)
+        for prec in ("library", "split"):
+            st.precision = prec
+            (v1, pv1), (t1, pt1) = fused.forward(v, t, attention_mask_vision=mv, attention_mask_text=mt)
+            errs = {"vision": float((v0 - v1).abs().max()), "text": float((t0 - t1).abs().max()),
+                    "p_vision": float((pv0 - pv1).abs().max()), "p_text": float((pt0 - pt1).abs().max())}
+            assert errs["vision"] <= 2e-5 * float(v0.abs().max()) and errs["text"] <= 2e-5 * float(t0.abs().max()), (prec, errs)
+            assert errs["p_vision"] <= 1e-5 and errs["p_text"] <= 1e-5, (prec, errs)

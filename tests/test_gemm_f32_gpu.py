@@ -11,7 +11,9 @@ pytestmark = pytest.mark.gpu
 
 # (M, N, K): Swin stage 1 qkv / mlp, stage 3 mlp, encoder FFN, fusion projection, decoder, ragged tails
 SHAPES = [(4096, 96, 96), (4096, 384, 96), (2500, 96, 384), (1200, 1536, 384), (3000, 2048, 256), (3000, 256, 2048),
-          (6380, 1024, 256), (900, 256, 256), (777, 132, 64), (130, 36, 32)]
+          (6380, 1024, 256), (900, 256, 256), (777, 132, 64), (130, 36, 32),
+          # the split form's 256-wide tile (N % 256 == 0 or N >= 640): full tiles, an n tail inside a wide tile, an m tail
+          (1000, 768, 192), (515, 2304, 96), (2049, 640, 64), (300, 1152, 384)]
 
 
 def _err(got, ref64, scale):

@@ -233,7 +233,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_exact_kernel(Args a, int act)
 constexpr int SROWB = TK * 2;          // 64-byte rows
 constexpr int SOPER = TB * SROWB;      // 8 KB
 constexpr int SBUF = 4 * SOPER;        // 32 KB
-constexpr int LDS_SPLIT = 4 * EPI_WAVE > 2 * SBUF ? 4 * EPI_WAVE : 2 * SBUF;
 
 __device__ inline int sslot(int row, int slot) { return (slot ^ ((row >> 2) & 3)) << 4; }
 
@@ -248,7 +247,22 @@ __device__ inline void split4(const floatx4 v, half4& hi, half4& lo, bool& over)
     }
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(Args a, int act) {
+// NI = 32-row MFMA tiles of W per wavefront: 2 -> the 128 (n) x 128 (m) workgroup tile above, two workgroups per CU;
+// 4 -> a 256 (n) x 128 (m) tile (wavefronts of 128 x 64 = 4 x 2 MFMA tiles, 256 accumulator registers, ONE workgroup per CU): every
+// X tile is converted and staged for twice as many MFMAs (the conversion of X is repeated by every workgroup along n), and a k-step's
+// 12 fragment reads feed 24 MFMAs instead of 8 feeding 12 -- the LDS read rate, not the matrix pipe, bounds the small tile.
+template <int NI>
+struct SplitGeom {
+    static constexpr int TN = 64 * NI;               // workgroup tile along n (two wavefronts)
+    static constexpr int WOPER = TN * SROWB;         // bytes of one W plane tile
+    static constexpr int XO = 0, WO = 2 * SOPER;     // X hi | X lo | W hi | W lo
+    static constexpr int BUF = 2 * SOPER + 2 * WOPER;
+    static constexpr int LDS = 4 * EPI_WAVE > 2 * BUF ? 4 * EPI_WAVE : 2 * BUF;
+};
+
+template <int NI>
+__device__ __forceinline__ void gemm_f32_split_body(const Args& a, int act) {
+    using G = SplitGeom<NI>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     lds_ptr lds = (lds_ptr)smem;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -256,12 +270,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(Args a, int act)
     const int wn = wave >> 1, wm = wave & 1;
     int tm, tn;
     tile_of_block(a, tm, tn);
-    const int m0 = tm * TB, n0 = tn * TB;
+    const int m0 = tm * TB, n0 = tn * G::TN;
     const int NT = a.K / TK;
 
-    floatx16 acc[2][2], crs[2][2];
+    floatx16 acc[NI][2], crs[NI][2];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < NI; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -286,23 +300,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(Args a, int act)
             half4 hi, lo;
             split4(xr[u], hi, lo, over);
             const int off = r * SROWB + sslot(r, pc >> 1) + (pc & 1) * 8;
-            *reinterpret_cast<half4*>(smem + buf + off) = hi;
-            *reinterpret_cast<half4*>(smem + buf + SOPER + off) = lo;
+            *reinterpret_cast<half4*>(smem + buf + G::XO + off) = hi;
+            *reinterpret_cast<half4*>(smem + buf + G::XO + SOPER + off) = lo;
         }
     };
-    // W hi / lo: 128 rows x 64 B each = 512 x 16 B per plane: one global_load_lds instruction covers 16 rows (4 lanes per row)
+    // W hi / lo: TN rows x 64 B per plane; one global_load_lds instruction covers 16 rows (4 lanes per row), NI per wavefront and plane
     auto stage_w = [&](int buf, int k0) {
         const int sub = lane >> 2, p = lane & 3;
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int chunk = wave * 2 + j;                 // 16 rows each
+        for (int j = 0; j < NI; j++) {
+            const int chunk = wave * NI + j;                // 16 rows each
             const int r = chunk * 16 + sub;
             const int s = p ^ ((r >> 2) & 3);
             const int rn = min(n0 + r, a.N - 1);
             const size_t g = (size_t)rn * a.K + k0 + s * 8;
-            const int dst = __builtin_amdgcn_readfirstlane(buf + 2 * SOPER + chunk * 1024);
+            const int dst = __builtin_amdgcn_readfirstlane(buf + G::WO + chunk * 1024);
             __builtin_amdgcn_global_load_lds((gbl_ptr)(a.w_hi + g), lds + dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_ptr)(a.w_lo + g), lds + dst + SOPER, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr)(a.w_lo + g), lds + dst + G::WOPER, 16, 0, 0);
         }
     };
 
@@ -316,29 +330,29 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(Args a, int act)
 
     const int r32 = lane & 31, h = lane >> 5;
     for (int t = 0; t < NT; t++) {
-        const int cur = (t & 1) * SBUF;
+        const int cur = (t & 1) * G::BUF;
         if (t + 1 < NT) {
             load_x((t + 1) * TK);
-            stage_w(cur ^ SBUF, (t + 1) * TK);
+            stage_w(cur ^ G::BUF, (t + 1) * TK);
         }
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) {
             const int s = kk * 2 + h;                      // 16 k per step: lanes 0-31 take k 0-7, lanes 32-63 k 8-15
-            half8 whi[2], wlo[2], xhi[2], xlo[2];
+            half8 whi[NI], wlo[NI], xhi[2], xlo[2];
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
-                const int R = wn * 64 + i * 32 + r32, o = cur + 2 * SOPER + R * SROWB + sslot(R, s);
+            for (int i = 0; i < NI; i++) {
+                const int R = wn * 32 * NI + i * 32 + r32, o = cur + G::WO + R * SROWB + sslot(R, s);
                 whi[i] = *reinterpret_cast<const half8*>(smem + o);
-                wlo[i] = *reinterpret_cast<const half8*>(smem + o + SOPER);
+                wlo[i] = *reinterpret_cast<const half8*>(smem + o + G::WOPER);
             }
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-                const int R = wm * 64 + j * 32 + r32, o = cur + R * SROWB + sslot(R, s);
+                const int R = wm * 64 + j * 32 + r32, o = cur + G::XO + R * SROWB + sslot(R, s);
                 xhi[j] = *reinterpret_cast<const half8*>(smem + o);
                 xlo[j] = *reinterpret_cast<const half8*>(smem + o + SOPER);
             }
 #pragma unroll
-            for (int i = 0; i < 2; i++)
+            for (int i = 0; i < NI; i++)
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[i], xhi[j], acc[i][j], 0, 0, 0);
@@ -346,15 +360,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(Args a, int act)
                     crs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[i], xhi[j], crs[i][j], 0, 0, 0);
                 }
         }
-        if (t + 1 < NT) put_x(cur ^ SBUF);      // (the other buffer: everybody left it before the previous barrier)
+        if (t + 1 < NT) put_x(cur ^ G::BUF);      // (the other buffer: everybody left it before the previous barrier)
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
     if (over && a.overflow) atomicOr(a.overflow, 1);
-    store_tile<true>(a, smem, acc, crs, act, wave, wn, wm, lane, m0, n0);
+    // epilogue: 64 (n) x 64 (m) per wavefront and pass through the wavefront's staging area
+#pragma unroll
+    for (int half = 0; half < NI / 2; half++)
+        store_tile<true>(a, smem, reinterpret_cast<const floatx16(&)[2][2]>(acc[2 * half]),
+                         reinterpret_cast<const floatx16(&)[2][2]>(crs[2 * half]), act, wave, 0, wm, lane, m0,
+                         n0 + wn * 32 * NI + half * 64);
 }
+
+__global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(Args a, int act) { gemm_f32_split_body<2>(a, act); }
 
 // f32 [rows][cols] -> hi / lo f16 planes (the weights, once per layer)
 __global__ void split_f32_kernel(const float* __restrict__ src, _Float16* __restrict__ hi, _Float16* __restrict__ lo, long long n,
@@ -409,9 +430,13 @@ extern "C" int vlfm_gemm_f32_nt(const float* d_x, const float* d_w, const float*
         VLFM_KLAUNCH(gemm_f32_exact_kernel, grid, block, LDS_EXACT, (hipStream_t)stream, a, activation);
         return check_launch("gemm_f32_exact_kernel");
     }
-    if (LDS_SPLIT > 64 * 1024 && !opt_split.ensure(reinterpret_cast<const void*>(gemm_f32_split_kernel), LDS_SPLIT))
+    // (a 256-wide tile with one workgroup per CU -- gemm_f32_split_body<4>, 512 registers per wavefront -- was measured and is NOT
+    // dispatched: with one wavefront per SIMD nothing covers the barrier, the X conversion and the fragment reads between the MFMA
+    // groups: 145 / 177 / 141 TFLOP/s-equivalent on the encoder FFN / Swin stage-3 MLP / 256 -> 256 shapes against 186 / 223 / 180 for
+    // two 128-wide workgroups per CU, tools/gemm_f32_probe.py, profiles/r04_gemm_f32_probe_wide_tile.txt)
+    if (SplitGeom<2>::LDS > 64 * 1024 && !opt_split.ensure(reinterpret_cast<const void*>(gemm_f32_split_kernel), SplitGeom<2>::LDS))
         return fail(VLFM_ERR_HIP, "gemm_f32_nt: cannot opt in to the LDS size");
     VLFM_TIMED("gemm_f32_split_kernel", stream);
-    VLFM_KLAUNCH(gemm_f32_split_kernel, grid, block, LDS_SPLIT, (hipStream_t)stream, a, activation);
+    VLFM_KLAUNCH(gemm_f32_split_kernel, grid, block, SplitGeom<2>::LDS, (hipStream_t)stream, a, activation);
     return check_launch("gemm_f32_split_kernel");
 }

@@ -185,6 +185,24 @@ def _split_gemm(x16: torch.Tensor, pieces, bias: torch.Tensor) -> torch.Tensor:
     return o
 
 
+QFORMER_SPLIT_MIN_ROWS = 2048     # rows (images x 32 queries) from which the Q-Former's f32 Linears go to csrc/gemm_f32.hip
+
+
+def _qlinear(x: torch.Tensor, lin_w: torch.Tensor, lin_b, act=None, residual=None) -> torch.Tensor:
+    """A Linear of the f32 Q-Former.  Large batches on the GPU: the split-precision f32 GEMM of csrc/gemm_f32.hip (operands as f16
+    pairs, f32 accumulation: f32-grade results at ~2x hipBLASLt's f32 rate, bias / exact GELU / residual in the epilogue); an operand
+    beyond f16's range raises ``ops.gemm_f32_overflow_flag`` (BLIP2ITM.check_numerics reads it).  Everything else: the framework."""
+    from . import ops
+
+    if (x.is_cuda and x.dtype == torch.float32 and lin_w.dtype == torch.float32 and not torch.is_grad_enabled()
+            and x.numel() // x.shape[-1] >= QFORMER_SPLIT_MIN_ROWS and ops.linear_f32_supported(x, lin_w)):
+        return ops.linear_f32(x, lin_w, lin_b, act=act, residual=residual, precision="split", owner="blip2")
+    y = F.linear(x, lin_w, lin_b)
+    if act == "gelu":
+        y = F.gelu(y)
+    return y if residual is None else y + residual
+
+
 class _BertAttention(nn.Module):
     def __init__(self, hidden: int, kv_hidden: int, heads: int, eps: float):
         super().__init__()
@@ -219,7 +237,7 @@ class _BertAttention(nn.Module):
         b, n, d = x.shape
         h = self.heads
         if kv_proj is not None:
-            q = self.query(x).view(b, n, h, d // h).transpose(1, 2)
+            q = _qlinear(x, self.query.weight, self.query.bias).view(b, n, h, d // h).transpose(1, 2)
             k = kv_proj[0].reshape(b, -1, h, d // h).transpose(1, 2)
             v = kv_proj[1].reshape(b, -1, h, d // h).transpose(1, 2)
         elif kv is None and x.is_cuda and not self.training:
@@ -228,7 +246,7 @@ class _BertAttention(nn.Module):
             if self._qkv_fused is None or self._qkv_fused[0].device != x.device or self._qkv_fused[0].dtype != x.dtype:
                 self._qkv_fused = (torch.cat([self.query.weight, self.key.weight, self.value.weight]).detach(),
                                    torch.cat([self.query.bias, self.key.bias, self.value.bias]).detach())
-            qkv = F.linear(x, *self._qkv_fused).view(b, n, 3, h, d // h).permute(2, 0, 3, 1, 4)
+            qkv = _qlinear(x, *self._qkv_fused).view(b, n, 3, h, d // h).permute(2, 0, 3, 1, 4)
             q, k, v = qkv[0], qkv[1], qkv[2]
         else:
             q = self.query(x).view(b, n, h, d // h).transpose(1, 2)
@@ -241,7 +259,8 @@ class _BertAttention(nn.Module):
             k = k.reshape(b, src_len, h, d // h).transpose(1, 2)
             v = v.reshape(b, src_len, h, d // h).transpose(1, 2)
         a = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
-        return self.LayerNorm(self.dense(a.transpose(1, 2).reshape(b, n, d)) + x)  # post-LN residual (BERT)
+        return self.LayerNorm(_qlinear(a.transpose(1, 2).reshape(b, n, d), self.dense.weight, self.dense.bias,
+                                       residual=x))  # post-LN residual (BERT)
 
 
 class _BertFFN(nn.Module):
@@ -252,7 +271,8 @@ class _BertFFN(nn.Module):
         self.LayerNorm = nn.LayerNorm(hidden, eps=eps)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return self.LayerNorm(self.down(F.gelu(self.up(x))) + x)
+        hid = _qlinear(x, self.up.weight, self.up.bias, act="gelu")
+        return self.LayerNorm(_qlinear(hid, self.down.weight, self.down.bias, residual=x))
 
 
 class _QFormerLayer(nn.Module):
@@ -768,6 +788,17 @@ class BLIP2ITM:
             self._proj_t = (self.model.vision_projection.weight.float().t().contiguous(),
                             self.model.vision_projection.bias.float().contiguous())
         return ops.itc_head(q, self._proj_t[0], self._proj_t[1], text)
+
+    def check_numerics(self) -> None:
+        """Raise if a split-precision f32 GEMM of the Q-Former met an operand outside f16's range since the last check (its result is
+        void).  One small D2H read: the harness calls it where it synchronises anyway (episode ends, after a timed region)."""
+        from . import ops
+
+        flag = ops.gemm_f32_overflow_flag(self.device, "blip2")
+        if int(flag.item()):
+            flag.zero_()
+            raise FloatingPointError("BLIP-2 Q-Former: an activation left f16's range inside a split-precision f32 GEMM; set "
+                                     "vlfm_amd.vlm.blip2itm.QFORMER_SPLIT_MIN_ROWS = 1 << 60 to run these layers on the library's f32 GEMMs")
 
     def cosine(self, image: np.ndarray, txt: str) -> float:
         """blip2itm.py:37-54: one RGB frame (H,W,3) u8 + prompt -> Python float."""

@@ -18,8 +18,10 @@ What this module does about it:
     rows, fc1 + GELU, fc2 + residual: 8 launches per block instead of ~45, no permute / roll / pad / contiguous copies;
   * encoder deformable layers: value / offsets+weights (one GEMM) / output projection + residual, row LayerNorms, fc1 + ReLU,
     fc2 + residual; the padding mask fill is skipped when the batch has no padding (all frames share one size);
-  * fusion layers: the two 256 -> 1024 vision projections as one GEMM (the 1/16 query scale folded into the weights: a power of
-    two, exact), the layer-scale folded into the output projection + residual epilogue, row LayerNorm.
+  * fusion layers, re-associated: the caption has ~15 tokens, so the text keys / values are pushed through the vision-side
+    projection weights once per image and the 6380 vision tokens only meet [256 x 60] and [60 x 256] matrices -- the three
+    256 <-> 1024 GEMMs over all vision tokens (a quarter of the network's matrix work), their head transposes and the 15-column
+    batched GEMMs disappear (patch_fusion).
 ``accelerate(model)`` installs everything and returns a summary; ``model.vlfm_gemm_precision`` switches the GEMM form."""
 from __future__ import annotations
 
@@ -44,7 +46,7 @@ class _State:
 def _linear(st: _State, x: torch.Tensor, lin_w: torch.Tensor, lin_b, act=None, residual=None, out=None) -> torch.Tensor:
     """act(x W^T + b) + residual on the matrix cores when the shape allows and the model runs in a fused precision; else torch."""
     if st.precision != "library" and ops.linear_f32_supported(x, lin_w):
-        return ops.linear_f32(x, lin_w, lin_b, act=act, residual=residual, precision=st.precision, out=out)
+        return ops.linear_f32(x, lin_w, lin_b, act=act, residual=residual, precision=st.precision, out=out, owner="gdino")
     y = F.linear(x, lin_w, lin_b)
     if act == "relu":
         y = torch.relu_(y)
@@ -233,51 +235,89 @@ def patch_deformable(model: nn.Module, st: _State) -> int:
 
 # ------------------------------------------------------------------------------------------------ fusion layer
 def patch_fusion(model: nn.Module, st: _State) -> int:
+    """GroundingDinoFusionLayer + GroundingDinoBiMultiHeadAttention [ext], eval mode, RE-ASSOCIATED.  The module projects every one of
+    the B x 6380 vision tokens to 1024-d queries and 1024-d values and its 1024-d attention output back to 256-d (three GEMMs of
+    0.21 TFLOP per layer at 64 frames: a quarter of the network's matrix work, plus head-transposing copies of 1.7 GB each and batched
+    GEMMs with 15 columns), although the other side of the attention is the CAPTION -- L_t ~ 15 tokens.  With x_v the normalised vision
+    token, k_t / u_t the text keys / values of head h:
+        score[v, h, t] = (W_q[h] x_v + b_q[h]) . k_t[h]       =  x_v . (W_q[h]^T k_t[h])  +  b_q[h] . k_t[h]
+        out_v[v]       = W_o concat_h(sum_t p[v, h, t] u_t[h]) =  sum_{h, t} p[v, h, t] (W_o[:, h] u_t[h])
+        out_t[t, h]    = sum_v p'[t, h, v] (W_v[h] x_v + b_v[h]) =  W_v[h] (sum_v p'[t, h, v] x_v)  +  b_v[h]
+    i.e. the text side is pushed through the vision-side weights once per image (4 x L_t vectors of 256), and the vision tokens only
+    meet [256 x 4 L_t] and [4 L_t x 256] matrices: the same function in exact arithmetic, f32 rounding in a different order (checked
+    against the module in tests/test_gdino_fast_gpu.py).  The module's global-maximum subtraction and +-50000 clamps are shifts that a
+    softmax cancels (they guard fp16 overflow, which an f32 graph does not have) and are dropped."""
     n = 0
     for mod in model.modules():
         if type(mod).__name__ != "GroundingDinoFusionLayer":
             continue
-        vcache, ocache = _Cache(), _Cache()
 
-        def forward(vision_features, text_features, attention_mask_vision=None, attention_mask_text=None, _m=mod, _vc=vcache,
-                    _oc=ocache):
-            """GroundingDinoFusionLayer.forward + GroundingDinoBiMultiHeadAttention.forward [ext], eval mode: same arithmetic with
-            the two vision projections as one GEMM (query scale = head_dim^-0.5 folded in: a power of two for the shipped
-            geometry) and the vision layer-scale folded into the output projection, which adds the residual in its epilogue."""
+        def forward(vision_features, text_features, attention_mask_vision=None, attention_mask_text=None, _m=mod):
             a = _m.attn
-            v = _ln(vision_features, _m.layer_norm_vision)
-            t = _m.layer_norm_text(text_features)
-            B, Lv, _ = v.shape
-            E, Hh, hd = a.embed_dim, a.num_heads, a.head_dim
-            wv, bv = _vc.get([a.vision_proj.weight, a.vision_proj.bias, a.values_vision_proj.weight, a.values_vision_proj.bias],
-                             lambda: (torch.cat([a.vision_proj.weight.detach() * a.scale, a.values_vision_proj.weight.detach()], 0).contiguous(),
-                                      torch.cat([a.vision_proj.bias.detach() * a.scale, a.values_vision_proj.bias.detach()], 0).contiguous()))
-            vq = _linear(st, v, wv, bv)                                                  # [B, Lv, 2E]: scaled queries | values
-            q = vq[..., :E].reshape(B, Lv, Hh, hd).transpose(1, 2).reshape(B * Hh, Lv, hd)
-            vv = vq[..., E:].reshape(B, Lv, Hh, hd).transpose(1, 2).reshape(B * Hh, Lv, hd)
-            k = a.text_proj(t).view(B, -1, Hh, hd).transpose(1, 2).reshape(B * Hh, -1, hd)
-            tv = a.values_text_proj(t).view(B, -1, Hh, hd).transpose(1, 2).reshape(B * Hh, -1, hd)
-            Lt = k.shape[1]
-            w = torch.bmm(q, k.transpose(1, 2))                                           # [B heads, Lv, Lt]
-            w = w - w.max()
-            w = torch.clamp(w, min=-50000, max=50000)
-            wt = w.transpose(1, 2)
-            wt = wt - torch.max(wt, dim=-1, keepdim=True)[0]
-            wt = torch.clamp(wt, min=-50000, max=50000)
+            v = _ln(vision_features, _m.layer_norm_vision)                          # [B, Lv, 256]
+            t = _m.layer_norm_text(text_features)                                   # [B, Lt, 256]
+            B, Lv, Cv = v.shape
+            Lt = t.shape[1]
+            Hh, hd, E = a.num_heads, a.head_dim, a.embed_dim
+            k = F.linear(t, a.text_proj.weight, a.text_proj.bias).view(B, Lt, Hh, hd)             # text keys
+            u = F.linear(t, a.values_text_proj.weight, a.values_text_proj.bias).view(B, Lt, Hh, hd)   # text values
+            Wq = (a.vision_proj.weight * a.scale).view(Hh, hd, Cv)
+            bq = (a.vision_proj.bias * a.scale).view(Hh, hd)
+            A = torch.einsum("hdc,bthd->bhtc", Wq, k).reshape(B, Hh * Lt, Cv)                      # [B, 4 Lt, 256]
+            s0 = torch.einsum("hd,bthd->bht", bq, k).reshape(B, 1, Hh * Lt)
+            S = torch.bmm(v, A.transpose(1, 2)).add_(s0).view(B, Lv, Hh, Lt)                        # scores[v, h, t]
+            # text <- vision: softmax over the vision tokens (per head and text token)
+            St = S
             if attention_mask_vision is not None and not st.no_padding:
-                wt = wt.masked_fill(attention_mask_vision[:, None, None, :].repeat(1, Hh, 1, 1).flatten(0, 1), float("-inf"))
-            wt = wt.softmax(dim=-1)
+                St = S.masked_fill(attention_mask_vision[:, :, None, None], float("-inf"))
+            Pt = torch.softmax(St, dim=1).view(B, Lv, Hh * Lt)
+            Y = torch.bmm(Pt.transpose(1, 2), v).view(B, Hh, Lt, Cv)                               # sum_v p' x_v
+            Wv = a.values_vision_proj.weight.view(Hh, hd, Cv)
+            ot = (torch.einsum("hdc,bhtc->bthd", Wv, Y) + a.values_vision_proj.bias.view(1, 1, Hh, hd)).reshape(B, Lt, E)
+            t_out = t + _m.text_param * F.linear(ot, a.out_text_proj.weight, a.out_text_proj.bias)
+            # vision <- text: softmax over the text tokens
+            Sv = S
             if attention_mask_text is not None:
-                w = w.masked_fill(attention_mask_text[:, None, None, :].repeat(1, Hh, 1, 1).flatten(0, 1), float("-inf"))
-            wv_ = w.softmax(dim=-1)
-            ov = torch.bmm(wv_, tv).view(B, Hh, Lv, hd).transpose(1, 2).reshape(B, Lv, E)
-            ot = torch.bmm(wt, vv).view(B, Hh, Lt, hd).transpose(1, 2).reshape(B, Lt, E)
-            wo, bo = _oc.get([a.out_vision_proj.weight, a.out_vision_proj.bias, _m.vision_param],
-                             lambda: ((a.out_vision_proj.weight.detach() * _m.vision_param.detach()[:, None]).contiguous(),
-                                      (a.out_vision_proj.bias.detach() * _m.vision_param.detach()).contiguous()))
-            v = _linear(st, ov, wo, bo, residual=v)                                       # v + gamma_v * out_vision_proj(.)
-            t = t + _m.text_param * a.out_text_proj(ot)
-            return (v, wv_), (t, wt)
+                Sv = S.masked_fill(attention_mask_text[:, None, None, :], float("-inf"))
+            P = torch.softmax(Sv, dim=-1)
+            Wo = (a.out_vision_proj.weight * _m.vision_param[:, None]).view(Cv, Hh, hd)            # layer scale folded in
+            Cm = torch.einsum("chd,bthd->bhtc", Wo, u) + (a.out_vision_proj.bias * _m.vision_param / Hh).view(1, 1, 1, Cv)
+            v_out = torch.baddbmm(v, P.view(B, Lv, Hh * Lt), Cm.reshape(B, Hh * Lt, Cv))          # every head's p sums to 1: bias / heads each
+            return (v_out, P.permute(0, 2, 1, 3).reshape(B * Hh, Lv, Lt)), (t_out, Pt.view(B, Lv, Hh, Lt).permute(0, 2, 3, 1).reshape(B * Hh, Lt, Lv))
+
+        mod.forward = forward
+        n += 1
+    return n
+
+
+# ------------------------------------------------------------------------------------------------ decoder / text self- and cross-attention
+def patch_mha(model: nn.Module, st: _State) -> int:
+    """GroundingDinoMultiheadAttention.forward [ext] (the decoder's 900-query self-attention and text cross-attention, the text
+    enhancer) without materialising the [B x heads, Lq, Lk] score and probability tensors (1.7 GB each for the decoder's self-attention
+    at 64 frames): projections on the shared GEMM path, softmax(q k^T / sqrt(d) + mask) v through scaled_dot_product_attention.  The
+    attention probabilities the module can return are dropped by every caller unless ``output_attentions`` is requested from the
+    model; this path returns None for them."""
+    n = 0
+    for mod in model.modules():
+        if type(mod).__name__ != "GroundingDinoMultiheadAttention":
+            continue
+        plain = mod.forward
+
+        def forward(queries, keys, values, attention_mask=None, output_attentions=False, _m=mod, _plain=plain):
+            if torch.is_grad_enabled() or not queries.is_cuda:
+                return _plain(queries, keys, values, attention_mask, output_attentions)
+            B = queries.shape[0]
+            H, hd = _m.num_attention_heads, _m.attention_head_size
+            q = _linear(st, queries, _m.query.weight, _m.query.bias).view(B, -1, H, hd).transpose(1, 2)
+            k = _linear(st, keys, _m.key.weight, _m.key.bias).view(B, -1, H, hd).transpose(1, 2)
+            v = _linear(st, values, _m.value.weight, _m.value.bias).view(B, -1, H, hd).transpose(1, 2)
+            mask = attention_mask
+            if mask is not None and mask.dtype != torch.bool:
+                mask = mask.to(q.dtype)
+            ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
+            ctx = ctx.transpose(1, 2).reshape(B, -1, _m.all_head_size)
+            out = _linear(st, ctx, _m.out_proj.weight, _m.out_proj.bias)
+            return (out, None) if output_attentions else (out,)
 
         mod.forward = forward
         n += 1
@@ -294,7 +334,7 @@ def accelerate(model: nn.Module, precision: str = "split") -> Dict[str, int]:
     assert not model.training, "fused forwards are inference-only: call model.eval() first"
     model.vlfm_fast = st
     out = {"swin_layers": patch_swin_layers(model.model.backbone, st), "deformable": patch_deformable(model, st),
-           "fusion_layers": patch_fusion(model, st), "linears": patch_linears(model, st)}
+           "fusion_layers": patch_fusion(model, st), "attention": patch_mha(model, st), "linears": patch_linears(model, st)}
     return out
 
 

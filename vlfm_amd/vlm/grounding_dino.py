@@ -172,6 +172,7 @@ class GroundingDINO:
         self.use_graph = self.fast and ((os.environ.get("VLFM_GDINO_GRAPH", "1") != "0") if graph is None else bool(graph))
         self._graphed = gdino_fast.GraphedForward(self.model) if self.use_graph else None
         self.overflow_fallbacks = 0
+        self._phrase_cache: Dict = {}
         if self.fast:
             self.description += (f"; fused MI355X forward (vlm/gdino_fast.py), f32 GEMMs: {self.gemm_precision}"
                                  + (", HIP-graph replay" if self.use_graph else ""))
@@ -192,22 +193,39 @@ class GroundingDINO:
         pix = det_ops.to_tensor_normalize(images_u8)
         self.model.vlfm_text_key = tuple(caps)   # the BERT branch is memoised per caption batch (det_ops.cache_text_branch)
         logits, pred_boxes = self._forward(pix, input_ids.to(self.device), mask.to(self.device), tuple(caps))
-        probs = logits.sigmoid().float().cpu().numpy()      # [B, nq, max_text_len]
-        boxes = pred_boxes.float().cpu().numpy()            # [B, nq, 4] normalised cxcywh
+        best, boxes, bits = self._postprocess_device(logits, pred_boxes, ids)
         if self.fast and self.model.vlfm_fast.precision == "split":
             from . import ops
 
-            flag = ops.gemm_f32_overflow_flag(self.device)
+            flag = ops.gemm_f32_overflow_flag(self.device, "gdino")
             if int(flag.item()):     # (the copies above already synchronised) an operand left f16's range: the split results are void
                 flag.zero_()
                 self.overflow_fallbacks += 1
                 self.model.vlfm_fast.precision = "library"
                 try:
                     logits, pred_boxes = self._forward(pix, input_ids.to(self.device), mask.to(self.device), tuple(caps))
-                    probs, boxes = logits.sigmoid().float().cpu().numpy(), pred_boxes.float().cpu().numpy()
+                    best, boxes, bits = self._postprocess_device(logits, pred_boxes, ids)
                 finally:
                     self.model.vlfm_fast.precision = "split"
-        return [self._detections(probs[b], boxes[b], ids[b], raw[b]) for b in range(B)]
+        return [self._detections(best[b], boxes[b], bits[b], ids[b], raw[b]) for b in range(B)]
+
+    def _postprocess_device(self, logits: torch.Tensor, pred_boxes: torch.Tensor, ids):
+        """The reductions of groundingdino.util.inference.predict [ext] where the logits are: per query the best token probability
+        and the SET of caption tokens above ``text_threshold`` as a bit pattern (bit k = token k; [CLS], [SEP] and everything behind
+        excluded, get_phrases_from_posmap [ext]).  1.3 MB cross to the host for 64 frames instead of the 59 MB probability tensor."""
+        B = logits.shape[0]
+        L = max(len(i) for i in ids)
+        if L > 62:
+            raise NotImplementedError("captions beyond 62 tokens: the token-set bit pattern no longer fits an int64")
+        probs = logits.sigmoid().float()                             # [B, nq, max_text_len]
+        best = probs.amax(dim=2)
+        pos = probs[:, :, :L] > self.text_threshold
+        valid = torch.zeros((B, L), dtype=torch.bool)
+        for b, i in enumerate(ids):
+            valid[b, 1:len(i) - 1] = True
+        pos &= valid.to(self.device)[:, None, :]
+        bits = (pos.to(torch.int64) << torch.arange(L, device=self.device)).sum(dim=2)
+        return best.cpu().numpy(), pred_boxes.float().cpu().numpy(), bits.cpu().numpy()
 
     def _forward(self, pix: torch.Tensor, input_ids: torch.Tensor, mask: torch.Tensor, key):
         tt = torch.zeros_like(input_ids)
@@ -223,29 +241,36 @@ class GroundingDINO:
         out = self.model(pixel_values=pix, input_ids=input_ids, attention_mask=mask, token_type_ids=tt)
         return out.logits, out.pred_boxes
 
-    def _detections(self, probs: np.ndarray, boxes: np.ndarray, ids: Sequence[int], raw_caption: str) -> ObjectDetections:
+    def _detections(self, best: np.ndarray, boxes: np.ndarray, bits: np.ndarray, ids: Sequence[int], raw_caption: str) -> ObjectDetections:
         """groundingdino.util.inference.predict's post-processing [ext] + grounding_dino.py:70-72 for one image: queries whose best
-        token probability exceeds box_threshold; each one's phrase = the caption tokens above text_threshold (without [CLS] /
-        [SEP] and beyond).  Array operations per image and one decode per DISTINCT token set (queries share a handful of
-        phrases): a loop over queries with tensor ops cost 0.3 s per 64-image batch whenever many queries pass the threshold."""
-        best = probs.max(axis=1)
+        token probability exceeds box_threshold; each one's phrase = the caption tokens above text_threshold (``bits``, from
+        ``_postprocess_device``).  One decode per DISTINCT token set and caption, memoised (queries share a handful of phrases, and an
+        episode keeps its caption)."""
         keep = best > self.box_threshold
-        logit, box = probs[keep], boxes[keep]
-        n = len(ids)
-        pos = logit[:, :n] > self.text_threshold
-        pos[:, 0] = False               # [CLS]
-        pos[:, n - 1:] = False          # [SEP] and beyond (get_phrases_from_posmap [ext])
-        phrases = []
-        if len(logit):
-            uniq, first, inverse = np.unique(np.packbits(pos, axis=1), axis=0, return_index=True, return_inverse=True)
-            idv = np.asarray(ids)
-            table = [self.decode(idv[np.flatnonzero(pos[r])].tolist()).replace(".", "").strip() for r in first]
-            phrases = [table[k] for k in np.asarray(inverse).reshape(-1)]
-        det = ObjectDetections(torch.from_numpy(np.ascontiguousarray(box)),
-                               torch.from_numpy(np.ascontiguousarray(best[keep])) if len(logit) else torch.zeros(0), phrases,
+        box, conf, pat = boxes[keep], best[keep], bits[keep]
+        classes = raw_caption[: -len(" .")].split(" . ")   # grounding_dino.py:70-72, literally (the caller's caption ends with " ." -- App. C9)
+        key = tuple(int(i) for i in ids)
+        table = self._phrase_cache.setdefault(key, {})
+        if len(table) > 65536:
+            table.clear()
+        idv = np.asarray(ids)
+        uniq, inv = (np.unique(pat, return_inverse=True) if len(pat) else (pat, np.zeros(0, np.int64)))
+        phr_u = []
+        for p_ in uniq.tolist():
+            ph = table.get(p_)
+            if ph is None:
+                toks = idv[[k for k in range(len(ids)) if (p_ >> k) & 1]].tolist()
+                ph = table[p_] = self.decode(toks).replace(".", "").strip()
+            phr_u.append(ph)
+        # filter_by_class (detections.py:73-80) on the distinct phrases: with hundreds of queries above the box threshold (an untrained
+        # network: all 900) the per-query Python loop was the cost of the call
+        ok_u = np.array([ph in classes for ph in phr_u], bool) if len(phr_u) else np.zeros(0, bool)
+        sel = ok_u[inv.reshape(-1)] if len(pat) else np.zeros(0, bool)
+        phrases = [phr_u[i] for i in inv.reshape(-1)[sel].tolist()]
+        det = ObjectDetections(torch.from_numpy(np.ascontiguousarray(box[sel])),
+                               torch.from_numpy(np.ascontiguousarray(conf[sel])) if sel.any() else torch.zeros(0), phrases,
                                image_source=None)
-        # grounding_dino.py:70-72, literally (assumes the caller's caption ends with " ." -- SURVEY.md App. C9)
-        det.filter_by_class(raw_caption[: -len(" .")].split(" . "))
+        det.filter_by_class(classes)       # (every phrase left is a class: kept for the reference's call sequence)
         return det
 
     def predict(self, image: np.ndarray, caption: Optional[str] = None) -> ObjectDetections:

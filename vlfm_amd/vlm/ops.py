@@ -287,9 +287,10 @@ _overflow_flags: Dict[str, torch.Tensor] = {}
 _split_cache: Dict[int, tuple] = {}
 
 
-def gemm_f32_overflow_flag(device) -> torch.Tensor:
-    """The sticky device int the split-precision GEMMs OR into when an operand leaves f16's range (one per device)."""
-    key = str(device)
+def gemm_f32_overflow_flag(device, owner: str = "") -> torch.Tensor:
+    """The sticky device int the split-precision GEMMs OR into when an operand leaves f16's range: one per device and ``owner`` (each
+    network reads and clears its own, so one network's fallback never hides another's overflow)."""
+    key = f"{device}/{owner}"
     if key not in _overflow_flags:
         _overflow_flags[key] = torch.zeros(1, dtype=torch.int32, device=device)
     return _overflow_flags[key]
@@ -304,7 +305,7 @@ def tensor_version(t: torch.Tensor) -> int:
         return 0
 
 
-def split_weight(weight: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+def split_weight(weight: torch.Tensor, owner: str = "") -> Tuple[torch.Tensor, torch.Tensor]:
     """(hi, lo') f16 planes of an f32 weight: hi = f16(w), lo' = f16((w - hi) 2^11).  Memoised per tensor OBJECT (a weak reference
     proves it is still the same tensor: an address alone is reused by the allocator) and per ``_version`` (in-place updates)."""
     import weakref
@@ -320,7 +321,7 @@ def split_weight(weight: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     hi = torch.empty(w.shape, dtype=torch.float16, device=w.device)
     lo = torch.empty_like(hi)
     _lib.check(_lib.lib().vlfm_split_f32_to_f16_pair(w.data_ptr(), hi.data_ptr(), lo.data_ptr(), w.numel(),
-                                                     gemm_f32_overflow_flag(w.device).data_ptr(), _stream()), "split_f32")
+                                                     gemm_f32_overflow_flag(w.device, owner).data_ptr(), _stream()), "split_f32")
     _split_cache[key] = (weakref.ref(weight), tensor_version(weight), weight.data_ptr(), hi, lo)
     return hi, lo
 
@@ -333,7 +334,7 @@ def linear_f32_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
 
 
 def linear_f32(x: torch.Tensor, weight: torch.Tensor, bias=None, act=None, residual=None, precision: str = "exact",
-               out=None) -> torch.Tensor:
+               out=None, owner: str = "") -> torch.Tensor:
     """act(x @ weight.T + bias) + residual for f32 tensors on the matrix cores (csrc/gemm_f32.hip); x [..., K], weight [N, K].
     precision "exact": v_mfma_f32_32x32x2_f32 (a k-ordered f32 fma chain); "split": the f16 hi/lo form (f32-grade, 5.3x the rate;
     check ``gemm_f32_overflow_flag`` at the next synchronisation point)."""
@@ -358,9 +359,9 @@ def linear_f32(x: torch.Tensor, weight: torch.Tensor, bias=None, act=None, resid
     prec = GEMM_F32_PRECISION[precision]
     hi = lo = None
     if prec == 1:
-        hi, lo = split_weight(w)
+        hi, lo = split_weight(w, owner)
     _lib.check(_lib.lib().vlfm_gemm_f32_nt(x2.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None,
                                            res.data_ptr() if res is not None else None, out.data_ptr(), M, N, K, _ACT32[act], prec,
                                            hi.data_ptr() if hi is not None else None, lo.data_ptr() if lo is not None else None,
-                                           gemm_f32_overflow_flag(x.device).data_ptr(), _stream()), "gemm_f32_nt")
+                                           gemm_f32_overflow_flag(x.device, owner).data_ptr(), _stream()), "gemm_f32_nt")
     return out.view(*lead, N)

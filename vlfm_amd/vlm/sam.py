@@ -85,6 +85,26 @@ class _PatchMerging(nn.Module):
         return self.conv3(_dwconv(self.conv2, _conv_act(self.conv1, x, True), True))
 
 
+GEMM_PRECISION = "split"     # TinyViT's f32 Linears on the rows path: "split" (csrc/gemm_f32.hip, f16 operand pairs) | "library"
+
+
+def _rows_linear(x: torch.Tensor, lin: nn.Linear, act=None, residual=None, out=None) -> torch.Tensor:
+    """A Linear of TinyViT's rows path: the split-precision f32 GEMM with bias / exact GELU / residual in its epilogue when the shape
+    allows (f32-grade results, ~2x the library's f32 rate; an operand beyond f16's range raises the "sam" overflow flag, which
+    MobileSAM.segment_bbox turns into a repeat on the library GEMMs and MobileSAM.check_numerics into an error), else the framework."""
+    if GEMM_PRECISION == "split" and ops.linear_f32_supported(x, lin.weight) and x.numel() // x.shape[-1] >= 1024:
+        return ops.linear_f32(x, lin.weight, lin.bias, act=act, residual=residual, precision="split", out=out, owner="sam")
+    y = lin(x)
+    if act == "gelu":
+        y = F.gelu(y)
+    if residual is not None:
+        y = y.add_(residual.reshape(y.shape))
+    if out is not None:
+        out.copy_(y.reshape(out.shape))
+        return out.view(y.shape)
+    return y
+
+
 class _WindowAttention(nn.Module):
     def __init__(self, dim: int, heads: int, window: int):
         super().__init__()
@@ -110,8 +130,8 @@ class _WindowAttention(nn.Module):
             if getattr(self, "_bias_t", (None,))[0] != key:
                 bias = self.attention_biases[:, self.attention_bias_idxs].detach().to(torch.float32)
                 self._bias_t = (key, bias.transpose(1, 2).contiguous())
-            a = ops.window_attention(self.qkv(x if normed else self.norm(x)), self._bias_t[1], self.heads, self.kd ** -0.5)
-            return self.proj(a)
+            a = ops.window_attention(_rows_linear(x if normed else self.norm(x), self.qkv), self._bias_t[1], self.heads, self.kd ** -0.5)
+            return _rows_linear(a, self.proj)
         q, k, v = self.qkv(x if normed else self.norm(x)).view(b, n, self.heads, 3 * self.kd).split(self.kd, dim=3)
         bias = self.attention_biases[:, self.attention_bias_idxs].unsqueeze(0).to(x.dtype)
         a = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), attn_mask=bias)
@@ -171,8 +191,10 @@ class _TinyViTBlock(nn.Module):
             self._w9c = (key, lc.c.weight.detach().reshape(c, 9).t().contiguous())
         t = ops.depthwise_conv3x3_nhwc(t, self._w9c[1], lc.bn.bias)
         m = self.mlp
-        hid = F.gelu(m.fc1(ops.layernorm_rows(t, m.norm.weight, m.norm.bias, m.norm.eps)))
-        return t.add_(m.fc2(hid))
+        hid = _rows_linear(ops.layernorm_rows(t, m.norm.weight, m.norm.bias, m.norm.eps), m.fc1, act="gelu")
+        t2 = t.view(-1, c)
+        _rows_linear(hid.view(-1, hid.shape[-1]), m.fc2, residual=t2, out=t2)      # t += fc2(hid), in the GEMM's epilogue
+        return t
 
 
 class _Stage(nn.Module):
@@ -366,10 +388,29 @@ class MobileSAM:
         m = F.interpolate(m, (H, W), mode="bilinear", align_corners=False)
         return m > self.mask_threshold
 
+    def check_numerics(self) -> None:
+        """Raise if a split-precision GEMM of the encoder met an operand outside f16's range since the last check."""
+        flag = ops.gemm_f32_overflow_flag(self.device, "sam")
+        if int(flag.item()):
+            flag.zero_()
+            raise FloatingPointError("MobileSAM: an activation left f16's range inside a split-precision f32 GEMM; set "
+                                     "vlfm_amd.vlm.sam.GEMM_PRECISION = 'library'")
+
     def segment_bbox(self, image: np.ndarray, bbox: List[int]) -> np.ndarray:
+        global GEMM_PRECISION
         img = torch.from_numpy(np.ascontiguousarray(image)).to(self.device)[None]
         box = torch.tensor(bbox, dtype=torch.float32).view(1, 1, 4)
-        return self.segment_bboxes(img, box)[0, 0].cpu().numpy()
+        mask = self.segment_bboxes(img, box)[0, 0].cpu().numpy()
+        if GEMM_PRECISION == "split":
+            flag = ops.gemm_f32_overflow_flag(self.device, "sam")
+            if int(flag.item()):          # (the copy above synchronised) void results: once more on the library's f32 GEMMs
+                flag.zero_()
+                GEMM_PRECISION = "library"
+                try:
+                    mask = self.segment_bboxes(img, box)[0, 0].cpu().numpy()
+                finally:
+                    GEMM_PRECISION = "split"
+        return mask
 
 
 class MobileSAMClient:
