@@ -13,6 +13,11 @@
 //   frontier_kernel      dilate explored 5x5, small-pocket filter, border chain of the explored region, frontier runs
 //                        and their arc-length midpoints                                         obstacle_map.py:155-169 + B3
 //
+// Synchronisation between the phases of a kernel is WORKGROUP scope everywhere (wg_sync_global, border_parallel.h): one workgroup owns
+// an environment and is its own consumer.  Round 4: the explored-selection and frontier kernels still used __threadfence() -- a
+// device-scope release, i.e. an L2 write-back -- at 17 phase boundaries; alone in the machine that costs a few microseconds, with 256
+// workgroups doing it at once the phases around global-memory hand-offs took 10 x as long (tools/phase_probe.py: window copy 4 -> 47 us,
+// offset + pick 6 -> 116 us, bad flags 14 -> 136 us at 1 -> 256 environments).
 // Dense work (dilations, masks, rasterisation, packing) is data-parallel over words/pixels; the order-dependent part
 // (Suzuki-Abe border chains) is followed by the WHOLE workgroup: successor tables + list ranking by pointer jumping
 // (border_parallel.h), with the one-lane walk of bitmap.h kept for short borders and as the fallback.  No MFMA; bit and
@@ -837,8 +842,7 @@ __global__ __launch_bounds__(1024) void explored_select_kernel(const FogParams* 
     } else {
         for (int i = tid + y_lo * stride; i < (y_hi + 1) * stride; i += nth) { traced[i] = 0u; neg[i] = 0u; }
     }
-    __threadfence();
-    __syncthreads();
+    wg_sync_global();   // (workgroup scope: the consumers are this workgroup's own wavefronts)
     VLFM_PHASE(1, 1);
     int2* pts = sc.pts + (size_t)P.env * sc.cap_pts;
     int* cstart = sc.starts + (size_t)P.env * sc.cap_contours;
@@ -861,8 +865,7 @@ __global__ __launch_bounds__(1024) void explored_select_kernel(const FogParams* 
         VLFM_STAMP(1, 2);
         const int npt = sink.n_pts < sc.cap_pts ? sink.n_pts : sc.cap_pts;
         for (int i = tid; i < npt; i += nth) { int2 q = pts[i]; q.x += w_lo * 32; q.y += y_lo; pts[i] = q; }  // -> image coords
-        __threadfence();
-        __syncthreads();
+        wg_sync_global();   // (workgroup scope: the consumers are this workgroup's own wavefronts)
     }
     if (wave == 0) {
         if (!in_lds) {
@@ -885,8 +888,7 @@ __global__ __launch_bounds__(1024) void explored_select_kernel(const FogParams* 
         if (lane == 0) { sh_i[0] = sink.n_contours; sh_i[1] = sink.overflow; sh_i[2] = chosen; }
         VLFM_STAMP(1, 3);
     }
-    __threadfence();
-    __syncthreads();
+    wg_sync_global();   // (workgroup scope: the consumers are this workgroup's own wavefronts)
     if (tid == 0) { status[0] = sh_i[1]; status[1] = sh_i[0]; status[2] = sh_i[2]; status[3] = 0; }
     VLFM_PHASE(1, 4);
     if (sh_i[1] || sh_i[0] <= 1) return;
@@ -895,8 +897,7 @@ __global__ __launch_bounds__(1024) void explored_select_kernel(const FogParams* 
     unsigned* fs = sc.fill_solid + eoff;
     unsigned* fp = sc.fill_par + eoff;
     for (int i = tid; i < S * stride; i += nth) { fs[i] = 0u; fp[i] = 0u; }
-    __threadfence();
-    __syncthreads();
+    wg_sync_global();   // (workgroup scope: the consumers are this workgroup's own wavefronts)
     LdsBitmap fb;
     fb.solid = fs; fb.parity = fp; fb.rows = S; fb.cols = S; fb.words = stride;
     const int n = clen[chosen];
@@ -905,11 +906,9 @@ __global__ __launch_bounds__(1024) void explored_select_kernel(const FogParams* 
         const int2 a = cp[i == 0 ? n - 1 : i - 1], b = cp[i];
         raster_edge(fb, (long long)a.x << XY_SHIFT, a.y, (long long)b.x << XY_SHIFT, b.y);
     }
-    __threadfence();
-    __syncthreads();
+    wg_sync_global();   // (workgroup scope: the consumers are this workgroup's own wavefronts)
     resolve_rows(fb, tid, nth);
-    __threadfence();
-    __syncthreads();
+    wg_sync_global();   // (workgroup scope: the consumers are this workgroup's own wavefronts)
     for (int i = tid; i < S * stride; i += nth) expl[i] = fs[i] & tail_mask(S, i % stride);
     if (tid == 0) status[3] = 1;
 }
@@ -1024,8 +1023,7 @@ __global__ __launch_bounds__(1024) void frontier_kernel(const FogParams* __restr
     if (tid == 0) sc.derived_dirty[P.env] = shortcut ? 0 : 1;   // the other branch may write pocket fills into explored_d
     if (!shortcut) {
         for (int i = tid; i < S * stride; i += nth) { traced[i] = 0u; neg[i] = 0u; }
-        __threadfence();
-        __syncthreads();
+        wg_sync_global();   // (workgroup scope: the consumers are this workgroup's own wavefronts)
         if (wave == 0) {
             ContourSink sink;
             sink.pts = pts; sink.start = cstart; sink.len = clen; sink.cap_pts = sc.cap_pts; sink.cap_contours = sc.cap_contours;
@@ -1034,8 +1032,7 @@ __global__ __launch_bounds__(1024) void frontier_kernel(const FogParams* __restr
             scan_external(b, traced, neg, 0, S - 1, 2, sink);
             if (lane == 0) { sh_i[1] = sink.n_contours; sh_i[2] = sink.overflow; }
         }
-        __threadfence();
-        __syncthreads();
+        wg_sync_global();   // (workgroup scope: the consumers are this workgroup's own wavefronts)
         if (sh_i[2]) { if (tid == 0) { out_n[0] = 0; out_n[1] = 1; } return; }
         const int nc = sh_i[1];
         unsigned* fs = sc.fill_solid + eoff;
@@ -1062,19 +1059,16 @@ __global__ __launch_bounds__(1024) void frontier_kernel(const FogParams* __restr
             if (!(area < sc.area_thresh)) { __syncthreads(); continue; }
             // mask = filled outline; keep it only if every covered cell is unexplored-navigable
             for (int i = tid; i < S * stride; i += nth) { fs[i] = 0u; fp[i] = 0u; }
-            __threadfence();
-            __syncthreads();
+            wg_sync_global();   // (workgroup scope: the consumers are this workgroup's own wavefronts)
             LdsBitmap fb;
             fb.solid = fs; fb.parity = fp; fb.rows = S; fb.cols = S; fb.words = stride;
             for (int i = tid; i < n; i += nth) {
                 const int2 a = cp[i == 0 ? n - 1 : i - 1], b = cp[i];
                 raster_edge(fb, (long long)a.x << XY_SHIFT, a.y, (long long)b.x << XY_SHIFT, b.y);
             }
-            __threadfence();
-            __syncthreads();
+            wg_sync_global();   // (workgroup scope: the consumers are this workgroup's own wavefronts)
             resolve_rows(fb, tid, nth);
-            __threadfence();
-            __syncthreads();
+            wg_sync_global();   // (workgroup scope: the consumers are this workgroup's own wavefronts)
             for (int i = tid; i < S * stride; i += nth) {
                 const unsigned m = fs[i] & tail_mask(S, i % stride);
                 if (m & ~un[i]) atomicOr(&sh_i[3], 1);  // covers something that is not unexplored
@@ -1083,12 +1077,10 @@ __global__ __launch_bounds__(1024) void frontier_kernel(const FogParams* __restr
             __syncthreads();
             if (sh_i[4] && !sh_i[3])
                 for (int i = tid; i < S * stride; i += nth) ed[i] |= fs[i] & tail_mask(S, i % stride);
-            __threadfence();
-            __syncthreads();
+            wg_sync_global();   // (workgroup scope: the consumers are this workgroup's own wavefronts)
         }
         for (int i = tid; i < S * stride; i += nth) { traced[i] = 0u; neg[i] = 0u; }
-        __threadfence();
-        __syncthreads();
+        wg_sync_global();   // (workgroup scope: the consumers are this workgroup's own wavefronts)
     }
     VLFM_PHASE(2, 2);
     // ---- c. border chain (CHAIN_APPROX_NONE) of the filtered explored mask
@@ -1114,9 +1106,8 @@ __global__ __launch_bounds__(1024) void frontier_kernel(const FogParams* __restr
             }
         } else if (shortcut) {  // (the other branch zeroed the whole label planes after its own scan)
             for (int i = tid + y_lo * stride; i < (y_hi + 1) * stride; i += nth) { traced[i] = 0u; neg[i] = 0u; }
-            __threadfence();
         }
-        __syncthreads();
+        wg_sync_global();
         VLFM_PHASE(2, 3);
         ContourSink sink;
         sink.pts = pts; sink.start = cstart; sink.len = clen; sink.cap_pts = sc.cap_pts; sink.cap_contours = sc.cap_contours;
@@ -1142,8 +1133,7 @@ __global__ __launch_bounds__(1024) void frontier_kernel(const FogParams* __restr
             if (lane == 0) { sh_i[5] = sink.n_contours; sh_i[6] = sink.n_pts; sh_i[7] = sink.overflow; }
         }
     }
-    __threadfence();
-    __syncthreads();
+    wg_sync_global();   // (workgroup scope: the consumers are this workgroup's own wavefronts)
     const int nc = sh_i[5], npts_all = sh_i[6];
     if (sh_i[7]) { if (tid == 0) { out_n[0] = 0; out_n[1] = 1; } return; }
     VLFM_PHASE(2, 5);
@@ -1166,8 +1156,7 @@ __global__ __launch_bounds__(1024) void frontier_kernel(const FogParams* __restr
         }
         bad[i] = any ? 0 : 1;
     }
-    __threadfence();
-    __syncthreads();
+    wg_sync_global();   // (workgroup scope: the consumers are this workgroup's own wavefronts)
     VLFM_PHASE(2, 6);
     // ---- e. frontier runs + arc-length midpoints.  Contours in OpenCV order (reverse discovery); the chain handed to
     // contour_to_frontiers is the contour rotated by one (interpolate_contour emits end points only).
@@ -1238,8 +1227,7 @@ __global__ __launch_bounds__(1024) void frontier_kernel(const FogParams* __restr
         }
         if (lane == 0) { sh_i[8] = np; sh_i[9] = overflow; }
     }
-    __threadfence();
-    __syncthreads();
+    wg_sync_global();   // (workgroup scope: the consumers are this workgroup's own wavefronts)
     VLFM_PHASE(2, 7);
     const int np = sh_i[8];
     // get_frontier_midpoint per piece.  The arc-length cumsum is sequential by definition (np.cumsum's rounding order), but
