@@ -15,7 +15,11 @@ blip2 = BLIP2ITM(device=dev, allow_random_init=True)
 det = YOLOv7(device=dev, allow_random_init=True)
 sam = MobileSAM(device=dev, allow_random_init=True)
 pn = WrappedPointNavResNetPolicy(None, device=dev, n_envs=E, discrete_actions=True)
-sim = BatchedEpisodes(E, device=dev, blip2=blip2, detector=det, sam=sam, select_frontiers=True, pointnav=pn)
+import bench
+from vlfm_amd.harness import ScriptedSightings
+sim = BatchedEpisodes(E, device=dev, blip2=blip2, detector=det, sam=sam, select_frontiers=True, pointnav=pn, object_maps=True,
+                      sightings=ScriptedSightings(**bench.SIGHTING_SCRIPT), scripted_masks=True)
+sim.warm_up_segmenter()
 sim.fast_forward(40)
 for _ in range(3): sim.step()
 rgb = sim.rgb_pool[0]
