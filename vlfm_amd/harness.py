@@ -104,11 +104,11 @@ class ScriptedSightings:
         return [(wrong, 0.93, (cx, cy, ax, ay), depth)] if (g & 1) else [(target, 0.35, (cx, cy, ax, ay), depth)]
 
 
-SAM_BATCH_BUCKETS = (1, 2, 4, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256)
+SAM_BATCH_BUCKETS = (1, 2, 3, 4, 6, 8, 10, 12, 14, 16, 20, 24, 28, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256)
 
 
 def sam_batch_bucket(n: int) -> int:
-    """The batch size the segmenter runs ``n`` boxes at: the next of a few fixed sizes (<= 50 % padding)."""
+    """The batch size the segmenter runs ``n`` boxes at: the next of a fixed set of sizes (<= 25 % padding from 4 boxes on)."""
     for b in SAM_BATCH_BUCKETS:
         if b >= n:
             return b
@@ -351,7 +351,9 @@ class BatchedEpisodes:
         per = [[] for _ in range(self.E)]
         for (e, phrase, conf, (cx, cy, ax, ay), _) in self._sightings_at(t_ep):
             per[e].append(([(cx - ax) / self.W, (cy - ay) / self.H, (cx + ax) / self.W, (cy + ay) / self.H], conf, phrase))
-        return [ObjectDetections(torch.tensor([r[0] for r in rows], dtype=torch.float32).reshape(-1, 4),
+        none = (torch.zeros((0, 4), dtype=torch.float32), torch.zeros(0, dtype=torch.float32))    # most environments, most steps
+        return [ObjectDetections(none[0], none[1], [], image_source=None, fmt="xyxy") if not rows else
+                ObjectDetections(torch.tensor([r[0] for r in rows], dtype=torch.float32).reshape(-1, 4),
                                  torch.tensor([r[1] for r in rows], dtype=torch.float32), [r[2] for r in rows],
                                  image_source=None, fmt="xyxy") for rows in per]
 

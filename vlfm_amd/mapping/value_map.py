@@ -26,7 +26,7 @@ from .base_map import BaseMap, require_gpu
 def _stream_ptr() -> int:
     import torch
 
-    return torch.cuda.current_stream().cuda_stream
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())   # (see vlm/ops.py:_stream)
 
 
 _WAIT_EVENTS: Dict[int, Any] = {}

@@ -14,7 +14,9 @@ IMAGENET_STD = (0.229, 0.224, 0.225)
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    # (the raw handle of torch's current stream on the current device: torch.cuda.current_stream() builds a Stream object and looks the
+    # device up twice -- 9 us per launch, 4.5 ms per step of a 64-environment full step)
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 _AREA_TABS: Dict[Tuple[str, int, int], Tuple[torch.Tensor, torch.Tensor, torch.Tensor, int]] = {}

@@ -17,7 +17,9 @@ _coeff_cache: Dict[Tuple[str, int, int], Tuple[torch.Tensor, torch.Tensor, int]]
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    # (the raw handle of torch's current stream on the current device: torch.cuda.current_stream() builds a Stream object and looks the
+    # device up twice -- 9 us per launch, 4.5 ms per step of a 64-environment full step)
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def resample_coeffs(in_size: int, out_size: int, bilinear: bool = False) -> Tuple[np.ndarray, np.ndarray, int]:
