@@ -90,8 +90,19 @@ def test_find_contours_external_bit_exact(gpu_device, density, method):
             assert np.array_equal(g, w.reshape(-1, 2))
 
 
-def _gpu_contours_wg(img: np.ndarray, method: int, device, cap_p: int = 1 << 14, cap_c: int = 4096):
-    """The workgroup-parallel border follower (csrc/border_parallel.h) through vlfm_find_contours_external_wg."""
+def _walk_paths(reset: bool = True):
+    """(borders from the LDS tables, -, borders walked by one lane although the LDS tables existed, planes with LDS tables)."""
+    import ctypes
+
+    out = np.zeros(4, np.int64)
+    _lib.check(_lib.lib().vlfm_walk_path_counters(ctypes.c_void_p(out.ctypes.data), int(reset)))
+    return out
+
+
+def _gpu_contours_wg(img: np.ndarray, method: int, device, cap_p: int = 1 << 14, cap_c: int = 4096, global_tables: bool = False):
+    """The workgroup-parallel border follower (csrc/border_parallel.h) through vlfm_find_contours_external_wg: tables in LDS and
+    every border ranked at once (default), or tables in global memory and one ranking per border (``global_tables``)."""
+    method = method | (0x100 if global_tables else 0)
     planes, rows, cols = img.shape
     bits = _pack(torch.from_numpy(img).to(device))
     nbytes = _lib.lib().vlfm_find_contours_wg_scratch_bytes(planes, rows, cols, cap_p)
@@ -111,6 +122,35 @@ def _gpu_contours_wg(img: np.ndarray, method: int, device, cap_p: int = 1 << 14,
         cs = [pts[p, starts[p, k]:starts[p, k] + lens[p, k]] for k in range(counts[p, 0])]
         out.append(cs[::-1])
     return out
+
+
+def _follower_states(img: np.ndarray):
+    """(border pixels, states with an id) of the LDS follower for one plane: a state = (border pixel, direction of a border-pixel
+    neighbour) from which the counter-clockwise search reaches a border pixel (csrc/border_parallel.h: v2_alloc_mask)."""
+    from scipy import ndimage
+
+    dx, dy = [1, 1, 0, -1, -1, -1, 0, 1], [0, -1, -1, -1, 0, 1, 1, 1]
+    I = np.pad(img.astype(np.uint8), 2)
+    B = (I == 1) & (ndimage.minimum_filter(I, 3) == 0)
+    n = 0
+    for y, x in zip(*np.nonzero(B)):
+        nb = [I[y + dy[d], x + dx[d]] for d in range(8)]
+        bn = [B[y + dy[d], x + dx[d]] for d in range(8)]
+        for d in range(8):
+            if bn[d]:
+                s = next((d + k) & 7 for k in range(1, 9) if nb[(d + k) & 7])
+                n += bool(bn[s])
+    return int(B.sum()), n
+
+
+def _lds_tables_fit(plane: np.ndarray) -> bool:
+    """Does the follower keep this plane's tables in LDS (158 KB minus the three padded window planes)?"""
+    rows, cols = plane.shape
+    plane_words = (rows + 2) * (((cols + 31) // 32 + 2) | 1)
+    nb, n = _follower_states(plane)
+    w32 = (n + 31) // 32 + 1
+    need = 4 * n + 4 * max(0, n - 2 * plane_words) + ((4 * nb + 2 * (nb + 1) + 7) & ~7) + 8 * w32
+    return n < 65535 and nb <= 65535 and need <= 158 * 1024 - 12 * plane_words
 
 
 def _structured_planes():
@@ -154,26 +194,83 @@ def test_parallel_border_follower_equals_findcontours(gpu_device, method):
     oracle/cvport.c AND against the one-lane walk, on random noise of four densities and on structured bitmaps."""
     from oracle import cv
 
-    for density in (0.02, 0.3, 0.55, 0.8):
-        rng = np.random.default_rng(int(density * 100) + method)
-        img = (rng.uniform(size=(3, 60, 90)) < density).astype(np.uint8)
-        got = _gpu_contours_wg(img, method, gpu_device)
-        serial = _gpu_contours(img, method, gpu_device)
-        for p in range(3):
-            want, _ = cv.findContours(img[p], cv.RETR_EXTERNAL, method)
-            assert len(got[p]) == len(want) == len(serial[p]), (density, p, len(got[p]), len(want))
-            for g, w, q in zip(got[p], want, serial[p]):
-                assert np.array_equal(g, w.reshape(-1, 2)) and np.array_equal(g, q)
-    img = _structured_planes()
-    got = _gpu_contours_wg(img, method, gpu_device, cap_p=1 << 15)
-    longest = 0
-    for p in range(img.shape[0]):
-        want, _ = cv.findContours(img[p], cv.RETR_EXTERNAL, method)
-        assert len(got[p]) == len(want), (p, len(got[p]), len(want))
-        for g, w in zip(got[p], want):
-            assert np.array_equal(g, w.reshape(-1, 2))
-            longest = max(longest, len(g))
-    assert longest > (500 if method == 1 else 100)   # the ranking path ran (borders closing within 16 steps are walked by one lane)
+    for global_tables in (False, True):
+        _walk_paths()
+        n_borders = n_fit = 0
+        for density in (0.02, 0.3, 0.55, 0.8):
+            rng = np.random.default_rng(int(density * 100) + method)
+            img = (rng.uniform(size=(3, 60, 90)) < density).astype(np.uint8)
+            got = _gpu_contours_wg(img, method, gpu_device, global_tables=global_tables)
+            serial = _gpu_contours(img, method, gpu_device)
+            for p in range(3):
+                want, _ = cv.findContours(img[p], cv.RETR_EXTERNAL, method)
+                assert len(got[p]) == len(want) == len(serial[p]), (density, p, len(got[p]), len(want))
+                fit = _lds_tables_fit(img[p])
+                n_fit += fit
+                n_borders += len(want) if fit else 0
+                for g, w, q in zip(got[p], want, serial[p]):
+                    assert np.array_equal(g, w.reshape(-1, 2)) and np.array_equal(g, q)
+        full = _structured_planes()
+        longest = 0
+        # the full planes (most of them too intricate for the LDS tables: the global-table form or one lane) and three crops that fit
+        for y0, y1, x0, x1 in ((0, 240, 0, 330), (0, 120, 0, 165), (60, 180, 100, 265), (120, 240, 165, 330)):
+            img = np.ascontiguousarray(full[:, y0:y1, x0:x1])
+            got = _gpu_contours_wg(img, method, gpu_device, cap_p=1 << 15, global_tables=global_tables)
+            for p in range(img.shape[0]):
+                want, _ = cv.findContours(img[p], cv.RETR_EXTERNAL, method)
+                assert len(got[p]) == len(want), (global_tables, y0, x0, p, len(got[p]), len(want))
+                fit = _lds_tables_fit(img[p])
+                n_fit += fit
+                n_borders += len(want) if fit else 0
+                for k, (g, w) in enumerate(zip(got[p], want)):
+                    assert np.array_equal(g, w.reshape(-1, 2)), (global_tables, y0, x0, p, k, len(g), len(w))
+                    longest = max(longest, len(g))
+        assert longest > (500 if method == 1 else 100)   # the ranking path ran (borders closing within 16 steps are walked by one lane)
+        from_lds, _, one_lane, planes_lds = _walk_paths()
+        if global_tables:
+            assert from_lds == 0 and planes_lds == 0
+        else:
+            # every plane whose tables fit had them in LDS, and every border of those came out of them: no start state was dead
+            # or missing
+            assert n_fit >= 20 and planes_lds == n_fit and one_lane == 0 and from_lds == n_borders, (from_lds, one_lane, planes_lds,
+                                                                                                   n_fit, n_borders)
+
+
+def test_lds_border_tables_on_explored_area_shapes(gpu_device):
+    """The shapes the map kernels trace -- a mid-episode explored area (one sprawling component, ragged outline, pillars as
+    holes, specks around it) and obstacle blobs in a fog window -- at window sizes from the fog kernel's 205 x 205 to a
+    20 m x 20 m world: LDS tables whenever they fit behind the window planes (predicted here from the state count), every border
+    of such a plane from them, same chains as cv2.findContours either way."""
+    from oracle import cv
+    from scipy import ndimage
+
+    rng = np.random.default_rng(23)
+    fitted = 0
+    for rows, cols, sigma in ((205, 205, 9), (300, 420, 14), (402, 430, 18)):
+        planes = []
+        field = ndimage.gaussian_filter(rng.uniform(size=(rows, cols)), sigma)
+        area = field > np.quantile(field, 0.45)
+        area &= ~ndimage.binary_dilation(rng.uniform(size=(rows, cols)) < 0.0004, iterations=3)       # pillars
+        area |= rng.uniform(size=(rows, cols)) < 0.0005                                                # specks
+        planes.append(area)
+        planes.append(ndimage.binary_dilation(rng.uniform(size=(rows, cols)) < 0.002, iterations=2))   # obstacle blobs
+        img = np.stack(planes).astype(np.uint8)
+        fits = [_lds_tables_fit(img[p]) for p in range(2)]
+        fitted += sum(fits)
+        for method in (1, 2):
+            _walk_paths()
+            got = _gpu_contours_wg(img, method, gpu_device, cap_p=1 << 15)
+            n_lds = 0
+            for p in range(2):
+                want, _ = cv.findContours(img[p], cv.RETR_EXTERNAL, method)
+                assert len(got[p]) == len(want), (rows, cols, method, p, len(got[p]), len(want))
+                n_lds += len(want) if fits[p] else 0
+                for g, w in zip(got[p], want):
+                    assert np.array_equal(g, w.reshape(-1, 2))
+            from_lds, _, one_lane, planes_lds = _walk_paths()
+            assert planes_lds == sum(fits) and one_lane == 0 and from_lds == n_lds, (rows, cols, method, fits, from_lds, one_lane,
+                                                                                   planes_lds, n_lds)
+    assert fitted >= 4
 
 
 def test_parallel_border_follower_falls_back_when_the_tables_do_not_fit(gpu_device):

@@ -41,7 +41,7 @@ for _ in range(20):
     f1 = np.zeros((3, 1024), np.int64); l1 = np.zeros((3, 1024), np.int64)
     _lib.lib().vlfm_debug_wg_spans(ctypes.c_void_p(f1.ctypes.data), ctypes.c_void_p(l1.ctypes.data)); spans += (l1 - f1) * 0.01
     w = np.zeros(3, np.int64); _lib.lib().vlfm_debug_walk_stats(ctypes.c_void_p(w.ctypes.data)); walk += w
-names = {0: ["cone raster", "window+masks", "obst contours", "shadow pts", "cut lines", "visible contours+pick", "fill", "dilate+OR"],
+names = {0: ["cone raster", "window+masks", "obst contours", "shadow pts", "line ends", "cut lines", "visible contours+pick", "fill", "dilate+OR"],
          1: ["window copy", "scan+walk", "offset+pick", "publish"],
          2: ["dilate5 full planes", "small-unexplored filter", "window copy", "scan+walk", "offset", "bad flags", "pieces", "midpoints"]}
 for k, nm in names.items():
@@ -53,11 +53,30 @@ print(f"border walks, all envs and scans: {walk[0] * 0.01 / n / E:.0f} us per en
       f"{walk[1] / n / E:.0f} emitted points, {walk[2] / n / E:.1f} contours per env-step")
 wc = np.zeros(16, np.int64); _lib.lib().vlfm_debug_parallel_walk_clocks(ctypes.c_void_p(wc.ctypes.data))
 dw = np.diff(wc[:8]) * 0.01
-print("parallel follower, last call of workgroup 0 (frontier kernel): " + " ".join(f"{nm}={v:.0f}us" for nm, v in zip(
-    ["count+scan", "ranks", "successors", "(scan/short walk)", "init", "ranking", "emit"], dw)),
-    f"| tables ok={wc[12]} states={wc[13]} border pixels={wc[14]}")
+if wc[12] == 2:   # the LDS-table form (border_parallel.h, round 4): stamps 0..5 of wg_build_rank_lds
+    print("LDS-table follower, last build of workgroup 0 (frontier kernel): " + " ".join(f"{nm}={v:.0f}us" for nm, v in zip(
+        ["border mask+pixel list", "states per pixel+scan", "successors+init", "ranking (all borders)", "lengths+clear labels",
+         "first search", "first border out", "further borders + last search"], np.diff(wc[:9]) * 0.01)),
+        f"| states={wc[13]} border pixels={wc[14]}")
+else:
+    print("parallel follower, last call of workgroup 0 (frontier kernel): " + " ".join(f"{nm}={v:.0f}us" for nm, v in zip(
+        ["count+scan", "ranks", "successors", "(scan/short walk)", "init", "ranking", "emit"], dw)),
+        f"| tables ok={wc[12]} states={wc[13]} border pixels={wc[14]}")
+paths = np.zeros(4, np.int64); _lib.lib().vlfm_walk_path_counters(ctypes.c_void_p(paths.ctypes.data), 0)
+print(f"borders from the LDS tables {paths[0]}, by one lane although the LDS tables existed {paths[2]}, windows with LDS tables {paths[3]} "
+      f"(since the process started: {sim.steps_done if hasattr(sim, 'steps_done') else '?'} steps x {E} envs x 4 scans)")
 print("frontier counts (frontiers, overflow, contours, chain points) env 0:", sim.obstacles.counts[0].tolist())
 st = np.zeros((E, 8), np.int32)
 ob = sim.obstacles
 _lib.lib().vlfm_obstacle_status(ctypes.c_void_p(ob.scratch.data_ptr()), ob.n_envs, ob.size, ob.CAP_PTS, ob.CAP_CONTOURS, ctypes.c_void_p(st.ctypes.data))
 print("fog status env 0 (overflow, obstacle contours, shadow lines, -) + select status (overflow, contours, chosen, refilled):", st[0].tolist())
+for k, nm in enumerate(["fog_of_war", "explored_select", "frontier"]):
+    sp = spans[k, :E] / n
+    order = np.argsort(-sp)[:6]
+    print(f"{nm}: slowest workgroups (block: us, fog+select status of the LAST step, frontier counts): " + "; ".join(
+        f"{int(b)}: {sp[b]:.0f} {st[b].tolist()} {sim.obstacles.counts[b].tolist()}" for b in order))
+    print(f"{nm}: span percentiles 50/90/99: {np.percentile(sp, 50):.0f} / {np.percentile(sp, 90):.0f} / {np.percentile(sp, 99):.0f} us")
+bb = sim.obstacles.bbox.cpu().numpy() if hasattr(sim.obstacles, "bbox") else None
+if bb is not None:
+    hh, ww = bb[:, 1] - bb[:, 0] + 1, bb[:, 3] - bb[:, 2] + 1
+    print(f"explored bounding boxes: rows {hh.min()}..{hh.max()} (mean {hh.mean():.0f}), cols {ww.min()}..{ww.max()} (mean {ww.mean():.0f})")

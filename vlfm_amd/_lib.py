@@ -170,6 +170,7 @@ def lib() -> ctypes.CDLL:
         L.vlfm_find_contours_wg_scratch_bytes.argtypes = [ci, ci, ci, ci]
         L.vlfm_find_contours_wg_scratch_bytes.restype = ctypes.c_size_t
         L.vlfm_find_contours_external_wg.argtypes = [vp, ci, ci, ci, ci, vp, ctypes.c_size_t, vp, ci, vp, vp, ci, vp, vp]
+        L.vlfm_walk_path_counters.argtypes = [vp, ci]
         L.vlfm_fog_params_host.argtypes = [vp, vp, vp, cd, cd, vp, vp, ci, vp]
         L.vlfm_obstacle_scratch_bytes.argtypes = [ci, ci, ci, ci]
         L.vlfm_obstacle_scratch_bytes.restype = ctypes.c_size_t

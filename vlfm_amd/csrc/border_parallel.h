@@ -410,37 +410,76 @@ __device__ inline bool row_next_start(const Bits& img, const unsigned* traced, c
     return true;
 }
 
+// scan_external's decision for ONE row by ONE LANE (same rule as row_next_start, the words taken left to right with the
+// entering state carried along): the first border start to the right of x_done (-1: whole row), or -1.  A row per wavefront cost
+// ~60 instructions per row and wavefront; a row per lane costs them per 64 rows.  (The callers keep the padded row stride odd,
+// so that 64 lanes reading the same word of 64 consecutive rows hit 32 different banks.)
+__device__ inline int row_next_start_lane(const Bits& img, const unsigned* traced, const unsigned* neg, int y, int x_done) {
+    const unsigned* row = img.w + (size_t)y * img.stride;
+    const unsigned* tr = traced + (size_t)y * img.stride;
+    const unsigned* ngp = neg + (size_t)y * img.stride;
+    const int words = (img.cols + 31) >> 5;
+    unsigned prev = 0u, enter = 0u;
+    for (int wi = 0; wi < words; wi++) {
+        const unsigned w = row[wi], tw = tr[wi];
+        unsigned need = w & ~((w << 1) | (prev >> 31)) & ~tw;     // run starts without a label
+        prev = w;
+        if ((need | tw) == 0u) continue;
+        const unsigned pos = tw ? (tw & ~ngp[wi]) : 0u;
+        if (need) {
+            // inside[x] = the nearest labelled bit below x (in this word, else the entering state) is positive
+            unsigned seed = pos << 1;
+            if (enter) seed |= 1u;
+            need &= ~fill_up_through(seed & ~tw, ~tw);
+            if (x_done >= 0) {
+                const int wd = x_done >> 5;
+                if (wi < wd) need = 0u;
+                else if (wi == wd) need &= ~((2u << (x_done & 31)) - 1u);
+            }
+            if (need) return wi * 32 + __builtin_ctz(need);
+        }
+        if (tw) enter = (pos >> (31 - __builtin_clz(tw))) & 1u;
+    }
+    return -1;
+}
+
+// The next border start in raster order at or after row y (right of x_done in row y itself), by the whole workgroup: one row per
+// lane (labels only change between searches, so the rows can be judged independently), the earliest hit wins.  One barrier pair
+// per search -- the block-wise, row-per-wavefront search this replaces spent 18 us on the LAST search of a 450-row window
+// (nothing left to find: 7 blocks x 3 barriers), in each of the four scans of a step.  `slot` alternates between calls
+// (sh[44], sh[45]).
+__device__ inline bool wg_next_start(const Bits& img, const unsigned* traced, const unsigned* neg, int y, int x_done, int* sh,
+                                     int slot, int& fx, int& fy) {
+    const int tid = threadIdx.x, lane = tid & 63, nth = blockDim.x;
+    int* best = &sh[44 + (slot & 1)];
+    if (tid == 0) *best = 0x7FFFFFFF;
+    __syncthreads();
+    for (int r0 = y; r0 < img.rows; r0 += nth) {
+        const int r = r0 + tid;
+        const int x = r < img.rows ? row_next_start_lane(img, traced, neg, r, r == y ? x_done : -1) : -1;
+        const unsigned long long hit = __ballot(x >= 0);
+        if (hit) {
+            if (lane == __builtin_ctzll(hit)) atomicMin(best, (r << 11) | x);
+            break;
+        }
+    }
+    __syncthreads();
+    const int v = *best;
+    if (v == 0x7FFFFFFF) return false;
+    fx = v & 2047; fy = v >> 11;
+    return true;
+}
+
 // RETR_EXTERNAL scan of a padded LDS window by the whole workgroup (all threads must call; labels zero on entry).
 // sink's counters end up identical in every thread.  sh: WG_SH_INTS ints of shared memory.
 __device__ inline void wg_scan_external(const Bits& img, unsigned* traced, unsigned* neg, int method, ContourSink& sink,
                                         WalkTables& T, int* sh) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     wg_build_walk_tables(img, traced, neg, T, sh);
-    const int nwaves = (blockDim.x + 63) >> 6;
-    constexpr int RPW = 4;               // rows per wavefront and search step
     int y = 0, x_done = -1;              // scan position (uniform)
-    for (;;) {
-        // the next start in raster order: every wavefront examines RPW rows of a block of nwaves * RPW; labels only change
-        // between searches, so the rows can be judged independently (a row costs ~0.15 us: one wavefront alone spent
-        // 115 us on a 700-row window)
-        bool found = false;
+    for (int call = 0;; call++) {
         int fx = 0, fy = 0;
-        for (int yb = y; yb < img.rows && !found; yb += nwaves * RPW) {
-            if (tid == 0) sh[40] = 0x7FFFFFFF;
-            __syncthreads();
-            for (int q = 0; q < RPW; q++) {
-                const int r = yb + wave * RPW + q;
-                int x = 0;
-                if (r < img.rows && row_next_start(img, traced, neg, r, r == y ? x_done : -1, x)) {
-                    if (lane == 0) atomicMin(&sh[40], (r << 11) | x);
-                    break;
-                }
-            }
-            __syncthreads();
-            const int v = sh[40];
-            if (v != 0x7FFFFFFF) { found = true; fx = v & 2047; fy = v >> 11; }
-            __syncthreads();
-        }
+        const bool found = wg_next_start(img, traced, neg, y, x_done, sh, call, fx, fy);
         if (!found) break;
         y = fy; x_done = fx;
         const int x = fx, yy = fy;
@@ -462,6 +501,460 @@ __device__ inline void wg_scan_external(const Bits& img, unsigned* traced, unsig
         sink.n_contours++;
         sink.n_pts += n;
         wg_sync_global();
+    }
+}
+
+
+// =====================================================================================================================
+// Round 4: the follower with ALL its tables in LDS, every border of the image ranked at once.
+//
+// What the form above costs (tools/phase_probe.py, 256 environments): ~45 us to build the tables and ~47 us to rank ONE border of a
+// mid-episode explored area -- a chain of ~40 barrier-separated passes, each a round trip through L2 because the tables live in
+// global memory, over ~5 states per border pixel of which the traced border uses one.  This form:
+//   * STATES are (border pixel p, direction d of a BORDER-pixel neighbour): a traced border only ever visits border pixels (set
+//     pixels with a clear 8-neighbour; checked on 400 000 chain points of outer and hole borders), so states entered from an
+//     interior pixel are on no border -- ~3 states per border pixel instead of ~5.3.  A state whose successor pixel is not a
+//     border pixel (walking a border the wrong way round dives into the interior: about a third of them) is not given an id at
+//     all; a state whose successor is such a state becomes a fixed point marked DEAD, and DEAD spreads backwards through the chains that end there; f stays injective everywhere else, so a state
+//     is either dead or on a genuine cycle -- a start state that is dead (it never is) sends its border to the one-lane walk.
+//   * every cycle is ranked ONCE per image, in place: word A = (jump, dist) doubles as usual, word B = (m, dm) carries the
+//     LARGEST state id in the window [i, jump) and the distance to its first occurrence; when the window has wrapped the
+//     cycle, m is the cycle's HEAD h (its largest state) and dm the distance to it (largest, so that DEAD = 0xFFFF spreads by
+//     the same rule).  A border traced from state0 is then
+//     { i : m[i] == h } in the order pos(i) = (dm[state0] - dm[i]) mod L, L = the cycle's length (kept in the head's own dm
+//     slot) -- a border costs one pass over the states, no ranking of its own (fog of war traces ~3-10 blobs per window).
+//     In-place rounds converge at least as fast as synchronous ones; a reader takes A[j] before B[j], a writer publishes B[i]
+//     before A[i] (workgroup-scope fences between), so an observed B window is never shorter than the observed A distance and
+//     the union [i, jump_i) + [jump_i, ..) stays gap-free.  The rounds end after one in which every state found its m of the
+//     round's START equal to the m it read from its jump target (possibly newer, hence larger): then m_i >= m_jump(i) held for
+//     the whole start-of-round snapshot, along the chain i -> jump -> ... the values cannot decrease, the chain ends in a
+//     periodic part whose windows tile the cycle and therefore hold its maximum, so every m was the maximum already.
+//     When the LDS has room for it, A and B are ONE 64-bit word per state (a round is then two LDS round trips and no fence).
+//   * tables: B (4 B / state), the s_back nibble (1/2), position flags of the CHAIN_APPROX_SIMPLE compaction (1/4) and
+//     6 B per border pixel sit behind the window planes in LDS; A (4 B / state) borrows the two label planes, which are all
+//     zero while the borders are ranked (no border has been traced yet) and are zeroed again afterwards -- what does not fit
+//     there (bit planes grow with the window's area, states with the outlines' length) follows B.
+// Whatever does not fit (LDS, 16-bit ids) goes through the form above, and a start state that is not in the tables or is dead through
+// the one-lane walk: same output in every case (tests/test_obstacle_prims_gpu.py).
+__device__ unsigned long long g_walk_paths[4];   // contours traced by: this form, the global-table form, one lane; images
+constexpr unsigned WALK_DEAD = 0xFFFFu;   // m of a state whose chain ends in a fixed point (ids stay below it)
+struct WalkLds {
+    unsigned* A;               // [n_lab] label planes while ranking ...
+    unsigned* Aext;            // [N - n_lab] ... and behind B what they cannot hold
+    int n_lab;
+    unsigned* B;               // [N]   m | dm << 16; head: h | L << 16
+    int* pixxy;                // [nb]  x | y << 11 | (directions with a state) << 22, raster order
+    unsigned short* pixbase;   // [nb + 1] first state of border pixel #rank; [nb] = N
+    unsigned* posflag;         // [ceil(N / 32) + 1]
+    int* posprefix;            // [ceil(N / 32) + 1]
+    unsigned long long* AB;    // [N]   packed form: A | B << 32 while ranking (then B is extracted to the front of it)
+    int N, nb, ok, packed;
+};
+
+__device__ __forceinline__ size_t walk_pix_bytes(int nb) { return ((size_t)4 * nb + (size_t)2 * (nb + 1) + 7) & ~(size_t)7; }
+__device__ __forceinline__ size_t walk_lds_bytes(int N, int nb, int n_lab) {    // the split form: A in the label planes
+    const size_t w32 = (size_t)(N + 31) / 32 + 1;
+    return (size_t)4 * N + (size_t)4 * (N > n_lab ? N - n_lab : 0) + walk_pix_bytes(nb) + 8 * w32;
+}
+__device__ __forceinline__ size_t walk_lds_bytes_packed(int N, int nb) {
+    const size_t w32 = (size_t)(N + 31) / 32 + 1;
+    return (size_t)8 * N + walk_pix_bytes(nb) + 8 * w32;
+}
+
+__device__ __forceinline__ int v2_rank_of_pixel(const WalkLds& T, int key) {   // key = x | y << 11; caller checks the hit
+    int lo = 0, hi = T.nb - 1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((T.pixxy[mid] & 0x3FFFFF) < key) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+// directions d of a border pixel's border-pixel neighbours (bnb) from which the walk goes on to a border pixel: the states that get ids
+__device__ __forceinline__ unsigned v2_alloc_mask(unsigned nbm, unsigned bnb) {
+    unsigned am = 0u, dirs = bnb;
+    const unsigned nn = nbm | (nbm << 8);
+    while (dirs) {
+        const int d = __builtin_ctz(dirs);
+        dirs &= dirs - 1;
+        const int from = (d + 1) & 7;
+        const int s = (from + __builtin_ctz((nn >> from) & 0xFFu)) & 7;
+        if ((bnb >> s) & 1u) am |= 1u << d;
+    }
+    return am;
+}
+
+// One in-place round over all states (see the header of this section); returns whether one of this lane's states is still open.
+// MODE 0: A in the label planes; 1: A split between the label planes and the arena; 2: A and B packed in 64-bit words.
+template <int U, int MODE>
+__device__ __forceinline__ bool v2_round(const WalkLds& T, int tid, int nth) {
+    const int N = T.N;
+    bool open = false;
+    if (MODE == 2) {
+        unsigned long long* const AB = T.AB;
+        for (int i0 = tid; i0 < N; i0 += U * nth) {
+            unsigned long long own[U], tgt[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) { const int i = i0 + u * nth; own[u] = i < N ? AB[i] : 0ull; }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                tgt[u] = __hip_atomic_load(&AB[(unsigned)own[u] & 0xFFFFu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const unsigned a = (unsigned)own[u], bi = (unsigned)(own[u] >> 32), aj = (unsigned)tgt[u], bj = (unsigned)(tgt[u] >> 32);
+                const unsigned mj = bj & 0xFFFFu, mi = bi & 0xFFFFu;
+                const unsigned nbw = mj > mi ? (mj | ((a & 0xFFFF0000u) + (bj & 0xFFFF0000u))) : bi;
+                const unsigned na = (aj & 0xFFFFu) | ((a & 0xFFFF0000u) + (aj & 0xFFFF0000u));
+                const int i = i0 + u * nth;
+                if (i < N) {
+                    if (mj != mi) open = true;
+                    __hip_atomic_store(&AB[i], (unsigned long long)na | ((unsigned long long)nbw << 32), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+        return open;
+    }
+    unsigned* const B = T.B;
+    unsigned* const A_lab = T.A;
+    unsigned* const A_ext = T.Aext - T.n_lab;
+    const int n_lab = T.n_lab;
+    auto A = [&](int i) -> unsigned* { return (MODE == 0 || i < n_lab) ? A_lab + i : A_ext + i; };
+    for (int i0 = tid; i0 < N; i0 += U * nth) {
+        unsigned a[U], aj[U], bi[U], bj[U], na[U], nbw[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int i = i0 + u * nth; a[u] = i < N ? *A(i) : 0u; bi[u] = i < N ? B[i] : 0u; }
+#pragma unroll
+        for (int u = 0; u < U; u++) aj[u] = __hip_atomic_load(A((int)(a[u] & 0xFFFFu)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+        for (int u = 0; u < U; u++) bj[u] = __hip_atomic_load(&B[a[u] & 0xFFFFu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const unsigned mj = bj[u] & 0xFFFFu, mi = bi[u] & 0xFFFFu;
+            nbw[u] = mj > mi ? (mj | ((a[u] & 0xFFFF0000u) + (bj[u] & 0xFFFF0000u))) : bi[u];
+            na[u] = (aj[u] & 0xFFFFu) | ((a[u] & 0xFFFF0000u) + (aj[u] & 0xFFFF0000u));
+            // my m of the round's start against the (possibly newer) m of the target
+            if (i0 + u * nth < N && mj != mi) open = true;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int i = i0 + u * nth; if (i < N) __hip_atomic_store(&B[i], nbw[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int i = i0 + u * nth; if (i < N) __hip_atomic_store(A(i), na[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    }
+    return open;
+}
+
+template <int MODE>
+__device__ __forceinline__ bool v2_round_cnt(const WalkLds& T, int cnt, int tid, int nth) {
+    // all of a lane's states in ONE batch when there are at most six of them: a batch is a chain of dependent LDS round trips,
+    // and a second, nearly empty batch doubled the round
+    if (cnt <= 1) return v2_round<1, MODE>(T, tid, nth);
+    if (cnt <= 2) return v2_round<2, MODE>(T, tid, nth);
+    if (cnt <= 3) return v2_round<3, MODE>(T, tid, nth);
+    if (cnt <= 4 || cnt == 7 || cnt == 8) return v2_round<4, MODE>(T, tid, nth);
+    if (cnt <= 5) return v2_round<5, MODE>(T, tid, nth);
+    return v2_round<6, MODE>(T, tid, nth);
+}
+
+// Tables + ranking of every cycle.  All threads; img padded, lt / ln = its two label planes (contiguous: ln == lt + plane words,
+// zero on entry, zero again on return).  T.ok = 0: nothing was changed, use the global-table form.
+__device__ inline void wg_build_rank_lds(const Bits& img, unsigned* lt, unsigned* ln, unsigned* arena, unsigned arena_bytes,
+                                         int wrows, int wwords, WalkLds& T, int* sh) {
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const unsigned* base = img.w;
+    const int pw = img.stride, W = wrows * wwords;
+    const int plane_words = (wrows + 2) * pw;
+    T.ok = 0; T.N = 0; T.nb = 0; T.n_lab = 0; T.packed = 0;
+    if (ln != lt + plane_words || arena == nullptr) return;
+    if (((unsigned)(size_t)arena & 7u) && arena_bytes >= 4u) { arena += 1; arena_bytes -= 4u; }   // the packed words are 8 bytes
+    unsigned* lab0 = lt - (pw + 1);            // the padded origin of the label planes: 2 * plane_words words
+    auto border_word = [&](int ly, int lw) -> unsigned {
+        const unsigned* r = base + ly * pw + lw;
+        auto h = [](const unsigned* q) { const unsigned c = q[0]; return c & ((c << 1) | (q[-1] >> 31)) & ((c >> 1) | (q[1] << 31)); };
+        return r[0] & ~(h(r - pw) & h(r) & h(r + pw));
+    };
+    WALK_STAMP(0);
+    // a. border mask; raster-order rank of every word's first border pixel (the per-word loops only count and copy: a word of a
+    //    horizontal outline holds 32 border pixels, and anything heavier per pixel made its lane the critical path -- 36 us per pass)
+    for (int k = tid; k < W; k += nth) { const int ly = k / wwords, lw = k - ly * wwords; lt[ly * pw + lw] = border_word(ly, lw); }
+    __syncthreads();
+    const int per = (W + nth - 1) / nth;
+    const int k0 = min(tid * per, W), k1 = min(k0 + per, W);
+    int nb = 0;
+    for (int k = k0; k < k1; k++) { const int ly = k / wwords, lw = k - ly * wwords; nb += __builtin_popcount(lt[ly * pw + lw]); }
+    int nb_ex, d_ex, nb_tot, d_tot;
+    wg_scan2(nb, 0, sh, nb_ex, d_ex, nb_tot, d_tot);
+    const size_t pix_bytes = walk_pix_bytes(nb_tot);
+    if (nb_tot > 65535 || pix_bytes > (size_t)arena_bytes) {
+        for (int k = tid; k < W; k += nth) { const int ly = k / wwords, lw = k - ly * wwords; lt[ly * pw + lw] = 0u; }
+        __syncthreads();
+        return;
+    }
+    T.nb = nb_tot;
+    T.pixxy = reinterpret_cast<int*>(arena);
+    T.pixbase = reinterpret_cast<unsigned short*>(T.pixxy + nb_tot);
+    for (int k = k0; k < k1; k++) {
+        const int ly = k / wwords, lw = k - ly * wwords;
+        ln[ly * pw + lw] = (unsigned)nb_ex;
+        nb_ex += __builtin_popcount(lt[ly * pw + lw]);
+    }
+    __syncthreads();
+    for (int k = tid; k < W; k += nth) {
+        const int ly = k / wwords, lw = k - ly * wwords;
+        unsigned bm = lt[ly * pw + lw];
+        int rank = (int)ln[ly * pw + lw];
+        while (bm) { const int bit = __builtin_ctz(bm); bm &= bm - 1; T.pixxy[rank++] = (lw * 32 + bit) | (ly << 11); }
+    }
+    __syncthreads();
+    WALK_STAMP(1);
+    // b. ONE BORDER PIXEL PER LANE from here on: the directions that get a state (bits 22..29 of the pixel's entry), their count
+    for (int r = tid; r < nb_tot; r += nth) {
+        const int xy = T.pixxy[r], x = xy & 2047, ly = xy >> 11;
+        T.pixxy[r] = xy | (int)(v2_alloc_mask(nbr8_padded(base, pw, x, ly), nbr8_padded(lt, pw, x, ly)) << 22);
+    }
+    __syncthreads();
+    const int pper = (nb_tot + nth - 1) / nth;
+    const int r0 = min(tid * pper, nb_tot), r1 = min(r0 + pper, nb_tot);
+    int ns = 0;
+    for (int r = r0; r < r1; r++) ns += __builtin_popcount(((unsigned)T.pixxy[r] >> 22) & 0xFFu);
+    int ns_ex, ns_tot;
+    wg_scan2(ns, 0, sh, ns_ex, d_ex, ns_tot, d_tot);
+    const bool packed = walk_lds_bytes_packed(ns_tot, nb_tot) <= (size_t)arena_bytes;
+    const bool fits = ns_tot < (int)WALK_DEAD && (packed || walk_lds_bytes(ns_tot, nb_tot, 2 * plane_words) <= (size_t)arena_bytes);
+    if (!fits || ns_tot == 0) {
+        for (int k = tid; k < W; k += nth) { const int ly = k / wwords, lw = k - ly * wwords; lt[ly * pw + lw] = 0u; ln[ly * pw + lw] = 0u; }
+        __syncthreads();
+        T.ok = fits;     // no states at all: every border is a single pixel (wg_emit_border_lds needs no table for those)
+        return;
+    }
+    const int N = ns_tot;
+    T.N = N;
+    T.packed = packed;
+    const int w32 = (N + 31) / 32 + 1;
+    T.B = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(arena) + pix_bytes);
+    T.AB = reinterpret_cast<unsigned long long*>(T.B);
+    T.n_lab = N < 2 * plane_words ? N : 2 * plane_words;
+    T.Aext = T.B + N;
+    T.posflag = packed ? T.B + 2 * N : T.Aext + (N - T.n_lab);
+    T.posprefix = reinterpret_cast<int*>(T.posflag + w32);
+    T.A = lab0;
+    for (int r = r0; r < r1; r++) { T.pixbase[r] = (unsigned short)ns_ex; ns_ex += __builtin_popcount(((unsigned)T.pixxy[r] >> 22) & 0xFFu); }
+    for (int i = tid; i < w32; i += nth) T.posflag[i] = 0u;
+    if (tid == 0) T.pixbase[nb_tot] = (unsigned short)N;
+    __syncthreads();
+    WALK_STAMP(2);
+    // c. successors: A = (next, 1), B = (self, 0) -- (DEAD, 0) for the fixed points.  The split form parks `next` in B first (the
+    //    label planes are still border mask and ranks) and moves it over in a second pass.
+    for (int r = tid; r < nb_tot; r += nth) {
+        const int xy = T.pixxy[r], x = xy & 2047, ly = (xy >> 11) & 2047;
+        const int sb0 = T.pixbase[r];
+        const unsigned nbm = nbr8_padded(base, pw, x, ly);
+        unsigned dirs = ((unsigned)xy >> 22) & 0xFFu;
+        int t = 0;
+        while (dirs) {
+            const int d = __builtin_ctz(dirs);
+            dirs &= dirs - 1;
+            const int from = (d + 1) & 7;
+            const int s = (from + __builtin_ctz(((nbm | (nbm << 8)) >> from) & 0xFFu)) & 7;   // a border pixel: the state has an id
+            const int id = sb0 + t;
+            const int x2 = x + code_dx(s), y2 = ly + code_dy(s), sb2 = (s + 4) & 7;
+            const int w2 = y2 * pw + (x2 >> 5);
+            const int rank2 = (int)ln[w2] + __builtin_popcount(lt[w2] & ((1u << (x2 & 31)) - 1u));
+            const unsigned am2 = ((unsigned)T.pixxy[rank2] >> 22) & 0xFFu;
+            // successor state without an id: fixed point
+            const int id2 = (am2 >> sb2) & 1u ? (int)T.pixbase[rank2] + __builtin_popcount(am2 & ((1u << sb2) - 1u)) : id;
+            if (packed) T.AB[id] = (unsigned long long)((unsigned)id2 | (1u << 16)) | ((unsigned long long)(id2 == id ? WALK_DEAD : (unsigned)id) << 32);
+            else T.B[id] = (unsigned)id2;
+            t++;
+        }
+    }
+    __syncthreads();
+    if (!packed) {
+        for (int i = tid; i < N; i += nth) {
+            const unsigned nx = T.B[i];
+            *(i < T.n_lab ? T.A + i : T.Aext + (i - T.n_lab)) = nx | (1u << 16);
+            T.B[i] = (int)nx == i ? WALK_DEAD : (unsigned)i;
+        }
+    }
+    if (tid < 3) sh[36 + tid] = 0;
+    __syncthreads();
+    WALK_STAMP(3);
+    // e. rounds, in place
+    const int cap_rounds = 33 - __builtin_clz((unsigned)N);
+    const int cnt = (N + nth - 1) / nth;
+    const int mode = packed ? 2 : (N > T.n_lab ? 1 : 0);
+    for (int r = 0; r < cap_rounds; r++) {
+        const bool open = mode == 2 ? v2_round_cnt<2>(T, cnt, tid, nth) : (mode == 1 ? v2_round_cnt<1>(T, cnt, tid, nth) : v2_round_cnt<0>(T, cnt, tid, nth));
+        if (open) sh[36 + r % 3] = 1;
+        __syncthreads();
+        const int any = sh[36 + r % 3];
+        if (tid == 0) sh[36 + (r + 2) % 3] = 0;
+        if (!any) break;
+    }
+    __syncthreads();
+    if (packed) {   // B to the front of the packed words: blocks of 8 states per lane in ascending order, read -- barrier -- write
+                    // (B[i] lands on AB[i / 2], a word of this block or an earlier one)
+        for (int i0 = 0; i0 < N; i0 += 8 * nth) {
+            unsigned hi[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int i = i0 + tid + u * nth; hi[u] = i < N ? (unsigned)(T.AB[i] >> 32) : 0u; }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int i = i0 + tid + u * nth; if (i < N) T.B[i] = hi[u]; }
+            __syncthreads();
+        }
+    }
+    WALK_STAMP(4);
+    // f. cycle lengths into the heads' dm slots; the label planes are labels again
+    unsigned* B = T.B;
+    for (int i = tid; i < N; i += nth) {
+        const unsigned w = B[i], m = w & 0xFFFFu;
+        if ((int)m != i && m != WALK_DEAD) atomicMax(&B[m], m | (((w >> 16) + 1u) << 16));
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * plane_words; i += nth) lab0[i] = 0u;
+    __syncthreads();
+    T.ok = 1;
+    WALK_STAMP(5);
+#ifdef VLFM_PHASE_TIMING
+    if ((int)blockIdx.x == g_walk_block && threadIdx.x == 0) { g_walk_clk[12] = 2; g_walk_clk[13] = N; g_walk_clk[14] = nb_tot; }
+#endif
+}
+
+// One outer border from (x0, y0) out of the ranked tables.  All threads; returns the number of emitted points (uniform), or -1
+// when the border is not in the tables (nothing was written: the caller lets one lane walk it).
+__device__ inline int wg_emit_border_lds(const Bits& img, const WalkLds& T, unsigned* traced, unsigned* neg, int x0, int y0,
+                                         int method, int2* out, int cap, int* sh) {
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const unsigned* base = img.w;
+    const int pw = img.stride;
+    const unsigned nb = nbr8_padded(base, pw, x0, y0);
+    const unsigned nb0 = nb & ~(1u << 4);
+    if (nb0 == 0u) {                                     // isolated pixel
+        if (tid == 0) {
+            const int wi = y0 * pw + (x0 >> 5);
+            const unsigned m = 1u << (x0 & 31);
+            traced[wi] |= m; neg[wi] |= m;
+            if (cap > 0) out[0] = make_int2(x0, y0);
+        }
+        __syncthreads();
+        return 1;
+    }
+    if (T.N == 0) return -1;
+    const unsigned mir = __brev(nb0) >> 24;
+    const unsigned rot = ((mir | (mir << 8)) >> 4) & 0xFFu;
+    const int s = (3 - __builtin_ctz(rot)) & 7;          // direction of i1 = s_back of state0
+    const int key0 = x0 | (y0 << 11);
+    const int r0 = v2_rank_of_pixel(T, key0);
+    if ((T.pixxy[r0] & 0x3FFFFF) != key0) return -1;
+    const unsigned am0 = ((unsigned)T.pixxy[r0] >> 22) & 0xFFu;
+    if (!((am0 >> s) & 1u)) return -1;                   // i1 is not a border pixel: cannot happen on a traced border
+    const int id0 = (int)T.pixbase[r0] + __builtin_popcount(am0 & ((1u << s) - 1u));
+    const unsigned w0 = T.B[id0];
+    if ((w0 & 0xFFFFu) == WALK_DEAD) return -1;          // the start state's chain ends in the interior: cannot happen either
+    const int h = (int)(w0 & 0xFFFFu);
+    const int d0 = id0 == h ? 0 : (int)(w0 >> 16);
+    const int L = (int)(T.B[h] >> 16);
+    if (L < 2 || d0 >= L) return -1;
+    // ---- labels and points: one BORDER PIXEL per lane and step -- its states are consecutive ids, its coordinates and the
+    // directions of its states one table entry (no search from a state back to its pixel)
+    const int pwords = (L + 31) >> 5;
+    for (int r = tid; r < T.nb; r += nth) {
+        const int xy = T.pixxy[r];
+        unsigned am = ((unsigned)xy >> 22) & 0xFFu;
+        if (!am) continue;
+        const int x = xy & 2047, y = (xy >> 11) & 2047;
+        const unsigned nbm = nbr8_padded(base, pw, x, y);
+        for (int i = T.pixbase[r]; am; am &= am - 1, i++) {
+            const unsigned w = T.B[i];
+            if ((int)(w & 0xFFFFu) != h) continue;
+            const int dm = i == h ? 0 : (int)(w >> 16);
+            int pos = d0 - dm;
+            if (pos < 0) pos += L;
+            const int sb = __builtin_ctz(am);
+            const int from = (sb + 1) & 7;
+            const int so = (from + __builtin_ctz(((nbm | (nbm << 8)) >> from) & 0xFFu)) & 7;
+            const int wi = y * pw + (x >> 5);
+            const unsigned m = 1u << (x & 31);
+            atomicOr(&traced[wi], m);
+            if ((unsigned)(so - 1) < (unsigned)sb) atomicOr(&neg[wi], m);
+            if (method == 1) { if (pos < cap) out[pos] = make_int2(x, y); }
+            else if (so != (sb ^ 4)) atomicOr(&T.posflag[pos >> 5], 1u << (pos & 31));
+        }
+    }
+    __syncthreads();
+    if (method == 1) return L;
+    // CHAIN_APPROX_SIMPLE: ordered compaction through the position flags
+    int total = 0;
+    for (int w0i = 0; w0i < pwords; w0i += nth) {        // (one pass unless the border has more than 32 768 states)
+        const int wi = w0i + tid;
+        const int c = wi < pwords ? __builtin_popcount(T.posflag[wi]) : 0;
+        int ex, dummy_ex, tot, dummy_tot;
+        wg_scan2(c, 0, sh, ex, dummy_ex, tot, dummy_tot);
+        if (wi < pwords) T.posprefix[wi] = total + ex;
+        total += tot;
+    }
+    __syncthreads();
+    for (int r = tid; r < T.nb; r += nth) {
+        const int xy = T.pixxy[r];
+        unsigned am = ((unsigned)xy >> 22) & 0xFFu;
+        for (int i = T.pixbase[r]; am; am &= am - 1, i++) {
+            const unsigned w = T.B[i];
+            if ((int)(w & 0xFFFFu) != h) continue;
+            const int dm = i == h ? 0 : (int)(w >> 16);
+            int pos = d0 - dm;
+            if (pos < 0) pos += L;
+            const unsigned fw = T.posflag[pos >> 5];
+            if (!((fw >> (pos & 31)) & 1u)) continue;
+            const int idx = T.posprefix[pos >> 5] + __builtin_popcount(fw & ((1u << (pos & 31)) - 1u));
+            if (idx < cap) out[idx] = make_int2(xy & 2047, (xy >> 11) & 2047);
+        }
+    }
+    __syncthreads();
+    for (int wi = tid; wi < pwords; wi += nth) T.posflag[wi] = 0u;
+    __syncthreads();
+    return total;
+}
+
+// wg_scan_external with the LDS tables when they fit (arena: what is left of the kernel's LDS behind the window planes)
+__device__ inline void wg_scan_external_lds(const Bits& img, unsigned* traced, unsigned* neg, int method, ContourSink& sink,
+                                            WalkTables& Tglobal, unsigned* arena, unsigned arena_bytes, int* sh) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    WalkLds T;
+    wg_build_rank_lds(img, traced, neg, arena, arena_bytes, Tglobal.wrows, Tglobal.wwords, T, sh);
+    if (!T.ok) { wg_scan_external(img, traced, neg, method, sink, Tglobal, sh); return; }
+    int y = 0, x_done = -1;
+    int n_fast = 0, n_serial = 0;
+    for (int call = 0;; call++) {
+        int fx = 0, fy = 0;
+        const bool found = wg_next_start(img, traced, neg, y, x_done, sh, call, fx, fy);
+        if (!found) break;
+        y = fy; x_done = fx;
+        const int room = sink.cap_pts - sink.n_pts > 0 ? sink.cap_pts - sink.n_pts : 0;
+        if (sink.n_contours == 0) WALK_STAMP(6);
+        int n = wg_emit_border_lds(img, T, traced, neg, fx, fy, method, sink.pts + sink.n_pts, room, sh);
+        if (sink.n_contours == 0) WALK_STAMP(7);
+        if (n < 0) {
+            if (tid == 0) sh[46] = follow_border(img, traced, neg, fx, fy, method, sink.pts + sink.n_pts, room);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            n = sh[46];
+            n_serial++;
+        } else {
+            n_fast++;
+        }
+        if (sink.n_contours < sink.cap_contours && sink.n_pts + n <= sink.cap_pts) {
+            if (tid == 0) { sink.start[sink.n_contours] = sink.n_pts; sink.len[sink.n_contours] = n; }
+        } else {
+            sink.overflow = 1;
+        }
+        sink.n_contours++;
+        sink.n_pts += n;
+        wg_sync_global();
+    }
+    WALK_STAMP(8);
+    if (tid == 0) {
+        if (n_fast) atomicAdd(&g_walk_paths[0], (unsigned long long)n_fast);
+        if (n_serial) atomicAdd(&g_walk_paths[2], (unsigned long long)n_serial);
+        atomicAdd(&g_walk_paths[3], 1ull);
     }
 }
 

@@ -132,16 +132,17 @@ __global__ __launch_bounds__(64) void find_contours_kernel(const unsigned* __res
 // The same scan by a whole workgroup (border_parallel.h) on a padded LDS copy of the plane: what fog_of_war / explored_select /
 // frontier do on their windows, exposed for images that fit (3 planes of (rows + 2) x (stride + 2) words in 144 KB) so that the
 // parallel follower can be checked against cv2.findContours on arbitrary bitmaps (tests/test_obstacle_prims_gpu.py).
-struct WgContourWork { unsigned* planes6; int* pixbase; int plane_words, cap_states; };
+struct WgContourWork { unsigned* planes6; int* pixbase; int plane_words, cap_states, use_lds; };
 __global__ __launch_bounds__(1024) void find_contours_wg_kernel(const unsigned* __restrict__ img, int rows, int cols, int stride,
-                                                                int method, WgContourWork wk, int2* __restrict__ pts, int cap_pts,
+                                                                int method, WgContourWork wk, unsigned lds_total,
+                                                                int2* __restrict__ pts, int cap_pts,
                                                                 int* __restrict__ starts, int* __restrict__ lens,
                                                                 int cap_contours, int* __restrict__ counts /* [planes][3] */) {
     extern __shared__ __attribute__((aligned(16))) unsigned lds_win[];
     __shared__ int sh_wg[WG_SH_INTS];
     const size_t plane = blockIdx.x;
     const int tid = threadIdx.x, nth = blockDim.x;
-    const int pw = stride + 2, wn = (rows + 2) * pw;
+    const int pw = (stride + 2) | 1, wn = (rows + 2) * pw;   // (odd row stride: border_parallel.h, row_next_start_lane)
     unsigned* L_img = lds_win;
     unsigned* L_tr = lds_win + wn;
     unsigned* L_ng = lds_win + 2 * wn;
@@ -166,7 +167,10 @@ __global__ __launch_bounds__(1024) void find_contours_wg_kernel(const unsigned* 
     T.pixbase = wk.pixbase + plane * cap_pts;
     T.cap_bp = cap_pts; T.cap_states = wk.cap_states;
     T.wrows = rows; T.wwords = stride;
-    wg_scan_external(b, L_tr + pw + 1, L_ng + pw + 1, method, sink, T, sh_wg);
+    // tables of the follower in what is left of the LDS (border_parallel.h, round 4); wk.use_lds = 0 forces the global-table form
+    const unsigned used = 3u * (unsigned)wn * 4u;
+    wg_scan_external_lds(b, L_tr + pw + 1, L_ng + pw + 1, method, sink, T, wk.use_lds ? lds_win + 3 * wn : nullptr,
+                         lds_total > used ? lds_total - used : 0u, sh_wg);
     if (tid == 0) {
         counts[plane * 3 + 0] = sink.n_contours;
         counts[plane * 3 + 1] = sink.n_pts;
@@ -548,7 +552,7 @@ __global__ __launch_bounds__(1024) void fog_of_war_kernel(const FogParams* __res
     unsigned* vis = obst + plane_words;
     unsigned* fill = vis + plane_words;
     // padded copies for the two border scans (Bits::padded): image + both label planes, (wn + 2) x (words + 2) words each
-    const int pw = words + 2, pad_words = (wn + 2) * pw;
+    const int pw = (words + 2) | 1, pad_words = (wn + 2) * pw;
     unsigned* p_img = fill + plane_words;
     unsigned* p_tr = p_img + pad_words;
     unsigned* p_ng = p_tr + pad_words;
@@ -612,7 +616,7 @@ __global__ __launch_bounds__(1024) void fog_of_war_kernel(const FogParams* __res
         Bits b{p_img + pw + 1, pw, wn, wn, 1};
         WalkTables T = fog_walk_tables(sc, P.env, wn, words);
         T.ljd0 = l_jd; T.ljd1 = l_jd + sc.lds_states;
-        wg_scan_external(b, p_tr + pw + 1, p_ng + pw + 1, 2, sink, T, sh_wg);   // the whole workgroup (border_parallel.h)
+        wg_scan_external_lds(b, p_tr + pw + 1, p_ng + pw + 1, 2, sink, T, l_jd, 8u * (unsigned)sc.lds_states, sh_wg);   // the whole workgroup (border_parallel.h)
         if (tid == 0) { sh_i[0] = sink.n_contours; sh_i[1] = sink.n_pts; sh_i[2] = sink.overflow; }
     }
     __threadfence_block();
@@ -689,13 +693,14 @@ __global__ __launch_bounds__(1024) void fog_of_war_kernel(const FogParams* __res
     }
     __threadfence_block();
     __syncthreads();
+    VLFM_PHASE(0, 5);
     for (int t = tid; t < n_lines * THICK_LINE_PARTS; t += nth) {
         const int part = t / n_lines, i = t - part * n_lines;
         const int4 ln = lines[i];
         thick_line2_clear(vis, W, ln.x + ox, ln.y + oy, ln.z, ln.w, part);
     }
     __syncthreads();
-    VLFM_PHASE(0, 5);
+    VLFM_PHASE(0, 6);
     // ---- 6. external contours of what is left; keep the one nearest the agent (|pointPolygonTest|, <= 3 px)
     for (int i = tid; i < pad_words; i += nth) {
         const int ly = i / pw - 1, lw = i % pw - 1;
@@ -710,7 +715,7 @@ __global__ __launch_bounds__(1024) void fog_of_war_kernel(const FogParams* __res
         Bits b{p_img + pw + 1, pw, wn, wn, 1};
         WalkTables T = fog_walk_tables(sc, P.env, wn, words);
         T.ljd0 = l_jd; T.ljd1 = l_jd + sc.lds_states;
-        wg_scan_external(b, p_tr + pw + 1, p_ng + pw + 1, 2, sink, T, sh_wg);
+        wg_scan_external_lds(b, p_tr + pw + 1, p_ng + pw + 1, 2, sink, T, l_jd, 8u * (unsigned)sc.lds_states, sh_wg);
     }
     // distance of the agent to every contour: one wavefront per contour, 16 at a time (the line list is free: it holds the
     // distances); then wavefront 0 picks.  OpenCV lists contours in reverse discovery order and the reference's loop keeps the
@@ -743,7 +748,7 @@ __global__ __launch_bounds__(1024) void fog_of_war_kernel(const FogParams* __res
     if (sh_i[6]) { if (tid == 0) status[0] = 1; return; }
     const int best = sh_i[5];
     if (best < 0 || sh_i[7]) return;  // nothing visible / closest contour too far away
-    VLFM_PHASE(0, 6);
+    VLFM_PHASE(0, 7);
     // ---- 7. drawContours(fog, [visible_area], 0, 1, -1): fill the chosen outline (component + enclosed holes)
     {
         LdsBitmap fb;
@@ -758,7 +763,7 @@ __global__ __launch_bounds__(1024) void fog_of_war_kernel(const FogParams* __res
         resolve_rows(fb, tid, nth);
         __syncthreads();
     }
-    VLFM_PHASE(0, 7);
+    VLFM_PHASE(0, 8);
     // ---- 8. dilate 3x3 (obstacle_map.py:125), keep navigable cells (:127), OR into the explored plane (:126)
     unsigned* expl = mp.explored + eoff;
     for (int i = tid; i < plane_words; i += nth) {
@@ -786,7 +791,7 @@ __global__ __launch_bounds__(1024) void fog_of_war_kernel(const FogParams* __res
         if (lo && wi >= 0 && wi < mp.stride) atomicOr(&expl[(size_t)y * mp.stride + wi], lo & tail_mask(S, wi));
         if (hi && wi + 1 >= 0 && wi + 1 < mp.stride) atomicOr(&expl[(size_t)y * mp.stride + wi + 1], hi & tail_mask(S, wi + 1));
     }
-    VLFM_PHASE(0, 8);
+    VLFM_PHASE(0, 9);
     if (tid == 0) {
         int* bb = sc.bbox + (size_t)P.env * 4;
         atomicMin(&bb[0], max(oy, 0)); atomicMax(&bb[1], min(oy + wn - 1, S - 1));
@@ -827,7 +832,7 @@ __global__ __launch_bounds__(1024) void explored_select_kernel(const FogParams* 
     extern __shared__ __attribute__((aligned(16))) unsigned lds_win[];
     const int w_lo = max(bb[2] - 1, 0) >> 5, w_hi = min(bb[3] + 1, S - 1) >> 5;
     const int wrows = y_hi - y_lo + 1, wwords = w_hi - w_lo + 1;
-    const int pw = wwords + 2, wn = (wrows + 2) * pw;  // padded: one zero row / word all around (Bits::padded)
+    const int pw = (wwords + 2) | 1, wn = (wrows + 2) * pw;  // padded: one zero row / word all around (Bits::padded), odd stride
     const bool in_lds = (size_t)3 * wn * sizeof(unsigned) <= sc.lds_bytes;
     unsigned* L_img = lds_win;
     unsigned* L_tr = lds_win + wn;
@@ -861,7 +866,7 @@ __global__ __launch_bounds__(1024) void explored_select_kernel(const FogParams* 
         T.pixbase = sc.walk_pixbase + (size_t)P.env * sc.cap_pts;
         T.cap_bp = sc.cap_pts; T.cap_states = min(sc.walk_states, S * stride);
         T.wrows = wrows; T.wwords = wwords;
-        wg_scan_external(b, L_tr + pw + 1, L_ng + pw + 1, 2, sink, T, sh_wg);
+        wg_scan_external_lds(b, L_tr + pw + 1, L_ng + pw + 1, 2, sink, T, lds_win + 3 * wn, sc.lds_bytes - 12u * (unsigned)wn, sh_wg);
         VLFM_STAMP(1, 2);
         const int npt = sink.n_pts < sc.cap_pts ? sink.n_pts : sc.cap_pts;
         for (int i = tid; i < npt; i += nth) { int2 q = pts[i]; q.x += w_lo * 32; q.y += y_lo; pts[i] = q; }  // -> image coords
@@ -1092,7 +1097,7 @@ __global__ __launch_bounds__(1024) void frontier_kernel(const FogParams* __restr
         const int y_lo = shortcut ? max(bb[0] - 3, 0) : 0, y_hi = shortcut ? min(bb[1] + 3, S - 1) : S - 1;
         const int w_lo = shortcut ? (max(bb[2] - 3, 0) >> 5) : 0, w_hi = shortcut ? (min(bb[3] + 3, S - 1) >> 5) : stride - 1;
         const int wrows = y_hi - y_lo + 1, wwords = w_hi - w_lo + 1;
-        const int pw = wwords + 2, wn = (wrows + 2) * pw;  // padded (Bits::padded)
+        const int pw = (wwords + 2) | 1, wn = (wrows + 2) * pw;  // padded (Bits::padded), odd stride
         const bool in_lds = wrows > 0 && (size_t)3 * wn * sizeof(unsigned) <= sc.lds_bytes;
         unsigned* L_img = lds_win;
         unsigned* L_tr = lds_win + wn;
@@ -1122,7 +1127,8 @@ __global__ __launch_bounds__(1024) void frontier_kernel(const FogParams* __restr
             T.pixbase = sc.walk_pixbase + (size_t)P.env * sc.cap_pts;
             T.cap_bp = sc.cap_pts; T.cap_states = min(sc.walk_states, S * stride);
             T.wrows = wrows; T.wwords = wwords;
-            wg_scan_external(b, L_tr + pw + 1, L_ng + pw + 1, 1, sink, T, sh_wg);
+            wg_scan_external_lds(b, L_tr + pw + 1, L_ng + pw + 1, 1, sink, T, lds_win + 3 * wn, sc.lds_bytes - 12u * (unsigned)wn,
+                                 sh_wg);
             VLFM_STAMP(2, 4);
             const int npt = sink.n_pts < sc.cap_pts ? sink.n_pts : sc.cap_pts;
             for (int i = tid; i < npt; i += nth) { int2 q = pts[i]; q.x += w_lo * 32; q.y += y_lo; pts[i] = q; }
@@ -1369,6 +1375,11 @@ extern "C" int vlfm_find_contours_external(const uint32_t* d_img, int planes, in
     return check_launch("find_contours_kernel");
 }
 
+// dynamic LDS of the border walks of explored_select / frontier: image + two label planes of a window up to ~640 x 640 cells, and
+// behind them the tables of the workgroup-parallel follower (border_parallel.h).  The chip has 160 KB per CU and these kernels run
+// one workgroup per environment, so occupancy is irrelevant; 2 KB stay free for the kernels' static shared variables.
+constexpr unsigned kWalkLdsBytes = 158 * 1024;
+
 extern "C" size_t vlfm_find_contours_wg_scratch_bytes(int planes, int rows, int cols, int cap_pts) {
     if (planes <= 0 || rows <= 0 || cols <= 0 || cap_pts <= 0) return 0;
     const size_t stride = (cols + 31) / 32;
@@ -1383,33 +1394,33 @@ extern "C" int vlfm_find_contours_external_wg(const uint32_t* d_img, int planes,
                                               void* d_scratch, size_t scratch_bytes, int32_t* d_pts, int cap_pts,
                                               int32_t* d_starts, int32_t* d_lens, int cap_contours, int32_t* d_counts,
                                               void* stream) {
+    const int global_tables = (method & 0x100) != 0;   // test switch: the follower's tables in global memory (the fallback form)
+    method &= 0xFF;
     if (!d_img || !d_scratch || !d_pts || !d_starts || !d_lens || !d_counts || planes <= 0 || rows <= 0 || cols <= 0 ||
         (method != 1 && method != 2) || cols > 2048)
         return fail(VLFM_ERR_INVALID, "find_contours_external_wg: bad argument (method 1|2, cols <= 2048)");
     const int stride = (cols + 31) / 32;
-    const size_t lds = (size_t)3 * (rows + 2) * (stride + 2) * 4;
+    const size_t lds = (size_t)3 * (rows + 2) * ((stride + 2) | 1) * 4;
     const size_t need = vlfm_find_contours_wg_scratch_bytes(planes, rows, cols, cap_pts);
     if (lds > 144 * 1024 || need == 0) return fail(VLFM_ERR_CAPACITY, "find_contours_external_wg: the image does not fit the LDS window");
+    const size_t lds_launch = global_tables ? lds : (size_t)kWalkLdsBytes;
     if (scratch_bytes < need) return fail(VLFM_ERR_CAPACITY, "find_contours_external_wg: scratch too small");
     static LdsOptIn opt;
-    if (!opt.ensure(reinterpret_cast<const void*>(find_contours_wg_kernel), 144 * 1024))
-        return fail(VLFM_ERR_HIP, "find_contours_external_wg: cannot opt in to 144 KB of LDS");
+    if (!opt.ensure(reinterpret_cast<const void*>(find_contours_wg_kernel), kWalkLdsBytes))
+        return fail(VLFM_ERR_HIP, "find_contours_external_wg: cannot opt in to 158 KB of LDS");
     size_t plane_words = (size_t)rows * stride;
     if (plane_words < (size_t)2 * cap_pts) plane_words = (size_t)2 * cap_pts;
     if (plane_words > 65535) plane_words = 65535;
     WgContourWork wk{(unsigned*)d_scratch, (int*)((unsigned*)d_scratch + (size_t)planes * 6 * plane_words), (int)plane_words,
-                     (int)plane_words};
+                     (int)plane_words, !global_tables};
     VLFM_TIMED("find_contours_wg_kernel", stream);
-    VLFM_KLAUNCH(find_contours_wg_kernel, dim3(planes), dim3(1024), lds, (hipStream_t)stream, d_img, rows, cols, stride, method, wk,
-                 reinterpret_cast<int2*>(d_pts), cap_pts, d_starts, d_lens, cap_contours, d_counts);
+    VLFM_KLAUNCH(find_contours_wg_kernel, dim3(planes), dim3(1024), lds_launch, (hipStream_t)stream, d_img, rows, cols, stride, method,
+                 wk, (unsigned)lds_launch, reinterpret_cast<int2*>(d_pts), cap_pts, d_starts, d_lens, cap_contours, d_counts);
     return check_launch("find_contours_wg_kernel");
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
-// dynamic LDS for the border walks of explored_select / frontier: image + two label planes of a window up to ~640 x 640
-// cells (the chip has 160 KB per CU; these kernels run one narrow workgroup per environment, so occupancy is irrelevant)
-constexpr unsigned kWalkLdsBytes = 144 * 1024;
 
 struct ScratchLayout {
     size_t plane_words, total;
@@ -1484,7 +1495,7 @@ extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, in
                       {planes[0], planes[1], planes[2], planes[3], planes[4], planes[5]}, (int*)(base + L.off_pixbase),
                       map_size * stride, 0};
         const int wn = 2 * fog_radius + 5, words = (wn + 31) / 32;
-        size_t lds = (size_t)6 * wn * words * 4 + (size_t)3 * (wn + 2) * (words + 2) * 4 + 64;
+        size_t lds = (size_t)6 * wn * words * 4 + (size_t)3 * (wn + 2) * ((words + 2) | 1) * 4 + 64;
         if (lds > 160 * 1024) return fail(VLFM_ERR_CAPACITY, "obstacle_map_update_batched: fog window too large for LDS");
         // what is left of 152 KB holds the border follower's list-ranking buffers (two words per state; a window of 205 x 205
         // cells has a few thousand states): a ranking round is then an LDS round trip instead of an L2 one
@@ -1504,7 +1515,7 @@ extern "C" int vlfm_obstacle_map_update_batched(const vlfm_fog_params* d_prm, in
         static LdsOptIn opt_select, opt_frontier;
         if (!opt_select.ensure(reinterpret_cast<const void*>(explored_select_kernel), kWalkLdsBytes) ||
             !opt_frontier.ensure(reinterpret_cast<const void*>(frontier_kernel), kWalkLdsBytes))
-            return fail(VLFM_ERR_HIP, "obstacle_map_update_batched: cannot opt in to 144 KB of LDS");
+            return fail(VLFM_ERR_HIP, "obstacle_map_update_batched: cannot opt in to 158 KB of LDS");
         // the fog kernel's line list (cap_pts x int4 per environment) is free from here on: two pointer-jumping buffers of
         // 2 * cap_pts words for the parallel border follower
         SelectScratch ss{planes[0], planes[1], planes[2], planes[3], pts, starts, lens, status + (size_t)n_envs * 4,
@@ -1561,6 +1572,17 @@ extern "C" int vlfm_debug_walk_stats(long long* h_out /* ticks, points, calls; r
     return VLFM_OK;
 }
 #endif
+
+extern "C" int vlfm_walk_path_counters(long long* h_out4, int reset) {
+    // borders traced from the LDS tables / (unused) / by one lane after the tables declined; images whose tables were in LDS
+    if (!h_out4) return fail(VLFM_ERR_INVALID, "walk_path_counters: bad argument");
+    if (hipMemcpyFromSymbol(h_out4, HIP_SYMBOL(vlfm::g_walk_paths), 32) != hipSuccess) return check_launch("walk_path_counters");
+    if (reset) {
+        const long long z[4] = {0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(vlfm::g_walk_paths), z, 32) != hipSuccess) return check_launch("walk_path_counters");
+    }
+    return VLFM_OK;
+}
 
 extern "C" int vlfm_obstacle_status(const void* d_scratch, int n_envs, int map_size, int cap_pts, int cap_contours,
                                     int32_t* h_out /* [n_envs][8] */) {
