@@ -479,8 +479,9 @@ int vlfm_find_contours_external(const uint32_t* d_img, int planes, int rows, int
  * d_scratch: vlfm_find_contours_wg_scratch_bytes(...) bytes.  method | 0x100 keeps the follower's tables in global memory (the
  * fallback form of the map kernels, for windows whose tables do not fit the LDS behind the window planes); without the flag the
  * tables live in LDS and every border of the plane is ranked at once (the form the map kernels use when it fits).
- * vlfm_walk_path_counters: how the borders of all launches so far were traced -- h_out4 = (borders from the LDS tables, unused,
- * borders walked by one lane although the LDS tables existed, planes / windows whose tables were in LDS); reset != 0 zeroes them. */
+ * vlfm_walk_path_counters: how the borders of all launches so far were traced -- h_out4 = (borders from the ranked tables, planes /
+ * windows whose per-pixel tables were in global memory (large windows), borders walked by one lane although the ranked tables
+ * existed, planes / windows with every table in LDS); reset != 0 zeroes them. */
 size_t vlfm_find_contours_wg_scratch_bytes(int planes, int rows, int cols, int cap_pts);
 int vlfm_walk_path_counters(long long* h_out4, int reset);
 int vlfm_find_contours_external_wg(const uint32_t* d_img, int planes, int rows, int cols, int method, void* d_scratch,

@@ -91,7 +91,8 @@ def test_find_contours_external_bit_exact(gpu_device, density, method):
 
 
 def _walk_paths(reset: bool = True):
-    """(borders from the LDS tables, -, borders walked by one lane although the LDS tables existed, planes with LDS tables)."""
+    """(borders from the ranked tables, planes with the per-pixel tables in global memory, borders walked by one lane although the
+    ranked tables existed, planes with every table in LDS)."""
     import ctypes
 
     out = np.zeros(4, np.int64)
@@ -143,14 +144,25 @@ def _follower_states(img: np.ndarray):
     return int(B.sum()), n
 
 
-def _lds_tables_fit(plane: np.ndarray) -> bool:
-    """Does the follower keep this plane's tables in LDS (158 KB minus the three padded window planes)?"""
+def _lds_tables_fit(plane: np.ndarray, cap_p: int = 1 << 15):
+    """Which form of the follower takes this plane (csrc/border_parallel.h: wg_build_rank_lds): "lds" = every table in the LDS behind
+    the three padded window planes (158 KB in all), "gpix" = the per-pixel tables in global memory, None = the global-table form."""
     rows, cols = plane.shape
     plane_words = (rows + 2) * (((cols + 31) // 32 + 2) | 1)
     nb, n = _follower_states(plane)
-    w32 = (n + 31) // 32 + 1
-    need = 4 * n + 4 * max(0, n - 2 * plane_words) + ((4 * nb + 2 * (nb + 1) + 7) & ~7) + 8 * w32
-    return n < 65535 and nb <= 65535 and need <= 158 * 1024 - 12 * plane_words
+    arena = 158 * 1024 - 12 * plane_words - (4 if plane_words & 1 else 0)
+    rr = (2 * (rows + 1) + 7) & ~7
+    pix = (4 * nb + 2 * (nb + 1) + 7) & ~7
+    w32b = 8 * ((n + 31) // 32 + 1)
+
+    def states_fit(left):
+        return n < 65535 and (8 * n + w32b <= left or 4 * n + 4 * max(0, n - 2 * plane_words) + w32b <= left)
+
+    if nb <= 65535 and rr + pix + 5 * nb <= arena and states_fit(arena - rr - pix):
+        return "lds"
+    if nb + 1 <= min(65535, 2 * cap_p) and rr <= arena and states_fit(arena - rr):
+        return "gpix"
+    return None
 
 
 def _structured_planes():
@@ -196,7 +208,8 @@ def test_parallel_border_follower_equals_findcontours(gpu_device, method):
 
     for global_tables in (False, True):
         _walk_paths()
-        n_borders = n_fit = 0
+        n_borders = 0
+        n_fit = {"lds": 0, "gpix": 0, None: 0}
         for density in (0.02, 0.3, 0.55, 0.8):
             rng = np.random.default_rng(int(density * 100) + method)
             img = (rng.uniform(size=(3, 60, 90)) < density).astype(np.uint8)
@@ -205,8 +218,8 @@ def test_parallel_border_follower_equals_findcontours(gpu_device, method):
             for p in range(3):
                 want, _ = cv.findContours(img[p], cv.RETR_EXTERNAL, method)
                 assert len(got[p]) == len(want) == len(serial[p]), (density, p, len(got[p]), len(want))
-                fit = _lds_tables_fit(img[p])
-                n_fit += fit
+                fit = _lds_tables_fit(img[p], 1 << 14)
+                n_fit[fit] += 1
                 n_borders += len(want) if fit else 0
                 for g, w, q in zip(got[p], want, serial[p]):
                     assert np.array_equal(g, w.reshape(-1, 2)) and np.array_equal(g, q)
@@ -220,20 +233,21 @@ def test_parallel_border_follower_equals_findcontours(gpu_device, method):
                 want, _ = cv.findContours(img[p], cv.RETR_EXTERNAL, method)
                 assert len(got[p]) == len(want), (global_tables, y0, x0, p, len(got[p]), len(want))
                 fit = _lds_tables_fit(img[p])
-                n_fit += fit
+                n_fit[fit] += 1
                 n_borders += len(want) if fit else 0
                 for k, (g, w) in enumerate(zip(got[p], want)):
                     assert np.array_equal(g, w.reshape(-1, 2)), (global_tables, y0, x0, p, k, len(g), len(w))
                     longest = max(longest, len(g))
         assert longest > (500 if method == 1 else 100)   # the ranking path ran (borders closing within 16 steps are walked by one lane)
-        from_lds, _, one_lane, planes_lds = _walk_paths()
+        from_lds, planes_gpix, one_lane, planes_lds = _walk_paths()
         if global_tables:
-            assert from_lds == 0 and planes_lds == 0
+            assert from_lds == 0 and planes_lds == 0 and planes_gpix == 0
         else:
-            # every plane whose tables fit had them in LDS, and every border of those came out of them: no start state was dead
-            # or missing
-            assert n_fit >= 20 and planes_lds == n_fit and one_lane == 0 and from_lds == n_borders, (from_lds, one_lane, planes_lds,
-                                                                                                   n_fit, n_borders)
+            # every plane whose tables fit had them in LDS (all of them, or all but the per-pixel ones), and every border of those
+            # came out of them: no start state was dead or missing
+            assert n_fit["lds"] >= 20, n_fit
+            assert planes_lds == n_fit["lds"] and planes_gpix == n_fit["gpix"] and one_lane == 0 and from_lds == n_borders, (
+                from_lds, planes_gpix, one_lane, planes_lds, n_fit, n_borders)
 
 
 def test_lds_border_tables_on_explored_area_shapes(gpu_device):
@@ -246,17 +260,22 @@ def test_lds_border_tables_on_explored_area_shapes(gpu_device):
 
     rng = np.random.default_rng(23)
     fitted = 0
-    for rows, cols, sigma in ((205, 205, 9), (300, 420, 14), (402, 430, 18)):
+    forms = []
+    # (rows, cols, smoothing of the outline, pillar / speck / obstacle-seed densities); the last one is a window whose three planes
+    # leave 31 KB of LDS: per-pixel tables in global memory
+    for rows, cols, sigma, pillars, specks, seeds in ((205, 205, 9, 4e-4, 5e-4, 2e-3), (300, 420, 14, 4e-4, 5e-4, 2e-3),
+                                                    (402, 430, 18, 4e-4, 5e-4, 2e-3), (556, 454, 32, 1e-4, 1e-4, 4e-4)):
         planes = []
         field = ndimage.gaussian_filter(rng.uniform(size=(rows, cols)), sigma)
         area = field > np.quantile(field, 0.45)
-        area &= ~ndimage.binary_dilation(rng.uniform(size=(rows, cols)) < 0.0004, iterations=3)       # pillars
-        area |= rng.uniform(size=(rows, cols)) < 0.0005                                                # specks
+        area &= ~ndimage.binary_dilation(rng.uniform(size=(rows, cols)) < pillars, iterations=3)
+        area |= rng.uniform(size=(rows, cols)) < specks
         planes.append(area)
-        planes.append(ndimage.binary_dilation(rng.uniform(size=(rows, cols)) < 0.002, iterations=2))   # obstacle blobs
+        planes.append(ndimage.binary_dilation(rng.uniform(size=(rows, cols)) < seeds, iterations=2))   # obstacle blobs
         img = np.stack(planes).astype(np.uint8)
         fits = [_lds_tables_fit(img[p]) for p in range(2)]
-        fitted += sum(fits)
+        fitted += sum(f is not None for f in fits)
+        forms += fits
         for method in (1, 2):
             _walk_paths()
             got = _gpu_contours_wg(img, method, gpu_device, cap_p=1 << 15)
@@ -267,10 +286,10 @@ def test_lds_border_tables_on_explored_area_shapes(gpu_device):
                 n_lds += len(want) if fits[p] else 0
                 for g, w in zip(got[p], want):
                     assert np.array_equal(g, w.reshape(-1, 2))
-            from_lds, _, one_lane, planes_lds = _walk_paths()
-            assert planes_lds == sum(fits) and one_lane == 0 and from_lds == n_lds, (rows, cols, method, fits, from_lds, one_lane,
-                                                                                   planes_lds, n_lds)
-    assert fitted >= 4
+            from_lds, planes_gpix, one_lane, planes_lds = _walk_paths()
+            assert planes_lds == fits.count("lds") and planes_gpix == fits.count("gpix") and one_lane == 0 and from_lds == n_lds, (
+                rows, cols, method, fits, from_lds, planes_gpix, one_lane, planes_lds, n_lds)
+    assert fitted >= 7 and forms.count("gpix") >= 2, forms
 
 
 def test_parallel_border_follower_falls_back_when_the_tables_do_not_fit(gpu_device):

@@ -414,7 +414,7 @@ __device__ inline bool row_next_start(const Bits& img, const unsigned* traced, c
 // entering state carried along): the first border start to the right of x_done (-1: whole row), or -1.  A row per wavefront cost
 // ~60 instructions per row and wavefront; a row per lane costs them per 64 rows.  (The callers keep the padded row stride odd,
 // so that 64 lanes reading the same word of 64 consecutive rows hit 32 different banks.)
-__device__ inline int row_next_start_lane(const Bits& img, const unsigned* traced, const unsigned* neg, int y, int x_done) {
+__device__ __forceinline__ int row_next_start_lane(const Bits& img, const unsigned* traced, const unsigned* neg, int y, int x_done) {
     const unsigned* row = img.w + (size_t)y * img.stride;
     const unsigned* tr = traced + (size_t)y * img.stride;
     const unsigned* ngp = neg + (size_t)y * img.stride;
@@ -448,7 +448,7 @@ __device__ inline int row_next_start_lane(const Bits& img, const unsigned* trace
 // per search -- the block-wise, row-per-wavefront search this replaces spent 18 us on the LAST search of a 450-row window
 // (nothing left to find: 7 blocks x 3 barriers), in each of the four scans of a step.  `slot` alternates between calls
 // (sh[44], sh[45]).
-__device__ inline bool wg_next_start(const Bits& img, const unsigned* traced, const unsigned* neg, int y, int x_done, int* sh,
+__device__ __forceinline__ bool wg_next_start(const Bits& img, const unsigned* traced, const unsigned* neg, int y, int x_done, int* sh,
                                      int slot, int& fx, int& fy) {
     const int tid = threadIdx.x, lane = tid & 63, nth = blockDim.x;
     int* best = &sh[44 + (slot & 1)];
@@ -548,24 +548,11 @@ struct WalkLds {
     unsigned* posflag;         // [ceil(N / 32) + 1]
     int* posprefix;            // [ceil(N / 32) + 1]
     unsigned long long* AB;    // [N]   packed form: A | B << 32 while ranking (then B is extracted to the front of it)
+    unsigned short* rowrank;   // [rows + 1] rank of the first border pixel of every row
     int N, nb, ok, packed;
 };
 
 __device__ __forceinline__ size_t walk_pix_bytes(int nb) { return ((size_t)4 * nb + (size_t)2 * (nb + 1) + 7) & ~(size_t)7; }
-__device__ __forceinline__ size_t walk_lds_bytes(int N, int nb, int n_lab) {    // the split form: A in the label planes
-    const size_t w32 = (size_t)(N + 31) / 32 + 1;
-    return (size_t)4 * N + (size_t)4 * (N > n_lab ? N - n_lab : 0) + walk_pix_bytes(nb) + 8 * w32;
-}
-__device__ __forceinline__ size_t walk_lds_bytes_packed(int N, int nb) {
-    const size_t w32 = (size_t)(N + 31) / 32 + 1;
-    return (size_t)8 * N + walk_pix_bytes(nb) + 8 * w32;
-}
-
-__device__ __forceinline__ int v2_rank_of_pixel(const WalkLds& T, int key) {   // key = x | y << 11; caller checks the hit
-    int lo = 0, hi = T.nb - 1;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((T.pixxy[mid] & 0x3FFFFF) < key) lo = mid + 1; else hi = mid; }
-    return lo;
-}
 // directions d of a border pixel's border-pixel neighbours (bnb) from which the walk goes on to a border pixel: the states that get ids
 __device__ __forceinline__ unsigned v2_alloc_mask(unsigned nbm, unsigned bnb) {
     unsigned am = 0u, dirs = bnb;
@@ -654,10 +641,20 @@ __device__ __forceinline__ bool v2_round_cnt(const WalkLds& T, int cnt, int tid,
     return v2_round<6, MODE>(T, tid, nth);
 }
 
+// Barrier behind writes to the per-pixel tables: they are in global memory when GPIX (a window so large that its three planes leave
+// no room for them in LDS: late in an episode the explored area spans the whole 20 m world), else in LDS.
+template <bool GPIX>
+__device__ __forceinline__ void sync_pix() {
+    if (GPIX) wg_sync_global();
+    else __syncthreads();
+}
+
 // Tables + ranking of every cycle.  All threads; img padded, lt / ln = its two label planes (contiguous: ln == lt + plane words,
-// zero on entry, zero again on return).  T.ok = 0: nothing was changed, use the global-table form.
-__device__ inline void wg_build_rank_lds(const Bits& img, unsigned* lt, unsigned* ln, unsigned* arena, unsigned arena_bytes,
-                                         int wrows, int wwords, WalkLds& T, int* sh) {
+// zero on entry, zero again on return).  T.ok = 0: nothing was changed, use another form.
+template <bool GPIX>
+__device__ __forceinline__ void wg_build_rank_lds(const Bits& img, unsigned* lt, unsigned* ln, unsigned* arena, unsigned arena_bytes,
+                                         int* gpixxy, unsigned short* gpixbase, int gpix_cap, int wrows, int wwords, WalkLds& T,
+                                         int* sh) {
     const int tid = threadIdx.x, nth = blockDim.x;
     const unsigned* base = img.w;
     const int pw = img.stride, W = wrows * wwords;
@@ -665,6 +662,8 @@ __device__ inline void wg_build_rank_lds(const Bits& img, unsigned* lt, unsigned
     T.ok = 0; T.N = 0; T.nb = 0; T.n_lab = 0; T.packed = 0;
     if (ln != lt + plane_words || arena == nullptr) return;
     if (((unsigned)(size_t)arena & 7u) && arena_bytes >= 4u) { arena += 1; arena_bytes -= 4u; }   // the packed words are 8 bytes
+    const size_t rr_bytes = ((size_t)2 * (wrows + 1) + 7) & ~(size_t)7;
+    if (rr_bytes > (size_t)arena_bytes) return;
     unsigned* lab0 = lt - (pw + 1);            // the padded origin of the label planes: 2 * plane_words words
     auto border_word = [&](int ly, int lw) -> unsigned {
         const unsigned* r = base + ly * pw + lw;
@@ -682,15 +681,24 @@ __device__ inline void wg_build_rank_lds(const Bits& img, unsigned* lt, unsigned
     for (int k = k0; k < k1; k++) { const int ly = k / wwords, lw = k - ly * wwords; nb += __builtin_popcount(lt[ly * pw + lw]); }
     int nb_ex, d_ex, nb_tot, d_tot;
     wg_scan2(nb, 0, sh, nb_ex, d_ex, nb_tot, d_tot);
-    const size_t pix_bytes = walk_pix_bytes(nb_tot);
-    if (nb_tot > 65535 || pix_bytes > (size_t)arena_bytes) {
+    const size_t pix_bytes = GPIX ? 0 : walk_pix_bytes(nb_tot);
+    // (the last clause: with fewer than ~1.25 states per border pixel to come the LDS would still be too small -- do not spend the
+    // next passes on finding that out; only the choice of the form depends on it)
+    if (nb_tot > 65535 || rr_bytes + pix_bytes > (size_t)arena_bytes || (GPIX && nb_tot + 1 > gpix_cap) ||
+        (!GPIX && rr_bytes + pix_bytes + (size_t)5 * nb_tot > (size_t)arena_bytes)) {
         for (int k = tid; k < W; k += nth) { const int ly = k / wwords, lw = k - ly * wwords; lt[ly * pw + lw] = 0u; }
         __syncthreads();
         return;
     }
     T.nb = nb_tot;
-    T.pixxy = reinterpret_cast<int*>(arena);
-    T.pixbase = reinterpret_cast<unsigned short*>(T.pixxy + nb_tot);
+    T.rowrank = reinterpret_cast<unsigned short*>(arena);
+    if (GPIX) {
+        T.pixxy = gpixxy;
+        T.pixbase = gpixbase;
+    } else {
+        T.pixxy = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(arena) + rr_bytes);
+        T.pixbase = reinterpret_cast<unsigned short*>(T.pixxy + nb_tot);
+    }
     for (int k = k0; k < k1; k++) {
         const int ly = k / wwords, lw = k - ly * wwords;
         ln[ly * pw + lw] = (unsigned)nb_ex;
@@ -701,24 +709,36 @@ __device__ inline void wg_build_rank_lds(const Bits& img, unsigned* lt, unsigned
         const int ly = k / wwords, lw = k - ly * wwords;
         unsigned bm = lt[ly * pw + lw];
         int rank = (int)ln[ly * pw + lw];
+        if (lw == 0) T.rowrank[ly] = (unsigned short)rank;
         while (bm) { const int bit = __builtin_ctz(bm); bm &= bm - 1; T.pixxy[rank++] = (lw * 32 + bit) | (ly << 11); }
     }
-    __syncthreads();
+    if (tid == 0) T.rowrank[wrows] = (unsigned short)nb_tot;
+    sync_pix<GPIX>();
     WALK_STAMP(1);
     // b. ONE BORDER PIXEL PER LANE from here on: the directions that get a state (bits 22..29 of the pixel's entry), their count
     for (int r = tid; r < nb_tot; r += nth) {
         const int xy = T.pixxy[r], x = xy & 2047, ly = xy >> 11;
         T.pixxy[r] = xy | (int)(v2_alloc_mask(nbr8_padded(base, pw, x, ly), nbr8_padded(lt, pw, x, ly)) << 22);
     }
-    __syncthreads();
+    sync_pix<GPIX>();
     const int pper = (nb_tot + nth - 1) / nth;
     const int r0 = min(tid * pper, nb_tot), r1 = min(r0 + pper, nb_tot);
     int ns = 0;
-    for (int r = r0; r < r1; r++) ns += __builtin_popcount(((unsigned)T.pixxy[r] >> 22) & 0xFFu);
+    for (int rb = r0; rb < r1; rb += 8) {      // (eight entries requested before the first is used: they may be in global memory)
+        int v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = rb + u < r1 ? T.pixxy[rb + u] : 0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) ns += __builtin_popcount(((unsigned)v[u] >> 22) & 0xFFu);
+    }
     int ns_ex, ns_tot;
     wg_scan2(ns, 0, sh, ns_ex, d_ex, ns_tot, d_tot);
-    const bool packed = walk_lds_bytes_packed(ns_tot, nb_tot) <= (size_t)arena_bytes;
-    const bool fits = ns_tot < (int)WALK_DEAD && (packed || walk_lds_bytes(ns_tot, nb_tot, 2 * plane_words) <= (size_t)arena_bytes);
+    const size_t left = (size_t)arena_bytes - rr_bytes - pix_bytes;
+    const size_t w32b = (size_t)8 * ((size_t)(ns_tot + 31) / 32 + 1);
+    const bool packed = (size_t)8 * ns_tot + w32b <= left;
+    const size_t n_lab_max = (size_t)2 * plane_words;
+    const bool fits = ns_tot < (int)WALK_DEAD &&
+                      (packed || (size_t)4 * ns_tot + (size_t)4 * ((size_t)ns_tot > n_lab_max ? ns_tot - n_lab_max : 0) + w32b <= left);
     if (!fits || ns_tot == 0) {
         for (int k = tid; k < W; k += nth) { const int ly = k / wwords, lw = k - ly * wwords; lt[ly * pw + lw] = 0u; ln[ly * pw + lw] = 0u; }
         __syncthreads();
@@ -729,17 +749,26 @@ __device__ inline void wg_build_rank_lds(const Bits& img, unsigned* lt, unsigned
     T.N = N;
     T.packed = packed;
     const int w32 = (N + 31) / 32 + 1;
-    T.B = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(arena) + pix_bytes);
+    T.B = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(arena) + rr_bytes + pix_bytes);
     T.AB = reinterpret_cast<unsigned long long*>(T.B);
     T.n_lab = N < 2 * plane_words ? N : 2 * plane_words;
     T.Aext = T.B + N;
     T.posflag = packed ? T.B + 2 * N : T.Aext + (N - T.n_lab);
     T.posprefix = reinterpret_cast<int*>(T.posflag + w32);
     T.A = lab0;
-    for (int r = r0; r < r1; r++) { T.pixbase[r] = (unsigned short)ns_ex; ns_ex += __builtin_popcount(((unsigned)T.pixxy[r] >> 22) & 0xFFu); }
+    for (int rb = r0; rb < r1; rb += 8) {
+        int v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = rb + u < r1 ? T.pixxy[rb + u] : 0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (rb + u < r1) T.pixbase[rb + u] = (unsigned short)ns_ex;
+            ns_ex += __builtin_popcount(((unsigned)v[u] >> 22) & 0xFFu);
+        }
+    }
     for (int i = tid; i < w32; i += nth) T.posflag[i] = 0u;
     if (tid == 0) T.pixbase[nb_tot] = (unsigned short)N;
-    __syncthreads();
+    sync_pix<GPIX>();
     WALK_STAMP(2);
     // c. successors: A = (next, 1), B = (self, 0) -- (DEAD, 0) for the fixed points.  The split form parks `next` in B first (the
     //    label planes are still border mask and ranks) and moves it over in a second pass.
@@ -747,23 +776,42 @@ __device__ inline void wg_build_rank_lds(const Bits& img, unsigned* lt, unsigned
         const int xy = T.pixxy[r], x = xy & 2047, ly = (xy >> 11) & 2047;
         const int sb0 = T.pixbase[r];
         const unsigned nbm = nbr8_padded(base, pw, x, ly);
-        unsigned dirs = ((unsigned)xy >> 22) & 0xFFu;
-        int t = 0;
-        while (dirs) {
+        const unsigned dirs0 = ((unsigned)xy >> 22) & 0xFFu;
+        // every successor's table entries are requested before the first is used (global memory when GPIX)
+        int rank2[8], xy2[8];
+        unsigned short pb2[8];
+        {
+            unsigned dirs = dirs0;
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                rank2[t] = 0;
+                if (dirs) {
+                    const int d = __builtin_ctz(dirs);
+                    dirs &= dirs - 1;
+                    const int from = (d + 1) & 7;
+                    const int s = (from + __builtin_ctz(((nbm | (nbm << 8)) >> from) & 0xFFu)) & 7;   // a border pixel: the state has an id
+                    const int x2 = x + code_dx(s), y2 = ly + code_dy(s);
+                    const int w2 = y2 * pw + (x2 >> 5);
+                    rank2[t] = (int)ln[w2] + __builtin_popcount(lt[w2] & ((1u << (x2 & 31)) - 1u));
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 8; t++) { xy2[t] = T.pixxy[rank2[t]]; pb2[t] = T.pixbase[rank2[t]]; }
+        }
+        unsigned dirs = dirs0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            if (!dirs) break;
             const int d = __builtin_ctz(dirs);
             dirs &= dirs - 1;
             const int from = (d + 1) & 7;
-            const int s = (from + __builtin_ctz(((nbm | (nbm << 8)) >> from) & 0xFFu)) & 7;   // a border pixel: the state has an id
-            const int id = sb0 + t;
-            const int x2 = x + code_dx(s), y2 = ly + code_dy(s), sb2 = (s + 4) & 7;
-            const int w2 = y2 * pw + (x2 >> 5);
-            const int rank2 = (int)ln[w2] + __builtin_popcount(lt[w2] & ((1u << (x2 & 31)) - 1u));
-            const unsigned am2 = ((unsigned)T.pixxy[rank2] >> 22) & 0xFFu;
+            const int s = (from + __builtin_ctz(((nbm | (nbm << 8)) >> from) & 0xFFu)) & 7;
+            const int id = sb0 + t, sb2 = (s + 4) & 7;
+            const unsigned am2 = ((unsigned)xy2[t] >> 22) & 0xFFu;
             // successor state without an id: fixed point
-            const int id2 = (am2 >> sb2) & 1u ? (int)T.pixbase[rank2] + __builtin_popcount(am2 & ((1u << sb2) - 1u)) : id;
+            const int id2 = (am2 >> sb2) & 1u ? (int)pb2[t] + __builtin_popcount(am2 & ((1u << sb2) - 1u)) : id;
             if (packed) T.AB[id] = (unsigned long long)((unsigned)id2 | (1u << 16)) | ((unsigned long long)(id2 == id ? WALK_DEAD : (unsigned)id) << 32);
             else T.B[id] = (unsigned)id2;
-            t++;
         }
     }
     __syncthreads();
@@ -815,15 +863,16 @@ __device__ inline void wg_build_rank_lds(const Bits& img, unsigned* lt, unsigned
     T.ok = 1;
     WALK_STAMP(5);
 #ifdef VLFM_PHASE_TIMING
-    if ((int)blockIdx.x == g_walk_block && threadIdx.x == 0) { g_walk_clk[12] = 2; g_walk_clk[13] = N; g_walk_clk[14] = nb_tot; }
+    if ((int)blockIdx.x == g_walk_block && threadIdx.x == 0) { g_walk_clk[12] = GPIX ? 3 : 2; g_walk_clk[13] = N; g_walk_clk[14] = nb_tot; }
 #endif
 }
 
 // One outer border from (x0, y0) out of the ranked tables.  All threads; returns the number of emitted points (uniform), or -1
 // when the border is not in the tables (nothing was written: the caller lets one lane walk it).
-__device__ inline int wg_emit_border_lds(const Bits& img, const WalkLds& T, unsigned* traced, unsigned* neg, int x0, int y0,
+template <bool GPIX>
+__device__ __forceinline__ int wg_emit_border_lds(const Bits& img, const WalkLds& T, unsigned* traced, unsigned* neg, int x0, int y0,
                                          int method, int2* out, int cap, int* sh) {
-    const int tid = threadIdx.x, nth = blockDim.x;
+    const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63;
     const unsigned* base = img.w;
     const int pw = img.stride;
     const unsigned nb = nbr8_padded(base, pw, x0, y0);
@@ -842,10 +891,17 @@ __device__ inline int wg_emit_border_lds(const Bits& img, const WalkLds& T, unsi
     const unsigned mir = __brev(nb0) >> 24;
     const unsigned rot = ((mir | (mir << 8)) >> 4) & 0xFFu;
     const int s = (3 - __builtin_ctz(rot)) & 7;          // direction of i1 = s_back of state0
+    // the start pixel's table entry: the border pixels of row y0 are ranks rowrank[y0] .. rowrank[y0 + 1] - 1, 64 of them per probe
+    // (every wavefront does the same probe: no exchange)
     const int key0 = x0 | (y0 << 11);
-    const int r0 = v2_rank_of_pixel(T, key0);
-    if ((T.pixxy[r0] & 0x3FFFFF) != key0) return -1;
-    const unsigned am0 = ((unsigned)T.pixxy[r0] >> 22) & 0xFFu;
+    int r0 = -1, xy0 = 0;
+    for (int q = T.rowrank[y0], q1 = T.rowrank[y0 + 1]; q < q1 && r0 < 0; q += 64) {
+        const int v = q + lane < q1 ? T.pixxy[q + lane] : -1;
+        const unsigned long long hit = __ballot(v >= 0 && (v & 0x3FFFFF) == key0);
+        if (hit) { const int l = __builtin_ctzll(hit); r0 = q + l; xy0 = __shfl(v, l, 64); }
+    }
+    if (r0 < 0) return -1;
+    const unsigned am0 = ((unsigned)xy0 >> 22) & 0xFFu;
     if (!((am0 >> s) & 1u)) return -1;                   // i1 is not a border pixel: cannot happen on a traced border
     const int id0 = (int)T.pixbase[r0] + __builtin_popcount(am0 & ((1u << s) - 1u));
     const unsigned w0 = T.B[id0];
@@ -855,29 +911,36 @@ __device__ inline int wg_emit_border_lds(const Bits& img, const WalkLds& T, unsi
     const int L = (int)(T.B[h] >> 16);
     if (L < 2 || d0 >= L) return -1;
     // ---- labels and points: one BORDER PIXEL per lane and step -- its states are consecutive ids, its coordinates and the
-    // directions of its states one table entry (no search from a state back to its pixel)
+    // directions of its states one table entry (no search from a state back to its pixel); four entries requested at a time
     const int pwords = (L + 31) >> 5;
-    for (int r = tid; r < T.nb; r += nth) {
-        const int xy = T.pixxy[r];
-        unsigned am = ((unsigned)xy >> 22) & 0xFFu;
-        if (!am) continue;
-        const int x = xy & 2047, y = (xy >> 11) & 2047;
-        const unsigned nbm = nbr8_padded(base, pw, x, y);
-        for (int i = T.pixbase[r]; am; am &= am - 1, i++) {
-            const unsigned w = T.B[i];
-            if ((int)(w & 0xFFFFu) != h) continue;
-            const int dm = i == h ? 0 : (int)(w >> 16);
-            int pos = d0 - dm;
-            if (pos < 0) pos += L;
-            const int sb = __builtin_ctz(am);
-            const int from = (sb + 1) & 7;
-            const int so = (from + __builtin_ctz(((nbm | (nbm << 8)) >> from) & 0xFFu)) & 7;
-            const int wi = y * pw + (x >> 5);
-            const unsigned m = 1u << (x & 31);
-            atomicOr(&traced[wi], m);
-            if ((unsigned)(so - 1) < (unsigned)sb) atomicOr(&neg[wi], m);
-            if (method == 1) { if (pos < cap) out[pos] = make_int2(x, y); }
-            else if (so != (sb ^ 4)) atomicOr(&T.posflag[pos >> 5], 1u << (pos & 31));
+    for (int rb = tid; rb < T.nb; rb += 4 * nth) {
+        int xy4[4];
+        unsigned short pb4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int r = rb + u * nth; xy4[u] = r < T.nb ? T.pixxy[r] : 0; pb4[u] = r < T.nb ? T.pixbase[r] : (unsigned short)0; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int xy = xy4[u];
+            unsigned am = ((unsigned)xy >> 22) & 0xFFu;
+            if (!am) continue;
+            const int x = xy & 2047, y = (xy >> 11) & 2047;
+            const unsigned nbm = nbr8_padded(base, pw, x, y);
+            for (int i = pb4[u]; am; am &= am - 1, i++) {
+                const unsigned w = T.B[i];
+                if ((int)(w & 0xFFFFu) != h) continue;
+                const int dm = i == h ? 0 : (int)(w >> 16);
+                int pos = d0 - dm;
+                if (pos < 0) pos += L;
+                const int sb = __builtin_ctz(am);
+                const int from = (sb + 1) & 7;
+                const int so = (from + __builtin_ctz(((nbm | (nbm << 8)) >> from) & 0xFFu)) & 7;
+                const int wi = y * pw + (x >> 5);
+                const unsigned m = 1u << (x & 31);
+                atomicOr(&traced[wi], m);
+                if ((unsigned)(so - 1) < (unsigned)sb) atomicOr(&neg[wi], m);
+                if (method == 1) { if (pos < cap) out[pos] = make_int2(x, y); }
+                else if (so != (sb ^ 4)) atomicOr(&T.posflag[pos >> 5], 1u << (pos & 31));
+            }
         }
     }
     __syncthreads();
@@ -893,19 +956,26 @@ __device__ inline int wg_emit_border_lds(const Bits& img, const WalkLds& T, unsi
         total += tot;
     }
     __syncthreads();
-    for (int r = tid; r < T.nb; r += nth) {
-        const int xy = T.pixxy[r];
-        unsigned am = ((unsigned)xy >> 22) & 0xFFu;
-        for (int i = T.pixbase[r]; am; am &= am - 1, i++) {
-            const unsigned w = T.B[i];
-            if ((int)(w & 0xFFFFu) != h) continue;
-            const int dm = i == h ? 0 : (int)(w >> 16);
-            int pos = d0 - dm;
-            if (pos < 0) pos += L;
-            const unsigned fw = T.posflag[pos >> 5];
-            if (!((fw >> (pos & 31)) & 1u)) continue;
-            const int idx = T.posprefix[pos >> 5] + __builtin_popcount(fw & ((1u << (pos & 31)) - 1u));
-            if (idx < cap) out[idx] = make_int2(xy & 2047, (xy >> 11) & 2047);
+    for (int rb = tid; rb < T.nb; rb += 4 * nth) {
+        int xy4[4];
+        unsigned short pb4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int r = rb + u * nth; xy4[u] = r < T.nb ? T.pixxy[r] : 0; pb4[u] = r < T.nb ? T.pixbase[r] : (unsigned short)0; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int xy = xy4[u];
+            unsigned am = ((unsigned)xy >> 22) & 0xFFu;
+            for (int i = pb4[u]; am; am &= am - 1, i++) {
+                const unsigned w = T.B[i];
+                if ((int)(w & 0xFFFFu) != h) continue;
+                const int dm = i == h ? 0 : (int)(w >> 16);
+                int pos = d0 - dm;
+                if (pos < 0) pos += L;
+                const unsigned fw = T.posflag[pos >> 5];
+                if (!((fw >> (pos & 31)) & 1u)) continue;
+                const int idx = T.posprefix[pos >> 5] + __builtin_popcount(fw & ((1u << (pos & 31)) - 1u));
+                if (idx < cap) out[idx] = make_int2(xy & 2047, (xy >> 11) & 2047);
+            }
         }
     }
     __syncthreads();
@@ -914,13 +984,11 @@ __device__ inline int wg_emit_border_lds(const Bits& img, const WalkLds& T, unsi
     return total;
 }
 
-// wg_scan_external with the LDS tables when they fit (arena: what is left of the kernel's LDS behind the window planes)
-__device__ inline void wg_scan_external_lds(const Bits& img, unsigned* traced, unsigned* neg, int method, ContourSink& sink,
-                                            WalkTables& Tglobal, unsigned* arena, unsigned arena_bytes, int* sh) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    WalkLds T;
-    wg_build_rank_lds(img, traced, neg, arena, arena_bytes, Tglobal.wrows, Tglobal.wwords, T, sh);
-    if (!T.ok) { wg_scan_external(img, traced, neg, method, sink, Tglobal, sh); return; }
+// The RETR_EXTERNAL scan over ranked tables (wg_scan_external's loop)
+template <bool GPIX>
+__device__ __forceinline__ void wg_scan_ranked(const Bits& img, const WalkLds& T, unsigned* traced, unsigned* neg, int method,
+                                      ContourSink& sink, int* sh) {
+    const int tid = threadIdx.x;
     int y = 0, x_done = -1;
     int n_fast = 0, n_serial = 0;
     for (int call = 0;; call++) {
@@ -930,7 +998,7 @@ __device__ inline void wg_scan_external_lds(const Bits& img, unsigned* traced, u
         y = fy; x_done = fx;
         const int room = sink.cap_pts - sink.n_pts > 0 ? sink.cap_pts - sink.n_pts : 0;
         if (sink.n_contours == 0) WALK_STAMP(6);
-        int n = wg_emit_border_lds(img, T, traced, neg, fx, fy, method, sink.pts + sink.n_pts, room, sh);
+        int n = wg_emit_border_lds<GPIX>(img, T, traced, neg, fx, fy, method, sink.pts + sink.n_pts, room, sh);
         if (sink.n_contours == 0) WALK_STAMP(7);
         if (n < 0) {
             if (tid == 0) sh[46] = follow_border(img, traced, neg, fx, fy, method, sink.pts + sink.n_pts, room);
@@ -954,8 +1022,22 @@ __device__ inline void wg_scan_external_lds(const Bits& img, unsigned* traced, u
     if (tid == 0) {
         if (n_fast) atomicAdd(&g_walk_paths[0], (unsigned long long)n_fast);
         if (n_serial) atomicAdd(&g_walk_paths[2], (unsigned long long)n_serial);
-        atomicAdd(&g_walk_paths[3], 1ull);
+        atomicAdd(&g_walk_paths[GPIX ? 1 : 3], 1ull);
     }
+}
+
+// wg_scan_external with the ranked tables: everything in LDS when it fits behind the window planes (arena), the per-pixel tables
+// in the global scratch of the fallback form when that is what it takes (large windows), the fallback form itself otherwise.
+__device__ __forceinline__ void wg_scan_external_lds(const Bits& img, unsigned* traced, unsigned* neg, int method, ContourSink& sink,
+                                            WalkTables& Tglobal, unsigned* arena, unsigned arena_bytes, int* sh) {
+    WalkLds T;
+    wg_build_rank_lds<false>(img, traced, neg, arena, arena_bytes, nullptr, nullptr, 0, Tglobal.wrows, Tglobal.wwords, T, sh);
+    if (T.ok) { wg_scan_ranked<false>(img, T, traced, neg, method, sink, sh); return; }
+    const int gcap = min(Tglobal.cap_states, 2 * Tglobal.cap_bp);
+    wg_build_rank_lds<true>(img, traced, neg, arena, arena_bytes, reinterpret_cast<int*>(Tglobal.jd0),
+                            reinterpret_cast<unsigned short*>(Tglobal.pixbase), gcap, Tglobal.wrows, Tglobal.wwords, T, sh);
+    if (T.ok) { wg_scan_ranked<true>(img, T, traced, neg, method, sink, sh); return; }
+    wg_scan_external(img, traced, neg, method, sink, Tglobal, sh);
 }
 
 }  // namespace vlfm
