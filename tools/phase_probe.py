@@ -13,7 +13,8 @@ if "VLFM_LIB_PATH" not in os.environ:   # build the diagnostic library here: onl
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     obj, out = os.path.join(ROOT, "gpurun_out", "obstacle_map_phase.o"), os.path.join(ROOT, "gpurun_out", "libvlfm_amd_phase.so")
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-                           "-DVLFM_PHASE_TIMING", "-c", os.path.join(csrc, "obstacle_map.hip"), "-o", obj])
+                           "-DVLFM_PHASE_TIMING"] + ([f"-DVLFM_CUT_SKIP={os.environ['VLFM_CUT_SKIP']}"] if "VLFM_CUT_SKIP" in os.environ else [])
+                          + ["-c", os.path.join(csrc, "obstacle_map.hip"), "-o", obj])
     objs = [os.path.join(csrc, "build", f) for f in os.listdir(os.path.join(csrc, "build"))
             if f.endswith(".o") and not f.startswith("obstacle_map")]
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, obj] + objs)

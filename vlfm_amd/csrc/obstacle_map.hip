@@ -228,8 +228,10 @@ __device__ inline void win_clear_px(unsigned* plane, const Win& w, long long x, 
     win_clear_span(plane, w, (int)y, (int)x, (int)x);
 }
 
-// cv Line2: DDA between 16.16 endpoints, clipped to the image
-__device__ inline void line2_clear(unsigned* plane, const Win& w, long long x1, long long y1, long long x2, long long y2) {
+// cv Line2: DDA between 16.16 endpoints, clipped to the image.  seg / nseg: only that share of the DDA's steps (the steps are
+// x1 + k, y1 + k * y_step -- exact integer arithmetic, so a share can start anywhere), so that one line can be spread over lanes
+__device__ inline void line2_clear(unsigned* plane, const Win& w, long long x1, long long y1, long long x2, long long y2,
+                                   int seg = 0, int nseg = 1) {
     if (!clip_line((long long)w.S << XY_SHIFT, (long long)w.S << XY_SHIFT, x1, y1, x2, y2)) return;
     long long dx = x2 - x1, dy = y2 - y1;
     const long long j = dx < 0 ? -1 : 0, i = dy < 0 ? -1 : 0;
@@ -251,21 +253,27 @@ __device__ inline void line2_clear(unsigned* plane, const Win& w, long long x1, 
     }
     x1 += XY_ONE >> 1;
     y1 += XY_ONE >> 1;
-    win_clear_px(plane, w, (x2 + (XY_ONE >> 1)) >> XY_SHIFT, (y2 + (XY_ONE >> 1)) >> XY_SHIFT);
+    if (seg == 0) win_clear_px(plane, w, (x2 + (XY_ONE >> 1)) >> XY_SHIFT, (y2 + (XY_ONE >> 1)) >> XY_SHIFT);
+    const int n = ecount + 1;                     // steps k = 0 .. ecount
+    const int k0 = n > 0 ? (int)((long long)n * seg / nseg) : 0;
+    int left = n > 0 ? (int)((long long)n * (seg + 1) / nseg) - k0 : 0;
     if (ax > ay) {
-        x1 >>= XY_SHIFT;
-        while (ecount >= 0) { win_clear_px(plane, w, x1, y1 >> XY_SHIFT); x1++; y1 += y_step; ecount--; }
+        x1 = (x1 >> XY_SHIFT) + k0;
+        y1 += (long long)k0 * y_step;
+        while (left-- > 0) { win_clear_px(plane, w, x1, y1 >> XY_SHIFT); x1++; y1 += y_step; }
     } else {
-        y1 >>= XY_SHIFT;
-        while (ecount >= 0) { win_clear_px(plane, w, x1 >> XY_SHIFT, y1); x1 += x_step; y1++; ecount--; }
+        y1 = (y1 >> XY_SHIFT) + k0;
+        x1 += (long long)k0 * x_step;
+        while (left-- > 0) { win_clear_px(plane, w, x1 >> XY_SHIFT, y1); x1 += x_step; y1++; }
     }
 }
 
 // cv FillConvexPoly for a 16.16 quadrilateral (LINE_8), painting zeros
 // part < 0: everything; part 0..3: only outline edge `part`; part 4: only the interior scanlines (all parts clear bits, so
-// they may run concurrently on different lanes)
+// they may run concurrently on different lanes).  seg / nseg: that share of the edge's DDA steps, or of the interior's scanlines
+// inside the window (rows in front of the share are stepped over edge event by edge event: the edges are linear in between)
 __device__ inline void fill_convex_quad_clear(unsigned* plane, const Win& w, const long long* vx, const long long* vy,
-                                              int part = -1) {
+                                              int part = -1, int seg = 0, int nseg = 1) {
     const int npts = 4, shift = XY_SHIFT;
     const int delta = 1 << shift >> 1;
     struct { int idx, di; long long x, dx; int ye; } edge[2];
@@ -277,7 +285,8 @@ __device__ inline void fill_convex_quad_clear(unsigned* plane, const Win& w, con
         if (vy[i] > ymax) ymax = vy[i];
         if (vx[i] > xmax) xmax = vx[i];
         if (vx[i] < xmin) xmin = vx[i];
-        if (part < 0 || part == i) line2_clear(plane, w, p0x, p0y, vx[i], vy[i]);
+        if (part < 0) line2_clear(plane, w, p0x, p0y, vx[i], vy[i]);
+        else if (part == i) line2_clear(plane, w, p0x, p0y, vx[i], vy[i], seg, nseg);
         p0x = vx[i]; p0y = vy[i];
     }
     if (part >= 0 && part < 4) return;
@@ -285,6 +294,18 @@ __device__ inline void fill_convex_quad_clear(unsigned* plane, const Win& w, con
     ymin = (ymin + delta) >> shift; ymax = (ymax + delta) >> shift;
     if ((int)xmax < 0 || (int)ymax < 0 || (int)xmin >= w.S || (int)ymin >= w.S) return;
     if (ymax > w.S - 1) ymax = w.S - 1;
+    // rows this call paints: the rows of the quadrilateral that lie in the image AND in the window (rows outside the window
+    // paint nothing), then the caller's share of them
+    int ya = (int)ymin > 0 ? (int)ymin : 0, yb = (int)ymax;
+    if (ya < w.oy) ya = w.oy;
+    if (yb > w.oy + w.wn - 1) yb = w.oy + w.wn - 1;
+    if (ya > yb) return;
+    if (nseg > 1) {
+        const int n = yb - ya + 1, a0 = ya;
+        ya = a0 + (int)((long long)n * seg / nseg);
+        yb = a0 + (int)((long long)n * (seg + 1) / nseg) - 1;
+        if (ya > yb) return;
+    }
     edge[0].idx = edge[1].idx = imin;
     int y = (int)ymin;
     edge[0].ye = edge[1].ye = y;
@@ -315,6 +336,17 @@ __device__ inline void fill_convex_quad_clear(unsigned* plane, const Win& w, con
             }
         }
         if (edges < 0) break;
+        if (y < ya) {   // nothing to paint before row ya: on to the next edge event or to ya, whichever comes first
+            int ny = ya;
+            if (edge[0].ye < ny) ny = edge[0].ye;
+            if (edge[1].ye < ny) ny = edge[1].ye;
+            if (ny <= y) ny = y + 1;
+            const long long k = ny - y;
+            edge[0].x += edge[0].dx * k;
+            edge[1].x += edge[1].dx * k;
+            y = ny - 1;
+            continue;
+        }
         if (y >= 0) {
             int left = 0, right = 1;
             if (edge[0].x > edge[1].x) { left = 1; right = 0; }
@@ -328,6 +360,7 @@ __device__ inline void fill_convex_quad_clear(unsigned* plane, const Win& w, con
         }
         edge[0].x += edge[0].dx;
         edge[1].x += edge[1].dx;
+        if (y >= yb) break;
     } while (++y <= (int)ymax);
 }
 
@@ -357,7 +390,9 @@ __device__ inline void circle_clear(unsigned* plane, const Win& w, int cx, int c
 // part < 0: the whole line; parts 0..6 = the four outline edges, the interior, the two end discs (independent: every part
 // only clears bits), so that one line can be spread over seven lanes
 constexpr int THICK_LINE_PARTS = 7;
-__device__ inline void thick_line2_clear(unsigned* plane, const Win& w, int p0x, int p0y, int p1x, int p1y, int part = -1) {
+constexpr int THICK_LINE_SEGS = 4;   // shares per outline edge and of the interior (a 105-px edge on one lane took 50 us)
+__device__ inline void thick_line2_clear(unsigned* plane, const Win& w, int p0x, int p0y, int p1x, int p1y, int part = -1,
+                                         int seg = 0, int nseg = 1) {
     const long long a0x = (long long)p0x << XY_SHIFT, a0y = (long long)p0y << XY_SHIFT;
     const long long a1x = (long long)p1x << XY_SHIFT, a1y = (long long)p1y << XY_SHIFT;
     const double INV = 1. / XY_ONE;
@@ -369,7 +404,7 @@ __device__ inline void thick_line2_clear(unsigned* plane, const Win& w, int p0x,
         const long long dpx = __double2ll_rn(__dmul_rn(dy, r)), dpy = __double2ll_rn(__dmul_rn(dx, r));
         const long long vx[4] = {a0x + dpx, a0x - dpx, a1x - dpx, a1x + dpx};
         const long long vy[4] = {a0y + dpy, a0y - dpy, a1y - dpy, a1y + dpy};
-        if (part < 5) fill_convex_quad_clear(plane, w, vx, vy, part);
+        if (part < 5) fill_convex_quad_clear(plane, w, vx, vy, part, seg, nseg);
     }
     const int rad = (int)((thickness + (XY_ONE >> 1)) >> XY_SHIFT);
     if (part < 0 || part == 5) circle_clear(plane, w, p0x, p0y, rad);
@@ -694,10 +729,17 @@ __global__ __launch_bounds__(1024) void fog_of_war_kernel(const FogParams* __res
     __threadfence_block();
     __syncthreads();
     VLFM_PHASE(0, 5);
-    for (int t = tid; t < n_lines * THICK_LINE_PARTS; t += nth) {
-        const int part = t / n_lines, i = t - part * n_lines;
+    // tasks, part-major: [edge 0 .. 3, interior] x THICK_LINE_SEGS shares, then the two end discs
+    constexpr int kCutTasks = 5 * THICK_LINE_SEGS + 2;
+    for (int t = tid; t < n_lines * kCutTasks; t += nth) {
+        const int p = t / n_lines, i = t - p * n_lines;
+        const int part = p < 5 * THICK_LINE_SEGS ? p / THICK_LINE_SEGS : p - 5 * THICK_LINE_SEGS + 5;
+        const int seg = p < 5 * THICK_LINE_SEGS ? p % THICK_LINE_SEGS : 0;
+#ifdef VLFM_CUT_SKIP   // diagnostic builds only (tools/phase_probe.py): leave parts out to see what each costs
+        if ((VLFM_CUT_SKIP >> part) & 1) continue;
+#endif
         const int4 ln = lines[i];
-        thick_line2_clear(vis, W, ln.x + ox, ln.y + oy, ln.z, ln.w, part);
+        thick_line2_clear(vis, W, ln.x + ox, ln.y + oy, ln.z, ln.w, part, seg, part < 5 ? THICK_LINE_SEGS : 1);
     }
     __syncthreads();
     VLFM_PHASE(0, 6);
