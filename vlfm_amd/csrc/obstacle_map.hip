@@ -612,11 +612,12 @@ __global__ __launch_bounds__(1024) void fog_of_war_kernel(const FogParams* __res
     LdsBitmap bm;
     bm.solid = cone; bm.parity = par; bm.rows = S; bm.cols = S; bm.words = words;
     bm.ox = ox; bm.oy = oy; bm.wrows = wn; bm.wcols = wn;
-    for (int i = tid; i < P.n_poly; i += nth) {
-        const int j = i == 0 ? P.n_poly - 1 : i - 1;
+    // (eight lanes per edge: raster.h, raster_edge_shared -- the cone's two straight sides are 100 pixels long)
+    for (int t = tid; t < P.n_poly * 8; t += nth) {
+        const int i = t >> 3, j = i == 0 ? P.n_poly - 1 : i - 1;
         const long long ax = P.poly[2 * j], ay = (P.poly[2 * j + 1] + (XY_ONE >> 1)) >> XY_SHIFT;
         const long long bx = P.poly[2 * i], by = (P.poly[2 * i + 1] + (XY_ONE >> 1)) >> XY_SHIFT;
-        raster_edge(bm, ax, (int)ay, bx, (int)by);
+        raster_edge_shared(bm, ax, (int)ay, bx, (int)by, t & 7, 8);
     }
     __syncthreads();
     resolve_rows(bm, tid, nth);
@@ -797,9 +798,11 @@ __global__ __launch_bounds__(1024) void fog_of_war_kernel(const FogParams* __res
         fb.solid = fill; fb.parity = par; fb.rows = wn; fb.cols = wn; fb.words = words;  // window-local polygon
         const int n = clen[best];
         const int2* cp = pts + cstart[best];
-        for (int i = tid; i < n; i += nth) {
+        const int G = n * 8 <= nth ? 8 : (n * 4 <= nth ? 4 : (n * 2 <= nth ? 2 : 1));   // lanes per edge (raster_edge_shared)
+        for (int t = tid; t < n * G; t += nth) {
+            const int i = t / G;
             const int2 a = cp[i == 0 ? n - 1 : i - 1], b = cp[i];
-            raster_edge(fb, (long long)a.x << XY_SHIFT, a.y, (long long)b.x << XY_SHIFT, b.y);
+            raster_edge_shared(fb, (long long)a.x << XY_SHIFT, a.y, (long long)b.x << XY_SHIFT, b.y, t - i * G, G);
         }
         __syncthreads();
         resolve_rows(fb, tid, nth);

@@ -138,6 +138,59 @@ __device__ inline void raster_edge(const LdsBitmap& bm, long long ax, int ay, lo
     }
 }
 
+// raster_edge by a GROUP of lanes: lane g of G takes every G-th step of the boundary line and every G-th scanline of the edge.
+// The line iterator has a closed form -- before major step i it has made m_i = max(0, ceil((2 dy i - dx) / (2 dx))) minor steps
+// (err_i = dx - 2 dy (i + 1) + 2 dx m_i, and a minor step is taken iff err_i < 0; checked against the iterative form for all
+// dx, dy < 80) -- and the crossings are linear in y already, so nothing in an edge is sequential: the two 100-pixel sides of the
+// fog-of-war cone were 22 us on one lane each.
+__device__ inline void raster_edge_shared(const LdsBitmap& bm, long long ax, int ay, long long bx, int by, int g, int G) {
+    const long long tx0 = (ax + (XY_ONE >> 1)) >> XY_SHIFT, tx1 = (bx + (XY_ONE >> 1)) >> XY_SHIFT;
+    {
+        long long x0 = tx0, y0 = ay, x1 = tx1, y1 = by;
+        bool ok = true;
+        if ((unsigned long long)x0 >= (unsigned long long)bm.cols || (unsigned long long)x1 >= (unsigned long long)bm.cols ||
+            (unsigned long long)y0 >= (unsigned long long)bm.rows || (unsigned long long)y1 >= (unsigned long long)bm.rows)
+            ok = clip_line(bm.cols, bm.rows, x0, y0, x1, y1);
+        if (ok) {
+            int dx = (int)(x1 - x0), dy = (int)(y1 - y0);
+            int sx = 1, sy = 1;
+            long long px = x0, py = y0;
+            if (dx < 0) { dx = -dx; dy = -dy; px = x1; py = y1; }
+            if (dy < 0) { dy = -dy; sy = -1; }
+            const bool vert = dy > dx;
+            if (vert) { int t = dx; dx = dy; dy = t; t = sx; sx = sy; sy = t; }
+            const int count = dx + 1;
+            for (int i = g; i < count; i += G) {
+                const int num = 2 * dy * i - dx;
+                const int m = num <= 0 ? 0 : (int)(((unsigned)num + 2u * (unsigned)dx - 1u) / (2u * (unsigned)dx));
+                if (!vert) bm_or(bm, (int)py + sy * m, (int)px + sx * i);
+                else bm_or(bm, (int)py + sx * i, (int)px + sy * m);
+            }
+        }
+    }
+    if (ay == by) return;
+    const long long dxdy = (bx - ax) / (long long)(by - ay);  // truncating, same value for either orientation
+    int y0, y1;
+    long long xs;
+    if (ay < by) { y0 = ay; y1 = by; xs = ax; } else { y0 = by; y1 = ay; xs = bx; }
+    int ys = y0 < 0 ? 0 : y0;
+    int ye = y1 > bm.rows ? bm.rows : y1;  // half-open [y0, y1), clipped to the image
+    if (ys < bm.oy) ys = bm.oy;            // ... and to the window rows
+    if (ye > bm.oy + bm.win_rows()) ye = bm.oy + bm.win_rows();
+    for (int y = ys + g; y < ye; y += G) {
+        const long long c = xs + (long long)(y - y0) * dxdy;
+        const long long px = c >> XY_SHIFT;  // floor
+        if ((c & (XY_ONE - 1)) == 0 && px >= 0 && px < bm.cols) bm_or(bm, y, (int)px);
+        long long first = px + 1;  // first pixel strictly right of the crossing
+        if (first < 0) first = 0;
+        if (first < bm.cols) {
+            long long lf = first - bm.ox;  // a toggle left of the window flips the whole window row
+            if (lf < 0) lf = 0;
+            if (lf < bm.win_cols()) bm_toggle_local(bm, y - bm.oy, (int)lf);
+        }
+    }
+}
+
 // After all edges: coverage[row] = prefix_xor(parity[row]) | solid[row], written back into `solid`.
 __device__ inline void resolve_rows(const LdsBitmap& bm, int tid, int nthreads) {
     for (int y = tid; y < bm.win_rows(); y += nthreads) {
