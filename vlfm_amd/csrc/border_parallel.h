@@ -444,16 +444,18 @@ __device__ __forceinline__ int row_next_start_lane(const Bits& img, const unsign
 }
 
 // The next border start in raster order at or after row y (right of x_done in row y itself), by the whole workgroup: one row per
-// lane (labels only change between searches, so the rows can be judged independently), the earliest hit wins.  One barrier pair
+// lane (labels only change between searches, so the rows can be judged independently), the earliest hit wins.  One barrier
 // per search -- the block-wise, row-per-wavefront search this replaces spent 18 us on the LAST search of a 450-row window
 // (nothing left to find: 7 blocks x 3 barriers), in each of the four scans of a step.  `slot` alternates between calls
 // (sh[44], sh[45]).
 __device__ __forceinline__ bool wg_next_start(const Bits& img, const unsigned* traced, const unsigned* neg, int y, int x_done, int* sh,
-                                     int slot, int& fx, int& fy) {
+                                              int slot, int& fx, int& fy) {
     const int tid = threadIdx.x, lane = tid & 63, nth = blockDim.x;
     int* best = &sh[44 + (slot & 1)];
-    if (tid == 0) *best = 0x7FFFFFFF;
-    __syncthreads();
+    if (slot == 0) {                      // first search of a scan: both slots
+        if (tid == 0) { sh[44] = 0x7FFFFFFF; sh[45] = 0x7FFFFFFF; }
+        __syncthreads();
+    }
     for (int r0 = y; r0 < img.rows; r0 += nth) {
         const int r = r0 + tid;
         const int x = r < img.rows ? row_next_start_lane(img, traced, neg, r, r == y ? x_done : -1) : -1;
@@ -465,6 +467,9 @@ __device__ __forceinline__ bool wg_next_start(const Bits& img, const unsigned* t
     }
     __syncthreads();
     const int v = *best;
+    // the slot of the NEXT search is reset now: every path from here to that search's atomicMin passes a barrier (tracing a
+    // border always does), and nobody reads that slot before
+    if (tid == 0) sh[44 + ((slot + 1) & 1)] = 0x7FFFFFFF;
     if (v == 0x7FFFFFFF) return false;
     fx = v & 2047; fy = v >> 11;
     return true;
@@ -945,17 +950,23 @@ __device__ __forceinline__ int wg_emit_border_lds(const Bits& img, const WalkLds
     }
     __syncthreads();
     if (method == 1) return L;
-    // CHAIN_APPROX_SIMPLE: ordered compaction through the position flags
+    // CHAIN_APPROX_SIMPLE: ordered compaction through the position flags.  Borders of up to 256 states (the fragments a fog-of-war
+    // window is cut into: a dozen per window, each of them used to pay for a workgroup scan) add the few flag words up themselves.
+    const bool short_border = pwords <= 8;
     int total = 0;
-    for (int w0i = 0; w0i < pwords; w0i += nth) {        // (one pass unless the border has more than 32 768 states)
-        const int wi = w0i + tid;
-        const int c = wi < pwords ? __builtin_popcount(T.posflag[wi]) : 0;
-        int ex, dummy_ex, tot, dummy_tot;
-        wg_scan2(c, 0, sh, ex, dummy_ex, tot, dummy_tot);
-        if (wi < pwords) T.posprefix[wi] = total + ex;
-        total += tot;
+    if (short_border) {
+        for (int wi = 0; wi < pwords; wi++) total += __builtin_popcount(T.posflag[wi]);
+    } else {
+        for (int w0i = 0; w0i < pwords; w0i += nth) {        // (one pass unless the border has more than 32 768 states)
+            const int wi = w0i + tid;
+            const int c = wi < pwords ? __builtin_popcount(T.posflag[wi]) : 0;
+            int ex, dummy_ex, tot, dummy_tot;
+            wg_scan2(c, 0, sh, ex, dummy_ex, tot, dummy_tot);
+            if (wi < pwords) T.posprefix[wi] = total + ex;
+            total += tot;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     for (int rb = tid; rb < T.nb; rb += 4 * nth) {
         int xy4[4];
         unsigned short pb4[4];
@@ -973,7 +984,9 @@ __device__ __forceinline__ int wg_emit_border_lds(const Bits& img, const WalkLds
                 if (pos < 0) pos += L;
                 const unsigned fw = T.posflag[pos >> 5];
                 if (!((fw >> (pos & 31)) & 1u)) continue;
-                const int idx = T.posprefix[pos >> 5] + __builtin_popcount(fw & ((1u << (pos & 31)) - 1u));
+                int idx = __builtin_popcount(fw & ((1u << (pos & 31)) - 1u));
+                if (short_border) { for (int wi = 0; wi < (pos >> 5); wi++) idx += __builtin_popcount(T.posflag[wi]); }
+                else idx += T.posprefix[pos >> 5];
                 if (idx < cap) out[idx] = make_int2(xy & 2047, (xy >> 11) & 2047);
             }
         }
@@ -1016,8 +1029,8 @@ __device__ __forceinline__ void wg_scan_ranked(const Bits& img, const WalkLds& T
         }
         sink.n_contours++;
         sink.n_pts += n;
-        wg_sync_global();
     }
+    wg_sync_global();     // the points and the contour list (global memory) for whoever reads them next in this workgroup
     WALK_STAMP(8);
     if (tid == 0) {
         if (n_fast) atomicAdd(&g_walk_paths[0], (unsigned long long)n_fast);

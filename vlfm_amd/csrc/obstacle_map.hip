@@ -1198,11 +1198,27 @@ __global__ __launch_bounds__(1024) void frontier_kernel(const FogParams* __restr
     for (int i = tid; i < npts_all; i += nth) {
         const int2 p = pts[i];
         unsigned any = 0;
-        for (int dy = -1; dy <= 1; dy++) {
-            const int yy = reflect101(p.y + dy, S);
-            for (int dx = -1; dx <= 1; dx++) {
-                const int xx = reflect101(p.x + dx, S);
-                any |= bit_get(navp, stride, S, S, xx, yy) & (1u ^ bit_get(ed, stride, S, S, xx, yy));
+        if (p.x >= 1 && p.x + 1 < S && p.y >= 1 && p.y + 1 < S) {
+            // interior point (all but the map's rim): the 3 x 3 cells are bits x-1 .. x+1 of three rows -- six 64-bit windows
+            // requested together (bit_get per cell was 18 dependent global loads)
+            const int px = p.x - 1, wi = px >> 5, sh = px & 31;
+            unsigned long long nv[3], ev[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const size_t o = (size_t)(p.y - 1 + r) * stride + wi;
+                const bool two = wi + 1 < stride;
+                nv[r] = (unsigned long long)navp[o] | (two ? (unsigned long long)navp[o + 1] << 32 : 0ull);
+                ev[r] = (unsigned long long)ed[o] | (two ? (unsigned long long)ed[o + 1] << 32 : 0ull);
+            }
+#pragma unroll
+            for (int r = 0; r < 3; r++) any |= (unsigned)((nv[r] & ~ev[r]) >> sh) & 7u;
+        } else {
+            for (int dy = -1; dy <= 1; dy++) {
+                const int yy = reflect101(p.y + dy, S);
+                for (int dx = -1; dx <= 1; dx++) {
+                    const int xx = reflect101(p.x + dx, S);
+                    any |= bit_get(navp, stride, S, S, xx, yy) & (1u ^ bit_get(ed, stride, S, S, xx, yy));
+                }
             }
         }
         bad[i] = any ? 0 : 1;
@@ -1306,11 +1322,16 @@ __global__ __launch_bounds__(1024) void frontier_kernel(const FogParams* __restr
         // all segment lengths of all pieces at once (piece f owns seg[off[f] .. off[f] + m_f - 1)), then one lane PER PIECE adds
         // them up -- 16 pieces at a time instead of one (17 pieces took 70 us, two barriers each)
         __shared__ int sh_off[257];
+        __shared__ int sh_scan[32];
         const int npc = np < 256 ? np : 256;
-        if (tid == 0) {
-            int o = 0;
-            for (int f = 0; f < npc; f++) { sh_off[f] = o; const int m = pieces[6 * f + 3] + pieces[6 * f + 5]; o += m >= 2 ? m - 1 : 0; }
-            sh_off[npc] = o;
+        {   // segment offsets of the pieces: one piece per lane + a workgroup scan (one lane reading every piece's lengths from
+            // global memory in turn was most of this phase: 20 us for 17 pieces)
+            int mine = 0;
+            if (tid < npc) { const int m = pieces[6 * tid + 3] + pieces[6 * tid + 5]; mine = m >= 2 ? m - 1 : 0; }
+            int ex, ex2, tot, tot2;
+            wg_scan2(mine, 0, sh_scan, ex, ex2, tot, tot2);
+            if (tid < npc) sh_off[tid] = ex;
+            if (tid == 0) sh_off[npc] = tot;
         }
         __syncthreads();
         const int total = sh_off[npc];
@@ -1324,9 +1345,12 @@ __global__ __launch_bounds__(1024) void frontier_kernel(const FogParams* __restr
             }
         }
         __syncthreads();
+        // one lane per piece (pieces dealt round-robin to the wavefronts, so that up to 16 x 64 of them run at once); the sums are
+        // sequential (np.cumsum's rounding order) but the LDS reads are not: eight segment lengths are requested at a time
         const int nwaves = (nth + 63) >> 6;
-        for (int f = staged ? wave : 0; f < np; f += staged ? nwaves : 1) {
-            if (staged ? lane != 0 : tid != 0) continue;
+        for (int f0 = 0; f0 < np; f0 += staged ? nth : 1) {
+            const int f = staged ? f0 + (lane * nwaves + wave) : f0;
+            if (staged ? f >= np : tid != 0) continue;
             const int* pc = pieces + 6 * f;
             const int m = pc[3] + pc[5];
             const double* sg = seg + (staged ? sh_off[f] : 0);
@@ -1335,16 +1359,42 @@ __global__ __launch_bounds__(1024) void frontier_kernel(const FogParams* __restr
                 if (m == 1) { const int2 p2 = q(pc, 0); ox_ = p2.x; oy_ = p2.y; }
             } else {
                 double totlen = 0;
-                for (int k = 0; k + 1 < m; k++) totlen = __dadd_rn(totlen, staged ? sg[k] : seglen(pc, k));
+                if (staged) {
+                    for (int k0 = 0; k0 + 1 < m; k0 += 8) {
+                        double v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) v[u] = k0 + u + 1 < m ? sg[k0 + u] : 0.0;
+#pragma unroll
+                        for (int u = 0; u < 8; u++) if (k0 + u + 1 < m) totlen = __dadd_rn(totlen, v[u]);
+                    }
+                } else {
+                    for (int k = 0; k + 1 < m; k++) totlen = __dadd_rn(totlen, seglen(pc, k));
+                }
                 const double half = totlen / 2;
                 double cum = 0, upto = 0, sl = 0;
                 int idx = 0;
                 bool found = false;
-                for (int k = 0; k + 1 < m; k++) {
-                    const double l = staged ? sg[k] : seglen(pc, k);
-                    const double c2 = __dadd_rn(cum, l);
-                    if (c2 > half) { idx = k; upto = k > 0 ? cum : 0; sl = l; found = true; break; }
-                    cum = c2;
+                if (staged) {
+                    for (int k0 = 0; k0 + 1 < m && !found; k0 += 8) {
+                        double v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) v[u] = k0 + u + 1 < m ? sg[k0 + u] : 0.0;
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            if (!found && k0 + u + 1 < m) {
+                                const double c2 = __dadd_rn(cum, v[u]);
+                                if (c2 > half) { idx = k0 + u; upto = idx > 0 ? cum : 0; sl = v[u]; found = true; }
+                                else cum = c2;
+                            }
+                        }
+                    }
+                } else {
+                    for (int k = 0; k + 1 < m; k++) {
+                        const double l = seglen(pc, k);
+                        const double c2 = __dadd_rn(cum, l);
+                        if (c2 > half) { idx = k; upto = k > 0 ? cum : 0; sl = l; found = true; break; }
+                        cum = c2;
+                    }
                 }
                 if (!found) { idx = 0; upto = 0; sl = staged ? sg[0] : seglen(pc, 0); }
                 const double prop = __ddiv_rn(__dsub_rn(half, upto), sl);
