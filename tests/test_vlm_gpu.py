@@ -284,8 +284,10 @@ def test_vit_fast_path_full_geometry_vs_plain(gpu_device):
 
 
 def test_qformer_split_kv_projection_is_f32_grade(gpu_device):
-    """Cross-attention K/V projection of f16 tokens through the exact 3-way weight split (three f16 x f16 -> f32 GEMMs)
-    against the plain f32 GEMM path and against f64: not less accurate than the f32 GEMM."""
+    """Cross-attention K/V projection of f16 tokens through the split weights (f16 x f16 -> f32 GEMMs) against the plain f32 GEMM
+    path and against f64, with three pieces (exact weights) and with two (the product default: 22-23 of 24 bits): not less
+    accurate than the f32 GEMM, and within 1e-6 of the result's scale of the f32 result."""
+    from vlfm_amd.vlm import blip2itm
     from vlfm_amd.vlm.blip2itm import Blip2ITCConfig, Blip2ITCModel
 
     cfg = Blip2ITCConfig(image_size=56, patch_size=14, v_hidden=176, v_layers=1, v_heads=2, v_mlp=352, q_hidden=64,
@@ -301,25 +303,49 @@ def test_qformer_split_kv_projection_is_f32_grade(gpu_device):
     m.to(gpu_device)
     m.split_kv_min_rows = 0
     tokens16 = (torch.randn(6, 17, 176, generator=g) * 2).half()
-    with torch.inference_mode():
-        want = ref64.query_features(tokens16.double())
-        m.split_kv = True
-        split = m.query_features(tokens16.to(gpu_device)).double().cpu()
-        m.split_kv = False
-        plain = m.query_features(tokens16.to(gpu_device)).double().cpu()
-    e_split, e_plain = (split - want).abs().max(), (plain - want).abs().max()
-    assert e_split <= 5e-5 and e_plain <= 5e-5, (float(e_split), float(e_plain))
-    assert e_split <= 2.0 * e_plain + 1e-6   # f32-grade
-    cross = [l.crossattention for l in m.q_layers if l.crossattention is not None]
-    w1t, w2t, w3t, _ = m._kv_all            # all cross-attention layers, [K_0 | V_0 | K_1 | V_1 ...]
-    rec = w1t.double() + w2t.double() / 2048 + w3t.double() / 2048 ** 2
-    full = torch.cat([torch.cat([c.key.weight, c.value.weight]) for c in cross]).detach().double().t()
-    assert float((rec - full).abs().max()) <= 1e-12    # the three f16 pieces carry the f32 weights (2^-33 relative)
-    # the per-layer form of the same projection (used when a caller passes kv= directly)
-    k, v = cross[0]._project_kv_f16(tokens16.to(gpu_device))
-    want_k = torch.nn.functional.linear(tokens16.double(), cross[0].key.weight.detach().double().cpu(),
-                                        cross[0].key.bias.detach().double().cpu())
-    assert (k.double().cpu() - want_k).abs().max() <= 2e-5
+    default_pieces = blip2itm.KV_SPLIT_PIECES
+    assert default_pieces == 2
+    try:
+        with torch.inference_mode():
+            want = ref64.query_features(tokens16.double())
+            m.split_kv = False
+            plain = m.query_features(tokens16.to(gpu_device)).double().cpu()
+            e_plain = (plain - want).abs().max()
+            for pieces in (3, 2):
+                blip2itm.KV_SPLIT_PIECES = pieces
+                m.split_kv = True
+                split = m.query_features(tokens16.to(gpu_device)).double().cpu()
+                e_split = (split - want).abs().max()
+                assert e_split <= 5e-5 and e_plain <= 5e-5, (pieces, float(e_split), float(e_plain))
+                assert e_split <= 2.0 * e_plain + 1e-6, (pieces, float(e_split), float(e_plain))   # f32-grade
+        cross = [l.crossattention for l in m.q_layers if l.crossattention is not None]
+        w1t, w2t, w3t, _ = m._kv_all            # all cross-attention layers, [K_0 | V_0 | K_1 | V_1 ...]
+        full = torch.cat([torch.cat([c.key.weight, c.value.weight]) for c in cross]).detach().double().t()
+        rec3 = w1t.double() + w2t.double() / 2048 + w3t.double() / 2048 ** 2
+        assert float((rec3 - full).abs().max()) <= 1e-12    # the three f16 pieces carry the f32 weights (2^-33 relative)
+        rec2 = w1t.double() + w2t.double() / 2048
+        # two pieces: one f32 rounding of the weight (plus f16's subnormal floor of the second piece, 2^-25 / 2048 absolute)
+        assert bool(((rec2 - full).abs() <= 2.0 ** -22 * full.abs() + 2.0 ** -35).all())
+        # the projection itself at the Q-Former's REAL contraction length (1408) against f64 and against the f32 GEMM
+        x16 = (torch.randn(4096, 1408, generator=g) * 1.5).half().to(gpu_device)
+        w = (torch.randn(1536, 1408, generator=g) * 0.05).to(gpu_device)
+        b = torch.randn(1536, generator=g).to(gpu_device)
+        want = torch.nn.functional.linear(x16.double(), w.double(), b.double())
+        f32 = torch.nn.functional.linear(x16.float(), w, b).double()
+        pieces3 = tuple(t.t() for t in blip2itm._exact_split3(w))
+        scale = float(want.abs().max())
+        for pieces in (3, 2):
+            got = blip2itm._split_gemm(x16, pieces3, b, n_pieces=pieces).double()
+            e_got, e_f32 = float((got - want).abs().max()), float((f32 - want).abs().max())
+            assert e_got <= 2.0 * e_f32 + 1e-6 * scale, (pieces, e_got, e_f32, scale)
+            assert float((got - f32).abs().max()) <= 1e-6 * scale + 2.0 * e_f32, (pieces, float((got - f32).abs().max()), scale)
+        # the per-layer form of the same projection (used when a caller passes kv= directly)
+        k, v = cross[0]._project_kv_f16(tokens16.to(gpu_device))
+        want_k = torch.nn.functional.linear(tokens16.double(), cross[0].key.weight.detach().double().cpu(),
+                                            cross[0].key.bias.detach().double().cpu())
+        assert (k.double().cpu() - want_k).abs().max() <= 2e-5
+    finally:
+        blip2itm.KV_SPLIT_PIECES = default_pieces
 
 
 def test_blip2_full_geometry_fp16_hip_path_vs_fp32_on_the_gpu(gpu_device):
