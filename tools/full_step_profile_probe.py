@@ -18,6 +18,7 @@ sim = BatchedEpisodes(E, device=dev, blip2=BLIP2ITM(device=dev, allow_random_ini
                       sightings=ScriptedSightings(**bench.SIGHTING_SCRIPT), scripted_masks=True,
                       pointnav=WrappedPointNavResNetPolicy(None, device=dev, n_envs=E, discrete_actions=True))
 sim.fast_forward(40)
+sim.warm_up_segmenter()
 sim.prepare(N + 4)
 for _ in range(4): sim.step()
 torch.cuda.synchronize()
