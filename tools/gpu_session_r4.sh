@@ -29,7 +29,8 @@ python tools/rocprof_tail.py /tmp/prof_gd/p_results.db $(cat /tmp/gdino_window_m
 (timeout 300 python tools/gdino_sections_probe.py 64 1 split 2>&1 | grep -v amdgpu.ids) > $O/r04_gdino_sections_b64.txt
 (timeout 300 python tools/gemm_f32_probe.py 2>&1 | grep -v amdgpu.ids) > $O/r04_gemm_f32_probe.txt
 (timeout 400 python tools/full_step_profile_probe.py 64 12 2>&1 | grep -v amdgpu.ids | head -60) > $O/r04_full_step_host_profile_e64.txt
-(timeout 300 python tools/full_step_parts_probe.py 128 2>&1 | grep -v amdgpu.ids | tail -6) > $O/r04_full_step_parts_e128.txt
+(timeout 500 python tools/full_step_parts_probe.py 128 2>&1 | grep -v amdgpu.ids | tail -6) > $O/r04_full_step_parts_e128.txt
 (timeout 200 python tools/sam_probe.py 32 2>&1 | grep -v amdgpu.ids | tail -1) > $O/r04_mobile_sam_b32.txt
+(timeout 300 python tools/phase_probe.py 256 150 2>&1 | grep -v amdgpu.ids | tail -24) > $O/r04_obstacle_phase_probe_lds_tables.txt
 find gpurun_out -name "*.db" -size +20M -delete
 ls $O
