@@ -630,6 +630,9 @@ class BLIP2ITM:
 
         self.device = require_gpu(device)
         _lib.lib()
+        from . import ops as _ops
+
+        _ops.use_tuned_gemms()     # the library GEMMs' per-shape solutions measured on this image (tools/tune_gemms.py), if recorded
         self.cfg = config or Blip2ITCConfig()
         self.tokenizer = None
         model_dir = model_dir or os.environ.get("BLIP2ITM_MODEL_DIR")

@@ -367,3 +367,34 @@ def linear_f32(x: torch.Tensor, weight: torch.Tensor, bias=None, act=None, resid
                                            hi.data_ptr() if hi is not None else None, lo.data_ptr() if lo is not None else None,
                                            gemm_f32_overflow_flag(x.device, owner).data_ptr(), _stream()), "gemm_f32_nt")
     return out.view(*lead, N)
+
+
+_tuned_gemms_state = None
+
+
+def use_tuned_gemms() -> bool:
+    """Library GEMMs (the ViT's qkv / projection / fc2 go to hipBLASLt) through the solutions PyTorch's TunableOp measured to be the
+    fastest per shape on this image: ``vlfm_amd/tunableop_results.csv``, written by ``tools/tune_gemms.py`` (no tuning happens at
+    run time; shapes that are not in the file, or a file recorded by other library versions, take the library's own heuristic).
+    ``VLFM_TUNED_GEMMS=0`` switches it off."""
+    global _tuned_gemms_state
+    if _tuned_gemms_state is None:
+        import os
+
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tunableop_results.csv")
+        ok = False
+        if os.environ.get("VLFM_TUNED_GEMMS", "1") != "0" and os.path.exists(path) and torch.cuda.is_available():
+            try:
+                import torch.cuda.tunable as tunable
+
+                tunable.enable(True)
+                tunable.tuning_enable(False)
+                tunable.set_filename(path)
+                ok = bool(tunable.read_file(path))
+            except Exception as exc:  # noqa: BLE001 -- an optional speed-up: say so and go on with the library's heuristic
+                import warnings
+
+                warnings.warn(f"tuned GEMM solutions not loaded ({type(exc).__name__}: {exc})")
+                ok = False
+        _tuned_gemms_state = ok
+    return _tuned_gemms_state
