@@ -241,3 +241,24 @@ def test_lavis_artefacts_load_strictly_and_give_the_hf_ports_scores(vit_in_file)
         both = dict(sd); both["visual_encoder.cls_token"] = vit["cls_token"]
         with pytest.raises(KeyError, match="twice"):
             Blip2ITCModel(cfg).load_lavis_state_dict(both, vit)
+
+
+def test_tuned_gemm_table_is_well_formed_and_optional():
+    """vlfm_amd/tunableop_results.csv (tools/tune_gemms.py): TunableOp's validators + one solution per library-GEMM shape of the
+    BLIP-2 forward at the benchmark's batch sizes; loading it is optional (no GPU here: use_tuned_gemms() says no and does not raise)."""
+    import os
+
+    import vlfm_amd
+    from vlfm_amd.vlm import ops
+
+    path = os.path.join(os.path.dirname(vlfm_amd.__file__), "tunableop_results.csv")
+    rows = [line.strip().split(",") for line in open(path) if line.strip()]
+    validators = {r[1] for r in rows if r[0] == "Validator"}
+    assert {"PT_VERSION", "HIPBLASLT_VERSION", "ROCBLAS_VERSION", "GCN_ARCH_NAME"} <= validators
+    shapes = {r[1] for r in rows if r[0] != "Validator"}
+    tokens = 256 * 257                                       # the headline: 256 images x 257 tokens
+    for n, k in ((4224, 1408), (1408, 1408), (1408, 6144)):  # qkv, projection, fc2 of ViT-g
+        assert f"tn_{n}_{tokens}_{k}_ld_{k}_{k}_{n}" in shapes
+    assert all(len(r) == 4 and float(r[3]) > 0 for r in rows if r[0] != "Validator")
+    if not torch.cuda.is_available():
+        assert ops.use_tuned_gemms() is False

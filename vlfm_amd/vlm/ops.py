@@ -387,9 +387,12 @@ def use_tuned_gemms() -> bool:
             try:
                 import torch.cuda.tunable as tunable
 
+                import tempfile
+
                 tunable.enable(True)
                 tunable.tuning_enable(False)
-                tunable.set_filename(path)
+                # TunableOp writes its table back to ITS file name when the process exits: that must not be the package's file
+                tunable.set_filename(os.path.join(tempfile.gettempdir(), f"vlfm_amd_tunableop_{os.getpid()}.csv"))
                 ok = bool(tunable.read_file(path))
             except Exception as exc:  # noqa: BLE001 -- an optional speed-up: say so and go on with the library's heuristic
                 import warnings
