@@ -341,3 +341,31 @@ def test_hoisted_reciprocal_division_equals_the_ieee_division(gpu_device):
             _lib.check(L.vlfm_selftest_div_exact(d_a.data_ptr(), d_a.numel(), float(fx), bad.data_ptr(),
                                                  torch.cuda.current_stream().cuda_stream), "selftest_div_exact")
             assert int(bad.item()) == 0, (fx, k, int(bad.item()))
+
+
+@pytest.mark.gpu
+def test_lds_follower_on_tall_and_degenerate_planes(gpu_device):
+    """Planes taller than the workgroup (the start search walks the rows in blocks of 1024 lanes, the row-rank table has more than
+    1024 entries), a plane of isolated pixels only (no state at all), an empty plane and a full one: same chains as
+    cv2.findContours, both methods."""
+    from oracle import cv
+
+    rng = np.random.default_rng(31)
+    tall = np.zeros((2, 1500, 40), np.uint8)
+    tall[0] = rng.uniform(size=(1500, 40)) < 0.45
+    tall[1, 5:1495, 3:37] = 1
+    tall[1, 700:720, 10:30] = 0
+    tall[1, 1100:1103, 0:40] = 0          # splits the solid in two components, the second one starting below row 1024
+    specks = np.zeros((3, 64, 96), np.uint8)
+    specks[0, ::3, ::5] = 1               # isolated pixels only
+    specks[2] = 1                         # full plane
+    for img in (tall, specks):
+        for method in (1, 2):
+            _walk_paths()
+            got = _gpu_contours_wg(img, method, gpu_device, cap_p=1 << 15, cap_c=8192)
+            for p in range(img.shape[0]):
+                want, _ = cv.findContours(img[p], cv.RETR_EXTERNAL, method)
+                assert len(got[p]) == len(want), (img.shape, method, p, len(got[p]), len(want))
+                for g, w in zip(got[p], want):
+                    assert np.array_equal(g, w.reshape(-1, 2))
+            assert _walk_paths()[2] == 0      # no border needed the one-lane walk
