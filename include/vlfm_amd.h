@@ -475,7 +475,7 @@ int vlfm_find_contours_external(const uint32_t* d_img, int planes, int rows, int
 
 /* The same result from ONE 1024-thread workgroup per plane (csrc/border_parallel.h: successor tables + list ranking on a padded
  * LDS copy) -- the form the obstacle-map kernels use on their windows.  The plane must fit the LDS window
- * (3 * (rows + 2) * (ceil(cols/32) + 2) * 4 <= 144 KB and rows * ceil(cols/32) <= 65535), else VLFM_ERR_CAPACITY.
+ * (3 * (rows + 2) * ((ceil(cols/32) + 2) | 1) * 4 <= 144 KB and rows * ceil(cols/32) <= 65535), else VLFM_ERR_CAPACITY.
  * d_scratch: vlfm_find_contours_wg_scratch_bytes(...) bytes.  method | 0x100 keeps the follower's tables in global memory (the
  * fallback form of the map kernels, for windows whose tables do not fit the LDS behind the window planes); without the flag the
  * tables live in LDS and every border of the plane is ranked at once (the form the map kernels use when it fits).
