@@ -221,6 +221,106 @@ __global__ __launch_bounds__(THREADS) void window_attention_f32_kernel(const flo
     for (int c = 0; c < 8; c++) orow[c] = make_float4(o[4 * c] * inv, o[4 * c + 1] * inv, o[4 * c + 2] * inv, o[4 * c + 3] * inv);
 }
 
+
+// The same attention on the matrix cores, in exact f32 (v_mfma_f32_32x32x2_f32: every product and every accumulation is an f32
+// operation, as on the vector ALU -- the vector form above is bound by the f32 VALU at ~34 TFLOP/s on the 196-token windows).
+// One workgroup per (window, head); K (rows padded to 33 floats: 32 lanes read one column of 32 rows) and V (row-major) of the
+// window in LDS; a wavefront owns 32 queries at a time.  S^T = K Q^T with the keys as the M index: in the 32 x 32 accumulator
+// layout a lane then holds, for ONE query (column lane & 31), the scores of 16 keys per 32-key tile -- the softmax is lane-local
+// plus one exchange with lane ^ 32, and the probabilities are already the B operand of O^T = V^T P^T: accumulator register r of a
+// lane in half g belongs to key 32 t + (r & 3) + 8 (r >> 2) + 4 g, so MFMA step r takes V[that key][channel lane & 31] as its A
+// operand -- a row of V, contiguous over the lanes, no transposition anywhere.  The additive bias (and Swin's window mask) is the
+// accumulators' initial value (-inf for the padding keys), so the scores leave the matrix pipe complete.  KT = key / query tiles.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int KT>
+__global__ __launch_bounds__(KT >= 4 ? 256 : 128) void window_attention_mfma_f32_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ bias_t, float* __restrict__ out, int N, int heads, float scale_log2e,
+    const float* __restrict__ mask_t, int wins_per_image) {
+    constexpr int NP = 32 * KT, WAVES = KT >= 4 ? 4 : 2, KS = 33;
+    __shared__ float Ks[NP * KS];
+    __shared__ __attribute__((aligned(16))) float Vs[NP * 32];
+    const int h = blockIdx.x % heads;
+    const long long win = blockIdx.x / heads;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, grp = lane >> 5;
+    const size_t row = (size_t)heads * 96;                      // floats per token in qkv
+    const float* base = qkv + (size_t)win * N * row + (size_t)h * 96;
+    for (int idx = tid; idx < NP * 8; idx += 64 * WAVES) {
+        const int j = idx >> 3, c4 = idx & 7;
+        float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;
+        if (j < N) {
+            kk = reinterpret_cast<const float4*>(base + (size_t)j * row + 32)[c4];
+            vv = reinterpret_cast<const float4*>(base + (size_t)j * row + 64)[c4];
+        }
+        float* kd = Ks + j * KS + 4 * c4;
+        kd[0] = kk.x; kd[1] = kk.y; kd[2] = kk.z; kd[3] = kk.w;
+        reinterpret_cast<float4*>(Vs + j * 32)[c4] = vv;
+    }
+    __syncthreads();
+    const float LOG2E = 1.4426950408889634f;
+    const float* bh = bias_t + (size_t)h * N * N;                              // bias[h][i][j] at bh[j * N + i]
+    const float* mh = mask_t ? mask_t + (size_t)(win % wins_per_image) * N * N : nullptr;
+    for (int qt = wave; qt < KT; qt += WAVES) {
+        const int i = 32 * qt + col;                                            // this lane's query
+        const bool qlive = i < N;
+        // Q^T fragments: step s contracts channels 2 s and 2 s + 1; half g of the wavefront holds channel 2 s + g
+        float qf[16];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const float4 t4 = qlive ? reinterpret_cast<const float4*>(base + (size_t)i * row)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            qf[2 * c] = (grp ? t4.y : t4.x) * scale_log2e;
+            qf[2 * c + 1] = (grp ? t4.w : t4.z) * scale_log2e;
+        }
+        // one key tile at a time, online softmax across the tiles (the whole score row in registers -- 16 KT of them -- spilled)
+        float m = -INFINITY, l = 0.f;
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[r] = 0.f;
+        for (int t = 0; t < KT; t++) {
+            // scores start from the bias (padding keys: -inf; padding queries: 0, never stored).  (Requesting the next tile's bias
+            // one tile ahead was measured: with the loop unrolled the 7-tile form spills, rolled it needs 256 registers -- 1.05 to
+            // 1.86 ms per block against 0.75.)
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int j = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * grp;
+                float b0 = 0.f;
+                if (j >= N) b0 = -INFINITY;
+                else if (qlive) b0 = (mh ? bh[(size_t)j * N + i] + mh[(size_t)j * N + i] : bh[(size_t)j * N + i]) * LOG2E;
+                acc[r] = b0;
+            }
+            const float* kr = Ks + (32 * t + col) * KS + grp;
+#pragma unroll
+            for (int sidx = 0; sidx < 16; sidx++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[2 * sidx], qf[sidx], acc, 0, 0, 0);
+            float tm = acc[0];
+#pragma unroll
+            for (int r = 1; r < 16; r++) tm = fmaxf(tm, acc[r]);
+            tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+            const float mn = fmaxf(m, tm);                    // finite from the first tile on (key 0 exists)
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);   // first tile: exp2(-inf) = 0 (v_exp_f32: arguments <= 0)
+            m = mn;
+            l *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; r++) o[r] *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { const float pj = __builtin_amdgcn_exp2f(acc[r] - mn); l += pj; acc[r] = pj; }
+            const float* vr = Vs + (32 * t + 4 * grp) * 32 + col;
+#pragma unroll
+            for (int r = 0; r < 16; r++) o = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[((r & 3) + 8 * (r >> 2)) * 32], acc[r], o, 0, 0, 0);
+        }
+        l += __shfl_xor(l, 32, 64);
+        if (qlive) {
+            const float inv = 1.0f / l;
+            // o[r] = channel (r & 3) + 8 (r >> 2) + 4 g of query i: four consecutive channels per register quad
+            float* orow = out + ((size_t)win * N + i) * ((size_t)heads * 32) + (size_t)h * 32 + 4 * grp;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++)
+                *reinterpret_cast<float4*>(orow + 8 * q4) =
+                    make_float4(o[4 * q4] * inv, o[4 * q4 + 1] * inv, o[4 * q4 + 2] * inv, o[4 * q4 + 3] * inv);
+        }
+    }
+}
+
 }  // namespace sam
 }  // namespace vlfm
 
@@ -246,6 +346,16 @@ extern "C" int vlfm_window_attention_masked_f32(const float* d_qkv, const float*
     const dim3 grid((unsigned)(windows * heads));
     const float sl = scale * 1.4426950408889634f;
     hipStream_t s = (hipStream_t)stream;
+    // the matrix-core form for the window sizes of TinyViT and Swin (7 x 7 and 14 x 14 tokens: 2 and 7 key tiles);
+    // VLFM_WINDOW_ATTENTION=valu keeps the vector form (A/B, tests)
+    static const bool use_mfma = [] { const char* e = getenv("VLFM_WINDOW_ATTENTION"); return !(e && e[0] == 'v'); }();
+    const int kt = (tokens + 31) / 32;
+    if (use_mfma && (kt == 2 || kt == 7)) {
+        VLFM_TIMED("window_attention_mfma_f32_kernel", stream);
+        if (kt == 2) VLFM_KLAUNCH((sam::window_attention_mfma_f32_kernel<2>), grid, dim3(128), 0, s, d_qkv, d_bias_t, d_out, tokens, heads, sl, d_mask_t, windows_per_image);
+        else VLFM_KLAUNCH((sam::window_attention_mfma_f32_kernel<7>), grid, dim3(256), 0, s, d_qkv, d_bias_t, d_out, tokens, heads, sl, d_mask_t, windows_per_image);
+        return check_launch("window_attention_mfma_f32_kernel");
+    }
     VLFM_TIMED("window_attention_f32_kernel", stream);
     if (tokens <= 64) VLFM_KLAUNCH((sam::window_attention_f32_kernel<64>), grid, dim3(64), 0, s, d_qkv, d_bias_t, d_out, tokens, heads, sl, d_mask_t, windows_per_image);
     else if (tokens <= 128) VLFM_KLAUNCH((sam::window_attention_f32_kernel<128>), grid, dim3(128), 0, s, d_qkv, d_bias_t, d_out, tokens, heads, sl, d_mask_t, windows_per_image);
