@@ -28,5 +28,7 @@ for B in [int(a) for a in sys.argv[1:]] or [256]:
             m.cosine_batch(rgb, ["Seems like there is a bed ahead."])
     torch.cuda.synchronize()
     print(f"B={B}: tuned in {time.perf_counter() - t0:.1f} s, {len(tunable.get_results())} entries", flush=True)
-tunable.write_file(out) if hasattr(tunable, "write_file") else None
-print(open(out).read()[:3000] if os.path.exists(out) else "no file written")
+# TunableOp writes its table to `out` when the process exits (this torch has no explicit write call): show what is known so far
+for row in tunable.get_results():
+    print(",".join(str(v) for v in row))
+print(f"-> {out} at exit; copy it to vlfm_amd/tunableop_results.csv")
