@@ -96,3 +96,35 @@ def test_split_form_flags_operands_outside_f16_range(gpu_device):
     got = ops.linear_f32(tiny, w, precision="split")
     want = tiny.double() @ w.double().t()
     assert float((got.double() - want).abs().max()) <= 1e-6 * float((tiny.double().abs() @ w.double().abs().t()).max())
+
+
+def test_overflow_flag_is_one_tensor_for_every_spelling_of_the_device(gpu_device):
+    from vlfm_amd.vlm import ops
+
+    """ADVICE r4: the kernels are handed the flag of ``x.device`` ("cuda:0"), a network built with ``device="cuda"`` (the
+    reference's spelling) must read the SAME tensor, or an overflow is never seen and void results are used."""
+    a = ops.gemm_f32_overflow_flag("cuda", "spelling")
+    b = ops.gemm_f32_overflow_flag(torch.device("cuda:0"), "spelling")
+    c = ops.gemm_f32_overflow_flag(torch.device("cuda", torch.cuda.current_device()), "spelling")
+    assert a is b and b is c and a.device.index == 0
+    assert ops.gemm_f32_overflow_flag("cuda", "other") is not a
+
+
+def test_a_weight_outside_f16_range_keeps_raising_the_flag(gpu_device):
+    from vlfm_amd.vlm import ops
+
+    """ADVICE r4: the range check of a weight runs when its hi/lo planes are built; the cached planes must not become silent after
+    the owner's flag was cleared once."""
+    w = torch.randn(64, 64, device=gpu_device)
+    w[3, 5] = 1.0e6
+    x = torch.randn(128, 64, device=gpu_device)
+    flag = ops.gemm_f32_overflow_flag(gpu_device, "badweight")
+    flag.zero_()
+    with torch.inference_mode():
+        ops.linear_f32(x, w, precision="split", owner="badweight")
+        assert int(flag.item()) != 0
+        flag.zero_()
+        assert ops.split_weights_bad(gpu_device, "badweight")
+        ops.linear_f32(x, w, precision="split", owner="badweight")      # cache hit: the verdict travels with the planes
+        assert int(flag.item()) != 0
+    flag.zero_()

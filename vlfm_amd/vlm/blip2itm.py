@@ -811,6 +811,7 @@ class BLIP2ITM:
         flag = ops.gemm_f32_overflow_flag(self.device, "blip2")
         if int(flag.item()):
             flag.zero_()
+            ops.split_weights_bad(self.device, "blip2")    # (a weight out of range keeps raising the flag on every later use)
             raise FloatingPointError("BLIP-2 Q-Former: an activation left f16's range inside a split-precision f32 GEMM; set "
                                      "vlfm_amd.vlm.blip2itm.QFORMER_SPLIT_MIN_ROWS = 1 << 60 to run these layers on the library's f32 GEMMs")
 

@@ -97,6 +97,10 @@ def xywh2xyxy(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+# what the last non_max_suppression calls worked on (host ints that the function reads back anyway; bench.py reports them)
+NMS_STATS = {"frames": 0, "candidates": 0, "boxes_in": 0}
+
+
 def non_max_suppression(prediction: torch.Tensor, conf_thres: float = 0.25, iou_thres: float = 0.45,
                         classes: Optional[Sequence[int]] = None, agnostic: bool = False,
                         nms_fn=nms) -> List[torch.Tensor]:
@@ -112,6 +116,9 @@ def non_max_suppression(prediction: torch.Tensor, conf_thres: float = 0.25, iou_
     dev = prediction.device
     out = [torch.zeros((0, 6), device=dev)] * B
     cand = (prediction[..., 4] > conf_thres).nonzero()            # [(image, row)], image-major, rows ascending
+    NMS_STATS["frames"] += B
+    NMS_STATS["candidates"] += int(cand.shape[0])
+    NMS_STATS["boxes_in"] = int(prediction.shape[1])
     if cand.shape[0] == 0:
         return out
     x = prediction[cand[:, 0], cand[:, 1]].clone()

@@ -108,6 +108,11 @@ def _swin_qkv(att) -> tuple:
 
 def patch_swin_layers(backbone: nn.Module, st: _State) -> int:
     n = 0
+    for stage in backbone.modules():     # blocks after the first of a stage own their input (it is the previous block's output)
+        blocks = getattr(stage, "blocks", None)
+        if type(stage).__name__.endswith("SwinStage") and blocks is not None:
+            for i, blk in enumerate(blocks):
+                blk.vlfm_stage_entry = i == 0
     for layer in backbone.modules():
         if type(layer).__name__ != "SwinLayer" or layer.attention.head_dim != 32:
             continue
@@ -131,6 +136,10 @@ def patch_swin_layers(backbone: nn.Module, st: _State) -> int:
             x = x.reshape(B, H, W, C)
             if not x.is_contiguous():
                 x = x.contiguous()
+            elif getattr(_l, "vlfm_stage_entry", True):
+                # the block updates its rows in place: the first block of a stage must not do that to the CALLER's tensor (the
+                # embeddings / the previous stage's output, which `output_hidden_states` and `out_features` hand out)
+                x = x.clone()
             nwy, nwx = -(-H // ws), -(-W // ws)
             wins = ops.layernorm_rows(x, _l.layernorm_before.weight, _l.layernorm_before.bias, _l.layernorm_before.eps,
                                       window=ws, shift=shift, pad_zero=True)                       # [B nW, ws^2, C]
@@ -333,6 +342,17 @@ def accelerate(model: nn.Module, precision: str = "split") -> Dict[str, int]:
     assert cfg.activation_function == "relu", "the fused encoder FFN assumes ReLU (GroundingDINO_SwinT_OGC)"
     assert not model.training, "fused forwards are inference-only: call model.eval() first"
     model.vlfm_fast = st
+
+    def refuse_padding(_mod, args, kwargs):
+        """The fused encoder / fusion forwards skip the padding masks (``no_padding``): every frame of a batch this repo feeds has the
+        same size.  An explicit ``pixel_mask`` with holes would silently give other results than the unpatched model: refuse it."""
+        pm = kwargs.get("pixel_mask", None)
+        if st.no_padding and pm is not None and not bool(pm.all()):
+            raise NotImplementedError("accelerated GroundingDINO forward: padded batches (pixel_mask with zeros) are not supported; "
+                                      "set model.vlfm_fast.no_padding = False to take the masked paths")
+        return None
+
+    model.register_forward_pre_hook(refuse_padding, with_kwargs=True)
     out = {"swin_layers": patch_swin_layers(model.model.backbone, st), "deformable": patch_deformable(model, st),
            "fusion_layers": patch_fusion(model, st), "attention": patch_mha(model, st), "linears": patch_linears(model, st)}
     return out

@@ -206,7 +206,8 @@ class GroundingDINO:
                     logits, pred_boxes = self._forward(pix, input_ids.to(self.device), mask.to(self.device), tuple(caps))
                     best, boxes, bits = self._postprocess_device(logits, pred_boxes, ids)
                 finally:
-                    self.model.vlfm_fast.precision = "split"
+                    # a WEIGHT outside f16's range poisons its cached planes for good: stay on the library from then on
+                    self.model.vlfm_fast.precision = "library" if ops.split_weights_bad(self.device, "gdino") else "split"
         return [self._detections(best[b], boxes[b], bits[b], ids[b], raw[b]) for b in range(B)]
 
     def _postprocess_device(self, logits: torch.Tensor, pred_boxes: torch.Tensor, ids):

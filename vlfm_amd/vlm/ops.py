@@ -285,16 +285,20 @@ def vit_attention(qkv: torch.Tensor, batch: int, tokens: int, heads: int, head_d
 # ------------------------------------------------------------------------------------------------ f32 Linear on the matrix cores
 _ACT32 = {None: 0, "none": 0, "relu": 1, "gelu": 2}
 GEMM_F32_PRECISION = {"exact": 0, "split": 1}
-_overflow_flags: Dict[str, torch.Tensor] = {}
+_overflow_flags: Dict[tuple, torch.Tensor] = {}
 _split_cache: Dict[int, tuple] = {}
 
 
 def gemm_f32_overflow_flag(device, owner: str = "") -> torch.Tensor:
     """The sticky device int the split-precision GEMMs OR into when an operand leaves f16's range: one per device and ``owner`` (each
     network reads and clears its own, so one network's fallback never hides another's overflow)."""
-    key = f"{device}/{owner}"
+    d = torch.device(device)
+    # "cuda" (the reference's spelling) and "cuda:0" are the same device: the kernels are handed the flag of ``x.device`` (always
+    # indexed), the networks look theirs up with whatever the caller passed -- both must meet in one tensor
+    index = d.index if d.index is not None else (torch.cuda.current_device() if d.type == "cuda" else 0)
+    key = (d.type, index, owner)
     if key not in _overflow_flags:
-        _overflow_flags[key] = torch.zeros(1, dtype=torch.int32, device=device)
+        _overflow_flags[key] = torch.zeros(1, dtype=torch.int32, device=torch.device(d.type, index))
     return _overflow_flags[key]
 
 
@@ -309,12 +313,16 @@ def tensor_version(t: torch.Tensor) -> int:
 
 def split_weight(weight: torch.Tensor, owner: str = "") -> Tuple[torch.Tensor, torch.Tensor]:
     """(hi, lo') f16 planes of an f32 weight: hi = f16(w), lo' = f16((w - hi) 2^11).  Memoised per tensor OBJECT (a weak reference
-    proves it is still the same tensor: an address alone is reused by the allocator) and per ``_version`` (in-place updates)."""
+    proves it is still the same tensor: an address alone is reused by the allocator) and per ``_version`` (in-place updates).
+    The range check (|w| >= 65504, inf, NaN) runs only when the planes are built, so its verdict is KEPT with the planes: a private
+    device int per weight, OR-ed into the owner's flag on every use of the cached planes (a cleared owner flag does not forget it)."""
     import weakref
 
     key = id(weight)
     hit = _split_cache.get(key)
     if hit is not None and hit[0]() is weight and hit[1] == tensor_version(weight) and hit[2] == weight.data_ptr():
+        if hit[6]:     # known-bad planes (established at a synchronisation point): say so again, every time
+            gemm_f32_overflow_flag(weight.device, owner).bitwise_or_(hit[5])
         return hit[3], hit[4]
     if len(_split_cache) > 2048:
         for k in [k for k, v in _split_cache.items() if v[0]() is None]:
@@ -322,10 +330,27 @@ def split_weight(weight: torch.Tensor, owner: str = "") -> Tuple[torch.Tensor, t
     w = weight.detach().contiguous()
     hi = torch.empty(w.shape, dtype=torch.float16, device=w.device)
     lo = torch.empty_like(hi)
-    _lib.check(_lib.lib().vlfm_split_f32_to_f16_pair(w.data_ptr(), hi.data_ptr(), lo.data_ptr(), w.numel(),
-                                                     gemm_f32_overflow_flag(w.device, owner).data_ptr(), _stream()), "split_f32")
-    _split_cache[key] = (weakref.ref(weight), tensor_version(weight), weight.data_ptr(), hi, lo)
+    bad = torch.zeros(1, dtype=torch.int32, device=w.device)
+    _lib.check(_lib.lib().vlfm_split_f32_to_f16_pair(w.data_ptr(), hi.data_ptr(), lo.data_ptr(), w.numel(), bad.data_ptr(),
+                                                     _stream()), "split_f32")
+    gemm_f32_overflow_flag(w.device, owner).bitwise_or_(bad)
+    _split_cache[key] = [weakref.ref(weight), tensor_version(weight), weight.data_ptr(), hi, lo, bad, False, owner]
     return hi, lo
+
+
+def split_weights_bad(device, owner: str = "") -> bool:
+    """True when a cached hi/lo pair of ``owner`` was built from a weight outside f16's range.  One read-back over all of the owner's
+    private flags: called after an overflow was seen (a synchronisation point), never per step.  Marks such entries so that every later
+    use of their planes raises the owner's flag again."""
+    d = torch.device(device)
+    entries = [v for v in _split_cache.values() if v[7] == owner and v[0]() is not None and v[5].device.type == d.type
+               and (d.index is None or v[5].device.index == d.index)]
+    if not entries:
+        return False
+    verdict = torch.cat([v[5] for v in entries]).cpu().tolist()
+    for v, b in zip(entries, verdict):
+        v[6] = bool(b)
+    return any(verdict)
 
 
 def linear_f32_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:

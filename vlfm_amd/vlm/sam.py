@@ -85,6 +85,9 @@ class _PatchMerging(nn.Module):
         return self.conv3(_dwconv(self.conv2, _conv_act(self.conv1, x, True), True))
 
 
+import threading as _threading
+
+_PRECISION_LOCK = _threading.Lock()   # the switch below is module-wide: a fallback re-run holds this while it flips it
 GEMM_PRECISION = "split"     # TinyViT's f32 Linears on the rows path: "split" (csrc/gemm_f32.hip, f16 operand pairs) | "library"
 
 
@@ -373,10 +376,10 @@ class MobileSAM:
         self.folded_batchnorms = fold_batchnorm_(self.model)   # TinyViT's Conv2d_BN.fuse(): conv + eval-mode BN = one conv
         self.model.to(self.device)
         self.mask_threshold = 0.0
+        self.overflow_fallbacks = 0
 
     @torch.inference_mode()
-    def segment_bboxes(self, images_u8: torch.Tensor, boxes_xyxy: torch.Tensor) -> torch.Tensor:
-        """images_u8 [B,H,W,3] u8 on device; boxes [B,K,4] pixel xyxy -> [B,K,H,W] bool masks."""
+    def _segment_bboxes_once(self, images_u8: torch.Tensor, boxes_xyxy: torch.Tensor) -> torch.Tensor:
         B, H, W, _ = images_u8.shape
         pix, (oh, ow) = ops.preprocess_sam(images_u8)
         emb = self.model.get_image_embeddings(pix)
@@ -388,8 +391,29 @@ class MobileSAM:
         m = F.interpolate(m, (H, W), mode="bilinear", align_corners=False)
         return m > self.mask_threshold
 
+    def segment_bboxes(self, images_u8: torch.Tensor, boxes_xyxy: torch.Tensor) -> torch.Tensor:
+        """images_u8 [B,H,W,3] u8 on device; boxes [B,K,4] pixel xyxy -> [B,K,H,W] bool masks.  With the split-precision GEMMs
+        switched on, the overflow flag is read here (one 4-byte read-back; every caller reads the masks next anyway) and a flagged
+        batch is repeated on the library's f32 GEMMs -- the batched callers (harness, clients) never see void masks."""
+        global GEMM_PRECISION
+        masks = self._segment_bboxes_once(images_u8, boxes_xyxy)
+        if GEMM_PRECISION == "split":
+            flag = ops.gemm_f32_overflow_flag(self.device, "sam")
+            if int(flag.item()):
+                flag.zero_()
+                self.overflow_fallbacks += 1
+                with _PRECISION_LOCK:
+                    GEMM_PRECISION = "library"
+                    try:
+                        masks = self._segment_bboxes_once(images_u8, boxes_xyxy)
+                    finally:
+                        # a WEIGHT outside f16's range poisons its cached planes for good: stay on the library from then on
+                        GEMM_PRECISION = "library" if ops.split_weights_bad(self.device, "sam") else "split"
+        return masks
+
     def check_numerics(self) -> None:
-        """Raise if a split-precision GEMM of the encoder met an operand outside f16's range since the last check."""
+        """Raise if a split-precision GEMM of the encoder met an operand outside f16's range since the last check (only reachable
+        when something other than ``segment_bboxes`` ran the encoder)."""
         flag = ops.gemm_f32_overflow_flag(self.device, "sam")
         if int(flag.item()):
             flag.zero_()
@@ -397,20 +421,9 @@ class MobileSAM:
                                      "vlfm_amd.vlm.sam.GEMM_PRECISION = 'library'")
 
     def segment_bbox(self, image: np.ndarray, bbox: List[int]) -> np.ndarray:
-        global GEMM_PRECISION
         img = torch.from_numpy(np.ascontiguousarray(image)).to(self.device)[None]
         box = torch.tensor(bbox, dtype=torch.float32).view(1, 1, 4)
-        mask = self.segment_bboxes(img, box)[0, 0].cpu().numpy()
-        if GEMM_PRECISION == "split":
-            flag = ops.gemm_f32_overflow_flag(self.device, "sam")
-            if int(flag.item()):          # (the copy above synchronised) void results: once more on the library's f32 GEMMs
-                flag.zero_()
-                GEMM_PRECISION = "library"
-                try:
-                    mask = self.segment_bboxes(img, box)[0, 0].cpu().numpy()
-                finally:
-                    GEMM_PRECISION = "split"
-        return mask
+        return self.segment_bboxes(img, box)[0, 0].cpu().numpy()
 
 
 class MobileSAMClient:
