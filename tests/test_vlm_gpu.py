@@ -283,6 +283,38 @@ def test_vit_fast_path_full_geometry_vs_plain(gpu_device):
     assert (fast - plain).abs().mean() <= 4e-3 and (fast - mid).abs().mean() <= 4e-3
 
 
+def test_vit_all_four_gemms_on_the_8phase_kernel_full_geometry(gpu_device):
+    """ViT-g/14 at the real geometry with qkv / projection / fc1 / fc2 of every block on csrc/gemm_f16.hip (bias, accumulate-into-the-
+    stream and bias + GELU epilogues) against the same blocks on hipBLASLt, same f16 weights, 40 images (10 280 rows: a ragged last
+    m-tile, the half-empty last n-tile of N = 1408 and 4224)."""
+    from vlfm_amd.vlm.blip2itm import BLIP2ITM
+
+    m = BLIP2ITM(device=gpu_device, allow_random_init=True).model
+    g = torch.Generator(device=gpu_device).manual_seed(5)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.dim() == 1 and "norm" not in n.lower():
+                p.copy_(torch.randn(p.shape, generator=g, device=gpu_device, dtype=torch.float32).to(p.dtype) * 0.1)
+    m._deferred_c = None
+    pat = torch.randn(40, 256, 588, generator=g, device=gpu_device, dtype=torch.float32).half()
+    with torch.inference_mode():
+        m.deferred_bias = True
+        for blk in m.blocks:
+            blk.hip_gemms = frozenset(("qkv", "proj", "fc1", "fc2"))
+            blk.hip_mlp_min_rows = 1
+        assert m.blocks[0].hip_gemms_at(40 * 257) == frozenset(("qkv", "proj", "fc1", "fc2"))
+        hip = m.vision_tokens(pat).float()
+        for blk in m.blocks:
+            blk.hip_gemms = frozenset()
+        lib = m.vision_tokens(pat).float()
+        m.deferred_bias = False
+        plain = m.vision_tokens(pat[:4]).float()
+    assert torch.isfinite(hip).all()
+    assert (hip - lib).abs().max() <= 6e-2 and (hip - lib).abs().mean() <= 4e-3          # 39 blocks of f16 rounding noise
+    assert (hip[:4] - plain).abs().max() <= 6e-2 and (hip[:4] - plain).abs().mean() <= 4e-3
+    assert (hip[:4] - plain).abs().mean() <= 1.3 * (lib[:4] - plain).abs().mean() + 1e-4     # not noisier than the library path
+
+
 def test_qformer_split_kv_projection_is_f32_grade(gpu_device):
     """Cross-attention K/V projection of f16 tokens through the split weights (f16 x f16 -> f32 GEMMs) against the plain f32 GEMM
     path and against f64, with three pieces (exact weights) and with two (the product default: 22-23 of 24 bits): not less

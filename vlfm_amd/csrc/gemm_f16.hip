@@ -48,7 +48,8 @@ constexpr int EPI_ROW = 272;       // epilogue staging row stride (128 n x 2 B +
 constexpr int EPI_WAVE = 64 * EPI_ROW;
 constexpr int GEMM_LDS = 8 * EPI_WAVE > 2 * BUF ? 8 * EPI_WAVE : 2 * BUF;
 
-enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1 };
+constexpr int GEMM_DEFAULT_VARIANT = 2;   // 0 ping-pong (round 2), 1 lock-step, 2 8-phase, 3 8-phase balanced
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_ACCUM = 2 };   // 2: C += X . W^T (+ bias): the residual-stream GEMMs (projection, fc2)
 
 struct GemmArgs {
     const _Float16* x;     // [M][K]
@@ -152,9 +153,18 @@ __device__ inline void store_tile(const GemmArgs& a, unsigned char* smem, const 
 #pragma unroll
     for (int it = 0; it < 16; it++) {
         const int row = it * 4 + rsub;
-        const uint4 v = *reinterpret_cast<const uint4*>(stg + row * EPI_ROW + chunk * 16);
+        uint4 v = *reinterpret_cast<const uint4*>(stg + row * EPI_ROW + chunk * 16);
         const int m = m0 + wm * 64 + row, n = n0 + wn * 128 + chunk * 8;
-        if (m < a.M && n + 8 <= a.N) *reinterpret_cast<uint4*>(a.c + (size_t)m * a.N + n) = v;
+        if (m < a.M && n + 8 <= a.N) {
+            if (EPI == EPI_ACCUM) {   // beta = 1: the stream's 8 halves of this row segment + the product, summed in f32
+                const half8 old = *reinterpret_cast<const half8*>(a.c + (size_t)m * a.N + n);
+                half8 h = *reinterpret_cast<const half8*>(&v);
+#pragma unroll
+                for (int e = 0; e < 8; e++) h[e] = (_Float16)((float)h[e] + (float)old[e]);
+                v = *reinterpret_cast<const uint4*>(&h);
+            }
+            *reinterpret_cast<uint4*>(a.c + (size_t)m * a.N + n) = v;
+        }
     }
 }
 
@@ -308,17 +318,253 @@ __global__ __launch_bounds__(512) void gemm_f16_nt_kernel(GemmArgs a) {
     store_tile<EPI>(a, smem, acc, wave, wn, wm, lane, m0, n0);
 }
 
+
+// ------------------------------------------------------------------------------------------------ 8-phase schedule
+// Round 5.  Same tile (256 x 256 x 64), same operand roles, swizzle and epilogue, and the same ping-pong between the two wavefronts
+// of a SIMD -- but a K-tile is FOUR phases of 16 MFMAs (one quadrant of the wavefront's 128 x 64 accumulator block each) instead of
+// two of 32, an operand tile is staged as two HALF-tiles, one half-tile (2 global_load_lds per wavefront) per phase, and the loads
+// are never drained inside the loop: ONE counted s_waitcnt vmcnt(4) per K-tile leaves the two half-tiles issued last in flight across
+// every barrier (the guide's 256^2 8-phase template; the ping-pong kernel above waits vmcnt(0) once per K-tile, i.e. every load of
+// the next tile has to land inside ~3 phases of the current one and the wait sits on the critical path of all 8 wavefronts).
+//
+// LDS: two K-tile buffers of four 16 KB slots, in the order the phases need them:
+//     slot 0 = Q_H0   X rows {wm * 64 + [ 0, 32)}  for the four wm      read in phase 1 (4 ds_read_b128 per wavefront)
+//     slot 1 = P_H0   W rows {wn * 128 + [ 0, 64)} for the two wn       read in phase 1 (8)
+//     slot 2 = Q_H1   X rows {wm * 64 + [32, 64)}                       read in phase 2 (4)
+//     slot 3 = P_H1   W rows {wn * 128 + [64,128)}                      read in phase 3 (8)
+//   (a "half" is the same half of EVERY wavefront's rows, so one slot serves all eight wavefronts in one phase.)
+// Quadrants: phase 1 (P_H0, Q_H0), phase 2 (P_H0, Q_H1), phase 3 (P_H1, Q_H1), phase 4 (P_H1, Q_H0): one new fragment set per phase,
+// none in phase 4; P fragments 32 VGPRs, Q_H0 and Q_H1 16 each.
+// Staging while tile t (buffer b) is computed:    phase 1: slot 2 of tile t + 1 (buffer b ^ 1)   phase 2: slot 3 of tile t + 1
+//                                                 phase 3: slot 0 of tile t + 2 (buffer b)       phase 4: slot 1 of tile t + 2
+//   WAR: a slot is re-staged >= 2 phases after the phase that read it last (slot 0 / 1: read in 1, staged in 3 / 4; slot 2: read in
+//        2 of tile t - 1, staged in 1 of tile t; slot 3: read in 3, staged in 2), and every wavefront retires its reads of phase p
+//        (lgkmcnt(0)) right behind the first barrier of phase p -- the late group one barrier later, still before phase p + 2.
+//   RAW: the wait of phase 4 -- before that phase's FIRST barrier -- leaves only the 4 loads of phases 3 and 4 (tile t + 2) in flight:
+//        tile t + 1 is complete as far as this wavefront's shares go; the early group reads it two barriers later, the late group
+//        three, and by then every wavefront has executed its own wait (the late group's sits one barrier behind the early group's).
+template <int EPI, int BAL>
+struct Gemm8p {
+    static constexpr int SLOT = 128 * ROWB;      // 16 KB
+    static constexpr int KBUF = 4 * SLOT;        // one K-tile: 64 KB
+
+    const GemmArgs& a;
+    lds_ptr lds;
+    const unsigned char* smem;
+    int wave, lane;
+    bool active;                // this wavefront's 128 W rows are not all beyond N (the half-empty last n-tile of N = 1408 / 4224)
+    uint32_t voff[4][2];        // per slot and chunk: byte offset of this lane's 16 B inside the operand, without the K-tile term
+    uint32_t rdP[2], rdQ[2];    // fragment read offsets inside a slot, by kk (the swizzle turns kk into an XOR of 64 B)
+    half8 fp[4][2], fq0[BAL ? 2 : 1][2][2], fq1[2][2];   // BAL: Q_H0 of the NEXT tile is read in phase 4 into the other set
+    floatx4 acc[8][4];
+
+    __device__ Gemm8p(const GemmArgs& a_, unsigned char* smem_, int m0, int n0) : a(a_), lds((lds_ptr)smem_), smem(smem_) {
+        const int tid = threadIdx.x;
+        lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int wn = wave >> 2, wm = wave & 3;
+        active = n0 + wn * 128 < a.N;
+        const int sub = lane >> 3, p = lane & 7;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int rho = (wave * 2 + j) * 8 + sub;            // row inside the slot
+            const int s = p ^ ((rho >> 1) & 7);                  // the 16-byte slot of the row this lane FETCHES (lands at p)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int rq = min(m0 + (rho >> 5) * 64 + h * 32 + (rho & 31), a.M - 1);
+                const int rp = min(n0 + (rho >> 6) * 128 + h * 64 + (rho & 63), a.N - 1);
+                voff[2 * h][j] = (uint32_t)rq * (uint32_t)a.K * 2u + (uint32_t)s * 16u;
+                voff[2 * h + 1][j] = (uint32_t)rp * (uint32_t)a.K * 2u + (uint32_t)s * 16u;
+            }
+        }
+        const int r16 = lane & 15, swz = (r16 >> 1) & 7, s0 = lane >> 4;
+        const uint32_t bp = (uint32_t)(wn * 64 + r16) * ROWB + (uint32_t)((s0 ^ swz) << 4);
+        const uint32_t bq = (uint32_t)(wm * 32 + r16) * ROWB + (uint32_t)((s0 ^ swz) << 4);
+        rdP[0] = bp; rdP[1] = bp ^ 64u;
+        rdQ[0] = bq; rdQ[1] = bq ^ 64u;
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // half-tile `slot` of K-tile t -> buffer b
+    template <int SLOT_ID>
+    __device__ inline void stage(int b, int t) {
+        const unsigned char* base = reinterpret_cast<const unsigned char*>((SLOT_ID & 1) ? a.w : a.x) + (size_t)t * (GK * 2);
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int dst = __builtin_amdgcn_readfirstlane(b * KBUF + SLOT_ID * SLOT + (wave * 2 + j) * 1024);
+            __builtin_amdgcn_global_load_lds((gbl_ptr)(base + voff[SLOT_ID][j]), lds + dst, 16, 0, 0);
+        }
+    }
+    template <int B, int SLOT_ID>
+    __device__ inline void read_p() {
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+            for (int f = 0; f < 4; f++)
+                fp[f][kk] = *reinterpret_cast<const half8*>(smem + B * KBUF + SLOT_ID * SLOT + f * 16 * ROWB + rdP[kk]);
+    }
+    template <int B, int SLOT_ID>
+    __device__ inline void read_q(half8 (&fq)[2][2]) {
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+            for (int g = 0; g < 2; g++)
+                fq[g][kk] = *reinterpret_cast<const half8*>(smem + B * KBUF + SLOT_ID * SLOT + g * 16 * ROWB + rdQ[kk]);
+    }
+    template <int PI, int QJ>
+    __device__ inline void mma(const half8 (&fq)[2][2]) {
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+            for (int f = 0; f < 4; f++)
+#pragma unroll
+                for (int g = 0; g < 2; g++)
+                    acc[PI * 4 + f][QJ * 2 + g] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_f16(fp[f][kk], fq[g][kk], acc[PI * 4 + f][QJ * 2 + g], 0, 0, 0);
+    }
+    static __device__ inline void bar() {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    // [fragments + staging issued by the caller] | barrier | fragments have arrived | 16 MFMAs | barrier
+    template <int PI, int QJ>
+    __device__ inline void compute(const half8 (&fq)[2][2]) {
+        bar();
+        __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this phase's reads are in registers -- and out of the slot
+        __builtin_amdgcn_sched_barrier(0);
+        if (active) {
+            __builtin_amdgcn_s_setprio(1);
+            mma<PI, QJ>(fq);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        bar();
+    }
+
+    // K-tile t in buffer B (compile-time: the buffer term of every ds_read offset is an immediate).
+    // BAL = 1 ("balanced"): the Q_H0 fragments of tile t + 1 are read in phase 4 of tile t (which has no reads of its own) instead
+    // of in phase 1 of tile t + 1 (which has the 8 P reads): 8 / 4 / 8 / 4 ds_read_b128 per phase instead of 12 / 4 / 8 / 0.  Slot 0 of
+    // tile t + 1 therefore has to be complete one phase earlier: a second counted wait, vmcnt(8), in phase 3.
+    template <int B>
+    __device__ inline void tile(int t, int NT) {
+        constexpr int QS = BAL ? B : 0;
+        // ---- phase 1
+        if (active) {
+            if (!BAL) read_q<B, 0>(fq0[QS]);
+            read_p<B, 1>();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < NT) stage<2>(B ^ 1, t + 1);
+        compute<0, 0>(fq0[QS]);
+        // ---- phase 2
+        if (active) read_q<B, 2>(fq1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < NT) stage<3>(B ^ 1, t + 1);
+        compute<0, 1>(fq1);
+        // ---- phase 3
+        if (active) read_p<B, 3>();
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 2 < NT) {
+            stage<0>(B, t + 2);
+            if (BAL) __builtin_amdgcn_s_waitcnt(0x0F78);     // vmcnt(8): slot 0 of tile t + 1 has landed (slots 1-3 of t + 1 and
+        } else if (BAL) {                                     //           slot 0 of t + 2 may still be in flight)
+            __builtin_amdgcn_s_waitcnt(0x0F76);              // vmcnt(6): no slot 0 of t + 2 behind it
+        }
+        compute<1, 1>(fq1);
+        // ---- phase 4: tile t + 1 must be complete when this phase's first barrier is passed
+        if (BAL && active && t + 1 < NT) read_q<B ^ 1, 0>(fq0[BAL ? (B ^ 1) : 0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 2 < NT) {
+            stage<1>(B, t + 2);
+            __builtin_amdgcn_s_waitcnt(0x0F74);      // vmcnt(4): only the loads of phases 3 and 4 (tile t + 2) stay in flight
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): nothing newer was issued
+        }
+        compute<1, 0>(fq0[QS]);
+    }
+
+    __device__ inline void run(int m0, int n0) {
+        const int NT = a.K / GK;
+        const int late = wave >> 2;
+        // prologue: all of tile 0, slots 0 and 1 of tile 1
+        stage<0>(0, 0); stage<1>(0, 0); stage<2>(0, 0); stage<3>(0, 0);
+        if (NT > 1) {
+            stage<0>(1, 1); stage<1>(1, 1);
+            __builtin_amdgcn_s_waitcnt(0x0F74);
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
+        bar();
+        if (late) bar();
+        if (BAL && active) read_q<0, 0>(fq0[0]);     // (retired by the lgkmcnt(0) of the first phase)
+        for (int t = 0; t < NT; t += 2) {
+            tile<0>(t, NT);
+            if (t + 1 < NT) tile<1>(t + 1, NT);
+        }
+        if (!late) bar();       // the late group's last MFMA phase; behind it nobody reads the operand buffers any more
+        store_tile<EPI>(a, const_cast<unsigned char*>(smem), acc, wave, wave >> 2, wave & 3, lane, m0, n0);
+    }
+};
+
+template <int EPI, int BAL>
+__global__ __launch_bounds__(512) void gemm_f16_8p_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nwg = a.tiles_m * a.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int tm, tn;
+    {
+        const int GM = a.group_m;
+        const int per_group = GM * a.tiles_n, grp = bid / per_group, in = bid - grp * per_group;
+        const int rows = min(GM, a.tiles_m - grp * GM);
+        tn = in / rows;
+        tm = grp * GM + (in - tn * rows);
+    }
+    const int m0 = tm * GB, n0 = tn * GB;
+    Gemm8p<EPI, BAL> g(a, smem, m0, n0);
+    g.run(m0, n0);
+}
+
 }  // namespace vlfm
 
 using namespace vlfm;
 
-// C = epilogue(X . W^T + bias), f16 in / f16 out / f32 accumulate.  epilogue: 0 = bias only, 1 = bias + exact (erf) GELU.
-// K must be a multiple of 64, N a multiple of 8; M and N tails are handled.  d_bias may be NULL.
+// C = epilogue(X . W^T + bias), f16 in / f16 out / f32 accumulate.  epilogue: 0 = bias only, 1 = bias + exact (erf) GELU,
+// 2 = accumulate into C (C += X . W^T + bias: the residual-stream GEMMs).  K must be a multiple of 64, N a multiple of 8; M and N
+// tails are handled.  d_bias may be NULL.  Kernel: the 8-phase schedule; VLFM_GEMM_VARIANT=0 / 1 select the round-2 ping-pong /
+// lock-step kernels (A/B runs of tools/gemm_f16_probe.py; they do not implement epilogue 2), 2 / 3 the 8-phase kernel's two read schedules.
+template <int EPI>
+static int launch_gemm(const GemmArgs& a, int variant, hipStream_t stream) {
+    const void* fn = variant == 0 ? reinterpret_cast<const void*>(gemm_f16_nt_kernel<EPI>)
+                   : variant == 1 ? reinterpret_cast<const void*>(gemm_f16_nt_lockstep_kernel<EPI>)
+                   : variant == 2 ? reinterpret_cast<const void*>(gemm_f16_8p_kernel<EPI, 0>)
+                                  : reinterpret_cast<const void*>(gemm_f16_8p_kernel<EPI, 1>);
+    static LdsOptIn opt[4];
+    if (!opt[variant].ensure(fn, GEMM_LDS)) return fail(VLFM_ERR_HIP, "gemm_f16_nt: cannot opt in to the LDS size");
+    const dim3 grid(a.tiles_m * a.tiles_n), block(512);
+    // (profile name by epilogue: in the ViT block 0 = qkv, 1 = fc1 + GELU, 2 = projection and fc2, one launch each)
+    VLFM_TIMED(variant < 2 ? "gemm_f16_nt_kernel" : EPI == EPI_BIAS ? "gemm_f16_8p_kernel<0>" : EPI == EPI_BIAS_GELU
+               ? "gemm_f16_8p_kernel<1>" : "gemm_f16_8p_kernel<2>", stream);
+    if (variant == 0) VLFM_KLAUNCH(gemm_f16_nt_kernel<EPI>, grid, block, GEMM_LDS, stream, a);
+    else if (variant == 1) VLFM_KLAUNCH(gemm_f16_nt_lockstep_kernel<EPI>, grid, block, GEMM_LDS, stream, a);
+    else if (variant == 2) VLFM_KLAUNCH((gemm_f16_8p_kernel<EPI, 0>), grid, block, GEMM_LDS, stream, a);
+    else VLFM_KLAUNCH((gemm_f16_8p_kernel<EPI, 1>), grid, block, GEMM_LDS, stream, a);
+    return check_launch("gemm_f16_nt_kernel");
+}
+
 extern "C" int vlfm_gemm_f16_nt(const void* d_x, const void* d_w, const void* d_bias, void* d_c, int m, int n, int k,
                                 int epilogue, void* stream) {
     if (m == 0 || n == 0) return VLFM_OK;
-    if (!d_x || !d_w || !d_c || m < 0 || n < 0 || k <= 0 || (k % GK) != 0 || (n % 8) != 0 || epilogue < 0 || epilogue > 1)
-        return fail(VLFM_ERR_INVALID, "gemm_f16_nt: K must be a multiple of 64, N of 8, epilogue 0 or 1");
+    if (!d_x || !d_w || !d_c || m < 0 || n < 0 || k <= 0 || (k % GK) != 0 || (n % 8) != 0 || epilogue < 0 || epilogue > 2)
+        return fail(VLFM_ERR_INVALID, "gemm_f16_nt: K must be a multiple of 64, N of 8, epilogue 0, 1 or 2");
+    if ((size_t)m * (size_t)k * 2 >= (1ull << 32) || (size_t)n * (size_t)k * 2 >= (1ull << 32))
+        return fail(VLFM_ERR_INVALID, "gemm_f16_nt: an operand of 4 GB or more (32-bit byte offsets inside an operand)");
     GemmArgs a;
     a.x = (const _Float16*)d_x; a.w = (const _Float16*)d_w; a.bias = (const _Float16*)d_bias; a.c = (_Float16*)d_c;
     a.M = m; a.N = n; a.K = k;
@@ -328,22 +574,11 @@ extern "C" int vlfm_gemm_f16_nt(const void* d_x, const void* d_w, const void* d_
     const char* eg = getenv("VLFM_GEMM_GROUP_M");
     a.group_m = eg ? atoi(eg) : (a.tiles_n >= 12 ? 8 : 1);
     if (a.group_m < 1) a.group_m = 1;
-    const char* ev = getenv("VLFM_GEMM_VARIANT");   // 1 = the lock-step kernel (A/B baseline of tools/gemm_f16_probe.py)
-    const bool lockstep = ev && atoi(ev) == 1;
-    const void* fn = lockstep ? (epilogue == 0 ? reinterpret_cast<const void*>(gemm_f16_nt_lockstep_kernel<EPI_BIAS>)
-                                               : reinterpret_cast<const void*>(gemm_f16_nt_lockstep_kernel<EPI_BIAS_GELU>))
-                              : (epilogue == 0 ? reinterpret_cast<const void*>(gemm_f16_nt_kernel<EPI_BIAS>)
-                                               : reinterpret_cast<const void*>(gemm_f16_nt_kernel<EPI_BIAS_GELU>));
-    static LdsOptIn opt[4];
-    if (!opt[(lockstep ? 2 : 0) + epilogue].ensure(fn, GEMM_LDS)) return fail(VLFM_ERR_HIP, "gemm_f16_nt: cannot opt in to the LDS size");
-    const dim3 grid(a.tiles_m * a.tiles_n), block(512);
-    VLFM_TIMED("gemm_f16_nt_kernel", stream);
-    if (lockstep) {
-        if (epilogue == 0) VLFM_KLAUNCH(gemm_f16_nt_lockstep_kernel<EPI_BIAS>, grid, block, GEMM_LDS, (hipStream_t)stream, a);
-        else VLFM_KLAUNCH(gemm_f16_nt_lockstep_kernel<EPI_BIAS_GELU>, grid, block, GEMM_LDS, (hipStream_t)stream, a);
-    } else {
-        if (epilogue == 0) VLFM_KLAUNCH(gemm_f16_nt_kernel<EPI_BIAS>, grid, block, GEMM_LDS, (hipStream_t)stream, a);
-        else VLFM_KLAUNCH(gemm_f16_nt_kernel<EPI_BIAS_GELU>, grid, block, GEMM_LDS, (hipStream_t)stream, a);
-    }
-    return check_launch("gemm_f16_nt_kernel");
+    const char* ev = getenv("VLFM_GEMM_VARIANT");
+    int variant = ev ? atoi(ev) : GEMM_DEFAULT_VARIANT;
+    if (variant < 0 || variant > 3) variant = GEMM_DEFAULT_VARIANT;
+    if (epilogue == 2 && variant < 2) return fail(VLFM_ERR_INVALID, "gemm_f16_nt: epilogue 2 needs an 8-phase kernel");
+    if (epilogue == 0) return launch_gemm<EPI_BIAS>(a, variant, (hipStream_t)stream);
+    if (epilogue == 1) return launch_gemm<EPI_BIAS_GELU>(a, variant, (hipStream_t)stream);
+    return launch_gemm<EPI_ACCUM>(a, variant, (hipStream_t)stream);
 }

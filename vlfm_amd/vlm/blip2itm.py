@@ -61,6 +61,29 @@ class Blip2ITCConfig:
                               max_position_embeddings=40, num_query_tokens=5, proj_dim=8)
 
 
+DEFAULT_HIP_GEMMS = ("fc1",)
+
+
+def x_is_contiguous_f16(t: torch.Tensor) -> bool:
+    return t.dtype == torch.float16 and t.is_contiguous()
+
+
+def _default_hip_gemms() -> frozenset:
+    import os
+
+    v = os.environ.get("VLFM_VIT_GEMMS")
+    if v is None:
+        return frozenset(DEFAULT_HIP_GEMMS)
+    v = v.strip().lower()
+    if v == "all":
+        return frozenset(("qkv", "proj", "fc1", "fc2"))
+    if v in ("none", ""):
+        return frozenset()
+    names = frozenset(t.strip() for t in v.split(","))
+    assert names <= {"qkv", "proj", "fc1", "fc2"}, f"VLFM_VIT_GEMMS={v!r}"
+    return names
+
+
 class _VitBlock(nn.Module):
     def __init__(self, c: Blip2ITCConfig):
         super().__init__()
@@ -80,6 +103,9 @@ class _VitBlock(nn.Module):
         # fc1 + exact GELU in one hand-written MFMA kernel once the GEMM has this many rows (below, the library's smaller
         # tiles win: tools/gemm_f16_probe.py); 0 = always the library GEMM + a separate GELU pass
         self.hip_mlp_min_rows = 32 * 257
+        # which of the block's four GEMMs run on csrc/gemm_f16.hip's 8-phase kernel once the GEMM has hip_mlp_min_rows rows (the
+        # others go to hipBLASLt): any of "qkv", "proj", "fc1", "fc2".  VLFM_VIT_GEMMS = all | none | a comma list overrides.
+        self.hip_gemms = _default_hip_gemms()
 
     def pack_heads(self, multiple: int = 32) -> None:
         """Inference-time repacking for the attention kernel: the 88-wide heads of ViT-g are zero-padded to the next
@@ -105,6 +131,14 @@ class _VitBlock(nn.Module):
         self._packed = (wq.view(3 * h * hp, d).contiguous(), bb.view(-1).contiguous(), wp.view(d, h * hp).contiguous(),
                         hp, float(hd) ** -0.5)
 
+    def hip_gemms_at(self, rows: int) -> frozenset:
+        """The GEMMs of this block that run on csrc/gemm_f16.hip for an activation of ``rows`` rows: the configured set when the
+        batch is large enough for 256 x 256 tiles to fill the chip and the shapes meet the kernel's constraints (f16, K % 64, N % 8)."""
+        d = self.qkv.in_features
+        ok = (self.hip_mlp_min_rows and rows >= self.hip_mlp_min_rows and self.fc1.weight.dtype == torch.float16 and d % 64 == 0
+              and self.fc1.out_features % 64 == 0 and self.qkv.out_features % 8 == 0 and x_is_contiguous_f16(self.fc1.weight))
+        return self.hip_gemms if ok else frozenset()
+
     def forward_deferred(self, x: torch.Tensor, c_in: torch.Tensor, c_mid: torch.Tensor) -> torch.Tensor:
         """Same block, residual adds folded into the GEMMs: ``x`` is the residual stream MINUS the bias vectors of all
         projection / fc2 layers so far (``c_in`` = their f32 sum, a constant of the network; ``c_mid`` = c_in + this
@@ -116,13 +150,17 @@ class _VitBlock(nn.Module):
 
         b, n, d = x.shape
         hd = d // self.heads
+        hip = self.hip_gemms_at(b * n)
         h = ops.layernorm_bias(x, c_in, self.layer_norm1.weight, self.layer_norm1.bias, self.layer_norm1.eps)
         x2 = x.view(b * n, d)
         a = None
         if self.hip_attention and n == ops.VIT_ATTENTION_TOKENS and hd in ops.VIT_ATTENTION_HEADS:
             # native head width: the HIP kernel pads 88 -> 96 in LDS / registers only, so the qkv and projection GEMMs keep
             # their original sizes and the attention output needs no transpose copy
-            qkv = F.linear(h.view(b * n, d), self.qkv.weight, self.qkv.bias)
+            if "qkv" in hip:
+                qkv = ops.linear_f16(h.view(b * n, d), self.qkv.weight, self.qkv.bias, "bias")
+            else:
+                qkv = F.linear(h.view(b * n, d), self.qkv.weight, self.qkv.bias)
             try:
                 a = ops.vit_attention(qkv, b, n, self.heads, hd, float(hd) ** -0.5)
             except (RuntimeError, AssertionError, IndexError) as exc:   # e.g. the 117 KB LDS opt-in refused on this device
@@ -133,7 +171,10 @@ class _VitBlock(nn.Module):
                 warnings.warn(f"vlfm_vit_attention_f16 unavailable ({exc}); using the library attention kernel instead")
                 self.hip_attention = False
         if a is not None:
-            x2.addmm_(a, self.projection.weight.t())
+            if "proj" in hip:
+                ops.linear_f16(a, self.projection.weight, None, "accumulate", out=x2)     # x += a Wp^T, summed in f32
+            else:
+                x2.addmm_(a, self.projection.weight.t())
         elif self._packed is not None:
             wq, bq, wp, hp, scale = self._packed
             q = F.linear(h.view(b * n, d), wq, bq).view(b, n, 3, self.heads, hp).permute(2, 0, 3, 1, 4)
@@ -144,12 +185,14 @@ class _VitBlock(nn.Module):
             a = F.scaled_dot_product_attention(q[0], q[1], q[2]).transpose(1, 2).reshape(b * n, d)
             x2.addmm_(a, self.projection.weight.t())
         h = ops.layernorm_bias(x, c_mid, self.layer_norm2.weight, self.layer_norm2.bias, self.layer_norm2.eps)
-        if (self.hip_mlp_min_rows and b * n >= self.hip_mlp_min_rows and self.fc1.weight.dtype == torch.float16
-                and d % 64 == 0 and self.fc1.out_features % 8 == 0):   # the kernel's tile constraints (K % 64, N % 8)
+        if "fc1" in hip:
             act = ops.linear_gelu(h.view(b * n, d), self.fc1.weight, self.fc1.bias)   # GELU in the GEMM epilogue
         else:
             act = F.gelu(F.linear(h, self.fc1.weight, self.fc1.bias)).view(b * n, -1)
-        x2.addmm_(act, self.fc2.weight.t())
+        if "fc2" in hip:
+            ops.linear_f16(act, self.fc2.weight, None, "accumulate", out=x2)
+        else:
+            x2.addmm_(act, self.fc2.weight.t())
         return x
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -719,9 +762,14 @@ class BLIP2ITM:
         (hipBLASLt GEMM + a GELU pass)."""
         blk = self.model.blocks[0]
         rows = n_images * ((self.cfg.image_size // self.cfg.patch_size) ** 2 + 1)
-        ok = (blk.hip_mlp_min_rows and rows >= blk.hip_mlp_min_rows and blk.fc1.weight.dtype == torch.float16
-              and blk.fc1.in_features % 64 == 0 and blk.fc1.out_features % 8 == 0)
-        return "hip" if ok else "library"
+        return "hip" if "fc1" in blk.hip_gemms_at(rows) else "library"
+
+    def gemm_path(self, n_images: int) -> str:
+        """Which of a ViT block's GEMMs run on the hand-written 8-phase kernel at this batch size, e.g. "hip:fc1,fc2,proj,qkv"."""
+        blk = self.model.blocks[0]
+        rows = n_images * ((self.cfg.image_size // self.cfg.patch_size) ** 2 + 1)
+        names = sorted(blk.hip_gemms_at(rows))
+        return "hip:" + ",".join(names) if names else "library"
 
     def _load_pretrained(self, model_dir: str) -> None:
         from safetensors.torch import load_file

@@ -2,7 +2,7 @@
 from __future__ import annotations
 
 import ctypes
-from typing import Dict, Tuple
+from typing import Dict, Optional, Tuple
 
 import numpy as np
 import torch
@@ -253,19 +253,41 @@ def window_attention(qkv: torch.Tensor, bias_t: torch.Tensor, heads: int, scale:
     return out
 
 
-def linear_gelu(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
-    """gelu(x @ weight.T + bias), exact (erf) form, f16 in / f16 out with f32 accumulation: the hand-written MFMA GEMM of
-    csrc/gemm_f16.hip with the activation in its epilogue (hipBLASLt only fuses the tanh approximation, so the library path
-    is a GEMM plus a separate pass over the 4x-wide activation).  x [M, K], weight [N, K], bias [N]; K % 32 == 0, N % 8 == 0."""
+GEMM_F16_EPILOGUE = {"bias": 0, "bias_gelu": 1, "accumulate": 2}
+
+
+def linear_f16_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """Shapes csrc/gemm_f16.hip takes: f16 on the GPU, K % 64 == 0, N % 8 == 0, each operand below 4 GB."""
+    k = weight.shape[1]
+    return (x.is_cuda and x.dtype == torch.float16 and weight.dtype == torch.float16 and x.shape[-1] == k and k % 64 == 0
+            and weight.shape[0] % 8 == 0 and x.numel() * 2 < (1 << 32) and weight.numel() * 2 < (1 << 32))
+
+
+def linear_f16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: str = "bias",
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """epilogue(x @ weight.T + bias), f16 in / f16 out, f32 accumulation on the matrix cores: the hand-written 256 x 256 x 64
+    8-phase GEMM of csrc/gemm_f16.hip.  x [M, K], weight [N, K], bias [N] or None.  epilogue "bias": the plain Linear;
+    "bias_gelu": exact (erf) GELU on the f32 accumulators (hipBLASLt only fuses the tanh approximation, so the library path is a GEMM
+    plus a separate pass over the 4x-wide activation); "accumulate": ``out += x @ weight.T (+ bias)`` in place, summed in f32 -- the
+    residual-stream GEMMs (``out`` is required)."""
     assert x.is_cuda and x.dtype == torch.float16 and x.is_contiguous() and x.dim() == 2
     assert weight.dtype == torch.float16 and weight.is_contiguous() and weight.shape[1] == x.shape[1]
     assert bias is None or (bias.dtype == torch.float16 and bias.is_contiguous())
     M, K = x.shape
     N = weight.shape[0]
-    out = torch.empty((M, N), dtype=torch.float16, device=x.device)
+    if out is None:
+        assert epilogue != "accumulate", "accumulate needs the tensor to accumulate into"
+        out = torch.empty((M, N), dtype=torch.float16, device=x.device)
+    else:
+        assert out.dtype == torch.float16 and out.is_contiguous() and out.shape == (M, N) and out.device == x.device
     _lib.check(_lib.lib().vlfm_gemm_f16_nt(x.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                           out.data_ptr(), M, N, K, 1, _stream()), "gemm_f16_nt")
+                                           out.data_ptr(), M, N, K, GEMM_F16_EPILOGUE[epilogue], _stream()), "gemm_f16_nt")
     return out
+
+
+def linear_gelu(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """gelu(x @ weight.T + bias), exact (erf) form: ``linear_f16(..., epilogue="bias_gelu")``."""
+    return linear_f16(x, weight, bias, "bias_gelu")
 
 
 VIT_ATTENTION_TOKENS, VIT_ATTENTION_HEADS = 257, (88, 96)
