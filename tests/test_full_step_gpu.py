@@ -145,3 +145,46 @@ def test_full_step_harness_equals_the_single_environment_policy(gpu_device, monk
         assert np.array_equal(expl[e], np.asarray(om.explored_area).astype(bool)), e
         assert np.array_equal(conf[e], vm._map), e
         assert np.array_equal(value[e].reshape(vm._value_map.shape), vm._value_map), e
+
+
+def test_blip2_beside_the_detector_equals_blip2_behind_it(gpu_device):
+    """At small batches the harness enqueues the BLIP-2 forward on its own stream BEFORE the detector (harness.vlm_stream) so that
+    the two run beside each other.  The order is not allowed to change anything: same cosines, same maps, same detections and
+    actions as with the forward behind the detector on the main stream (concurrent_vlm_max_envs=0), step by step."""
+    from vlfm_amd.harness import BatchedEpisodes, ScriptedSightings
+    from vlfm_amd.pointnav import WrappedPointNavResNetPolicy
+    from vlfm_amd.vlm.blip2itm import BLIP2ITM
+    from vlfm_amd.vlm.sam import MobileSAM
+    from vlfm_amd.vlm.yolov7 import YOLOv7
+
+    n = 4
+    blip2 = BLIP2ITM(device=gpu_device, allow_random_init=True)
+    det = YOLOv7(device=gpu_device, allow_random_init=True, width_multiple=0.25)
+    sam = MobileSAM(device=gpu_device, allow_random_init=True)
+    runs = []
+    for limit in (16, 0):
+        torch.manual_seed(5)
+        sight = ScriptedSightings(in_view_rate=0.9, distractor_rate=0.2, search_min=2, search_span=3, nav_steps=8, height=480,
+                                  width=640, desync=False)
+        sim = BatchedEpisodes(n, device=gpu_device, blip2=blip2, detector=det, sam=sam, select_frontiers=True, object_maps=True,
+                              sightings=sight, scripted_masks=True, concurrent_vlm_max_envs=limit,
+                              pointnav=WrappedPointNavResNetPolicy(None, device=gpu_device, n_envs=n, discrete_actions=True))
+        assert (sim.vlm_stream is not None) == (limit > 0)
+        trace = []
+        for _ in range(22):
+            sim.step()
+            torch.cuda.synchronize()
+            trace.append((sim.last_cosines.double().cpu().numpy().copy(), list(sim.last_modes),
+                          None if sim.last_goals is None else np.array(sim.last_goals, copy=True),
+                          [int(d.num_detections) for d in sim.last_detections]))
+        sim.check()
+        runs.append((trace, sim.values.conf.cpu().numpy().copy(), sim.values.value.cpu().numpy().copy(),
+                     sim.obstacles.explored.cpu().numpy().copy()))
+        del sim
+    (ta, ca, va, ea), (tb, cb, vb, eb) = runs
+    for k, (a, b) in enumerate(zip(ta, tb)):
+        assert np.array_equal(a[0], b[0]), k
+        assert a[1] == b[1] and a[3] == b[3], k
+        assert (a[2] is None and b[2] is None) or np.array_equal(a[2], b[2], equal_nan=True), k
+    assert np.array_equal(ca, cb) and np.array_equal(va, vb) and np.array_equal(ea, eb)
+    assert any(m == "navigate" for a in ta for m in a[1])      # the object-map branch ran

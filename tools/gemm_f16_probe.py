@@ -82,6 +82,17 @@ for name, N, K, epi in [("fc1+gelu", 6144, 1408, 1), ("qkv", 4224, 1408, 0), ("p
         ts = sorted(ts); med = ts[len(ts) // 2]
         line += f"{k} {med*1e6:7.1f} us ({fl/med/1e15:.3f} PF, min {ts[0]*1e6:.1f}) | "
     print(line)
+    # tile order: m-tiles per group (VLFM_GEMM_GROUP_M), 8-phase kernel
+    line = f"{name:9s} group_m sweep (8-phase): "
+    for gm in (1, 2, 4, 8, 16, 32):
+        os.environ["VLFM_GEMM_GROUP_M"] = str(gm)
+        fn = arms[NAMES[2]] if NAMES[2] in arms else None
+        if fn is None: break
+        for _ in range(2): fn()
+        ts = sorted(t_once(fn, 5) for _ in range(3))
+        line += f"gm={gm}: {ts[1]*1e6:.1f} us | "
+    os.environ.pop("VLFM_GEMM_GROUP_M", None)
+    print(line)
 if not args.quick:
     # crossover against the library at small batches (fc1 + GELU), best 8-phase variant vs library
     for imgs in (1, 8, 16, 32, 64, 128):

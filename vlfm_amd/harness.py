@@ -194,7 +194,7 @@ class BatchedEpisodes:
                  pointnav=None, world: str = "rooms", object_maps: bool = False,
                  sightings: Optional["ScriptedSightings"] = None, scripted_masks: bool = False,
                  coco_threshold: float = 0.8, non_coco_threshold: float = 0.4, pointnav_stop_radius: float = 0.9,
-                 object_map_erosion_size: float = 5) -> None:
+                 object_map_erosion_size: float = 5, concurrent_vlm_max_envs: int = 16) -> None:
         self.device = require_gpu(device)
         # a rank waiting for its GPU must not hold a host core (bench.py `host`).  Effective only before the device's first
         # stream exists (bench.py sets it first thing); here it is best effort: a warning on failure, VLFM_HOST_WAIT=spin opts out
@@ -288,6 +288,10 @@ class BatchedEpisodes:
         self.map_stream = torch.cuda.Stream(self.device) if overlap else None
         # SAM + ObjectPointCloudMap updates (a chain of small kernels and host read-backs) run beside the BLIP-2 forward (step())
         self.obj_stream = torch.cuda.Stream(self.device) if overlap else None
+        # Small batches (BASELINE configs[2]: 8 environments): neither the detector (a HIP graph of ~1 700 short kernels for
+        # GroundingDINO) nor the BLIP-2 forward of 8 frames fills the chip, so the BLIP-2 forward is enqueued FIRST, on its own
+        # stream, and the detector runs beside it instead of in front of it.  At large batches both saturate the GPU on their own.
+        self.vlm_stream = torch.cuda.Stream(self.device) if overlap and n_envs <= concurrent_vlm_max_envs else None
         self.last_cosines: Optional[torch.Tensor] = None
         self.last_frontier_values: Optional[np.ndarray] = None
         # frontier selection of ITMPolicyV2 (stick-to-last rule, itm_policy.py:76-152), one selector per environment
@@ -647,12 +651,23 @@ class BatchedEpisodes:
                 d = self._scripted_detections(t_ep)     # the scripted HEAD: the network above ran (and is timed), its random logits are not used
             return d
 
+        def perceive():
+            return (self.blip2.cosine_batch_graphed(rgb, self.prompts) if self.graph_blip2
+                    else self.blip2.cosine_batch(rgb, self.prompts))
+
+        cos = None
+        vlm_beside = detector_first and self.vlm_stream is not None and self.blip2 is not None
+        if vlm_beside:
+            self.vlm_stream.wait_stream(main)          # (the frames of this step are complete on the main stream)
+            with torch.cuda.stream(self.vlm_stream):
+                cos = perceive()
         if detector_first:
             dets = detect()
         # ---- perception (main stream): one batched BLIP-2 ITC forward for all resident envs
-        if self.blip2 is not None:
-            cos = (self.blip2.cosine_batch_graphed(rgb, self.prompts) if self.graph_blip2
-                   else self.blip2.cosine_batch(rgb, self.prompts))
+        if cos is not None:
+            pass
+        elif self.blip2 is not None:
+            cos = perceive()
         else:
             cos = torch.from_numpy(self.stub_rng.uniform(0.15, 0.45, size=self.E)).to(self.device)
         self.last_cosines = cos
@@ -685,6 +700,9 @@ class BatchedEpisodes:
             env_of = np.repeat(np.arange(self.E), self.n_frontiers)
         # ---- mapping, part 2 (main stream): value-map fusion needs the cosines and the column maxima
         main.wait_stream(side)
+        if vlm_beside:
+            main.wait_stream(self.vlm_stream)          # the cosines; and the next step may not repaint the frames under the ViT
+            cos.record_stream(main)
         self.values.update(cos.reshape(self.E, 1), None, tf, MIN_DEPTH, MAX_DEPTH, self.fov, colmax=colmax)
         # ---- frontier scoring (ITMPolicyV2._sort_frontiers_by_value, radius 0.5 m)
         self.last_frontier_values = None
