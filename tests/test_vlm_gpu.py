@@ -295,6 +295,8 @@ def test_vit_all_four_gemms_on_the_8phase_kernel_full_geometry(gpu_device):
         for n, p in m.named_parameters():
             if p.dim() == 1 and "norm" not in n.lower():
                 p.copy_(torch.randn(p.shape, generator=g, device=gpu_device, dtype=torch.float32).to(p.dtype) * 0.1)
+        for blk in m.blocks:
+            blk.pack_heads()          # (the plain path runs on packed copies of the qkv / projection parameters)
     m._deferred_c = None
     pat = torch.randn(40, 256, 588, generator=g, device=gpu_device, dtype=torch.float32).half()
     with torch.inference_mode():

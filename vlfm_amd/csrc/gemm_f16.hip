@@ -48,7 +48,7 @@ constexpr int EPI_ROW = 272;       // epilogue staging row stride (128 n x 2 B +
 constexpr int EPI_WAVE = 64 * EPI_ROW;
 constexpr int GEMM_LDS = 8 * EPI_WAVE > 2 * BUF ? 8 * EPI_WAVE : 2 * BUF;
 
-constexpr int GEMM_DEFAULT_VARIANT = 2;   // 0 ping-pong (round 2), 1 lock-step, 2 8-phase, 3 8-phase balanced
+constexpr int GEMM_DEFAULT_VARIANT = 3;   // 0 ping-pong (round 2), 1 lock-step, 2 8-phase, 3 8-phase balanced (fastest), 4 / 5 = 2 / 3 with one barrier per phase
 enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_ACCUM = 2 };   // 2: C += X . W^T (+ bias): the residual-stream GEMMs (projection, fc2)
 
 struct GemmArgs {
@@ -126,20 +126,38 @@ __device__ inline void mma_half(const half8 (&fa)[8], const half8 (&fb)[4], floa
 
 // Epilogue of one wavefront: bias (+ exact GELU) on the f32 accumulators, f16, transpose through a wavefront-private LDS region
 // (it aliases the operand buffers: the caller guarantees that every wavefront is past its last operand read), 16-byte stores.
+// Round 5: every global load of the epilogue (the 8 bias quads; for EPI_ACCUM the 16 row segments of the residual stream) is
+// issued BEFORE the arithmetic, all 16 LDS reads of the second half before the first store, and the stores back to back.  The
+// round-2 form loaded each bias quad where it was used (8 dependent L2 round trips) and re-used one register quad for the 16
+// ds_read_b128 / global_store pairs, which made hipcc wait vmcnt(0) -- for the previous STORE to leave -- before every read: a
+// fixed 13-15 us per tile (tools/gemm_f16_probe.py: time = a + b K / 64 over the K = 1408 / 6144 pair of shapes), a third of a
+// K = 1408 tile.
 template <int EPI>
 __device__ inline void store_tile(const GemmArgs& a, unsigned char* smem, const floatx4 (&acc)[8][4], int wave, int wn, int wm,
-                                  int lane, int m0, int n0) {
+                                  int lane, int m0, int n0, int wave_cols = 128) {
+    // wave_cols: n columns this wavefront owns (128; 64 in the 8-phase kernel's half-tile mode, where acc[4..7] are unused)
+    n0 += wn * wave_cols - wn * 128;     // (the code below adds wn * 128)
     unsigned char* stg = smem + wave * EPI_WAVE;
     const int g4 = (lane >> 4) * 4, c16 = lane & 15;
+    const int rsub = lane >> 4, chunk = lane & 15;
+    half4 bias4[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        bias4[i] = half4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        if (a.bias) bias4[i] = *reinterpret_cast<const half4*>(a.bias + min(n0 + wn * 128 + i * 16 + g4, a.N - 4));
+    }
+    uint4 old[EPI == EPI_ACCUM ? 16 : 1];
+    if (EPI == EPI_ACCUM) {
+#pragma unroll
+        for (int it = 0; it < 16; it++) {   // (clamped addresses: rows / columns beyond the matrix are loaded from its edge, never stored)
+            const int m = min(m0 + wm * 64 + it * 4 + rsub, a.M - 1), n = max(min(n0 + wn * 128 + chunk * 8, a.N - 8), 0);
+            old[it] = *reinterpret_cast<const uint4*>(a.c + (size_t)m * a.N + n);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const int nl = i * 16 + g4;                    // 4 consecutive n of this lane, wavefront-local
-        float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-        if (a.bias) {
-            const int n = min(n0 + wn * 128 + nl, a.N - 4);
-            const half4 bv = *reinterpret_cast<const half4*>(a.bias + n);
-            b0 = (float)bv[0]; b1 = (float)bv[1]; b2 = (float)bv[2]; b3 = (float)bv[3];
-        }
+        const float b0 = (float)bias4[i][0], b1 = (float)bias4[i][1], b2 = (float)bias4[i][2], b3 = (float)bias4[i][3];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             float v0 = acc[i][j][0] + b0, v1 = acc[i][j][1] + b1, v2 = acc[i][j][2] + b2, v3 = acc[i][j][3] + b3;
@@ -149,21 +167,25 @@ __device__ inline void store_tile(const GemmArgs& a, unsigned char* smem, const 
         }
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);   // wavefront-private region: no workgroup barrier needed
-    const int rsub = lane >> 4, chunk = lane & 15;
+    uint4 v[16];
 #pragma unroll
-    for (int it = 0; it < 16; it++) {
-        const int row = it * 4 + rsub;
-        uint4 v = *reinterpret_cast<const uint4*>(stg + row * EPI_ROW + chunk * 16);
-        const int m = m0 + wm * 64 + row, n = n0 + wn * 128 + chunk * 8;
-        if (m < a.M && n + 8 <= a.N) {
-            if (EPI == EPI_ACCUM) {   // beta = 1: the stream's 8 halves of this row segment + the product, summed in f32
-                const half8 old = *reinterpret_cast<const half8*>(a.c + (size_t)m * a.N + n);
-                half8 h = *reinterpret_cast<const half8*>(&v);
+    for (int it = 0; it < 16; it++) v[it] = *reinterpret_cast<const uint4*>(stg + (it * 4 + rsub) * EPI_ROW + chunk * 16);
+    if (EPI == EPI_ACCUM) {   // beta = 1: the stream's 8 halves of each row segment + the product, summed in f32
 #pragma unroll
-                for (int e = 0; e < 8; e++) h[e] = (_Float16)((float)h[e] + (float)old[e]);
-                v = *reinterpret_cast<const uint4*>(&h);
-            }
-            *reinterpret_cast<uint4*>(a.c + (size_t)m * a.N + n) = v;
+        for (int it = 0; it < 16; it++) {
+            half8 h = *reinterpret_cast<const half8*>(&v[it]);
+            const half8 o = *reinterpret_cast<const half8*>(&old[it]);
+#pragma unroll
+            for (int e = 0; e < 8; e++) h[e] = (_Float16)((float)h[e] + (float)o[e]);
+            v[it] = *reinterpret_cast<const uint4*>(&h);
+        }
+    }
+    const int n = n0 + wn * 128 + chunk * 8;
+    if (n + 8 <= a.N && chunk * 8 < wave_cols) {
+#pragma unroll
+        for (int it = 0; it < 16; it++) {
+            const int m = m0 + wm * 64 + it * 4 + rsub;
+            if (m < a.M) *reinterpret_cast<uint4*>(a.c + (size_t)m * a.N + n) = v[it];
         }
     }
 }
@@ -343,7 +365,20 @@ __global__ __launch_bounds__(512) void gemm_f16_nt_kernel(GemmArgs a) {
 //   RAW: the wait of phase 4 -- before that phase's FIRST barrier -- leaves only the 4 loads of phases 3 and 4 (tile t + 2) in flight:
 //        tile t + 1 is complete as far as this wavefront's shares go; the early group reads it two barriers later, the late group
 //        three, and by then every wavefront has executed its own wait (the late group's sits one barrier behind the early group's).
-template <int EPI, int BAL>
+// Optional per-workgroup wall-clock stamps (diagnostic build with -DVLFM_PHASE_TIMING; tools/gemm_stamp_probe.py): thread 0 of
+// every workgroup records entry / prologue done / main loop done / epilogue done on the 100 MHz clock.
+#ifdef VLFM_PHASE_TIMING
+__device__ long long g_gemm_bar[2 * 512];    // workgroup 300 (a mid-launch one), wavefronts 0 and 4: shader clock behind each barrier
+__device__ long long g_gemm_clk[8192 * 4];
+#define GEMM_STAMP(k)                                                                                         \
+    do {                                                                                                      \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_clk[blockIdx.x * 4 + (k)] = wall_clock64();        \
+    } while (0)
+#else
+#define GEMM_STAMP(k) do {} while (0)
+#endif
+
+template <int EPI, int BAL, int SYNC = 2>
 struct Gemm8p {
     static constexpr int SLOT = 128 * ROWB;      // 16 KB
     static constexpr int KBUF = 4 * SLOT;        // one K-tile: 64 KB
@@ -352,7 +387,11 @@ struct Gemm8p {
     lds_ptr lds;
     const unsigned char* smem;
     int wave, lane;
-    bool active;                // this wavefront's 128 W rows are not all beyond N (the half-empty last n-tile of N = 1408 / 4224)
+    bool half;                  // half tile: at most 128 valid W rows (the last n-tile of N = 1408 / 4224).  The two wavefront groups
+                                // then take 64 rows each (P_H0 only) and phases 3 and 4 carry no work -- with the full-tile mapping
+                                // one group would own all 128 rows, the other none, and the ping-pong would degenerate to "read, then
+                                // compute" at three quarters of a full tile's time for half the work
+    bool active;                // this wavefront's W rows are not all beyond N
     uint32_t voff[4][2];        // per slot and chunk: byte offset of this lane's 16 B inside the operand, without the K-tile term
     uint32_t rdP[2], rdQ[2];    // fragment read offsets inside a slot, by kk (the swizzle turns kk into an XOR of 64 B)
     half8 fp[4][2], fq0[BAL ? 2 : 1][2][2], fq1[2][2];   // BAL: Q_H0 of the NEXT tile is read in phase 4 into the other set
@@ -363,7 +402,8 @@ struct Gemm8p {
         lane = tid & 63;
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int wn = wave >> 2, wm = wave & 3;
-        active = n0 + wn * 128 < a.N;
+        half = false;   // (half-tile mode: measured, no gain -- see tile())
+        active = n0 + wn * (half ? 64 : 128) < a.N;
         const int sub = lane >> 3, p = lane & 7;
 #pragma unroll
         for (int j = 0; j < 2; j++) {
@@ -372,7 +412,7 @@ struct Gemm8p {
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const int rq = min(m0 + (rho >> 5) * 64 + h * 32 + (rho & 31), a.M - 1);
-                const int rp = min(n0 + (rho >> 6) * 128 + h * 64 + (rho & 63), a.N - 1);
+                const int rp = min(n0 + (half ? rho + h * 128 : (rho >> 6) * 128 + h * 64 + (rho & 63)), a.N - 1);
                 voff[2 * h][j] = (uint32_t)rq * (uint32_t)a.K * 2u + (uint32_t)s * 16u;
                 voff[2 * h + 1][j] = (uint32_t)rp * (uint32_t)a.K * 2u + (uint32_t)s * 16u;
             }
@@ -425,29 +465,53 @@ struct Gemm8p {
                     acc[PI * 4 + f][QJ * 2 + g] =
                         __builtin_amdgcn_mfma_f32_16x16x32_f16(fp[f][kk], fq[g][kk], acc[PI * 4 + f][QJ * 2 + g], 0, 0, 0);
     }
+#ifdef VLFM_PHASE_TIMING
+    int bar_count = 0;
+    __device__ inline void bar() {
+        const long long t_arrive = clock64();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (blockIdx.x == 300 && lane == 0 && (wave & 3) == 0 && bar_count < 256) {
+            g_gemm_bar[(wave >> 2) * 512 + 2 * bar_count] = t_arrive;
+            g_gemm_bar[(wave >> 2) * 512 + 2 * bar_count + 1] = clock64();
+        }
+        bar_count++;
+    }
+#else
     static __device__ inline void bar() {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
+#endif
     // [fragments + staging issued by the caller] | barrier | fragments have arrived | 16 MFMAs | barrier
     template <int PI, int QJ>
-    __device__ inline void compute(const half8 (&fq)[2][2]) {
+    __device__ inline void compute(const half8 (&fq)[2][2], bool work = true) {
         bar();
         __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this phase's reads are in registers -- and out of the slot
         __builtin_amdgcn_sched_barrier(0);
-        if (active) {
+        if (active && work) {
             __builtin_amdgcn_s_setprio(1);
             mma<PI, QJ>(fq);
             __builtin_amdgcn_s_setprio(0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        bar();
+        // SYNC 2: a second barrier closes the phase, and the late group runs one barrier behind: strict alternation of the two
+        // wavefronts of a SIMD between "read" and "MFMA".  SYNC 1: ONE barrier per phase and no stagger -- the two wavefronts of a
+        // SIMD leave the barrier together, one gets the matrix pipe first, the other follows, and each reads its next fragments
+        // when it is done: the offset re-creates itself every phase.  Same hazards: a slot is re-staged two barriers after the
+        // barrier that followed its last read (whose lgkmcnt(0) every wavefront executes before it can arrive at the next one),
+        // and the counted vmcnt wait precedes the barrier in front of the first read.
+        if (SYNC == 2) bar();
     }
 
     // K-tile t in buffer B (compile-time: the buffer term of every ds_read offset is an immediate).
     // BAL = 1 ("balanced"): the Q_H0 fragments of tile t + 1 are read in phase 4 of tile t (which has no reads of its own) instead
     // of in phase 1 of tile t + 1 (which has the 8 P reads): 8 / 4 / 8 / 4 ds_read_b128 per phase instead of 12 / 4 / 8 / 0.  Slot 0 of
     // tile t + 1 therefore has to be complete one phase earlier: a second counted wait, vmcnt(8), in phase 3.
+    // Measured and dropped (round 5, profiles/r05_gemm_*): a counted wait in EVERY phase (vmcnt(8): each half-tile gets four
+    // phases to land instead of two to five) -- no gain on the N = 4224 / 6144 shapes, 7 % slower on fc2: the K-tile time is not a
+    // memory-latency effect (see the barrier stamps in DESIGN.md); a half-tile mode that splits the 128 valid W rows of the last
+    // n-tile over both wavefront groups and leaves phases 3 and 4 empty -- no gain either, the barriers cost what they cost.
     template <int B>
     __device__ inline void tile(int t, int NT) {
         constexpr int QS = BAL ? B : 0;
@@ -488,46 +552,72 @@ struct Gemm8p {
 
     __device__ inline void run(int m0, int n0) {
         const int NT = a.K / GK;
-        const int late = wave >> 2;
+        const int late = SYNC == 2 ? wave >> 2 : 0;
+        GEMM_STAMP(0);
         // prologue: all of tile 0, slots 0 and 1 of tile 1
         stage<0>(0, 0); stage<1>(0, 0); stage<2>(0, 0); stage<3>(0, 0);
         if (NT > 1) {
             stage<0>(1, 1); stage<1>(1, 1);
-            __builtin_amdgcn_s_waitcnt(0x0F74);
+            __builtin_amdgcn_s_waitcnt(0x0F74);      // all of tile 0 (behind it: slots 0, 1 of tile 1)
         } else {
             __builtin_amdgcn_s_waitcnt(0x0F70);
         }
         bar();
+        GEMM_STAMP(1);
         if (late) bar();
         if (BAL && active) read_q<0, 0>(fq0[0]);     // (retired by the lgkmcnt(0) of the first phase)
         for (int t = 0; t < NT; t += 2) {
             tile<0>(t, NT);
             if (t + 1 < NT) tile<1>(t + 1, NT);
         }
-        if (!late) bar();       // the late group's last MFMA phase; behind it nobody reads the operand buffers any more
-        store_tile<EPI>(a, const_cast<unsigned char*>(smem), acc, wave, wave >> 2, wave & 3, lane, m0, n0);
+        if (!late) bar();       // (the late group's last MFMA phase;) behind it nobody reads the operand buffers any more
+        GEMM_STAMP(2);
+        store_tile<EPI>(a, const_cast<unsigned char*>(smem), acc, wave, wave >> 2, wave & 3, lane, m0, n0, half ? 64 : 128);
+#ifdef VLFM_PHASE_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the stamp below is "stores have left", not "stores were issued")
+#endif
+        GEMM_STAMP(3);
     }
 };
 
-template <int EPI, int BAL>
-__global__ __launch_bounds__(512) void gemm_f16_8p_kernel(GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// Tile of a workgroup.  Workgroup ids go round-robin over the 8 XCDs; every XCD gets a contiguous range of the tile list (tiles
+// sharing operand panels meet in one L2), walked in groups of GM m-tiles, m fastest.  When the last column of n-tiles is at most
+// half full (N = 1408: 5.5 tiles, N = 4224: 16.5) its tiles run in about half the time of a full one (the wavefronts of the empty
+// half skip their reads and MFMAs): they are listed LAST within each XCD, so that they fill the ragged end of the last wave of
+// workgroups instead of being scattered through it -- 257 x 6 tiles on 256 CUs were 7 rounds of full-tile time, the work is 5.6.
+__device__ inline void tile_of_block(const GemmArgs& a, int& tm, int& tn) {
     const int nwg = a.tiles_m * a.tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    int tm, tn;
-    {
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int tail_cols = a.N - (a.tiles_n - 1) * GB;
+    const bool ragged = a.tiles_n > 1 && tail_cols <= GB / 2;
+    const int ncols = ragged ? a.tiles_n - 1 : a.tiles_n;
+    const int nfull = a.tiles_m * ncols, nhalf = nwg - nfull;
+    const int qf = nfull >> 3, rf = nfull & 7, qh = nhalf >> 3, rh = nhalf & 7;
+    const int myfull = qf + (xcd < rf ? 1 : 0);
+    if (idx < myfull) {
+        const int f = xcd * qf + min(xcd, rf) + idx;
         const int GM = a.group_m;
-        const int per_group = GM * a.tiles_n, grp = bid / per_group, in = bid - grp * per_group;
+        const int per_group = GM * ncols, grp = f / per_group, in = f - grp * per_group;
         const int rows = min(GM, a.tiles_m - grp * GM);
         tn = in / rows;
         tm = grp * GM + (in - tn * rows);
+    } else {
+        // the XCDs {rf, rf + 1, ...} (mod 8) take the nhalf % 8 extra half tiles: together with the nfull % 8 extra full ones of
+        // XCDs [0, rf) that is exactly the round-robin share of every XCD
+        int before = 0;
+        for (int x = 0; x < xcd; x++) before += (((x - rf) & 7) < rh) ? 1 : 0;
+        tm = xcd * qh + before + (idx - myfull);
+        tn = a.tiles_n - 1;
     }
+}
+
+template <int EPI, int BAL, int SYNC = 2>
+__global__ __launch_bounds__(512) void gemm_f16_8p_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int tm, tn;
+    tile_of_block(a, tm, tn);
     const int m0 = tm * GB, n0 = tn * GB;
-    Gemm8p<EPI, BAL> g(a, smem, m0, n0);
+    Gemm8p<EPI, BAL, SYNC> g(a, smem, m0, n0);
     g.run(m0, n0);
 }
 
@@ -543,9 +633,11 @@ template <int EPI>
 static int launch_gemm(const GemmArgs& a, int variant, hipStream_t stream) {
     const void* fn = variant == 0 ? reinterpret_cast<const void*>(gemm_f16_nt_kernel<EPI>)
                    : variant == 1 ? reinterpret_cast<const void*>(gemm_f16_nt_lockstep_kernel<EPI>)
-                   : variant == 2 ? reinterpret_cast<const void*>(gemm_f16_8p_kernel<EPI, 0>)
-                                  : reinterpret_cast<const void*>(gemm_f16_8p_kernel<EPI, 1>);
-    static LdsOptIn opt[4];
+                   : variant == 2 ? reinterpret_cast<const void*>(gemm_f16_8p_kernel<EPI, 0, 2>)
+                   : variant == 3 ? reinterpret_cast<const void*>(gemm_f16_8p_kernel<EPI, 1, 2>)
+                   : variant == 4 ? reinterpret_cast<const void*>(gemm_f16_8p_kernel<EPI, 0, 1>)
+                                  : reinterpret_cast<const void*>(gemm_f16_8p_kernel<EPI, 1, 1>);
+    static LdsOptIn opt[6];
     if (!opt[variant].ensure(fn, GEMM_LDS)) return fail(VLFM_ERR_HIP, "gemm_f16_nt: cannot opt in to the LDS size");
     const dim3 grid(a.tiles_m * a.tiles_n), block(512);
     // (profile name by epilogue: in the ViT block 0 = qkv, 1 = fc1 + GELU, 2 = projection and fc2, one launch each)
@@ -553,8 +645,10 @@ static int launch_gemm(const GemmArgs& a, int variant, hipStream_t stream) {
                ? "gemm_f16_8p_kernel<1>" : "gemm_f16_8p_kernel<2>", stream);
     if (variant == 0) VLFM_KLAUNCH(gemm_f16_nt_kernel<EPI>, grid, block, GEMM_LDS, stream, a);
     else if (variant == 1) VLFM_KLAUNCH(gemm_f16_nt_lockstep_kernel<EPI>, grid, block, GEMM_LDS, stream, a);
-    else if (variant == 2) VLFM_KLAUNCH((gemm_f16_8p_kernel<EPI, 0>), grid, block, GEMM_LDS, stream, a);
-    else VLFM_KLAUNCH((gemm_f16_8p_kernel<EPI, 1>), grid, block, GEMM_LDS, stream, a);
+    else if (variant == 2) VLFM_KLAUNCH((gemm_f16_8p_kernel<EPI, 0, 2>), grid, block, GEMM_LDS, stream, a);
+    else if (variant == 3) VLFM_KLAUNCH((gemm_f16_8p_kernel<EPI, 1, 2>), grid, block, GEMM_LDS, stream, a);
+    else if (variant == 4) VLFM_KLAUNCH((gemm_f16_8p_kernel<EPI, 0, 1>), grid, block, GEMM_LDS, stream, a);
+    else VLFM_KLAUNCH((gemm_f16_8p_kernel<EPI, 1, 1>), grid, block, GEMM_LDS, stream, a);
     return check_launch("gemm_f16_nt_kernel");
 }
 
@@ -576,9 +670,20 @@ extern "C" int vlfm_gemm_f16_nt(const void* d_x, const void* d_w, const void* d_
     if (a.group_m < 1) a.group_m = 1;
     const char* ev = getenv("VLFM_GEMM_VARIANT");
     int variant = ev ? atoi(ev) : GEMM_DEFAULT_VARIANT;
-    if (variant < 0 || variant > 3) variant = GEMM_DEFAULT_VARIANT;
+    if (variant < 0 || variant > 5) variant = GEMM_DEFAULT_VARIANT;
     if (epilogue == 2 && variant < 2) return fail(VLFM_ERR_INVALID, "gemm_f16_nt: epilogue 2 needs an 8-phase kernel");
     if (epilogue == 0) return launch_gemm<EPI_BIAS>(a, variant, (hipStream_t)stream);
     if (epilogue == 1) return launch_gemm<EPI_BIAS_GELU>(a, variant, (hipStream_t)stream);
     return launch_gemm<EPI_ACCUM>(a, variant, (hipStream_t)stream);
 }
+
+#ifdef VLFM_PHASE_TIMING
+extern "C" int vlfm_debug_gemm_barriers(long long* h_out1024) {
+    return hipMemcpyFromSymbol(h_out1024, HIP_SYMBOL(g_gemm_bar), sizeof(long long) * 1024) == hipSuccess ? VLFM_OK : VLFM_ERR_HIP;
+}
+extern "C" int vlfm_debug_gemm_clocks(long long* h_out, int n_workgroups) {
+    if (n_workgroups > 8192) n_workgroups = 8192;
+    return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_gemm_clk), sizeof(long long) * 4 * n_workgroups) == hipSuccess ? VLFM_OK
+                                                                                                               : VLFM_ERR_HIP;
+}
+#endif

@@ -194,7 +194,7 @@ class BatchedEpisodes:
                  pointnav=None, world: str = "rooms", object_maps: bool = False,
                  sightings: Optional["ScriptedSightings"] = None, scripted_masks: bool = False,
                  coco_threshold: float = 0.8, non_coco_threshold: float = 0.4, pointnav_stop_radius: float = 0.9,
-                 object_map_erosion_size: float = 5, concurrent_vlm_max_envs: int = 16) -> None:
+                 object_map_erosion_size: float = 5, concurrent_vlm_max_envs: int = 0) -> None:
         self.device = require_gpu(device)
         # a rank waiting for its GPU must not hold a host core (bench.py `host`).  Effective only before the device's first
         # stream exists (bench.py sets it first thing); here it is best effort: a warning on failure, VLFM_HOST_WAIT=spin opts out
@@ -288,9 +288,16 @@ class BatchedEpisodes:
         self.map_stream = torch.cuda.Stream(self.device) if overlap else None
         # SAM + ObjectPointCloudMap updates (a chain of small kernels and host read-backs) run beside the BLIP-2 forward (step())
         self.obj_stream = torch.cuda.Stream(self.device) if overlap else None
-        # Small batches (BASELINE configs[2]: 8 environments): neither the detector (a HIP graph of ~1 700 short kernels for
-        # GroundingDINO) nor the BLIP-2 forward of 8 frames fills the chip, so the BLIP-2 forward is enqueued FIRST, on its own
-        # stream, and the detector runs beside it instead of in front of it.  At large batches both saturate the GPU on their own.
+        # Optional (concurrent_vlm_max_envs > 0, VLFM_VLM_BESIDE): at small batches neither the detector (a HIP graph of ~1 700 short
+        # kernels for GroundingDINO) nor the BLIP-2 forward of 8 frames fills the chip, so the BLIP-2 forward can be enqueued FIRST,
+        # on its own stream, with the detector beside it.  Measured in round 5 (profiles/r05_full_step_ab.txt): 323.6 -> 323.5
+        # env-steps/s at 8 environments (YOLOv7-E6E), 184 -> 185 with GroundingDINO, 783 -> 672 at 64: no gain -- the 8-environment
+        # step is bound by the host's launch rate and its read-backs, not by GPU occupancy -- so it is OFF by default; the
+        # equivalence test (tests/test_full_step_gpu.py) keeps the path honest.
+        import os
+
+        if os.environ.get("VLFM_VLM_BESIDE") is not None:      # diagnostic override (A/B runs): 0 = never, n = up to n environments
+            concurrent_vlm_max_envs = int(os.environ["VLFM_VLM_BESIDE"])
         self.vlm_stream = torch.cuda.Stream(self.device) if overlap and n_envs <= concurrent_vlm_max_envs else None
         self.last_cosines: Optional[torch.Tensor] = None
         self.last_frontier_values: Optional[np.ndarray] = None

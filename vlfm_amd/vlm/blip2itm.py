@@ -61,7 +61,10 @@ class Blip2ITCConfig:
                               max_position_embeddings=40, num_query_tokens=5, proj_dim=8)
 
 
-DEFAULT_HIP_GEMMS = ("fc1",)
+# measured at 256 images (tools/gemm_f16_probe.py, profiles/r05_gemm_probe.txt): fc1 + GELU 1.08 ms here against 1.24 ms for
+# hipBLASLt + a GELU pass; the projection 283 against 290-296 us; qkv 685 against 670 and fc2 1 021 against 956-980 us stay on the
+# library (with its per-shape tuned solutions)
+DEFAULT_HIP_GEMMS = ("fc1", "proj")
 
 
 def x_is_contiguous_f16(t: torch.Tensor) -> bool:
