@@ -401,6 +401,13 @@ __device__ __forceinline__ void depth_ingest_body(const IngestArgs& a) {
 //    entries on ONE counter per image serialises at ~260 ns each, and 4096 workgroups reading the same few hundred plane words
 //    at once are slower than the same reads spread over the streaming pass;
 //  * one queue per workgroup drained by all 512 lanes between two barriers: 185-213 us (every round stops all eight wavefronts).
+// Round 5 (tools/ingest_probe.py, same checksums): (a) a wavefront-level reject in front of the four candidate tests -- the hull
+// of fma(z, gx + gy, t11) over a lane's four texels (exact: the estimate is monotone in depth and column) against the band, one
+// ballot: 96.7 us against 95.7, no gain -- the rows row_may_hit() lets through are not where the time goes; (b) the f32 placement
+// tier INSIDE the drain (one candidate per lane, rigorous 16 x 2^-24 x M bound, exact chain for the ~3 per mille it cannot decide):
+// the tier's 19 uniform floats beside the exact chain's 24 overflow the scalar file -- 98 vector registers with the constants in
+// scalar registers, 154-168 with the constants in LDS (volatile or not), 121 + a 336-byte stack frame as a noinline function:
+// every form gives up the third workgroup per CU before it saves an instruction.  The kernel stays as it is.
 // Register budget / prefetch variants measured at 256 x 640x480 (tools/ingest_probe.py, round 3): the compiler's own
 // allocation without software prefetch (79 VGPRs, 3 workgroups per CU) 95 us; prefetch of the next iteration's rows held to
 // 4 waves per SIMD 96 us, to 6 waves per SIMD (spills) 130 us; no prefetch held to 4 waves 107 us.  One form is kept.

@@ -401,9 +401,18 @@ __device__ long long g_vm_phase[16];
 // where the visible bit -- which already contains the cone sector -- is set, so template[y][x] == quad[|y-T/2|][|x-T/2|] for
 // every tap taken.  With the taps in LDS there is nothing to batch in the first phase: each row's new confidence is finished
 // at once and only one float per row stays live, which keeps the kernel free of register spills at 16 wavefronts.
+// Round 5: the cells a tile wants to fuse (new confidence != 0) are first COLLECTED into a per-workgroup LDS list -- (row, col,
+// new confidence), 8 bytes -- and fused afterwards by fuse_list() with one lane per cell.  The tile sweep above was 14 dependent
+// [LDS phase -> issue map reads -> wait -> fuse -> store] round trips per wavefront (7 passes x 2 half tiles) with three quarters
+// of the lanes idle in each; at 256 observations, every CU waiting on the same memory system, those round trips were 26 of the
+// kernel's 56 us (tools/vm_phase_probe.py).  The list form is one or two round trips with every lane busy.  When the list is full
+// (more than `cap` cells: only a cone far wider than a camera's) a wavefront fuses its rows in place, the old way.
+constexpr unsigned LIST_SENTINEL = 0xFFFFFFFFu;
+
 template <int C_STATIC>
 __device__ inline void fuse_tile_lds(const UpdateArgs& a, const vlfm_vm_pose& pose, const unsigned* vis, const float* quad,
-                                     const int2* row_xy0, const int4 box, int row_begin, int tid, unsigned* written) {
+                                     const int2* row_xy0, const int4 box, int row_begin, int tid, unsigned* written,
+                                     uint2* list = nullptr, int* list_n = nullptr, int cap = 0) {
     const int T = a.T, S = a.S;
     const int words = (T + 31) >> 5;
     const int C = C_STATIC > 0 ? C_STATIC : a.C;
@@ -478,6 +487,33 @@ __device__ inline void fuse_tile_lds(const UpdateArgs& a, const vlfm_vm_pose& po
             for (int k = 0; k < R; k++) any_on |= nw[k] != 0.0f;
             if (__ballot(any_on) == 0ull) continue;
         }
+        if (list) {
+            // one LDS atomic per wavefront and half tile reserves the slots of its R rows; row k's cells follow row k - 1's
+            unsigned long long mk[R];
+            int tot = 0;
+#pragma unroll
+            for (int k = 0; k < R; k++) {
+                mk[k] = __ballot(nw[k] != 0.0f);
+                tot += __popcll(mk[k]);
+            }
+            int base = 0;
+            if (lane == 0) base = atomicAdd(list_n, tot);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base + tot <= cap) {
+                int off = base;
+#pragma unroll
+                for (int k = 0; k < R; k++) {
+                    if (nw[k] != 0.0f) {
+                        const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(mk[k] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk[k], 0u));
+                        list[off + (int)below] = make_uint2(((unsigned)(pose.row0 + row_base + k) << 16) | (unsigned)mc, __float_as_uint(nw[k]));
+                    }
+                    off += __popcll(mk[k]);
+                }
+                continue;
+            }
+            // list full: the slots reserved above (if any are inside the list) become holes, the rows are fused in place below
+            for (int j = base + lane; j < min(base + tot, cap); j += 64) list[j] = make_uint2(LIST_SENTINEL, 0u);
+        }
         // ---- phase B: issue the map reads of every active pixel
         float old[R];
         double oldv1[R];
@@ -545,6 +581,136 @@ __device__ inline void fuse_tile_lds(const UpdateArgs& a, const vlfm_vm_pose& po
     }
 }
 
+// ---- Round 5: block-sparse sweep of the window.
+// The tile sweep evaluates source coordinates and four visibility taps for EVERY cell of the cone's destination bounding box --
+// ~40 instructions per cell for ~16 000-25 000 cells of which ~3 000 (the part of the cone the depth profile leaves visible) end
+// up with a confidence: 50 000 wavefront-instructions per observation, 25 us of pure VALU time on a CU that holds one workgroup
+// (tools/vm_phase_probe.py: "fuse tiles" 7 us for ONE pass of one workgroup at 1 environment, no memory system in the way).
+// Here the window is cut into 4 x 4 blocks; a block is kept only if the source footprint of its cells (bounding box of the four
+// corner cells' coordinates -- exact: the fixed-point coordinate is a monotone function of the row plus a monotone function of
+// the column, so its extremes over a rectangle sit in the corners -- widened by the +1 taps) contains a visible bit.  The kept
+// blocks (a few hundred) are listed in LDS and swept four per wavefront, one lane per cell, with the same per-cell arithmetic as
+// the tile sweep; the cells that receive a confidence go to the cell list and are fused by fuse_list().
+constexpr int VB = 4;   // block side
+
+// any visible bit in rows [y0, y1] x columns [x0, x1] of the T x T plane (clipped)?
+__device__ inline bool any_visible(const unsigned* vis, int words, int T, int x0, int x1, int y0, int y1) {
+    x0 = max(x0, 0); y0 = max(y0, 0); x1 = min(x1, T - 1); y1 = min(y1, T - 1);
+    if (x0 > x1 || y0 > y1) return false;
+    const int w0 = x0 >> 5, w1 = x1 >> 5;
+    unsigned acc = 0u;
+    for (int y = y0; y <= y1; y++) {
+        for (int w = w0; w <= w1; w++) {
+            unsigned m = 0xFFFFFFFFu;
+            if (w == w0) m &= 0xFFFFFFFFu << (x0 & 31);
+            if (w == w1) m &= 0xFFFFFFFFu >> (31 - (x1 & 31));
+            acc |= vis[y * words + w] & m;
+        }
+    }
+    return acc != 0u;
+}
+
+// new confidence of ONE destination cell (x, y) of the window: fuse_tile_lds's phase A for a single cell
+__device__ inline float cell_new_confidence(const unsigned* vis, const float* quad, int T, int words, int2 rxy, int2 cxy, bool ok) {
+    const int cq = T >> 1, Q = cq + 1;
+    const int xq = (rxy.x + cxy.x) >> 5, yq = (rxy.y + cxy.y) >> 5;
+    const int sx = xq >> 5, sy = yq >> 5;
+    const bool vx0 = (unsigned)sx < (unsigned)T, vx1 = (unsigned)(sx + 1) < (unsigned)T;
+    const bool vy0 = (unsigned)sy < (unsigned)T, vy1 = (unsigned)(sy + 1) < (unsigned)T;
+    const int r0 = vy0 ? sy * words : 0, r1 = vy1 ? (sy + 1) * words : 0;
+    const int c0 = vx0 ? (sx >> 5) : 0, c1 = vx1 ? ((sx + 1) >> 5) : 0;
+    const unsigned w00 = vis[r0 + c0], w01 = vis[r0 + c1], w10 = vis[r1 + c0], w11 = vis[r1 + c1];
+    const unsigned b0 = (ok && vy0 && vx0) ? ((w00 >> (sx & 31)) & 1u) : 0u;
+    const unsigned b1 = (ok && vy0 && vx1) ? ((w01 >> ((sx + 1) & 31)) & 1u) : 0u;
+    const unsigned b2 = (ok && vy1 && vx0) ? ((w10 >> (sx & 31)) & 1u) : 0u;
+    const unsigned b3 = (ok && vy1 && vx1) ? ((w11 >> ((sx + 1) & 31)) & 1u) : 0u;
+    const unsigned bk = b0 | (b1 << 1) | (b2 << 2) | (b3 << 3);
+    float v = 0.0f;
+    if (__ballot(bk != 0u) != 0ull) {
+        const int qy0 = min(abs(sy - cq), cq) * Q, qy1 = min(abs(sy + 1 - cq), cq) * Q;
+        const int qx0 = min(abs(sx - cq), cq), qx1 = min(abs(sx + 1 - cq), cq);
+        const float q0 = quad[qy0 + qx0], q1 = quad[qy0 + qx1], q2 = quad[qy1 + qx0], q3 = quad[qy1 + qx1];
+        const float t0 = (bk & 1u) ? q0 : 0.0f, t1 = (bk & 2u) ? q1 : 0.0f, t2 = (bk & 4u) ? q2 : 0.0f, t3 = (bk & 8u) ? q3 : 0.0f;
+        // BilinearTab_f weights are products of k/32 in float (exact); accumulate in double like remapBilinear<double>
+        const float fx = (float)(xq & 31) * 0.03125f, fy = (float)(yq & 31) * 0.03125f;
+        const float w0 = (1.f - fy) * (1.f - fx), w1 = (1.f - fy) * fx, w2 = fy * (1.f - fx), w3 = fy * fx;
+        v = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn((double)t0, (double)w0), __dmul_rn((double)t1, (double)w1)),
+                                        __dmul_rn((double)t2, (double)w2)), __dmul_rn((double)t3, (double)w3));
+    }
+    return v;  // curr_map is f32 (value_map.py:316-317); 0 = the cell is not touched
+}
+
+// The collected cells, one per lane: all map reads of a lane's (up to four) cells are in flight together.
+template <int C_STATIC>
+__device__ inline void fuse_list(const UpdateArgs& a, const vlfm_vm_pose& pose, const uint2* list, int n, int tid, int nth,
+                                 unsigned* written) {
+    const int S = a.S;
+    const int C = C_STATIC > 0 ? C_STATIC : a.C;
+    float* conf = a.conf + (size_t)pose.env * S * S;
+    double* value = a.value + (size_t)pose.env * S * S * C;
+    const int ex_stride = (S + 31) >> 5;
+    const unsigned* explored = a.explored ? a.explored + (size_t)pose.env * S * ex_stride : nullptr;
+    const double* vals = a.values + (size_t)pose.reserved * C;
+    constexpr int U = 4;
+    for (int i0 = tid; i0 < n; i0 += nth * U) {
+        unsigned rc[U];
+        float nw[U];
+        bool on[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = i0 + u * nth;
+            const uint2 e = i < n ? list[i] : make_uint2(LIST_SENTINEL, 0u);
+            rc[u] = e.x; nw[u] = __uint_as_float(e.y);
+            on[u] = e.x != LIST_SENTINEL;
+        }
+        if (explored) {   // new_map[explored == 0] = 0 (value_map.py:373); the old values of such cells are cleared by the mask step
+            unsigned ew[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) ew[u] = explored[on[u] ? (size_t)(rc[u] >> 16) * ex_stride + ((rc[u] & 0xFFFFu) >> 5) : 0];
+#pragma unroll
+            for (int u = 0; u < U; u++) on[u] = on[u] && ((ew[u] >> (rc[u] & 31u)) & 1u);
+        }
+        int cell[U];
+        float old[U];
+        double oldv1[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            cell[u] = on[u] ? (int)(rc[u] >> 16) * S + (int)(rc[u] & 0xFFFFu) : 0;
+            old[u] = conf[cell[u]];
+            if (C_STATIC == 1) oldv1[u] = value[cell[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (!on[u]) continue;
+            bool stored = false;
+            if (C_STATIC == 1) {
+                float c_out;
+                double v_out;
+                if (fuse_cell<1>(a, nw[u], old[u], &oldv1[u], vals, c_out, &v_out)) {
+                    conf[cell[u]] = c_out;
+                    value[cell[u]] = v_out;
+                    stored = true;
+                }
+            } else {
+                float c_out = 0.0f;
+                for (int c = 0; c < C; c++) {
+                    const double ov = value[(size_t)cell[u] * C + c];
+                    double nv;
+                    stored = fuse_cell<1>(a, nw[u], old[u], &ov, vals + c, c_out, &nv);
+                    if (!stored) break;
+                    value[(size_t)cell[u] * C + c] = nv;
+                }
+                if (stored) conf[cell[u]] = c_out;
+            }
+            if (stored && written) {
+                unsigned* wp = written + (size_t)(rc[u] >> 16) * ex_stride + ((rc[u] & 0xFFFFu) >> 5);
+                const unsigned bit = 1u << (rc[u] & 31u);
+                if (!(*wp & bit)) atomicOr(wp, bit);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ single-launch update
 // ValueMap.update_map for n observations in ONE launch: grid = (G, n), 1024 threads.  Every workgroup of an observation
 //   1. turns the column-max keys into the depth-profile polygon and rasterises it into LDS (the same arithmetic as
@@ -561,6 +727,8 @@ struct FusedExtra {
     unsigned* written;   // [n_envs][S][ceil(S/32)] or null
     int* counters;       // [n] zero on entry, zero again on exit
     const float* quad;   // [(T/2+1)^2] confidence quadrant (unmasked table, rows/cols >= T/2)
+    int list_cap;        // entries of the LDS cell list behind the other dynamic LDS arrays (0 = fuse every tile in place)
+    int block_cap;       // entries of the LDS list of active 4 x 4 blocks behind the cell list (0 = the tile sweep)
 };
 
 // ---- polygon raster with the work FLATTENED over the workgroup.
@@ -679,6 +847,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void value_map_update_fused_kernel(U
     const int Q = (T >> 1) + 1;
     float* quad = reinterpret_cast<float*>(pref + n_vert + 1 + ((n_vert + 1) & 1));  // [Q * Q]
     int2* row_xy0 = reinterpret_cast<int2*>(quad + Q * Q + ((Q * Q) & 1));          // [T] row part of the source coordinate
+    uint2* cell_list = reinterpret_cast<uint2*>(row_xy0 + T);                       // [fx.list_cap]
+    int2* col_xy = reinterpret_cast<int2*>(cell_list + fx.list_cap);               // [T] column part of the source coordinate
+    unsigned* block_list = reinterpret_cast<unsigned*>(col_xy + T);                // [fx.block_cap] (by << 16) | bx
+    __shared__ int sh_list_n, sh_block_n;
     __shared__ int sh_wave_tot[FUSED_THREADS / 64];
     __shared__ int sh_last;
     __shared__ int sh_box[4];
@@ -708,7 +880,11 @@ __global__ __launch_bounds__(FUSED_THREADS) void value_map_update_fused_kernel(U
     LdsBitmap bm;
     bm.solid = solid; bm.parity = parity; bm.rows = T; bm.cols = T; bm.words = words;
     for (int i = tid; i < 2 * T * words; i += nth) solid[i] = 0u;
-    if (tid == 0) { sh_box[0] = T; sh_box[1] = -1; sh_box[2] = T; sh_box[3] = -1; }
+    if (tid == 0) { sh_box[0] = T; sh_box[1] = -1; sh_box[2] = T; sh_box[3] = -1; sh_list_n = 0; sh_block_n = 0; }
+    if (fx.block_cap > 0)
+        for (int x = tid; x < T; x += nth)   // the column part of cv::warpAffine's fixed-point coordinate (fuse_tile_lds: adelta, bdelta)
+            col_xy[x] = make_int2(__double2int_rn(__dmul_rn(__dmul_rn(pose.inv_affine[0], (double)x), 1024.0)),
+                                  __double2int_rn(__dmul_rn(__dmul_rn(pose.inv_affine[3], (double)x), 1024.0)));
     for (int y = tid; y < T; y += nth)   // cv::warpAffine: X0 = round((M01 y + M02) * 1024) + 16, Y0 likewise (AB_BITS = 10)
         row_xy0[y] = make_int2(
             __double2int_rn(__dmul_rn(__dadd_rn(__dmul_rn(pose.inv_affine[1], (double)y), pose.inv_affine[2]), 1024.0)) + 16,
@@ -864,8 +1040,73 @@ __global__ __launch_bounds__(FUSED_THREADS) void value_map_update_fused_kernel(U
     const int tiles_per_pass = nth >> 8, tg = tid >> 8, t_in = tid & 255;
     const int t_lo = max(box.x, max(0, -pose.row0)) / ROWS_PER_TILE;
     const int t_hi = min(min(box.y, T - 1), S - 1 - pose.row0) / ROWS_PER_TILE;   // inclusive
+    uint2* list = fx.list_cap > 0 ? cell_list : nullptr;
+    if (fx.block_cap > 0 && list) {
+        // ---- 3a: which 4 x 4 blocks of the destination box can hold a cell with a visible tap?
+        const int by_lo = max(box.x, max(0, -pose.row0)) / VB, by_hi = min(min(box.y, T - 1), S - 1 - pose.row0) / VB;
+        const int bx_lo = max(box.z, max(0, -pose.col0)) / VB, bx_hi = min(min(box.w, T - 1), S - 1 - pose.col0) / VB;
+        const int nbx = bx_hi - bx_lo + 1, nby = by_hi - by_lo + 1;
+        const int nblk = nbx > 0 && nby > 0 ? nbx * nby : 0;
+        const int wave = tid >> 6;
+        for (int b0 = g * nth; b0 < nblk; b0 += G * nth) {       // (wavefront-uniform trip count: the ballot below needs every lane)
+            const int b = b0 + tid;
+            bool act = false;
+            int by = 0, bx = 0;
+            if (b < nblk) {
+                by = by_lo + b / nbx; bx = bx_lo + b % nbx;
+                const int y0 = by * VB, y1 = min(y0 + VB - 1, T - 1), x0 = bx * VB, x1 = min(x0 + VB - 1, T - 1);
+                const int2 ra = row_xy0[y0], rb = row_xy0[y1], ca = col_xy[x0], cb = col_xy[x1];
+                // fixed-point coordinate (>> 10 = the cell's first tap) in the four corners
+                const int xa = ra.x + ca.x, xb = ra.x + cb.x, xc = rb.x + ca.x, xd = rb.x + cb.x;
+                const int ya = ra.y + ca.y, yb = ra.y + cb.y, yc = rb.y + ca.y, yd = rb.y + cb.y;
+                const int sx0 = min(min(xa, xb), min(xc, xd)) >> 10, sx1 = (max(max(xa, xb), max(xc, xd)) >> 10) + 1;
+                const int sy0 = min(min(ya, yb), min(yc, yd)) >> 10, sy1 = (max(max(ya, yb), max(yc, yd)) >> 10) + 1;
+                act = any_visible(parity, words, T, sx0, sx1, sy0, sy1);
+            }
+            const unsigned long long m = __ballot(act);
+            if (m == 0ull) continue;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&sh_block_n, __popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (act) {
+                const int k = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                if (k < fx.block_cap) block_list[k] = ((unsigned)by << 16) | (unsigned)bx;
+            }
+        }
+        __syncthreads();
+        // ---- 3b: the cells of the listed blocks, four blocks per wavefront and round, one lane per cell
+        const int nb = min(sh_block_n, fx.block_cap);   // (block_cap covers every block of the window: nothing is ever dropped)
+        for (int i0 = wave * 4; i0 < nb; i0 += (nth >> 6) * 4) {
+            const int bi = i0 + (lane >> 4);
+            const bool have = bi < nb;
+            const unsigned blk = block_list[have ? bi : 0];
+            const int y = (int)(blk >> 16) * VB + ((lane >> 2) & 3), x = (int)(blk & 0xFFFFu) * VB + (lane & 3);
+            const int mr = pose.row0 + y, mc = pose.col0 + x;
+            const bool ok = have && y < T && x < T && (unsigned)mr < (unsigned)S && (unsigned)mc < (unsigned)S;
+            const float nwv = cell_new_confidence(parity, quad, T, words, row_xy0[y < T ? y : 0], col_xy[x < T ? x : 0], ok);
+            const unsigned long long m = __ballot(nwv != 0.0f);
+            if (m == 0ull) continue;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&sh_list_n, __popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (nwv != 0.0f) {
+                const int k = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                const uint2 e = make_uint2(((unsigned)mr << 16) | (unsigned)mc, __float_as_uint(nwv));
+                if (k < fx.list_cap) list[k] = e;
+                else fuse_list<C_STATIC>(a, pose, &e, 1, 0, 1, written);    // list full (a cone far wider than a camera's): in place
+            }
+        }
+        __syncthreads();
+        fuse_list<C_STATIC>(a, pose, list, min(sh_list_n, fx.list_cap), tid, nth, written);
+        VM_PHASE(7);
+        return;
+    }
     for (int t = t_lo + g * tiles_per_pass + tg; t <= t_hi; t += G * tiles_per_pass)
-        fuse_tile_lds<C_STATIC>(a, pose, parity, quad, row_xy0, box, t * ROWS_PER_TILE, t_in, written);
+        fuse_tile_lds<C_STATIC>(a, pose, parity, quad, row_xy0, box, t * ROWS_PER_TILE, t_in, written, list, &sh_list_n, fx.list_cap);
+    if (list) {
+        __syncthreads();
+        fuse_list<C_STATIC>(a, pose, list, min(sh_list_n, fx.list_cap), tid, nth, written);
+    }
     VM_PHASE(7);
 }
 
@@ -1057,6 +1298,11 @@ extern "C" int vlfm_debug_vm_phase_clocks(long long* h_out /* [16] */) {
 }
 #endif
 
+static int target_override_g() {
+    static const int v = [] { const char* e = getenv("VLFM_VM_TARGET_WGS"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 extern "C" int vlfm_value_map_update_fused_batched(uint32_t* d_colmax_keys, int width, const double* d_tan,
                                                    const float* d_template, const uint32_t* d_template_bits,
                                                    int template_size, const vlfm_vm_pose* d_pose,
@@ -1085,13 +1331,36 @@ extern "C" int vlfm_value_map_update_fused_batched(uint32_t* d_colmax_keys, int 
     a.ppm_d = (double)pixels_per_meter;
     a.half_t_d = template_size / 2.0;
     a.use_max_conf = use_max_confidence; a.fusion = fusion_type;
-    FusedExtra fx{d_written_bits, d_counters, d_conf_quadrant};
+    FusedExtra fx{d_written_bits, d_counters, d_conf_quadrant, 0, 0};
     const int T = template_size, words = (T + 31) >> 5;
     const int n_vert = width + 2, Q = T / 2 + 1;
-    const size_t lds = (size_t)(2 * T * words + ((2 * T * words) & 1)) * 4 + (size_t)n_vert * sizeof(int2) +
+    size_t lds = (size_t)(2 * T * words + ((2 * T * words) & 1)) * 4 + (size_t)n_vert * sizeof(int2) +
                        (size_t)(n_vert + 1 + ((n_vert + 1) & 1)) * sizeof(int) + (size_t)(Q * Q + ((Q * Q) & 1)) * 4 +
                        (size_t)T * sizeof(int2);
     if (lds > 150 * 1024) return fail(VLFM_ERR_CAPACITY, "value_map_update_fused_batched: template/width too large for LDS");
+    // the cell list takes what is left, up to 8192 entries (a 79-degree cone at 5 m marks ~3 000 cells; VLFM_VM_LIST=0: fuse in place)
+    static const int list_override = [] { const char* e = getenv("VLFM_VM_LIST"); return e ? atoi(e) : -1; }();
+    {
+        size_t cap = (150 * 1024 - lds) / sizeof(uint2);
+        if (cap > 8192) cap = 8192;
+        if (list_override >= 0 && (size_t)list_override < cap) cap = (size_t)list_override;
+        if (cap < 1024) cap = 0;
+        fx.list_cap = (int)cap;
+        lds += cap * sizeof(uint2);
+        // block-sparse sweep: the column table + one list entry for EVERY 4 x 4 block of the window (VLFM_VM_BLOCKS=0: tile sweep)
+        static const int blocks_off = [] { const char* e = getenv("VLFM_VM_BLOCKS"); return e && atoi(e) == 0; }();
+        const int nb_side = (T + 3) / 4;
+        const size_t extra = (size_t)T * sizeof(int2) + (size_t)nb_side * nb_side * 4;
+        // ... when an observation has at most two workgroups: with more (small batches: G = CUs / n) the tile sweep split over
+        // G workgroups is the shorter chain (measured, tools/vm_phase_probe.py, old / new: 256 obs 56 / 38 us, 128 obs 37 / 35,
+        // 64 obs 27 / 36, 16 HD obs 31 / 40, 8 obs 23 / 29)
+        const int cu = target_override_g() > 0 ? target_override_g() : device_cu_count();
+        const bool few_wgs = (cu + n - 1) / n <= 2;
+        if (!blocks_off && few_wgs && cap > 0 && lds + extra <= 150 * 1024 && T < 65536) {
+            fx.block_cap = nb_side * nb_side;
+            lds += extra;
+        }
+    }
     if (lds > 64 * 1024) {   // beyond the default dynamic-LDS limit: opt in once per device and kernel
         static LdsOptIn opt1, opt0;
         const bool ok = channels == 1 ? opt1.ensure(reinterpret_cast<const void*>(value_map_update_fused_kernel<1>), 150 * 1024)
@@ -1102,8 +1371,7 @@ extern "C" int vlfm_value_map_update_fused_batched(uint32_t* d_colmax_keys, int 
     // workgroups per observation: a 1024-thread workgroup fills a CU (register budget), so aim for one per CU over all
     // observations; more than ceil(tiles / 4) would leave workgroups without a tile
     // (the device's CU count, asked once; VLFM_VM_TARGET_WGS -- read once per process -- is tools/vm_phase_probe.py's sweep knob)
-    static const int target_override = [] { const char* e = getenv("VLFM_VM_TARGET_WGS"); return e ? atoi(e) : 0; }();
-    const int target = target_override > 0 ? target_override : device_cu_count();
+    const int target = target_override_g() > 0 ? target_override_g() : device_cu_count();
     int G = (target + n - 1) / n;
     const int g_max = (tiles + FUSED_THREADS / 256 - 1) / (FUSED_THREADS / 256);
     if (G > g_max) G = g_max;

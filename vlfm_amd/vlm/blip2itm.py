@@ -61,10 +61,11 @@ class Blip2ITCConfig:
                               max_position_embeddings=40, num_query_tokens=5, proj_dim=8)
 
 
-# measured at 256 images (tools/gemm_f16_probe.py, profiles/r05_gemm_probe.txt): fc1 + GELU 1.08 ms here against 1.24 ms for
-# hipBLASLt + a GELU pass; the projection 283 against 290-296 us; qkv 685 against 670 and fc2 1 021 against 956-980 us stay on the
-# library (with its per-shape tuned solutions)
-DEFAULT_HIP_GEMMS = ("fc1", "proj")
+# measured at 256 images (tools/gemm_f16_probe.py, profiles/r05_gemm_probe_*.txt): fc1 + GELU 1.08 ms here against 1.24 ms for
+# hipBLASLt + a GELU pass.  As plain GEMMs the kernel ties the library: projection 283 against 290-296 us alone but 0.7 % SLOWER
+# inside the network (profiles/r05_full_step_ab.txt: 1 682 against 1 694 env-steps/s), qkv 685 against 670 us, fc2 1 021 against
+# 956-980 us -- so only the fused fc1 uses it
+DEFAULT_HIP_GEMMS = ("fc1",)
 
 
 def x_is_contiguous_f16(t: torch.Tensor) -> bool:
