@@ -28,7 +28,7 @@ def _run(ops, x, w, b, epi, variant, out=None):
             os.environ["VLFM_GEMM_VARIANT"] = old
 
 
-@pytest.mark.parametrize("variant", [0, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("shape", SHAPES)
 def test_gemm_f16_epilogues_against_f64(gpu_device, shape, variant):
     from vlfm_amd.vlm import ops
@@ -55,7 +55,7 @@ def test_gemm_f16_epilogues_against_f64(gpu_device, shape, variant):
         assert float((got - want).abs().max()) <= 2e-3 * max(1.0, float(want.abs().max()))
 
 
-@pytest.mark.parametrize("variant", [2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6])
 def test_gemm_f16_8phase_is_deterministic_under_repetition(gpu_device, variant):
     """Race screen: 30 repeats of three multi-wave-of-workgroups problems, bitwise equal to the first run, which is checked against
     an f32 product."""

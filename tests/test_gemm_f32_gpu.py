@@ -45,6 +45,10 @@ def test_f32_gemm_forms_against_f64(gpu_device, shape):
     assert e_split <= max(2 * e_exact, 3e-7), (shape, e_split, e_exact)
     rel = float((split - exact).abs().max() / exact.abs().max())
     assert rel <= 1e-6, (shape, rel)
+    # ... and PER ELEMENT (a bound relative to the largest output says nothing about the small ones): every
+    # output within 2e-6 of ITS OWN dot product's scale sum_k |a_k b_k| + |bias| of the exact-f32 result
+    per_elem = float(((split.double() - exact.double()).abs() / scale).max())
+    assert per_elem <= 2e-6, (shape, per_elem)
     # epilogues: ReLU, exact GELU, residual
     for act, fn in (("relu", torch.relu), ("gelu", torch.nn.functional.gelu)):
         for prec in ("exact", "split"):

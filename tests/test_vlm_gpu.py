@@ -317,6 +317,36 @@ def test_vit_all_four_gemms_on_the_8phase_kernel_full_geometry(gpu_device):
     assert (hip[:4] - plain).abs().mean() <= 1.3 * (lib[:4] - plain).abs().mean() + 1e-4     # not noisier than the library path
 
 
+def test_blip2_cosine_split_f16_qformer_equals_exact_f32_qformer_at_the_real_geometry(gpu_device):
+    """the product's Q-Former runs its f32 Linears as split-f16 GEMMs (hi / lo planes, ~22 mantissa bits) and
+    projects the cross-attention K / V from two weight pieces.  End to end, at the real ViT-g + Q-Former geometry and a batch that
+    takes those paths (64 images: 2 048 query rows), the ITC cosine must equal the one computed with exact-f32 library GEMMs and
+    three K / V pieces within 1e-5 (the reference's blip2itm.py:37-54 compares nothing tighter than its own f16 ViT allows: 5e-3)."""
+    from vlfm_amd.vlm import blip2itm, ops
+    from vlfm_amd.vlm.blip2itm import BLIP2ITM
+
+    m = BLIP2ITM(device=gpu_device, allow_random_init=True)
+    g = torch.Generator().manual_seed(9)
+    imgs = torch.randint(0, 256, (64, 480, 640, 3), generator=g, dtype=torch.uint8).to(gpu_device)
+    prompts = ["Seems like there is a chair ahead."]
+    ops.gemm_f32_overflow_flag(gpu_device, "blip2").zero_()
+    with torch.inference_mode():
+        fast = m.cosine_batch(imgs, prompts).double().cpu()
+        m.check_numerics()
+        saved = (blip2itm.QFORMER_SPLIT_MIN_ROWS, blip2itm.KV_SPLIT_PIECES)
+        blip2itm.QFORMER_SPLIT_MIN_ROWS, blip2itm.KV_SPLIT_PIECES = 1 << 60, 3
+        try:
+            for blk in m.model.modules():          # cached split / pieced weights belong to the other setting
+                for name in ("_kv_pieces", "_kv_cache"):
+                    if hasattr(blk, name):
+                        setattr(blk, name, None)
+            exact = m.cosine_batch(imgs, prompts).double().cpu()
+        finally:
+            blip2itm.QFORMER_SPLIT_MIN_ROWS, blip2itm.KV_SPLIT_PIECES = saved
+    assert torch.isfinite(fast).all() and fast.abs().max() <= 1.0 + 1e-6
+    assert float((fast - exact).abs().max()) <= 1e-5, float((fast - exact).abs().max())
+
+
 def test_qformer_split_kv_projection_is_f32_grade(gpu_device):
     """Cross-attention K/V projection of f16 tokens through the split weights (f16 x f16 -> f32 GEMMs) against the plain f32 GEMM
     path and against f64, with three pieces (exact weights) and with two (the product default: 22-23 of 24 bits): not less

@@ -15,7 +15,7 @@ _lib.build()
 L = _lib.lib()
 dev = torch.device("cuda:0")
 VARIANTS = [int(v) for v in args.variants.split(",")]
-NAMES = {0: "ping-pong", 1: "lock-step", 2: "8-phase", 3: "8-phase-bal", 4: "8p-1bar", 5: "8p-bal-1bar"}
+NAMES = {0: "ping-pong", 1: "lock-step", 2: "8-phase", 3: "8-phase-bal", 4: "8p-1bar", 5: "8p-bal-1bar", 6: "w4"}
 def ours(x, w, b, epi, variant, out=None):
     os.environ["VLFM_GEMM_VARIANT"] = str(variant)
     M, K = x.shape; N = w.shape[0]
@@ -41,7 +41,7 @@ for (M, N, K) in [(300, 264, 128), (512, 512, 64), (256, 256, 192), (1000, 776, 
             bad += not ok
             print(f"M={M} N={N} K={K} epi={epi} {NAMES[v]:11s}: max|err| {err:.3e} (max|ref| {scale:.2f})", "OK" if ok else "WRONG")
 # ---- race screen: the same problem many times, bitwise against the first result (and that against f64)
-for v in [v for v in VARIANTS if v >= 2]:
+for v in [v for v in VARIANTS if v >= 2]:  # (every kernel that keeps loads in flight across barriers)
     for (M, N, K) in [(4096, 4224, 1408), (2048, 1408, 6144), (8192, 6144, 1408)]:
         x = torch.randn(M, K, device=dev).half(); w = (torch.randn(N, K, device=dev) * 0.05).half(); b = torch.randn(N, device=dev).half()
         first = ours(x, w, b, 0, v).clone()
@@ -83,10 +83,10 @@ for name, N, K, epi in [("fc1+gelu", 6144, 1408, 1), ("qkv", 4224, 1408, 0), ("p
         line += f"{k} {med*1e6:7.1f} us ({fl/med/1e15:.3f} PF, min {ts[0]*1e6:.1f}) | "
     print(line)
     # tile order: m-tiles per group (VLFM_GEMM_GROUP_M), 8-phase kernel
-    line = f"{name:9s} group_m sweep (8-phase): "
+    line = f"{name:9s} group_m sweep ({NAMES[VARIANTS[-1]]}): "
     for gm in (1, 2, 4, 8, 16, 32):
         os.environ["VLFM_GEMM_GROUP_M"] = str(gm)
-        fn = arms[NAMES[2]] if NAMES[2] in arms else None
+        fn = arms.get(NAMES[VARIANTS[-1]])
         if fn is None: break
         for _ in range(2): fn()
         ts = sorted(t_once(fn, 5) for _ in range(3))

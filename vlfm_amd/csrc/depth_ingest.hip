@@ -520,6 +520,8 @@ extern "C" int vlfm_depth_ingest_batched(const float* d_depth, int n, int height
     // row bands: aim for ~2048 workgroups (8 per CU) so that enough 16-byte loads are in flight to cover HBM latency,
     // but never fewer than RL rows per band
     int bands = (int)((2048 + (long)n * gx - 1) / ((long)n * gx));
+    static const int bands_override = [] { const char* e = getenv("VLFM_INGEST_BANDS"); return e ? atoi(e) : 0; }();
+    if (bands_override > 0) bands = bands_override;
     const int max_bands = (height + RL - 1) / RL;
     if (bands > max_bands) bands = max_bands;
     if (bands < 1) bands = 1;

@@ -35,6 +35,7 @@ namespace vlfm {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 // s_waitcnt through the builtin (the compiler's own scoreboard sees it; beside inline-asm waits it re-waits for everything at
 // the loop head): simm16 = vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]; 0xC07F = lgkmcnt(0), 0x0F70 =
 // vmcnt(0), 0x0F78 = vmcnt(8)
@@ -621,6 +622,254 @@ __global__ __launch_bounds__(512) void gemm_f16_8p_kernel(GemmArgs a) {
     g.run(m0, n0);
 }
 
+
+// Epilogue of the 4-wavefront kernel: wavefront (wr, wc) holds 128 n x 128 m as 4 x 4 accumulator tiles of 32 x 32 (lane: column
+// m = lane & 31 of a tile, rows n = 8 g + 4 (lane >> 5) + {0..3}, g = 0..3).  Same scheme as store_tile: bias (+ GELU) in f32, f16,
+// transposed through a wavefront-private LDS region of 128 rows x 272 B, every global load issued up front, 16-byte stores.
+constexpr int EPI_WAVE4 = 128 * EPI_ROW;
+template <int EPI>
+__device__ inline void store_tile_w4(const GemmArgs& a, unsigned char* smem, const f32x16 (&acc)[4][4], int wave, int lane, int m0,
+                                     int n0) {
+    const int wr = wave >> 1, wc = wave & 1;
+    unsigned char* stg = smem + wave * EPI_WAVE4;
+    const int c32 = lane & 31, h4 = (lane >> 5) * 4;
+    const int rsub = lane >> 4, chunk = lane & 15;
+    const int nb = n0 + wr * 128, mb = m0 + wc * 128;
+    half4 bias4[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            bias4[i][g] = half4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+            if (a.bias) bias4[i][g] = *reinterpret_cast<const half4*>(a.bias + min(nb + i * 32 + g * 8 + h4, a.N - 4));
+        }
+    uint4 old[EPI == EPI_ACCUM ? 32 : 1];
+    if (EPI == EPI_ACCUM) {
+#pragma unroll
+        for (int it = 0; it < 32; it++) {
+            const int m = min(mb + it * 4 + rsub, a.M - 1), n = max(min(nb + chunk * 8, a.N - 8), 0);
+            old[it] = *reinterpret_cast<const uint4*>(a.c + (size_t)m * a.N + n);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const half4 bv = bias4[i][g];
+                float v0 = acc[i][j][4 * g + 0] + (float)bv[0], v1 = acc[i][j][4 * g + 1] + (float)bv[1];
+                float v2 = acc[i][j][4 * g + 2] + (float)bv[2], v3 = acc[i][j][4 * g + 3] + (float)bv[3];
+                if (EPI == EPI_BIAS_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+                const half4 h = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
+                *reinterpret_cast<half4*>(stg + (j * 32 + c32) * EPI_ROW + (i * 32 + g * 8 + h4) * 2) = h;
+            }
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // wavefront-private region: no workgroup barrier needed
+    uint4 v[32];
+#pragma unroll
+    for (int it = 0; it < 32; it++) v[it] = *reinterpret_cast<const uint4*>(stg + (it * 4 + rsub) * EPI_ROW + chunk * 16);
+    if (EPI == EPI_ACCUM) {
+#pragma unroll
+        for (int it = 0; it < 32; it++) {
+            half8 h = *reinterpret_cast<const half8*>(&v[it]);
+            const half8 o = *reinterpret_cast<const half8*>(&old[it]);
+#pragma unroll
+            for (int e = 0; e < 8; e++) h[e] = (_Float16)((float)h[e] + (float)o[e]);
+            v[it] = *reinterpret_cast<const uint4*>(&h);
+        }
+    }
+    const int n = nb + chunk * 8;
+    if (n + 8 <= a.N) {
+#pragma unroll
+        for (int it = 0; it < 32; it++) {
+            const int m = mb + it * 4 + rsub;
+            if (m < a.M) *reinterpret_cast<uint4*>(a.c + (size_t)m * a.N + n) = v[it];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ four wavefronts, one per SIMD
+// Round 5, after the counters (profiles/r05_gemm_pmc.txt): the library's kernel for these shapes runs HALF as many wavefronts as the
+// 8-wavefront kernels above for the same MFMA work -- one wavefront per SIMD with a 128 x 128 accumulator block (256 registers;
+// 512-register budget), no partner to trade the matrix pipe with and therefore no barriers inside a K-tile -- and its matrix pipe is
+// busy 66 % of the time against 50-59 % here, where every one of the 8 barrier-separated intervals of a K-tile costs ~150 cycles of
+// hand-over on top of its 16 MFMAs (tools/gemm_stamp_probe.py).  This is that structure in plain HIP:
+//   * 256 threads, wavefront (wr, wc) of a 2 x 2 grid owns W rows [wr * 128, +128) x X rows [wc * 128, +128): 4 x 4 fragments of
+//     v_mfma_f32_32x32x16_f16, 16 MFMAs (512 cycles of matrix pipe) per 16-wide k-step, four k-steps per K-tile;
+//   * the fragments of k-step s + 1 (8 ds_read_b128) are requested while the MFMAs of step s run, into the other fragment
+//     register set; the LDS-DMA loads of K-tile t + 2 are issued in the first steps after the tile's one barrier;
+//   * ONE barrier per K-tile, in front of k-step 3: behind it every wavefront has finished reading K-tile t (its buffer is free
+//     for tile t + 2) and -- each wavefront having waited for its own loads first -- K-tile t + 1 is complete.
+// Measured (profiles/r05_gemm_probe_w4.txt, 256 images, us; library / 8-phase / this): fc1 + GELU 1 260 / 1 100 / 1 202, qkv 683 / 702 /
+// 768, projection 294 / 286 / 315, fc2 976 / 1 050 / 1 202 -- correct on the first run (80 tests, race screen clean), and 10-15 %
+// SLOWER than the 8-wavefront kernel: without a partner wavefront the issue of an LDS-DMA load (~60 cycles each, 16 per K-tile),
+// the lgkmcnt wait in front of every k-step and the barrier + vmcnt(0) of every K-tile all stand in the one instruction stream that
+// also feeds the matrix pipe; hipcc weaves the fragment reads between the MFMAs as asked (sched_group_barrier) but serialises the
+// loads on M0.  The library's kernel is this structure with a hand-scheduled instruction stream.  Kept as VLFM_GEMM_VARIANT=6 for A/B.
+
+template <int EPI, int G0, int G1, int G2, int G3>
+struct GemmW4 {
+    static constexpr int KBUF = 2 * OPER;          // one K-tile: W tile (32 KB) + X tile (32 KB)
+    const GemmArgs& a;
+    lds_ptr lds;
+    const unsigned char* smem;
+    int wave, lane;
+    uint32_t voffP[8], voffQ[8];    // this lane's 16 bytes of each of the wavefront's 8 + 8 row chunks (8 rows x 128 B) of a K-tile
+    uint32_t rdP[4], rdQ[4];        // fragment read offsets by k-step (the swizzle turns the k-step into an XOR of 32 B)
+    half8 fa[2][4], fb[2][4];
+    f32x16 acc[4][4];
+
+    __device__ GemmW4(const GemmArgs& a_, unsigned char* smem_, int m0, int n0) : a(a_), lds((lds_ptr)smem_), smem(smem_) {
+        const int tid = threadIdx.x;
+        lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int sub = lane >> 3, p = lane & 7;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int r = (wave * 8 + j) * 8 + sub;               // row of the tile
+            const int sl = p ^ ((r >> 1) & 7);
+            voffP[j] = (uint32_t)min(n0 + r, a.N - 1) * (uint32_t)a.K * 2u + (uint32_t)sl * 16u;
+            voffQ[j] = (uint32_t)min(m0 + r, a.M - 1) * (uint32_t)a.K * 2u + (uint32_t)sl * 16u;
+        }
+        const int wr = wave >> 1, wc = wave & 1;
+        const int r32 = lane & 31, swz = (r32 >> 1) & 7, hi = lane >> 5;
+        const uint32_t bp = (uint32_t)(wr * 128 + r32) * ROWB + (uint32_t)((hi ^ swz) << 4);
+        const uint32_t bq = (uint32_t)OPER + (uint32_t)(wc * 128 + r32) * ROWB + (uint32_t)((hi ^ swz) << 4);
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) { rdP[ks] = bp ^ (uint32_t)(ks << 5); rdQ[ks] = bq ^ (uint32_t)(ks << 5); }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+    }
+    // chunks [c0, c0 + n) of this wavefront's 16 (0-7: W rows, 8-15: X rows) of K-tile t -> buffer b
+    template <int C0, int N>
+    __device__ inline void stage(int b, int t) {
+        const unsigned char* bw = reinterpret_cast<const unsigned char*>(a.w) + (size_t)t * (GK * 2);
+        const unsigned char* bx = reinterpret_cast<const unsigned char*>(a.x) + (size_t)t * (GK * 2);
+#pragma unroll
+        for (int c = C0; c < C0 + N; c++) {
+            const int j = c & 7;
+            const int dst = __builtin_amdgcn_readfirstlane(b * KBUF + (c < 8 ? 0 : OPER) + (wave * 8 + j) * 1024);
+            if (c < 8) __builtin_amdgcn_global_load_lds((gbl_ptr)(bw + voffP[j]), lds + dst, 16, 0, 0);
+            else __builtin_amdgcn_global_load_lds((gbl_ptr)(bx + voffQ[j]), lds + dst, 16, 0, 0);
+        }
+    }
+    template <int B, int KS, int F>
+    __device__ inline void read_frags() {
+#pragma unroll
+        for (int i = 0; i < 4; i++) fa[F][i] = *reinterpret_cast<const half8*>(smem + B * KBUF + i * 32 * ROWB + rdP[KS]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) fb[F][j] = *reinterpret_cast<const half8*>(smem + B * KBUF + j * 32 * ROWB + rdQ[KS]);
+    }
+    template <int F>
+    __device__ inline void mma() {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[F][i], fb[F][j], acc[i][j], 0, 0, 0);
+    }
+    static __device__ inline void bar() {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    // k-step KS of K-tile t (buffer B); its fragments are in register set F = KS & 1.  FULL: K-tiles t + 1 and t + 2 exist (the
+    // steady state: no branches, so that the scheduler may weave the fragment reads and the LDS-DMA loads between the MFMAs).
+    template <int B, int KS, int NG, int C0, bool FULL>
+    __device__ inline void step(int t, int NT) {
+        constexpr int F = KS & 1;
+        if constexpr (KS == 3) {
+            if (FULL || t + 1 < NT) {
+                // vmcnt(0): this wavefront's loads of K-tile t + 1 (nothing newer is in flight); lgkmcnt(0): its fragment reads of
+                // K-tile t (requested one k-step ago) have left the buffer that tile t + 2 is about to be written into
+                __builtin_amdgcn_s_waitcnt(0x0070);
+                bar();
+                read_frags<B ^ 1, 0, F ^ 1>();
+            }
+        } else {
+            read_frags<B, KS + 1, F ^ 1>();
+        }
+        // K-tile t + 2 goes into the buffer of K-tile t, free behind the barrier of k-step 3: its first G0 chunks in that step, the
+        // rest in k-steps 0..2 of K-tile t + 1 (whose "other" buffer that is)
+        if constexpr (NG > 0) {
+            const int tt = KS == 3 ? t + 2 : t + 1;
+            if (FULL || tt < NT) stage<C0, NG>(KS == 3 ? B : B ^ 1, tt);
+        }
+        mma<F>();
+        if constexpr (FULL) {
+            // weave: one fragment read behind each of the first eight MFMAs, one LDS-DMA load (two 64-bit adds, the M0 write, the
+            // load) behind each of the next NG; each MFMA occupies the pipe for 32 cycles and the wavefront's issue slot for 4
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < (NG < 8 ? NG : 8); k++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x004, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 8 - (NG < 8 ? NG : 8), 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    template <int B, bool FULL>
+    __device__ inline void tile(int t, int NT) {
+        step<B, 0, G1, G0, FULL>(t, NT);
+        step<B, 1, G2, G0 + G1, FULL>(t, NT);
+        step<B, 2, G3, G0 + G1 + G2, FULL>(t, NT);
+        step<B, 3, G0, 0, FULL>(t, NT);
+    }
+    __device__ inline void run(int m0, int n0) {
+        const int NT = a.K / GK;
+        GEMM_STAMP(0);
+        stage<0, 16>(0, 0);
+        if (NT > 1) {
+            stage<0, G0>(1, 1);                          // (the rest of K-tile 1 follows in k-steps 0..2 of K-tile 0)
+            if (G0 == 4) __builtin_amdgcn_s_waitcnt(0x0F74);
+            else if (G0 == 6) __builtin_amdgcn_s_waitcnt(0x0F76);
+            else __builtin_amdgcn_s_waitcnt(0x0F78);     // vmcnt(G0): K-tile 0 has landed
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
+        bar();
+        GEMM_STAMP(1);
+        read_frags<0, 0, 0>();
+        __builtin_amdgcn_sched_barrier(0);
+        int t = 0;
+        for (; t + 3 < NT; t += 2) {       // K-tiles t + 1 and t + 2 exist for both tiles of the iteration
+            tile<0, true>(t, NT);
+            tile<1, true>(t + 1, NT);
+        }
+        for (; t < NT; t += 2) {
+            tile<0, false>(t, NT);
+            if (t + 1 < NT) tile<1, false>(t + 1, NT);
+        }
+        bar();
+        GEMM_STAMP(2);
+        store_tile_w4<EPI>(a, const_cast<unsigned char*>(smem), acc, wave, lane, m0, n0);
+#ifdef VLFM_PHASE_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        GEMM_STAMP(3);
+    }
+};
+
+template <int EPI, int G0, int G1, int G2, int G3>
+__global__ __launch_bounds__(256, 1) void gemm_f16_w4_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int tm, tn;
+    tile_of_block(a, tm, tn);
+    const int m0 = tm * GB, n0 = tn * GB;
+    GemmW4<EPI, G0, G1, G2, G3> g(a, smem, m0, n0);
+    g.run(m0, n0);
+}
+
 }  // namespace vlfm
 
 using namespace vlfm;
@@ -631,6 +880,16 @@ using namespace vlfm;
 // lock-step kernels (A/B runs of tools/gemm_f16_probe.py; they do not implement epilogue 2), 2 / 3 the 8-phase kernel's two read schedules.
 template <int EPI>
 static int launch_gemm(const GemmArgs& a, int variant, hipStream_t stream) {
+    if (variant >= 6) {     // four wavefronts, one per SIMD (LDS-DMA loads of the next-but-one K-tile in the two k-steps behind the barrier)
+        const void* fn = reinterpret_cast<const void*>(gemm_f16_w4_kernel<EPI, 8, 8, 0, 0>);
+        constexpr int LDS4 = 4 * EPI_WAVE4 > 2 * BUF ? 4 * EPI_WAVE4 : 2 * BUF;
+        static LdsOptIn opt4;
+        if (!opt4.ensure(fn, LDS4)) return fail(VLFM_ERR_HIP, "gemm_f16_nt: cannot opt in to the LDS size");
+        const dim3 grid(a.tiles_m * a.tiles_n), block(256);
+        VLFM_TIMED(EPI == EPI_BIAS ? "gemm_f16_w4_kernel<0>" : EPI == EPI_BIAS_GELU ? "gemm_f16_w4_kernel<1>" : "gemm_f16_w4_kernel<2>", stream);
+        VLFM_KLAUNCH((gemm_f16_w4_kernel<EPI, 8, 8, 0, 0>), grid, block, LDS4, stream, a);
+        return check_launch("gemm_f16_w4_kernel");
+    }
     const void* fn = variant == 0 ? reinterpret_cast<const void*>(gemm_f16_nt_kernel<EPI>)
                    : variant == 1 ? reinterpret_cast<const void*>(gemm_f16_nt_lockstep_kernel<EPI>)
                    : variant == 2 ? reinterpret_cast<const void*>(gemm_f16_8p_kernel<EPI, 0, 2>)
@@ -670,7 +929,7 @@ extern "C" int vlfm_gemm_f16_nt(const void* d_x, const void* d_w, const void* d_
     if (a.group_m < 1) a.group_m = 1;
     const char* ev = getenv("VLFM_GEMM_VARIANT");
     int variant = ev ? atoi(ev) : GEMM_DEFAULT_VARIANT;
-    if (variant < 0 || variant > 5) variant = GEMM_DEFAULT_VARIANT;
+    if (variant < 0 || variant > 6) variant = GEMM_DEFAULT_VARIANT;
     if (epilogue == 2 && variant < 2) return fail(VLFM_ERR_INVALID, "gemm_f16_nt: epilogue 2 needs an 8-phase kernel");
     if (epilogue == 0) return launch_gemm<EPI_BIAS>(a, variant, (hipStream_t)stream);
     if (epilogue == 1) return launch_gemm<EPI_BIAS_GELU>(a, variant, (hipStream_t)stream);

@@ -43,9 +43,14 @@ class _State:
         self.fused_sampling = True      # deformable attention: softmax + sampling locations inside the sampling kernel
 
 
+MIN_ROWS_OWN_GEMM = 1024
+
+
 def _linear(st: _State, x: torch.Tensor, lin_w: torch.Tensor, lin_b, act=None, residual=None, out=None) -> torch.Tensor:
     """act(x W^T + b) + residual on the matrix cores when the shape allows and the model runs in a fused precision; else torch."""
-    if st.precision != "library" and ops.linear_f32_supported(x, lin_w):
+    # (the caption's ~15 tokens per frame: a 128 x 128-tile kernel walks K alone on one or two CUs -- 25-60 us per Linear at 8 frames
+    # against ~10 us for the library's 16 x 16 tiles; tools/gdino_gemm_shapes_probe.py)
+    if st.precision != "library" and ops.linear_f32_supported(x, lin_w) and x.numel() // x.shape[-1] >= MIN_ROWS_OWN_GEMM:
         return ops.linear_f32(x, lin_w, lin_b, act=act, residual=residual, precision=st.precision, out=out, owner="gdino")
     y = F.linear(x, lin_w, lin_b)
     if act == "relu":
@@ -275,12 +280,15 @@ def patch_fusion(model: nn.Module, st: _State) -> int:
             A = torch.einsum("hdc,bthd->bhtc", Wq, k).reshape(B, Hh * Lt, Cv)                      # [B, 4 Lt, 256]
             s0 = torch.einsum("hd,bthd->bht", bq, k).reshape(B, 1, Hh * Lt)
             S = torch.bmm(v, A.transpose(1, 2)).add_(s0).view(B, Lv, Hh, Lt)                        # scores[v, h, t]
-            # text <- vision: softmax over the vision tokens (per head and text token)
-            St = S
+            # text <- vision: softmax over the vision tokens (per head and text token).  Evaluated on the TRANSPOSED scores
+            # [B, 4 Lt, Lv] (a second 60-row GEMM; s0 is constant along the vision tokens and cancels): the softmax then runs along
+            # the contiguous dimension -- along dim 1 of S it was torch's strided "spatial" softmax kernel, 409 us per layer at 8
+            # frames, 9 % of the forward's GPU time -- and its result is already the left operand of the next product
+            St = torch.bmm(A, v.transpose(1, 2))                                                    # [B, 4 Lt, Lv]
             if attention_mask_vision is not None and not st.no_padding:
-                St = S.masked_fill(attention_mask_vision[:, :, None, None], float("-inf"))
-            Pt = torch.softmax(St, dim=1).view(B, Lv, Hh * Lt)
-            Y = torch.bmm(Pt.transpose(1, 2), v).view(B, Hh, Lt, Cv)                               # sum_v p' x_v
+                St = St.masked_fill(attention_mask_vision[:, None, :], float("-inf"))
+            Pt = torch.softmax(St, dim=-1)                                                          # [B, 4 Lt, Lv]
+            Y = torch.bmm(Pt, v).view(B, Hh, Lt, Cv)                                                # sum_v p' x_v
             Wv = a.values_vision_proj.weight.view(Hh, hd, Cv)
             ot = (torch.einsum("hdc,bhtc->bthd", Wv, Y) + a.values_vision_proj.bias.view(1, 1, Hh, hd)).reshape(B, Lt, E)
             t_out = t + _m.text_param * F.linear(ot, a.out_text_proj.weight, a.out_text_proj.bias)
@@ -292,7 +300,7 @@ def patch_fusion(model: nn.Module, st: _State) -> int:
             Wo = (a.out_vision_proj.weight * _m.vision_param[:, None]).view(Cv, Hh, hd)            # layer scale folded in
             Cm = torch.einsum("chd,bthd->bhtc", Wo, u) + (a.out_vision_proj.bias * _m.vision_param / Hh).view(1, 1, 1, Cv)
             v_out = torch.baddbmm(v, P.view(B, Lv, Hh * Lt), Cm.reshape(B, Hh * Lt, Cv))          # every head's p sums to 1: bias / heads each
-            return (v_out, P.permute(0, 2, 1, 3).reshape(B * Hh, Lv, Lt)), (t_out, Pt.view(B, Lv, Hh, Lt).permute(0, 2, 3, 1).reshape(B * Hh, Lt, Lv))
+            return (v_out, P.permute(0, 2, 1, 3).reshape(B * Hh, Lv, Lt)), (t_out, Pt.view(B * Hh, Lt, Lv))
 
         mod.forward = forward
         n += 1
