@@ -200,18 +200,23 @@ __global__ __launch_bounds__(512) void conv_nhwc_kernel(ConvArgs a) {
     __builtin_amdgcn_s_barrier();   // every wavefront is done with the operand buffers: the epilogue staging aliases them
     asm volatile("" ::: "memory");
 
-    // ---- epilogue: bias (+ SiLU) on the f32 accumulators, f16, transpose through a wavefront-private LDS region, 16-byte stores
+    // ---- epilogue: bias (+ SiLU) on the f32 accumulators, f16, transpose through a wavefront-private LDS region, 16-byte stores.
+    // Round 5 (as in gemm_f16.hip's store_tile): the FA bias quads are loaded before the arithmetic instead of one dependent L2 round
+    // trip per fragment row, and all LDS reads of the second half precede the first store -- with one register quad re-used for every
+    // ds_read_b128 / global_store pair hipcc waits vmcnt(0), i.e. for the previous STORE to leave, before every read.  A 1x1 layer with
+    // 256 input channels is four K-tiles: the epilogue is a large share of such a tile.
     unsigned char* stg = smem + wave * (WM * EPI_ROW);
     const int g4 = (lane >> 4) * 4, c16 = lane & 15;
+    half4 bias4[FA];
+#pragma unroll
+    for (int i = 0; i < FA; i++) {
+        bias4[i] = half4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        if (a.bias) bias4[i] = *reinterpret_cast<const half4*>(a.bias + min(n0 + wn * WN + i * 16 + g4, a.Cout - 4));
+    }
 #pragma unroll
     for (int i = 0; i < FA; i++) {
         const int nl = i * 16 + g4;                    // 4 consecutive output channels of this lane, wavefront-local
-        float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-        if (a.bias) {
-            const int n = min(n0 + wn * WN + nl, a.Cout - 4);
-            const half4 bv = *reinterpret_cast<const half4*>(a.bias + n);
-            b0 = (float)bv[0]; b1 = (float)bv[1]; b2 = (float)bv[2]; b3 = (float)bv[3];
-        }
+        const float b0 = (float)bias4[i][0], b1 = (float)bias4[i][1], b2 = (float)bias4[i][2], b3 = (float)bias4[i][3];
 #pragma unroll
         for (int j = 0; j < FB; j++) {
             float v0 = acc[i][j][0] + b0, v1 = acc[i][j][1] + b1, v2 = acc[i][j][2] + b2, v3 = acc[i][j][3] + b3;
@@ -221,14 +226,18 @@ __global__ __launch_bounds__(512) void conv_nhwc_kernel(ConvArgs a) {
         }
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);   // wavefront-private region: no workgroup barrier needed
-    constexpr int CHUNKS = WN / 8, ROWS_PER_IT = 64 / CHUNKS;
+    constexpr int CHUNKS = WN / 8, ROWS_PER_IT = 64 / CHUNKS, ITS = WM / ROWS_PER_IT;
     const int rsub = lane / CHUNKS, chunk = lane % CHUNKS;
+    uint4 v[ITS];
 #pragma unroll
-    for (int it = 0; it < WM / ROWS_PER_IT; it++) {
-        const int row = it * ROWS_PER_IT + rsub;
-        const uint4 v = *reinterpret_cast<const uint4*>(stg + row * EPI_ROW + chunk * 16);
-        const int m = m0 + wm * WM + row, n = n0 + wn * WN + chunk * 8;
-        if (m < a.M && n + 8 <= a.Cout) *reinterpret_cast<uint4*>(a.out + (size_t)m * a.out_pix + n) = v;
+    for (int it = 0; it < ITS; it++) v[it] = *reinterpret_cast<const uint4*>(stg + (it * ROWS_PER_IT + rsub) * EPI_ROW + chunk * 16);
+    const int n = n0 + wn * WN + chunk * 8;
+    if (n + 8 <= a.Cout) {
+#pragma unroll
+        for (int it = 0; it < ITS; it++) {
+            const int m = m0 + wm * WM + it * ROWS_PER_IT + rsub;
+            if (m < a.M) *reinterpret_cast<uint4*>(a.out + (size_t)m * a.out_pix + n) = v[it];
+        }
     }
 }
 

@@ -116,18 +116,26 @@ __device__ inline void store_tile(const Args& a, unsigned char* smem, const floa
                                   int act, int wave, int wn, int wm, int lane, int m0, int n0) {
     unsigned char* stg = smem + wave * EPI_WAVE;
     const int c32 = lane & 31, h4 = (lane >> 5) * 4;
+    floatx4 bias4[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            floatx4 b = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias) {
+                const int n = n0 + wn * 64 + i * 32 + g * 8 + h4;
+                if (n + 4 <= a.N && ((uintptr_t)a.bias & 15) == 0) b = *reinterpret_cast<const floatx4*>(a.bias + n);
+                else
+                    for (int e = 0; e < 4; e++) b[e] = n + e < a.N ? a.bias[n + e] : 0.f;
+            }
+            bias4[i][g] = b;
+        }
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             const int nl = i * 32 + g * 8 + h4;                       // 4 consecutive n, wavefront-local
-            floatx4 b = {0.f, 0.f, 0.f, 0.f};
-            if (a.bias) {
-                const int n = n0 + wn * 64 + nl;
-                if (n + 4 <= a.N && ((uintptr_t)a.bias & 15) == 0) b = *reinterpret_cast<const floatx4*>(a.bias + n);
-                else
-                    for (int e = 0; e < 4; e++) b[e] = n + e < a.N ? a.bias[n + e] : 0.f;
-            }
+            const floatx4 b = bias4[i][g];
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 floatx4 v;
@@ -146,21 +154,29 @@ __device__ inline void store_tile(const Args& a, unsigned char* smem, const floa
     __builtin_amdgcn_s_waitcnt(0xC07F);   // wavefront-private area
     const int rsub = lane >> 4, chunk = lane & 15;
     const bool vec = (a.N & 3) == 0;      // rows of C / residual are 16-byte aligned
-#pragma unroll 4
+    // Round 5 (as in gemm_f16.hip): all 16 residual loads first, then all 16 LDS reads, then the stores -- the loop that loaded,
+    // read, added and stored one row at a time (unrolled by four, one register quad per slot) waited for a residual load AND for
+    // the previous store before every LDS read.
+    const int n = n0 + wn * 64 + chunk * 4;
+    const bool fast = vec && n + 4 <= a.N;
+    floatx4 r[16], v[16];
+#pragma unroll
     for (int it = 0; it < 16; it++) {
-        const int row = it * 4 + rsub;
-        floatx4 v = *reinterpret_cast<const floatx4*>(stg + row * EPI_ROW + chunk * 16);
-        const int m = m0 + wm * 64 + row, n = n0 + wn * 64 + chunk * 4;
+        const int m = m0 + wm * 64 + it * 4 + rsub;
+        r[it] = floatx4{0.f, 0.f, 0.f, 0.f};
+        if (a.residual && fast && m < a.M) r[it] = *reinterpret_cast<const floatx4*>(a.residual + (size_t)m * a.N + n);
+    }
+#pragma unroll
+    for (int it = 0; it < 16; it++) v[it] = *reinterpret_cast<const floatx4*>(stg + (it * 4 + rsub) * EPI_ROW + chunk * 16);
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+        const int m = m0 + wm * 64 + it * 4 + rsub;
         if (m >= a.M || n >= a.N) continue;
         const size_t at = (size_t)m * a.N + n;
-        if (vec && n + 4 <= a.N) {
-            if (a.residual) {
-                const floatx4 r = *reinterpret_cast<const floatx4*>(a.residual + at);
-                v += r;
-            }
-            *reinterpret_cast<floatx4*>(a.c + at) = v;
+        if (fast) {
+            *reinterpret_cast<floatx4*>(a.c + at) = v[it] + r[it];
         } else {
-            for (int e = 0; e < 4 && n + e < a.N; e++) a.c[at + e] = v[e] + (a.residual ? a.residual[at + e] : 0.f);
+            for (int e = 0; e < 4 && n + e < a.N; e++) a.c[at + e] = v[it][e] + (a.residual ? a.residual[at + e] : 0.f);
         }
     }
 }
