@@ -259,3 +259,45 @@ def test_other_map_sizes_and_camera_models(gpu_device, size, hfov_deg, max_depth
         a, av = ours_v.sort_waypoints(ref_o.frontiers, 0.5)
         b, bv = ref_v.sort_waypoints(ref_o.frontiers, 0.5)
         assert np.array_equal(a, b) and np.array_equal(np.asarray(av, float), np.asarray(bv, float))
+
+
+def test_wide_cone_overflows_the_cell_list_and_is_fused_in_place(gpu_device):
+    """Round 5: the update collects the cells that receive a confidence in an LDS list of at most 8 192 entries and fuses the list
+    one cell per lane.  A 79-degree cone at 5 m marks ~3 000-6 900 cells; a 120-degree cone with nothing in the way marks ~10 500: the
+    list overflows and the rest must be fused in place -- same maps as the oracle, every yaw."""
+    from oracle.ref_value_map import RefValueMap
+    from vlfm_amd.mapping import ValueMap
+
+    H, W = 240, 320
+    fov = camera_intrinsics(W, 120.0)[2]
+    ours = ValueMap(1, use_max_confidence=False, device=gpu_device)
+    ref = RefValueMap(1, use_max_confidence=False)
+    rng = np.random.default_rng(8)
+    for t in range(7):
+        depth = np.ones((H, W), np.float32) if t % 3 else rng.uniform(0.6, 1.0, (H, W)).astype(np.float32)
+        tf = pose_to_tf(0.4 * t, 0.3 * t, 0.9 * t - 2.0)
+        vals = rng.uniform(0.15, 0.45, 1)
+        ours.update_map(vals, depth, tf, MIN_DEPTH, MAX_DEPTH, fov)
+        ref.update_map(vals, depth.copy(), tf, MIN_DEPTH, MAX_DEPTH, fov)
+    assert int((ref._map != 0).sum()) > 9000          # (the union of the cones: far more than the list holds per observation)
+    _compare(ours, ref)
+
+
+def test_block_sparse_sweep_at_every_batch_size(gpu_device):
+    """Round 5: with at most two workgroups per observation (>= 128 observations on a 256-CU device) the update sweeps only the
+    4 x 4 blocks of the window whose source footprint holds a visible bit (csrc/value_map.hip, step 3a / 3b); smaller batches keep
+    the tile sweep.  VLFM_VM_TARGET_WGS=1 (read once per process) makes a one-observation launch take the block-sparse path: the
+    oracle comparisons of this file and the reference fixtures are repeated under it in a child process."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VLFM_VM_TARGET_WGS="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(root, "tests", "test_value_map_gpu.py"), os.path.join(root, "tests", "test_golden_gpu.py"),
+                        "-k", "not block_sparse_sweep and not three_launch and not obstacle_map_matches and not multicamera_obstacle "
+                              "and not depth_islands"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout, r.stdout[-500:]
