@@ -927,8 +927,12 @@ def side_legs(args, sim, device, common):
                              "wrong class / low confidence, dropped by the filters), 30 steps with the target in view (0.8 of them "
                              "carry a confidence-0.9 detection), then arrival = episode end, the next episode starts in place; "
                              f"expected {sight.mean_detections_per_env_step():.3f} surviving detections per env-step; environments are "
-                             "spread over all phases; the network's forward runs on every frame and is timed, its random logits are "
-                             "not used",
+                             "spread over all phases; the network's forward runs on every frame and is timed; " + (
+                                 "GroundingDINO: its random logits are not used (all 900 queries of an untrained network pass the "
+                                 "box threshold, so the timed post-processing sees MORE than a trained one's)"
+                                 if tag else
+                                 "YOLOv7: the head's candidates (24 jittered boxes per sighting) are written into the raw prediction "
+                                 "and go through the detector's own non_max_suppression / scale_coords (harness._inject_candidates)"),
             "segmenter": "MobileSAM (TinyViT-5M) random-init: one forward per surviving box (frame re-encoded per box, as the "
                          "reference does); the mask handed on is the box's inscribed ellipse",
             "object_map": "ObjectPointCloudMap.update_map per mask (erosion 5, back-projection, 5000-point subsample, DBSCAN eps "

@@ -188,3 +188,41 @@ def test_blip2_beside_the_detector_equals_blip2_behind_it(gpu_device):
         assert (a[2] is None and b[2] is None) or np.array_equal(a[2], b[2], equal_nan=True), k
     assert np.array_equal(ca, cb) and np.array_equal(va, vb) and np.array_equal(ea, eb)
     assert any(m == "navigate" for a in ta for m in a[1])      # the object-map branch ran
+
+
+def test_scripted_head_speaks_through_the_real_nms(gpu_device):
+    """in the timed full step the YOLOv7 network runs on every frame but its random logits decide nothing.  The
+    scripted head's candidates (24 jittered boxes per sighting, the scripted confidence on the best one) are now written into the
+    network's raw prediction, and the detector's own non_max_suppression / scale_coords / rounding (yolov7.py:91-110) turn them into
+    the detections: one per sighting, the scripted class and confidence, the scripted box within the rounding of the path."""
+    from vlfm_amd.harness import BatchedEpisodes, ScriptedSightings
+    from vlfm_amd.vlm import det_ops
+    from vlfm_amd.vlm.yolov7 import YOLOv7
+
+    n = 16
+    det = YOLOv7(device=gpu_device, allow_random_init=True, width_multiple=0.25)
+    sight = ScriptedSightings(in_view_rate=0.9, distractor_rate=0.5, search_min=2, search_span=3, nav_steps=8, height=480, width=640)
+    sim = BatchedEpisodes(n, device=gpu_device, use_blip2=False, detector=det, object_maps=True, sightings=sight, scripted_masks=True)
+    assert sim.scripted_through_nms
+    det_ops.NMS_STATS.update(frames=0, candidates=0, boxes_in=0)
+    seen = 0
+    for _ in range(30):
+        t_ep = sim.t % sim.episode_len
+        want = sim._scripted_detections(t_ep)
+        sim.step()
+        torch.cuda.synchronize()
+        got = sim.last_detections
+        for e in range(n):
+            # (the harness filtered `got` by class and confidence in place: compare what survives both)
+            w = want[e]
+            w.filter_by_class(sim.targets[e].split("|"))
+            w.filter_by_conf(sim.det_threshold)
+            assert got[e].num_detections == w.num_detections, (sim.t, e, got[e].phrases, w.phrases)
+            for i in range(w.num_detections):
+                assert got[e].phrases[i] == w.phrases[i]
+                assert abs(float(got[e].logits[i]) - float(w.logits[i])) <= 2e-3
+                px = (got[e].boxes[i] - w.boxes[i]).abs() * torch.tensor([640.0, 480.0, 640.0, 480.0])
+                assert float(px.max()) <= 2.0, (px, got[e].boxes[i], w.boxes[i])
+                seen += 1
+    assert seen > 10 and sim.object_stats.get("head_mismatch", 0) == 0
+    assert det_ops.NMS_STATS["candidates"] >= 24 * seen          # the NMS really had the clusters to suppress

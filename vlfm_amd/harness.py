@@ -272,6 +272,7 @@ class BatchedEpisodes:
             self.object_maps = [ObjectPointCloudMap(object_map_erosion_size, device=self.device,
                                                     rng=np.random.RandomState(1000 + i)) for i in self.env_ids]
         self.sightings, self.scripted_masks = sightings, scripted_masks
+        self.scripted_through_nms = True    # YOLOv7: the scripted head's candidates go through the detector's real post-processing
         self._sight_cache: Dict[int, List] = {}
         self._sched_cache: Dict[int, tuple] = {}
         if sightings is not None and self.rooms is not None:
@@ -355,6 +356,45 @@ class BatchedEpisodes:
         cur = frames[idx]
         frames[idx] = torch.where(m, torch.minimum(cur, d), cur)   # (an environment has at most one sighting per step)
         return frames
+
+    CANDIDATES_PER_SIGHTING = 24
+
+    def _inject_candidates(self, pred: torch.Tensor, in_hw, t_ep: int) -> torch.Tensor:
+        """Write the scripted head's candidates into the detector's raw prediction [E, N, 5 + classes] (xywh in network-input pixels,
+        objectness, class scores): per sighting a cluster of CANDIDATES_PER_SIGHTING boxes -- the scripted box with the scripted
+        confidence and jittered, slightly less confident copies that the NMS has to suppress -- in the first rows of its frame;
+        every other row keeps the network's own output (random weights: nothing passes the objectness gate)."""
+        from .vlm.coco_classes import COCO_CLASSES
+
+        sg = self._sightings_at(t_ep)
+        if not sg:
+            return pred
+        K = self.CANDIDATES_PER_SIGHTING
+        # the inverse of scale_coords (yolov7 [ext], as yolov7.py:99 calls it: one gain + centring pads, although the frame was
+        # resized anisotropically -- the reference's quirk is kept): a box given in frame pixels comes back as itself, rounded
+        gain = min(in_hw[0] / self.H, in_hw[1] / self.W)
+        padx, pady = (in_hw[1] - self.W * gain) / 2, (in_hw[0] - self.H * gain) / 2
+        rows = np.zeros((len(sg), K, pred.shape[2]), np.float32)
+        jit = np.random.Generator(np.random.PCG64(4242 + t_ep)).uniform(-2.0, 2.0, size=(len(sg), K, 4)).astype(np.float32)
+        jit[:, 0] = 0.0
+        used = {}
+        dst_e, dst_r = [], []
+        for n, (e, phrase, conf, (cx, cy, ax, ay), _) in enumerate(sg):
+            cls = COCO_CLASSES.index(phrase)
+            rows[n, :, 0] = cx * gain + padx + jit[n, :, 0]
+            rows[n, :, 1] = cy * gain + pady + jit[n, :, 1]
+            rows[n, :, 2] = 2 * ax * gain + jit[n, :, 2]
+            rows[n, :, 3] = 2 * ay * gain + jit[n, :, 3]
+            rows[n, :, 4] = 1.0
+            rows[n, :, 5 + cls] = conf * np.concatenate([[1.0], np.linspace(0.97, 0.75, K - 1)])   # conf = objectness x class score
+            base = used.get(e, 0)
+            used[e] = base + K
+            dst_e += [e] * K
+            dst_r += list(range(base, base + K))
+        pred = pred.clone() if pred.requires_grad else pred
+        pred[torch.tensor(dst_e, device=pred.device), torch.tensor(dst_r, device=pred.device)] = \
+            torch.from_numpy(rows.reshape(-1, rows.shape[2])).to(pred.device, pred.dtype)
+        return pred
 
     def _scripted_detections(self, t_ep: int):
         """What the scripted head reports for every environment at this step, as the detector clients' ``ObjectDetections``
@@ -652,9 +692,25 @@ class BatchedEpisodes:
 
         def detect():
             # YOLOv7 takes the frames alone; GroundingDINO is prompted (MP3D-style caption, habitat_policies.py:139-141)
-            d = (self.detector.predict_batch(rgb, [self.gdino_caption]) if self.detector_is_prompted
-                 else self.detector.predict_batch(rgb)) if self.detector is not None else None
-            if self.sightings is not None and (self.detector is not None or self.object_maps is not None):
+            scripted = self.sightings is not None and (self.detector is not None or self.object_maps is not None)
+            if self.detector is None:
+                d = None
+            elif self.detector_is_prompted:
+                d = self.detector.predict_batch(rgb, [self.gdino_caption])
+            elif scripted and self.scripted_through_nms and hasattr(self.detector, "in_hw"):
+                # the scripted head speaks THROUGH the detector's own post-processing: its candidates (a cluster of jittered boxes
+                # per sighting, the scripted confidence on the best one) are written into the network's raw prediction, and
+                # non_max_suppression / scale_coords / the rounding and normalisation of yolov7.py:91-110 produce the detections
+                d = self.detector.predict_batch(rgb, pred_hook=lambda pred, in_hw: self._inject_candidates(pred, in_hw, t_ep))
+                want = [0] * self.E
+                for sg in self._sightings_at(t_ep):
+                    want[sg[0]] += 1
+                self.object_stats["head_mismatch"] = self.object_stats.get("head_mismatch", 0) + sum(
+                    int(det.num_detections != w) for det, w in zip(d, want))
+                return d
+            else:
+                d = self.detector.predict_batch(rgb)
+            if scripted:
                 d = self._scripted_detections(t_ep)     # the scripted HEAD: the network above ran (and is timed), its random logits are not used
             return d
 

@@ -91,8 +91,12 @@ class YOLOv7:
 
     @torch.inference_mode()
     def predict_batch(self, images_u8: torch.Tensor, conf_thres: float = 0.25, iou_thres: float = 0.45,
-                      classes: Optional[Sequence[int]] = None, agnostic_nms: bool = False) -> List[ObjectDetections]:
-        """images_u8 [B,H,W,3] u8 RGB on device -> one ObjectDetections per image (boxes normalised xyxy)."""
+                      classes: Optional[Sequence[int]] = None, agnostic_nms: bool = False,
+                      pred_hook=None) -> List[ObjectDetections]:
+        """images_u8 [B,H,W,3] u8 RGB on device -> one ObjectDetections per image (boxes normalised xyxy).
+        ``pred_hook(pred, in_hw)``: called with the network's raw prediction [B, N, 85] (xywh in input pixels, objectness, class
+        scores) before the post-processing; the benchmark harness uses it to let a SCRIPTED head speak through the real
+        non_max_suppression / scale_coords path when the weights are random (vlfm_amd/harness.py)."""
         B, H, W, _ = images_u8.shape
         img = det_ops.resize_area(images_u8, self.in_hw[0], self.in_hw[1],
                                   torch.float16 if self.half_precision else torch.float32)
@@ -105,6 +109,8 @@ class YOLOv7:
             pred = self.model(img[i:i + self.MAX_FRAMES_PER_FORWARD])
             preds.append(pred[0] if isinstance(pred, (tuple, list)) else pred)
         pred = preds[0] if len(preds) == 1 else torch.cat(preds, 0)
+        if pred_hook is not None:
+            pred = pred_hook(pred, self.in_hw)
         dets = det_ops.non_max_suppression(pred.float(), conf_thres, iou_thres, classes=classes, agnostic=agnostic_nms)
         # rescale / round / normalise all detections of the batch at once, one transfer to the host (yolov7.py:99-110 per image)
         sizes = [int(p.shape[0]) for p in dets]
