@@ -646,6 +646,7 @@ def main():
     torch.cuda.synchronize(device)
     kms = read_kernel_ms()
     timed_launches = LAUNCHES_TIMED.get("value_map_update_fused_kernel", LAUNCHES_TIMED.get("value_map_fuse_kernel", 0))
+    gemm_ms, gemm_n = _lib.profile_read("gemm_f16_8p_kernel<1>")
     _lib.lib().vlfm_profile_enable(0)
     if rank == 0:
         H, W, E = args.height, args.width, args.envs
@@ -700,6 +701,21 @@ def main():
             roofline_depth = block(depth_name, per_kernel[depth_name], (
                 "the one map kernel that STREAMS HBM: every depth texel of every environment once per step (4*H*W B + the "
                 "column-maximum keys), feeding both maps; `frac` as above (PMC traffic when committed)"))
+        # the kernel the STEP is made of: the ViT-g's fc1 + GELU GEMM on csrc/gemm_f16.hip (the other three GEMMs of a block are
+        # hipBLASLt's and carry no events of ours), timed by the same dispatch events, priced against the dense f16 MFMA peak
+        roofline_mfma = None
+        if sim.blip2 is not None:
+            gms, gn = gemm_ms, gemm_n
+            if gn:
+                cfg = sim.blip2.cfg
+                rows = E * ((cfg.image_size // cfg.patch_size) ** 2 + 1)
+                flop = 2.0 * rows * cfg.v_mlp * cfg.v_hidden
+                tf = flop / (gms * 1e-3) / 1e12
+                roofline_mfma = {"bound": "mfma", "kernel": "gemm_f16_8p_kernel<1> (ViT-g fc1 + erf-GELU, f16 in / f32 accumulate)",
+                                 "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
+                                 "traffic": None, "launch_ms": round(gms, 5), "launches_timed": gn, "flop_per_launch": int(flop),
+                                 "meaning": "2 M N K of the GEMM (the GELU's ~13 operations per output are not counted) / mean launch "
+                                            "time / 2.5 PFLOP/s dense f16; 39 launches per step = ~28 % of the step's GPU time"}
         out = {
             "metric": "env-steps/s (VLM+value-map update), 640x480 RGB-D",
             "value": round(env_steps / elapsed_max, 2), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
@@ -731,6 +747,7 @@ def main():
                        "parallelism": f"env-sharded x{world} (contiguous blocks), metric all-reduce only"},
             "roofline": roofline,
             "roofline_depth_pass": roofline_depth,
+            "roofline_mfma": roofline_mfma,
             # 8-GPU readiness without the node: how much host CPU one rank needs, against what the container may use
             "host": {"cpu_s_per_step_per_rank": round(host_cpu_sum / world / args.steps, 5),
                      "busy_cores_per_rank": round(host_busy_sum / world, 3), "busy_cores_all_ranks": round(host_busy_sum, 3),
