@@ -286,9 +286,8 @@ class BatchedEpisodes:
         self.last_rho_theta = np.full((n_envs, 2), np.nan)
         self.object_stats = {"detections": 0, "masks": 0, "cloud_updates": 0, "env_steps": 0,
                              "modes": {"initialize": 0, "explore": 0, "navigate": 0}}
-        self.map_stream = torch.cuda.Stream(self.device) if overlap else None
         # SAM + ObjectPointCloudMap updates (a chain of small kernels and host read-backs) run beside the BLIP-2 forward (step()).
-        # From 128 environments on their stream is a HIGH-PRIORITY queue: beside a forward whose GEMMs hold every CU for a millisecond
+        # In the full step from 128 environments on, their stream and the map stream are HIGH-PRIORITY queues: beside a forward whose GEMMs hold every CU for a millisecond
         # at a time, the chain's small kernels otherwise wait their turn and the step ends when THEY do -- measured on one box, three
         # runs each (profiles/r05_side_stream_priority.txt): 726-738 env-steps/s at priority 0 (other boxes: 845-849, i.e. the slow
         # mode is box- or run-dependent) against 819-828 at priority -1; at 64 environments the priority costs 7 % (746-767 -> 702-715:
@@ -296,8 +295,11 @@ class BatchedEpisodes:
         # VLFM_SIDE_PRIORITY overrides (diagnostic).
         import os as _os
 
-        prio = int(_os.environ["VLFM_SIDE_PRIORITY"]) if "VLFM_SIDE_PRIORITY" in _os.environ else (-1 if n_envs >= 128 else 0)
+        full_step = detector is not None and object_maps
+        prio = int(_os.environ["VLFM_SIDE_PRIORITY"]) if "VLFM_SIDE_PRIORITY" in _os.environ else (-1 if n_envs >= 128 and full_step else 0)
+        self.map_stream = torch.cuda.Stream(self.device, priority=prio) if overlap else None
         self.obj_stream = torch.cuda.Stream(self.device, priority=prio) if overlap else None
+        # (the object stream alone at priority -1: 790-796; both: 819-828; the headline -- no detector -- keeps priority 0: -0.3 % with it)
         # Optional (concurrent_vlm_max_envs > 0, VLFM_VLM_BESIDE): at small batches neither the detector (a HIP graph of ~1 700 short
         # kernels for GroundingDINO) nor the BLIP-2 forward of 8 frames fills the chip, so the BLIP-2 forward can be enqueued FIRST,
         # on its own stream, with the detector beside it.  Measured in round 5 (profiles/r05_full_step_ab.txt): 323.6 -> 323.5
