@@ -31,5 +31,9 @@ cp profiles/pmc_traffic.json $O/pmc_traffic.json
 (timeout 500 python tools/full_step_parts_probe.py 8 2>&1 | grep -v amdgpu.ids | tail -6) > $O/r05_full_step_parts_e8.txt
 (timeout 200 python tools/sam_probe.py 32 2>&1 | grep -v amdgpu.ids | tail -1) > $O/r05_mobile_sam_b32.txt
 (timeout 300 python tools/phase_probe.py 256 150 2>&1 | grep -v amdgpu.ids | tail -24) > $O/r05_obstacle_phase_probe.txt
-find gpurun_out -name "*.db" -size +20M -delete
+# only summaries travel back (gpurun copies at most 64 MiB): traces, counter databases and the diagnostic libraries stay behind
+find gpurun_out -name "*.db" -delete
+rm -rf $O/prof_default $O/prof_cfg5 $O/prof_maps gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/gemm_pmc_[0-9]
+rm -f gpurun_out/*.so gpurun_out/*.o
+du -sh gpurun_out
 ls $O
