@@ -105,7 +105,9 @@ class _VitBlock(nn.Module):
         # explicitly (BLIP2ITM(..., strict_hip_attention=False)) to let a block switch to the library kernel with a warning
         self.strict_hip_attention = True
         # fc1 + exact GELU in one hand-written MFMA kernel once the GEMM has this many rows (below, the library's smaller
-        # tiles win: tools/gemm_f16_probe.py); 0 = always the library GEMM + a separate GELU pass
+        # tiles win INSIDE the network: standalone (tools/gemm_f16_probe.py, round 5) the kernel is ahead from 8 images on -- 47
+        # against 52 us for GEMM + GELU pass, 16: 86 / 95, 32: 165 / 173 -- but with the threshold at 8 images the 8-environment step
+        # went from 9.47 to 9.85 ms); 0 = always the library GEMM + a separate GELU pass
         self.hip_mlp_min_rows = 32 * 257
         # which of the block's four GEMMs run on csrc/gemm_f16.hip's 8-phase kernel once the GEMM has hip_mlp_min_rows rows (the
         # others go to hipBLASLt): any of "qkv", "proj", "fc1", "fc2".  VLFM_VIT_GEMMS = all | none | a comma list overrides.
