@@ -13,7 +13,9 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 SHAPES = [(300, 264, 128), (512, 512, 64), (256, 256, 192), (1000, 776, 1408), (130, 8, 64), (2500, 1408, 192), (777, 4224, 320),
-          (1028, 1408, 6144), (257, 6144, 1408)]
+          (1028, 1408, 6144), (257, 6144, 1408),
+          # more tiles than CUs (the persistent kernel walks 2 tiles per workgroup), ragged in m and n, 2 K-tiles and 1
+          (7000, 2568, 128), (5000, 4224, 64)]
 
 
 def _run(ops, x, w, b, epi, variant, out=None):
@@ -28,7 +30,7 @@ def _run(ops, x, w, b, epi, variant, out=None):
             os.environ["VLFM_GEMM_VARIANT"] = old
 
 
-@pytest.mark.parametrize("variant", [0, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [0, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("shape", SHAPES)
 def test_gemm_f16_epilogues_against_f64(gpu_device, shape, variant):
     from vlfm_amd.vlm import ops
@@ -55,7 +57,7 @@ def test_gemm_f16_epilogues_against_f64(gpu_device, shape, variant):
         assert float((got - want).abs().max()) <= 2e-3 * max(1.0, float(want.abs().max()))
 
 
-@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 7])
 def test_gemm_f16_8phase_is_deterministic_under_repetition(gpu_device, variant):
     """Race screen: 30 repeats of three multi-wave-of-workgroups problems, bitwise equal to the first run, which is checked against
     an f32 product."""

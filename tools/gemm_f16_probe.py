@@ -15,7 +15,7 @@ _lib.build()
 L = _lib.lib()
 dev = torch.device("cuda:0")
 VARIANTS = [int(v) for v in args.variants.split(",")]
-NAMES = {0: "ping-pong", 1: "lock-step", 2: "8-phase", 3: "8-phase-bal", 4: "8p-1bar", 5: "8p-bal-1bar", 6: "w4"}
+NAMES = {0: "ping-pong", 1: "lock-step", 2: "8-phase", 3: "8-phase-bal", 4: "8p-1bar", 5: "8p-bal-1bar", 6: "w4", 7: "8p-persist"}
 def ours(x, w, b, epi, variant, out=None):
     os.environ["VLFM_GEMM_VARIANT"] = str(variant)
     M, K = x.shape; N = w.shape[0]

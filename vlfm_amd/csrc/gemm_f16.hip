@@ -14,8 +14,12 @@
 //   * operand roles are swapped (A-operand = W rows, B-operand = X rows): a lane then holds 4 CONSECUTIVE n of one m, i.e.
 //     8 contiguous bytes of the output row after conversion; the epilogue transposes through LDS (row stride 272 B:
 //     conflict-free 8-byte writes, 16-byte reads) and stores 256-byte row segments with 16 B per lane.
-//   * the schedule is a PING-PONG between the two wavefronts of a SIMD (gemm_f16_nt_kernel below); the lock-step form it
-//     replaced is kept as gemm_f16_nt_lockstep_kernel for A/B runs.
+//   * the schedule is a PING-PONG between the two wavefronts of a SIMD.  Round 5 (what runs by default): the 8-phase form of it
+//     (Gemm8p: four phases of 16 MFMAs per K-tile, half-tile staging, counted vmcnt waits) as a PERSISTENT kernel
+//     (gemm_f16_8pp_kernel: one workgroup per CU walks the tile list, the next tile's first K-tile is requested before the
+//     epilogue, the stores drain under the next tile) with the GELU in packed f32 (gelu_f16.h).  The earlier forms -- round 2's
+//     4-phase ping-pong gemm_f16_nt_kernel, the lock-step kernel, the one-tile-per-workgroup 8-phase kernel, the 4-wavefront
+//     kernel -- stay selectable (VLFM_GEMM_VARIANT) for A/B runs and are covered by the same tests.
 // Measured at 256 images (tools/gemm_f16_probe.py, tools/mlp_probe.py; DESIGN.md section 6c has the table): fc1 + GELU 1.11-1.16 ms
 // against 1.41-1.45 ms for hipBLASLt + the GELU pass on random data, 1.19 against 1.24 ms on the network's own activations; as a
 // plain GEMM 1.0-1.1 PFLOP/s, i.e. 5-10 % BELOW hipBLASLt -- so only the fused fc1 uses it (vlfm_amd/vlm/ops.py:linear_gelu).
@@ -27,6 +31,7 @@
 #include <stdlib.h>
 
 #include "../../include/vlfm_amd.h"
+#include "gelu_f16.h"
 #include "profile.h"
 #include "status.h"
 
@@ -49,7 +54,8 @@ constexpr int EPI_ROW = 272;       // epilogue staging row stride (128 n x 2 B +
 constexpr int EPI_WAVE = 64 * EPI_ROW;
 constexpr int GEMM_LDS = 8 * EPI_WAVE > 2 * BUF ? 8 * EPI_WAVE : 2 * BUF;
 
-constexpr int GEMM_DEFAULT_VARIANT = 3;   // 0 ping-pong (round 2), 1 lock-step, 2 8-phase, 3 8-phase balanced (fastest), 4 / 5 = 2 / 3 with one barrier per phase
+constexpr int GEMM_DEFAULT_VARIANT = 7;   // 0 ping-pong (round 2), 1 lock-step, 2 8-phase, 3 8-phase balanced, 4 / 5 = 2 / 3 with one barrier per phase,
+                                          // 6 four wavefronts, 7 = 3 as a persistent kernel (fastest)
 enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_ACCUM = 2 };   // 2: C += X . W^T (+ bias): the residual-stream GEMMs (projection, fc2)
 
 struct GemmArgs {
@@ -61,25 +67,6 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int group_m;          // tile order of the ping-pong kernel: m-tiles per group (1 = plain n-fastest order)
 };
-
-// Exact-form GELU, 0.5 v (1 + erf(v / sqrt 2)), without the library erff (two polynomial branches + exp, ~36 VALU instructions
-// per value once both sides of the branch run in a wavefront).  erfc(u / sqrt 2) = exp2(-u q(u)) with q a degree-7 polynomial
-// (weighted minimax fit on u in [0, 5.55], monotone beyond: the tail underflows to 0 like erfc), so
-//   gelu(v) = max(v, 0) - 0.5 |v| exp2(-|v| q(|v|)):   9 FMA/mul + v_exp_f32 + max, no branch, no cancellation in the negative tail.
-// |gelu - f64| <= 2.8e-7 over [-12, 12] (torch's f32 erf form: 1.2e-6); tools/gemm_f16_probe.py checks it against torch.
-__device__ inline float gelu_erf(float v) {
-    const float u = fabsf(v);
-    float q = 2.834908400e-06f;
-    q = fmaf(q, u, -3.937762449e-05f);
-    q = fmaf(q, u, 1.861798810e-04f);
-    q = fmaf(q, u, 1.369373058e-04f);
-    q = fmaf(q, u, -7.063421421e-03f);
-    q = fmaf(q, u, 5.249617994e-02f);
-    q = fmaf(q, u, 4.592081904e-01f);
-    q = fmaf(q, u, 1.151105165e+00f);
-    const float e = __builtin_amdgcn_exp2f(-(q * u));
-    return fmaf(-0.5f * u, e, fmaxf(v, 0.0f));
-}
 
 using lds_ptr = __attribute__((address_space(3))) unsigned char*;
 using gbl_ptr = const __attribute__((address_space(1))) unsigned char*;
@@ -162,7 +149,7 @@ __device__ inline void store_tile(const GemmArgs& a, unsigned char* smem, const 
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             float v0 = acc[i][j][0] + b0, v1 = acc[i][j][1] + b1, v2 = acc[i][j][2] + b2, v3 = acc[i][j][3] + b3;
-            if (EPI == EPI_BIAS_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+            if (EPI == EPI_BIAS_GELU) gelu_erf4(v0, v1, v2, v3);
             const half4 h = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
             *reinterpret_cast<half4*>(stg + (j * 16 + c16) * EPI_ROW + nl * 2) = h;
         }
@@ -405,6 +392,37 @@ struct Gemm8p {
         const int wn = wave >> 2, wm = wave & 3;
         half = false;   // (half-tile mode: measured, no gain -- see tile())
         active = n0 + wn * (half ? 64 : 128) < a.N;
+        offsets(m0, n0, voff);
+        const int r16 = lane & 15, swz = (r16 >> 1) & 7, s0 = lane >> 4;
+        const uint32_t bp = (uint32_t)(wn * 64 + r16) * ROWB + (uint32_t)((s0 ^ swz) << 4);
+        const uint32_t bq = (uint32_t)(wm * 32 + r16) * ROWB + (uint32_t)((s0 ^ swz) << 4);
+        rdP[0] = bp; rdP[1] = bp ^ 64u;
+        rdQ[0] = bq; rdQ[1] = bq ^ 64u;
+        zero_acc();
+    }
+    __device__ inline void zero_acc() {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+    // (persistent kernel: the fragment registers are read and used under `active`; without a definition on every path they
+    // would stay live -- 80 registers -- through the epilogue of every tile)
+    __device__ inline void kill_fragments() {
+        const half8 z = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+#pragma unroll
+        for (int f = 0; f < 4; f++) { fp[f][0] = z; fp[f][1] = z; }
+#pragma unroll
+        for (int g = 0; g < 2; g++)
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                fq1[g][k] = z;
+#pragma unroll
+                for (int q = 0; q < (BAL ? 2 : 1); q++) fq0[q][g][k] = z;
+            }
+    }
+    // staging offsets of this lane for the tile at (m0, n0)
+    __device__ inline void offsets(int m0, int n0, uint32_t (&vo)[4][2]) const {
         const int sub = lane >> 3, p = lane & 7;
 #pragma unroll
         for (int j = 0; j < 2; j++) {
@@ -414,31 +432,24 @@ struct Gemm8p {
             for (int h = 0; h < 2; h++) {
                 const int rq = min(m0 + (rho >> 5) * 64 + h * 32 + (rho & 31), a.M - 1);
                 const int rp = min(n0 + (half ? rho + h * 128 : (rho >> 6) * 128 + h * 64 + (rho & 63)), a.N - 1);
-                voff[2 * h][j] = (uint32_t)rq * (uint32_t)a.K * 2u + (uint32_t)s * 16u;
-                voff[2 * h + 1][j] = (uint32_t)rp * (uint32_t)a.K * 2u + (uint32_t)s * 16u;
+                vo[2 * h][j] = (uint32_t)rq * (uint32_t)a.K * 2u + (uint32_t)s * 16u;
+                vo[2 * h + 1][j] = (uint32_t)rp * (uint32_t)a.K * 2u + (uint32_t)s * 16u;
             }
         }
-        const int r16 = lane & 15, swz = (r16 >> 1) & 7, s0 = lane >> 4;
-        const uint32_t bp = (uint32_t)(wn * 64 + r16) * ROWB + (uint32_t)((s0 ^ swz) << 4);
-        const uint32_t bq = (uint32_t)(wm * 32 + r16) * ROWB + (uint32_t)((s0 ^ swz) << 4);
-        rdP[0] = bp; rdP[1] = bp ^ 64u;
-        rdQ[0] = bq; rdQ[1] = bq ^ 64u;
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
     }
 
     // half-tile `slot` of K-tile t -> buffer b
     template <int SLOT_ID>
-    __device__ inline void stage(int b, int t) {
+    __device__ inline void stage_at(int b, int t, const uint32_t (&vo)[4][2]) {
         const unsigned char* base = reinterpret_cast<const unsigned char*>((SLOT_ID & 1) ? a.w : a.x) + (size_t)t * (GK * 2);
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const int dst = __builtin_amdgcn_readfirstlane(b * KBUF + SLOT_ID * SLOT + (wave * 2 + j) * 1024);
-            __builtin_amdgcn_global_load_lds((gbl_ptr)(base + voff[SLOT_ID][j]), lds + dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr)(base + vo[SLOT_ID][j]), lds + dst, 16, 0, 0);
         }
     }
+    template <int SLOT_ID>
+    __device__ inline void stage(int b, int t) { stage_at<SLOT_ID>(b, t, voff); }
     template <int B, int SLOT_ID>
     __device__ inline void read_p() {
 #pragma unroll
@@ -586,9 +597,9 @@ struct Gemm8p {
 // half full (N = 1408: 5.5 tiles, N = 4224: 16.5) its tiles run in about half the time of a full one (the wavefronts of the empty
 // half skip their reads and MFMAs): they are listed LAST within each XCD, so that they fill the ragged end of the last wave of
 // workgroups instead of being scattered through it -- 257 x 6 tiles on 256 CUs were 7 rounds of full-tile time, the work is 5.6.
-__device__ inline void tile_of_block(const GemmArgs& a, int& tm, int& tn) {
+__device__ inline void tile_of(const GemmArgs& a, int bid, int& tm, int& tn) {
     const int nwg = a.tiles_m * a.tiles_n;
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int xcd = bid & 7, idx = bid >> 3;
     const int tail_cols = a.N - (a.tiles_n - 1) * GB;
     const bool ragged = a.tiles_n > 1 && tail_cols <= GB / 2;
     const int ncols = ragged ? a.tiles_n - 1 : a.tiles_n;
@@ -612,6 +623,8 @@ __device__ inline void tile_of_block(const GemmArgs& a, int& tm, int& tn) {
     }
 }
 
+__device__ inline void tile_of_block(const GemmArgs& a, int& tm, int& tn) { tile_of(a, blockIdx.x, tm, tn); }
+
 template <int EPI, int BAL, int SYNC = 2>
 __global__ __launch_bounds__(512) void gemm_f16_8p_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -620,6 +633,171 @@ __global__ __launch_bounds__(512) void gemm_f16_8p_kernel(GemmArgs a) {
     const int m0 = tm * GB, n0 = tn * GB;
     Gemm8p<EPI, BAL, SYNC> g(a, smem, m0, n0);
     g.run(m0, n0);
+}
+
+
+// ------------------------------------------------------------------------------------------------ 8-phase, persistent
+// One workgroup per CU walks the tile list with stride gridDim.x (a multiple of 8: a workgroup stays on the XCD whose share of the
+// list it walks, and the tiles of one round are the neighbours the one-tile-per-workgroup launch would run together).  What a tile
+// costs outside its K loop in that launch (tools/gemm_stamp_probe.py: ~1.5 us from entry to the first MFMA -- a cold fetch of
+// K-tile 0 -- and ~3.6 us from the last MFMA to "stores have left", of 49-55 us) is taken off the critical path:
+//   * K-tile 0 of the NEXT tile is requested (8 global_load_lds per wavefront, buffer 0) right behind the last operand read of this
+//     one and lands while the epilogue does its arithmetic;
+//   * the epilogue stages through [64 KB, 136 KB) only -- buffer 1 and the tail -- in two passes of 64 n-columns (64 rows x 144 B per
+//     wavefront and pass), both passes' rows held in registers, then ONE s_waitcnt vmcnt(0) (the residual-stream loads of
+//     EPI_ACCUM and the prefetch: everything this wavefront asked for) and the 16 stores back to back;
+//   * the stores drain under the next tile's first phases: nothing waits for them before the counted wait of its phase 4.
+// After the epilogue one barrier (every wavefront's staging reads are over and its share of K-tile 0 is in LDS), then slots 0 / 1
+// of K-tile 1 are requested and the phases start; the wait of phase 4 of K-tile 0 covers them as it does in the steady state.
+constexpr int EPI2_ROW = 144;                 // 64 n x 2 B + 16
+constexpr int EPI2_WAVE = 64 * EPI2_ROW;      // 9216 B; 8 wavefronts: 72 KB behind buffer 0
+constexpr int PBIAS_OFF = GEMM_LDS;           // 256 bias halves behind everything else
+constexpr int GEMM_LDS_P = GEMM_LDS + 512;
+
+// (plain vector values, not HIP's uint4 struct: its copies are memcpy calls between address spaces that pin the arrays in scratch)
+__device__ __forceinline__ half8 add_half8(half8 a, const half8 b) {       // 8 halves + 8 halves, summed in f32
+#pragma unroll
+    for (int e = 0; e < 8; e++) a[e] = (_Float16)((float)a[e] + (float)b[e]);
+    return a;
+}
+// one pass of the persistent kernel's epilogue: n-columns [64 H, 64 H + 64) of the wavefront's block -> 8 row segments per lane
+template <int EPI, int H>
+__device__ __forceinline__ void epi2_pass(const floatx4 (&acc)[8][4], const half4 (&bias4)[8], unsigned char* stg, int g4, int c16, int rsub,
+                                 int chunk, half8 (&v)[8]) {
+#pragma unroll
+    for (int ii = 0; ii < 4; ii++) {
+        constexpr int I0 = H * 4;
+        const float b0 = (float)bias4[I0 + ii][0], b1 = (float)bias4[I0 + ii][1], b2 = (float)bias4[I0 + ii][2], b3 = (float)bias4[I0 + ii][3];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float v0 = acc[I0 + ii][j][0] + b0, v1 = acc[I0 + ii][j][1] + b1, v2 = acc[I0 + ii][j][2] + b2, v3 = acc[I0 + ii][j][3] + b3;
+            if (EPI == EPI_BIAS_GELU) gelu_erf4(v0, v1, v2, v3);
+            const half4 hv = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
+            *reinterpret_cast<half4*>(stg + (j * 16 + c16) * EPI2_ROW + (ii * 16 + g4) * 2) = hv;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // wavefront-private rows: no workgroup barrier
+#pragma unroll
+    for (int it = 0; it < 8; it++) v[it] = *reinterpret_cast<const half8*>(stg + (it * 8 + rsub) * EPI2_ROW + chunk * 16);
+}
+__device__ __forceinline__ void stage_bias(const GemmArgs& a, lds_ptr lds, int wave, int lane, int n_first) {
+    if (a.bias != nullptr && wave == 0 && lane < 32) {
+        const _Float16* src = a.bias + min(n_first + lane * 8, a.N - 8);
+        __builtin_amdgcn_global_load_lds((gbl_ptr)src, lds + PBIAS_OFF, 16, 0, 0);
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_f16_8pp_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using G = Gemm8p<EPI, 1, 2>;
+    const int nwg = a.tiles_m * a.tiles_n, stride = gridDim.x;
+    int bid = blockIdx.x;
+    int tm, tn;
+    tile_of(a, bid, tm, tn);
+    int m0 = tm * GB, n0 = tn * GB;
+    G g(a, smem, m0, n0);
+    const int NT = a.K / GK;
+    const int wave = g.wave, lane = g.lane, wn = wave >> 2, wm = wave & 3, late = wn;
+    const int g4 = (lane >> 4) * 4, c16 = lane & 15;      // accumulator layout: 4 consecutive n at g4, m = c16
+    const int rsub = lane >> 3, chunk = lane & 7;         // store layout: 8 rows x 8 chunks of 16 B per instruction
+    unsigned char* stg = smem + G::KBUF + wave * EPI2_WAVE;
+    const bool has_bias = a.bias != nullptr;
+    // bias[n0 .. n0 + 256) -> LDS behind the staging rows: one 16-byte LDS-DMA load by lanes 0-31 of wavefront 0.  Issued BEFORE the
+    // tile's first operand loads, so every counted wait that covers those covers it
+    stage_bias(a, g.lds, wave, lane, n0);
+    g.template stage<0>(0, 0); g.template stage<1>(0, 0); g.template stage<2>(0, 0); g.template stage<3>(0, 0);
+    if (NT > 1) {
+        g.template stage<0>(1, 1); g.template stage<1>(1, 1);
+        __builtin_amdgcn_s_waitcnt(0x0F74);
+    } else {
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+    }
+    g.bar();
+    for (;;) {
+        g.kill_fragments();
+        if (late) g.bar();
+        if (g.active) g.template read_q<0, 0>(g.fq0[0]);
+        for (int t = 0; t < NT; t += 2) {
+            g.template tile<0>(t, NT);
+            if (t + 1 < NT) g.template tile<1>(t + 1, NT);
+        }
+        if (!late) g.bar();       // behind it nobody reads the operand buffers any more
+
+        // ---- the tile's 256 bias values come from LDS (stage_bias(): requested with the tile's first loads).  Nothing in the
+        // epilogue's arithmetic depends on a VMEM load -- a bias quad loaded here made hipcc drain vmcnt(0), prefetch included,
+        // before the first addition
+        half4 bias4[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const half4 ld = *reinterpret_cast<const half4*>(smem + PBIAS_OFF + (wn * 128 + i * 16 + g4) * 2);
+            bias4[i] = has_bias ? ld : half4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- K-tile 0 of the next tile -> buffer 0.  Unconditional (a branch here makes hipcc drain vmcnt at the join): the last
+        // tile of a workgroup requests its own K-tile 0 again, which nobody reads
+        const int nbid = bid + stride;
+        const bool more = nbid < nwg;
+        tile_of(a, more ? nbid : bid, tm, tn);
+        const int m1 = tm * GB, n1 = tn * GB;
+        uint32_t von[4][2];
+        g.offsets(m1, n1, von);
+        g.template stage_at<0>(0, 0, von); g.template stage_at<1>(0, 0, von);
+        g.template stage_at<2>(0, 0, von); g.template stage_at<3>(0, 0, von);
+        __builtin_amdgcn_sched_barrier(0);
+        half8 old[EPI == EPI_ACCUM ? 16 : 1];       // the residual stream's row segments: used behind the vmcnt(0) below
+        if (EPI == EPI_ACCUM) {
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int it = 0; it < 8; it++) {
+                    const int m = min(m0 + wm * 64 + it * 8 + rsub, a.M - 1);
+                    const int n = max(min(n0 + wn * 128 + h * 64 + chunk * 8, a.N - 8), 0);
+                    old[h * 8 + it] = *reinterpret_cast<const half8*>(a.c + (size_t)m * a.N + n);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- bias (+ GELU), f16, transpose through the wavefront's staging rows: two passes of 64 n
+        half8 v0[8], v1[8];
+        epi2_pass<EPI, 0>(g.acc, bias4, stg, g4, c16, rsub, chunk, v0);
+        epi2_pass<EPI, 1>(g.acc, bias4, stg, g4, c16, rsub, chunk, v1);
+        if (EPI == EPI_ACCUM) {
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                v0[it] = add_half8(v0[it], old[it]);
+                v1[it] = add_half8(v1[it], old[8 + it]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);       // this wavefront's share of the next K-tile 0 is in LDS (no store is in flight yet)
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const int n = n0 + wn * 128 + chunk * 8;
+            if (n + 8 <= a.N) {
+#pragma unroll
+                for (int it = 0; it < 8; it++) {
+                    const int m = m0 + wm * 64 + it * 8 + rsub;
+                    if (m < a.M) *reinterpret_cast<half8*>(a.c + (size_t)m * a.N + n) = v0[it];
+                }
+            }
+            if (n + 64 + 8 <= a.N) {
+#pragma unroll
+                for (int it = 0; it < 8; it++) {
+                    const int m = m0 + wm * 64 + it * 8 + rsub;
+                    if (m < a.M) *reinterpret_cast<half8*>(a.c + (size_t)m * a.N + n + 64) = v1[it];
+                }
+            }
+        }
+        if (!more) break;
+        bid = nbid; m0 = m1; n0 = n1;
+#pragma unroll
+        for (int s = 0; s < 4; s++) { g.voff[s][0] = von[s][0]; g.voff[s][1] = von[s][1]; }
+        g.active = n0 + wn * 128 < a.N;
+        g.zero_acc();
+        g.bar();      // staging rows are free again (they lie in buffer 1), K-tile 0 is complete for everybody
+        stage_bias(a, g.lds, wave, lane, n0);
+        if (NT > 1) { g.template stage<0>(1, 1); g.template stage<1>(1, 1); }
+    }
 }
 
 
@@ -660,7 +838,7 @@ __device__ inline void store_tile_w4(const GemmArgs& a, unsigned char* smem, con
                 const half4 bv = bias4[i][g];
                 float v0 = acc[i][j][4 * g + 0] + (float)bv[0], v1 = acc[i][j][4 * g + 1] + (float)bv[1];
                 float v2 = acc[i][j][4 * g + 2] + (float)bv[2], v3 = acc[i][j][4 * g + 3] + (float)bv[3];
-                if (EPI == EPI_BIAS_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+                if (EPI == EPI_BIAS_GELU) gelu_erf4(v0, v1, v2, v3);
                 const half4 h = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
                 *reinterpret_cast<half4*>(stg + (j * 32 + c32) * EPI_ROW + (i * 32 + g * 8 + h4) * 2) = h;
             }
@@ -880,6 +1058,23 @@ using namespace vlfm;
 // lock-step kernels (A/B runs of tools/gemm_f16_probe.py; they do not implement epilogue 2), 2 / 3 the 8-phase kernel's two read schedules.
 template <int EPI>
 static int launch_gemm(const GemmArgs& a, int variant, hipStream_t stream) {
+    if (variant == 7) {     // persistent 8-phase: one workgroup per CU (a multiple of 8 of them: see the kernel)
+        const void* fn = reinterpret_cast<const void*>(gemm_f16_8pp_kernel<EPI>);
+        static LdsOptIn optp;
+        if (!optp.ensure(fn, GEMM_LDS_P)) return fail(VLFM_ERR_HIP, "gemm_f16_nt: cannot opt in to the LDS size");
+        static int n_cu = 0;
+        if (n_cu == 0) {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 8)
+                v = 256;
+            n_cu = v & ~7;
+        }
+        const int nwg = a.tiles_m * a.tiles_n;
+        const dim3 grid(nwg < n_cu ? nwg : n_cu), block(512);
+        VLFM_TIMED(EPI == EPI_BIAS ? "gemm_f16_8pp_kernel<0>" : EPI == EPI_BIAS_GELU ? "gemm_f16_8pp_kernel<1>" : "gemm_f16_8pp_kernel<2>", stream);
+        VLFM_KLAUNCH((gemm_f16_8pp_kernel<EPI>), grid, block, GEMM_LDS_P, stream, a);
+        return check_launch("gemm_f16_8pp_kernel");
+    }
     if (variant >= 6) {     // four wavefronts, one per SIMD (LDS-DMA loads of the next-but-one K-tile in the two k-steps behind the barrier)
         const void* fn = reinterpret_cast<const void*>(gemm_f16_w4_kernel<EPI, 8, 8, 0, 0>);
         constexpr int LDS4 = 4 * EPI_WAVE4 > 2 * BUF ? 4 * EPI_WAVE4 : 2 * BUF;
@@ -929,7 +1124,8 @@ extern "C" int vlfm_gemm_f16_nt(const void* d_x, const void* d_w, const void* d_
     if (a.group_m < 1) a.group_m = 1;
     const char* ev = getenv("VLFM_GEMM_VARIANT");
     int variant = ev ? atoi(ev) : GEMM_DEFAULT_VARIANT;
-    if (variant < 0 || variant > 6) variant = GEMM_DEFAULT_VARIANT;
+    if (variant < 0 || variant > 7) variant = GEMM_DEFAULT_VARIANT;
+    if (variant == 7 && !eg) a.group_m = 4;   // persistent walk: groups of 4 m-tiles on every ViT shape (probe: 2-8 within 1 %, 1 and 16+ behind)
     if (epilogue == 2 && variant < 2) return fail(VLFM_ERR_INVALID, "gemm_f16_nt: epilogue 2 needs an 8-phase kernel");
     if (epilogue == 0) return launch_gemm<EPI_BIAS>(a, variant, (hipStream_t)stream);
     if (epilogue == 1) return launch_gemm<EPI_BIAS_GELU>(a, variant, (hipStream_t)stream);
