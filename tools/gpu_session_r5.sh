@@ -20,7 +20,7 @@ python tools/rocprof_summary.py $O/prof_maps/p_results.db $O/r05_maps_e256_kerne
 VLFM_COMMIT=${VLFM_COMMIT:-unknown} bash tools/pmc_traffic.sh 256 640 480 > $O/pmc_e256.log 2>&1
 VLFM_COMMIT=${VLFM_COMMIT:-unknown} bash tools/pmc_traffic.sh 16 1280 720 sync > $O/pmc_cfg5.log 2>&1
 cp profiles/pmc_traffic.json $O/pmc_traffic.json
-(timeout 600 python tools/gemm_f16_probe.py --variants 0,3,6 2>&1 | grep -v amdgpu.ids) > $O/r05_gemm_probe.txt
+(timeout 600 python tools/gemm_f16_probe.py --variants 0,3,7 2>&1 | grep -v amdgpu.ids) > $O/r05_gemm_probe.txt
 (timeout 300 python tools/gemm_stamp_probe.py 3 2>&1 | grep -v amdgpu.ids | grep -v "in flight") > $O/r05_gemm_stamps.txt
 (bash tools/gemm_pmc.sh 2>&1 | grep -v amdgpu.ids) > $O/r05_gemm_pmc.txt
 (timeout 300 python tools/vm_phase_probe.py 2>&1 | grep -v amdgpu.ids | cut -c1-400) > $O/r05_vm_phase_probe.txt
