@@ -321,6 +321,11 @@ int vlfm_vit_attention_f16(const void* d_qkv, void* d_out, int batch, int tokens
 int vlfm_gemm_f16_nt(const void* d_x, const void* d_w, const void* d_bias, void* d_c, int m, int n, int k, int epilogue,
                      void* stream);
 
+/* Diagnostic, host only (no GPU needed): the order in which vlfm_gemm_f16_nt's 8-phase kernels walk the 256 x 256 tiles of an
+ * m x n result -- list position i -> (m-tile, n-tile) in out[2 i], out[2 i + 1]; position i runs on XCD i % 8, the persistent kernel's
+ * workgroup w takes positions w, w + grid, ...  Returns the number of tiles (negative: error).  group_m <= 0: the default. */
+int vlfm_gemm_f16_tile_order(int m, int n, int group_m, int* out, int capacity_pairs);
+
 /* C[M][N] = act(X[M][K] . W[N][K]^T + bias[N]) + residual[M][N]: f32 operands, f32 accumulation, f32 result on the matrix cores
  * (csrc/gemm_f32.hip) -- the Linear layers of GroundingDINO, which the reference runs in fp32 (vlfm/vlm/grounding_dino.py:38-74,
  * groundingdino's build_model [ext]), and of MobileSAM's TinyViT (vlfm/vlm/sam.py:40-57).

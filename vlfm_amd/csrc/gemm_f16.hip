@@ -597,7 +597,7 @@ struct Gemm8p {
 // half full (N = 1408: 5.5 tiles, N = 4224: 16.5) its tiles run in about half the time of a full one (the wavefronts of the empty
 // half skip their reads and MFMAs): they are listed LAST within each XCD, so that they fill the ragged end of the last wave of
 // workgroups instead of being scattered through it -- 257 x 6 tiles on 256 CUs were 7 rounds of full-tile time, the work is 5.6.
-__device__ inline void tile_of(const GemmArgs& a, int bid, int& tm, int& tn) {
+__host__ __device__ inline void tile_of(const GemmArgs& a, int bid, int& tm, int& tn) {
     const int nwg = a.tiles_m * a.tiles_n;
     const int xcd = bid & 7, idx = bid >> 3;
     const int tail_cols = a.N - (a.tiles_n - 1) * GB;
@@ -1130,6 +1130,21 @@ extern "C" int vlfm_gemm_f16_nt(const void* d_x, const void* d_w, const void* d_
     if (epilogue == 0) return launch_gemm<EPI_BIAS>(a, variant, (hipStream_t)stream);
     if (epilogue == 1) return launch_gemm<EPI_BIAS_GELU>(a, variant, (hipStream_t)stream);
     return launch_gemm<EPI_ACCUM>(a, variant, (hipStream_t)stream);
+}
+
+// The tile order of the 8-phase kernels, evaluated on the HOST (tests/test_gemm_tile_order_cpu.py: a bijection for every shape, the
+// half n-tiles last within each XCD, the persistent walk of gridDim workgroups covering every tile once): out[2 i], out[2 i + 1] =
+// (m-tile, n-tile) of list position i.  group_m <= 0: the default vlfm_gemm_f16_nt chooses for the persistent kernel.
+extern "C" int vlfm_gemm_f16_tile_order(int m, int n, int group_m, int* out, int capacity_pairs) {
+    if (m <= 0 || n <= 0 || !out) return fail(VLFM_ERR_INVALID, "gemm_f16_tile_order: m, n > 0 and an output array");
+    GemmArgs a{};
+    a.M = m; a.N = n; a.K = GK;
+    a.tiles_m = (m + GB - 1) / GB; a.tiles_n = (n + GB - 1) / GB;
+    a.group_m = group_m > 0 ? group_m : 4;
+    const int nwg = a.tiles_m * a.tiles_n;
+    if (capacity_pairs < nwg) return fail(VLFM_ERR_INVALID, "gemm_f16_tile_order: output array too small");
+    for (int b = 0; b < nwg; b++) tile_of(a, b, out[2 * b], out[2 * b + 1]);
+    return nwg;
 }
 
 #ifdef VLFM_PHASE_TIMING
