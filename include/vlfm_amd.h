@@ -325,6 +325,10 @@ int vlfm_gemm_f16_nt(const void* d_x, const void* d_w, const void* d_bias, void*
  * m x n result -- list position i -> (m-tile, n-tile) in out[2 i], out[2 i + 1]; position i runs on XCD i % 8, the persistent kernel's
  * workgroup w takes positions w, w + grid, ...  Returns the number of tiles (negative: error).  group_m <= 0: the default. */
 int vlfm_gemm_f16_tile_order(int m, int n, int group_m, int* out, int capacity_pairs);
+/* ... and the persistent kernel's work items for `grid` workgroups: item i -> (list position of its tile, n-half 0 / 1 or -1 = the whole
+ * tile) in out[2 i], out[2 i + 1]; the tiles of a ragged last round are split into their two n-halves when that round is at most half
+ * full.  Returns the number of items. */
+int vlfm_gemm_f16_work_items(int m, int n, int grid, int* out, int capacity_pairs);
 
 /* C[M][N] = act(X[M][K] . W[N][K]^T + bias[N]) + residual[M][N]: f32 operands, f32 accumulation, f32 result on the matrix cores
  * (csrc/gemm_f32.hip) -- the Linear layers of GroundingDINO, which the reference runs in fp32 (vlfm/vlm/grounding_dino.py:38-74,

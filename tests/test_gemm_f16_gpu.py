@@ -15,7 +15,10 @@ pytestmark = pytest.mark.gpu
 SHAPES = [(300, 264, 128), (512, 512, 64), (256, 256, 192), (1000, 776, 1408), (130, 8, 64), (2500, 1408, 192), (777, 4224, 320),
           (1028, 1408, 6144), (257, 6144, 1408),
           # more tiles than CUs (the persistent kernel walks 2 tiles per workgroup), ragged in m and n, 2 K-tiles and 1
-          (7000, 2568, 128), (5000, 4224, 64)]
+          (7000, 2568, 128), (5000, 4224, 64),
+          # fc1 at 32 images: 792 tiles = 3 rounds of 256 + 24, the leftover tiles run as 48 n-half items (both wavefront groups as the
+          # only active one)
+          (8224, 6144, 128)]
 
 
 def _run(ops, x, w, b, epi, variant, out=None):
@@ -63,7 +66,7 @@ def test_gemm_f16_8phase_is_deterministic_under_repetition(gpu_device, variant):
     an f32 product."""
     from vlfm_amd.vlm import ops
 
-    for (M, N, K) in [(4096, 4224, 1408), (2048, 1408, 6144), (8192, 6144, 1408)]:
+    for (M, N, K) in [(4096, 4224, 1408), (2048, 1408, 6144), (8192, 6144, 1408), (8224, 6144, 1408)]:
         g = torch.Generator().manual_seed(M + N + K)
         x = torch.randn(M, K, generator=g).half().to(gpu_device)
         w = (torch.randn(N, K, generator=g) * 0.05).half().to(gpu_device)

@@ -73,3 +73,53 @@ def test_tile_order_rejects_bad_arguments():
     assert L.vlfm_gemm_f16_tile_order(0, 8, 0, out, 2) < 0
     assert L.vlfm_gemm_f16_tile_order(1024, 1024, 0, out, 2) < 0      # 16 tiles do not fit 2 pairs
     assert L.vlfm_gemm_f16_tile_order(256, 256, 0, None, 2) < 0
+
+
+@pytest.mark.parametrize("grid", [256, 304, 32, 8])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_work_items_cover_every_tile_once_whole_or_as_two_halves(shape, grid):
+    from vlfm_amd import _lib
+
+    _lib.build()
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    L.vlfm_gemm_f16_work_items.restype = ctypes.c_int
+    m, n = shape
+    tiles = ((m + 255) // 256) * ((n + 255) // 256)
+    out = np.full((2 * tiles, 2), -7, np.int32)
+    items = L.vlfm_gemm_f16_work_items(m, n, grid, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), 2 * tiles)
+    assert tiles <= items <= tiles + grid // 2
+    it = out[:items]
+    whole = np.zeros(tiles, np.int32)
+    halves = np.zeros((tiles, 2), np.int32)
+    for pos, h in it:
+        assert 0 <= pos < tiles and h in (-1, 0, 1)
+        if h < 0:
+            whole[pos] += 1
+        else:
+            halves[pos, h] += 1
+    split = halves.sum(axis=1) > 0
+    assert (whole[~split] == 1).all() and (whole[split] == 0).all() and (halves[split] == 1).all()
+    g = min(grid, tiles)
+    left = tiles % g if tiles > g else 0
+    if left and 2 * left <= g:
+        assert split.sum() == left and split[tiles - left:].all()      # exactly the ragged round, and it becomes one full-width round
+        assert items == tiles + left
+    else:
+        assert not split.any()
+    per_wg = np.bincount(np.arange(items) % g, minlength=g)
+    assert per_wg.max() - per_wg.min() <= 1
+
+
+def test_the_vit_fc1_shapes_end_in_split_rounds():
+    """fc1 at 256 / 128 / 64 / 32 images: 24.1 / 12.1 / 6.1 / 3.1 rounds of 256 workgroups -- the 24 leftover tiles become 48 half items."""
+    from vlfm_amd import _lib
+
+    _lib.build()
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    L.vlfm_gemm_f16_work_items.restype = ctypes.c_int
+    for images in (256, 128, 64, 32):
+        m = images * 257
+        tiles = ((m + 255) // 256) * 24
+        out = np.zeros((2 * tiles, 2), np.int32)
+        assert L.vlfm_gemm_f16_work_items(m, 6144, 256, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), 2 * tiles) == tiles + tiles % 256
+        assert tiles % 256 == 24

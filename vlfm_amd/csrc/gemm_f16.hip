@@ -66,6 +66,7 @@ struct GemmArgs {
     int M, N, K;
     int tiles_m, tiles_n;
     int group_m;          // tile order of the ping-pong kernel: m-tiles per group (1 = plain n-fastest order)
+    int split_ragged;     // persistent kernel: split the tiles of a ragged last round into n-halves (0: diagnostic VLFM_GEMM_NO_SPLIT)
 };
 
 using lds_ptr = __attribute__((address_space(3))) unsigned char*;
@@ -687,16 +688,38 @@ __device__ __forceinline__ void stage_bias(const GemmArgs& a, lds_ptr lds, int w
     }
 }
 
+// Work items of the persistent walk.  With more tiles than workgroups the last round is ragged: 6 168 tiles on 256 workgroups are
+// 24 rounds + 24 tiles, and those 24 cost a 25th round (792 tiles at 32 images: 3 rounds + 24, i.e. 4).  When the leftover is at most
+// half a round, each leftover tile becomes TWO items -- its n-columns [0, 128) and [128, 256), i.e. one wavefront group each (the
+// other group's wavefronts skip their reads and MFMAs, as they do in the half-empty last n-tile of N = 1408) -- which take ~0.6 of a
+// tile's time on twice as many workgroups.  item -> (list position of the tile, half or -1)
+struct WorkList {
+    int nwg, first_split, nitems;
+    __host__ __device__ WorkList(int nwg_, int grid, bool allow = true) : nwg(nwg_) {
+        const int left = nwg > grid ? nwg % grid : 0;
+        const bool split = allow && left > 0 && 2 * left <= grid;
+        first_split = split ? nwg - left : nwg;
+        nitems = nwg + (split ? left : 0);
+    }
+    __host__ __device__ void item(int w, int& pos, int& half) const {
+        if (w < first_split) { pos = w; half = -1; }
+        else { const int j = w - first_split; pos = first_split + (j >> 1); half = j & 1; }
+    }
+};
+
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_f16_8pp_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using G = Gemm8p<EPI, 1, 2>;
-    const int nwg = a.tiles_m * a.tiles_n, stride = gridDim.x;
-    int bid = blockIdx.x;
-    int tm, tn;
-    tile_of(a, bid, tm, tn);
+    const int stride = gridDim.x;
+    const WorkList work(a.tiles_m * a.tiles_n, stride, a.split_ragged != 0);
+    int bid = blockIdx.x;        // work item
+    int tm, tn, pos, half;
+    work.item(bid, pos, half);
+    tile_of(a, pos, tm, tn);
     int m0 = tm * GB, n0 = tn * GB;
     G g(a, smem, m0, n0);
+    g.active = g.active && (half < 0 || half == (g.wave >> 2));
     const int NT = a.K / GK;
     const int wave = g.wave, lane = g.lane, wn = wave >> 2, wm = wave & 3, late = wn;
     const int g4 = (lane >> 4) * 4, c16 = lane & 15;      // accumulator layout: 4 consecutive n at g4, m = c16
@@ -737,8 +760,10 @@ __global__ __launch_bounds__(512) void gemm_f16_8pp_kernel(GemmArgs a) {
         // ---- K-tile 0 of the next tile -> buffer 0.  Unconditional (a branch here makes hipcc drain vmcnt at the join): the last
         // tile of a workgroup requests its own K-tile 0 again, which nobody reads
         const int nbid = bid + stride;
-        const bool more = nbid < nwg;
-        tile_of(a, more ? nbid : bid, tm, tn);
+        const bool more = nbid < work.nitems;
+        const bool store = g.active;          // (a wavefront outside the item's columns holds zeros, not results)
+        work.item(more ? nbid : bid, pos, half);
+        tile_of(a, pos, tm, tn);
         const int m1 = tm * GB, n1 = tn * GB;
         uint32_t von[4][2];
         g.offsets(m1, n1, von);
@@ -773,14 +798,14 @@ __global__ __launch_bounds__(512) void gemm_f16_8pp_kernel(GemmArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         {
             const int n = n0 + wn * 128 + chunk * 8;
-            if (n + 8 <= a.N) {
+            if (store && n + 8 <= a.N) {
 #pragma unroll
                 for (int it = 0; it < 8; it++) {
                     const int m = m0 + wm * 64 + it * 8 + rsub;
                     if (m < a.M) *reinterpret_cast<half8*>(a.c + (size_t)m * a.N + n) = v0[it];
                 }
             }
-            if (n + 64 + 8 <= a.N) {
+            if (store && n + 64 + 8 <= a.N) {
 #pragma unroll
                 for (int it = 0; it < 8; it++) {
                     const int m = m0 + wm * 64 + it * 8 + rsub;
@@ -792,7 +817,7 @@ __global__ __launch_bounds__(512) void gemm_f16_8pp_kernel(GemmArgs a) {
         bid = nbid; m0 = m1; n0 = n1;
 #pragma unroll
         for (int s = 0; s < 4; s++) { g.voff[s][0] = von[s][0]; g.voff[s][1] = von[s][1]; }
-        g.active = n0 + wn * 128 < a.N;
+        g.active = n0 + wn * 128 < a.N && (half < 0 || half == wn);
         g.zero_acc();
         g.bar();      // staging rows are free again (they lie in buffer 1), K-tile 0 is complete for everybody
         stage_bias(a, g.lds, wave, lane, n0);
@@ -1122,6 +1147,7 @@ extern "C" int vlfm_gemm_f16_nt(const void* d_x, const void* d_w, const void* d_
     const char* eg = getenv("VLFM_GEMM_GROUP_M");
     a.group_m = eg ? atoi(eg) : (a.tiles_n >= 12 ? 8 : 1);
     if (a.group_m < 1) a.group_m = 1;
+    a.split_ragged = getenv("VLFM_GEMM_NO_SPLIT") ? 0 : 1;
     const char* ev = getenv("VLFM_GEMM_VARIANT");
     int variant = ev ? atoi(ev) : GEMM_DEFAULT_VARIANT;
     if (variant < 0 || variant > 7) variant = GEMM_DEFAULT_VARIANT;
@@ -1145,6 +1171,17 @@ extern "C" int vlfm_gemm_f16_tile_order(int m, int n, int group_m, int* out, int
     if (capacity_pairs < nwg) return fail(VLFM_ERR_INVALID, "gemm_f16_tile_order: output array too small");
     for (int b = 0; b < nwg; b++) tile_of(a, b, out[2 * b], out[2 * b + 1]);
     return nwg;
+}
+
+// The persistent kernel's work items for a grid of `grid` workgroups, on the host: out[2 i], out[2 i + 1] = (list position of the tile,
+// n-half 0 / 1 or -1 for the whole tile) of item i; workgroup w takes items w, w + grid, ...
+extern "C" int vlfm_gemm_f16_work_items(int m, int n, int grid, int* out, int capacity_pairs) {
+    if (m <= 0 || n <= 0 || grid <= 0 || !out) return fail(VLFM_ERR_INVALID, "gemm_f16_work_items: m, n, grid > 0 and an output array");
+    const int nwg = ((m + GB - 1) / GB) * ((n + GB - 1) / GB);
+    const WorkList work(nwg, grid < nwg ? grid : nwg);
+    if (capacity_pairs < work.nitems) return fail(VLFM_ERR_INVALID, "gemm_f16_work_items: output array too small");
+    for (int w = 0; w < work.nitems; w++) work.item(w, out[2 * w], out[2 * w + 1]);
+    return work.nitems;
 }
 
 #ifdef VLFM_PHASE_TIMING
