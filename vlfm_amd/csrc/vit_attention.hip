@@ -54,6 +54,12 @@ constexpr size_t AT_LDS_PART = (size_t)AT_WAVES * (AT_D + 2) * 4;  // partials o
 constexpr size_t AT_LDS_QCLS = (size_t)AT_D * 2;                   // the CLS query row
 constexpr size_t AT_LDS_BYTES = AT_LDS_K + AT_LDS_V + AT_LDS_PART + AT_LDS_QCLS;
 
+// Diagnostic builds only (tools/vit_attn_stub_probe.py): -DVLFM_ATT_STUB=1 memory side only (loads, staging, stores of zeros; no
+// attention), 2 no global loads (constants are staged instead), 3 no CLS share, 4 no stores.  Undefined (0) in the product.
+#ifndef VLFM_ATT_STUB
+#define VLFM_ATT_STUB 0
+#endif
+
 // Optional phase timing (diagnostic build with -DVLFM_PHASE_TIMING; tools/vit_attn_phase_probe.py): lane 0 of wavefront 0
 // of the LAST workgroup stamps the 100 MHz wall clock at phase boundaries.
 #ifdef VLFM_PHASE_TIMING
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const int s = s0 + u;
-            if (i < kItems && s < AT_S && ch < DH / 8) {
+            if (VLFM_ATT_STUB != 2 && i < kItems && s < AT_S && ch < DH / 8) {
                 const _Float16* src = base + (size_t)s * row_halfs + (size_t)H * DH + 8 * ch;
                 kreg[it][u] = *reinterpret_cast<const half8_t*>(src);                      // K
                 vreg[it][u] = *reinterpret_cast<const half8_t*>(src + (size_t)H * DH);     // V
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _
     half8_t qmain[AT_D / 16];
 #pragma unroll
     for (int kk = 0; kk < AT_D / 16; kk++) {
-        if (2 * kk + grp < DH / 8) {
+        if (VLFM_ATT_STUB != 2 && 2 * kk + grp < DH / 8) {
             qmain[kk] = *reinterpret_cast<const half8_t*>(base + (size_t)tq * row_halfs + 8 * grp + 16 * kk);
         } else {
 #pragma unroll
@@ -286,12 +292,20 @@ __global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _
     // Wavefronts w and w + 4 share a SIMD: the upper four do their (short) CLS share first, so that the pair is out of
     // phase -- one in the matrix pipe while the other does softmax VALU work.
     const bool cls_first = stagger && wave >= AT_WAVES / 2;
-    if (cls_first) cls_part();
+    if (VLFM_ATT_STUB != 1 && VLFM_ATT_STUB != 3 && cls_first) cls_part();
     // ---- the 32 queries of tokens 1 + 32 wave .. 32 + 32 wave
     {
         f32x16_t o[AT_D / 32];
         float m, l;
-        attend<AT_KT>(Kl, Vl, qmain, 0, c, o, m, l);
+        if (VLFM_ATT_STUB != 1) {
+            attend<AT_KT>(Kl, Vl, qmain, 0, c, o, m, l);
+        } else {
+            l = 1.0f;
+#pragma unroll
+            for (int dt = 0; dt < AT_D / 32; dt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) o[dt][r] = (float)qmain[dt][r & 7];
+        }
         AT_PHASE(7);
         const float inv = 1.0f / l;
         _Float16* dst = out + ((size_t)(b * AT_S + tq) * H + h) * DH + 4 * grp;
@@ -301,12 +315,13 @@ __global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _
             for (int q4 = 0; q4 < 4; q4++) {
                 const half4_t v = half4_t{(_Float16)(o[dt][4 * q4] * inv), (_Float16)(o[dt][4 * q4 + 1] * inv),
                                           (_Float16)(o[dt][4 * q4 + 2] * inv), (_Float16)(o[dt][4 * q4 + 3] * inv)};
-                if (32 * dt + 8 * q4 + 4 * grp < DH) *reinterpret_cast<half4_t*>(dst + 32 * dt + 8 * q4) = v;
+                if ((VLFM_ATT_STUB != 4 || v[0] == (_Float16)12345.0f) && 32 * dt + 8 * q4 + 4 * grp < DH)
+                    *reinterpret_cast<half4_t*>(dst + 32 * dt + 8 * q4) = v;
             }
         }
     }
     AT_PHASE(8);
-    if (!cls_first) cls_part();
+    if (VLFM_ATT_STUB != 1 && VLFM_ATT_STUB != 3 && !cls_first) cls_part();
     AT_PHASE(9);
     __syncthreads();
     AT_PHASE(10);
