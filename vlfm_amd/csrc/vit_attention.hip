@@ -26,6 +26,7 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/vlfm_amd.h"
 #include "profile.h"
@@ -362,7 +363,10 @@ extern "C" int vlfm_vit_attention_f16(const void* d_qkv, void* d_out, int batch,
     if (!(head_dim == 88 ? opt_in88.ensure(reinterpret_cast<const void*>(vit_attention_kernel<88>), AT_LDS_BYTES)
                          : opt_in96.ensure(reinterpret_cast<const void*>(vit_attention_kernel<96>), AT_LDS_BYTES)))
         return fail(VLFM_ERR_HIP, "vit_attention_f16: cannot opt in to 117 KB of LDS");
-    const int stagger = 1;  // measured neutral to +3 %; kept: it costs nothing
+    // the upper four wavefronts do their CLS share first (VLFM_ATT_STAGGER=0, diagnostic: all do it last): 269 against 277 us at 256
+    // images; delaying them further (up to 3 000 cycles) changes nothing (round 5, profiles/r05_vit_attention_stub_probe.txt)
+    const char* es = getenv("VLFM_ATT_STAGGER");
+    const int stagger = es ? (atoi(es) != 0) : 1;
     VLFM_TIMED("vit_attention_kernel", stream);
     const dim3 grid(8 * ((batch + 7) / 8) * heads), block(64 * AT_WAVES);
     if (head_dim == 88) {
