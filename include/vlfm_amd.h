@@ -306,9 +306,9 @@ int vlfm_layernorm_bias_f16(const void* d_x, const float* d_channel_bias, const 
 /* Self-attention of the ViT-g blocks: d_qkv [batch][tokens][3][heads][head_dim] f16 (the qkv GEMM's output as it is),
  * d_out [batch][tokens][heads][head_dim] f16 = softmax(q k^T * scale) v per (image, head), ready for the projection
  * GEMM.  Specialised for tokens == 257 and head_dim == 88 (ViT-g's native head width: the qkv and projection GEMMs keep
- * their original sizes) or 96 (heads zero-padded inside the weights; scale stays 1/sqrt(88)); anything else returns
- * VLFM_ERR_INVALID and the caller uses the library attention.  One workgroup per
- * (image, head) with K and V^T resident in 114 KB of LDS, v_mfma_f32_32x32x16_f16, f32 softmax. */
+ * their original sizes); anything else returns VLFM_ERR_INVALID and the caller uses the library attention.  A persistent
+ * kernel: one workgroup per CU walks its (image, head) items with K / V / Q arriving by LDS-DMA under the previous
+ * item's MFMAs (150 KB of LDS), v_mfma_f32_32x32x16_f16, f32 softmax, the CLS query on the VALU. */
 int vlfm_vit_attention_f16(const void* d_qkv, void* d_out, int batch, int tokens, int heads, int head_dim, float scale,
                            void* stream);
 

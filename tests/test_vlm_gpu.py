@@ -233,27 +233,45 @@ def test_vit_block_with_the_fc1_gelu_kernel(gpu_device):
         assert (ours - want).abs().mean() <= 1.2 * (lib - want).abs().mean() + 1e-4
 
 
-@pytest.mark.parametrize("D", [88, 96])
-def test_vit_attention_kernel_vs_fp32_reference(gpu_device, D):
-    """vlfm_vit_attention_f16 (257 tokens, 16 heads of 88 -- native, or zero-padded to 96) against
-    softmax(q k^T / sqrt(88)) v in fp32."""
+@pytest.mark.parametrize("B", [1, 3, 19, 40])
+def test_vit_attention_kernel_vs_fp32_reference(gpu_device, B):
+    """vlfm_vit_attention_f16 (257 tokens, 16 heads of 88) against softmax(q k^T / sqrt(88)) v in fp32.  B = 19 and 40 make the
+    persistent workgroups walk 2 and 3 (image, head) items each (the LDS-DMA pipeline across items), B = 1 uses one XCD only; the
+    run is repeated (a race between the DMA pieces, the staged rows and the barriers would not be deterministic)."""
     from vlfm_amd.vlm import ops
 
-    g = torch.Generator().manual_seed(7)
-    B, S, H = 3, 257, 16
+    g = torch.Generator().manual_seed(7 + B)
+    S, H, D = 257, 16, 88
     qkv = torch.randn(B, S, 3, H, D, generator=g) * 1.5
-    qkv[..., 88:] = 0                                     # what the zero-padded qkv weights produce (D = 96)
-    qkv[0, :, 0, 0, :88] *= 4.0                           # a head with peaked softmax rows
+    qkv[0, :, 0, 0] *= 4.0                                # a head with peaked softmax rows
+    qkv[B - 1, :, 0, 5] *= 3.0
+    qkv[B - 1, 0, 0, 7] *= 5.0                            # a peaked CLS query (the VALU path)
     half = qkv.half()
     scale = 88 ** -0.5
     q, k, v = [half[:, :, i].float().permute(0, 2, 1, 3) for i in range(3)]          # [B,H,S,D]
     want = torch.softmax(q @ k.transpose(-1, -2) * scale, dim=-1) @ v                 # [B,H,S,D]
     want = want.permute(0, 2, 1, 3).reshape(B * S, H * D)
-    got = ops.vit_attention(half.to(gpu_device).reshape(B * S, 3 * H * D).contiguous(), B, S, H, D, scale).float().cpu()
-    err = (got - want).abs()
-    assert err.max() <= 6e-3, (float(err.max()), int(err.argmax()))
-    if D == 96:
-        assert float(got.view(B * S, H, D)[:, :, 88:].abs().max()) == 0.0
+    x = half.to(gpu_device).reshape(B * S, 3 * H * D).contiguous()
+    first = None
+    for _ in range(3):
+        got = ops.vit_attention(x, B, S, H, D, scale)
+        if first is None:
+            first = got.clone()
+        assert torch.equal(got, first)                    # bitwise reproducible
+        err = (got.float().cpu() - want).abs()
+        assert err.max() <= 6e-3, (float(err.max()), int(err.argmax()))
+
+
+def test_vit_attention_rejects_other_shapes(gpu_device):
+    """Anything but 257 tokens x heads of 88 is VLFM_ERR_INVALID (the caller then uses the library attention)."""
+    from vlfm_amd import _lib
+
+    x = torch.zeros(2 * 257 * 3 * 16 * 96, dtype=torch.float16, device=gpu_device)
+    out = torch.zeros(2 * 257 * 16 * 96, dtype=torch.float16, device=gpu_device)
+    L = _lib.lib()
+    assert L.vlfm_vit_attention_f16(x.data_ptr(), out.data_ptr(), 2, 257, 16, 96, 0.1, None) == _lib.VLFM_ERR_INVALID
+    assert L.vlfm_vit_attention_f16(x.data_ptr(), out.data_ptr(), 2, 256, 16, 88, 0.1, None) == _lib.VLFM_ERR_INVALID
+    assert L.vlfm_vit_attention_f16(x.data_ptr(), out.data_ptr(), 0, 257, 16, 88, 0.1, None) == _lib.VLFM_OK
 
 
 def test_vit_fast_path_full_geometry_vs_plain(gpu_device):

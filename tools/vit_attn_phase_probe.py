@@ -1,12 +1,10 @@
-"""Phase breakdown of vit_attention_kernel (last workgroup, wavefront 0).  Diagnostic build:
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -DVLFM_PHASE_TIMING \
-          -o scratch/libvlfm_amd_phase.so vlfm_amd/csrc/*.hip vlfm_amd/csrc/host.cpp
-    VLFM_LIB_PATH=$PWD/scratch/libvlfm_amd_phase.so python tools/vit_attn_phase_probe.py 128"""
+"""Phase stamps of the persistent vit_attention kernel (workgroup 0, wavefronts 0 and 4, every item they walk).  Builds a diagnostic
+library (-DVLFM_PHASE_TIMING, only vit_attention.hip recompiled) under gpurun_out/ and prints cycles per phase (shader clock)."""
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from vlfm_amd import _lib
-if "VLFM_LIB_PATH" not in os.environ:   # build the diagnostic library here: only vit_attention.hip is recompiled
+if "VLFM_LIB_PATH" not in os.environ:
     _lib.build()
     csrc = os.path.join(ROOT, "vlfm_amd", "csrc")
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
@@ -22,16 +20,20 @@ if "VLFM_LIB_PATH" not in os.environ:   # build the diagnostic library here: onl
 import numpy as np, torch
 from vlfm_amd.vlm import ops
 dev = torch.device("cuda:0")
-names = ["issue K/V loads", "Q loads + LDS writes", "barrier", "QK^T (54 MFMA)", "softmax", "-", "PV (54 MFMA)", "store", "CLS tile", "barrier", "CLS merge"]
-for B in (int(a) for a in (sys.argv[1:] or ["128"])):
+names = ["wait K,Q", "barrier A", "Qread Oout mrg", "odd scores", "QK^T+V dma", "C,softmax+Qdma", "wait V", "barrier B", "odd PV", "PV+K dma", "normalise", "(loop)"]
+for B in (int(a) for a in (sys.argv[1:] or ["256"])):
     qkv = torch.randn(B * 257, 3 * 16 * 88, device=dev, dtype=torch.float16)
-    acc = np.zeros(11); n = 0
-    for _ in range(12):
+    for _ in range(3):
         ops.vit_attention(qkv, B, 257, 16, 88, 88 ** -0.5); torch.cuda.synchronize()
-        buf = np.zeros(16, np.int64)
-        _lib.lib().vlfm_debug_attention_clocks(ctypes.c_void_p(buf.ctypes.data))
-        d = np.diff(buf[:12]) * 0.01
-        d[5] = 0  # stamp 6 unused: phase 5 -> 7 is PV
-        d[6] = (buf[7] - buf[5]) * 0.01
-        if _ >= 2: acc += d; n += 1
-    print(f"B={B}: " + "  ".join(f"{nm}={a / n:.2f}us" for nm, a in zip(names, acc) if nm != "-") + f"   total={acc.sum() / n:.2f}us")
+    buf = np.zeros((2, 20, 12), np.int64)
+    _lib.lib().vlfm_debug_attention_pers_clocks(ctypes.c_void_p(buf.ctypes.data))
+    items = min(20, (B + 7) // 8 * 16 // 32) or 1
+    for w in range(2):
+        print(f"B={B} wavefront {4 * w}: cycles per phase, items 0..{items - 1} (shader clock; 100 cycles ~ 0.045 us)")
+        print("      " + " ".join(f"{nm[:15]:>15s}" for nm in names) + "       total")
+        for n in range(items):
+            s = buf[w, n]
+            nxt = buf[w, n + 1, 0] if n + 1 < items else s[11]
+            d = list(np.diff(s)) + [nxt - s[11]]
+            print(f"  {n:2d}: " + " ".join(f"{int(x):15d}" for x in d) + f"   {int(nxt - s[0]):9d}")
+        print(f"   first stamp -> last stamp: {int(buf[w, items - 1, 11] - buf[w, 0, 0])} cycles")

@@ -1,10 +1,10 @@
-"""vlfm_vit_attention_f16 vs library SDPA at the ViT-g shape (B images, 16 heads, 257 tokens, 96-padded heads)."""
+"""vlfm_vit_attention_f16 vs library SDPA at the ViT-g shape (B images, 16 heads of 88, 257 tokens)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.nn.functional as F
 from vlfm_amd.vlm import ops
 dev = torch.device("cuda:0")
-for B, D in [(int(a), d) for a in (sys.argv[1:] or ["128"]) for d in (96, 88)]:
+for B, D in [(int(a), d) for a in (sys.argv[1:] or ["128"]) for d in (88,)]:
     S, H = 257, 16
     qkv = torch.randn(B * S, 3 * H * D, device=dev, dtype=torch.float16)
     def t(fn, n=30):

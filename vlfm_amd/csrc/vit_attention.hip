@@ -1,28 +1,28 @@
 // vit_attention.hip -- self-attention of the BLIP-2 ViT-g blocks (S = 257 tokens, 16 heads of 88), gfx950.
 //
 // Replaces F.scaled_dot_product_attention in vlfm_amd/vlm/blip2itm.py:_VitBlock (the reference reaches the same maths
-// through LAVIS' eva_vit Attention, vlfm/vlm/blip2itm.py:29-34,52 [ext]).  The library flash kernel spends 290 us per
-// block at 128 images on this shape (257 = 8 x 32 + 1 tokens, head 88); this kernel is specialised for it:
+// through LAVIS' eva_vit Attention, vlfm/vlm/blip2itm.py:29-34,52 [ext]).  The library flash kernel needs the heads padded to 96
+// and a transpose copy on this shape (257 = 8 x 32 + 1 tokens, head 88): 1 050 us per block at 256 images; this kernel is
+// specialised for the shape and reads / writes the GEMMs' own layouts (qkv [B, S, 3, H, 88] in, [B, S, H, 88] out):
 //
-//   * one workgroup per (image, head), 8 wavefronts; the head's whole K (257 x 96) and V^T (96 x 257) live in LDS
-//     (117 KB of the 160 KB), so nothing is re-read and there is no online-softmax rescaling;
-//   * wavefront w owns the 32 queries of tokens 1+32w .. 32+32w.  It computes S^T = K Q^T with
-//     v_mfma_f32_32x32x16_f16 (A = K rows from LDS, B = Q^T held in registers): in the 32x32 accumulator layout every
-//     lane then holds 16 keys of ONE query column per key tile, so the softmax statistics are lane-local apart from one
-//     exchange with lane^32, and the probabilities are ALREADY in B-operand order for O^T = V^T P^T -- no cross-lane
-//     movement between the two GEMMs (the pairing of accumulator registers with key indices is mirrored in the V^T loads);
-//   * the odd token (the CLS query) is a ninth query tile with one live column: its keys are split over the 8
-//     wavefronts (12 MFMAs each), partial (max, sum, O) are merged through LDS by wavefront 0;
-//   * the MFMA-friendly head width 96 exists only in LDS / registers (channels 88..95 are zeros written while staging);
-//     global memory holds the native 88-wide rows, so the qkv and projection GEMMs keep their sizes (DH = 96 serves
-//     weights that were zero-padded instead);
-//   * output goes straight to the [B, S, H, DH] layout the projection GEMM consumes (the library path needs a
-//     transpose copy);
-//   * LDS operand fetches run one contraction step ahead of the MFMAs; key tiles are processed in groups of three so
-//     that consecutive MFMAs write different accumulators.
+//   * a PERSISTENT kernel (round 6): one workgroup of 8 wavefronts per CU walks its (image, head) items; K, V and Q of the next
+//     item travel by LDS-DMA while the current one is in the matrix pipe, output rows leave through LDS as whole rows;
+//   * the head's whole K and V are resident in LDS for the item, so there is no online-softmax rescaling;
+//   * wavefront w owns the 32 queries of tokens 1 + 32 w .. 32 + 32 w.  It computes S^T = K Q^T with v_mfma_f32_32x32x16_f16
+//     (A = K rows from LDS, B = Q^T held in registers): in the 32 x 32 accumulator layout every lane then holds 16 keys of ONE
+//     query column per key tile, so the softmax statistics are lane-local apart from one exchange with lane ^ 32, and the
+//     probabilities are ALREADY in B-operand order for O^T = V^T P^T -- no cross-lane movement between the two GEMMs;
+//   * V stays row-major in LDS (as the DMA delivers it); the A operand of the PV MFMAs comes out of it through
+//     ds_read_b64_tr_b16, the hardware transpose read (semantics pinned by tools/native/tr_read_probe.hip);
+//   * the odd token (the CLS query) runs on the VALU (v_dot2_f32_f16 scores against the wavefront's 32 keys, DPP reductions,
+//     partial (max, sum, O) per wavefront merged by wavefront 0 behind the next barrier) instead of a ninth query tile of MFMAs;
+//   * the MFMA-friendly head width 96 exists only as zeros in the Q registers; global memory and LDS hold the native 88 channels.
 //
-// 4 x 257^2 x 88 flop per (image, head); HBM traffic = qkv read once + output written once (404 MB at 128 images), which
-// is what bounds it: one workgroup per CU (LDS), so staging cannot overlap another workgroup's MFMA phase.
+// 4 x 257^2 x 88 flop and 180 KB of traffic per (image, head): 95 GFLOP and 741 MB at 256 images.  What bounds it is the memory
+// side: the rows of a head are 176-byte pieces at a stride of 8 448 B (in) / 2 816 B (out), which this chip serves at 4.5 TB/s
+// for the reads alone and 3.9 TB/s with the writes (the kernel with everything but its memory traffic compiled out runs 192 us,
+// with the traffic compiled out 115 us, the product 231 us; a head-major qkv layout would read at 5.9 TB/s --
+// profiles/r06_vit_attention_stub_probe.txt).
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -38,314 +38,450 @@ using half4_t = __attribute__((ext_vector_type(4))) _Float16;
 using half8_t = __attribute__((ext_vector_type(8))) _Float16;
 using f32x16_t = __attribute__((ext_vector_type(16))) float;
 
-constexpr int AT_D = 96;                  // padded head width (88 real)
+constexpr int AT_D = 96;                  // head width as the MFMAs see it (88 real channels + zeros in the Q registers)
 constexpr int AT_NT = 8;                  // full 32-token tiles
 constexpr int AT_S = 32 * AT_NT + 1;      // 257 tokens
 constexpr int AT_KT = AT_NT + 1;          // key tiles incl. the one-token tail
-// LDS row strides (halfs).  Both operands are fetched with ds_read_b128, which the LDS serves in four fixed 16-lane
-// groups; the lanes of a group read 16 different rows at the same column, so a row stride of an ODD number of 16-byte
-// slots (13 and 37) puts them on 16 different slots: conflict-free.
-constexpr int AT_KS = AT_D + 8;           // 208 B = 13 slots
-constexpr int AT_VS = 32 * AT_KT + 8;     // 592 B = 37 slots
-constexpr int AT_KROWS = 32 * AT_KT;      // 288 (rows >= 257 are zero)
 constexpr int AT_WAVES = 8;
-constexpr size_t AT_LDS_K = (size_t)AT_KROWS * AT_KS * 2;        // 59 904 B
-constexpr size_t AT_LDS_V = (size_t)AT_D * AT_VS * 2;            // 56 832 B
-constexpr size_t AT_LDS_PART = (size_t)AT_WAVES * (AT_D + 2) * 4;  // partials of the CLS query
-constexpr size_t AT_LDS_QCLS = (size_t)AT_D * 2;                   // the CLS query row
-constexpr size_t AT_LDS_BYTES = AT_LDS_K + AT_LDS_V + AT_LDS_PART + AT_LDS_QCLS;
 
-// Diagnostic builds only (tools/vit_attn_stub_probe.py): -DVLFM_ATT_STUB=1 memory side only (loads, staging, stores of zeros; no
-// attention), 2 no global loads (constants are staged instead), 3 no CLS share, 4 no stores.  Undefined (0) in the product.
-#ifndef VLFM_ATT_STUB
-#define VLFM_ATT_STUB 0
+// One workgroup per CU walks its (image, head) items.  Every byte enters and leaves through LDS in
+// whole 176-byte rows: K, V and Q arrive by LDS-DMA (global_load_lds, no registers) while the previous item is in the matrix pipe,
+// the output rows are staged in LDS and leave as 16 bytes per lane.  (The first persistent form loaded the Q fragments and stored the
+// output straight in MFMA operand layout: 32 cache lines per instruction -- those 12 instructions per wavefront took longer to
+// issue than the 14 DMA pieces that move twice the bytes, and the memory side alone ran 211 us at 256 images; 139 with the stores
+// staged, profiles/r06_vit_attention_stub_probe.txt.)  The odd (CLS) query runs on the VALU instead of a ninth MFMA tile; V stays
+// row-major in LDS and is transposed by ds_read_b64_tr_b16 on the way to the PV MFMAs.
+// LDS (bytes):  buffer 0 | buffer 1 | V | partials of the odd query x 2 | its probabilities.  Item n (kb = n & 1):
+//   buffer kb      K_n (257 rows x 176 B, the native 88 channels, no padding; a row stride of 11 sixteen-byte slots is odd, so the 16
+//                  lanes of a ds_read_b128 group hit 16 different slots) -> behind barrier B: Q_{n+1} (same image; row 0 is the odd query)
+//   buffer 1 - kb  Q_n -> read into registers behind barrier A, then the wavefront's rows are overwritten with O_{n-1} (f16) and
+//                  leave during the softmax -> behind barrier B: K_{n+1}
+//   V              288 rows x 192 B.  Channels 88..95 and rows 257.. hold finite junk (duplicates written by run-over lanes): junk
+//                  channels only reach rows 88..95 of O^T, which are never stored; junk rows meet P = 0.
+// The sixth contraction step of QK^T reads 16 B past a K row (channels 88..95 = the next row's first 8): they meet zeros in the Q
+// registers, and LDS is zeroed once at kernel start so that such bytes are always finite.  Rows 257..287 of the ninth key tile
+// are whatever follows the buffer: their scores are replaced by -inf (a select, not arithmetic).
+// DMA pieces: one wavefront instruction moves 64 x 16 B to 1 KB of consecutive LDS.  K = 2 827 slots as 48 pieces at a pitch of 59,
+// V = 3 084 slots (12 per row, the 12th a duplicate of the 11th) as 56 pieces at a pitch of 56, Q = the wavefront's own 33 rows as 6
+// pieces: every wavefront issues exactly 7 (V, between the MFMAs of QK^T) + 6 + 6 (K, Q of the next item, between the MFMAs of PV)
+// pieces per item; overlapping lanes rewrite identical bytes.  vmcnt is waited by COUNT (gfx9 retires vector memory operations in
+// issue order): the six row stores of the previous item stay in flight across barrier B.
+constexpr int PA_KROW = 176, PA_VROW = 192;
+constexpr int PA_KB = 45440;                          // one K / Q / O buffer incl. the run-over of the last DMA piece
+constexpr int PA_V_OFF = 2 * PA_KB;                   // 90 880
+constexpr int PA_V_BYTES = 288 * PA_VROW;             // 55 296
+constexpr int PA_PART_OFF = PA_V_OFF + PA_V_BYTES;    // 146 176
+constexpr int PA_PART = 100;                          // floats per wavefront: O (96) + max + sum + p of key 256; two sets (item parity)
+constexpr int PA_PS_OFF = PA_PART_OFF + 2 * AT_WAVES * PA_PART * 4;   // 152 576: the odd query's 256 probabilities (f32)
+constexpr int PA_LDS = PA_PS_OFF + AT_WAVES * 32 * 4;                 // 153 600
+constexpr int PA_KPIECES = 6, PA_VPIECES = 7, PA_QPIECES = 6, PA_KPITCH = 59, PA_VPITCH = 56;
+constexpr int PA_KSLOTS = AT_S * 11, PA_VSLOTS = AT_S * 12;
+
+using lds_ptr = __attribute__((address_space(3))) unsigned char*;
+using gbl_ptr = const __attribute__((address_space(1))) unsigned char*;
+typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
+typedef short short8v __attribute__((__vector_size__(8 * sizeof(short))));
+using half2_t = __attribute__((ext_vector_type(2))) _Float16;
+
+#define PA_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))   /* vmcnt(n), n < 64 */
+#define PA_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
+#define PA_BARRIER()                               \
+    do {                                           \
+        asm volatile("" ::: "memory");             \
+        __builtin_amdgcn_s_barrier();              \
+        asm volatile("" ::: "memory");             \
+    } while (0)
+
+// reductions over the 16 lanes of a DPP row (quad swaps, then the two mirrors): every lane ends with the row's result
+#define PA_DPP(x, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xF, 0xF, true))
+__device__ inline float row16_max(float x) {
+    x = fmaxf(x, PA_DPP(x, 0xB1));     // quad_perm [1,0,3,2]
+    x = fmaxf(x, PA_DPP(x, 0x4E));     // quad_perm [2,3,0,1]
+    x = fmaxf(x, PA_DPP(x, 0x141));    // row_half_mirror
+    return fmaxf(x, PA_DPP(x, 0x140)); // row_mirror
+}
+__device__ inline float row16_sum(float x) {
+    x += PA_DPP(x, 0xB1);
+    x += PA_DPP(x, 0x4E);
+    x += PA_DPP(x, 0x141);
+    return x + PA_DPP(x, 0x140);
+}
+
+__device__ inline half8_t tr_pair(const unsigned char* p0, const unsigned char* p1) {
+    const short4v a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(lds_ptr)p0);
+    const short4v b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(lds_ptr)p1);
+    const short8v ab = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(half8_t, ab);
+}
+
+#ifndef PA_NO_STORES
+#define PA_NO_STORES 0   // diagnostic: the product without the row stores
 #endif
-
-// Optional phase timing (diagnostic build with -DVLFM_PHASE_TIMING; tools/vit_attn_phase_probe.py): lane 0 of wavefront 0
-// of the LAST workgroup stamps the 100 MHz wall clock at phase boundaries.
+#ifndef PA_STUB
+#define PA_STUB 0      // diagnostic builds (tools/vit_attn_stub_probe.py): 1 no MFMAs, 2 + no softmax, 3 + no odd-query passes, 4 + no sleeps
+#endif                 // (memory traffic and barriers only), 5 + no stores; 6 = the product without any vector memory operation
+// Optional stamps (diagnostic build -DVLFM_PHASE_TIMING, tools/vit_attn_phase_probe.py): wavefronts 0 and 4 of workgroup 0 record the
+// shader clock at the phase boundaries of every item they walk.
 #ifdef VLFM_PHASE_TIMING
-__device__ long long g_att_clk[16];
-#define AT_PHASE(k)                                                                              \
-    do {                                                                                         \
-        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) g_att_clk[k] = wall_clock64();      \
+__device__ long long g_pa_clk[2][20][12];
+#define PA_STAMP(k)                                                                                              \
+    do {                                                                                                         \
+        if (blockIdx.x == 0 && (tid & 255) == 0 && n < 20) g_pa_clk[tid >> 8][n][k] = __builtin_readcyclecounter(); \
     } while (0)
 #else
-#define AT_PHASE(k) do {} while (0)
+#define PA_STAMP(k) do {} while (0)
 #endif
 
-// Column of token ``key`` in a V^T row.  Accumulator register r of a 32x32 MFMA tile holds row (r & 3) + 8 (r >> 2) +
-// 4 (lane >> 5): the 8 probabilities a lane feeds to one PV MFMA belong to keys {4g..4g+3, 8+4g..8+4g+3} of a 16-key
-// chunk (g = lane >> 5).  V^T is stored with exactly those 8 keys adjacent, so the matching A operand is ONE 16-byte read.
-__device__ inline int vt_col(int key) {
-    const int e = key & 15;
-    return (key & ~15) + 8 * ((e >> 2) & 1) + 4 * (e >> 3) + (e & 3);
-}
-
-// Attention of the 32 query columns in ``qf`` against key tiles kt0 .. kt0+KT-1.  Returns the UNNORMALISED O^T
-// accumulators (3 tiles of 32 head channels), the column maximum of the raw scores and the column sum of
-// exp2((s - max) * c), all per lane for query column lane&31 (combined over both lane halves).
-template <int KT>
-__device__ inline void attend(const _Float16* __restrict__ Kl, const _Float16* __restrict__ Vl, const half8_t (&qf)[AT_D / 16],
-                              int kt0, float c, f32x16_t (&o)[AT_D / 32], float& m_out, float& l_out) {
-    const int lane = threadIdx.x & 63, col = lane & 31, grp = lane >> 5;
-    f32x16_t acc[KT];
-#pragma unroll
-    for (int t = 0; t < KT; t++) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
-    }
-    // S^T = K Q^T.  Key tiles are taken in groups of (up to) 3 with the contraction step as the outer loop: consecutive
-    // MFMAs then write DIFFERENT accumulators (a dependent MFMA is three issue slots away), and the K operands of step
-    // kk + 1 are fetched from LDS while step kk is in the matrix pipe.
-    constexpr int G = KT >= 3 ? 3 : KT;
-    static_assert(KT % G == 0, "key tiles come in whole groups");
-    const _Float16* kbase = Kl + (size_t)(32 * kt0 + col) * AT_KS + 8 * grp;
-#pragma unroll
-    for (int g0 = 0; g0 < KT; g0 += G) {
-        half8_t a_cur[G], a_nxt[G];
-#pragma unroll
-        for (int t = 0; t < G; t++) a_cur[t] = *reinterpret_cast<const half8_t*>(kbase + (size_t)(32 * (g0 + t)) * AT_KS);
-#pragma unroll
-        for (int kk = 0; kk < AT_D / 16; kk++) {
-            if (kk + 1 < AT_D / 16) {
-#pragma unroll
-                for (int t = 0; t < G; t++)
-                    a_nxt[t] = *reinterpret_cast<const half8_t*>(kbase + (size_t)(32 * (g0 + t)) * AT_KS + 16 * (kk + 1));
-            }
-#pragma unroll
-            for (int t = 0; t < G; t++)
-                acc[g0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[t], qf[kk], acc[g0 + t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < G; t++) a_cur[t] = a_nxt[t];
-        }
-    }
-    if (KT == AT_KT) AT_PHASE(4);
-    // accumulator register r of tile t holds key 32 (kt0 + t) + (r & 3) + 8 (r >> 2) + 4 grp of query column ``col``
-    float m = -__builtin_huge_valf();
-#pragma unroll
-    for (int t = 0; t < KT; t++) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int key = 32 * (kt0 + t) + (r & 3) + 8 * (r >> 2) + 4 * grp;
-            if (key >= AT_S) acc[t][r] = -__builtin_huge_valf();
-            m = fmaxf(m, acc[t][r]);
-        }
-    }
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float l = 0.0f;
-    const float mc = -m * c;
-#pragma unroll
-    for (int t = 0; t < KT; t++) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const float p = __builtin_amdgcn_exp2f(fmaf(acc[t][r], c, mc));   // v_exp_f32: argument <= 0, denormals may flush
-            l += p;
-            acc[t][r] = p;
-        }
-    }
-    l += __shfl_xor(l, 32, 64);
-    if (KT == AT_KT) AT_PHASE(5);
-#pragma unroll
-    for (int dt = 0; dt < AT_D / 32; dt++) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) o[dt][r] = 0.0f;
-    }
-    // O^T = V^T P^T: three channel tiles per 16-key chunk (independent accumulators), the next chunk's V^T operands in flight
-    const _Float16* vbase = Vl + (size_t)col * AT_VS + 32 * kt0 + 8 * grp;
-    half8_t v_cur[AT_D / 32], v_nxt[AT_D / 32];
-#pragma unroll
-    for (int dt = 0; dt < AT_D / 32; dt++) v_cur[dt] = *reinterpret_cast<const half8_t*>(vbase + (size_t)(32 * dt) * AT_VS);
-#pragma unroll
-    for (int ch = 0; ch < 2 * KT; ch++) {       // chunk ch = 16 keys: tile ch / 2, half ch & 1
-        if (ch + 1 < 2 * KT) {
-#pragma unroll
-            for (int dt = 0; dt < AT_D / 32; dt++)
-                v_nxt[dt] = *reinterpret_cast<const half8_t*>(vbase + (size_t)(32 * dt) * AT_VS + 16 * (ch + 1));
-        }
-        half8_t pb;
-        // keys behind pb[0..3]: 16 ch + 4 grp + (0..3); behind pb[4..7]: the same + 8 -- the order vt_col() stores
-#pragma unroll
-        for (int j = 0; j < 8; j++) pb[j] = (_Float16)acc[ch >> 1][8 * (ch & 1) + j];
-#pragma unroll
-        for (int dt = 0; dt < AT_D / 32; dt++) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_cur[dt], pb, o[dt], 0, 0, 0);
-#pragma unroll
-        for (int dt = 0; dt < AT_D / 32; dt++) v_cur[dt] = v_nxt[dt];
-    }
-    m_out = m;
-    l_out = l;
-}
-
-// DH = head width as stored in global memory: 96 (heads zero-padded inside the qkv / projection weights) or 88 (ViT-g's
-// native width: the missing 8 channels are zeros that exist only in LDS / registers, so the GEMMs on either side
-// keep their original sizes).
-template <int DH>
 __global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _Float16* __restrict__ qkv,
-                                                                         _Float16* __restrict__ out, int B, int H,
-                                                                         float scale, int stagger) {
+                                                                              _Float16* __restrict__ out, int B, int H,
+                                                                              float scale) {
+    constexpr int DH = 88;
     extern __shared__ __attribute__((aligned(16))) unsigned char at_lds[];
-    _Float16* Kl = reinterpret_cast<_Float16*>(at_lds);
-    _Float16* Vl = reinterpret_cast<_Float16*>(at_lds + AT_LDS_K);
-    float* part = reinterpret_cast<float*>(at_lds + AT_LDS_K + AT_LDS_V);
-    _Float16* qcls = reinterpret_cast<_Float16*>(at_lds + AT_LDS_K + AT_LDS_V + AT_LDS_PART);
-    // XCD-aware placement: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2).  A head's K / V
-    // rows are 192-byte pieces of 9 KB token rows, so neighbouring heads share cache lines: all 16 heads of an image are
-    // given to ONE XCD, back to back, and each line is fetched from HBM once instead of once per XCD that touches it.
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int b = xcd + 8 * (slot / H), h = slot % H;
-    if (b >= B) return;
-    const int tid = threadIdx.x, nth = blockDim.x;
-    AT_PHASE(0);
-    const int lane = tid & 63, wave = tid >> 6, col = lane & 31, grp = lane >> 5;
-    static_assert(DH % 8 == 0 && DH <= AT_D, "head width in whole 16-byte chunks");
-    const size_t row_halfs = (size_t)3 * H * DH;                         // one token of qkv: [3][H][DH]
-    const _Float16* base = qkv + (size_t)b * AT_S * row_halfs + (size_t)h * DH;
-    // ---- stage K (row-major) and V^T into LDS; padding rows / columns are zero
-    for (int i = tid; i < (AT_KROWS - AT_S) * AT_KS; i += nth) Kl[(size_t)AT_S * AT_KS + i] = (_Float16)0.0f;
-    for (int i = tid; i < AT_D * (AT_KROWS - AT_S); i += nth) {   // keys 257 .. 287 of every V^T row
-        const int d = i / (AT_KROWS - AT_S), k = AT_S + i % (AT_KROWS - AT_S);
-        Vl[(size_t)d * AT_VS + vt_col(k)] = (_Float16)0.0f;
-    }
-    // All global loads of the staging phase are issued before the first LDS write (one exposure to HBM latency, not
-    // one per iteration); a work item is (token pair, 8-channel chunk) so that V^T is written two tokens (4 bytes) at
-    // a time -- vt_col() keeps an even token and its successor adjacent.
-    constexpr int kPairs = (AT_S + 1) / 2, kItems = kPairs * (AT_D / 8), kIters = (kItems + 64 * AT_WAVES - 1) / (64 * AT_WAVES);
-    half8_t kreg[kIters][2], vreg[kIters][2];
+    const lds_ptr lds = (lds_ptr)at_lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), col = lane & 31, grp = lane >> 5;
+    // the 16 heads of an image go to ONE XCD back to back (their K / V rows share cache lines): workgroup id -> (XCD, lane j of
+    // the XCD); the XCD's items are (image x + 8 i, head) in head-fastest order, lane j takes items j, j + per, ...
+    const int xcd = blockIdx.x & 7, per = gridDim.x >> 3;
+    int t = blockIdx.x >> 3;
+    const int nimg = B > xcd ? (B - xcd + 7) >> 3 : 0;      // images of this XCD: xcd, xcd + 8, ...
+    if (t / H >= nimg) return;
+    auto image_of = [&](int tt) { return xcd + 8 * (tt / H); };
+#ifdef PA_HEAD_MAJOR   // timing experiment only: qkv read as [B][H][3][S][88] (every K / V / Q block contiguous)
+    const int row_halfs = 3 * H * DH, row_bytes = 2 * DH, part_bytes = AT_S * 2 * DH;
+#else
+    const int row_halfs = 3 * H * DH, row_bytes = 2 * row_halfs, part_bytes = 2 * H * DH;
+#endif
+    // ---- zero the whole LDS once (over-read bytes must be finite)
+    for (int i = tid; i < PA_LDS / 16; i += 64 * AT_WAVES) *reinterpret_cast<uint4*>(at_lds + 16 * i) = uint4{0, 0, 0, 0};
+    PA_WAIT_LGKM0();
+    PA_BARRIER();
+    auto item_base = [&](int tt) {
+        const int b = image_of(tt), h = tt % H;
+#ifdef PA_HEAD_MAJOR
+        return reinterpret_cast<const unsigned char*>(qkv) + (size_t)(b * H + h) * 3 * AT_S * DH * 2;
+#else
+        return reinterpret_cast<const unsigned char*>(qkv) + ((size_t)b * AT_S * row_halfs + (size_t)h * DH) * 2;
+#endif
+    };
+    // LDS-DMA pieces go through inline asm: hipcc books a global_load_lds builtin as a FLAT operation that touches both memories and,
+    // while one is pending, turns every LDS or vector-memory dependency into a wait for ZERO (the operand prefetch of the MFMA loops
+    // would wait for the pieces just issued).  Hidden from its scoreboard, the pieces are waited by count below; M0 (the
+    // destination) is saved and restored around each piece.  The lane index is made opaque per call, so the per-lane source
+    // offsets are recomputed (a few VALU per piece) instead of being hoisted into 19 registers the main pass has no room for.
+    // A vector-memory instruction blocks its wavefront at ISSUE while the CU's queue is full -- 104 KB issued back to back cost 6 000
+    // cycles during which nothing else ran -- so the pieces are spread between the MFMAs at about the rate HBM drains them.
+    auto dma16 = [&](const unsigned char* sbase, uint32_t voff, int dst) {
+        if (PA_STUB == 6) return;
+        unsigned keep;
+        const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(lds + dst));
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(m0v), "s"(sbase) : "memory");
+    };
+    auto k_piece = [&](const unsigned char* base, int bo, int j) {
+        int lane = threadIdx.x & 63;
+        asm volatile("" : "+v"(lane));
+        const int p = wave + AT_WAVES * j;
+        const int sg = min(PA_KPITCH * p + lane, PA_KSLOTS - 1), row = sg / 11, s = sg - 11 * row;
+        dma16(base + part_bytes, (uint32_t)(row * row_bytes + 16 * s), bo + 16 * PA_KPITCH * p);
+    };
+    auto v_piece = [&](const unsigned char* base, int j) {
+        int lane = threadIdx.x & 63;
+        asm volatile("" : "+v"(lane));
+        const int p = wave + AT_WAVES * j;
+        const int sg = PA_VPITCH * p + lane, row = min(sg / 12, AT_S - 1), s = min(sg % 12, 10);
+        dma16(base + 2 * part_bytes, (uint32_t)(row * row_bytes + 16 * s), PA_V_OFF + 16 * PA_VPITCH * p);
+    };
+    // Q: rows 32 wave .. 32 wave + 33 of the [257][88] image (the wavefront's 32 queries are rows 1 + 32 wave ..; wavefront 0 brings the
+    // odd query's row 0 with it); the run-over lanes fetch the neighbour's rows (identical bytes), none past the image
+    auto q_piece = [&](const unsigned char* base, int bo, int j) {
+        int lane = threadIdx.x & 63;
+        asm volatile("" : "+v"(lane));
+        const int sg = 32 * 11 * wave + 64 * j + lane, row = sg / 11, s = sg - 11 * row;
+        if (sg < PA_KSLOTS) dma16(base, (uint32_t)(row * row_bytes + 16 * s), bo + 16 * (32 * 11 * wave + 64 * j));
+    };
+    // store-out of the staged rows of item tt (buffer offset bo): instruction i = slots 64 i .. of the wavefront's 352 (32 rows x 11)
+    auto store_out = [&](int tt, int bo, int i) {
+        int lane = threadIdx.x & 63;
+        asm volatile("" : "+v"(lane));
+        const int sg = 64 * i + lane, row = sg / 11, s = sg - 11 * row;
+        if (PA_STUB < 5 && !PA_NO_STORES && sg < 352) {
+            const int b = image_of(tt), h = tt % H;
+            const uint4 v = *reinterpret_cast<const uint4*>(at_lds + bo + (1 + 32 * wave) * PA_KROW + 16 * sg);
+            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(out) + ((size_t)(b * AT_S + 1 + 32 * wave + row) * H + h) * (2 * DH) + 16 * s) = v;
+        }
+    };
+    const unsigned char* base = item_base(t);
 #pragma unroll
-    for (int it = 0; it < kIters; it++) {
-        const int i = tid + it * 64 * AT_WAVES;
-        const int s0 = 2 * (i / (AT_D / 8)), ch = i % (AT_D / 8);
+    for (int j = 0; j < PA_KPIECES; j++) k_piece(base, 0, j);
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int s = s0 + u;
-            if (VLFM_ATT_STUB != 2 && i < kItems && s < AT_S && ch < DH / 8) {
-                const _Float16* src = base + (size_t)s * row_halfs + (size_t)H * DH + 8 * ch;
-                kreg[it][u] = *reinterpret_cast<const half8_t*>(src);                      // K
-                vreg[it][u] = *reinterpret_cast<const half8_t*>(src + (size_t)H * DH);     // V
-            } else {   // token 257 of the last pair, and channels DH .. 95: zeros
+    for (int j = 0; j < PA_QPIECES; j++) q_piece(base, PA_KB, j);
+    const float c = scale * 1.4426950408889634f;
+    // merge of the odd query's partials (wavefront 0): written during an item (set = item parity), read behind barrier A of the next
+    auto merge_odd = [&](int tt, int set) {
+        if (wave == 0) {
+            const float* part = reinterpret_cast<const float*>(at_lds + PA_PART_OFF) + set * AT_WAVES * PA_PART;
+            float mx = -__builtin_huge_valf();
 #pragma unroll
-                for (int j = 0; j < 8; j++) { kreg[it][u][j] = (_Float16)0.0f; vreg[it][u][j] = (_Float16)0.0f; }
+            for (int w = 0; w < AT_WAVES; w++) mx = fmaxf(mx, part[w * PA_PART + 96]);
+            float o0 = 0.0f, o1 = 0.0f, lsum = 0.0f;
+            const int cp = min(lane, 47);
+#pragma unroll
+            for (int w = 0; w < AT_WAVES; w++) {
+                const float wgt = __builtin_amdgcn_exp2f((part[w * PA_PART + 96] - mx) * c);
+                lsum = fmaf(wgt, part[w * PA_PART + 97], lsum);
+                const float2 ov = *reinterpret_cast<const float2*>(part + w * PA_PART + 2 * cp);
+                o0 = fmaf(wgt, ov.x, o0);
+                o1 = fmaf(wgt, ov.y, o1);
+            }
+            const float inv = 1.0f / lsum;
+            const int b = image_of(tt), h = tt % H;
+            if (PA_STUB < 5 && lane < DH / 2)
+                *reinterpret_cast<half2_t*>(out + ((size_t)(b * AT_S) * H + h) * DH + 2 * lane) = half2_t{(_Float16)(o0 * inv), (_Float16)(o1 * inv)};
+        }
+    };
+    half4_t of[11];          // the wavefront's 32 output rows of the previous item (f16, accumulator layout) until they are staged
+    // rows of the accumulator layout -> LDS: lane (col, grp) holds channels 32 dt + 8 q4 + 4 grp .. + 3 of row col
+    auto stage_rows = [&](int bo) {
+        unsigned char* st = at_lds + bo + (1 + 32 * wave + col) * PA_KROW + 8 * grp;
+#pragma unroll
+        for (int i = 0; i < 11; i++) *reinterpret_cast<half4_t*>(st + 16 * i) = of[i];
+    };
+    int n = 0, t_prev = -1;
+    for (;;) {
+        const int tn = t + per;
+        const bool has_next = tn / H < nimg;
+        const unsigned char* base_n = has_next ? item_base(tn) : base;
+        const int kb = (n & 1) * PA_KB, ob = PA_KB - kb;
+        PA_STAMP(0);
+        // ---- A: K and Q of this item are in LDS (this wavefront's pieces: the last vector-memory operations of the previous item)
+        PA_WAIT_VM(0);
+        PA_STAMP(1);
+        PA_BARRIER();
+        PA_STAMP(2);
+        // the B operand (Q^T) of the wavefront's 32 queries: lane (col, grp) = channels 16 kk + 8 grp .. of row 1 + 32 wave + col;
+        // channels 88..95 (kk = 5, upper half) read 16 B of the next row: zeroed
+        half8_t qf[AT_D / 16];
+        {
+            const unsigned char* qr = at_lds + ob + (1 + 32 * wave + col) * PA_KROW + 16 * grp;
+#pragma unroll
+            for (int kk = 0; kk < AT_D / 16; kk++) qf[kk] = *reinterpret_cast<const half8_t*>(qr + 32 * kk);
+            if (grp) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) qf[AT_D / 16 - 1][j] = (_Float16)0.0f;
             }
         }
-    }
-    AT_PHASE(1);
-    // the Q fragments of this wavefront's 32 queries travel while K / V are being staged
-    const int tq = 1 + 32 * wave + col;
-    half8_t qmain[AT_D / 16];
-#pragma unroll
-    for (int kk = 0; kk < AT_D / 16; kk++) {
-        if (VLFM_ATT_STUB != 2 && 2 * kk + grp < DH / 8) {
-            qmain[kk] = *reinterpret_cast<const half8_t*>(base + (size_t)tq * row_halfs + 8 * grp + 16 * kk);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; j++) qmain[kk][j] = (_Float16)0.0f;
+        if (n > 0) {       // ... and the same rows take the previous item's output (this wavefront's LDS operations retire in order), which
+            stage_rows(ob);                                                   // leaves at once as whole rows: nothing else is in the
+#pragma unroll                                                                // memory queue right behind barrier A
+            for (int i = 0; i < 6; i++) store_out(t_prev, ob, i);
         }
-    }
-    if (tid < AT_D / 8) {
-        half8_t qv;
+        if (PA_STUB < 3 && t_prev >= 0) merge_odd(t_prev, (n + 1) & 1);
+        PA_STAMP(3);
+        // ---- the odd query (row 0 of the Q image) against keys 32 wave .. 32 wave + 31 (+ key 256 in wavefront 7) on the VALU, ahead of
+        // the MFMAs in program order so that its reductions run in their shadow: lane (col, grp) takes channels 48 grp .. of key
+        // 32 wave + col (the upper half has 40: its 6th slot is masked)
+        float* mine = reinterpret_cast<float*>(at_lds + PA_PART_OFF) + ((n & 1) * AT_WAVES + wave) * PA_PART;
+        if (PA_STUB < 3) {
+            float ps, p2 = 0.0f;
+            const unsigned char* q0 = at_lds + ob + 96 * grp;
+            const unsigned char* kr = at_lds + kb + (32 * wave + col) * PA_KROW + 96 * grp;
+            const unsigned char* kl = at_lds + kb + 256 * PA_KROW + 96 * grp;
+            float s = 0.0f, s2 = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 8; j++) qv[j] = (_Float16)0.0f;
-        if (tid < DH / 8) qv = *reinterpret_cast<const half8_t*>(base + 8 * tid);
-        *reinterpret_cast<half8_t*>(qcls + 8 * tid) = qv;
-    }
+            for (int i = 0; i < 6; i++) {
+                half8_t qv = *reinterpret_cast<const half8_t*>(q0 + 16 * i);
+                if (i == 5 && grp) {
 #pragma unroll
-    for (int it = 0; it < kIters; it++) {
-        const int i = tid + it * 64 * AT_WAVES;
-        const int s0 = 2 * (i / (AT_D / 8)), ch = i % (AT_D / 8);
-        if (i < kItems) {
-            *reinterpret_cast<half8_t*>(Kl + (size_t)s0 * AT_KS + 8 * ch) = kreg[it][0];
-            if (s0 + 1 < AT_S) *reinterpret_cast<half8_t*>(Kl + (size_t)(s0 + 1) * AT_KS + 8 * ch) = kreg[it][1];
-            const int vc = vt_col(s0);   // s0 is even: vt_col(s0 + 1) == vc + 1 (token 257 does not exist: zero)
-            using half2_t = __attribute__((ext_vector_type(2))) _Float16;
+                    for (int j = 0; j < 8; j++) qv[j] = (_Float16)0.0f;
+                }
+                const half8_t kv = *reinterpret_cast<const half8_t*>(kr + 16 * i);
 #pragma unroll
-            for (int j = 0; j < 8; j++)
-                *reinterpret_cast<half2_t*>(Vl + (size_t)(8 * ch + j) * AT_VS + vc) = half2_t{vreg[it][0][j], vreg[it][1][j]};
+                for (int e = 0; e < 4; e++) s = __builtin_amdgcn_fdot2(half2_t{qv[2 * e], qv[2 * e + 1]}, half2_t{kv[2 * e], kv[2 * e + 1]}, s, false);
+                if (wave == AT_WAVES - 1) {
+                    const half8_t k2 = *reinterpret_cast<const half8_t*>(kl + 16 * i);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) s2 = __builtin_amdgcn_fdot2(half2_t{qv[2 * e], qv[2 * e + 1]}, half2_t{k2[2 * e], k2[2 * e + 1]}, s2, false);
+                }
+            }
+            s += __shfl_xor(s, 32, 64);
+            float m = row16_max(s);
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            if (wave == AT_WAVES - 1) {
+                s2 += __shfl_xor(s2, 32, 64);
+                m = fmaxf(m, s2);
+                p2 = __builtin_amdgcn_exp2f((s2 - m) * c);
+            }
+            ps = __builtin_amdgcn_exp2f((s - m) * c);
+            float l = row16_sum(ps);
+            l += __shfl_xor(l, 16, 64);
+            if (grp == 0) reinterpret_cast<float*>(at_lds + PA_PS_OFF)[32 * wave + col] = ps;    // read back (broadcast) by the odd query's P V
+            if (lane == 0) { mine[96] = m; mine[97] = l + p2; mine[98] = p2; }
         }
-    }
-    AT_PHASE(2);
-    __syncthreads();
-    AT_PHASE(3);
-    const float c = scale * 1.4426950408889634f;   // exp(x * scale) = exp2(x * c)
-    // ---- the CLS query (token 0): column 0 of a ninth query tile; its keys are split over the wavefronts (tile w for
-    // wavefront w, tiles 7 and 8 for the last), partial (max, sum, O) go to LDS and are merged below
-    auto cls_part = [&]() {
-        half8_t qf[AT_D / 16];
+        PA_STAMP(4);
+        // ---- S^T = K Q^T for the wavefront's 32 queries: 9 key tiles x 6 contraction steps; the 7 V pieces of this item in between
+        f32x16_t acc[AT_KT];
 #pragma unroll
-        for (int kk = 0; kk < AT_D / 16; kk++) {
-            half8_t z;
+        for (int tt = 0; tt < AT_KT; tt++)
 #pragma unroll
-            for (int j = 0; j < 8; j++) z[j] = (_Float16)0.0f;
-            qf[kk] = col == 0 ? *reinterpret_cast<const half8_t*>(qcls + 8 * grp + 16 * kk) : z;
+            for (int r = 0; r < 16; r++) acc[tt][r] = 0.0f;
+        {
+            const unsigned char* kbase = at_lds + kb + col * PA_KROW + 16 * grp;
+#pragma unroll
+            for (int g0 = 0; g0 < AT_KT; g0 += 3) {
+                half8_t a_cur[3], a_nxt[3];
+#pragma unroll
+                for (int u = 0; u < 3; u++) a_cur[u] = *reinterpret_cast<const half8_t*>(kbase + 32 * (g0 + u) * PA_KROW);
+#pragma unroll
+                for (int kk = 0; kk < AT_D / 16; kk++) {
+                    if (kk + 1 < AT_D / 16) {
+#pragma unroll
+                        for (int u = 0; u < 3; u++) a_nxt[u] = *reinterpret_cast<const half8_t*>(kbase + 32 * (g0 + u) * PA_KROW + 32 * (kk + 1));
+                    }
+#if PA_STUB == 0 || PA_STUB == 6
+#pragma unroll
+                    for (int u = 0; u < 3; u++) acc[g0 + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[u], qf[kk], acc[g0 + u], 0, 0, 0);
+#else
+                    if (g0 == 0 && kk == 0) acc[0][0] = (float)qf[0][0] + (float)qf[1][0] + (float)qf[2][0] + (float)qf[3][0] + (float)qf[4][0] + (float)qf[5][0];
+                    if (PA_STUB < 4) __builtin_amdgcn_s_sleep(4);
+#endif
+#pragma unroll
+                    for (int u = 0; u < 3; u++) a_cur[u] = a_nxt[u];
+                    const int step = 2 * g0 + kk;          // 0 .. 17
+                    if (step >= 1 && step <= 13 && (step & 1)) v_piece(base, step >> 1);     // 7 pieces at steps 1, 3, .., 13
+                }
+            }
         }
+        PA_STAMP(5);
+        // ---- C: every wavefront is done with K (and with the odd query's row, and has read its staged rows out of the other buffer)
+        PA_BARRIER();
+        // ---- softmax of the 32 main queries: accumulator register r of tile tt = key 32 tt + (r & 3) + 8 (r >> 2) + 4 grp
+        float m = -__builtin_huge_valf();
+#pragma unroll
+        for (int tt = 0; tt < (PA_STUB >= 2 && PA_STUB < 6 ? 1 : AT_KT); tt++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                if (32 * tt + (r & 3) + 8 * (r >> 2) + 4 * grp >= AT_S) acc[tt][r] = -__builtin_huge_valf();
+                m = fmaxf(m, acc[tt][r]);
+            }
+        }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.0f;
+        const float mc = -m * c;
+        // probabilities go to f16 at once (the B operands of the PV MFMAs: chunk ch = 16 keys = registers 8 (ch & 1) .. + 7 of tile
+        // ch >> 1): 72 registers instead of 144; the previous item's rows leave LDS in between (6 x 16 B per lane)
+        constexpr int NCH = 2 * AT_KT - 1;      // 17 chunks of 16 keys: keys 272.. do not exist
+        half8_t pb[NCH];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
+            if (PA_STUB < 2 || PA_STUB == 6 || ch == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(acc[ch >> 1][8 * (ch & 1) + j], c, mc));
+                    l += p;
+                    pb[ch][j] = (_Float16)p;
+                }
+            } else {
+                pb[ch] = pb[0];
+            }
+            if (has_next && ch % 3 == 1) q_piece(base_n, kb, ch / 3);       // the 6 Q pieces of the next item -> this item's K buffer
+        }
+        l += __shfl_xor(l, 32, 64);
+        // ---- B: V of this item is in LDS (this wavefront's pieces: older than the 6 Q pieces)
+        PA_STAMP(6);
+        if (has_next) PA_WAIT_VM(6);
+        else PA_WAIT_VM(0);
+        PA_WAIT_LGKM0();
+        PA_STAMP(7);
+        PA_BARRIER();
+        PA_STAMP(8);
+        // ---- the odd query's share of P V (ahead of the MFMAs in program order): lane = channel pair, its 32 probabilities are read
+        // back from LDS (one address per instruction: a broadcast)
+        if (PA_STUB < 3 || PA_STUB == 6) {
+            const int cp = min(lane, 47);
+            const unsigned char* vr = at_lds + PA_V_OFF + (32 * wave) * PA_VROW + 4 * cp;
+            const float* pr = reinterpret_cast<const float*>(at_lds + PA_PS_OFF) + 32 * wave;
+            float o0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, o1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < 32; k++) {
+                const float pk = pr[k];
+                const half2_t vv = *reinterpret_cast<const half2_t*>(vr + k * PA_VROW);
+                o0[k & 3] = fmaf(pk, (float)vv[0], o0[k & 3]);
+                o1[k & 3] = fmaf(pk, (float)vv[1], o1[k & 3]);
+            }
+            if (wave == AT_WAVES - 1) {
+                const half2_t vv = *reinterpret_cast<const half2_t*>(at_lds + PA_V_OFF + 256 * PA_VROW + 4 * cp);
+                const float p2 = mine[98];
+                o0[0] = fmaf(p2, (float)vv[0], o0[0]);
+                o1[0] = fmaf(p2, (float)vv[1], o1[0]);
+            }
+            if (lane < 48) *reinterpret_cast<float2*>(mine + 2 * lane) = float2{(o0[0] + o0[1]) + (o0[2] + o0[3]), (o1[0] + o1[1]) + (o1[2] + o1[3])};
+        }
+        PA_STAMP(9);
+        // ---- O^T = V^T P^T: per 16-key chunk three channel tiles; the A operand (32 channels x 16 keys) comes out of the row-major V
+        // by two ds_read_b64_tr_b16: a 16-lane group addresses a [4 keys][16 channels] block (lane j: key j >> 2, channels 4 (j & 3) ..)
+        // and lane j receives channel j of the 4 keys.  Keys behind the 8 operand elements: 16 ch + 4 grp + (0..3), then + 8.
+        // In between: the 6 K pieces (-> the other buffer) and the 6 Q pieces (-> this item's K buffer) of the next item.
         f32x16_t o[AT_D / 32];
-        float m, l;
-        if (wave < AT_WAVES - 1) attend<1>(Kl, Vl, qf, wave, c, o, m, l);
-        else attend<2>(Kl, Vl, qf, AT_WAVES - 1, c, o, m, l);
-        float* mine = part + (size_t)wave * (AT_D + 2);
-        if (col == 0) {
+#pragma unroll
+        for (int dt = 0; dt < AT_D / 32; dt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) o[dt][r] = 0.0f;
+        {
+            const int j16 = lane & 15, g16 = (lane >> 4) & 1;
+            const unsigned char* vb = at_lds + PA_V_OFF + (4 * grp + (j16 >> 2)) * PA_VROW + 2 * (16 * g16 + 4 * (j16 & 3));
+            half8_t v_cur[AT_D / 32], v_nxt[AT_D / 32];
+#pragma unroll
+            for (int dt = 0; dt < AT_D / 32; dt++) v_cur[dt] = tr_pair(vb + 64 * dt, vb + 64 * dt + 8 * PA_VROW);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ch++) {
+                if (ch + 1 < NCH) {
+#pragma unroll
+                    for (int dt = 0; dt < AT_D / 32; dt++)
+                        v_nxt[dt] = tr_pair(vb + 16 * (ch + 1) * PA_VROW + 64 * dt, vb + 16 * (ch + 1) * PA_VROW + 64 * dt + 8 * PA_VROW);
+                }
+#if PA_STUB == 0 || PA_STUB == 6
+#pragma unroll
+                for (int dt = 0; dt < AT_D / 32; dt++) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_cur[dt], pb[ch], o[dt], 0, 0, 0);
+#else
+                if (ch == 0) { o[0][0] = (float)pb[0][0]; }
+                if (PA_STUB < 4) __builtin_amdgcn_s_sleep(4);
+#endif
+#pragma unroll
+                for (int dt = 0; dt < AT_D / 32; dt++) v_cur[dt] = v_nxt[dt];
+                if (has_next && ch >= 2 && ch <= 12 && !(ch & 1)) k_piece(base_n, ob, (ch - 2) >> 1);     // the 6 K pieces of the next item
+            }
+        }
+        PA_STAMP(10);
+        // ---- normalise; the rows stay in registers (f16) until the next item's Q has been read out of the buffer that stages them
+        {
+            const float inv = 1.0f / l;
+            int i = 0;
 #pragma unroll
             for (int dt = 0; dt < AT_D / 32; dt++) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) mine[32 * dt + (r & 3) + 8 * (r >> 2) + 4 * grp] = o[dt][r];
-            }
-            if (grp == 0) { mine[AT_D] = m; mine[AT_D + 1] = l; }
-        }
-    };
-    // Wavefronts w and w + 4 share a SIMD: the upper four do their (short) CLS share first, so that the pair is out of
-    // phase -- one in the matrix pipe while the other does softmax VALU work.
-    const bool cls_first = stagger && wave >= AT_WAVES / 2;
-    if (VLFM_ATT_STUB != 1 && VLFM_ATT_STUB != 3 && cls_first) cls_part();
-    // ---- the 32 queries of tokens 1 + 32 wave .. 32 + 32 wave
-    {
-        f32x16_t o[AT_D / 32];
-        float m, l;
-        if (VLFM_ATT_STUB != 1) {
-            attend<AT_KT>(Kl, Vl, qmain, 0, c, o, m, l);
-        } else {
-            l = 1.0f;
-#pragma unroll
-            for (int dt = 0; dt < AT_D / 32; dt++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) o[dt][r] = (float)qmain[dt][r & 7];
-        }
-        AT_PHASE(7);
-        const float inv = 1.0f / l;
-        _Float16* dst = out + ((size_t)(b * AT_S + tq) * H + h) * DH + 4 * grp;
-#pragma unroll
-        for (int dt = 0; dt < AT_D / 32; dt++) {
-#pragma unroll
-            for (int q4 = 0; q4 < 4; q4++) {
-                const half4_t v = half4_t{(_Float16)(o[dt][4 * q4] * inv), (_Float16)(o[dt][4 * q4 + 1] * inv),
-                                          (_Float16)(o[dt][4 * q4 + 2] * inv), (_Float16)(o[dt][4 * q4 + 3] * inv)};
-                if ((VLFM_ATT_STUB != 4 || v[0] == (_Float16)12345.0f) && 32 * dt + 8 * q4 + 4 * grp < DH)
-                    *reinterpret_cast<half4_t*>(dst + 32 * dt + 8 * q4) = v;
+                for (int q4 = 0; q4 < 4; q4++) {
+                    if (32 * dt + 8 * q4 + 8 <= DH) {      // 11 x 4 channels per lane
+                        of[i] = half4_t{(_Float16)(o[dt][4 * q4] * inv), (_Float16)(o[dt][4 * q4 + 1] * inv),
+                                        (_Float16)(o[dt][4 * q4 + 2] * inv), (_Float16)(o[dt][4 * q4 + 3] * inv)};
+                        i++;
+                    }
+                }
             }
         }
+        PA_WAIT_LGKM0();     // the partials are written before the next barrier A
+        PA_STAMP(11);
+        t_prev = t;
+        if (!has_next) break;
+        t = tn;
+        base = base_n;
+        n++;
     }
-    AT_PHASE(8);
-    if (VLFM_ATT_STUB != 1 && VLFM_ATT_STUB != 3 && !cls_first) cls_part();
-    AT_PHASE(9);
-    __syncthreads();
-    AT_PHASE(10);
-    if (wave == 0) {
-        float mx = -__builtin_huge_valf();
+    // the last item's rows: through this item's K buffer (dead behind barrier B), then out
+    stage_rows((n & 1) * PA_KB);
 #pragma unroll
-        for (int w = 0; w < AT_WAVES; w++) mx = fmaxf(mx, part[(size_t)w * (AT_D + 2) + AT_D]);
-        float wgt[AT_WAVES], lsum = 0.0f;
-#pragma unroll
-        for (int w = 0; w < AT_WAVES; w++) {
-            wgt[w] = exp2f((part[(size_t)w * (AT_D + 2) + AT_D] - mx) * c);
-            lsum += wgt[w] * part[(size_t)w * (AT_D + 2) + AT_D + 1];
-        }
-        const float inv = 1.0f / lsum;
-        _Float16* dst = out + ((size_t)(b * AT_S) * H + h) * DH;
-        for (int d = lane; d < DH; d += 64) {
-            float v = 0.0f;
-#pragma unroll
-            for (int w = 0; w < AT_WAVES; w++) v += wgt[w] * part[(size_t)w * (AT_D + 2) + d];
-            dst[d] = (_Float16)(v * inv);
-        }
-    }
-    AT_PHASE(11);
+    for (int i = 0; i < 6; i++) store_out(t_prev, (n & 1) * PA_KB, i);
+    PA_BARRIER();
+    if (PA_STUB < 3) merge_odd(t_prev, n & 1);
 }
 
 }  // namespace vlfm
@@ -357,30 +493,24 @@ extern "C" int vlfm_vit_attention_f16(const void* d_qkv, void* d_out, int batch,
     if (batch == 0) return VLFM_OK;
     if (!d_qkv || !d_out || batch < 0 || heads <= 0)
         return fail(VLFM_ERR_INVALID, "vit_attention_f16: bad argument");
-    if (tokens != AT_S || (head_dim != AT_D && head_dim != 88))
-        return fail(VLFM_ERR_INVALID, "vit_attention_f16: specialised for 257 tokens and a head width of 88 or 96");
-    static LdsOptIn opt_in96, opt_in88;
-    if (!(head_dim == 88 ? opt_in88.ensure(reinterpret_cast<const void*>(vit_attention_kernel<88>), AT_LDS_BYTES)
-                         : opt_in96.ensure(reinterpret_cast<const void*>(vit_attention_kernel<96>), AT_LDS_BYTES)))
-        return fail(VLFM_ERR_HIP, "vit_attention_f16: cannot opt in to 117 KB of LDS");
-    // the upper four wavefronts do their CLS share first (VLFM_ATT_STAGGER=0, diagnostic: all do it last): 269 against 277 us at 256
-    // images; delaying them further (up to 3 000 cycles) changes nothing (round 5, profiles/r05_vit_attention_stub_probe.txt)
-    const char* es = getenv("VLFM_ATT_STAGGER");
-    const int stagger = es ? (atoi(es) != 0) : 1;
+    if (tokens != AT_S || head_dim != 88)
+        return fail(VLFM_ERR_INVALID, "vit_attention_f16: specialised for 257 tokens and a head width of 88");
+    if (heads > 1024)      // (per-lane source offsets within an image are 32-bit: 257 rows of 6 * heads * 88 bytes)
+        return fail(VLFM_ERR_INVALID, "vit_attention_f16: at most 1024 heads");
+    static LdsOptIn opt_in;
+    if (!opt_in.ensure(reinterpret_cast<const void*>(vit_attention_kernel), PA_LDS))
+        return fail(VLFM_ERR_HIP, "vit_attention_f16: cannot opt in to 150 KB of LDS");
+    // one workgroup per CU, in whole XCDs (workgroup id mod 8 = XCD); fewer when the batch has fewer items than that
+    const int cus = device_cu_count() & ~7, images_per_xcd = (batch + 7) / 8;
+    const int per = min(cus / 8, images_per_xcd * heads);
     VLFM_TIMED("vit_attention_kernel", stream);
-    const dim3 grid(8 * ((batch + 7) / 8) * heads), block(64 * AT_WAVES);
-    if (head_dim == 88) {
-        VLFM_KLAUNCH(vit_attention_kernel<88>, grid, block, AT_LDS_BYTES, (hipStream_t)stream, (const _Float16*)d_qkv,
-                     (_Float16*)d_out, batch, heads, scale, stagger);
-    } else {
-        VLFM_KLAUNCH(vit_attention_kernel<96>, grid, block, AT_LDS_BYTES, (hipStream_t)stream, (const _Float16*)d_qkv,
-                     (_Float16*)d_out, batch, heads, scale, stagger);
-    }
+    VLFM_KLAUNCH(vit_attention_kernel, dim3(8 * per), dim3(64 * AT_WAVES), PA_LDS, (hipStream_t)stream, (const _Float16*)d_qkv,
+                 (_Float16*)d_out, batch, heads, scale);
     return check_launch("vit_attention_kernel");
 }
 
 #ifdef VLFM_PHASE_TIMING
-extern "C" int vlfm_debug_attention_clocks(long long* h_out16) {
-    return hipMemcpyFromSymbol(h_out16, HIP_SYMBOL(g_att_clk), sizeof(long long) * 16) == hipSuccess ? VLFM_OK : VLFM_ERR_HIP;
+extern "C" int vlfm_debug_attention_pers_clocks(long long* h_out480) {
+    return hipMemcpyFromSymbol(h_out480, HIP_SYMBOL(g_pa_clk), sizeof(long long) * 480) == hipSuccess ? VLFM_OK : VLFM_ERR_HIP;
 }
 #endif

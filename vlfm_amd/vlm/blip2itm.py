@@ -169,7 +169,7 @@ class _VitBlock(nn.Module):
                 qkv = F.linear(h.view(b * n, d), self.qkv.weight, self.qkv.bias)
             try:
                 a = ops.vit_attention(qkv, b, n, self.heads, hd, float(hd) ** -0.5)
-            except (RuntimeError, AssertionError, IndexError) as exc:   # e.g. the 117 KB LDS opt-in refused on this device
+            except (RuntimeError, AssertionError, IndexError) as exc:   # e.g. the 150 KB LDS opt-in refused on this device
                 if self.strict_hip_attention:
                     raise
                 import warnings

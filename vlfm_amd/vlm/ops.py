@@ -290,11 +290,11 @@ def linear_gelu(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> to
     return linear_f16(x, weight, bias, "bias_gelu")
 
 
-VIT_ATTENTION_TOKENS, VIT_ATTENTION_HEADS = 257, (88, 96)
+VIT_ATTENTION_TOKENS, VIT_ATTENTION_HEADS = 257, (88,)
 
 
 def vit_attention(qkv: torch.Tensor, batch: int, tokens: int, heads: int, head_dim: int, scale: float) -> torch.Tensor:
-    """softmax(q k^T * scale) v for the ViT-g shape (257 tokens, heads of 88 -- or 96 when padded): ``qkv`` is the qkv GEMM's output
+    """softmax(q k^T * scale) v for the ViT-g shape (257 tokens, heads of 88): ``qkv`` is the qkv GEMM's output
     [batch*tokens, 3*heads*head_dim] f16 as it is; returns [batch*tokens, heads*head_dim] f16 for the projection GEMM."""
     assert qkv.is_cuda and qkv.dtype == torch.float16 and qkv.is_contiguous()
     assert qkv.numel() == batch * tokens * 3 * heads * head_dim
