@@ -207,7 +207,11 @@ __global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _
         if (PA_STUB < 5 && !PA_NO_STORES && sg < 352) {
             const int b = image_of(tt), h = tt % H;
             const uint4 v = *reinterpret_cast<const uint4*>(at_lds + bo + (1 + 32 * wave) * PA_KROW + 16 * sg);
+#ifdef PA_CONTIG_OUT   // timing experiment only: head-major output (each (image, head) block of 257 rows contiguous)
+            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(out) + ((size_t)(b * H + h) * AT_S + 1 + 32 * wave) * (2 * DH) + 16 * sg) = v;
+#else
             *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(out) + ((size_t)(b * AT_S + 1 + 32 * wave + row) * H + h) * (2 * DH) + 16 * s) = v;
+#endif
         }
     };
     const unsigned char* base = item_base(t);
@@ -250,6 +254,8 @@ __global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _
     for (;;) {
         const int tn = t + per;
         const bool has_next = tn / H < nimg;
+        // (the last item fetches itself again as its "next": the DMA pieces between the MFMAs stay unconditional -- a branch around each
+        // would cut the MFMA loops into separate scheduling regions -- at the price of 90 KB of extra L2 traffic per workgroup)
         const unsigned char* base_n = has_next ? item_base(tn) : base;
         const int kb = (n & 1) * PA_KB, ob = PA_KB - kb;
         PA_STAMP(0);
@@ -297,20 +303,17 @@ __global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _
                 const half8_t kv = *reinterpret_cast<const half8_t*>(kr + 16 * i);
 #pragma unroll
                 for (int e = 0; e < 4; e++) s = __builtin_amdgcn_fdot2(half2_t{qv[2 * e], qv[2 * e + 1]}, half2_t{kv[2 * e], kv[2 * e + 1]}, s, false);
-                if (wave == AT_WAVES - 1) {
-                    const half8_t k2 = *reinterpret_cast<const half8_t*>(kl + 16 * i);
+                const half8_t k2 = *reinterpret_cast<const half8_t*>(kl + 16 * i);      // (key 256: every wavefront, no branch; used by the last)
 #pragma unroll
-                    for (int e = 0; e < 4; e++) s2 = __builtin_amdgcn_fdot2(half2_t{qv[2 * e], qv[2 * e + 1]}, half2_t{k2[2 * e], k2[2 * e + 1]}, s2, false);
-                }
+                for (int e = 0; e < 4; e++) s2 = __builtin_amdgcn_fdot2(half2_t{qv[2 * e], qv[2 * e + 1]}, half2_t{k2[2 * e], k2[2 * e + 1]}, s2, false);
             }
             s += __shfl_xor(s, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            const bool last = wave == AT_WAVES - 1;
             float m = row16_max(s);
             m = fmaxf(m, __shfl_xor(m, 16, 64));
-            if (wave == AT_WAVES - 1) {
-                s2 += __shfl_xor(s2, 32, 64);
-                m = fmaxf(m, s2);
-                p2 = __builtin_amdgcn_exp2f((s2 - m) * c);
-            }
+            m = fmaxf(m, last ? s2 : m);
+            p2 = last ? __builtin_amdgcn_exp2f((s2 - m) * c) : 0.0f;
             ps = __builtin_amdgcn_exp2f((s - m) * c);
             float l = row16_sum(ps);
             l += __shfl_xor(l, 16, 64);
@@ -383,13 +386,12 @@ __global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _
             } else {
                 pb[ch] = pb[0];
             }
-            if (has_next && ch % 3 == 1) q_piece(base_n, kb, ch / 3);       // the 6 Q pieces of the next item -> this item's K buffer
+            if (ch % 3 == 1) q_piece(base_n, kb, ch / 3);       // the 6 Q pieces of the next item -> this item's K buffer
         }
         l += __shfl_xor(l, 32, 64);
         // ---- B: V of this item is in LDS (this wavefront's pieces: older than the 6 Q pieces)
         PA_STAMP(6);
-        if (has_next) PA_WAIT_VM(6);
-        else PA_WAIT_VM(0);
+        PA_WAIT_VM(6);
         PA_WAIT_LGKM0();
         PA_STAMP(7);
         PA_BARRIER();
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _
                 o0[k & 3] = fmaf(pk, (float)vv[0], o0[k & 3]);
                 o1[k & 3] = fmaf(pk, (float)vv[1], o1[k & 3]);
             }
-            if (wave == AT_WAVES - 1) {
+            {       // key 256: p2 is zero except in the last wavefront
                 const half2_t vv = *reinterpret_cast<const half2_t*>(at_lds + PA_V_OFF + 256 * PA_VROW + 4 * cp);
                 const float p2 = mine[98];
                 o0[0] = fmaf(p2, (float)vv[0], o0[0]);
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _
 #endif
 #pragma unroll
                 for (int dt = 0; dt < AT_D / 32; dt++) v_cur[dt] = v_nxt[dt];
-                if (has_next && ch >= 2 && ch <= 12 && !(ch & 1)) k_piece(base_n, ob, (ch - 2) >> 1);     // the 6 K pieces of the next item
+                if (ch >= 2 && ch <= 12 && !(ch & 1)) k_piece(base_n, ob, (ch - 2) >> 1);     // the 6 K pieces of the next item
             }
         }
         PA_STAMP(10);
@@ -476,7 +478,9 @@ __global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _
         base = base_n;
         n++;
     }
-    // the last item's rows: through this item's K buffer (dead behind barrier B), then out
+    // the last item's rows: through this item's K buffer, once the (unused) pieces that were still aimed at it have landed
+    PA_WAIT_VM(0);
+    PA_BARRIER();
     stage_rows((n & 1) * PA_KB);
 #pragma unroll
     for (int i = 0; i < 6; i++) store_out(t_prev, (n & 1) * PA_KB, i);
