@@ -1,5 +1,5 @@
 """-m gpu: csrc/gemm_f16.hip (the ViT-g GEMMs of BLIP2ITM.cosine, /root/reference/vlfm/vlm/blip2itm.py:37-54 -> LAVIS eva_vit [ext])
-against an f64 reference: every epilogue (bias / bias + erf-GELU / accumulate into the residual stream), every kernel variant,
+against an f64 reference: every epilogue (bias / bias + erf-GELU / accumulate into the residual stream), the persistent 8-phase kernel,
 ragged M and N, 1-, 2-, 3-tile and long K (the 8-phase kernel's prologue and tail wait counts), the half-empty last n-tile of
 N = 1408 / 4224 -- and a race screen: the 8-phase kernel keeps LDS-DMA loads in flight across barriers, so a wrong wait count is a
 RARE wrong tile; the same launch is repeated and compared bitwise.  Tolerance: f16 output rounding (2^-11 relative) + f32
@@ -21,19 +21,11 @@ SHAPES = [(300, 264, 128), (512, 512, 64), (256, 256, 192), (1000, 776, 1408), (
           (8224, 6144, 128)]
 
 
-def _run(ops, x, w, b, epi, variant, out=None):
-    old = os.environ.get("VLFM_GEMM_VARIANT")
-    os.environ["VLFM_GEMM_VARIANT"] = str(variant)
-    try:
-        return ops.linear_f16(x, w, b, epi, out=out)
-    finally:
-        if old is None:
-            os.environ.pop("VLFM_GEMM_VARIANT", None)
-        else:
-            os.environ["VLFM_GEMM_VARIANT"] = old
+def _run(ops, x, w, b, epi, variant=None, out=None):
+    return ops.linear_f16(x, w, b, epi, out=out)      # (one kernel since round 6: the persistent 8-phase schedule)
 
 
-@pytest.mark.parametrize("variant", [0, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [7])
 @pytest.mark.parametrize("shape", SHAPES)
 def test_gemm_f16_epilogues_against_f64(gpu_device, shape, variant):
     from vlfm_amd.vlm import ops
@@ -60,7 +52,7 @@ def test_gemm_f16_epilogues_against_f64(gpu_device, shape, variant):
         assert float((got - want).abs().max()) <= 2e-3 * max(1.0, float(want.abs().max()))
 
 
-@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [7])
 def test_gemm_f16_8phase_is_deterministic_under_repetition(gpu_device, variant):
     """Race screen: 30 repeats of three multi-wave-of-workgroups problems, bitwise equal to the first run, which is checked against
     an f32 product."""

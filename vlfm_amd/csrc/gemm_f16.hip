@@ -14,18 +14,15 @@
 //   * operand roles are swapped (A-operand = W rows, B-operand = X rows): a lane then holds 4 CONSECUTIVE n of one m, i.e.
 //     8 contiguous bytes of the output row after conversion; the epilogue transposes through LDS (row stride 272 B:
 //     conflict-free 8-byte writes, 16-byte reads) and stores 256-byte row segments with 16 B per lane.
-//   * the schedule is a PING-PONG between the two wavefronts of a SIMD.  Round 5 (what runs by default): the 8-phase form of it
-//     (Gemm8p: four phases of 16 MFMAs per K-tile, half-tile staging, counted vmcnt waits) as a PERSISTENT kernel
-//     (gemm_f16_8pp_kernel: one workgroup per CU walks the tile list, the next tile's first K-tile is requested before the
-//     epilogue, the stores drain under the next tile) with the GELU in packed f32 (gelu_f16.h).  The earlier forms -- round 2's
-//     4-phase ping-pong gemm_f16_nt_kernel, the lock-step kernel, the one-tile-per-workgroup 8-phase kernel, the 4-wavefront
-//     kernel -- stay selectable (VLFM_GEMM_VARIANT) for A/B runs and are covered by the same tests.
+//   * the schedule is a PING-PONG between the two wavefronts of a SIMD in the 8-phase form (Gemm8p: four phases of 16 MFMAs per K-tile,
+//     half-tile staging, counted vmcnt waits) as a PERSISTENT kernel (gemm_f16_8pp_kernel: one workgroup per CU walks the tile list,
+//     the next tile's first K-tile is requested before the epilogue, the stores drain under the next tile) with the GELU in packed
+//     f32 (gelu_f16.h).  Round 6: the earlier schedules (round 2's 4-phase ping-pong, the lock-step kernel, the one-tile-per-workgroup
+//     8-phase kernel, the 4-wavefront kernel) were A/B baselines only -- none is faster on any ViT shape -- and are gone from the
+//     tree (git history: round 5; their numbers: DESIGN.md section 6c / 6g).
 // Measured at 256 images (tools/gemm_f16_probe.py, tools/mlp_probe.py; DESIGN.md section 6c has the table): fc1 + GELU 1.11-1.16 ms
 // against 1.41-1.45 ms for hipBLASLt + the GELU pass on random data, 1.19 against 1.24 ms on the network's own activations; as a
 // plain GEMM 1.0-1.1 PFLOP/s, i.e. 5-10 % BELOW hipBLASLt -- so only the fused fc1 uses it (vlfm_amd/vlm/ops.py:linear_gelu).
-// Tried and removed: two workgroups per CU on 256 x 128 tiles with 64-byte rows (hides the epilogue completely but the main loop
-// drops to 0.88 PFLOP/s), the ping-pong with K-steps of 32 in a ring of four stages (no gain: prefetch distance is not the
-// limiter), the loads issued between the MFMAs (10x slower).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -53,9 +50,6 @@ constexpr int BUF = 2 * OPER;      // W tile + X tile
 constexpr int EPI_ROW = 272;       // epilogue staging row stride (128 n x 2 B + 16)
 constexpr int EPI_WAVE = 64 * EPI_ROW;
 constexpr int GEMM_LDS = 8 * EPI_WAVE > 2 * BUF ? 8 * EPI_WAVE : 2 * BUF;
-
-constexpr int GEMM_DEFAULT_VARIANT = 7;   // 0 ping-pong (round 2), 1 lock-step, 2 8-phase, 3 8-phase balanced, 4 / 5 = 2 / 3 with one barrier per phase,
-                                          // 6 four wavefronts, 7 = 3 as a persistent kernel (fastest)
 enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_ACCUM = 2 };   // 2: C += X . W^T (+ bias): the residual-stream GEMMs (projection, fc2)
 
 struct GemmArgs {
@@ -72,271 +66,13 @@ struct GemmArgs {
 using lds_ptr = __attribute__((address_space(3))) unsigned char*;
 using gbl_ptr = const __attribute__((address_space(1))) unsigned char*;
 
-// one K-tile of both operands -> LDS buffer `buf` (byte offset): 4 + 4 global_load_lds per wavefront
-__device__ inline void stage_tile(const GemmArgs& a, lds_ptr lds, int buf, int n0, int m0, int k0, int wave, int lane) {
-    const int sub = lane >> 3, p = lane & 7;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int chunk = wave * 4 + j;                 // 8 rows each
-        const int r = chunk * 8 + sub;
-        const int s = p ^ ((r >> 1) & 7);               // the slot this lane fetches lands at physical slot p
-        const int rn = min(n0 + r, a.N - 1), rm = min(m0 + r, a.M - 1);
-        const _Float16* gw = a.w + (size_t)rn * a.K + k0 + s * 8;
-        const _Float16* gx = a.x + (size_t)rm * a.K + k0 + s * 8;
-        const int dst = __builtin_amdgcn_readfirstlane(buf + chunk * 1024);
-        __builtin_amdgcn_global_load_lds((gbl_ptr)gw, lds + dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_ptr)gx, lds + dst + OPER, 16, 0, 0);
-    }
-}
-
-// MFMA fragments of one half K-tile (32 of the 64 k): 8 A-operand (W rows) + 4 B-operand (X rows) ds_read_b128
-__device__ inline void read_frags(const unsigned char* smem, int buf, int kk, int wn, int wm, int lane, half8 (&fa)[8],
-                                  half8 (&fb)[4]) {
-    const int r16 = lane & 15, s = kk * 4 + (lane >> 4);
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int R = wn * 128 + i * 16 + r16;
-        fa[i] = *reinterpret_cast<const half8*>(smem + buf + R * ROWB + ((s ^ ((R >> 1) & 7)) << 4));
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int R = wm * 64 + j * 16 + r16;
-        fb[j] = *reinterpret_cast<const half8*>(smem + buf + OPER + R * ROWB + ((s ^ ((R >> 1) & 7)) << 4));
-    }
-}
-
-__device__ inline void mma_half(const half8 (&fa)[8], const half8 (&fb)[4], floatx4 (&acc)[8][4]) {
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-}
-
-// Epilogue of one wavefront: bias (+ exact GELU) on the f32 accumulators, f16, transpose through a wavefront-private LDS region
-// (it aliases the operand buffers: the caller guarantees that every wavefront is past its last operand read), 16-byte stores.
-// Round 5: every global load of the epilogue (the 8 bias quads; for EPI_ACCUM the 16 row segments of the residual stream) is
-// issued BEFORE the arithmetic, all 16 LDS reads of the second half before the first store, and the stores back to back.  The
-// round-2 form loaded each bias quad where it was used (8 dependent L2 round trips) and re-used one register quad for the 16
-// ds_read_b128 / global_store pairs, which made hipcc wait vmcnt(0) -- for the previous STORE to leave -- before every read: a
-// fixed 13-15 us per tile (tools/gemm_f16_probe.py: time = a + b K / 64 over the K = 1408 / 6144 pair of shapes), a third of a
-// K = 1408 tile.
-template <int EPI>
-__device__ inline void store_tile(const GemmArgs& a, unsigned char* smem, const floatx4 (&acc)[8][4], int wave, int wn, int wm,
-                                  int lane, int m0, int n0, int wave_cols = 128) {
-    // wave_cols: n columns this wavefront owns (128; 64 in the 8-phase kernel's half-tile mode, where acc[4..7] are unused)
-    n0 += wn * wave_cols - wn * 128;     // (the code below adds wn * 128)
-    unsigned char* stg = smem + wave * EPI_WAVE;
-    const int g4 = (lane >> 4) * 4, c16 = lane & 15;
-    const int rsub = lane >> 4, chunk = lane & 15;
-    half4 bias4[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        bias4[i] = half4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
-        if (a.bias) bias4[i] = *reinterpret_cast<const half4*>(a.bias + min(n0 + wn * 128 + i * 16 + g4, a.N - 4));
-    }
-    uint4 old[EPI == EPI_ACCUM ? 16 : 1];
-    if (EPI == EPI_ACCUM) {
-#pragma unroll
-        for (int it = 0; it < 16; it++) {   // (clamped addresses: rows / columns beyond the matrix are loaded from its edge, never stored)
-            const int m = min(m0 + wm * 64 + it * 4 + rsub, a.M - 1), n = max(min(n0 + wn * 128 + chunk * 8, a.N - 8), 0);
-            old[it] = *reinterpret_cast<const uint4*>(a.c + (size_t)m * a.N + n);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int nl = i * 16 + g4;                    // 4 consecutive n of this lane, wavefront-local
-        const float b0 = (float)bias4[i][0], b1 = (float)bias4[i][1], b2 = (float)bias4[i][2], b3 = (float)bias4[i][3];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            float v0 = acc[i][j][0] + b0, v1 = acc[i][j][1] + b1, v2 = acc[i][j][2] + b2, v3 = acc[i][j][3] + b3;
-            if (EPI == EPI_BIAS_GELU) gelu_erf4(v0, v1, v2, v3);
-            const half4 h = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
-            *reinterpret_cast<half4*>(stg + (j * 16 + c16) * EPI_ROW + nl * 2) = h;
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);   // wavefront-private region: no workgroup barrier needed
-    uint4 v[16];
-#pragma unroll
-    for (int it = 0; it < 16; it++) v[it] = *reinterpret_cast<const uint4*>(stg + (it * 4 + rsub) * EPI_ROW + chunk * 16);
-    if (EPI == EPI_ACCUM) {   // beta = 1: the stream's 8 halves of each row segment + the product, summed in f32
-#pragma unroll
-        for (int it = 0; it < 16; it++) {
-            half8 h = *reinterpret_cast<const half8*>(&v[it]);
-            const half8 o = *reinterpret_cast<const half8*>(&old[it]);
-#pragma unroll
-            for (int e = 0; e < 8; e++) h[e] = (_Float16)((float)h[e] + (float)o[e]);
-            v[it] = *reinterpret_cast<const uint4*>(&h);
-        }
-    }
-    const int n = n0 + wn * 128 + chunk * 8;
-    if (n + 8 <= a.N && chunk * 8 < wave_cols) {
-#pragma unroll
-        for (int it = 0; it < 16; it++) {
-            const int m = m0 + wm * 64 + it * 4 + rsub;
-            if (m < a.M) *reinterpret_cast<uint4*>(a.c + (size_t)m * a.N + n) = v[it];
-        }
-    }
-}
-
-// Lock-step schedule (the first form; kept as the A/B baseline, VLFM_GEMM_VARIANT=1): all 8 wavefronts move through the K-tile
-// together, two fragment register sets, one barrier per K-tile.
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_f16_nt_lockstep_kernel(GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    lds_ptr lds = (lds_ptr)smem;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave >> 2, wm = wave & 3;
-    // XCD-aware tile order: consecutive workgroup ids go round-robin over the 8 XCDs; give every XCD a contiguous range of
-    // tiles (n fastest) so that the tiles sharing an X row panel and the W matrix meet in one L2
-    const int nwg = a.tiles_m * a.tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tm = bid / a.tiles_n, tn = bid - tm * a.tiles_n;
-    const int m0 = tm * GB, n0 = tn * GB;
-    const int NT = a.K / GK;
-
-    floatx4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-    half8 fa0[8], fb0[4], fa1[8], fb1[4];
-
-    stage_tile(a, lds, 0, n0, m0, 0, wave, lane);
-    if (NT > 1) stage_tile(a, lds, BUF, n0, m0, GK, wave, lane);
-    if (NT > 1) __builtin_amdgcn_s_waitcnt(0x0F78);
-    else __builtin_amdgcn_s_waitcnt(0x0F70);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    read_frags(smem, 0, 0, wn, wm, lane, fa0, fb0);
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-
-    for (int t = 0; t < NT; t++) {
-        const int cur = (t & 1) * BUF;
-        read_frags(smem, cur, 1, wn, wm, lane, fa1, fb1);     // second half of tile t: in flight under the MFMAs below
-        __builtin_amdgcn_sched_barrier(0);
-        mma_half(fa0, fb0, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_waitcnt(0xC07F);    // every LDS read of tile t by this wavefront has returned
-        if (t + 1 < NT) {
-            __builtin_amdgcn_s_waitcnt(0x0F70);  // ... and its share of tile t + 1 has landed (nothing newer is in flight)
-            __builtin_amdgcn_s_barrier();                      // ... for everybody: buffer `cur` is free, the other one is complete
-            asm volatile("" ::: "memory");
-            if (t + 2 < NT) stage_tile(a, lds, cur, n0, m0, (t + 2) * GK, wave, lane);
-            read_frags(smem, cur ^ BUF, 0, wn, wm, lane, fa0, fb0);  // first half of tile t + 1: in flight under the MFMAs below
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        mma_half(fa1, fb1, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-    }
-
-    __builtin_amdgcn_s_barrier();   // every wavefront is done with the operand buffers
-    asm volatile("" ::: "memory");
-    store_tile<EPI>(a, smem, acc, wave, wn, wm, lane, m0, n0);
-}
-
-
-// ------------------------------------------------------------------------------------------------ ping-pong schedule
-// Same tile, staging and fragments as the lock-step kernel, but the two wavefronts of a SIMD (w and w + 4) never do the same thing
-// at the same time.  PMC counters of the lock-step form (tools/gemm_pmc.sh): the matrix pipe is busy 46-51 % of the cycles against
-// 67 % for hipBLASLt's kernel, with the same MFMA count, fewer bank conflicts and similar LDS activity -- what is lost is the time in
-// which BOTH wavefronts of a SIMD are behind the same barrier issuing loads and waiting for fragments.  Here a K-tile is four phases
-// per wavefront -- fragments of half 0 | 32 MFMAs | fragments of half 1 | 32 MFMAs -- each closed by the workgroup barrier, and
-// wavefronts 4-7 run ONE PHASE BEHIND wavefronts 0-3 (one extra barrier in front of their loop, one behind the others'): whenever
-// one wavefront of a SIMD waits for LDS, its partner is in the matrix pipe.  One fragment register set instead of two.
-//   tile t + 1 is requested at the start of "fragments of half 0" of tile t into the other LDS buffer (every wavefront finished
-//   reading tile t - 1 at least one barrier earlier, the late group included) and awaited at the end of "fragments of half 1".
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_f16_nt_kernel(GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    lds_ptr lds = (lds_ptr)smem;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave >> 2, wm = wave & 3;
-    const int late = wn;                               // wavefronts 4-7: one phase behind
-    const int nwg = a.tiles_m * a.tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    // ... walked in groups of GM m-tiles, m fastest: the 32 tiles an XCD works on at one time are GM (m) x 32 / GM (n), i.e.
-    // GM + 32 / GM operand panels per K-step instead of 24 + 2, and the X panels of a group stay in the L2 while n advances
-    int tm, tn;
-    {
-        const int GM = a.group_m;
-        const int per_group = GM * a.tiles_n, grp = bid / per_group, in = bid - grp * per_group;
-        const int rows = min(GM, a.tiles_m - grp * GM);
-        tn = in / rows;
-        tm = grp * GM + (in - tn * rows);
-    }
-    const int m0 = tm * GB, n0 = tn * GB;
-    const int NT = a.K / GK;
-
-    floatx4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-    half8 fa[8], fb[4];
-
-    stage_tile(a, lds, 0, n0, m0, 0, wave, lane);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (late) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
-
-    for (int t = 0; t < NT; t++) {
-        const int cur = (t & 1) * BUF;
-        // ---- fragments of half 0 (+ request tile t + 1)
-        read_frags(smem, cur, 0, wn, wm, lane, fa, fb);       // first, so that the fragments travel while the loads below issue
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < NT) stage_tile(a, lds, cur ^ BUF, n0, m0, (t + 1) * GK, wave, lane);
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        // ---- 32 MFMAs
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-        mma_half(fa, fb, acc);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        // ---- fragments of half 1 (+ tile t + 1 has landed, as far as this wavefront's share goes)
-        read_frags(smem, cur, 1, wn, wm, lane, fa, fb);
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        // ---- 32 MFMAs
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-        mma_half(fa, fb, acc);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    }
-    if (!late) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }   // the late group's last MFMA phase: its LDS reads are over
-
-    store_tile<EPI>(a, smem, acc, wave, wn, wm, lane, m0, n0);
-}
-
-
 // ------------------------------------------------------------------------------------------------ 8-phase schedule
-// Round 5.  Same tile (256 x 256 x 64), same operand roles, swizzle and epilogue, and the same ping-pong between the two wavefronts
-// of a SIMD -- but a K-tile is FOUR phases of 16 MFMAs (one quadrant of the wavefront's 128 x 64 accumulator block each) instead of
+// The two wavefronts of a SIMD (w and w + 4) never do the same thing at the same time (wavefronts 4-7 run one barrier behind 0-3).
+// A K-tile is FOUR phases of 16 MFMAs (one quadrant of the wavefront's 128 x 64 accumulator block each) instead of
 // two of 32, an operand tile is staged as two HALF-tiles, one half-tile (2 global_load_lds per wavefront) per phase, and the loads
 // are never drained inside the loop: ONE counted s_waitcnt vmcnt(4) per K-tile leaves the two half-tiles issued last in flight across
-// every barrier (the guide's 256^2 8-phase template; the ping-pong kernel above waits vmcnt(0) once per K-tile, i.e. every load of
-// the next tile has to land inside ~3 phases of the current one and the wait sits on the critical path of all 8 wavefronts).
+// every barrier (the guide's 256^2 8-phase template; a schedule that waits vmcnt(0) once per K-tile needs every load of the next tile to land
+// inside ~3 phases of the current one, with the wait on the critical path of all 8 wavefronts).
 //
 // LDS: two K-tile buffers of four 16 KB slots, in the order the phases need them:
 //     slot 0 = Q_H0   X rows {wm * 64 + [ 0, 32)}  for the four wm      read in phase 1 (4 ds_read_b128 per wavefront)
@@ -562,35 +298,6 @@ struct Gemm8p {
         }
         compute<1, 0>(fq0[QS]);
     }
-
-    __device__ inline void run(int m0, int n0) {
-        const int NT = a.K / GK;
-        const int late = SYNC == 2 ? wave >> 2 : 0;
-        GEMM_STAMP(0);
-        // prologue: all of tile 0, slots 0 and 1 of tile 1
-        stage<0>(0, 0); stage<1>(0, 0); stage<2>(0, 0); stage<3>(0, 0);
-        if (NT > 1) {
-            stage<0>(1, 1); stage<1>(1, 1);
-            __builtin_amdgcn_s_waitcnt(0x0F74);      // all of tile 0 (behind it: slots 0, 1 of tile 1)
-        } else {
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-        }
-        bar();
-        GEMM_STAMP(1);
-        if (late) bar();
-        if (BAL && active) read_q<0, 0>(fq0[0]);     // (retired by the lgkmcnt(0) of the first phase)
-        for (int t = 0; t < NT; t += 2) {
-            tile<0>(t, NT);
-            if (t + 1 < NT) tile<1>(t + 1, NT);
-        }
-        if (!late) bar();       // (the late group's last MFMA phase;) behind it nobody reads the operand buffers any more
-        GEMM_STAMP(2);
-        store_tile<EPI>(a, const_cast<unsigned char*>(smem), acc, wave, wave >> 2, wave & 3, lane, m0, n0, half ? 64 : 128);
-#ifdef VLFM_PHASE_TIMING
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the stamp below is "stores have left", not "stores were issued")
-#endif
-        GEMM_STAMP(3);
-    }
 };
 
 // Tile of a workgroup.  Workgroup ids go round-robin over the 8 XCDs; every XCD gets a contiguous range of the tile list (tiles
@@ -624,19 +331,6 @@ __host__ __device__ inline void tile_of(const GemmArgs& a, int bid, int& tm, int
     }
 }
 
-__device__ inline void tile_of_block(const GemmArgs& a, int& tm, int& tn) { tile_of(a, blockIdx.x, tm, tn); }
-
-template <int EPI, int BAL, int SYNC = 2>
-__global__ __launch_bounds__(512) void gemm_f16_8p_kernel(GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int tm, tn;
-    tile_of_block(a, tm, tn);
-    const int m0 = tm * GB, n0 = tn * GB;
-    Gemm8p<EPI, BAL, SYNC> g(a, smem, m0, n0);
-    g.run(m0, n0);
-}
-
-
 // ------------------------------------------------------------------------------------------------ 8-phase, persistent
 // One workgroup per CU walks the tile list with stride gridDim.x (a multiple of 8: a workgroup stays on the XCD whose share of the
 // list it walks, and the tiles of one round are the neighbours the one-tile-per-workgroup launch would run together).  What a tile
@@ -647,7 +341,10 @@ __global__ __launch_bounds__(512) void gemm_f16_8p_kernel(GemmArgs a) {
 //   * the epilogue stages through [64 KB, 136 KB) only -- buffer 1 and the tail -- in two passes of 64 n-columns (64 rows x 144 B per
 //     wavefront and pass), both passes' rows held in registers, then ONE s_waitcnt vmcnt(0) (the residual-stream loads of
 //     EPI_ACCUM and the prefetch: everything this wavefront asked for) and the 16 stores back to back;
-//   * the stores drain under the next tile's first phases: nothing waits for them before the counted wait of its phase 4.
+//   * the stores drain under the next tile's first phases: on gfx9 they share vmcnt with the LDS-DMA loads and retire IN ISSUE ORDER
+//     with them (the assumption every counted wait of this file rests on; tests/test_gemm_f16_gpu.py's 30-repeat bitwise screen is
+//     what covers it), so the first counted wait behind them -- vmcnt(8) in phase 3 of K-tile 0, BAL form -- also waits for all 16
+//     stores of the previous tile; nothing waits for them earlier.
 // After the epilogue one barrier (every wavefront's staging reads are over and its share of K-tile 0 is in LDS), then slots 0 / 1
 // of K-tile 1 are requested and the phases start; the wait of phase 4 of K-tile 0 covers them as it does in the steady state.
 constexpr int EPI2_ROW = 144;                 // 64 n x 2 B + 16
@@ -826,309 +523,25 @@ __global__ __launch_bounds__(512) void gemm_f16_8pp_kernel(GemmArgs a) {
 }
 
 
-// Epilogue of the 4-wavefront kernel: wavefront (wr, wc) holds 128 n x 128 m as 4 x 4 accumulator tiles of 32 x 32 (lane: column
-// m = lane & 31 of a tile, rows n = 8 g + 4 (lane >> 5) + {0..3}, g = 0..3).  Same scheme as store_tile: bias (+ GELU) in f32, f16,
-// transposed through a wavefront-private LDS region of 128 rows x 272 B, every global load issued up front, 16-byte stores.
-constexpr int EPI_WAVE4 = 128 * EPI_ROW;
-template <int EPI>
-__device__ inline void store_tile_w4(const GemmArgs& a, unsigned char* smem, const f32x16 (&acc)[4][4], int wave, int lane, int m0,
-                                     int n0) {
-    const int wr = wave >> 1, wc = wave & 1;
-    unsigned char* stg = smem + wave * EPI_WAVE4;
-    const int c32 = lane & 31, h4 = (lane >> 5) * 4;
-    const int rsub = lane >> 4, chunk = lane & 15;
-    const int nb = n0 + wr * 128, mb = m0 + wc * 128;
-    half4 bias4[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            bias4[i][g] = half4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
-            if (a.bias) bias4[i][g] = *reinterpret_cast<const half4*>(a.bias + min(nb + i * 32 + g * 8 + h4, a.N - 4));
-        }
-    uint4 old[EPI == EPI_ACCUM ? 32 : 1];
-    if (EPI == EPI_ACCUM) {
-#pragma unroll
-        for (int it = 0; it < 32; it++) {
-            const int m = min(mb + it * 4 + rsub, a.M - 1), n = max(min(nb + chunk * 8, a.N - 8), 0);
-            old[it] = *reinterpret_cast<const uint4*>(a.c + (size_t)m * a.N + n);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const half4 bv = bias4[i][g];
-                float v0 = acc[i][j][4 * g + 0] + (float)bv[0], v1 = acc[i][j][4 * g + 1] + (float)bv[1];
-                float v2 = acc[i][j][4 * g + 2] + (float)bv[2], v3 = acc[i][j][4 * g + 3] + (float)bv[3];
-                if (EPI == EPI_BIAS_GELU) gelu_erf4(v0, v1, v2, v3);
-                const half4 h = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
-                *reinterpret_cast<half4*>(stg + (j * 32 + c32) * EPI_ROW + (i * 32 + g * 8 + h4) * 2) = h;
-            }
-    __builtin_amdgcn_s_waitcnt(0xC07F);   // wavefront-private region: no workgroup barrier needed
-    uint4 v[32];
-#pragma unroll
-    for (int it = 0; it < 32; it++) v[it] = *reinterpret_cast<const uint4*>(stg + (it * 4 + rsub) * EPI_ROW + chunk * 16);
-    if (EPI == EPI_ACCUM) {
-#pragma unroll
-        for (int it = 0; it < 32; it++) {
-            half8 h = *reinterpret_cast<const half8*>(&v[it]);
-            const half8 o = *reinterpret_cast<const half8*>(&old[it]);
-#pragma unroll
-            for (int e = 0; e < 8; e++) h[e] = (_Float16)((float)h[e] + (float)o[e]);
-            v[it] = *reinterpret_cast<const uint4*>(&h);
-        }
-    }
-    const int n = nb + chunk * 8;
-    if (n + 8 <= a.N) {
-#pragma unroll
-        for (int it = 0; it < 32; it++) {
-            const int m = mb + it * 4 + rsub;
-            if (m < a.M) *reinterpret_cast<uint4*>(a.c + (size_t)m * a.N + n) = v[it];
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ four wavefronts, one per SIMD
-// Round 5, after the counters (profiles/r05_gemm_pmc.txt): the library's kernel for these shapes runs HALF as many wavefronts as the
-// 8-wavefront kernels above for the same MFMA work -- one wavefront per SIMD with a 128 x 128 accumulator block (256 registers;
-// 512-register budget), no partner to trade the matrix pipe with and therefore no barriers inside a K-tile -- and its matrix pipe is
-// busy 66 % of the time against 50-59 % here, where every one of the 8 barrier-separated intervals of a K-tile costs ~150 cycles of
-// hand-over on top of its 16 MFMAs (tools/gemm_stamp_probe.py).  This is that structure in plain HIP:
-//   * 256 threads, wavefront (wr, wc) of a 2 x 2 grid owns W rows [wr * 128, +128) x X rows [wc * 128, +128): 4 x 4 fragments of
-//     v_mfma_f32_32x32x16_f16, 16 MFMAs (512 cycles of matrix pipe) per 16-wide k-step, four k-steps per K-tile;
-//   * the fragments of k-step s + 1 (8 ds_read_b128) are requested while the MFMAs of step s run, into the other fragment
-//     register set; the LDS-DMA loads of K-tile t + 2 are issued in the first steps after the tile's one barrier;
-//   * ONE barrier per K-tile, in front of k-step 3: behind it every wavefront has finished reading K-tile t (its buffer is free
-//     for tile t + 2) and -- each wavefront having waited for its own loads first -- K-tile t + 1 is complete.
-// Measured (profiles/r05_gemm_probe_w4.txt, 256 images, us; library / 8-phase / this): fc1 + GELU 1 260 / 1 100 / 1 202, qkv 683 / 702 /
-// 768, projection 294 / 286 / 315, fc2 976 / 1 050 / 1 202 -- correct on the first run (80 tests, race screen clean), and 10-15 %
-// SLOWER than the 8-wavefront kernel: without a partner wavefront the issue of an LDS-DMA load (~60 cycles each, 16 per K-tile),
-// the lgkmcnt wait in front of every k-step and the barrier + vmcnt(0) of every K-tile all stand in the one instruction stream that
-// also feeds the matrix pipe; hipcc weaves the fragment reads between the MFMAs as asked (sched_group_barrier) but serialises the
-// loads on M0.  The library's kernel is this structure with a hand-scheduled instruction stream.  Kept as VLFM_GEMM_VARIANT=6 for A/B.
-
-template <int EPI, int G0, int G1, int G2, int G3>
-struct GemmW4 {
-    static constexpr int KBUF = 2 * OPER;          // one K-tile: W tile (32 KB) + X tile (32 KB)
-    const GemmArgs& a;
-    lds_ptr lds;
-    const unsigned char* smem;
-    int wave, lane;
-    uint32_t voffP[8], voffQ[8];    // this lane's 16 bytes of each of the wavefront's 8 + 8 row chunks (8 rows x 128 B) of a K-tile
-    uint32_t rdP[4], rdQ[4];        // fragment read offsets by k-step (the swizzle turns the k-step into an XOR of 32 B)
-    half8 fa[2][4], fb[2][4];
-    f32x16 acc[4][4];
-
-    __device__ GemmW4(const GemmArgs& a_, unsigned char* smem_, int m0, int n0) : a(a_), lds((lds_ptr)smem_), smem(smem_) {
-        const int tid = threadIdx.x;
-        lane = tid & 63;
-        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const int sub = lane >> 3, p = lane & 7;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int r = (wave * 8 + j) * 8 + sub;               // row of the tile
-            const int sl = p ^ ((r >> 1) & 7);
-            voffP[j] = (uint32_t)min(n0 + r, a.N - 1) * (uint32_t)a.K * 2u + (uint32_t)sl * 16u;
-            voffQ[j] = (uint32_t)min(m0 + r, a.M - 1) * (uint32_t)a.K * 2u + (uint32_t)sl * 16u;
-        }
-        const int wr = wave >> 1, wc = wave & 1;
-        const int r32 = lane & 31, swz = (r32 >> 1) & 7, hi = lane >> 5;
-        const uint32_t bp = (uint32_t)(wr * 128 + r32) * ROWB + (uint32_t)((hi ^ swz) << 4);
-        const uint32_t bq = (uint32_t)OPER + (uint32_t)(wc * 128 + r32) * ROWB + (uint32_t)((hi ^ swz) << 4);
-#pragma unroll
-        for (int ks = 0; ks < 4; ks++) { rdP[ks] = bp ^ (uint32_t)(ks << 5); rdQ[ks] = bq ^ (uint32_t)(ks << 5); }
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
-    }
-    // chunks [c0, c0 + n) of this wavefront's 16 (0-7: W rows, 8-15: X rows) of K-tile t -> buffer b
-    template <int C0, int N>
-    __device__ inline void stage(int b, int t) {
-        const unsigned char* bw = reinterpret_cast<const unsigned char*>(a.w) + (size_t)t * (GK * 2);
-        const unsigned char* bx = reinterpret_cast<const unsigned char*>(a.x) + (size_t)t * (GK * 2);
-#pragma unroll
-        for (int c = C0; c < C0 + N; c++) {
-            const int j = c & 7;
-            const int dst = __builtin_amdgcn_readfirstlane(b * KBUF + (c < 8 ? 0 : OPER) + (wave * 8 + j) * 1024);
-            if (c < 8) __builtin_amdgcn_global_load_lds((gbl_ptr)(bw + voffP[j]), lds + dst, 16, 0, 0);
-            else __builtin_amdgcn_global_load_lds((gbl_ptr)(bx + voffQ[j]), lds + dst, 16, 0, 0);
-        }
-    }
-    template <int B, int KS, int F>
-    __device__ inline void read_frags() {
-#pragma unroll
-        for (int i = 0; i < 4; i++) fa[F][i] = *reinterpret_cast<const half8*>(smem + B * KBUF + i * 32 * ROWB + rdP[KS]);
-#pragma unroll
-        for (int j = 0; j < 4; j++) fb[F][j] = *reinterpret_cast<const half8*>(smem + B * KBUF + j * 32 * ROWB + rdQ[KS]);
-    }
-    template <int F>
-    __device__ inline void mma() {
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[F][i], fb[F][j], acc[i][j], 0, 0, 0);
-    }
-    static __device__ inline void bar() {
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    }
-    // k-step KS of K-tile t (buffer B); its fragments are in register set F = KS & 1.  FULL: K-tiles t + 1 and t + 2 exist (the
-    // steady state: no branches, so that the scheduler may weave the fragment reads and the LDS-DMA loads between the MFMAs).
-    template <int B, int KS, int NG, int C0, bool FULL>
-    __device__ inline void step(int t, int NT) {
-        constexpr int F = KS & 1;
-        if constexpr (KS == 3) {
-            if (FULL || t + 1 < NT) {
-                // vmcnt(0): this wavefront's loads of K-tile t + 1 (nothing newer is in flight); lgkmcnt(0): its fragment reads of
-                // K-tile t (requested one k-step ago) have left the buffer that tile t + 2 is about to be written into
-                __builtin_amdgcn_s_waitcnt(0x0070);
-                bar();
-                read_frags<B ^ 1, 0, F ^ 1>();
-            }
-        } else {
-            read_frags<B, KS + 1, F ^ 1>();
-        }
-        // K-tile t + 2 goes into the buffer of K-tile t, free behind the barrier of k-step 3: its first G0 chunks in that step, the
-        // rest in k-steps 0..2 of K-tile t + 1 (whose "other" buffer that is)
-        if constexpr (NG > 0) {
-            const int tt = KS == 3 ? t + 2 : t + 1;
-            if (FULL || tt < NT) stage<C0, NG>(KS == 3 ? B : B ^ 1, tt);
-        }
-        mma<F>();
-        if constexpr (FULL) {
-            // weave: one fragment read behind each of the first eight MFMAs, one LDS-DMA load (two 64-bit adds, the M0 write, the
-            // load) behind each of the next NG; each MFMA occupies the pipe for 32 cycles and the wavefront's issue slot for 4
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-#pragma unroll
-            for (int k = 0; k < (NG < 8 ? NG : 8); k++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x004, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 8 - (NG < 8 ? NG : 8), 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    template <int B, bool FULL>
-    __device__ inline void tile(int t, int NT) {
-        step<B, 0, G1, G0, FULL>(t, NT);
-        step<B, 1, G2, G0 + G1, FULL>(t, NT);
-        step<B, 2, G3, G0 + G1 + G2, FULL>(t, NT);
-        step<B, 3, G0, 0, FULL>(t, NT);
-    }
-    __device__ inline void run(int m0, int n0) {
-        const int NT = a.K / GK;
-        GEMM_STAMP(0);
-        stage<0, 16>(0, 0);
-        if (NT > 1) {
-            stage<0, G0>(1, 1);                          // (the rest of K-tile 1 follows in k-steps 0..2 of K-tile 0)
-            if (G0 == 4) __builtin_amdgcn_s_waitcnt(0x0F74);
-            else if (G0 == 6) __builtin_amdgcn_s_waitcnt(0x0F76);
-            else __builtin_amdgcn_s_waitcnt(0x0F78);     // vmcnt(G0): K-tile 0 has landed
-        } else {
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-        }
-        bar();
-        GEMM_STAMP(1);
-        read_frags<0, 0, 0>();
-        __builtin_amdgcn_sched_barrier(0);
-        int t = 0;
-        for (; t + 3 < NT; t += 2) {       // K-tiles t + 1 and t + 2 exist for both tiles of the iteration
-            tile<0, true>(t, NT);
-            tile<1, true>(t + 1, NT);
-        }
-        for (; t < NT; t += 2) {
-            tile<0, false>(t, NT);
-            if (t + 1 < NT) tile<1, false>(t + 1, NT);
-        }
-        bar();
-        GEMM_STAMP(2);
-        store_tile_w4<EPI>(a, const_cast<unsigned char*>(smem), acc, wave, lane, m0, n0);
-#ifdef VLFM_PHASE_TIMING
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        GEMM_STAMP(3);
-    }
-};
-
-template <int EPI, int G0, int G1, int G2, int G3>
-__global__ __launch_bounds__(256, 1) void gemm_f16_w4_kernel(GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int tm, tn;
-    tile_of_block(a, tm, tn);
-    const int m0 = tm * GB, n0 = tn * GB;
-    GemmW4<EPI, G0, G1, G2, G3> g(a, smem, m0, n0);
-    g.run(m0, n0);
-}
-
 }  // namespace vlfm
 
 using namespace vlfm;
 
 // C = epilogue(X . W^T + bias), f16 in / f16 out / f32 accumulate.  epilogue: 0 = bias only, 1 = bias + exact (erf) GELU,
 // 2 = accumulate into C (C += X . W^T + bias: the residual-stream GEMMs).  K must be a multiple of 64, N a multiple of 8; M and N
-// tails are handled.  d_bias may be NULL.  Kernel: the 8-phase schedule; VLFM_GEMM_VARIANT=0 / 1 select the round-2 ping-pong /
-// lock-step kernels (A/B runs of tools/gemm_f16_probe.py; they do not implement epilogue 2), 2 / 3 the 8-phase kernel's two read schedules.
+// tails are handled.  d_bias may be NULL.  One kernel: the persistent 8-phase schedule, one workgroup per CU (a multiple of 8 of them).
 template <int EPI>
-static int launch_gemm(const GemmArgs& a, int variant, hipStream_t stream) {
-    if (variant == 7) {     // persistent 8-phase: one workgroup per CU (a multiple of 8 of them: see the kernel)
-        const void* fn = reinterpret_cast<const void*>(gemm_f16_8pp_kernel<EPI>);
-        static LdsOptIn optp;
-        if (!optp.ensure(fn, GEMM_LDS_P)) return fail(VLFM_ERR_HIP, "gemm_f16_nt: cannot opt in to the LDS size");
-        static int n_cu = 0;
-        if (n_cu == 0) {
-            int dev = 0, v = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 8)
-                v = 256;
-            n_cu = v & ~7;
-        }
-        const int nwg = a.tiles_m * a.tiles_n;
-        const dim3 grid(nwg < n_cu ? nwg : n_cu), block(512);
-        VLFM_TIMED(EPI == EPI_BIAS ? "gemm_f16_8pp_kernel<0>" : EPI == EPI_BIAS_GELU ? "gemm_f16_8pp_kernel<1>" : "gemm_f16_8pp_kernel<2>", stream);
-        VLFM_KLAUNCH((gemm_f16_8pp_kernel<EPI>), grid, block, GEMM_LDS_P, stream, a);
-        return check_launch("gemm_f16_8pp_kernel");
-    }
-    if (variant >= 6) {     // four wavefronts, one per SIMD (LDS-DMA loads of the next-but-one K-tile in the two k-steps behind the barrier)
-        const void* fn = reinterpret_cast<const void*>(gemm_f16_w4_kernel<EPI, 8, 8, 0, 0>);
-        constexpr int LDS4 = 4 * EPI_WAVE4 > 2 * BUF ? 4 * EPI_WAVE4 : 2 * BUF;
-        static LdsOptIn opt4;
-        if (!opt4.ensure(fn, LDS4)) return fail(VLFM_ERR_HIP, "gemm_f16_nt: cannot opt in to the LDS size");
-        const dim3 grid(a.tiles_m * a.tiles_n), block(256);
-        VLFM_TIMED(EPI == EPI_BIAS ? "gemm_f16_w4_kernel<0>" : EPI == EPI_BIAS_GELU ? "gemm_f16_w4_kernel<1>" : "gemm_f16_w4_kernel<2>", stream);
-        VLFM_KLAUNCH((gemm_f16_w4_kernel<EPI, 8, 8, 0, 0>), grid, block, LDS4, stream, a);
-        return check_launch("gemm_f16_w4_kernel");
-    }
-    const void* fn = variant == 0 ? reinterpret_cast<const void*>(gemm_f16_nt_kernel<EPI>)
-                   : variant == 1 ? reinterpret_cast<const void*>(gemm_f16_nt_lockstep_kernel<EPI>)
-                   : variant == 2 ? reinterpret_cast<const void*>(gemm_f16_8p_kernel<EPI, 0, 2>)
-                   : variant == 3 ? reinterpret_cast<const void*>(gemm_f16_8p_kernel<EPI, 1, 2>)
-                   : variant == 4 ? reinterpret_cast<const void*>(gemm_f16_8p_kernel<EPI, 0, 1>)
-                                  : reinterpret_cast<const void*>(gemm_f16_8p_kernel<EPI, 1, 1>);
-    static LdsOptIn opt[6];
-    if (!opt[variant].ensure(fn, GEMM_LDS)) return fail(VLFM_ERR_HIP, "gemm_f16_nt: cannot opt in to the LDS size");
-    const dim3 grid(a.tiles_m * a.tiles_n), block(512);
+static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
+    const void* fn = reinterpret_cast<const void*>(gemm_f16_8pp_kernel<EPI>);
+    static LdsOptIn optp;
+    if (!optp.ensure(fn, GEMM_LDS_P)) return fail(VLFM_ERR_HIP, "gemm_f16_nt: cannot opt in to the LDS size");
+    const int n_cu = device_cu_count() & ~7;       // per device (status.h): the grid and the XCD walk follow the CURRENT device
+    const int nwg = a.tiles_m * a.tiles_n;
+    const dim3 grid(nwg < n_cu ? nwg : n_cu), block(512);
     // (profile name by epilogue: in the ViT block 0 = qkv, 1 = fc1 + GELU, 2 = projection and fc2, one launch each)
-    VLFM_TIMED(variant < 2 ? "gemm_f16_nt_kernel" : EPI == EPI_BIAS ? "gemm_f16_8p_kernel<0>" : EPI == EPI_BIAS_GELU
-               ? "gemm_f16_8p_kernel<1>" : "gemm_f16_8p_kernel<2>", stream);
-    if (variant == 0) VLFM_KLAUNCH(gemm_f16_nt_kernel<EPI>, grid, block, GEMM_LDS, stream, a);
-    else if (variant == 1) VLFM_KLAUNCH(gemm_f16_nt_lockstep_kernel<EPI>, grid, block, GEMM_LDS, stream, a);
-    else if (variant == 2) VLFM_KLAUNCH((gemm_f16_8p_kernel<EPI, 0, 2>), grid, block, GEMM_LDS, stream, a);
-    else if (variant == 3) VLFM_KLAUNCH((gemm_f16_8p_kernel<EPI, 1, 2>), grid, block, GEMM_LDS, stream, a);
-    else if (variant == 4) VLFM_KLAUNCH((gemm_f16_8p_kernel<EPI, 0, 1>), grid, block, GEMM_LDS, stream, a);
-    else VLFM_KLAUNCH((gemm_f16_8p_kernel<EPI, 1, 1>), grid, block, GEMM_LDS, stream, a);
-    return check_launch("gemm_f16_nt_kernel");
+    VLFM_TIMED(EPI == EPI_BIAS ? "gemm_f16_8pp_kernel<0>" : EPI == EPI_BIAS_GELU ? "gemm_f16_8pp_kernel<1>" : "gemm_f16_8pp_kernel<2>", stream);
+    VLFM_KLAUNCH((gemm_f16_8pp_kernel<EPI>), grid, block, GEMM_LDS_P, stream, a);
+    return check_launch("gemm_f16_8pp_kernel");
 }
 
 extern "C" int vlfm_gemm_f16_nt(const void* d_x, const void* d_w, const void* d_bias, void* d_c, int m, int n, int k,
@@ -1142,20 +555,15 @@ extern "C" int vlfm_gemm_f16_nt(const void* d_x, const void* d_w, const void* d_
     a.x = (const _Float16*)d_x; a.w = (const _Float16*)d_w; a.bias = (const _Float16*)d_bias; a.c = (_Float16*)d_c;
     a.M = m; a.N = n; a.K = k;
     a.tiles_m = (m + GB - 1) / GB; a.tiles_n = (n + GB - 1) / GB;
-    // tile order (diagnostic override VLFM_GEMM_GROUP_M): groups of 8 m-tiles when there are many n-tiles (fc1, qkv), plain
-    // n-fastest order otherwise (measured: fc2 / projection shapes, 6 n-tiles, lose 5-8 % to the grouping)
-    const char* eg = getenv("VLFM_GEMM_GROUP_M");
-    a.group_m = eg ? atoi(eg) : (a.tiles_n >= 12 ? 8 : 1);
-    if (a.group_m < 1) a.group_m = 1;
-    a.split_ragged = getenv("VLFM_GEMM_NO_SPLIT") ? 0 : 1;
-    const char* ev = getenv("VLFM_GEMM_VARIANT");
-    int variant = ev ? atoi(ev) : GEMM_DEFAULT_VARIANT;
-    if (variant < 0 || variant > 7) variant = GEMM_DEFAULT_VARIANT;
-    if (variant == 7 && !eg) a.group_m = 4;   // persistent walk: groups of 4 m-tiles on every ViT shape (probe: 2-8 within 1 %, 1 and 16+ behind)
-    if (epilogue == 2 && variant < 2) return fail(VLFM_ERR_INVALID, "gemm_f16_nt: epilogue 2 needs an 8-phase kernel");
-    if (epilogue == 0) return launch_gemm<EPI_BIAS>(a, variant, (hipStream_t)stream);
-    if (epilogue == 1) return launch_gemm<EPI_BIAS_GELU>(a, variant, (hipStream_t)stream);
-    return launch_gemm<EPI_ACCUM>(a, variant, (hipStream_t)stream);
+    // tile order of the persistent walk: groups of 4 m-tiles on every ViT shape (probe: 2-8 within 1 %, 1 and 16+ behind); the two
+    // diagnostic switches are read once per process
+    static const int env_group_m = [] { const char* e = getenv("VLFM_GEMM_GROUP_M"); return e ? atoi(e) : 0; }();
+    static const bool env_no_split = getenv("VLFM_GEMM_NO_SPLIT") != nullptr;
+    a.group_m = env_group_m >= 1 ? env_group_m : 4;
+    a.split_ragged = env_no_split ? 0 : 1;
+    if (epilogue == 0) return launch_gemm<EPI_BIAS>(a, (hipStream_t)stream);
+    if (epilogue == 1) return launch_gemm<EPI_BIAS_GELU>(a, (hipStream_t)stream);
+    return launch_gemm<EPI_ACCUM>(a, (hipStream_t)stream);
 }
 
 // The tile order of the 8-phase kernels, evaluated on the HOST (tests/test_gemm_tile_order_cpu.py: a bijection for every shape, the
