@@ -15,18 +15,18 @@ timed steps see a mid-episode map (explored area, obstacle planes, contour lengt
 independent: rank r owns the contiguous block of environments [r * envs, (r + 1) * envs) (weak scaling, --envs per GPU
 fixed); the only collectives are the two metric all-reduces at the end (RCCL).
 
-Prints ONE JSON line (rank 0) with the driver's keys plus:
-  roofline      the map-fusion kernel (value_map_update_fused_kernel): `frac` = HBM bytes the launch moves (PMC traffic from
-                profiles/pmc_traffic.json when this kernel was counted at this configuration, else the bytes it must move:
-                cells stored x 28 B + keys, counted in this run) / mean launch time (dispatch timestamps on the launch
-                stream, inside the timed region) / 8 TB/s -- always a bandwidth fraction, never above 1; SURVEY 8d's
-                pricing of the reference's whole window is `reference_window_equivalent_frac`; `bound` from `frac`
-  roofline_depth_pass   the same block for depth_ingest_scatter_kernel, the one map kernel that streams HBM
-  small_batch   the reference's own geometries (configs[1], [2], [3], [4] per GPU), PCIe-inclusive rate, map-kernel times
-                at episode steps 25 / 250 / 475
-  cpu_baseline  the reference-faithful CPU path (oracle/ NumPy+C restatement of the maps + the same ITC graph in fp32 on
-                the host cores): 20 warm-up + 5 x 40 timed map steps on 1 core (median of the 5), the same on every usable
-                core at once (whole box), BLIP-2 fp32 on the quota's threads; rank 0 at N=1 only
+Prints ONE JSON line (rank 0) with the driver's keys plus (one roofline vocabulary: `achieved` = SURVEY.md 8d's ALGORITHMIC bytes of
+the launch(es) / mean launch duration, `frac` = achieved / peak, `traffic` = HBM bytes per launch from the committed PMC runs or null;
+launch durations are HIP events on the dispatch itself, every n-th launch inside the timed region):
+  roofline             SURVEY 8d's value-map-update row (depth image + template + confidence / value RMW of the window) over the SUM
+                       of the two launches that execute it: depth_ingest_kernel (column maxima, shared with the obstacle map) +
+                       value_map_update_fused_kernel -- north_star's ">= 50 % of the HBM roofline on the map-fusion kernel"
+  roofline_cfg5        the same row at BASELINE configs[4]'s per-GPU geometry (16 envs, 1280x720, full-map explored sync)
+  roofline_depth_pass  the depth pass alone (4 H W bytes per observation)
+  roofline_mfma        the ViT-g fc1 + GELU GEMM (csrc/gemm_f16.hip) against the dense f16 MFMA peak
+  small_batch / full_step   the reference's own geometries (configs[1], [2], [3], [4] per GPU) and the PCIe-inclusive rate
+  cpu_baseline         the oracle (NumPy + C restatement of the maps + the same ITC graph in fp32) on the host cores, bounded sample
+DESIGN.md section 5 has the prose; the full record of a run goes to --detail.
 """
 from __future__ import annotations
 
@@ -324,72 +324,46 @@ def load_pmc():
         return {}
 
 
-def count_stored_cells(sim) -> float:
-    """Cells one value-map update of the CURRENT step really stores, per observation (mean): the same frames and poses
-    fused with fusion_type 'replace' into an empty scratch map leave a non-zero confidence exactly in the cells the
-    launch writes (new confidence != 0).  Outside the timed region."""
-    import torch
-
-    from vlfm_amd.mapping.value_map import ValueMapBatch
-    from vlfm_amd.synthetic import MAX_DEPTH, MIN_DEPTH
-
-    n = min(sim.E, 16)
-    depth = sim.current_depth(n)
-    tf = sim.tf_table[sim.t % sim.episode_len][:n]
-    scratch = ValueMapBatch(n, 1, sim.S, use_max_confidence=False, fusion_type="replace", device=sim.device)
-    scratch.update(torch.full((n, 1), 0.3, dtype=torch.float64), depth, tf, MIN_DEPTH, MAX_DEPTH, sim.fov)
-    return float((scratch.conf != 0).sum().item()) / n
-
-
-def map_roofline(kms, E, H, W, sync, stored_cells, pmc):
-    """Per HBM kernel: SURVEY.md 8d algorithmic bytes, the bytes the launch must really move, PMC traffic if committed."""
+def survey_bytes(H, W, sync):
+    """SURVEY.md 8d, algorithmic bytes per env-step (f32 maps, C = 1): the depth image once; the value-map row = depth + template +
+    confidence RMW + value RMW of the 201 x 201 window (or explored plane + full-map RMW with the explored-area sync)."""
     T, S = 2 * int(5.0 * 20) + 1, 1000
-    table = {}
+    depth = 4 * H * W
+    window = 4 * T * T + 16 * T * T
+    full = 4 * T * T + S * S + 16 * S * S
+    return {"depth": depth, "update": full if sync else window, "row": depth + (full if sync else window)}
 
-    def entry(name, window_equivalent, necessary, note):
-        """`frac` is ALWAYS a bandwidth fraction: PMC-measured HBM bytes per launch (profiles/pmc_traffic.json) when this kernel
-        was counted at this configuration, else the bytes the launch must move, / launch time / 8 TB/s.  SURVEY 8d's pricing of
-        the reference's whole window is kept under `reference_window_equivalent_*` (it is a speed-up-over-the-reference's-traffic
-        figure and can exceed 1; never under a key named `frac`)."""
-        if name not in kms:
-            return
-        sec = kms[name] * 1e-3
-        p = pmc.get(f"{name}@E={E},{W}x{H}" + (",sync" if sync else ""))
-        moved = p["bytes_per_launch"] if p else necessary
-        rec = {"launch_ms": round(kms[name], 5),
-               "frac_basis": "pmc_traffic" if p else "necessary_bytes",
-               "achieved": round(moved / sec / 1e9, 1), "frac": round(moved / sec / 1e9 / HBM_PEAK_GBS, 4),
-               "traffic": p["bytes_per_launch"] if p else None,
-               "necessary_bytes_per_launch": int(necessary),
-               "necessary_frac": round(necessary / sec / 1e9 / HBM_PEAK_GBS, 4), "necessary_note": note,
-               "traffic_over_necessary": round(p["bytes_per_launch"] / necessary, 3) if p and necessary else None,
-               "reference_window_equivalent_bytes_per_launch": int(window_equivalent),
-               "reference_window_equivalent_frac": round(window_equivalent / sec / 1e9 / HBM_PEAK_GBS, 4)}
-        table[name] = rec
 
-    depth_bytes = 4 * H * W
-    # one pass reads every texel ONCE for both maps: priced at the bytes it reads (SURVEY 8d prices 4*H*W per map because
-    # the reference reads the image twice; that "reference-equivalent" 8*H*W figure is not reported as a fraction any more)
-    entry("depth_ingest_scatter_kernel", E * depth_bytes, E * (depth_bytes + 4 * W),
-          "4*H*W texel reads + W column-max keys; obstacle-bit atomics not counted")
-    entry("depth_ingest_kernel", E * depth_bytes, E * (depth_bytes + 4 * W), "4*H*W texel reads + W keys")
-    entry("depth_scatter_kernel", E * depth_bytes, E * depth_bytes // 2, "only rows that can reach the height band are read")
-    window = 4 * T * T + 8 * T * T + 8 * T * T                      # template + conf RMW + value RMW (C = 1)
-    full = S * S + 8 * S * S + 8 * S * S + 4 * T * T                # explored + full-map conf/value RMW + template
-    need = stored_cells * (8 + 16 + 4) + 4 * W + ((2 * S * ((S + 31) // 32) * 4) if sync else 0)
-    entry("value_map_update_fused_kernel", E * (full if sync else window), E * need,
-          "cells stored x (8 B conf RMW + 16 B value RMW (f64, like the reference's promoted array) + 4 B template tap) + W keys"
-          + (" + explored and written bit planes" if sync else ""))
-    if "value_map_update_fused_kernel" in table:
-        # SURVEY 8d prices the value map at 4 B per cell; the reference's array -- and since round 3 the device's -- is f64
-        f64_bytes = E * ((full + 8 * S * S) if sync else (window + 8 * T * T))
-        rec = table["value_map_update_fused_kernel"]
-        rec["reference_window_equivalent_bytes_per_launch_f64_value"] = int(f64_bytes)
-        rec["reference_window_equivalent_frac_f64_value"] = round(
-            f64_bytes / (kms["value_map_update_fused_kernel"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-    entry("value_map_fuse_kernel", E * window, E * (stored_cells * 20 + 5632), "cells stored x 20 B + visibility plane")
-    entry("mask_unexplored_kernel", E * (S * S + 8 * S * S + 8 * S * S), E * S * 125, "explored bit plane only when nothing is cleared")
-    return table
+def map_roofline(kms, E, H, W, sync, pmc):
+    """One vocabulary for every HBM-priced figure: `achieved` = SURVEY 8d's ALGORITHMIC bytes of the launch / its mean duration
+    (GB/s), `frac` = achieved / 8 TB/s, `traffic` = HBM bytes per launch from the committed PMC runs (profiles/pmc_traffic.json) or
+    None.  Keys: the two kernels of the value-map row, and `row` = SURVEY 8d's value-map-update row (a6 + a9 + a10) priced over the
+    SUM of the two launches that execute it (depth pass: column maxima, shared with the obstacle map; fused update) -- the figure
+    north_star's ">= 50 % of the HBM roofline on the map-fusion kernel" is read against."""
+    b = survey_bytes(H, W, sync)
+    tag = f"@E={E},{W}x{H}" + (",sync" if sync else "")
+    depth_k = next((k for k in ("depth_ingest_scatter_kernel", "depth_ingest_kernel") if k in kms), None)
+    upd_k = next((k for k in ("value_map_update_fused_kernel", "value_map_fuse_kernel") if k in kms), None)
+
+    def rec(kernel, nbytes, ms, traffic):
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "launch_ms": round(ms, 5),
+                "algorithmic_bytes_per_launch": int(nbytes)}
+
+    def traffic_of(k):
+        p = pmc.get(k + tag)
+        return int(p["bytes_per_launch"]) if p else None
+
+    out = {}
+    if depth_k:
+        out["depth_pass"] = rec(depth_k, E * b["depth"], kms[depth_k], traffic_of(depth_k))
+    if upd_k:
+        out["update"] = rec(upd_k, E * b["update"], kms[upd_k], traffic_of(upd_k))
+    if depth_k and upd_k:
+        t = [traffic_of(depth_k), traffic_of(upd_k)]
+        out["row"] = rec(f"{depth_k} + {upd_k}", E * b["row"], kms[depth_k] + kms[upd_k], sum(t) if None not in t else None)
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ dry run
@@ -462,10 +436,8 @@ def _short_roofline(r):
     """Contract keys + the few figures a reader needs; numbers and enum strings only."""
     if not isinstance(r, dict):
         return None
-    keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_basis", "launch_ms",
-            "necessary_bytes_per_launch", "necessary_frac", "traffic_over_necessary", "reference_window_equivalent_frac",
-            "algorithmic_bytes_per_launch", "launches_timed", "flop_per_launch", "survey8d_row_bytes_per_env_step",
-            "survey8d_row_launch_ms_sum", "survey8d_row_frac")
+    keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "algorithmic_bytes_per_launch",
+            "launches_timed", "flop_per_launch")
     return {k: _num(r[k]) for k in keep if k in r}
 
 
@@ -518,6 +490,8 @@ def compact_line(out: dict) -> str:
             else:
                 continue   # per-phase kernel tables: detail only
             small[tag] = _leg(v)
+            if tag == "cfg5_16env_1280x720_sync" and isinstance(v, dict) and v.get("roofline"):
+                line["roofline_cfg5"] = _short_roofline(v["roofline"])     # SURVEY 8d's own ">= 4 TB/s at config 5" row
         line["small_batch"] = small
     fs = out.get("full_step")
     if isinstance(fs, dict):
@@ -534,7 +508,7 @@ def compact_line(out: dict) -> str:
     line["detail"] = out.get("detail")
     txt = json.dumps(line, separators=(",", ":"))
     if len(txt) > LINE_BUDGET:   # never print an unreadable line: shed the side legs, keep the contract
-        for k in ("small_batch", "host", "roofline_mfma", "roofline_depth_pass", "full_step"):
+        for k in ("small_batch", "host", "roofline_mfma", "roofline_depth_pass", "roofline_cfg5", "full_step"):
             line.pop(k, None)
             txt = json.dumps(line, separators=(",", ":"))
             if len(txt) <= LINE_BUDGET:
@@ -645,66 +619,19 @@ def main():
 
     torch.cuda.synchronize(device)
     kms = read_kernel_ms()
-    timed_launches = LAUNCHES_TIMED.get("value_map_update_fused_kernel", LAUNCHES_TIMED.get("value_map_fuse_kernel", 0))
-    gemm_kernel = "gemm_f16_8pp_kernel<1>"                     # the default (persistent) form; VLFM_GEMM_VARIANT=2..5: the one-tile form
+    gemm_kernel = "gemm_f16_8pp_kernel<1>"
     gemm_ms, gemm_n = _lib.profile_read(gemm_kernel)
-    if not gemm_n:
-        gemm_kernel = "gemm_f16_8p_kernel<1>"
-        gemm_ms, gemm_n = _lib.profile_read(gemm_kernel)
     _lib.lib().vlfm_profile_enable(0)
     if rank == 0:
         H, W, E = args.height, args.width, args.envs
-        stored = count_stored_cells(sim)
-        per_kernel = map_roofline(kms, E, H, W, args.sync_explored, stored, load_pmc())
-        # the kernel BASELINE.json's north_star names for the roofline target is the map-fusion kernel
-        name = "value_map_update_fused_kernel" if "value_map_update_fused_kernel" in per_kernel else "value_map_fuse_kernel"
-        head = per_kernel[name]
-        pmc_commit = str(load_pmc().get("_commit", "unknown"))
-
-        def block(name_, rec, what):
-            """One top-level roofline object (contract keys first)."""
-            return {"bound": "hbm" if rec["frac"] >= 0.3 else "latency", "priced_against": "hbm", "kernel": name_,
-                    "achieved": rec["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rec["frac"],
-                    "traffic": rec["traffic"], "frac_basis": rec["frac_basis"],
-                    "meaning": what,
-                    "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of tools/pmc_traffic.sh; null = not "
-                                      "collected for this kernel / configuration); produced by commit " + pmc_commit,
-                    "necessary_bytes_per_launch": rec["necessary_bytes_per_launch"], "necessary_frac": rec["necessary_frac"],
-                    "necessary_note": rec["necessary_note"], "traffic_over_necessary": rec["traffic_over_necessary"],
-                    "reference_window_equivalent_frac": rec["reference_window_equivalent_frac"],
-                    "launch_ms": rec["launch_ms"],
-                    "launch_ms_source": f"HIP events on the dispatch (hipExtLaunchKernelGGL), every {args.kernel_event_every}"
-                                        f". launch of each kernel in the timed region: "
-                                        f"{LAUNCHES_TIMED.get(name_, 0)} launches timed"}
-
-        roofline = block(name, head, (
-            "`frac` = HBM bytes this launch moves (PMC FETCH_SIZE + WRITE_SIZE per launch; `necessary_bytes_per_launch` when no "
-            "counter run is committed) / launch time / 8 TB/s: a BANDWIDTH fraction.  The map-fusion kernel stores only the cells of "
-            "the visible cone (`written & ~explored` bit planes instead of the reference's full-window / full-map passes), i.e. "
-            "about a tenth of what SURVEY 8d prices; `reference_window_equivalent_frac` is that pricing (the reference's window "
-            "bytes / our launch time) and says how much faster than a window-streaming kernel this is, not how busy HBM is.  "
-            "bound = latency: one wave of workgroups whose keys -> profile -> polygon -> fuse chain is the kernel time"))
-        roofline["stored_cells_per_observation"] = round(stored, 1)
-        # SURVEY 8d's value-map-update row (a6 + a9 + a10: depth image + template + confidence / value RMW of the window, or of the
-        # full map with the explored-area sync) is executed by TWO launches here -- the depth pass (column maxima; it also feeds the
-        # obstacle map) and the fused update -- so the row's algorithmic bytes are priced over the SUM of their launch times:
-        # the figure VERDICT r4 computes (0.37) and the one north_star's ">= 50 % HBM roofline" is read against
-        T_, S_ = 2 * int(5.0 * 20) + 1, 1000
-        row_bytes = (4 * H * W + 4 * T_ * T_ + (S_ * S_ + 16 * S_ * S_ if args.sync_explored else 16 * T_ * T_))
-        depth_k = next((k for k in ("depth_ingest_scatter_kernel", "depth_ingest_kernel") if k in kms), None)
-        if depth_k and name in kms:
-            row_ms = kms[depth_k] + kms[name]
-            roofline["survey8d_row_bytes_per_env_step"] = int(row_bytes)
-            roofline["survey8d_row_launch_ms_sum"] = round(row_ms, 5)
-            roofline["survey8d_row_frac"] = round(E * row_bytes / (row_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-        roofline["hbm_kernels"] = per_kernel
+        # north_star's roofline target is the map-fusion kernel: SURVEY 8d's value-map row over the two launches that execute it
+        rf = map_roofline(kms, E, H, W, args.sync_explored, load_pmc())
+        roofline = dict(rf.get("row") or rf.get("update") or {"bound": "hbm", "kernel": None, "achieved": None, "peak": HBM_PEAK_GBS,
+                                                               "unit": "GB/s", "frac": None, "traffic": None})
+        roofline["update_kernel"] = rf.get("update")
+        roofline["launches_timed"] = LAUNCHES_TIMED.get("value_map_update_fused_kernel", 0)
         roofline["all_kernels_ms"] = {k: round(v, 5) for k, v in kms.items()}
-        depth_name = next((k for k in ("depth_ingest_scatter_kernel", "depth_ingest_kernel") if k in per_kernel), None)
-        roofline_depth = None
-        if depth_name:
-            roofline_depth = block(depth_name, per_kernel[depth_name], (
-                "the one map kernel that STREAMS HBM: every depth texel of every environment once per step (4*H*W B + the "
-                "column-maximum keys), feeding both maps; `frac` as above (PMC traffic when committed)"))
+        roofline_depth = rf.get("depth_pass")
         # the kernel the STEP is made of: the ViT-g's fc1 + GELU GEMM on csrc/gemm_f16.hip (the other three GEMMs of a block are
         # hipBLASLt's and carry no events of ours), timed by the same dispatch events, priced against the dense f16 MFMA peak
         roofline_mfma = None
@@ -875,12 +802,10 @@ def side_legs(args, sim, device, common):
         dt = timed(s5, 0, 20)
         kms5 = read_kernel_ms()
         _lib.lib().vlfm_profile_enable(0)
-        stored = count_stored_cells(s5)
+        rf5 = map_roofline(kms5, 16, 720, 1280, True, load_pmc())
         side["configs[4] per-GPU geometry: 16 envs, 1280x720, explored-area sync"] = {
             "value": round(16 / dt, 2), "unit": "env-steps/s", "ms_per_step": round(dt * 1e3, 3),
-            "value_map_update": "split (3 launches)" if s5.values.split_update else "single launch",
-            "stored_cells_per_observation": round(stored, 1),
-            "hbm_kernels": map_roofline(kms5, 16, 720, 1280, True, stored, load_pmc()),
+            "roofline": rf5.get("row"), "roofline_kernels": rf5,
             "all_kernels_ms": {k: round(v, 5) for k, v in kms5.items()}}
         del s5
 

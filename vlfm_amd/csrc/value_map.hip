@@ -1334,9 +1334,10 @@ extern "C" int vlfm_value_map_update_fused_batched(uint32_t* d_colmax_keys, int 
     FusedExtra fx{d_written_bits, d_counters, d_conf_quadrant, 0, 0};
     const int T = template_size, words = (T + 31) >> 5;
     const int n_vert = width + 2, Q = T / 2 + 1;
-    size_t lds = (size_t)(2 * T * words + ((2 * T * words) & 1)) * 4 + (size_t)n_vert * sizeof(int2) +
-                       (size_t)(n_vert + 1 + ((n_vert + 1) & 1)) * sizeof(int) + (size_t)(Q * Q + ((Q * Q) & 1)) * 4 +
-                       (size_t)T * sizeof(int2);
+    const size_t lds_base = (size_t)(2 * T * words + ((2 * T * words) & 1)) * 4 + (size_t)n_vert * sizeof(int2) +
+                            (size_t)(n_vert + 1 + ((n_vert + 1) & 1)) * sizeof(int) + (size_t)(Q * Q + ((Q * Q) & 1)) * 4 +
+                            (size_t)T * sizeof(int2);
+    size_t lds = lds_base;
     if (lds > 150 * 1024) return fail(VLFM_ERR_CAPACITY, "value_map_update_fused_batched: template/width too large for LDS");
     // the cell list takes what is left, up to 8192 entries (a 79-degree cone at 5 m marks ~3 000 cells; VLFM_VM_LIST=0: fuse in place)
     static const int list_override = [] { const char* e = getenv("VLFM_VM_LIST"); return e ? atoi(e) : -1; }();
@@ -1345,6 +1346,7 @@ extern "C" int vlfm_value_map_update_fused_batched(uint32_t* d_colmax_keys, int 
         if (cap > 8192) cap = 8192;
         if (list_override >= 0 && (size_t)list_override < cap) cap = (size_t)list_override;
         if (cap < 1024) cap = 0;
+        if (map_size >= 65535 || T >= 65536) cap = 0;   // a list entry packs (row << 16) | col of a MAP cell, 0xFFFFFFFF is the sentinel
         fx.list_cap = (int)cap;
         lds += cap * sizeof(uint2);
         // block-sparse sweep: the column table + one list entry for EVERY 4 x 4 block of the window (VLFM_VM_BLOCKS=0: tile sweep)
@@ -1365,7 +1367,14 @@ extern "C" int vlfm_value_map_update_fused_batched(uint32_t* d_colmax_keys, int 
         static LdsOptIn opt1, opt0;
         const bool ok = channels == 1 ? opt1.ensure(reinterpret_cast<const void*>(value_map_update_fused_kernel<1>), 150 * 1024)
                                       : opt0.ensure(reinterpret_cast<const void*>(value_map_update_fused_kernel<0>), 150 * 1024);
-        if (!ok) return fail(VLFM_ERR_HIP, "value_map_update_fused_batched: cannot opt in to large LDS");
+        if (!ok) {
+            // no large LDS on this device: without the cell and block lists the base layout may still fit the default 64 KB
+            // (fuse every tile in place, the tile sweep): slower, same results
+            if (lds_base > 64 * 1024) return fail(VLFM_ERR_HIP, "value_map_update_fused_batched: cannot opt in to large LDS");
+            fx.list_cap = 0;
+            fx.block_cap = 0;
+            lds = lds_base;
+        }
     }
     const int tiles = (T + ROWS_PER_TILE - 1) / ROWS_PER_TILE;
     // workgroups per observation: a 1024-thread workgroup fills a CU (register budget), so aim for one per CU over all

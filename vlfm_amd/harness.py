@@ -22,6 +22,7 @@ vlfm_amd/distributed.py); the only collective is the metric all-reduce in bench.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -293,10 +294,8 @@ class BatchedEpisodes:
         # mode is box- or run-dependent) against 819-828 at priority -1; at 64 environments the priority costs 7 % (746-767 -> 702-715:
         # there the forward is the shorter part and is the one being pushed aside), so it is not set below 128.
         # VLFM_SIDE_PRIORITY overrides (diagnostic).
-        import os as _os
-
         full_step = detector is not None and object_maps
-        prio = int(_os.environ["VLFM_SIDE_PRIORITY"]) if "VLFM_SIDE_PRIORITY" in _os.environ else (-1 if n_envs >= 128 and full_step else 0)
+        prio = int(os.environ["VLFM_SIDE_PRIORITY"]) if "VLFM_SIDE_PRIORITY" in os.environ else (-1 if n_envs >= 128 and full_step else 0)
         self.map_stream = torch.cuda.Stream(self.device, priority=prio) if overlap else None
         self.obj_stream = torch.cuda.Stream(self.device, priority=prio) if overlap else None
         # (the object stream alone at priority -1: 790-796; both: 819-828; the headline -- no detector -- keeps priority 0: -0.3 % with it)
@@ -306,8 +305,6 @@ class BatchedEpisodes:
         # env-steps/s at 8 environments (YOLOv7-E6E), 184 -> 185 with GroundingDINO, 783 -> 672 at 64: no gain -- the 8-environment
         # step is bound by the host's launch rate and its read-backs, not by GPU occupancy -- so it is OFF by default; the
         # equivalence test (tests/test_full_step_gpu.py) keeps the path honest.
-        import os
-
         if os.environ.get("VLFM_VLM_BESIDE") is not None:      # diagnostic override (A/B runs): 0 = never, n = up to n environments
             concurrent_vlm_max_envs = int(os.environ["VLFM_VLM_BESIDE"])
         self.vlm_stream = torch.cuda.Stream(self.device) if overlap and n_envs <= concurrent_vlm_max_envs else None
@@ -386,23 +383,26 @@ class BatchedEpisodes:
         gain = min(in_hw[0] / self.H, in_hw[1] / self.W)
         padx, pady = (in_hw[1] - self.W * gain) / 2, (in_hw[0] - self.H * gain) / 2
         rows = np.zeros((len(sg), K, pred.shape[2]), np.float32)
-        jit = np.random.Generator(np.random.PCG64(4242 + t_ep)).uniform(-2.0, 2.0, size=(len(sg), K, 4)).astype(np.float32)
+        # jitter of the suppressed copies: at most +-2 network pixels, scaled down for small boxes so that every copy keeps an IoU
+        # above the NMS threshold (0.45) with the scripted box -- a copy that drifted below it would survive as a second detection
+        jit = np.random.Generator(np.random.PCG64(4242 + t_ep)).uniform(-1.0, 1.0, size=(len(sg), K, 4)).astype(np.float32)
         jit[:, 0] = 0.0
         used = {}
         dst_e, dst_r = [], []
         for n, (e, phrase, conf, (cx, cy, ax, ay), _) in enumerate(sg):
             cls = COCO_CLASSES.index(phrase)
-            rows[n, :, 0] = cx * gain + padx + jit[n, :, 0]
-            rows[n, :, 1] = cy * gain + pady + jit[n, :, 1]
-            rows[n, :, 2] = 2 * ax * gain + jit[n, :, 2]
-            rows[n, :, 3] = 2 * ay * gain + jit[n, :, 3]
+            amp = min(2.0, 0.05 * 2 * min(ax, ay) * gain)          # 5 % of the smaller side: IoU of a jittered copy >= ~0.8
+            rows[n, :, 0] = cx * gain + padx + amp * jit[n, :, 0]
+            rows[n, :, 1] = cy * gain + pady + amp * jit[n, :, 1]
+            rows[n, :, 2] = 2 * ax * gain + amp * jit[n, :, 2]
+            rows[n, :, 3] = 2 * ay * gain + amp * jit[n, :, 3]
             rows[n, :, 4] = 1.0
             rows[n, :, 5 + cls] = conf * np.concatenate([[1.0], np.linspace(0.97, 0.75, K - 1)])   # conf = objectness x class score
             base = used.get(e, 0)
             used[e] = base + K
             dst_e += [e] * K
             dst_r += list(range(base, base + K))
-        pred = pred.clone() if pred.requires_grad else pred
+        # (written in place: the prediction is the detector's own scratch output of this step, produced under inference_mode)
         pred[torch.tensor(dst_e, device=pred.device), torch.tensor(dst_r, device=pred.device)] = \
             torch.from_numpy(rows.reshape(-1, rows.shape[2])).to(pred.device, pred.dtype)
         return pred
@@ -646,8 +646,6 @@ class BatchedEpisodes:
     def _log_finished_episodes(self) -> None:
         """One JSON file per finished episode in the reference's log format (vlfm/utils/log_saver.py:9-22) when
         ZSOS_LOG_DIR is set: what the reference's eval loop writes through episode_stats_logger.log_episode_stats."""
-        import os
-
         if "ZSOS_LOG_DIR" not in os.environ:
             return
         from .utils.log_saver import is_evaluated, log_episode

@@ -84,7 +84,8 @@ def _default_hip_gemms() -> frozenset:
     if v in ("none", ""):
         return frozenset()
     names = frozenset(t.strip() for t in v.split(","))
-    assert names <= {"qkv", "proj", "fc1", "fc2"}, f"VLFM_VIT_GEMMS={v!r}"
+    if not names <= {"qkv", "proj", "fc1", "fc2"}:
+        raise ValueError(f"VLFM_VIT_GEMMS={v!r}: expected all, none or a comma list of qkv, proj, fc1, fc2")
     return names
 
 
@@ -138,12 +139,21 @@ class _VitBlock(nn.Module):
                         hp, float(hd) ** -0.5)
 
     def hip_gemms_at(self, rows: int) -> frozenset:
-        """The GEMMs of this block that run on csrc/gemm_f16.hip for an activation of ``rows`` rows: the configured set when the
-        batch is large enough for 256 x 256 tiles to fill the chip and the shapes meet the kernel's constraints (f16, K % 64, N % 8)."""
-        d = self.qkv.in_features
-        ok = (self.hip_mlp_min_rows and rows >= self.hip_mlp_min_rows and self.fc1.weight.dtype == torch.float16 and d % 64 == 0
-              and self.fc1.out_features % 64 == 0 and self.qkv.out_features % 8 == 0 and x_is_contiguous_f16(self.fc1.weight))
-        return self.hip_gemms if ok else frozenset()
+        """The GEMMs of this block that run on csrc/gemm_f16.hip for an activation of ``rows`` rows: those of the configured set whose
+        OWN operands meet the kernel's constraints (f16, contiguous, K % 64, N % 8, bias f16 or absent), once the batch is large enough
+        for 256 x 256 tiles to fill the chip.  Anything else goes to hipBLASLt -- per GEMM, never an assertion inside the forward."""
+        from . import ops
+
+        if not (self.hip_mlp_min_rows and rows >= self.hip_mlp_min_rows):
+            return frozenset()
+        layers = {"qkv": self.qkv, "proj": self.projection, "fc1": self.fc1, "fc2": self.fc2}
+
+        def ok(lin: nn.Linear) -> bool:
+            w, b = lin.weight, lin.bias
+            return (x_is_contiguous_f16(w) and w.shape[1] % 64 == 0 and w.shape[0] % 8 == 0 and w.numel() * 2 < (1 << 32)
+                    and rows * max(w.shape) * 2 < (1 << 32) and (b is None or x_is_contiguous_f16(b)))
+
+        return frozenset(n for n in self.hip_gemms if ok(layers[n]))
 
     def forward_deferred(self, x: torch.Tensor, c_in: torch.Tensor, c_mid: torch.Tensor) -> torch.Tensor:
         """Same block, residual adds folded into the GEMMs: ``x`` is the residual stream MINUS the bias vectors of all
@@ -177,7 +187,7 @@ class _VitBlock(nn.Module):
                 warnings.warn(f"vlfm_vit_attention_f16 unavailable ({exc}); using the library attention kernel instead")
                 self.hip_attention = False
         if a is not None:
-            if "proj" in hip:
+            if "proj" in hip and x2.is_contiguous():
                 ops.linear_f16(a, self.projection.weight, None, "accumulate", out=x2)     # x += a Wp^T, summed in f32
             else:
                 x2.addmm_(a, self.projection.weight.t())
@@ -195,7 +205,7 @@ class _VitBlock(nn.Module):
             act = ops.linear_gelu(h.view(b * n, d), self.fc1.weight, self.fc1.bias)   # GELU in the GEMM epilogue
         else:
             act = F.gelu(F.linear(h, self.fc1.weight, self.fc1.bias)).view(b * n, -1)
-        if "fc2" in hip:
+        if "fc2" in hip and x2.is_contiguous():
             ops.linear_f16(act, self.fc2.weight, None, "accumulate", out=x2)
         else:
             x2.addmm_(act, self.fc2.weight.t())
