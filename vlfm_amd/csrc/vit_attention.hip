@@ -19,10 +19,11 @@
 //   * the MFMA-friendly head width 96 exists only as zeros in the Q registers; global memory and LDS hold the native 88 channels.
 //
 // 4 x 257^2 x 88 flop and 180 KB of traffic per (image, head): 95 GFLOP and 741 MB at 256 images.  What bounds it is the memory
-// side: the rows of a head are 176-byte pieces at a stride of 8 448 B (in) / 2 816 B (out), which this chip serves at 4.5 TB/s
-// for the reads alone and 3.9 TB/s with the writes (the kernel with everything but its memory traffic compiled out runs 192 us,
-// with the traffic compiled out 115 us, the product 231 us; a head-major qkv layout would read at 5.9 TB/s --
-// profiles/r06_vit_attention_stub_probe.txt).
+// side: the rows of a head are 176-byte pieces at a stride of 8 448 B (in) / 2 816 B (out).  With everything but the memory traffic
+// compiled out the kernel runs 190 us (220 with no waits or barriers at all: it is the issue rate of this access pattern, 556 MB of
+// loads at 4.5 TB/s + 185 MB of stores), with the traffic compiled out 105 us, the product 231 us -- round 5's kernel: 299.  Reading
+// qkv head-major would stream the loads at 5.9 TB/s (memory side 139 us with a head-major output too), but the GEMMs on either side
+// are the library's and write / read token-major (profiles/r06_vit_attention_stub_probe.txt).
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -83,14 +84,22 @@ typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
 typedef short short8v __attribute__((__vector_size__(8 * sizeof(short))));
 using half2_t = __attribute__((ext_vector_type(2))) _Float16;
 
+#ifdef PA_FREE_RUN     // timing experiment only (with PA_STUB=4): no waits, no barriers inside the item loop -- the memory side's issue rate alone
+#define PA_WAIT_VM(n) do {} while (0)
+#else
 #define PA_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))   /* vmcnt(n), n < 64 */
+#endif
 #define PA_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
+#ifdef PA_FREE_RUN
+#define PA_BARRIER() asm volatile("" ::: "memory")
+#else
 #define PA_BARRIER()                               \
     do {                                           \
         asm volatile("" ::: "memory");             \
         __builtin_amdgcn_s_barrier();              \
         asm volatile("" ::: "memory");             \
     } while (0)
+#endif
 
 // reductions over the 16 lanes of a DPP row (quad swaps, then the two mirrors): every lane ends with the row's result
 #define PA_DPP(x, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xF, 0xF, true))
@@ -283,43 +292,28 @@ __global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _
         }
         if (PA_STUB < 3 && t_prev >= 0) merge_odd(t_prev, (n + 1) & 1);
         PA_STAMP(3);
-        // ---- the odd query (row 0 of the Q image) against keys 32 wave .. 32 wave + 31 (+ key 256 in wavefront 7) on the VALU, ahead of
-        // the MFMAs in program order so that its reductions run in their shadow: lane (col, grp) takes channels 48 grp .. of key
-        // 32 wave + col (the upper half has 40: its 6th slot is masked)
+        // ---- the odd query (row 0 of the Q image) against keys 32 wave .. 32 wave + 31 (+ key 256: every wavefront computes it, the last
+        // one uses it) on the VALU, BETWEEN the MFMAs of QK^T below (one 16-byte slot per three contraction steps): lane (col, grp)
+        // takes channels 48 grp .. of key 32 wave + col (the upper half has 40: its 6th slot is masked)
         float* mine = reinterpret_cast<float*>(at_lds + PA_PART_OFF) + ((n & 1) * AT_WAVES + wave) * PA_PART;
-        if (PA_STUB < 3) {
-            float ps, p2 = 0.0f;
-            const unsigned char* q0 = at_lds + ob + 96 * grp;
-            const unsigned char* kr = at_lds + kb + (32 * wave + col) * PA_KROW + 96 * grp;
-            const unsigned char* kl = at_lds + kb + 256 * PA_KROW + 96 * grp;
-            float s = 0.0f, s2 = 0.0f;
+        const unsigned char* oq0 = at_lds + ob + 96 * grp;
+        const unsigned char* okr = at_lds + kb + (32 * wave + col) * PA_KROW + 96 * grp;
+        const unsigned char* okl = at_lds + kb + 256 * PA_KROW + 96 * grp;
+        float os = 0.0f, os2 = 0.0f;
+        auto odd_score_slot = [&](int i) {
+            half8_t qv = *reinterpret_cast<const half8_t*>(oq0 + 16 * i);
+            if (i == 5 && grp) {
 #pragma unroll
-            for (int i = 0; i < 6; i++) {
-                half8_t qv = *reinterpret_cast<const half8_t*>(q0 + 16 * i);
-                if (i == 5 && grp) {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) qv[j] = (_Float16)0.0f;
-                }
-                const half8_t kv = *reinterpret_cast<const half8_t*>(kr + 16 * i);
-#pragma unroll
-                for (int e = 0; e < 4; e++) s = __builtin_amdgcn_fdot2(half2_t{qv[2 * e], qv[2 * e + 1]}, half2_t{kv[2 * e], kv[2 * e + 1]}, s, false);
-                const half8_t k2 = *reinterpret_cast<const half8_t*>(kl + 16 * i);      // (key 256: every wavefront, no branch; used by the last)
-#pragma unroll
-                for (int e = 0; e < 4; e++) s2 = __builtin_amdgcn_fdot2(half2_t{qv[2 * e], qv[2 * e + 1]}, half2_t{k2[2 * e], k2[2 * e + 1]}, s2, false);
+                for (int j = 0; j < 8; j++) qv[j] = (_Float16)0.0f;
             }
-            s += __shfl_xor(s, 32, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            const bool last = wave == AT_WAVES - 1;
-            float m = row16_max(s);
-            m = fmaxf(m, __shfl_xor(m, 16, 64));
-            m = fmaxf(m, last ? s2 : m);
-            p2 = last ? __builtin_amdgcn_exp2f((s2 - m) * c) : 0.0f;
-            ps = __builtin_amdgcn_exp2f((s - m) * c);
-            float l = row16_sum(ps);
-            l += __shfl_xor(l, 16, 64);
-            if (grp == 0) reinterpret_cast<float*>(at_lds + PA_PS_OFF)[32 * wave + col] = ps;    // read back (broadcast) by the odd query's P V
-            if (lane == 0) { mine[96] = m; mine[97] = l + p2; mine[98] = p2; }
-        }
+            const half8_t kv = *reinterpret_cast<const half8_t*>(okr + 16 * i);
+            const half8_t k2 = *reinterpret_cast<const half8_t*>(okl + 16 * i);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                os = __builtin_amdgcn_fdot2(half2_t{qv[2 * e], qv[2 * e + 1]}, half2_t{kv[2 * e], kv[2 * e + 1]}, os, false);
+                os2 = __builtin_amdgcn_fdot2(half2_t{qv[2 * e], qv[2 * e + 1]}, half2_t{k2[2 * e], k2[2 * e + 1]}, os2, false);
+            }
+        };
         PA_STAMP(4);
         // ---- S^T = K Q^T for the wavefront's 32 queries: 9 key tiles x 6 contraction steps; the 7 V pieces of this item in between
         f32x16_t acc[AT_KT];
@@ -351,8 +345,23 @@ __global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _
                     for (int u = 0; u < 3; u++) a_cur[u] = a_nxt[u];
                     const int step = 2 * g0 + kk;          // 0 .. 17
                     if (step >= 1 && step <= 13 && (step & 1)) v_piece(base, step >> 1);     // 7 pieces at steps 1, 3, .., 13
+                    if (PA_STUB < 3 && step % 3 == 0) odd_score_slot(step / 3);              // 6 slots at steps 0, 3, .., 15
                 }
             }
+        }
+        if (PA_STUB < 3) {      // the odd query's 32 scores -> probabilities against the wavefront's own maximum (merged later)
+            float s = os + __shfl_xor(os, 32, 64);
+            const float s2 = os2 + __shfl_xor(os2, 32, 64);
+            const bool last = wave == AT_WAVES - 1;
+            float m = row16_max(s);
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, last ? s2 : m);
+            const float p2 = last ? __builtin_amdgcn_exp2f((s2 - m) * c) : 0.0f;
+            const float ps = __builtin_amdgcn_exp2f((s - m) * c);
+            float l = row16_sum(ps);
+            l += __shfl_xor(l, 16, 64);
+            if (grp == 0) reinterpret_cast<float*>(at_lds + PA_PS_OFF)[32 * wave + col] = ps;    // read back (broadcast) by the odd query's P V
+            if (lane == 0) { mine[96] = m; mine[97] = l + p2; mine[98] = p2; }
         }
         PA_STAMP(5);
         // ---- C: every wavefront is done with K (and with the odd query's row, and has read its staged rows out of the other buffer)
@@ -396,28 +405,18 @@ __global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _
         PA_STAMP(7);
         PA_BARRIER();
         PA_STAMP(8);
-        // ---- the odd query's share of P V (ahead of the MFMAs in program order): lane = channel pair, its 32 probabilities are read
-        // back from LDS (one address per instruction: a broadcast)
-        if (PA_STUB < 3 || PA_STUB == 6) {
-            const int cp = min(lane, 47);
-            const unsigned char* vr = at_lds + PA_V_OFF + (32 * wave) * PA_VROW + 4 * cp;
-            const float* pr = reinterpret_cast<const float*>(at_lds + PA_PS_OFF) + 32 * wave;
-            float o0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, o1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int k = 0; k < 32; k++) {
-                const float pk = pr[k];
-                const half2_t vv = *reinterpret_cast<const half2_t*>(vr + k * PA_VROW);
-                o0[k & 3] = fmaf(pk, (float)vv[0], o0[k & 3]);
-                o1[k & 3] = fmaf(pk, (float)vv[1], o1[k & 3]);
-            }
-            {       // key 256: p2 is zero except in the last wavefront
-                const half2_t vv = *reinterpret_cast<const half2_t*>(at_lds + PA_V_OFF + 256 * PA_VROW + 4 * cp);
-                const float p2 = mine[98];
-                o0[0] = fmaf(p2, (float)vv[0], o0[0]);
-                o1[0] = fmaf(p2, (float)vv[1], o1[0]);
-            }
-            if (lane < 48) *reinterpret_cast<float2*>(mine + 2 * lane) = float2{(o0[0] + o0[1]) + (o0[2] + o0[3]), (o1[0] + o1[1]) + (o1[2] + o1[3])};
-        }
+        // ---- the odd query's share of P V runs BETWEEN the PV MFMAs below (two keys per 16-key chunk): lane = channel pair, its 32
+        // probabilities are read back from LDS (one address per instruction: a broadcast)
+        const int cp = min(lane, 47);
+        const unsigned char* ovr = at_lds + PA_V_OFF + (32 * wave) * PA_VROW + 4 * cp;
+        const float* opr = reinterpret_cast<const float*>(at_lds + PA_PS_OFF) + 32 * wave;
+        float oo0[2] = {0.0f, 0.0f}, oo1[2] = {0.0f, 0.0f};
+        auto odd_pv_key = [&](int k) {
+            const float pk = opr[k];
+            const half2_t vv = *reinterpret_cast<const half2_t*>(ovr + k * PA_VROW);
+            oo0[k & 1] = fmaf(pk, (float)vv[0], oo0[k & 1]);
+            oo1[k & 1] = fmaf(pk, (float)vv[1], oo1[k & 1]);
+        };
         PA_STAMP(9);
         // ---- O^T = V^T P^T: per 16-key chunk three channel tiles; the A operand (32 channels x 16 keys) comes out of the row-major V
         // by two ds_read_b64_tr_b16: a 16-lane group addresses a [4 keys][16 channels] block (lane j: key j >> 2, channels 4 (j & 3) ..)
@@ -451,7 +450,17 @@ __global__ __launch_bounds__(64 * AT_WAVES, 2) void vit_attention_kernel(const _
 #pragma unroll
                 for (int dt = 0; dt < AT_D / 32; dt++) v_cur[dt] = v_nxt[dt];
                 if (ch >= 2 && ch <= 12 && !(ch & 1)) k_piece(base_n, ob, (ch - 2) >> 1);     // the 6 K pieces of the next item
+                if (PA_STUB < 3 || PA_STUB == 6) {
+                    if (ch < 16) { odd_pv_key(2 * ch); odd_pv_key(2 * ch + 1); }
+                }
             }
+        }
+        if (PA_STUB < 3 || PA_STUB == 6) {       // key 256 (p2 is zero except in the last wavefront), then the partial sums
+            const half2_t vv = *reinterpret_cast<const half2_t*>(at_lds + PA_V_OFF + 256 * PA_VROW + 4 * cp);
+            const float p2 = mine[98];
+            oo0[0] = fmaf(p2, (float)vv[0], oo0[0]);
+            oo1[0] = fmaf(p2, (float)vv[1], oo1[0]);
+            if (lane < 48) *reinterpret_cast<float2*>(mine + 2 * lane) = float2{oo0[0] + oo0[1], oo1[0] + oo1[1]};
         }
         PA_STAMP(10);
         // ---- normalise; the rows stay in registers (f16) until the next item's Q has been read out of the buffer that stages them
