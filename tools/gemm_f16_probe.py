@@ -1,23 +1,22 @@
 """vlfm_gemm_f16_nt (hand-written MFMA GEMMs of csrc/gemm_f16.hip) against PyTorch / hipBLASLt: correctness on ragged shapes, a
 race screen (the 8-phase kernel keeps LDS-DMA loads in flight across barriers: a wrong wait count shows up as RARE wrong tiles), and
-interleaved A/B timing of the kernel variants on the four ViT-g GEMM shapes at 256 images, random operands.
+interleaved A/B timing against the library on the four ViT-g GEMM shapes at 256 images, random operands.  (Round 6: one kernel, the
+persistent 8-phase schedule; the superseded variants of rounds 2-5 and their A/B numbers: DESIGN.md 6c / 6g, profiles/r05_gemm_probe*.)
 
-    python tools/gemm_f16_probe.py [--quick] [--rounds 5]
-variants (VLFM_GEMM_VARIANT): 0 ping-pong (round 2), 1 lock-step, 2 8-phase (12/4/8/0 reads), 3 8-phase balanced (8/4/8/4)."""
+    python tools/gemm_f16_probe.py [--quick] [--rounds 5]"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.nn.functional as F
 from vlfm_amd import _lib
 ap = argparse.ArgumentParser(); ap.add_argument("--quick", action="store_true"); ap.add_argument("--rounds", type=int, default=5)
-ap.add_argument("--variants", default="0,2,3"); args = ap.parse_args()
+args = ap.parse_args()
 _lib.build()
 L = _lib.lib()
 dev = torch.device("cuda:0")
-VARIANTS = [int(v) for v in args.variants.split(",")]
+VARIANTS = [7]
 NAMES = {0: "ping-pong", 1: "lock-step", 2: "8-phase", 3: "8-phase-bal", 4: "8p-1bar", 5: "8p-bal-1bar", 6: "w4", 7: "8p-persist"}
 def ours(x, w, b, epi, variant, out=None):
-    os.environ["VLFM_GEMM_VARIANT"] = str(variant)
     M, K = x.shape; N = w.shape[0]
     c = out if out is not None else torch.empty((M, N), dtype=torch.float16, device=dev)
     _lib.check(L.vlfm_gemm_f16_nt(x.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None, c.data_ptr(), M, N, K, epi,
@@ -82,17 +81,6 @@ for name, N, K, epi in [("fc1+gelu", 6144, 1408, 1), ("qkv", 4224, 1408, 0), ("p
         ts = sorted(ts); med = ts[len(ts) // 2]
         line += f"{k} {med*1e6:7.1f} us ({fl/med/1e15:.3f} PF, min {ts[0]*1e6:.1f}) | "
     print(line)
-    # tile order: m-tiles per group (VLFM_GEMM_GROUP_M), 8-phase kernel
-    line = f"{name:9s} group_m sweep ({NAMES[VARIANTS[-1]]}): "
-    for gm in (1, 2, 4, 8, 16, 32):
-        os.environ["VLFM_GEMM_GROUP_M"] = str(gm)
-        fn = arms.get(NAMES[VARIANTS[-1]])
-        if fn is None: break
-        for _ in range(2): fn()
-        ts = sorted(t_once(fn, 5) for _ in range(3))
-        line += f"gm={gm}: {ts[1]*1e6:.1f} us | "
-    os.environ.pop("VLFM_GEMM_GROUP_M", None)
-    print(line)
 if not args.quick:
     # crossover against the library at small batches (fc1 + GELU), best 8-phase variant vs library
     for imgs in (1, 8, 16, 32, 64, 128):
@@ -103,5 +91,4 @@ if not args.quick:
         for v in VARIANTS:
             line += f"  {NAMES[v]} {t_once(lambda: ours(x, w, b, 1, v), 30)*1e6:7.1f} us"
         print(line)
-os.environ.pop("VLFM_GEMM_VARIANT", None)
 print("PROBE", "FAILED" if bad else "PASSED", f"({bad} wrong)")

@@ -24,7 +24,7 @@ __device__ inline float gelu_erf(float v) {
 
 // The same arithmetic on two values per lane in packed f32 (v_pk_fma_f32 / v_pk_mul_f32: one issue slot for both): 8 VALU
 // instructions per value instead of 13 -- the epilogue of fc1 is VALU-bound (128 values per lane, two wavefronts per SIMD, nothing
-// to overlap with: ~5.9 us of a ~46 us tile before, tools/gemm_stamp_probe.py).  Every operation is the scalar form's, in the same
+// to overlap with: ~5.9 us of a ~46 us tile before, round 5's stamp probe).  Every operation is the scalar form's, in the same
 // order (max(v, 0) as 0.5 (v + |v|), exact below 2^127): bit-identical results for every f32 input below 2^127
 // (tools/native/gelu_pk_check.hip sweeps all 2^32 bit patterns).
 typedef float floatx2 __attribute__((ext_vector_type(2)));

@@ -90,19 +90,8 @@ using gbl_ptr = const __attribute__((address_space(1))) unsigned char*;
 //   RAW: the wait of phase 4 -- before that phase's FIRST barrier -- leaves only the 4 loads of phases 3 and 4 (tile t + 2) in flight:
 //        tile t + 1 is complete as far as this wavefront's shares go; the early group reads it two barriers later, the late group
 //        three, and by then every wavefront has executed its own wait (the late group's sits one barrier behind the early group's).
-// Optional per-workgroup wall-clock stamps (diagnostic build with -DVLFM_PHASE_TIMING; tools/gemm_stamp_probe.py): thread 0 of
-// every workgroup records entry / prologue done / main loop done / epilogue done on the 100 MHz clock.
-#ifdef VLFM_PHASE_TIMING
-__device__ long long g_gemm_bar[2 * 512];    // workgroup 300 (a mid-launch one), wavefronts 0 and 4: shader clock behind each barrier
-__device__ long long g_gemm_clk[8192 * 4];
-#define GEMM_STAMP(k)                                                                                         \
-    do {                                                                                                      \
-        if (threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_clk[blockIdx.x * 4 + (k)] = wall_clock64();        \
-    } while (0)
-#else
-#define GEMM_STAMP(k) do {} while (0)
-#endif
-
+// (Round 5 instrumented this schedule with per-workgroup and per-barrier clock stamps -- tools/gemm_stamp_probe.py of that tree,
+// profiles/r05_gemm_stamps.txt; the instrumentation left with the one-tile kernel it was written for.)
 template <int EPI, int BAL, int SYNC = 2>
 struct Gemm8p {
     static constexpr int SLOT = 128 * ROWB;      // 16 KB
@@ -214,24 +203,10 @@ struct Gemm8p {
                     acc[PI * 4 + f][QJ * 2 + g] =
                         __builtin_amdgcn_mfma_f32_16x16x32_f16(fp[f][kk], fq[g][kk], acc[PI * 4 + f][QJ * 2 + g], 0, 0, 0);
     }
-#ifdef VLFM_PHASE_TIMING
-    int bar_count = 0;
-    __device__ inline void bar() {
-        const long long t_arrive = clock64();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (blockIdx.x == 300 && lane == 0 && (wave & 3) == 0 && bar_count < 256) {
-            g_gemm_bar[(wave >> 2) * 512 + 2 * bar_count] = t_arrive;
-            g_gemm_bar[(wave >> 2) * 512 + 2 * bar_count + 1] = clock64();
-        }
-        bar_count++;
-    }
-#else
     static __device__ inline void bar() {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
-#endif
     // [fragments + staging issued by the caller] | barrier | fragments have arrived | 16 MFMAs | barrier
     template <int PI, int QJ>
     __device__ inline void compute(const half8 (&fq)[2][2], bool work = true) {
@@ -334,7 +309,7 @@ __host__ __device__ inline void tile_of(const GemmArgs& a, int bid, int& tm, int
 // ------------------------------------------------------------------------------------------------ 8-phase, persistent
 // One workgroup per CU walks the tile list with stride gridDim.x (a multiple of 8: a workgroup stays on the XCD whose share of the
 // list it walks, and the tiles of one round are the neighbours the one-tile-per-workgroup launch would run together).  What a tile
-// costs outside its K loop in that launch (tools/gemm_stamp_probe.py: ~1.5 us from entry to the first MFMA -- a cold fetch of
+// costs outside its K loop in that launch (round 5's stamps: ~1.5 us from entry to the first MFMA -- a cold fetch of
 // K-tile 0 -- and ~3.6 us from the last MFMA to "stores have left", of 49-55 us) is taken off the critical path:
 //   * K-tile 0 of the NEXT tile is requested (8 global_load_lds per wavefront, buffer 0) right behind the last operand read of this
 //     one and lands while the epilogue does its arithmetic;
@@ -591,14 +566,3 @@ extern "C" int vlfm_gemm_f16_work_items(int m, int n, int grid, int* out, int ca
     for (int w = 0; w < work.nitems; w++) work.item(w, out[2 * w], out[2 * w + 1]);
     return work.nitems;
 }
-
-#ifdef VLFM_PHASE_TIMING
-extern "C" int vlfm_debug_gemm_barriers(long long* h_out1024) {
-    return hipMemcpyFromSymbol(h_out1024, HIP_SYMBOL(g_gemm_bar), sizeof(long long) * 1024) == hipSuccess ? VLFM_OK : VLFM_ERR_HIP;
-}
-extern "C" int vlfm_debug_gemm_clocks(long long* h_out, int n_workgroups) {
-    if (n_workgroups > 8192) n_workgroups = 8192;
-    return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_gemm_clk), sizeof(long long) * 4 * n_workgroups) == hipSuccess ? VLFM_OK
-                                                                                                               : VLFM_ERR_HIP;
-}
-#endif

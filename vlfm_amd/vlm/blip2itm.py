@@ -255,7 +255,7 @@ def _split_gemm(x16: torch.Tensor, pieces, bias: torch.Tensor, n_pieces: Optiona
     return o
 
 
-QFORMER_SPLIT_MIN_ROWS = 2048     # rows (images x 32 queries) from which the Q-Former's f32 Linears go to csrc/gemm_f32.hip
+QFORMER_SPLIT_MIN_ROWS = int(os.environ.get("VLFM_QFORMER_SPLIT_MIN_ROWS", "2048"))   # rows (images x 32 queries) from which the Q-Former's f32 Linears go to csrc/gemm_f32.hip
 
 
 def _qlinear(x: torch.Tensor, lin_w: torch.Tensor, lin_b, act=None, residual=None) -> torch.Tensor:
@@ -291,7 +291,7 @@ class _BertAttention(nn.Module):
         24), and X W^T is accumulated from three f16 x f16 -> f32 MFMA GEMMs, smallest term first.  Every product x * w_i is
         exact in f32 and the accumulation is f32, i.e. the same arithmetic class as an f32 GEMM on the same operands --
         measured against f64 it is 2.5x MORE accurate than the f32 GEMM (fewer roundings) and 1.5x faster
-        (tools/split_gemm_probe.py); gfx950 has no TF32-like mode and f32 MFMA runs at 1/16 of the f16 rate."""
+        (tools/split_gemm_probe.py, round-5 tree); gfx950 has no TF32-like mode and f32 MFMA runs at 1/16 of the f16 rate."""
         if self._kv_split is None or self._kv_split[0].device != kv16.device:
             w1, w2, w3 = _exact_split3(torch.cat([self.key.weight, self.value.weight]))
             bias = torch.cat([self.key.bias, self.value.bias]).detach().float()
