@@ -222,3 +222,36 @@ def test_harness_surfaces_off_map_obstacle_points_at_episode_end(gpu_device):
     with pytest.raises(IndexError):
         for _ in range(26):
             sim.step()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_random_angles_random_clutter_against_the_oracle(gpu_device, seed):
+    """the fog-of-war sector (cv2.ellipse polygon at an arbitrary integer-rounded heading), the shadow lines, the
+    visible-contour pick, the explored-area selection and the frontier tracing on RANDOM headings and RANDOM clutter instead of the
+    smooth tours of the trajectory tests: 40 steps per seed, each with a fresh uniformly random yaw (every fourth an exact or
+    one-ulp-off multiple of 45 degrees), a jump of up to 0.6 m, and a depth frame with 0-6 random near boxes (pillars and wall pieces at
+    random columns / ranges) in front of a far wall.  Planes and frontier pixels bit-exact after EVERY step."""
+    ours, ref = _pair(gpu_device)
+    rng = np.random.default_rng(1000 + seed)
+    x = y = 0.0
+    grown = 0
+    for step in range(40):
+        yaw = rng.uniform(-np.pi, np.pi)
+        if step % 4 == 3:
+            yaw = float(np.nextafter(int(rng.integers(-4, 5)) * np.pi / 4, [np.inf, -np.inf, 0.0][step % 3]))
+        x += rng.uniform(-0.6, 0.6)
+        y += rng.uniform(-0.6, 0.6)
+        d = depth_frame(rng)
+        if step % 3 != 2:
+            d[:] = np.maximum(d, np.float32(0.85))                        # a far wall ...
+        for _ in range(int(rng.integers(0, 7))):                          # ... with near clutter in front of it
+            c0 = int(rng.integers(0, 600)); w = int(rng.integers(4, 120))
+            r0 = int(rng.integers(0, 300)); h = int(rng.integers(40, 480 - r0))
+            d[r0:r0 + h, c0:c0 + w] = np.float32(rng.uniform(0.05, 0.7))
+        tf = pose_to_tf(x, y, yaw)
+        before = int(ref.explored_area.sum())
+        ours.update_map(d, tf, MIN_DEPTH, MAX_DEPTH, FX, FY, FOV)
+        ref.update_map(d, tf, MIN_DEPTH, MAX_DEPTH, FX, FY, FOV)
+        _same(ours, ref, step)
+        grown += int(ref.explored_area.sum()) > before
+    assert grown >= 10 and ref._map.sum() > 200          # the sequence really revealed area and placed obstacles

@@ -301,3 +301,59 @@ def test_block_sparse_sweep_at_every_batch_size(gpu_device):
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout, r.stdout[-500:]
+
+
+def test_random_jagged_profiles_and_angles_against_the_oracle(gpu_device):
+    """raster.h against the oracle on RANDOM polygons and angles, not only on the smooth depth profiles of trajectories.
+    384 cases in batches of 64: per case a jagged column-maximum profile (independent per column, steps, single-column spikes, all-near,
+    all-far: 642-vertex polygons with edges of every slope, 490 000 random edges in total), a yaw drawn from [0, 2 pi) -- a sixth of them
+    exact or one-ulp-off multiples of 90 degrees -- and a position whose coordinates sit on and next to the truncation boundaries of
+    value_map.py:309-313.  Two observations per case (the second one exercises the weighted fuse on top of the first): confidence map,
+    value map and their dtypes equal to the oracle's."""
+    from oracle.ref_value_map import RefValueMap
+    from vlfm_amd.mapping import ValueMapBatch
+
+    rng = np.random.default_rng(2026)
+    E, rounds, H, W = 64, 6, 48, 640          # (the update only sees the column maxima: 48 rows carry the same profiles as 480)
+    for rnd in range(rounds):
+        batch = ValueMapBatch(E, 1, use_max_confidence=False, device=gpu_device)
+        refs = [RefValueMap(1, use_max_confidence=False) for _ in range(E)]
+        for obs in range(2):
+            depth = np.empty((E, H, W), np.float32)
+            tf = np.empty((E, 4, 4), np.float64)
+            vals = rng.uniform(0.05, 0.6, size=(E, 1))
+            for e in range(E):
+                kind = (e + rnd) % 6
+                if kind == 0:
+                    prof = rng.uniform(0.0, 1.0, W)
+                elif kind == 1:
+                    prof = np.repeat(rng.uniform(0.0, 1.0, W // 16), 16)
+                elif kind == 2:
+                    prof = np.full(W, rng.uniform(0.1, 0.9))
+                    prof[rng.integers(0, W, 12)] = rng.uniform(0.0, 1.0, 12)
+                elif kind == 3:
+                    prof = np.clip(np.cumsum(rng.normal(0, 0.03, W)) + 0.5, 0.0, 1.0)
+                elif kind == 4:
+                    prof = np.full(W, float(rng.choice([0.0, 1.0, 0.5, 1.0 / 3.0])))
+                else:
+                    prof = np.where(rng.uniform(size=W) < 0.5, 0.02, 0.98)
+                d = rng.uniform(0.0, 1.0, (H, W)).astype(np.float32) * prof[None, :].astype(np.float32)
+                d[rng.integers(0, H), :] = prof.astype(np.float32)       # the column maxima ARE the profile
+                depth[e] = d
+                yaw = rng.uniform(0.0, 2 * np.pi)
+                if e % 6 == 5:
+                    yaw = float(np.nextafter((e // 6 % 4) * np.pi / 2, [np.inf, -np.inf, 0.0][rnd % 3]))
+                x, y = rng.uniform(-15, 15, 2)
+                if e % 4 == 1:                                            # on / next to a cell boundary of the truncating placement
+                    x = np.round(x * 20) / 20 + float(rng.choice([0.0, 1e-12, -1e-12]))
+                    y = np.round(y * 20) / 20 + float(rng.choice([0.0, 1e-12, -1e-12]))
+                tf[e] = pose_to_tf(x, y, yaw)
+            batch.update(vals, depth, tf, MIN_DEPTH, MAX_DEPTH, _fov())
+            for e in range(E):
+                refs[e].update_map(vals[e], depth[e].copy(), tf[e], MIN_DEPTH, MAX_DEPTH, _fov())
+        conf = batch.conf.cpu().numpy()
+        val = batch.value.cpu().numpy()
+        for e in range(E):
+            assert conf[e].dtype == refs[e]._map.dtype
+            assert np.array_equal(conf[e], refs[e]._map), (rnd, e, float(np.abs(conf[e] - refs[e]._map).max()))
+            assert np.array_equal(val[e].reshape(refs[e]._value_map.shape), refs[e]._value_map), (rnd, e)

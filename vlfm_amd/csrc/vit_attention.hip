@@ -23,7 +23,7 @@
 // compiled out the kernel runs 190 us (220 with no waits or barriers at all: it is the issue rate of this access pattern, 556 MB of
 // loads at 4.5 TB/s + 185 MB of stores), with the traffic compiled out 105 us, the product 231 us -- round 5's kernel: 299.  Reading
 // qkv head-major would stream the loads at 5.9 TB/s (memory side 139 us with a head-major output too), but the GEMMs on either side
-// are the library's and write / read token-major (profiles/r06_vit_attention_stub_probe.txt).
+// are the library's and write / read token-major (profiles/r06_vit_attention_probes.txt).
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -50,7 +50,7 @@ constexpr int AT_WAVES = 8;
 // the output rows are staged in LDS and leave as 16 bytes per lane.  (The first persistent form loaded the Q fragments and stored the
 // output straight in MFMA operand layout: 32 cache lines per instruction -- those 12 instructions per wavefront took longer to
 // issue than the 14 DMA pieces that move twice the bytes, and the memory side alone ran 211 us at 256 images; 139 with the stores
-// staged, profiles/r06_vit_attention_stub_probe.txt.)  The odd (CLS) query runs on the VALU instead of a ninth MFMA tile; V stays
+// staged, profiles/r06_vit_attention_probes.txt.)  The odd (CLS) query runs on the VALU instead of a ninth MFMA tile; V stays
 // row-major in LDS and is transposed by ds_read_b64_tr_b16 on the way to the PV MFMAs.
 // LDS (bytes):  buffer 0 | buffer 1 | V | partials of the odd query x 2 | its probabilities.  Item n (kb = n & 1):
 //   buffer kb      K_n (257 rows x 176 B, the native 88 channels, no padding; a row stride of 11 sixteen-byte slots is odd, so the 16
