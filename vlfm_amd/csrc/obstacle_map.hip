@@ -687,8 +687,12 @@ __global__ __launch_bounds__(1024) void fog_of_war_kernel(const FogParams* __res
             int imin = 0x7FFFFFFF, imax = 0x7FFFFFFF;
             for (int i = lane; i < n; i += 64) {
                 const double px = (double)(cp[i].x - acx), py = (double)(cp[i].y - acy);
-                const double rx = __dadd_rn(__dmul_rn(px, P.rot_c), __dmul_rn(py, P.rot_s));
-                const double ry = __dadd_rn(__dmul_rn(px, -P.rot_s), __dmul_rn(py, P.rot_c));
+                // np.matmul accumulates from +0.0: a sum of two NEGATIVE zeros (the agent's own pixel, px = py = 0, under a rotation
+                // with negative entries) comes out as +0.0 there, and atan2(+0, +0) = 0 where atan2(+0, -0) would be pi -- a
+                // different angular extreme, different shadow lines (found by tests/test_obstacle_map_gpu.py's random headings:
+                // the agent standing inside a convex obstacle blob)
+                const double rx = __dadd_rn(__dadd_rn(0.0, __dmul_rn(px, P.rot_c)), __dmul_rn(py, P.rot_s));
+                const double ry = __dadd_rn(__dadd_rn(0.0, __dmul_rn(px, -P.rot_s)), __dmul_rn(py, P.rot_c));
                 const double a = atan2(ry, rx);
                 if (imin == 0x7FFFFFFF || a < amin) { amin = a; imin = i; }
                 if (imax == 0x7FFFFFFF || a > amax) { amax = a; imax = i; }
