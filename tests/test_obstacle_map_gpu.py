@@ -299,3 +299,55 @@ def test_random_angles_random_clutter_against_the_oracle(gpu_device, seed):
         grown += int(ref.explored_area.sum()) > before
     assert grown >= 3 and ref._map.sum() > 200          # the sequence really revealed area and placed obstacles
     # (tools: the same body over seeds 0..199 = 8 000 random steps: no parity difference, profiles/r06_random_parity_stress.txt)
+
+
+def _random_hole_frame(rng):
+    """A depth frame with random ZERO regions: rectangles, discs, rings with valid islands inside, thin cracks, speckle, zero texels
+    touching the image border, holes inside holes."""
+    d = depth_frame(rng)
+    H, W = d.shape
+    yy, xx = np.mgrid[0:H, 0:W]
+    for _ in range(int(rng.integers(1, 7))):
+        kind = int(rng.integers(0, 6))
+        cy, cx = int(rng.integers(0, H)), int(rng.integers(0, W))
+        if kind == 0:
+            h, w = int(rng.integers(1, 90)), int(rng.integers(1, 120))
+            d[cy:cy + h, cx:cx + w] = 0
+        elif kind == 1:
+            r = int(rng.integers(1, 45))
+            d[(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = 0
+        elif kind == 2:                                  # ring: a hole with a valid island (img_utils.py:385-388 rewrites it too)
+            r = int(rng.integers(6, 50)); t = int(rng.integers(1, 6))
+            rr = (yy - cy) ** 2 + (xx - cx) ** 2
+            d[(rr <= r * r) & (rr >= (r - t) ** 2)] = 0
+        elif kind == 3:                                  # a diagonal crack, one texel wide
+            n = int(rng.integers(5, 120)); s = int(rng.choice([-1, 1]))
+            ys = np.clip(cy + np.arange(n), 0, H - 1); xs = np.clip(cx + s * np.arange(n), 0, W - 1)
+            d[ys, xs] = 0
+        elif kind == 4:                                  # speckle
+            m = rng.uniform(size=(40, 60)) < 0.3
+            y0, x0 = min(cy, H - 40), min(cx, W - 60)
+            d[y0:y0 + 40, x0:x0 + 60][m] = 0
+        else:                                            # a band along an image border
+            side = int(rng.integers(0, 4)); t = int(rng.integers(1, 12))
+            if side == 0: d[:t] = 0
+            elif side == 1: d[-t:] = 0
+            elif side == 2: d[:, :t] = 0
+            else: d[:, -t:] = 0
+    return d
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_hole_patterns_against_the_oracle(gpu_device, seed):
+    """fill_small_holes + the speculative scatter / journal undo / hole scatter of depth_holes.hip and depth_ingest.hip on RANDOM zero
+    patterns (rings with islands, cracks, speckle, border bands, overlaps) instead of the six hand-made cases: 12 frames per seed with
+    the reference's default threshold, a threshold that fills only some contours and -1; obstacle planes bit-exact after every frame."""
+    rng = np.random.default_rng(500 + seed)
+    for thresh in (100000, int(rng.integers(30, 4000)), -1):
+        ours, ref = _pair(gpu_device, hole_area_thresh=thresh)
+        for k in range(4):
+            d = _random_hole_frame(rng)
+            tf = pose_to_tf(rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(-np.pi, np.pi))
+            for m in (ours, ref):
+                m.update_map(d.copy(), tf, MIN_DEPTH, MAX_DEPTH, FX, FY, FOV, explore=False)
+            assert np.array_equal(ours._map, ref._map), (seed, thresh, k, int((ours._map != ref._map).sum()))
