@@ -1,0 +1,136 @@
+"""The frontier-selection rule (stick-to-last within 0.01, 0.5 m re-match, best non-cyclic otherwise) of
+vlfm_amd/policy_step.py:FrontierSelector against the REFERENCE'S OWN method, run here: /root/reference/vlfm/policy/itm_policy.py:
+BaseITMPolicy._get_best_frontier is imported through oracle/ref_shim.py (stand-ins for the absent third-party imports only) and driven
+on random sequences of frontier sets -- frontiers that persist, move by less / more than 0.5 m, disappear and come back, values that
+drift around the 0.01 hysteresis, ties, single frontiers.  Skipped where /root/reference does not exist (the GPU box); the recorded
+episodes of tests/golden/policy_*.npz cover the same rule there."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.skipif(not os.path.isdir("/root/reference/vlfm"), reason="needs the reference checkout")
+
+
+def _reference_chooser():
+    from oracle import ref_shim
+
+    itm, _ = ref_shim.reference_policy()
+    from vlfm.policy.utils.acyclic_enforcer import AcyclicEnforcer
+
+    class Ref(itm.BaseITMPolicy):      # only the state _get_best_frontier touches (itm_policy.py:48-54, 59)
+        def __init__(self):
+            self._acyclic_enforcer = AcyclicEnforcer()
+            self._last_value = float("-inf")
+            self._last_frontier = np.zeros(2)
+            self._observations_cache = {}
+            self.sorted = None
+
+        def _sort_frontiers_by_value(self, observations, frontiers):
+            return self.sorted
+
+    return Ref()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_frontier_choice_equals_the_reference_method_on_random_sequences(seed, capsys):
+    from vlfm_amd.policy_step import FrontierSelector
+
+    rng = np.random.default_rng(seed)
+    ref, ours = _reference_chooser(), FrontierSelector()
+    pool = rng.uniform(-8, 8, (12, 2))
+    stuck = 0
+    for step in range(300):
+        # the frontier set of this step: a subset of a slowly moving pool, sometimes jittered by less / more than the 0.5 m re-match
+        pool += rng.normal(0, 0.02, pool.shape) * (rng.uniform(size=(12, 1)) < 0.3)
+        if rng.uniform() < 0.05:
+            pool[rng.integers(0, 12)] = rng.uniform(-8, 8, 2)
+        keep = rng.uniform(size=12) < rng.uniform(0.2, 0.9)
+        if not keep.any():
+            keep[rng.integers(0, 12)] = True
+        pts = pool[keep].copy()
+        if rng.uniform() < 0.3:
+            pts += rng.uniform(-0.45, 0.45, pts.shape) / np.sqrt(2)
+        if rng.uniform() < 0.3 and step and not np.array_equal(ours.last_frontier, np.zeros(2)):
+            pts[rng.integers(0, len(pts))] = ours.last_frontier          # the pursued frontier is listed again, exactly
+        vals = rng.choice([0.1, 0.2, 0.21, 0.205, 0.3], len(pts)) + rng.choice([0.0, 0.004, -0.004, 0.011, -0.011], len(pts))
+        order = np.argsort(-vals, kind="stable")
+        sorted_pts, sorted_vals = pts[order], [float(v) for v in vals[order]]
+        robot = rng.uniform(-8, 8, 2) if rng.uniform() < 0.2 else np.round(rng.uniform(-8, 8, 2), 1)
+        ref.sorted = (sorted_pts.copy(), list(sorted_vals))
+        ref._observations_cache = {"robot_xy": robot.copy()}
+        want_pt, want_val = ref._get_best_frontier({}, pts.copy())
+        got_pt, got_val = ours.choose(sorted_pts.copy(), list(sorted_vals), pts.copy(), robot.copy())
+        assert np.array_equal(np.asarray(got_pt), np.asarray(want_pt)) and got_val == want_val, (seed, step)
+        assert np.array_equal(ours.last_frontier, ref._last_frontier) and ours.last_value == ref._last_value
+        stuck += "Sticking" in os.environ.get("DEBUG_INFO", "")
+    capsys.readouterr()                                   # (the reference prints per decision)
+    assert 20 < stuck < 290                               # both branches were exercised
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_detector_routing_and_filters_equal_the_reference_method(seed):
+    """base_objectnav_policy.py:221-241 (COCO targets -> YOLOv7 at 0.8, others -> GroundingDINO at 0.4, mixed targets retry) through
+    the reference's own method and its own ObjectDetections, against ITMPolicyV2Step._get_object_detections over this package's
+    ObjectDetections: random targets (COCO, non-COCO, mixed with '|'), random detection lists around both thresholds."""
+    import types
+
+    import torch
+
+    from oracle import ref_shim
+
+    _, base = ref_shim.reference_policy()
+    import importlib
+
+    ref_det = importlib.import_module("vlfm.vlm.detections")
+    from vlfm_amd.policy_step import ITMPolicyV2Step
+    from vlfm_amd.vlm.coco_classes import COCO_CLASSES
+    from vlfm_amd.vlm.detections import ObjectDetections
+
+    rng = np.random.default_rng(40 + seed)
+    names = ["chair", "bed", "potted plant", "toilet", "tv", "couch", "cabinet", "fireplace", "shoe rack", "dog"]
+
+    def fake(kind, calls):
+        class D:
+            def predict(self, img, caption=None):
+                n = int(rng.integers(0, 6))
+                boxes = torch.tensor(rng.uniform(0.05, 0.45, (n, 4)), dtype=torch.float32)
+                boxes[:, 2:] += boxes[:, :2]
+                logits = torch.tensor(rng.choice([0.2, 0.39, 0.4, 0.41, 0.79, 0.8, 0.81, 0.95], n), dtype=torch.float32)
+                phrases = [str(rng.choice(names)) for _ in range(n)]
+                calls.append((kind, caption, boxes.clone(), logits.clone(), list(phrases)))
+                return None
+        return D()
+
+    for trial in range(200):
+        k = int(rng.integers(1, 4))
+        target = "|".join(rng.choice(names, k, replace=False))
+        load_yolo = bool(rng.uniform() < 0.85)
+        script = []                                         # the detector outputs are drawn once and replayed to both sides
+        det_rng_state = rng.bit_generator.state
+        outs = {}
+        for side, DetCls in (("ref", ref_det.ObjectDetections), ("ours", ObjectDetections)):
+            rng.bit_generator.state = det_rng_state
+            calls = []
+
+            def mk(kind):
+                d = fake(kind, calls)
+                inner = d.predict
+
+                def predict(img, caption=None, _inner=inner):
+                    _inner(img, caption)
+                    _, _, boxes, logits, phrases = calls[-1]
+                    return DetCls(boxes, logits, phrases, image_source=img, fmt="xyxy")
+                d.predict = predict
+                return d
+            ns = types.SimpleNamespace(_target_object=target, _load_yolo=load_yolo, _coco_object_detector=mk("yolo"),
+                                       _object_detector=mk("gdino"), _non_coco_caption="chair . bed . dog .",
+                                       _coco_threshold=0.8, _non_coco_threshold=0.4)
+            img = np.zeros((48, 64, 3), np.uint8)
+            fn = base.BaseObjectNavPolicy._get_object_detections if side == "ref" else ITMPolicyV2Step._get_object_detections
+            det = fn(ns, img)
+            outs[side] = (np.asarray(det.boxes), np.asarray(det.logits), list(det.phrases), [(c[0], c[1]) for c in calls])
+        assert outs["ref"][3] == outs["ours"][3], (trial, target)            # same detectors asked, in the same order, same captions
+        assert outs["ref"][2] == outs["ours"][2], (trial, target)
+        assert np.array_equal(outs["ref"][0], outs["ours"][0]) and np.array_equal(outs["ref"][1], outs["ours"][1])
+    assert any(n not in COCO_CLASSES for n in names) and any(n in COCO_CLASSES for n in names)
