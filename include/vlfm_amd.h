@@ -317,7 +317,7 @@ int vlfm_vit_attention_f16(const void* d_qkv, void* d_out, int batch, int tokens
  * only, 1 = bias + EXACT (erf) GELU on the f32 accumulator -- the fc1 + GELU of the ViT-g MLP inside the forward of
  * blip2itm.py:52 in one pass (hipBLASLt's fused GELU is the tanh approximation) --, 2 (ABI 6) = accumulate: C += X . W^T + bias,
  * summed in f32, the residual-stream GEMMs (projection, fc2).  K % 64 == 0, N % 8 == 0, each operand below 4 GB; d_bias may be
- * NULL.  VLFM_GEMM_VARIANT (environment, diagnostic) selects the older schedules for A/B runs. */
+ * NULL. */
 int vlfm_gemm_f16_nt(const void* d_x, const void* d_w, const void* d_bias, void* d_c, int m, int n, int k, int epilogue,
                      void* stream);
 

@@ -36,7 +36,7 @@ cp profiles/pmc_traffic.json $O/pmc_traffic.json
 (timeout 600 python tools/gemm_f16_probe.py 2>&1 | grep -v amdgpu.ids) > $O/r06_gemm_probe.txt
 (timeout 300 python tools/vm_phase_probe.py 2>&1 | grep -v amdgpu.ids | cut -c1-400) > $O/r06_vm_phase_probe.txt
 (timeout 300 python tools/ingest_probe.py 2>&1 | grep -v amdgpu.ids) > $O/r06_ingest_probe.txt
-(bash tools/kernel_pmc.sh ingest depth_ingest_kernel -- python $R/tools/ingest_probe.py x 256 480 640 2>&1 | grep -v amdgpu.ids) > $O/r06_ingest_sq_pmc.txt
+(bash tools/kernel_pmc.sh ingest depth_ingest_kernel -- python $R/tools/ingest_probe.py 0 256 480 640 2>&1 | grep -v amdgpu.ids) > $O/r06_ingest_sq_pmc.txt
 # ---- obstacle pipeline early / late in the episode
 (timeout 300 python tools/phase_probe.py 256 150 2>&1 | grep -v amdgpu.ids | tail -24 | cut -c1-600) > $O/r06_obstacle_phase_probe.txt
 (timeout 300 python tools/phase_probe.py 64 470 2>&1 | grep -v amdgpu.ids | tail -24 | cut -c1-600) > $O/r06_obstacle_phase_probe_step470.txt
