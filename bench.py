@@ -296,8 +296,7 @@ def cpu_baseline(args, with_blip2: bool):
 
 # ------------------------------------------------------------------------------------------------ roofline helpers
 MAP_KERNELS = ("depth_ingest_kernel", "depth_scatter_kernel", "depth_ingest_scatter_kernel", "fill_small_holes_kernel",
-               "hole_scatter_kernel", "value_map_update_fused_kernel", "visible_mask_kernel", "value_map_fuse_kernel",
-               "mask_unexplored_kernel", "sort_waypoints_kernel", "resample_h_kernel", "resample_v_norm_kernel",
+               "hole_scatter_kernel", "value_map_update_fused_kernel", "sort_waypoints_kernel", "resample_h_kernel", "resample_v_norm_kernel",
                "itc_head_kernel", "navigable_kernel", "fog_of_war_kernel", "explored_select_kernel",
                "frontier_prepare_kernel", "frontier_kernel")
 
@@ -343,7 +342,7 @@ def map_roofline(kms, E, H, W, sync, pmc):
     b = survey_bytes(H, W, sync)
     tag = f"@E={E},{W}x{H}" + (",sync" if sync else "")
     depth_k = next((k for k in ("depth_ingest_scatter_kernel", "depth_ingest_kernel") if k in kms), None)
-    upd_k = next((k for k in ("value_map_update_fused_kernel", "value_map_fuse_kernel") if k in kms), None)
+    upd_k = "value_map_update_fused_kernel" if "value_map_update_fused_kernel" in kms else None
 
     def rec(kernel, nbytes, ms, traffic):
         gbs = nbytes / (ms * 1e-3) / 1e9
@@ -674,7 +673,6 @@ def main():
                        "blip2": "ViT-g/14 39 blocks + Q-Former 12 layers, random-init" if not args.no_blip2 else None,
                        "attention_path": (sim.blip2.attention_path if sim.blip2 is not None else None),
                        "fc1_gelu_path": (sim.blip2.mlp_path(E) if sim.blip2 is not None else None),
-                       "value_map_update": "split (3 launches)" if sim.values.split_update else "single launch",
                        "parallelism": f"env-sharded x{world} (contiguous blocks), metric all-reduce only"},
             "roofline": roofline,
             "roofline_depth_pass": roofline_depth,

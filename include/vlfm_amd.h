@@ -54,7 +54,7 @@ int vlfm_host_wait_mode(int blocking);
 
 /* ---------------------------------------------------------------------------------------------
  * Per-observation pose parameters of one value-map update (64 bytes, uploaded to HBM by the caller).
- * Filled on the host by vlfm_value_map_pose_params(); consumed by vlfm_value_map_update_batched().
+ * Filled on the host by vlfm_value_map_pose_params(); consumed by vlfm_value_map_update_fused_batched().
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
     double inv_affine[6]; /* dst->src 2x3 matrix cv::warpAffine derives from getRotationMatrix2D
@@ -97,7 +97,7 @@ int vlfm_cone_template_build(const float* d_conf, const int64_t* d_poly_xy, int 
  *       obstacle_map.py:92-101 + geometry_utils.py:205-236 + base_map.py:44-46)          [optional]
  * d_depth: [n][H][W] f32 in [0,1].
  * d_colmax_keys [n][W] u32: column maxima as order-preserving keys (0 = -inf).  The buffer must be zero when the call
- * is made: allocate it zeroed once; vlfm_value_map_update_batched consumes the keys and writes the zeros back, so a
+ * is made: allocate it zeroed once; vlfm_value_map_update_fused_batched consumes the keys and writes the zeros back, so a
  * steady ingest -> update cadence needs no memset.  d_status [n][2] is sticky: the kernel only ever sets flags in it;
  * the caller zeroes it after reading.
  * ------------------------------------------------------------------------------------------- */
@@ -187,7 +187,9 @@ int vlfm_depth_scatter_holes_batched(const vlfm_ingest_params* d_params, int n, 
                                      void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * ValueMap.update_map for n observations (value_map.py:100-128 = :221-260 + :288-319 + :357-429).
+ * ValueMap.update_map for n observations (value_map.py:100-128 = :221-260 + :288-319 + :357-429) in ONE launch: every workgroup
+ * rasterises the depth-profile polygon of its observation into LDS itself, so no visibility plane goes through HBM and no scratch
+ * is needed.
  *   d_colmax_keys [n][W]     column-max keys from depth ingest (consumed: reset to 0 by this call)
  *   d_tan      [W]           f64 tan table (vlfm_tan_table_host)
  *   d_template [T*T]         f32 masked confidence template;  d_template_bits [T][ceil(T/32)] its (> 0) bit plane
@@ -200,30 +202,17 @@ int vlfm_depth_scatter_holes_batched(const vlfm_ingest_params* d_params, int n, 
  *              :381-384) the stored doubles are f32-representable.  Either way the array equals the reference's bit for bit.
  *   d_explored_bits [n_envs][S][ceil(S/32)] bit-packed ObstacleMap.explored_area when the value map was built with
  *              obstacle_map=... (value_map.py:369-375), or NULL = Habitat default (windowed update, exact).
- *              With it, the full-map zeroing is done by vlfm_value_map_mask_unexplored_batched (call it first).
- *   d_scratch  vlfm_value_map_scratch_bytes(n, T) bytes: per-observation visibility bit planes
- * Two launches: visible_mask_kernel (one workgroup per observation) and value_map_fuse_kernel (row tiles x n).
- * ------------------------------------------------------------------------------------------- */
-size_t vlfm_value_map_scratch_bytes(int n, int template_size);
-int vlfm_value_map_update_batched(uint32_t* d_colmax_keys, int width, const double* d_tan,
-                                  const float* d_template, const uint32_t* d_template_bits, int template_size,
-                                  const vlfm_vm_pose* d_pose, const double* d_values, int n,
-                                  float* d_conf, double* d_value, int map_size, int channels, int pixels_per_meter,
-                                  double min_depth, double max_depth,
-                                  int use_max_confidence, int fusion_type,
-                                  const uint32_t* d_explored_bits, void* d_scratch, void* stream);
-
-/* The same update in ONE launch (what ValueMapBatch uses): every workgroup rasterises the depth-profile polygon of its
- * observation into LDS itself, so no visibility plane goes through HBM and no scratch is needed.
  *   d_written_bits [n_envs][S][ceil(S/32)] bit plane, zero at reset, owned by the caller and maintained by this call:
  *              bit = the cell has received a confidence.  Required with d_explored_bits (NULL otherwise): the full-map
- *              half of _fuse_new_data (value_map.py:369-375) then clears exactly the cells in (written & ~explored) --
- *              no call to vlfm_value_map_mask_unexplored_batched.  Observations of one call must belong to distinct
- *              environment slots.
+ *              half of _fuse_new_data (value_map.py:369-375: conf = value = 0 wherever explored == 0) then clears exactly
+ *              the cells in (written & ~explored) -- every other cell is zero already.  Observations of one call must
+ *              belong to distinct environment slots.
  *   d_counters [n] int32, zero on entry and zero again on exit (hand-over of the column-max key buffer).
  *   d_conf_quadrant [(T/2+1)^2] f32: rows/cols >= T/2 of the UNMASKED confidence table of vlfm_cone_template_host (the
  *              table depends on |row - T/2| and |col - T/2| only, value_map.py:343-351).  Staged in LDS so that the rotated
- *              template taps are LDS reads (required). */
+ *              template taps are LDS reads (required).
+ * (Rounds 1-5 also exported the three-launch form this replaced -- mask_unexplored + visible_mask + fuse; removed in round 6.)
+ * ------------------------------------------------------------------------------------------- */
 int vlfm_value_map_update_fused_batched(uint32_t* d_colmax_keys, int width, const double* d_tan,
                                         const float* d_template, const uint32_t* d_template_bits, int template_size,
                                         const vlfm_vm_pose* d_pose, const double* d_values, int n,
@@ -231,16 +220,6 @@ int vlfm_value_map_update_fused_batched(uint32_t* d_colmax_keys, int width, cons
                                         double min_depth, double max_depth, int use_max_confidence, int fusion_type,
                                         const uint32_t* d_explored_bits, uint32_t* d_written_bits, int32_t* d_counters,
                                         const float* d_conf_quadrant, void* stream);
-
-/* Full-map half of _fuse_new_data when an obstacle map is attached (value_map.py:369-375): conf = value = 0 wherever
- * explored == 0, over rows [row_lo, row_hi) of the listed environment slots.  The reference sweeps the whole map; rows
- * that no update window has ever touched are zero already, so a host that tracks the union of its update windows may
- * pass that row range (identical result); row_lo = 0, row_hi = S is always valid.  max_rows = max(row_hi - row_lo)
- * sizes the launch.  Streaming, HBM-bound. */
-typedef struct { int32_t env, row_lo, row_hi, reserved; } vlfm_mask_job;
-int vlfm_value_map_mask_unexplored_batched(const vlfm_mask_job* d_jobs, int n, int max_rows,
-                                           const uint32_t* d_explored_bits, float* d_conf, double* d_value,
-                                           int map_size, int channels, void* stream);
 
 /* ValueMap.sort_waypoints scoring (value_map.py:146-187 + img_utils.py:213-266): per waypoint and channel the
  * median of the positive cells inside the radius disc, -1 if none.

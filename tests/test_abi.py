@@ -31,13 +31,12 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.IngestParams) == 152
     assert _lib.IngestParams.fx.offset == 112 and _lib.IngestParams.env.offset == 144
     # the NumPy views the host layer fills must agree with the ctypes mirrors field by field
-    from vlfm_amd.mapping.value_map import INGEST_DTYPE, MASK_JOB_DTYPE, VM_POSE_DTYPE
+    from vlfm_amd.mapping.value_map import INGEST_DTYPE, VM_POSE_DTYPE
 
     for dt, ct in ((VM_POSE_DTYPE, _lib.VmPose), (INGEST_DTYPE, _lib.IngestParams)):
         assert dt.itemsize == ctypes.sizeof(ct)
         for name, _ in ct._fields_:
             assert dt.fields[name][1] == getattr(ct, name).offset, name
-    assert MASK_JOB_DTYPE.itemsize == 16
 
 
 def test_no_cpu_fallback_and_no_oracle_import_in_product():

@@ -108,19 +108,3 @@ def test_two_camera_value_map_matches_reference_fixture(gpu_device):
     from vlfm_amd.mapping import ValueMap
 
     replay_two_cameras(lambda c, **kw: ValueMap(c, device=gpu_device, **kw))
-
-
-@pytest.mark.parametrize("name", ["vm_default_c1", "vm_default_c2"])
-def test_three_launch_value_map_path_still_matches_reference_fixture(gpu_device, name, monkeypatch):
-    """VLFM_VM_SPLIT=1 keeps the round-1 form of the update (mask_unexplored + visible_mask + fuse kernels) for A/B
-    measurements; it must stay as exact as the single-launch kernel."""
-    monkeypatch.setenv("VLFM_VM_SPLIT", "1")
-    test_value_map_matches_reference_fixture(gpu_device, name)
-    from vlfm_amd.mapping import ValueMap
-
-    assert ValueMap(1, device=gpu_device)._batch.split_update
-
-
-def test_three_launch_sync_explored_path_matches_reference_fixture(gpu_device, monkeypatch):
-    monkeypatch.setenv("VLFM_VM_SPLIT", "1")
-    test_sync_explored_matches_reference_fixture(gpu_device)

@@ -31,9 +31,7 @@ def main(E, W, H, sync=False):
     fetch = per_kernel(os.path.join(ROOT, "gpurun_out", "pmc_fetch", "pmc_results.db"))
     write = per_kernel(os.path.join(ROOT, "gpurun_out", "pmc_write", "pmc_results.db"))
     names = {"value_map_update_fused_kernel": "value_map_update_fused_kernel",
-             "value_map_fuse_kernel": "value_map_fuse_kernel", "depth_ingest_kernel<false>": "depth_ingest_kernel",
-             "depth_ingest_kernel<true>": "depth_ingest_scatter_kernel", "mask_unexplored_kernel": "mask_unexplored_kernel",
-             "visible_mask_kernel": "visible_mask_kernel"}
+             "depth_ingest_kernel<false>": "depth_ingest_kernel", "depth_ingest_kernel<true>": "depth_ingest_scatter_kernel"}
     for frag, label in names.items():
         f = [(v, n) for (k, c), (v, n) in fetch.items() if frag in k and c == "FETCH_SIZE"]
         w = [(v, n) for (k, c), (v, n) in write.items() if frag in k and c == "WRITE_SIZE"]

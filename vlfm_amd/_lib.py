@@ -133,13 +133,8 @@ def lib() -> ctypes.CDLL:
         L.vlfm_maxpool2x2_nhwc_f16.argtypes = [vp, vp, ci, ci, ci, ci, vp]
         L.vlfm_conv_nhwc_tile.argtypes = [ci, ci, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(ci)]
         L.vlfm_conv_nhwc_f16.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
-        L.vlfm_value_map_scratch_bytes.argtypes = [ci, ci]
-        L.vlfm_value_map_scratch_bytes.restype = ctypes.c_size_t
-        L.vlfm_value_map_update_batched.argtypes = [vp, ci, vp, vp, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci, cd, cd, ci,
-                                                    ci, vp, vp, vp]
         L.vlfm_value_map_update_fused_batched.argtypes = [vp, ci, vp, vp, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci, cd, cd,
                                                           ci, ci, vp, vp, vp, vp, vp]
-        L.vlfm_value_map_mask_unexplored_batched.argtypes = [vp, ci, ci, vp, vp, vp, ci, ci, vp]
         L.vlfm_value_map_sort_waypoints_batched.argtypes = [vp, ci, ci, vp, ci, ci, vp, ci, vp, vp]
         L.vlfm_resample_coeffs_host.argtypes = [ci, ci, vp, vp, ci, ctypes.POINTER(ci)]
         L.vlfm_resample_coeffs_filter_host.argtypes = [ci, ci, ci, vp, vp, ci, ctypes.POINTER(ci)]

@@ -17,7 +17,7 @@ void set_last_error(const char* msg) { g_last_error = msg ? msg : ""; }
 }  // namespace vlfm
 
 extern "C" const char* vlfm_last_error(void) { return vlfm::g_last_error.c_str(); }
-extern "C" int vlfm_abi_version(void) { return 7; }
+extern "C" int vlfm_abi_version(void) { return 8; }
 
 namespace {
 

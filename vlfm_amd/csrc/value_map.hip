@@ -10,14 +10,15 @@
 //
 // Kernels (all HBM/LDS integer+float work, no MFMA):
 //   cone_template_kernel        one-off: sector polygon -> masked confidence template [T][T]
-//   value_map_update_kernel     one workgroup per observation:
+//   value_map_update_fused_kernel   one launch per step (round 1's three-launch form -- mask_unexplored, visible_mask, fuse -- left
+//        the tree in round 6):
 //        phase 0  depth profile -> 642-vertex polygon (value_map.py:234-257)
 //        phase 1  polygon -> LDS coverage bitmap            (cv2.drawContours fill, value_map.py:260)
 //        phase 2  for each template pixel: inverse-affine bilinear tap of (template & ~coverage)  (rotate_image,
 //                 img_utils.py:9-28), place at the camera cell (place_img_in_img, img_utils.py:31-61) and fuse
 //                 straight into conf/value (value_map.py:357-429).  Cells whose new confidence is 0 are not touched:
-//                 the reference's full-map arithmetic leaves them bit-identical (w1 == 1, w2 == 0).
-//   mask_unexplored_kernel      streaming full-map pass for the obstacle_map-synchronised mode (value_map.py:369-375)
+//                 the reference's full-map arithmetic leaves them bit-identical (w1 == 1, w2 == 0).  With an obstacle map
+//                 attached, the cells in (written & ~explored) of the window's rows are cleared first (value_map.py:369-375).
 //   sort_waypoints_kernel       disc median per waypoint (value_map.py:146-187, img_utils.py:213-266)
 //
 // Index-producing float math uses explicit round-to-nearest intrinsics (__fmul_rn ...) so that no FMA contraction
@@ -78,14 +79,11 @@ struct UpdateArgs {
     const float* tmpl;        // [T][T]
     const unsigned* tmpl_bits;// [T][words]  template > 0
     const vlfm_vm_pose* pose; // [n]
-    unsigned* visible;        // [n][vis_stride] scratch per observation: 4-word header (dst bounding box) + the bit plane
-                              // (template > 0) & ~(beyond the depth profile)
     const double* values;     // [n][C]
     float* conf;              // [n_envs][S][S]
     double* value;            // [n_envs][S][S][C]
     const unsigned* explored; // [n_envs][S][ceil(S/32)] bit-packed ObstacleMap.explored_area, or null
     int W, T, S, C;
-    int vis_stride;           // words per observation in `visible` (T * words rounded up to a multiple of 4)
     float depth_scale, depth_offset;  // f32(max-min), f32(min)
     float ppm_f, half_t_f;            // f32(ppm), f32(T/2.0)
     double ppm_d, half_t_d;
@@ -93,102 +91,6 @@ struct UpdateArgs {
 };
 
 constexpr int ROWS_PER_TILE = 8;
-constexpr int VIS_META_WORDS = 4;  // per-observation header in the visibility scratch: dst row_lo,row_hi,col_lo,col_hi
-
-// One workgroup per observation: column-max keys -> depth-profile polygon (value_map.py:234-257) -> LDS coverage of the
-// "beyond the profile" region (cv2.drawContours fill, value_map.py:260) -> visible = (template > 0) & ~coverage, 5.6 KB
-// per observation written to HBM scratch.  The key buffer is handed back zeroed for the next depth ingest.
-// Doing this ONCE per observation (instead of once per fuse workgroup) is what keeps the fuse kernel HBM-bound.
-__global__ __launch_bounds__(512) void visible_mask_kernel(UpdateArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int T = a.T, W = a.W;
-    const int words = (T + 31) >> 5;
-    const int n_vert = W + 2;
-    unsigned* solid = reinterpret_cast<unsigned*>(smem);
-    unsigned* parity = solid + T * words;
-    int2* vert = reinterpret_cast<int2*>(parity + T * words + ((2 * T * words) & 1));  // 8-byte aligned
-    const int obs = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
-
-    LdsBitmap bm;
-    bm.solid = solid; bm.parity = parity; bm.rows = T; bm.cols = T; bm.words = words;
-    for (int i = tid; i < 2 * T * words; i += nth) solid[i] = 0u;
-    unsigned* cm = a.colmax + (size_t)obs * W;
-    for (int i = tid; i < W; i += nth) {
-        const unsigned key = cm[i];
-        cm[i] = 0u;
-        const float raw = __uint_as_float((key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key);
-        const float d = __fadd_rn(__fmul_rn(raw, a.depth_scale), a.depth_offset);        // f32 (value_map.py:234)
-        const float xr = __fadd_rn(__fmul_rn(d, a.ppm_f), a.half_t_f);                   // f32 (:248)
-        const double yl = __dadd_rn(__dmul_rn(__dmul_rn((double)d, a.tan_tab[i]), a.ppm_d), a.half_t_d);  // f64 (:242,249)
-        vert[i + 1] = make_int2((int)(long long)yl, (int)(long long)xr);                 // astype(int): truncation
-    }
-    if (tid == 0) {
-        vert[0] = make_int2(0, T - 1);              // [0, last_col]         (:253)
-        vert[W + 1] = make_int2(T - 1, T - 1);      // [last_row, last_col]  (:254)
-    }
-    __syncthreads();
-    for (int i = tid; i < n_vert; i += nth) {
-        const int2 p0 = vert[i == 0 ? n_vert - 1 : i - 1], p1 = vert[i];
-        raster_edge(bm, (long long)p0.x << XY_SHIFT, p0.y, (long long)p1.x << XY_SHIFT, p1.y);
-    }
-    __syncthreads();
-    resolve_rows(bm, tid, nth);
-    __syncthreads();
-    // visible plane + its bounding box in SOURCE (template) coordinates
-    __shared__ int box[4];  // row_lo, row_hi, col_lo, col_hi
-    if (tid == 0) { box[0] = T; box[1] = -1; box[2] = T; box[3] = -1; }
-    __syncthreads();
-    unsigned* blk = a.visible + (size_t)obs * a.vis_stride;
-    unsigned* out = blk + VIS_META_WORDS;
-    int r_lo = T, r_hi = -1, c_lo = T, c_hi = -1;
-    for (int i = tid; i < T * words; i += nth) {
-        const unsigned v = a.tmpl_bits[i] & ~solid[i];
-        out[i] = v;
-        if (v) {
-            const int y = i / words, w = i - y * words;
-            r_lo = min(r_lo, y); r_hi = max(r_hi, y);
-            c_lo = min(c_lo, w * 32 + __builtin_ctz(v)); c_hi = max(c_hi, w * 32 + 31 - __builtin_clz(v));
-        }
-    }
-    if (r_hi >= 0) { atomicMin(&box[0], r_lo); atomicMax(&box[1], r_hi); atomicMin(&box[2], c_lo); atomicMax(&box[3], c_hi); }
-    __syncthreads();
-    if (tid == 0) {
-        // Destination (rotated) bounding box of everything that can receive a non-zero tap: forward-map the corners of
-        // the source box grown by one pixel (bilinear footprint), then grow by two more for the 1/32-pixel rounding of
-        // the source coordinates.  The fuse kernel only uses it to skip work whose taps are all zero.
-        int* meta = reinterpret_cast<int*>(blk);
-        if (box[1] < 0) {
-            meta[0] = 1; meta[1] = 0; meta[2] = 1; meta[3] = 0;  // empty
-        } else {
-            const vlfm_vm_pose pose = a.pose[obs];
-            const double a0 = pose.inv_affine[0], a1 = pose.inv_affine[1], a2 = pose.inv_affine[2];
-            const double a3 = pose.inv_affine[3], a4 = pose.inv_affine[4], a5 = pose.inv_affine[5];
-            const double det = a0 * a4 - a1 * a3;
-            double xlo = 1e30, xhi = -1e30, ylo = 1e30, yhi = -1e30;
-            for (int k = 0; k < 4; k++) {
-                const double sx = (k & 1) ? box[3] + 1.0 : box[2] - 1.0, sy = (k & 2) ? box[1] + 1.0 : box[0] - 1.0;
-                const double dx = (a4 * (sx - a2) - a1 * (sy - a5)) / det, dy = (-a3 * (sx - a2) + a0 * (sy - a5)) / det;
-                xlo = fmin(xlo, dx); xhi = fmax(xhi, dx); ylo = fmin(ylo, dy); yhi = fmax(yhi, dy);
-            }
-            if (!(fabs(det) > 1e-9) || !(xlo == xlo) || !(ylo == ylo)) { xlo = ylo = 0; xhi = yhi = T; }  // degenerate: no skipping
-            meta[0] = max(0, (int)floor(ylo) - 2); meta[1] = min(T - 1, (int)ceil(yhi) + 2);
-            meta[2] = max(0, (int)floor(xlo) - 2); meta[3] = min(T - 1, (int)ceil(xhi) + 2);
-        }
-    }
-}
-
-// grid = (row tiles, observations), 4 wavefronts per workgroup.  The workgroup stages its observation's visible bitmap
-// in LDS (5.6 KB, L2-resident), then each wavefront walks template rows with lanes along x (coalesced 256-B map
-// segments).  Per pixel: inverse-affine 1/32-pixel source coordinate (cv::warpAffine, img_utils.py:9-28), four bit
-// tests in LDS, template taps from L2 only where a bit is set, placement at the camera cell with clipping
-// (place_img_in_img, img_utils.py:31-61) and the fusion read-modify-write (value_map.py:357-429).  Cells whose new
-// confidence is 0 are never touched: the reference's full-map arithmetic leaves them bit-identical (w1 == 1, w2 == 0).
-
-__device__ inline bool vis_test(const unsigned* vis, int words, int T, int y, int x) {
-    if ((unsigned)x >= (unsigned)T || (unsigned)y >= (unsigned)T) return false;
-    return (vis[y * words + (x >> 5)] >> (x & 31)) & 1u;
-}
-
 // The fusion arithmetic of one cell (value_map.py:377-429).  Returns false when the cell is left untouched.
 template <int C>
 __device__ inline bool fuse_cell(const UpdateArgs& a, float nw, float old, const double* oldv, const double* vals,
@@ -217,165 +119,6 @@ __device__ inline bool fuse_cell(const UpdateArgs& a, float nw, float old, const
         value_out[c] = __dadd_rn(__dmul_rn(oldv[c], (double)w_old), __dmul_rn(vals[c], (double)w_new));
     conf_out = __fadd_rn(__fmul_rn(old, w_old), __fmul_rn(nw, w_new));
     return true;
-}
-
-// The fuse of one 8-row tile of the template window by 4 wavefronts (see the comment above): shared by the split path
-// (value_map_fuse_kernel) and the single-launch path (value_map_update_fused_kernel).  `written`, when given, is the
-// environment's bit plane of cells that hold (or may hold) a non-zero confidence: every cell stored here gets its bit.
-template <int C_STATIC>
-__device__ inline void fuse_tile(const UpdateArgs& a, const vlfm_vm_pose& pose, const unsigned* vis, const int4 box,
-                                 int row_begin, int tid, unsigned* written) {
-    const int T = a.T, S = a.S;
-    const int words = (T + 31) >> 5;
-    const int C = C_STATIC > 0 ? C_STATIC : a.C;
-    float* conf = a.conf + (size_t)pose.env * S * S;
-    double* value = a.value + (size_t)pose.env * S * S * C;
-    const int ex_stride = (S + 31) >> 5;
-    const unsigned* explored = a.explored ? a.explored + (size_t)pose.env * S * ex_stride : nullptr;
-    const double* vals = a.values + (size_t)pose.reserved * C;
-    const float* __restrict__ tmpl = a.tmpl;
-    const int lane = tid & 63, wave = tid >> 6;
-
-    // Each wavefront owns a 64-column x segment of the tile (4 wavefronts cover T <= 256 in one pass) and processes the
-    // tile's rows as ONE batch in three straight-line phases, so that all template taps, then all map reads, are in
-    // flight together: one memory latency per phase instead of one per pixel.  Inactive pixels read a harmless fixed
-    // address and are masked at the end.
-    constexpr int ROWS_PER_WAVE = ROWS_PER_TILE;
-    for (int x = wave * 64 + lane; x < T; x += 256) {
-        if (x - lane > box.w || x - lane + 63 < box.z) continue;  // wave-uniform: segment outside the cone's columns
-        const int mc = pose.col0 + x;
-        const bool col_ok = (unsigned)mc < (unsigned)S;
-        // affine tables of cv::warpAffine (AB_BITS = 10, INTER_BITS = 5, round_delta = 16), evaluated per lane
-        const int adelta = __double2int_rn(__dmul_rn(__dmul_rn(pose.inv_affine[0], (double)x), 1024.0));
-        const int bdelta = __double2int_rn(__dmul_rn(__dmul_rn(pose.inv_affine[3], (double)x), 1024.0));
-        float tapv[ROWS_PER_WAVE][4];
-        int fxi[ROWS_PER_WAVE], fyi[ROWS_PER_WAVE];
-        bool any_tap[ROWS_PER_WAVE];
-        // ---- phase A: source coordinates, visibility bits (LDS), template taps (L2)
-#pragma unroll
-        for (int k = 0; k < ROWS_PER_WAVE; k++) {
-            const int y = row_begin + k;
-            const int X0 = __double2int_rn(__dmul_rn(__dadd_rn(__dmul_rn(pose.inv_affine[1], (double)y), pose.inv_affine[2]), 1024.0)) + 16;
-            const int Y0 = __double2int_rn(__dmul_rn(__dadd_rn(__dmul_rn(pose.inv_affine[4], (double)y), pose.inv_affine[5]), 1024.0)) + 16;
-            const int Xq = (X0 + adelta) >> 5, Yq = (Y0 + bdelta) >> 5;
-            const int sx = Xq >> 5, sy = Yq >> 5;
-            fxi[k] = Xq & 31; fyi[k] = Yq & 31;
-            const bool row_ok = y < T && (unsigned)(pose.row0 + y) < (unsigned)S && col_ok;
-            const bool b0 = row_ok && vis_test(vis, words, T, sy, sx), b1 = row_ok && vis_test(vis, words, T, sy, sx + 1);
-            const bool b2 = row_ok && vis_test(vis, words, T, sy + 1, sx), b3 = row_ok && vis_test(vis, words, T, sy + 1, sx + 1);
-            any_tap[k] = b0 | b1 | b2 | b3;
-            const float t0 = tmpl[b0 ? sy * T + sx : 0], t1 = tmpl[b1 ? sy * T + sx + 1 : 0];
-            const float t2 = tmpl[b2 ? (sy + 1) * T + sx : 0], t3 = tmpl[b3 ? (sy + 1) * T + sx + 1 : 0];
-            tapv[k][0] = b0 ? t0 : 0.0f; tapv[k][1] = b1 ? t1 : 0.0f; tapv[k][2] = b2 ? t2 : 0.0f; tapv[k][3] = b3 ? t3 : 0.0f;
-        }
-        // ---- phase B: bilinear blend -> new confidence; issue the map reads of every active pixel
-        float nw[ROWS_PER_WAVE], old[ROWS_PER_WAVE];
-        size_t cell[ROWS_PER_WAVE];
-        bool act[ROWS_PER_WAVE];
-        double oldv1[ROWS_PER_WAVE];
-#pragma unroll
-        for (int k = 0; k < ROWS_PER_WAVE; k++) {
-            // BilinearTab_f weights are products of k/32 in float (exact); accumulate in double like remapBilinear<double>
-            const float fx = (float)fxi[k] * 0.03125f, fy = (float)fyi[k] * 0.03125f;
-            const float w0 = (1.f - fy) * (1.f - fx), w1 = (1.f - fy) * fx, w2 = fy * (1.f - fx), w3 = fy * fx;
-            const double nd = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn((double)tapv[k][0], (double)w0), __dmul_rn((double)tapv[k][1], (double)w1)),
-                                                  __dmul_rn((double)tapv[k][2], (double)w2)), __dmul_rn((double)tapv[k][3], (double)w3));
-            nw[k] = (float)nd;  // curr_map is f32 (value_map.py:316-317)
-            const int mr = pose.row0 + row_begin + k;
-            act[k] = any_tap[k] && nw[k] != 0.0f;
-            // new_map[explored == 0] = 0 (:373); the old values of such cells were zeroed by mask_unexplored
-            if (explored && act[k]) act[k] = (explored[(size_t)mr * ex_stride + (mc >> 5)] >> (mc & 31)) & 1u;
-            cell[k] = act[k] ? (size_t)mr * S + mc : 0;
-            old[k] = conf[cell[k]];
-            if (C_STATIC == 1) oldv1[k] = value[cell[k]];
-        }
-        // ---- phase C: fuse and write back
-#pragma unroll
-        for (int k = 0; k < ROWS_PER_WAVE; k++) {
-            bool stored = false;
-            if (act[k] && C_STATIC == 1) {
-                float c_out;
-                double v_out;
-                if (fuse_cell<1>(a, nw[k], old[k], &oldv1[k], vals, c_out, &v_out)) {
-                    conf[cell[k]] = c_out;
-                    value[cell[k]] = v_out;
-                    stored = true;
-                }
-            }
-            if (written && C_STATIC == 1) {
-                // lanes are consecutive map columns: the stores of this row form at most three 32-cell words of the plane;
-                // the lowest storing lane of each word ORs the word's bits in, and only when the plane does not show them yet
-                const unsigned long long m = __ballot(stored);
-                if (stored) {
-                    const int lo = lane - (mc & 31);  // lane that holds bit 0 of this lane's word (may lie outside the wave)
-                    const unsigned wm = lo >= 0 ? (unsigned)(m >> lo) : (unsigned)(m << (-lo));
-                    if ((mc & 31) == __builtin_ctz(wm)) {
-                        unsigned* wp = written + (size_t)(pose.row0 + row_begin + k) * ex_stride + (mc >> 5);
-                        if ((*wp & wm) != wm) atomicOr(wp, wm);
-                    }
-                }
-            }
-            if (!act[k] || C_STATIC == 1) continue;
-            {
-                // the keep/skip decision and the new confidence do not depend on the channel
-                float c_out = 0.0f;
-                bool wrote = false;
-                for (int c = 0; c < C; c++) {
-                    const double ov = value[cell[k] * C + c];
-                    double nv;
-                    wrote = fuse_cell<1>(a, nw[k], old[k], &ov, vals + c, c_out, &nv);
-                    if (!wrote) break;
-                    value[cell[k] * C + c] = nv;
-                }
-                if (wrote) {
-                    conf[cell[k]] = c_out;
-                    if (written) atomicOr(written + (size_t)(pose.row0 + row_begin + k) * ex_stride + (mc >> 5), 1u << (mc & 31));
-                }
-            }
-        }
-    }
-}
-
-template <int C_STATIC>
-__global__ __launch_bounds__(256) void value_map_fuse_kernel(UpdateArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned* vis = reinterpret_cast<unsigned*>(smem);
-    const int T = a.T, S = a.S;
-    const int words = (T + 31) >> 5;
-    const int obs = blockIdx.y;
-    const int row_begin = blockIdx.x * ROWS_PER_TILE;
-    const int tid = threadIdx.x;
-    // Independent loads first, branches afterwards: pose, the cone's dst bounding box and this thread's share of the
-    // visibility plane are all in flight together (one memory round trip instead of three).
-    const unsigned* blk = a.visible + (size_t)obs * a.vis_stride;
-    const uint4* vsrc = reinterpret_cast<const uint4*>(blk + VIS_META_WORDS);
-    const int n_vec = (a.vis_stride - VIS_META_WORDS) / 4;
-    constexpr int VEC_PER_THREAD = 2;  // 2 x 256 x 16 B = 8 KB >= 5.6 KB (T = 201); larger templates loop below
-    uint4 vreg[VEC_PER_THREAD];
-#pragma unroll
-    for (int k = 0; k < VEC_PER_THREAD; k++) {
-        const int i = tid + k * 256;
-        vreg[k] = vsrc[i < n_vec ? i : 0];
-    }
-    const vlfm_vm_pose pose = a.pose[obs];
-    vlfm_vm_pose pose_obs = pose;
-    pose_obs.reserved = obs;  // fuse_tile reads the observation's values through it
-    const int4 box = *reinterpret_cast<const int4*>(blk);  // dst bounding box of the visible cone (visible_mask_kernel)
-    // whole tile clipped away by place_img_in_img, or outside the cone: no non-zero tap
-    if (pose.row0 + min(row_begin + ROWS_PER_TILE, T) <= 0 || pose.row0 + row_begin >= S) return;
-    if (row_begin > box.y || row_begin + ROWS_PER_TILE <= box.x || box.z > box.w) return;
-    {
-        uint4* dst = reinterpret_cast<uint4*>(vis);
-#pragma unroll
-        for (int k = 0; k < VEC_PER_THREAD; k++) {
-            const int i = tid + k * 256;
-            if (i < n_vec) dst[i] = vreg[k];
-        }
-        for (int i = tid + VEC_PER_THREAD * 256; i < n_vec; i += 256) dst[i] = vsrc[i];
-    }
-    __syncthreads();
-
-    fuse_tile<C_STATIC>(a, pose_obs, vis, box, row_begin, tid, nullptr);
 }
 
 // Optional phase timing of the single-launch update (compile with -DVLFM_PHASE_TIMING; tools/vm_phase_probe.py): thread 0
@@ -1110,54 +853,6 @@ __global__ __launch_bounds__(FUSED_THREADS) void value_map_update_fused_kernel(U
     VM_PHASE(7);
 }
 
-// ------------------------------------------------------------------------------------------------ full-map mask
-// conf = value = 0 where explored == 0 (value_map.py:369-375), for the rows [row_lo, row_hi) of each listed environment.
-// One thread per group of 4 cells: a 4-bit nibble of the bit-packed explored plane (8 lanes share a word), one 16-B conf
-// access and one 16-B value access (C == 1); a wavefront covers 1 KB of contiguous map.  A group whose cells are all
-// explored costs nothing beyond the bit word; otherwise conf/value are read and rewritten only if a non-zero cell has
-// to be cleared, so a clean map costs reads only.  The row range lets the host skip rows no update window has ever
-// touched (they are zero already): identical result, bytes proportional to the area the episode has covered.
-struct MaskJob { int env, row_lo, row_hi, reserved; };
-
-__device__ inline bool clear_unexplored4(float4& v, unsigned nib) {
-    bool dirty = false;
-    if (!(nib & 1u) && v.x != 0.0f) { v.x = 0.0f; dirty = true; }
-    if (!(nib & 2u) && v.y != 0.0f) { v.y = 0.0f; dirty = true; }
-    if (!(nib & 4u) && v.z != 0.0f) { v.z = 0.0f; dirty = true; }
-    if (!(nib & 8u) && v.w != 0.0f) { v.w = 0.0f; dirty = true; }
-    return dirty;
-}
-
-__global__ __launch_bounds__(256) void mask_unexplored_kernel(const MaskJob* __restrict__ jobs, int S, int C,
-                                                              const unsigned* __restrict__ explored,
-                                                              float* __restrict__ conf, double* __restrict__ value) {
-    const MaskJob job = jobs[blockIdx.y];
-    const int ex_stride = (S + 31) >> 5;
-    const int groups = S >> 2;  // S % 4 == 0 (checked by the host)
-    const size_t cells = (size_t)S * S;
-    const unsigned* ex = explored + (size_t)job.env * S * ex_stride;
-    float* cf = conf + (size_t)job.env * cells;
-    double* vl = value + (size_t)job.env * cells * C;
-    const long long total = (long long)(job.row_hi - job.row_lo) * groups;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int row = job.row_lo + (int)(i / groups), g = (int)(i % groups);
-        const unsigned nib = (ex[(size_t)row * ex_stride + (g >> 3)] >> ((g & 7) * 4)) & 0xFu;
-        if (nib == 0xFu) continue;
-        const size_t quad = ((size_t)row * S >> 2) + g;
-        float4 c4 = reinterpret_cast<float4*>(cf)[quad];
-        if (clear_unexplored4(c4, nib)) reinterpret_cast<float4*>(cf)[quad] = c4;
-        // `_value_map[explored_area == 0] *= 0` (:375): a product -- a negative value leaves -0.0, like the reference
-        for (int k = 0; k < 4; k++) {
-            if ((nib >> k) & 1u) continue;
-            for (int c = 0; c < C; c++) {
-                double* vp = vl + (quad * 4 + k) * C + c;
-                const double v = *vp;
-                if (v != 0.0) *vp = __dmul_rn(v, 0.0);
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ sort_waypoints
 // One workgroup (256 threads) per (waypoint, channel).  Gathers the positive cells of the disc into LDS, then finds
 // the median by rank counting (n <= (2r+1)^2, r = 10 -> 441; O(n^2) compares spread over the workgroup).  The map is f64
@@ -1238,60 +933,6 @@ extern "C" int vlfm_cone_template_build(const float* d_conf, const int64_t* d_po
     return check_launch("cone_template_kernel");
 }
 
-static int vis_stride_words(int T) {
-    const int words = (T + 31) >> 5;
-    return VIS_META_WORDS + ((T * words + 3) & ~3);
-}
-
-extern "C" size_t vlfm_value_map_scratch_bytes(int n, int template_size) {
-    if (n <= 0 || template_size <= 0) return 0;
-    return (size_t)n * vis_stride_words(template_size) * sizeof(uint32_t);
-}
-
-extern "C" int vlfm_value_map_update_batched(uint32_t* d_colmax_keys, int width, const double* d_tan,
-                                             const float* d_template, const uint32_t* d_template_bits,
-                                             int template_size, const vlfm_vm_pose* d_pose,
-                                             const double* d_values, int n, float* d_conf, double* d_value,
-                                             int map_size, int channels, int pixels_per_meter, double min_depth,
-                                             double max_depth, int use_max_confidence, int fusion_type,
-                                             const uint32_t* d_explored_bits, void* d_scratch, void* stream) {
-    if (n == 0) return VLFM_OK;
-    if (!d_colmax_keys || !d_tan || !d_template || !d_template_bits || !d_pose || !d_values || !d_conf || !d_value ||
-        n < 0 || width <= 0 || template_size <= 0 || map_size <= 0 || channels <= 0 || fusion_type < 0 || fusion_type > 2)
-        return fail(VLFM_ERR_INVALID, "value_map_update_batched: bad argument");
-    if (!d_scratch) return fail(VLFM_ERR_INVALID, "value_map_update_batched: d_scratch is null");
-    UpdateArgs a;
-    a.colmax = reinterpret_cast<unsigned*>(d_colmax_keys); a.tan_tab = d_tan; a.tmpl = d_template;
-    a.tmpl_bits = d_template_bits; a.pose = d_pose; a.values = d_values;
-    a.conf = d_conf; a.value = d_value; a.explored = d_explored_bits;
-    a.W = width; a.T = template_size; a.S = map_size; a.C = channels;
-    a.vis_stride = vis_stride_words(template_size);
-    a.visible = reinterpret_cast<unsigned*>(d_scratch);
-    // NumPy: f32 array (op) Python float -> the scalar is rounded to f32 first (value_map.py:234,248)
-    a.depth_scale = (float)(max_depth - min_depth);
-    a.depth_offset = (float)min_depth;
-    a.ppm_f = (float)pixels_per_meter;
-    a.half_t_f = (float)(template_size / 2.0);
-    a.ppm_d = (double)pixels_per_meter;
-    a.half_t_d = template_size / 2.0;
-    a.use_max_conf = use_max_confidence; a.fusion = fusion_type;
-    const int T = template_size, words = (T + 31) >> 5;
-    const size_t lds_mask = (size_t)(2 * T * words + ((2 * T * words) & 1)) * 4 + (size_t)(width + 2) * sizeof(int2);
-    const size_t lds_fuse = (size_t)(a.vis_stride - VIS_META_WORDS) * 4;
-    if (lds_mask > 160 * 1024) return fail(VLFM_ERR_CAPACITY, "value_map_update_batched: template/width too large for LDS");
-    {
-        VLFM_TIMED("visible_mask_kernel", stream);
-        VLFM_KLAUNCH(visible_mask_kernel, dim3(n), dim3(512), lds_mask, (hipStream_t)stream, a);
-    }
-    const int tiles = (template_size + ROWS_PER_TILE - 1) / ROWS_PER_TILE;
-    VLFM_TIMED("value_map_fuse_kernel", stream);
-    if (channels == 1)
-        VLFM_KLAUNCH(value_map_fuse_kernel<1>, dim3(tiles, n), dim3(256), lds_fuse, (hipStream_t)stream, a);
-    else
-        VLFM_KLAUNCH(value_map_fuse_kernel<0>, dim3(tiles, n), dim3(256), lds_fuse, (hipStream_t)stream, a);
-    return check_launch("value_map_fuse_kernel");
-}
-
 #ifdef VLFM_PHASE_TIMING
 extern "C" int vlfm_debug_vm_phase_clocks(long long* h_out /* [16] */) {
     return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(vlfm::g_vm_phase), sizeof(long long) * 16) == hipSuccess ? VLFM_OK : VLFM_ERR_HIP;
@@ -1323,7 +964,6 @@ extern "C" int vlfm_value_map_update_fused_batched(uint32_t* d_colmax_keys, int 
     a.tmpl_bits = d_template_bits; a.pose = d_pose; a.values = d_values;
     a.conf = d_conf; a.value = d_value; a.explored = d_explored_bits;
     a.W = width; a.T = template_size; a.S = map_size; a.C = channels;
-    a.vis_stride = 0; a.visible = nullptr;
     a.depth_scale = (float)(max_depth - min_depth);
     a.depth_offset = (float)min_depth;
     a.ppm_f = (float)pixels_per_meter;
@@ -1391,25 +1031,6 @@ extern "C" int vlfm_value_map_update_fused_batched(uint32_t* d_colmax_keys, int 
     else
         VLFM_KLAUNCH(value_map_update_fused_kernel<0>, dim3(G, n), dim3(FUSED_THREADS), lds, (hipStream_t)stream, a, fx);
     return check_launch("value_map_update_fused_kernel");
-}
-
-extern "C" int vlfm_value_map_mask_unexplored_batched(const vlfm_mask_job* d_jobs, int n, int max_rows,
-                                                      const uint32_t* d_explored_bits, float* d_conf, double* d_value,
-                                                      int map_size, int channels, void* stream) {
-    if (n == 0 || max_rows == 0) return VLFM_OK;
-    if (!d_jobs || !d_explored_bits || !d_conf || !d_value || n < 0 || max_rows < 0 || map_size <= 0 || channels <= 0)
-        return fail(VLFM_ERR_INVALID, "mask_unexplored_batched: bad argument");
-    if (map_size % 4 != 0) return fail(VLFM_ERR_INVALID, "mask_unexplored_batched: map size must be a multiple of 4");
-    static_assert(sizeof(MaskJob) == sizeof(vlfm_mask_job), "mask job layout");
-    const long long groups = (long long)max_rows * (map_size / 4);
-    long long bx = (groups + 255) / 256;
-    const long long cap = n >= 8 ? 256 : 2048 / (n > 0 ? n : 1);  // ~2048 workgroups in flight over all environments
-    if (bx > cap) bx = cap;
-    if (bx < 1) bx = 1;
-    VLFM_TIMED("mask_unexplored_kernel", stream);
-    VLFM_KLAUNCH(mask_unexplored_kernel, dim3((unsigned)bx, n), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const MaskJob*>(d_jobs), map_size, channels, d_explored_bits, d_conf, d_value);
-    return check_launch("mask_unexplored_kernel");
 }
 
 extern "C" int vlfm_value_map_sort_waypoints_batched(const double* d_value, int map_size, int channels,

@@ -105,8 +105,7 @@ VM_POSE_DTYPE = np.dtype([("inv_affine", "<f8", (6,)), ("row0", "<i4"), ("col0",
 INGEST_DTYPE = np.dtype([("tf", "<f8", (12,)), ("depth_scale", "<f4"), ("depth_offset", "<f4"), ("depth_max", "<f4"),
                          ("reserved0", "<f4"), ("fx", "<f8"), ("fy", "<f8"), ("min_height", "<f8"),
                          ("max_height", "<f8"), ("env", "<i4"), ("scatter", "<i4")])
-MASK_JOB_DTYPE = np.dtype([("env", "<i4"), ("row_lo", "<i4"), ("row_hi", "<i4"), ("reserved", "<i4")])
-assert VM_POSE_DTYPE.itemsize == 64 and INGEST_DTYPE.itemsize == 152 and MASK_JOB_DTYPE.itemsize == 16
+assert VM_POSE_DTYPE.itemsize == 64 and INGEST_DTYPE.itemsize == 152
 
 
 class _ConeTemplates:
@@ -239,17 +238,9 @@ class ValueMapBatch:
         # bit-packed ObstacleMap.explored_area of the same slots ([n_envs,S,ceil(S/32)] int32) when the value map is
         # synchronised with an obstacle map (value_map.py:369-375); None = Habitat default
         self.explored_bits = explored_bits
-        # rows any update window has ever touched, per slot: everything outside is still zero, so the full-map
-        # "zero where unexplored" sweep only has to visit these rows
-        self._row_lo = np.full(n_envs, size, np.int64)
-        self._row_hi = np.zeros(n_envs, np.int64)
         self._colmax = None
         self._status = None
         self._ring = None
-        self._vis = None
-        # single-launch update (csrc/value_map.hip: value_map_update_fused_kernel) unless VLFM_VM_SPLIT=1 asks for the
-        # three-launch form (mask_unexplored + visible_mask + fuse) it replaced -- kept for A/B measurements
-        self.split_update = os.environ.get("VLFM_VM_SPLIT", "0") == "1"
         self._written = None   # [n_envs,S,ceil(S/32)] cells that ever received a confidence (explored-synchronised mode)
         self._written_stale = False  # an update ran without the explored plane since `_written` was last complete
         self._counters = None
@@ -272,16 +263,12 @@ class ValueMapBatch:
         if env_ids is None:
             self.conf.zero_()
             self.value.zero_()
-            self._row_lo[:] = self.size
-            self._row_hi[:] = 0
             if self._written is not None:
                 self._written.zero_()
         else:
             idx = list(env_ids)
             self.conf[idx] = 0
             self.value[idx] = 0
-            self._row_lo[idx] = self.size
-            self._row_hi[idx] = 0
             if self._written is not None:
                 self._written[idx] = 0
 
@@ -298,14 +285,6 @@ class ValueMapBatch:
             self._colmax = torch.zeros((max(n, self.n_envs), width), dtype=torch.int32, device=self.device)
             self._status = torch.zeros((max(n, self.n_envs), 2), dtype=torch.int32, device=self.device)
         return self._colmax, self._status
-
-    def _vis_scratch(self, n: int, T: int):
-        import torch
-
-        need = _lib.lib().vlfm_value_map_scratch_bytes(max(n, self.n_envs), T)
-        if self._vis is None or self._vis.numel() < need:
-            self._vis = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._vis
 
     def column_max(self, depth) -> Any:
         """np.max(depth, axis=0) for a [n,H,W] device tensor via the depth-ingest kernel (no obstacle scatter).
@@ -373,56 +352,30 @@ class ValueMapBatch:
                 ex = self.explored_bits
                 assert ex.dtype == torch.int32 and ex.is_contiguous() and ex.shape[-2] == self.size
                 explored_ptr = ex.data_ptr()
-            # rows this step's windows may write (the split path's full-map sweep is limited to them)
-            np.minimum.at(self._row_lo, pose["env"], np.clip(pose["row0"], 0, self.size))
-            np.maximum.at(self._row_hi, pose["env"], np.clip(pose["row0"] + T, 0, self.size))
-            if not self.split_update:
-                written_ptr = None
-                if explored_ptr is None:
-                    self._written_stale = True   # cells fused from here on are not recorded in the plane
-                else:
-                    if self._written is None or self._written_stale:
-                        # conf may already hold values (an obstacle map attached mid-episode, or detached for a while and
-                        # attached again): (re)start from conf != 0
-                        if self._written is None:
-                            self._written = torch.zeros((self.n_envs, self.size, (self.size + 31) // 32),
-                                                        dtype=torch.int32, device=self.device)
-                        _lib.check(L.vlfm_bits_pack((self.conf != 0).to(torch.uint8).contiguous().data_ptr(),
-                                                    self._written.data_ptr(), self.n_envs, self.size, self.size,
-                                                    _stream_ptr()), "bits_pack")
-                        self._written_stale = False
-                    written_ptr = self._written.data_ptr()
-                if self._counters is None or self._counters.numel() < n:
-                    self._counters = torch.zeros(max(n, self.n_envs), dtype=torch.int32, device=self.device)
-                _lib.check(L.vlfm_value_map_update_fused_batched(
-                    colmax.data_ptr(), W, d_tan.data_ptr(), d_tmpl.data_ptr(), d_bits.data_ptr(), T, d_pose.data_ptr(),
-                    d_vals.data_ptr(), n, self.conf.data_ptr(), self.value.data_ptr(), self.size, self.channels,
-                    self.pixels_per_meter, float(min_depth), float(max_depth), int(self.use_max_confidence),
-                    _lib.FUSION_TYPES[self.fusion_type], explored_ptr, written_ptr, self._counters.data_ptr(),
-                    _TEMPLATES.quadrant(self.device, fov, max_depth, self.pixels_per_meter,
-                                        self._min_confidence).data_ptr(), _stream_ptr()), "value_map_update_fused")
-                return
-            if explored_ptr is not None:
-                slots = np.unique(pose["env"])
-                jobs = np.zeros(len(slots), MASK_JOB_DTYPE)
-                jobs["env"] = slots
-                jobs["row_lo"] = np.minimum(self._row_lo[slots], self.size)
-                jobs["row_hi"] = self._row_hi[slots]
-                jobs = jobs[jobs["row_hi"] > jobs["row_lo"]]
-                if len(jobs):
-                    d_jobs = ring.upload(jobs)
-                    _lib.check(L.vlfm_value_map_mask_unexplored_batched(
-                        d_jobs.data_ptr(), len(jobs), int((jobs["row_hi"] - jobs["row_lo"]).max()), explored_ptr,
-                        self.conf.data_ptr(), self.value.data_ptr(), self.size, self.channels, _stream_ptr()),
-                        "mask_unexplored")
-            _lib.check(L.vlfm_value_map_update_batched(colmax.data_ptr(), W, d_tan.data_ptr(), d_tmpl.data_ptr(),
-                                                       d_bits.data_ptr(), T, d_pose.data_ptr(), d_vals.data_ptr(), n,
-                                                       self.conf.data_ptr(), self.value.data_ptr(), self.size,
-                                                       self.channels, self.pixels_per_meter, float(min_depth),
-                                                       float(max_depth), int(self.use_max_confidence),
-                                                       _lib.FUSION_TYPES[self.fusion_type], explored_ptr,
-                                                       self._vis_scratch(n, T).data_ptr(), _stream_ptr()),
-                       "value_map_update")
+            written_ptr = None
+            if explored_ptr is None:
+                self._written_stale = True   # cells fused from here on are not recorded in the plane
+            else:
+                if self._written is None or self._written_stale:
+                    # conf may already hold values (an obstacle map attached mid-episode, or detached for a while and
+                    # attached again): (re)start from conf != 0
+                    if self._written is None:
+                        self._written = torch.zeros((self.n_envs, self.size, (self.size + 31) // 32),
+                                                    dtype=torch.int32, device=self.device)
+                    _lib.check(L.vlfm_bits_pack((self.conf != 0).to(torch.uint8).contiguous().data_ptr(),
+                                                self._written.data_ptr(), self.n_envs, self.size, self.size,
+                                                _stream_ptr()), "bits_pack")
+                    self._written_stale = False
+                written_ptr = self._written.data_ptr()
+            if self._counters is None or self._counters.numel() < n:
+                self._counters = torch.zeros(max(n, self.n_envs), dtype=torch.int32, device=self.device)
+            _lib.check(L.vlfm_value_map_update_fused_batched(
+                colmax.data_ptr(), W, d_tan.data_ptr(), d_tmpl.data_ptr(), d_bits.data_ptr(), T, d_pose.data_ptr(),
+                d_vals.data_ptr(), n, self.conf.data_ptr(), self.value.data_ptr(), self.size, self.channels,
+                self.pixels_per_meter, float(min_depth), float(max_depth), int(self.use_max_confidence),
+                _lib.FUSION_TYPES[self.fusion_type], explored_ptr, written_ptr, self._counters.data_ptr(),
+                _TEMPLATES.quadrant(self.device, fov, max_depth, self.pixels_per_meter,
+                                    self._min_confidence).data_ptr(), _stream_ptr()), "value_map_update_fused")
 
     # ------------------------------------------------------------------------------------------ frontier scoring
     def waypoint_values(self, waypoints_xy: np.ndarray, env_of_waypoint: Sequence[int], radius: float) -> np.ndarray:
