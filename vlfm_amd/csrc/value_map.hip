@@ -125,10 +125,13 @@ __device__ inline bool fuse_cell(const UpdateArgs& a, float nw, float old, const
 // of workgroup (0, 0) stamps the constant-rate 100 MHz counter at phase boundaries.  Zero cost otherwise.
 #ifdef VLFM_PHASE_TIMING
 __device__ long long g_vm_phase[16];
+__device__ long long g_vm_span[2048][2];     // first and last phase stamp of EVERY workgroup (observation-major): the imbalance
 #define VM_PHASE(k)                                                                                       \
     do {                                                                                                  \
         __syncthreads();                                                                                  \
         if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_vm_phase[k] = wall_clock64();        \
+        if (((k) == 0 || (k) == 7) && threadIdx.x == 0 && blockIdx.y * gridDim.x + blockIdx.x < 2048)       \
+            g_vm_span[blockIdx.y * gridDim.x + blockIdx.x][(k) == 7] = wall_clock64();                      \
     } while (0)
 #define VM_STAMP(k)                                                                                       \
     do {                                                                                                  \
@@ -936,6 +939,9 @@ extern "C" int vlfm_cone_template_build(const float* d_conf, const int64_t* d_po
 #ifdef VLFM_PHASE_TIMING
 extern "C" int vlfm_debug_vm_phase_clocks(long long* h_out /* [16] */) {
     return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(vlfm::g_vm_phase), sizeof(long long) * 16) == hipSuccess ? VLFM_OK : VLFM_ERR_HIP;
+}
+extern "C" int vlfm_debug_vm_span_clocks(long long* h_out /* [2048][2] */) {
+    return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(vlfm::g_vm_span), sizeof(long long) * 4096) == hipSuccess ? VLFM_OK : VLFM_ERR_HIP;
 }
 #endif
 
