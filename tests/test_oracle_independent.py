@@ -294,3 +294,133 @@ def test_ellipse_sector_agrees_with_pil_pieslice_away_from_the_boundary():
         safe |= rho > r + 2.0
         assert np.array_equal(ours[safe], pil[safe]), (fov_deg, r)
         assert abs(int(ours.sum()) - int(pil.sum())) <= 0.03 * pil.sum()
+
+
+# ----------------------------------------------------------------------------------------------------------- rotation, disc, blur, contour scalars
+@pytest.mark.parametrize("deg", [0.0, 17.3, 90.0, 133.0, -61.5, 180.0])
+def test_warp_affine_agrees_with_exact_bilinear_resampling_within_its_fixed_point_grid(deg):
+    """rotate_image (img_utils.py:9-28) = getRotationMatrix2D + warpAffine(INTER_LINEAR).  OpenCV evaluates the inverse map in fixed
+    point (coordinates on a 1/32-pixel grid, bilinear weights in 1/32768), so it cannot be bit-equal to an exact resampler -- but it
+    must be the SAME MAP: same centre, same sense of rotation (positive = counter-clockwise on screen), zero outside.  Compared with
+    scipy.ndimage.map_coordinates(order=1) fed with the analytic inverse rotation, on a smooth image: the difference is bounded by
+    the coordinate grid (1/32 px) times the image's largest gradient -- a wrong centre or sign would be off by whole pixels."""
+    h = w = 101
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    src = 0.5 + 0.25 * np.sin(xx / 9.0) * np.cos(yy / 7.0) + 0.002 * xx               # smooth, asymmetric
+    c = (w // 2, h // 2)
+    got = cv.warpAffine(src, cv.getRotationMatrix2D(c, deg, 1.0), (w, h))
+    a = np.deg2rad(deg)
+    # forward map of cv2.getRotationMatrix2D: x' = cos a (x - cx) + sin a (y - cy) + cx, y' = -sin a (x - cx) + cos a (y - cy) + cy;
+    # the sampled source point of destination (x', y') is its inverse
+    dx, dy = xx - c[0], yy - c[1]
+    sx = np.cos(a) * dx - np.sin(a) * dy + c[0]
+    sy = np.sin(a) * dx + np.cos(a) * dy + c[1]
+    want = ndimage.map_coordinates(src, [sy, sx], order=1, mode="constant", cval=0.0)
+    inside = (sx > 1) & (sx < w - 2) & (sy > 1) & (sy < h - 2)
+    grad = max(np.abs(np.diff(src, axis=0)).max(), np.abs(np.diff(src, axis=1)).max())
+    assert inside.sum() > 5000
+    assert np.abs(got - want)[inside].max() <= 2.0 * grad / 32 + 1e-4, deg
+    far = (sx < -1) | (sx > w) | (sy < -1) | (sy > h)
+    assert far.sum() == 0 or np.all(got[far] == 0.0)
+
+
+@pytest.mark.parametrize("r", [1, 2, 5, 10, 17])
+def test_filled_circle_is_the_analytic_disc_up_to_its_boundary_ring(r):
+    """cv2.circle(..., thickness=-1) behind pixel_value_within_radius (img_utils.py:247-253): every pixel strictly inside the
+    radius is set, none farther than radius + 1, and the shape has the disc's eightfold symmetry."""
+    n = 2 * r + 9
+    img = cv.circle(np.zeros((n, n), np.uint8), (n // 2, n // 2), r, 1, -1) > 0
+    yy, xx = np.mgrid[0:n, 0:n]
+    d = np.hypot(xx - n // 2, yy - n // 2)
+    assert img[d <= r - 0.75].all() and not img[d >= r + 1].any()
+    assert img[n // 2, n // 2 + r] and img[n // 2 + r, n // 2] and not img[n // 2, n // 2 + r + 1]
+    for s in (img[::-1], img[:, ::-1], img.T):
+        assert np.array_equal(img, s)
+
+
+def test_box_blur_equals_scipy_uniform_filter_with_reflect101_border():
+    """cv2.blur(mask, (3, 3)) of reveal_fog_of_war's smoothing [frontier_exploration, ext]: the 3 x 3 mean with BORDER_REFLECT_101,
+    rounded half to even... or half up?  The stand-in's choice is checked against the exact rational mean: a 3 x 3 sum of u8 values
+    divided by 9 is never at a .5 tie (9 is odd), so ANY correct rounding gives round(sum / 9)."""
+    rng = np.random.default_rng(0)
+    for _ in range(5):
+        img = (rng.integers(0, 2, (23, 31)) * 255).astype(np.uint8)
+        p = np.pad(img.astype(np.int64), 1, mode="reflect")            # numpy "reflect" = OpenCV REFLECT_101
+        s = sum(p[dy:dy + 23, dx:dx + 31] for dy in range(3) for dx in range(3))
+        assert np.array_equal(cv.blur(img, (3, 3)), np.rint(s / 9.0).astype(np.uint8))
+
+
+def test_contour_area_point_test_and_convexity_against_first_principles():
+    """contourArea = |shoelace| (Green's formula on the vertices); pointPolygonTest(measureDist=False) = +1 / 0 / -1 for inside / on an
+    edge / outside, decided here by exact integer cross products (winding number); isContourConvex = all turns of one sign."""
+    rng = np.random.default_rng(3)
+    for trial in range(200):
+        n = int(rng.integers(3, 9))
+        ang = np.sort(rng.uniform(0, 2 * np.pi, n))
+        rad = rng.uniform(3, 20, n) if trial % 2 else np.full(n, 15.0)
+        pts = np.unique(np.rint(np.stack([25 + rad * np.cos(ang), 25 + rad * np.sin(ang)], 1)).astype(np.int64), axis=0)
+        if len(pts) < 3:
+            continue
+        ctr = pts.mean(0)
+        pts = pts[np.argsort(np.arctan2(pts[:, 1] - ctr[1], pts[:, 0] - ctr[0]))]          # a simple (star-shaped) polygon
+        x, y = pts[:, 0], pts[:, 1]
+        shoelace = abs(int(np.sum(x * np.roll(y, -1) - np.roll(x, -1) * y))) / 2.0
+        assert cv.contourArea(pts) == shoelace
+        turns = [(int(pts[(i + 1) % len(pts)][0] - pts[i][0]) * int(pts[(i + 2) % len(pts)][1] - pts[(i + 1) % len(pts)][1])
+                  - int(pts[(i + 1) % len(pts)][1] - pts[i][1]) * int(pts[(i + 2) % len(pts)][0] - pts[(i + 1) % len(pts)][0]))
+                 for i in range(len(pts))]
+        strictly = all(t > 0 for t in turns) or all(t < 0 for t in turns)
+        if strictly:
+            assert cv.isContourConvex(pts)
+        elif any(t > 0 for t in turns) and any(t < 0 for t in turns):
+            assert not cv.isContourConvex(pts)
+        for _ in range(20):
+            q = rng.integers(0, 51, 2)
+            on_edge, wn = False, 0
+            for i in range(len(pts)):
+                a, b = pts[i], pts[(i + 1) % len(pts)]
+                cr = int(b[0] - a[0]) * int(q[1] - a[1]) - int(b[1] - a[1]) * int(q[0] - a[0])
+                if cr == 0 and min(a[0], b[0]) <= q[0] <= max(a[0], b[0]) and min(a[1], b[1]) <= q[1] <= max(a[1], b[1]):
+                    on_edge = True
+                if a[1] <= q[1] < b[1] and cr > 0:
+                    wn += 1
+                elif b[1] <= q[1] < a[1] and cr < 0:
+                    wn -= 1
+            want = 0.0 if on_edge else (1.0 if wn != 0 else -1.0)
+            assert cv.pointPolygonTest(pts, (float(q[0]), float(q[1])), False) == want, (pts.tolist(), q.tolist())
+
+
+def test_bounding_rect_of_a_mask_against_numpy():
+    rng = np.random.default_rng(4)
+    for _ in range(20):
+        m = np.zeros((40, 50), np.uint8)
+        y0, x0 = int(rng.integers(0, 30)), int(rng.integers(0, 40))
+        m[y0:y0 + int(rng.integers(1, 10)), x0:x0 + int(rng.integers(1, 10))] = 255
+        m[rng.integers(0, 40), rng.integers(0, 50)] = 1
+        ys, xs = np.nonzero(m)
+        assert cv.boundingRect(m) == (xs.min(), ys.min(), xs.max() - xs.min() + 1, ys.max() - ys.min() + 1)
+    assert cv.boundingRect(np.zeros((5, 5), np.uint8)) == (0, 0, 0, 0)
+
+
+@pytest.mark.parametrize("case", [(100, 100, 60, 0, -40, 40), (50, 70, 25, 90, 10, 170), (100, 100, 100, 37, -39, 39), (30, 30, 7, 0, 0, 360)])
+def test_ellipse_polygon_vertices_lie_on_the_analytic_arc(case):
+    """cv2.ellipse2Poly behind the cone template (value_map.py:325-334) and the fog-of-war wedge: integer vertices of a circular arc --
+    the vertices EllipseEx hands to the fill in 16.16 fixed point -- each within one pixel of the analytic circle (the double-precision
+    ellipse2Poly points, rounded to 1/65536),
+    angularly ordered from the start to the end angle (image coordinates: y down, angles measured from +x towards +y)."""
+    cx, cy, r, rot, a0, a1 = case
+    poly = cv.ellipse_polygon((cx, cy), (r, r), rot, a0, a1).reshape(-1, 2).astype(np.float64) / 65536.0     # 16.16 fixed point
+    assert len(poly) >= 3
+    d = np.hypot(poly[:, 0] - cx, poly[:, 1] - cy)
+    on_arc = np.abs(d - r) <= 1.0
+    centre = (poly[:, 0] == cx) & (poly[:, 1] == cy)            # a sector polygon may carry the centre as its apex
+    assert (on_arc | centre).all(), poly[~(on_arc | centre)]
+    arc = poly[on_arc]
+    ang = np.unwrap(np.arctan2(arc[:, 1] - cy, arc[:, 0] - cx))
+    ang = np.rad2deg(ang) - rot
+    ang -= 360.0 * np.round((ang[0] - a0) / 360.0)
+    tol = np.rad2deg(1.5 / r)                                    # one pixel of arc length
+    assert abs(ang[0] - a0) <= tol and abs(ang[-1] - a1) <= tol, (ang[0], ang[-1])
+    assert (np.diff(ang) >= -tol).all()                          # monotone up to the rounding of neighbouring vertices
+    if a1 - a0 < 360:
+        assert (np.diff(ang) <= 15 + tol).all()                  # no gap larger than the coarsest delta OpenCV uses (it picks 1-15 degrees by size)
