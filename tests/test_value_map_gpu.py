@@ -357,3 +357,41 @@ def test_random_jagged_profiles_and_angles_against_the_oracle(gpu_device):
             assert conf[e].dtype == refs[e]._map.dtype
             assert np.array_equal(conf[e], refs[e]._map), (rnd, e, float(np.abs(conf[e] - refs[e]._map).max()))
             assert np.array_equal(val[e].reshape(refs[e]._value_map.shape), refs[e]._value_map), (rnd, e)
+
+
+def test_random_channels_modes_corner_maps_and_sort_waypoints_against_the_oracle(gpu_device):
+    """Random maps in every fusion mode with 1-3 channels -- some hugging a map corner, so that the window is clipped and the disc of a
+    waypoint leaves the map -- then random waypoints at several radii: maps, `sort_waypoints` ORDER and values equal the oracle's
+    (scratch run over 240 such rounds: profiles/r06_random_parity_stress.txt)."""
+    from oracle.ref_value_map import RefValueMap
+    from vlfm_amd.mapping import ValueMap
+
+    modes = [("default", False), ("default", True), ("equal_weighting", False), ("replace", False)]
+    for rnd in range(24):
+        rng = np.random.default_rng(7000 + rnd)
+        fusion, use_max = modes[rnd % 4]
+        C = 1 + (rnd // 4) % 3
+        ours = ValueMap(C, use_max_confidence=use_max, fusion_type=fusion, device=gpu_device)
+        ref = RefValueMap(C, use_max_confidence=use_max, fusion_type=fusion)
+        centre = rng.uniform(-20, 20, 2) if rnd % 5 else np.array([24.2, -24.3]) * rng.choice([-1, 1], 2)
+        for _ in range(int(rng.integers(2, 7))):
+            W = 640
+            k = int(rng.integers(0, 4))
+            prof = (rng.uniform(0, 1, W) if k == 0 else np.repeat(rng.uniform(0, 1, W // 16), 16) if k == 1 else
+                    np.clip(np.cumsum(rng.normal(0, 0.04, W)) + rng.uniform(0.2, 0.8), 0, 1) if k == 2 else np.full(W, rng.uniform(0, 1)))
+            d = rng.uniform(0, 1, (16, W)).astype(np.float32) * prof[None].astype(np.float32)
+            d[0] = prof.astype(np.float32)
+            p = centre + rng.uniform(-0.6, 0.6, 2)
+            tf = pose_to_tf(p[0], p[1], rng.uniform(-np.pi, np.pi))
+            vals = rng.uniform(0.0, 0.6, C)
+            ref.update_map(vals, d.copy(), tf, MIN_DEPTH, MAX_DEPTH, _fov())
+            ours.update_map(vals, d.copy(), tf, MIN_DEPTH, MAX_DEPTH, _fov())
+        assert np.array_equal(ours._map, ref._map), rnd
+        assert np.asarray(ours._value_map).dtype == np.asarray(ref._value_map).dtype, rnd
+        assert np.array_equal(np.asarray(ours._value_map), np.asarray(ref._value_map)), rnd
+        wps = np.clip(centre + rng.uniform(-6, 6, (int(rng.integers(1, 24)), 2)), -24.4, 24.4)
+        radius = float(rng.choice([0.5, 0.25, 1.0, 0.05]))
+        kw = dict(reduce_fn=(lambda vs: [max(v) for v in vs])) if C > 1 else {}
+        a, b = ours.sort_waypoints(wps, radius, **kw), ref.sort_waypoints(wps, radius, **kw)
+        assert np.array_equal(a[0], b[0]), rnd
+        assert np.array_equal(np.array(a[1], float), np.array(b[1], float)), rnd
