@@ -103,3 +103,13 @@ def test_erosion_and_cloud_order(gpu_device):
         np.random.seed(5)
         want = extract_object_cloud(depth, m, it, MIN_DEPTH, MAX_DEPTH, fx, fy, use_dbscan=False)
         assert got.shape == want.shape and np.array_equal(got, want), (it, mask, got.shape, want.shape)
+    # a mask the erosion removes entirely, DBSCAN on: the reference's open3d_dbscan_filtering returns np.array([]) (shape (0,)) for an
+    # empty cloud as it does for an all-noise one (object_point_cloud_map.py:200-201) -- found by the random runs of round 6
+    m = np.zeros((480, 640), np.uint8)
+    m[100:103, 100:300] = 1
+    for use_db in (True, False):
+        om = ObjectPointCloudMap(erosion_size=3, device=gpu_device)
+        om.use_dbscan = use_db
+        got = om._extract_object_cloud(depth, m, MIN_DEPTH, MAX_DEPTH, fx, fy)
+        want = extract_object_cloud(depth, m, 3, MIN_DEPTH, MAX_DEPTH, fx, fy, use_dbscan=use_db)
+        assert got.shape == want.shape == ((0,) if use_db else (0, 3))

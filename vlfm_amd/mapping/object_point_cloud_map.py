@@ -184,8 +184,10 @@ class ObjectPointCloudMap:
                 idx = self._rng.choice(n, 5000, replace=False)
                 cloud = cloud[torch.from_numpy(idx).to(dev)].contiguous()
                 n = 5000
-            if not self.use_dbscan or n == 0:
+            if not self.use_dbscan:
                 return cloud.cpu().numpy()
+            if n == 0:
+                return np.array([])  # open3d_dbscan_filtering of an empty cloud: no non-noise label (:200-201), shape (0,) like the reference
             sc = torch.empty(L.vlfm_dbscan_scratch_bytes(n), dtype=torch.uint8, device=dev)
             labels = torch.empty(n, dtype=torch.int32, device=dev)
             keep = torch.empty(n, dtype=torch.int32, device=dev)
