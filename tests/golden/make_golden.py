@@ -425,6 +425,69 @@ def gen_object_map(om_mod):
     return out
 
 
+OBJECT_MAP_RANDOM_SEEDS = (0, 1, 2)
+
+
+def object_map_random_script(seed: int):
+    """A RANDOM session for ObjectPointCloudMap (round 6): three classes, blobs of random size and place -- some thinner than the
+    erosion (empty cloud), some at the far plane (the "too far" tagging draws from NumPy's global RNG), some cut by the image border,
+    depth holes inside masks -- random poses, `update_explored` and `get_best_object` calls in between."""
+    rng = np.random.Generator(np.random.PCG64(900 + seed))
+    from vlfm_amd.synthetic import depth_frame, pose_to_tf
+
+    H, W = 480, 640
+    yy, xx = np.mgrid[0:H, 0:W]
+    names = ("chair", "bed", "tv")
+    ops = []
+    x = y = 0.0
+    for k in range(10):
+        x += float(rng.uniform(-0.4, 0.4))
+        y += float(rng.uniform(-0.4, 0.4))
+        yaw = float(rng.uniform(-np.pi, np.pi))
+        depth = depth_frame(rng, H, W, holes=bool(rng.integers(0, 2)))
+        cx, cy = int(rng.integers(-20, W + 20)), int(rng.integers(-20, H + 20))
+        ax, ay = (int(rng.integers(2, 9)), int(rng.integers(2, 9))) if k % 4 == 3 else (int(rng.integers(15, 140)), int(rng.integers(15, 110)))
+        blob = (xx - cx) ** 2 / ax ** 2 + (yy - cy) ** 2 / ay ** 2 <= 1
+        near = float(rng.uniform(0.05, 0.95)) if k % 5 else 1.0          # every fifth object sits at the far plane
+        depth[(xx - cx) ** 2 / (1.3 * ax) ** 2 + (yy - cy) ** 2 / (1.3 * ay) ** 2 <= 1] = near
+        if k % 3 == 1 and blob.any():
+            depth[max(cy - 4, 0):cy + 4, max(cx - 4, 0):cx + 4] = 0.0     # a hole inside the mask -> "far"
+        mask = blob.astype(np.uint8)
+        tf = pose_to_tf(x, y, yaw)
+        ops.append(("update", names[int(rng.integers(0, 3))], depth, mask, tf))
+        ops.append(("best", names[int(rng.integers(0, 3))], np.array([x, y])))
+        if k % 3 == 2:
+            ops.append(("explored", pose_to_tf(x + float(rng.uniform(-1, 1)), y + float(rng.uniform(-1, 1)), float(rng.uniform(-np.pi, np.pi)))))
+    return ops
+
+
+def gen_object_map_random(om_mod, seed: int):
+    """The reference's ObjectPointCloudMap over object_map_random_script(seed): a digest of every class's cloud after every operation,
+    every get_best_object result, has_object per class, the final clouds."""
+    fx, fy, fov = camera_intrinsics(640)
+    np.random.seed(4321 + seed)
+    m = om_mod.ObjectPointCloudMap(erosion_size=int((3, 5, 2)[seed % 3]))
+    m.reset()       # `clouds` is a CLASS attribute of the reference (object_point_cloud_map.py:18): a new instance sees the previous one's
+    out = {}
+    for i, op in enumerate(object_map_random_script(seed)):
+        if op[0] == "update":
+            m.update_map(op[1], op[2], op[3], op[4], MIN_DEPTH, MAX_DEPTH, fx, fy)
+        elif op[0] == "best":
+            out[f"has_{i}"] = np.array([int(m.has_object(n)) for n in ("chair", "bed", "tv")])
+            if m.has_object(op[1]):
+                out[f"best_{i}"] = np.asarray(m.get_best_object(op[1], op[2]), np.float64)
+        else:
+            m.update_explored(op[1], MAX_DEPTH, fov)
+        for name in ("chair", "bed", "tv"):
+            if name in m.clouds:
+                c = np.asarray(m.clouds[name], np.float64)
+                out[f"sig_{i}_{name}"] = np.array([str(c.shape[0]), sha(c)])
+    for name in ("chair", "bed", "tv"):
+        if name in m.clouds:
+            out[f"final_{name}"] = np.asarray(m.clouds[name], np.float64)
+    return out
+
+
 def gen_policy(name):
     """One scripted episode through THE REFERENCE'S ``ITMPolicyV2`` (vlfm/policy/itm_policy.py:236-267 on top of
     BaseITMPolicy :26-234 and BaseObjectNavPolicy base_objectnav_policy.py:35-365, real source via
@@ -713,6 +776,8 @@ def generate():
     out["helpers"] = gen_helpers(geo, img, ref_vm)
     out["detections"] = gen_detections(ref_shim.reference_detections())
     out["object_map"] = gen_object_map(ref_shim.reference_object_map())
+    for seed in OBJECT_MAP_RANDOM_SEEDS:
+        out[f"object_map_rand{seed}"] = gen_object_map_random(ref_shim.reference_object_map(), seed)
     import policy_script as ps
 
     for name in ps.EPISODES:

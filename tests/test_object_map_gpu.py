@@ -44,6 +44,42 @@ def test_object_map_replays_reference_fixture(gpu_device):
         assert np.array_equal(np.asarray(m.clouds[name], np.float64), g[f"final_{name}"])
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_object_map_replays_random_reference_sessions(gpu_device, seed):
+    """Round 6: three RANDOM sessions (tests/golden/make_golden.py:object_map_random_script -- three classes, blobs thinner than the
+    erosion, objects at the far plane whose points get the random "too far" tag, masks cut by the image border, depth holes, random
+    poses, update_explored in between) recorded from THE REFERENCE'S ObjectPointCloudMap: every cloud after every operation (row count +
+    SHA-256 of the f64 array), has_object per class, every get_best_object result, the final clouds."""
+    from make_golden import object_map_random_script
+    from vlfm_amd.mapping.object_point_cloud_map import ObjectPointCloudMap
+
+    g = load(f"object_map_rand{seed}")
+    fx, fy, fov = camera_intrinsics(640)
+    np.random.seed(4321 + seed)
+    m = ObjectPointCloudMap(erosion_size=int((3, 5, 2)[seed % 3]), device=gpu_device)
+    m.reset()
+    n_best = 0
+    for i, op in enumerate(object_map_random_script(seed)):
+        if op[0] == "update":
+            m.update_map(op[1], op[2], op[3], op[4], MIN_DEPTH, MAX_DEPTH, fx, fy)
+        elif op[0] == "best":
+            assert [int(m.has_object(n)) for n in ("chair", "bed", "tv")] == list(g[f"has_{i}"]), i
+            if m.has_object(op[1]):
+                assert np.array_equal(np.asarray(m.get_best_object(op[1], op[2]), np.float64), g[f"best_{i}"]), i
+                n_best += 1
+        else:
+            m.update_explored(op[1], MAX_DEPTH, fov)
+        for name in ("chair", "bed", "tv"):
+            assert (name in m.clouds) == (f"sig_{i}_{name}" in g), (i, name)
+            if name in m.clouds:
+                c = np.asarray(m.clouds[name], np.float64)
+                assert [str(c.shape[0]), _sha(c)] == list(g[f"sig_{i}_{name}"]), (i, name, c.shape)
+    assert n_best >= 5
+    for name in ("chair", "bed", "tv"):
+        if f"final_{name}" in g:
+            assert np.array_equal(np.asarray(m.clouds[name], np.float64), g[f"final_{name}"])
+
+
 @pytest.mark.parametrize("n,seed", [(300, 0), (1500, 1), (5000, 2), (64, 3), (129, 4)])
 def test_dbscan_matches_sequential_oracle(gpu_device, n, seed):
     """Clustered + noisy point sets: labels up to renaming are checked through the selected largest cluster, which must be
