@@ -395,3 +395,46 @@ def test_random_channels_modes_corner_maps_and_sort_waypoints_against_the_oracle
         a, b = ours.sort_waypoints(wps, radius, **kw), ref.sort_waypoints(wps, radius, **kw)
         assert np.array_equal(a[0], b[0]), rnd
         assert np.array_equal(np.array(a[1], float), np.array(b[1], float)), rnd
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_explored_synchronised_mode_on_random_clutter_against_the_oracle(gpu_device, seed):
+    """ValueMap(obstacle_map=...) (value_map.py:369-375: new data, confidences and values are cleared wherever the obstacle map's
+    explored area is 0) with RANDOM clutter, headings and jumps, one fusion mode per seed: after every step the GPU pair's explored
+    area, confidence map and value map equal the oracle pair's.  (scratch run over 60 seeds: profiles/r06_random_parity_stress.txt)"""
+    from oracle.ref_obstacle_map import RefObstacleMap
+    from oracle.ref_value_map import RefValueMap
+    from vlfm_amd.mapping import ObstacleMap, ValueMap
+    from vlfm_amd.synthetic import depth_frame
+
+    fx, fy, fov = camera_intrinsics(640)
+    rng = np.random.default_rng(40_000 + seed)
+    fusion, use_max = [("default", False), ("default", True), ("equal_weighting", False), ("replace", False)][seed % 4]
+    kw = dict(min_height=0.61, max_height=0.88, agent_radius=0.18, area_thresh=1.5)
+    om, rom = ObstacleMap(device=gpu_device, **kw), RefObstacleMap(**kw)
+    vm = ValueMap(1, use_max_confidence=use_max, fusion_type=fusion, obstacle_map=om, device=gpu_device)
+    rvm = RefValueMap(1, use_max_confidence=use_max, fusion_type=fusion, obstacle_map=rom)
+    x = y = 0.0
+    cleared = 0
+    for step in range(30):
+        yaw = rng.uniform(-np.pi, np.pi) if step % 3 else float(int(rng.integers(-6, 7)) * np.pi / 6)
+        x += rng.uniform(-0.5, 0.5)
+        y += rng.uniform(-0.5, 0.5)
+        d = depth_frame(rng)
+        if step % 3 != 2:
+            d[:] = np.maximum(d, np.float32(0.85))
+        for _ in range(int(rng.integers(0, 6))):
+            c0 = int(rng.integers(0, 600)); w = int(rng.integers(4, 120)); r0 = int(rng.integers(0, 300)); h = int(rng.integers(40, 480 - r0))
+            d[r0:r0 + h, c0:c0 + w] = np.float32(rng.uniform(0.05, 0.7))
+        tf = pose_to_tf(x, y, yaw)
+        vals = rng.uniform(0.05, 0.6, 1)
+        before = int((rvm._map > 0).sum())
+        for o, v in ((om, vm), (rom, rvm)):
+            o.update_map(d.copy(), tf, MIN_DEPTH, MAX_DEPTH, fx, fy, fov)
+            v.update_map(vals, d.copy(), tf, MIN_DEPTH, MAX_DEPTH, fov)
+        if not np.array_equal(om.explored_area, rom.explored_area):
+            pytest.skip("an extreme-angle tie of the reference's fog of war (platform-dependent: tests/test_obstacle_map_gpu.py)")
+        assert np.array_equal(vm._map, rvm._map), (seed, step)
+        assert np.array_equal(np.asarray(vm._value_map), np.asarray(rvm._value_map)), (seed, step)
+        cleared += int((rvm._map > 0).sum()) < before
+    assert (rvm._map > 0).sum() > 500
