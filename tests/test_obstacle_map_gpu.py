@@ -351,3 +351,52 @@ def test_random_hole_patterns_against_the_oracle(gpu_device, seed):
             for m in (ours, ref):
                 m.update_map(d.copy(), tf, MIN_DEPTH, MAX_DEPTH, FX, FY, FOV, explore=False)
             assert np.array_equal(ours._map, ref._map), (seed, thresh, k, int((ours._map != ref._map).sum()))
+
+
+def test_long_random_walk_with_arbitrary_headings_in_the_rooms_world(gpu_device):
+    """The consistent rooms-and-pillars world of vlfm_amd/synthetic.py (the 500-step fixture's) on a RANDOM walk with arbitrary headings:
+    the explored area grows to tens of thousands of cells with a dozen frontiers -- the large, ragged outlines the short random-clutter
+    sequences never reach.  160 steps here; tools/stress/long_stress.py ran 36 such episodes of 400-500 steps (15 000+ steps, every plane
+    and every frontier pixel after every step: profiles/r06_random_parity_stress.txt)."""
+    from vlfm_amd import synthetic as syn
+
+    def wall_profile_any(x, y, yaw, width=640):
+        fx = syn.camera_intrinsics(width)[0]
+        c, s = float(np.cos(yaw)), float(np.sin(yaw))
+        m = -(np.arange(width, dtype=np.float64) - width // 2) / fx
+        dx, dy = (c - s * m)[:, None], (s + c * m)[:, None]
+        dx = np.where(np.abs(dx) < 1e-12, 1e-12, dx)
+        dy = np.where(np.abs(dy) < 1e-12, 1e-12, dy)
+        B = syn.BOXES
+        tx0, tx1 = (B[None, :, 0] - x) / dx, (B[None, :, 2] - x) / dx
+        ty0, ty1 = (B[None, :, 1] - y) / dy, (B[None, :, 3] - y) / dy
+        tmin = np.maximum(np.minimum(tx0, tx1), np.minimum(ty0, ty1))
+        tmax = np.minimum(np.maximum(tx0, tx1), np.maximum(ty0, ty1))
+        hit = (tmax >= np.maximum(tmin, 0.0)) & (tmin > 0.0)
+        return np.where(hit, tmin, np.inf).min(axis=1).astype(np.float32)
+
+    ours, ref = _pair(gpu_device)
+    rng = np.random.default_rng(90_000)
+    x = y = 0.0
+    for step in range(160):
+        yaw = rng.uniform(-np.pi, np.pi) if step % 5 else float(int(rng.integers(-6, 7)) * np.pi / 6)
+        for _ in range(30):
+            nx, ny = x + rng.uniform(-0.6, 0.6), y + rng.uniform(-0.6, 0.6)
+            if abs(nx) < 9.3 and abs(ny) < 9.3 and not syn._blocked(nx, ny, 0.35):
+                x, y = float(nx), float(ny)
+                break
+        d = syn.depth_from_profile(wall_profile_any(x, y, yaw))
+        tf = pose_to_tf(x, y, yaw)
+        for m in (ours, ref):
+            m.update_map(d, tf, MIN_DEPTH, MAX_DEPTH, FX, FY, FOV, explore=False)
+        tf2 = tf
+        for _ in range(20):
+            if not _extreme_angle_tie(ref, tf2):
+                break
+            tf2 = pose_to_tf(x + rng.uniform(-0.3, 0.3), y + rng.uniform(-0.3, 0.3), yaw)
+        else:
+            continue
+        for m in (ours, ref):
+            m.update_map(None, tf2, MIN_DEPTH, MAX_DEPTH, FX, FY, FOV, update_obstacles=False)
+        _same(ours, ref, step)
+    assert ref.explored_area.sum() > 15000 and len(np.asarray(ref._frontiers_px).reshape(-1, 2)) >= 4
