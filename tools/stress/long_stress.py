@@ -26,9 +26,14 @@ def wall_profile_any(x, y, yaw, width=640):
     return np.where(hit, tmin, np.inf).min(axis=1).astype(np.float32)
 a, n = int(sys.argv[1]), int(sys.argv[2])
 STEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 300
+VALUES = "--values" in sys.argv        # also a ValueMap beside the obstacle map, and sort_waypoints over the step's frontiers
+from oracle.ref_value_map import RefValueMap
+from vlfm_amd.mapping import ValueMap
 bad = 0
 for seed in range(a, a + n):
     ours, ref = t._pair(torch.device("cuda:0"))
+    vm = ValueMap(1, use_max_confidence=False, device=torch.device("cuda:0")) if VALUES else None
+    rvm = RefValueMap(1, use_max_confidence=False) if VALUES else None
     rng = np.random.default_rng(90_000 + seed)
     x = y = 0.0
     nudged = skipped = 0
@@ -51,6 +56,15 @@ for seed in range(a, a + n):
                 skipped += 1; continue
             for m in (ours, ref): m.update_map(None, tf2, MIN_DEPTH, MAX_DEPTH, t.FX, t.FY, t.FOV, update_obstacles=False)
             t._same(ours, ref, step)
+            if VALUES:
+                vals = rng.uniform(0.1, 0.5, 1)
+                vm.update_map(vals, d, tf, MIN_DEPTH, MAX_DEPTH, t.FOV); rvm.update_map(vals, d.copy(), tf, MIN_DEPTH, MAX_DEPTH, t.FOV)
+                fr = np.asarray(ref.frontiers, np.float64).reshape(-1, 2)
+                if len(fr):
+                    sa, sb = vm.sort_waypoints(fr, 0.5), rvm.sort_waypoints(fr, 0.5)
+                    assert np.array_equal(sa[0], sb[0]) and np.array_equal(np.array(sa[1], float), np.array(sb[1], float)), f"sort_waypoints differs at step {step}"
+                if step % 25 == 24 or step == STEPS - 1:
+                    assert np.array_equal(vm._map, rvm._map) and np.array_equal(np.asarray(vm._value_map), np.asarray(rvm._value_map)), f"value map differs at step {step}"
         print(f"seed {seed}: {STEPS} steps equal; explored {int(ref.explored_area.sum())} cells, obstacles {int(ref._map.sum())}, frontiers {len(np.asarray(ref._frontiers_px).reshape(-1, 2))}, ties nudged {nudged}", flush=True)
     except AssertionError as e:
         bad += 1; print("seed", seed, "FAILED:", str(e)[:300].replace("\n", " "), flush=True)
