@@ -31,6 +31,9 @@ EPISODES = {
     "policy_mp3d_cabinet": (13, 22, "mp3d", "cabinet", MP3D_CAPTION),
     # nothing is ever detected: a long explore phase (frontier sorting, stick-to-last rule, re-matching within 0.5 m)
     "policy_hm3d_explore": (14, 46, "hm3d", "toilet", ""),
+    # (round 6) the same with another seed for the cosines / frames and three times as long: more frontier re-sorting, re-matching and
+    # stick-to-last decisions, and a late sighting that ends in a stop
+    "policy_hm3d_explore_long": (15, 130, "hm3d", "toilet", ""),
 }
 
 
@@ -43,6 +46,11 @@ def _blob(depth: np.ndarray, cx: int, cy: int, ax: int, ay: int, d: float) -> No
 # "coco" entries are returned by the YOLOv7 stand-in, "gdino" entries by the GroundingDINO stand-in.
 SIGHTINGS = {
     "policy_hm3d_explore": {},
+    "policy_hm3d_explore_long": {
+        57: [("coco", "toilet", 0.7, (310, 250, 50, 60), 0.6)],                  # below the 0.8 threshold -> dropped
+        101: [("coco", "toilet", 0.9, (320, 255, 55, 65), 0.5)],                 # accepted -> navigate
+        102: [("coco", "toilet", 0.93, (320, 255, 60, 70), 0.45)],
+    },
     "policy_hm3d_chair": {
         13: [("coco", "chair", 0.62, (300, 260, 50, 60), 0.62)],                 # below the 0.8 threshold -> dropped
         15: [("coco", "couch", 0.93, (200, 250, 70, 50), 0.55)],                 # wrong class -> dropped

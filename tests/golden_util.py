@@ -52,7 +52,7 @@ def unpack_plane(bits, size=1000):
 
 
 # ---------------------------------------------------------------------------------------------- policy episodes
-POLICY_CASES = ["policy_hm3d_chair", "policy_mp3d_table", "policy_mp3d_cabinet", "policy_hm3d_explore"]
+POLICY_CASES = ["policy_hm3d_chair", "policy_mp3d_table", "policy_mp3d_cabinet", "policy_hm3d_explore", "policy_hm3d_explore_long"]
 
 
 def replay_policy_episode(name, make_step, make_detections, tol=1e-4):
