@@ -134,3 +134,40 @@ def test_detector_routing_and_filters_equal_the_reference_method(seed):
         assert outs["ref"][2] == outs["ours"][2], (trial, target)
         assert np.array_equal(outs["ref"][0], outs["ours"][0]) and np.array_equal(outs["ref"][1], outs["ours"][1])
     assert any(n not in COCO_CLASSES for n in names) and any(n in COCO_CLASSES for n in names)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_object_detections_container_equals_the_reference_class_on_random_inputs(seed):
+    """vlfm_amd/vlm/detections.py beside the reference's ObjectDetections (vlfm/vlm/detections.py:15-126; its torchvision box_convert is
+    the shim's stand-in) on random boxes / scores / phrases: construction in every box format, filter_by_conf (>=, incl. a score equal
+    to the threshold), filter_by_class, the early return when everything is kept, to_json / from_json round trips, repr, zero detections."""
+    import torch
+
+    from oracle import ref_shim
+    from vlfm_amd.vlm.detections import ObjectDetections as Ours
+
+    Ref = ref_shim.reference_detections().ObjectDetections
+    rng = np.random.default_rng(300 + seed)
+    names = ["chair", "bed", "tv", "potted plant", "dining table", "couch"]
+    for trial in range(120):
+        n = int(rng.integers(0, 9))
+        fmt = ["cxcywh", "xyxy"][trial % 2]          # the two formats the reference constructs with (grounding_dino.py:69, yolov7.py:108)
+        boxes = torch.from_numpy(rng.uniform(0, 1, (n, 4)).astype(np.float32))
+        logits = torch.from_numpy(np.round(rng.uniform(0, 1, n), 2).astype(np.float32))
+        phrases = [names[int(i)] for i in rng.integers(0, len(names), n)]
+        a, b = Ours(boxes.clone(), logits.clone(), list(phrases), None, fmt=fmt), Ref(boxes.clone(), logits.clone(), list(phrases), None, fmt=fmt)
+
+        def same():
+            assert torch.equal(a.boxes, b.boxes) and torch.equal(a.logits, b.logits) and a.phrases == b.phrases
+            assert a.num_detections == b.num_detections and repr(a) == repr(b) and a.to_json() == b.to_json()
+
+        same()
+        thr = float(logits[int(rng.integers(0, n))]) if n and trial % 2 else float(np.round(rng.uniform(0, 1), 2))
+        a.filter_by_conf(thr); b.filter_by_conf(thr)
+        same()
+        keep = [names[int(i)] for i in rng.integers(0, len(names), int(rng.integers(0, 4)))]
+        a.filter_by_class(keep); b.filter_by_class(keep)
+        same()
+        ja, jb = Ours.from_json(a.to_json()), Ref.from_json(b.to_json())
+        assert torch.equal(ja.boxes.reshape(-1, 4) if ja.boxes.numel() else ja.boxes, jb.boxes.reshape(-1, 4) if jb.boxes.numel() else jb.boxes)
+        assert ja.boxes.shape == jb.boxes.shape and ja.boxes.dtype == jb.boxes.dtype and torch.equal(ja.logits, jb.logits) and ja.phrases == jb.phrases
