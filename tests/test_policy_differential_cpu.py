@@ -171,3 +171,38 @@ def test_object_detections_container_equals_the_reference_class_on_random_inputs
         ja, jb = Ours.from_json(a.to_json()), Ref.from_json(b.to_json())
         assert torch.equal(ja.boxes.reshape(-1, 4) if ja.boxes.numel() else ja.boxes, jb.boxes.reshape(-1, 4) if jb.boxes.numel() else jb.boxes)
         assert ja.boxes.shape == jb.boxes.shape and ja.boxes.dtype == jb.boxes.dtype and torch.equal(ja.logits, jb.logits) and ja.phrases == jb.phrases
+
+
+def test_geometry_helpers_equal_the_reference_functions_on_random_inputs():
+    """The host-side helpers the decision path and the object map restate (vlfm_amd/policy_step.py, vlfm_amd/mapping/object_point_cloud_map.py)
+    beside vlfm/utils/geometry_utils.py itself: xyz_yaw_to_tf_matrix, get_fov, rho_theta, closest_point_within_threshold, extract_yaw,
+    within_fov_cone -- bit for bit on random inputs, incl. headings at +-pi, goals behind the agent, empty point sets, points on the cone's edge."""
+    from oracle import ref_shim
+    from vlfm_amd import policy_step as ps
+    from vlfm_amd.mapping import object_point_cloud_map as opm
+
+    geo = ref_shim.reference_modules()[2]
+    rng = np.random.default_rng(12)
+    for trial in range(400):
+        xyz = rng.uniform(-20, 20, 3)
+        yaw = float(rng.choice([rng.uniform(-np.pi, np.pi), np.pi, -np.pi, 0.0, np.pi / 2]))
+        tf_a, tf_b = ps.xyz_yaw_to_tf_matrix(xyz, yaw), geo.xyz_yaw_to_tf_matrix(xyz, yaw)
+        assert tf_a.dtype == tf_b.dtype and np.array_equal(tf_a, tf_b)
+        assert opm.extract_yaw(tf_a) == geo.extract_yaw(tf_b)
+        f, n = float(rng.uniform(50, 900)), int(rng.integers(8, 2000))
+        assert ps.get_fov(f, n) == geo.get_fov(f, n)
+        pos, goal = rng.uniform(-10, 10, 2), rng.uniform(-10, 10, 2)
+        if trial % 7 == 0:
+            goal = pos.copy()                                   # standing on the goal
+        ra, rb = ps.rho_theta(pos, yaw, goal), geo.rho_theta(pos, yaw, goal)
+        assert np.array_equal(np.asarray(ra, np.float64), np.asarray(rb, np.float64)), (trial, ra, rb)
+        pts = rng.uniform(-5, 5, (int(rng.integers(0, 12)), 2))
+        thr = float(rng.choice([0.5, 0.05, 3.0]))
+        if len(pts):
+            assert ps.closest_point_within_threshold(pts, pos / 4, thr) == geo.closest_point_within_threshold(pts, pos / 4, thr)
+        cloud = np.concatenate([rng.uniform(-6, 6, (int(rng.integers(0, 40)), 3)), rng.uniform(size=(0, 3))])
+        cloud = np.concatenate([cloud, rng.integers(0, 2, (len(cloud), 1)).astype(np.float64)], axis=1) if trial % 2 else cloud
+        ang, fov, rng_m = yaw, float(rng.uniform(0.3, 2.5)), float(rng.uniform(0.5, 6))
+        wa = opm.within_fov_cone(xyz / 4, ang, fov, rng_m, cloud)      # (the caller passes the 3-D camera position, object_point_cloud_map.py:99)
+        wb = geo.within_fov_cone(xyz / 4, ang, fov, rng_m, cloud)
+        assert wa.shape == wb.shape and np.array_equal(wa, wb), trial
